@@ -1,0 +1,156 @@
+/* include/zkm_hip.h -- C ABI of libzkmhip.so: the MI355X (gfx950) STARK/FRI hot path of the zkMIPS prover.
+ *
+ * This is the drop-in boundary.  The reference (zkMIPS/zkm @ 2025-04-04) has no FFI on this path: the
+ * prover calls the un-vendored plonky2 fork (prover/Cargo.toml:17-20) through Rust generics.  Each entry
+ * point below names the reference call site / plonky2 item it replaces; INTEGRATION.md shows the
+ * `extern "C"` block a patched plonky2 / zkm-prover would bind.  Error convention follows the reference's
+ * only existing FFI (recursion/src/snark/snarks.rs:7-20, 39-59): int status (0 = ok) + optional
+ * malloc'd message in *err that the caller releases with free().
+ *
+ * Data conventions
+ *   - field element: canonical uint64_t (< p = 2^64 - 2^32 + 1); F2 = F[X]/(X^2-7) as [c0, c1].
+ *   - matrices are column-major: element (row r, column c) of an n-row matrix is at c*n + r -- the layout
+ *     of Vec<PolynomialValues<F>> flattened (prover/src/util.rs:37-46).
+ *   - every data pointer may be a host pointer or a device (HBM) pointer of the context's GPU; the
+ *     library detects which (hipPointerGetAttributes).  Output buffers documented "host" must be host.
+ *   - a zkm_ctx is single-owner (one per GPU, driven from one thread at a time), like the reference's
+ *     `&mut Challenger` / `&mut TimingTree` threading (prover.rs:441-450).
+ */
+#ifndef ZKM_HIP_H
+#define ZKM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zkm_ctx zkm_ctx;
+typedef struct zkm_batch zkm_batch;
+
+/* ------------------------------------------------------------------ context / memory */
+int zkm_ctx_create(int device, zkm_ctx** out, char** err);
+void zkm_ctx_destroy(zkm_ctx* ctx);
+int zkm_ctx_synchronize(zkm_ctx* ctx, char** err);
+/* the hipStream_t every kernel of this context is launched on (for event timing by the host) */
+void* zkm_ctx_stream(zkm_ctx* ctx);
+int zkm_dev_alloc(zkm_ctx* ctx, size_t bytes, void** out, char** err);
+int zkm_dev_free(zkm_ctx* ctx, void* p);
+int zkm_dev_upload(zkm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, char** err);
+int zkm_dev_download(zkm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, char** err);
+
+/* ------------------------------------------------------------------ K1/K2/K9: batched Goldilocks NTT
+ * Replaces PolynomialValues::{ifft, coset_ifft} / PolynomialCoeffs::{fft, coset_fft}
+ * (call sites prover.rs:678-681, 787, 829).  In place over `ncols` columns of 2^log_n elements,
+ * natural order in and out.  coset_shift 0 or 1 = plain subgroup; otherwise forward = scale coeff i by
+ * shift^i then NTT, inverse = iNTT then scale coeff i by shift^-i (plonky2 conventions). */
+int zkm_ntt(zkm_ctx* ctx, uint64_t* cols, size_t ncols, unsigned log_n, int inverse, uint64_t coset_shift, char** err);
+
+/* ------------------------------------------------------------------ K1-K5: PolynomialBatch
+ * zkm_batch_commit_values == PolynomialBatch::from_values(values, rate_bits, false, cap_height, ..)
+ *   (prover.rs:154-163, 514-521); zkm_batch_commit_coeffs == from_coeffs (prover.rs:579-586).
+ * Inputs are borrowed for the call (no clone, cf. prover.rs:155-157); the batch owns device memory:
+ * coefficients (ncols x n), the LDE (ncols x 4n, rows in bit-reversed order == merkle_tree.leaves) and
+ * all Merkle digest layers. */
+int zkm_batch_commit_values(zkm_ctx* ctx, const uint64_t* values, size_t ncols, unsigned log_n, unsigned rate_bits,
+                            unsigned cap_height, zkm_batch** out, char** err);
+int zkm_batch_commit_coeffs(zkm_ctx* ctx, const uint64_t* coeffs, size_t ncols, unsigned log_n, unsigned rate_bits,
+                            unsigned cap_height, zkm_batch** out, char** err);
+void zkm_batch_free(zkm_batch* b);
+/* .merkle_tree.cap (prover.rs:180, 524, 588): 2^cap_height digests x 4 words, host out */
+int zkm_batch_cap(const zkm_batch* b, uint64_t* out);
+/* .polynomials (proof.rs:311): ncols x n coefficients, natural order; out may be host or device */
+int zkm_batch_coeffs(const zkm_batch* b, uint64_t* out);
+/* get_lde_values(natural_index, 1) (prover.rs:687): one LDE row, ncols words, host out */
+int zkm_batch_lde_row(const zkm_batch* b, size_t natural_index, uint64_t* out);
+/* merkle_tree.leaves[leaf_index] and merkle_tree.prove(leaf_index): (lde_bits - cap_height) x 4 words */
+int zkm_batch_leaf(const zkm_batch* b, size_t leaf_index, uint64_t* out);
+int zkm_batch_merkle_path(const zkm_batch* b, size_t leaf_index, uint64_t* siblings_out);
+/* digest layer `level` (0 = leaf digests), (4n >> level) x 4 words, host out -- parity/debug */
+int zkm_batch_digest_layer(const zkm_batch* b, unsigned level, uint64_t* out);
+
+/* ------------------------------------------------------------------ hash primitives
+ * a13: Poseidon permutation (prover/src/poseidon/poseidon_stark.rs:51-95; == plonky2 PoseidonHash's
+ * permutation); k states of 12 words, in place.  K15: Keccak-f[1600] (cpu/kernel/keccak_util.rs:6-31,
+ * keccak_sponge_stark.rs:410); k states of 25 words, in place. */
+int zkm_poseidon_permute_batch(zkm_ctx* ctx, uint64_t* states, size_t k, char** err);
+int zkm_keccakf_batch(zkm_ctx* ctx, uint64_t* states, size_t k, char** err);
+
+/* ------------------------------------------------------------------ a13: PoseidonStark witness
+ * PoseidonStark::generate_trace (poseidon_stark.rs:104-160): 262 columns x 2^log_n rows, column-major,
+ * from `num_perms` seeded 12-element inputs (SplitMix64(seed); timestamp 0, FILTER 1) padded with the
+ * default row (permutation of zeros, FILTER 0).  out must be a device pointer. */
+#define ZKM_POSEIDON_COLS 262
+int zkm_poseidon_trace(zkm_ctx* ctx, uint64_t seed, size_t num_perms, unsigned log_n, uint64_t* out_dev, char** err);
+
+/* ------------------------------------------------------------------ Fiat-Shamir (host)
+ * plonky2 Challenger<F, PoseidonHash> (uses at prover.rs:182-190, 466, 524-527, 588-591, 610). */
+typedef struct {
+    uint64_t state[12];
+    uint64_t in_buf[8];
+    uint64_t out_buf[8];
+    uint32_t n_in, n_out;
+} zkm_challenger;
+void zkm_challenger_init(zkm_challenger* ch);
+void zkm_challenger_observe(zkm_challenger* ch, const uint64_t* elems, size_t n);
+uint64_t zkm_challenger_get(zkm_challenger* ch);
+void zkm_challenger_compact(zkm_challenger* ch, uint64_t state_out[12]);
+
+/* ------------------------------------------------------------------ a5: prove_single_table
+ * StarkConfig::standard_fast_config (prover/src/config.rs:17-30). */
+typedef struct {
+    unsigned rate_bits, cap_height, pow_bits, num_challenges, num_queries, arity_bits, final_poly_bits;
+} zkm_stark_config;
+void zkm_standard_config(zkm_stark_config* cfg);
+
+#define ZKM_TABLE_POSEIDON 0
+
+/* Proof blob (uint64_t words) -- the fields of StarkProofWithMetadata (proof.rs:178-201) flattened:
+ *   [0] magic "ZKMPROOF" [1] degree_bits [2] W trace cols [3] A aux cols [4] Q quotient polys [5] Z ctl zs
+ *   [6] cap_height [7] L fri layers [8] F final_poly_len [9] num_queries [10] rate_bits [11] arity_bits
+ *   [12..15] 0
+ *   init_challenger_state[12]
+ *   trace_cap[C*4] aux_cap[C*4] quotient_cap[C*4]                    C = 2^cap_height
+ *   local_values[2W] next_values[2W] aux[2A] aux_next[2A] ctl_zs_first[Z] quotient[2Q]
+ *   commit_phase_merkle_caps[L][C*4]   final_poly[2F]   pow_witness[1]
+ *   query_round_proofs[num_queries]:
+ *       oracle 0..2: evals[ncols_o], siblings[(lde_bits - cap_height)*4]
+ *       layer i in 0..L: evals[2*2^arity_bits], siblings[(lde_bits - arity_bits*(i+1) - cap_height)*4]
+ */
+#define ZKM_PROOF_MAGIC 0x5a4b4d50524f4f46ULL
+size_t zkm_proof_words(const zkm_stark_config* cfg, unsigned log_n, size_t ncols, size_t naux, size_t nctl_zs);
+
+/* prove_single_table (prover.rs:441-641) for table `table_id`.
+ *   trace       ncols x 2^log_n trace values (host or device) -- used only if trace_batch is NULL
+ *   trace_batch optional existing commitment of the trace (prover.rs:445); NULL = commit here
+ *   aux         naux x 2^log_n auxiliary values = ctl helper columns ++ ctl z columns (prover.rs:497-508)
+ *   num_helpers helper-column count of each of the nctl_zs CtlZData (cross_table_lookup.rs:474-481)
+ *   challenger  in/out transcript (host)
+ *   proof_out   host buffer of zkm_proof_words() words */
+int zkm_prove_single_table(zkm_ctx* ctx, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t ncols,
+                           unsigned log_n, const zkm_batch* trace_batch, const uint64_t* aux, size_t naux,
+                           const uint32_t* num_helpers, size_t nctl_zs, zkm_challenger* challenger, uint64_t* proof_out,
+                           char** err);
+
+/* ------------------------------------------------------------------ stage entry points (parity / reuse)
+ * a6: compute_quotient_polys (prover.rs:645-789): nalphas polys of 2n coefficients, natural order;
+ * out host or device. */
+int zkm_quotient(zkm_ctx* ctx, int table_id, const zkm_batch* trace, const zkm_batch* aux, const uint32_t* num_helpers,
+                 size_t nctl_zs, const uint64_t* alphas, size_t nalphas, uint64_t* out_coeffs, char** err);
+/* a9: StarkOpeningSet::new building block (proof.rs:299-334): p(zeta) in F2 for every polynomial of the
+ * batch; out = ncols x 2 words, host. */
+int zkm_eval_openings(zkm_ctx* ctx, const zkm_batch* b, const uint64_t zeta[2], uint64_t* out, char** err);
+
+/* ------------------------------------------------------------------ profiling (HIP events on the ctx stream) */
+void zkm_profile_enable(zkm_ctx* ctx, int on);
+void zkm_profile_reset(zkm_ctx* ctx);
+/* number of distinct kernel names recorded since reset */
+size_t zkm_profile_count(zkm_ctx* ctx);
+/* i-th record: name (static string), number of launches, summed device milliseconds */
+int zkm_profile_get(zkm_ctx* ctx, size_t i, const char** name, uint64_t* launches, double* total_ms);
+
+const char* zkm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+/* oracle/constraints_tmpl.h -- constraint evaluation, instantiated for F (prover, quotient domain)
+ * and for F2 (verifier, at zeta).  Include with these macros defined:
+ *   T            element type            TNAME(x)    name mangler
+ *   T_ADD/T_SUB/T_MUL(a,b)               T_MULB(a,s) multiply by base-field scalar s
+ *   T_FROMB(s)   embed base scalar
+ *
+ * TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * Restates, in emission order (= alpha-power order, constraint_consumer.rs:57-62):
+ *   ConstraintConsumer            prover/src/constraint_consumer.rs:10-75
+ *   PoseidonStark constraints     prover/src/poseidon/poseidon_stark.rs:554-594 (eval_packed_generic) with
+ *     constant_layer_field :171-176, sbox_field :191-199, sbox_layer_field :253-275, mds_layer_field :295-308,
+ *     partial_first_constant_layer :371-375, mds_partial_layer_init_field :406-419,
+ *     partial_sbox_layer :442-454, mds_partial_layer_fast_field :503-519
+ *   CTL checks (helper-column shape) prover/src/cross_table_lookup.rs:1067-1118, eval_helper_columns :1006-1058
+ *   order table -> lookups -> CTL   prover/src/vanishing_poly.rs:30-45
+ */
+
+typedef struct {
+    size_t nalphas;
+    gl_t alphas[4];
+    T acc[4];
+    T z_last, l_first, l_last;
+} TNAME(consumer);
+
+static inline void TNAME(cons)(TNAME(consumer) * k, T c) {
+    for (size_t j = 0; j < k->nalphas; j++) k->acc[j] = T_ADD(T_MULB(k->acc[j], k->alphas[j]), c);
+}
+static inline void TNAME(cons_transition)(TNAME(consumer) * k, T c) { TNAME(cons)(k, T_MUL(c, k->z_last)); }
+static inline void TNAME(cons_first)(TNAME(consumer) * k, T c) { TNAME(cons)(k, T_MUL(c, k->l_first)); }
+static inline void TNAME(cons_last)(TNAME(consumer) * k, T c) { TNAME(cons)(k, T_MUL(c, k->l_last)); }
+
+static inline void TNAME(sbox_constr)(TNAME(consumer) * k, T in, T inter, T out) {
+    TNAME(cons)(k, T_SUB(T_MUL(T_MUL(in, in), in), inter));
+    TNAME(cons)(k, T_SUB(T_MUL(T_MUL(in, inter), inter), out));
+}
+
+static void TNAME(mds_layer)(T s[12]) {
+    T r[12];
+    for (int i = 0; i < 12; i++) {
+        T acc = T_FROMB(0);
+        for (int j = 0; j < 12; j++) acc = T_ADD(acc, T_MULB(s[(j + i) % 12], ZKM_POSEIDON_MDS_CIRC[j]));
+        acc = T_ADD(acc, T_MULB(s[i], ZKM_POSEIDON_MDS_DIAG[i]));
+        r[i] = acc;
+    }
+    for (int i = 0; i < 12; i++) s[i] = r[i];
+}
+
+static void TNAME(eval_poseidon)(const T* lv, TNAME(consumer) * k) {
+    T s[12];
+    for (int i = 0; i < 12; i++) s[i] = lv[1 + i];
+    int rc = 0;
+    for (int r = 0; r < 4; r++, rc++) {
+        for (int i = 0; i < 12; i++) s[i] = T_ADD(s[i], T_FROMB(gl_canon(ZKM_POSEIDON_RC[i + 12 * rc])));
+        for (int i = 0; i < 12; i++) {
+            T tmp = lv[26 + 24 * r + 2 * i], out = lv[26 + 24 * r + 2 * i + 1];
+            TNAME(sbox_constr)(k, s[i], tmp, out);
+            s[i] = out;
+        }
+        TNAME(mds_layer)(s);
+    }
+    for (int i = 0; i < 12; i++) s[i] = T_ADD(s[i], T_FROMB(ZKM_POSEIDON_FAST_FIRST_RC[i]));
+    {
+        T t[12];
+        t[0] = s[0];
+        for (int c = 1; c < 12; c++) t[c] = T_FROMB(0);
+        for (int r = 1; r < 12; r++)
+            for (int c = 1; c < 12; c++) t[c] = T_ADD(t[c], T_MULB(s[r], ZKM_POSEIDON_FAST_INIT[r - 1][c - 1]));
+        for (int i = 0; i < 12; i++) s[i] = t[i];
+    }
+    for (int r = 0; r < 22; r++) {
+        T inter = lv[122 + 2 * r], out = lv[122 + 2 * r + 1];
+        TNAME(sbox_constr)(k, s[0], inter, out);
+        s[0] = out;
+        if (r < 21) s[0] = T_ADD(s[0], T_FROMB(ZKM_POSEIDON_FAST_RC[r]));
+        T d = T_MULB(s[0], ZKM_POSEIDON_MDS_CIRC[0] + ZKM_POSEIDON_MDS_DIAG[0]);
+        for (int i = 1; i < 12; i++) d = T_ADD(d, T_MULB(s[i], ZKM_POSEIDON_FAST_W_HATS[r][i - 1]));
+        for (int i = 1; i < 12; i++) s[i] = T_ADD(T_MULB(s[0], ZKM_POSEIDON_FAST_VS[r][i - 1]), s[i]);
+        s[0] = d;
+    }
+    rc += 22;
+    for (int r = 0; r < 4; r++, rc++) {
+        for (int i = 0; i < 12; i++) s[i] = T_ADD(s[i], T_FROMB(gl_canon(ZKM_POSEIDON_RC[i + 12 * rc])));
+        for (int i = 0; i < 12; i++) {
+            T tmp = lv[166 + 24 * r + 2 * i], out = lv[166 + 24 * r + 2 * i + 1];
+            TNAME(sbox_constr)(k, s[i], tmp, out);
+            s[i] = out;
+        }
+        TNAME(mds_layer)(s);
+    }
+    for (int i = 0; i < 12; i++) TNAME(cons)(k, T_SUB(s[i], lv[13 + i]));
+}
+
+/* CTL checks for CtlZData with helper columns and no column sets (the benchmark's fake CTL data,
+ * poseidon_stark.rs:786-799): eval_helper_columns emits nothing (columns empty, cross_table_lookup.rs:1021),
+ * then last-row and transition checks on Z (:1111-1118). aux = helpers ++ zs. */
+static void TNAME(eval_ctl)(const T* aux_local, const T* aux_next, const uint32_t* num_helpers, size_t nctl,
+                            TNAME(consumer) * k) {
+    size_t total_helpers = 0, start = 0;
+    for (size_t i = 0; i < nctl; i++) total_helpers += num_helpers[i];
+    for (size_t i = 0; i < nctl; i++) {
+        T h_sum = T_FROMB(0);
+        for (size_t h = 0; h < num_helpers[i]; h++) h_sum = T_ADD(h_sum, aux_local[start + h]);
+        T local_z = aux_local[total_helpers + i], next_z = aux_next[total_helpers + i];
+        TNAME(cons_last)(k, T_SUB(local_z, h_sum));
+        TNAME(cons_transition)(k, T_SUB(T_SUB(local_z, next_z), h_sum));
+        start += num_helpers[i];
+    }
+}

@@ -1,0 +1,263 @@
+"""ctypes binding of the CPU oracle (oracle/libzkm_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as
+the checker.  Nothing under zkm_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libzkm_oracle.so")
+
+P = 0xFFFFFFFF00000001
+POSEIDON_COLS = 262
+u64p = C.POINTER(C.c_uint64)
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
+            for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+class Challenger(C.Structure):
+    _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("out_buf", C.c_uint64 * 8),
+                ("n_in", C.c_uint32), ("n_out", C.c_uint32)]
+
+
+class StarkConfig(C.Structure):
+    _fields_ = [(n, C.c_uint) for n in
+                ("rate_bits", "cap_height", "pow_bits", "num_challenges", "num_queries", "arity_bits", "final_poly_bits")]
+
+
+def _ptr(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(build())
+        L = self.lib
+        L.zko_gl_mul.restype = C.c_uint64
+        L.zko_gl_mul.argtypes = [C.c_uint64, C.c_uint64]
+        L.zko_gl_inv.restype = C.c_uint64
+        L.zko_gl_inv.argtypes = [C.c_uint64]
+        L.zko_gl_pow.restype = C.c_uint64
+        L.zko_gl_pow.argtypes = [C.c_uint64, C.c_uint64]
+        L.zko_gl_root_of_unity.restype = C.c_uint64
+        L.zko_gl_root_of_unity.argtypes = [C.c_uint]
+        L.zko_ntt.argtypes = [u64p, C.c_size_t, C.c_uint, C.c_int, C.c_uint64]
+        L.zko_batch_from_values.restype = C.c_void_p
+        L.zko_batch_from_values.argtypes = [u64p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
+        L.zko_batch_from_coeffs.restype = C.c_void_p
+        L.zko_batch_from_coeffs.argtypes = [u64p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
+        L.zko_batch_free.argtypes = [C.c_void_p]
+        for f in ("zko_batch_cap", "zko_batch_coeffs"):
+            getattr(L, f).argtypes = [C.c_void_p, u64p]
+        for f in ("zko_batch_lde_row", "zko_batch_leaf", "zko_batch_merkle_path"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_size_t, u64p]
+        L.zko_batch_digest_layer.argtypes = [C.c_void_p, C.c_uint, u64p]
+        L.zko_poseidon_trace.argtypes = [C.c_uint64, C.c_size_t, C.c_uint, u64p]
+        L.zko_proof_words.restype = C.c_size_t
+        L.zko_proof_words.argtypes = [C.POINTER(StarkConfig), C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t]
+        L.zko_prove_single_table.restype = C.c_int
+        L.zko_prove_single_table.argtypes = [C.c_int, C.POINTER(StarkConfig), u64p, C.c_size_t, C.c_uint, u64p, C.c_size_t,
+                                             C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Challenger), u64p,
+                                             C.POINTER(C.c_double)]
+        L.zko_verify_single_table.restype = C.c_int
+        L.zko_verify_single_table.argtypes = [C.c_int, C.POINTER(StarkConfig), u64p, C.c_size_t, C.c_size_t,
+                                              C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Challenger)]
+        L.zko_quotient_poseidon.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t, u64p, C.c_size_t, u64p]
+        L.zko_poseidon_eval_row.argtypes = [u64p, u64p, C.c_size_t, u64p]
+        L.zko_challenger_get.restype = C.c_uint64
+
+    # ---- primitives
+    def gl_mul(self, a, b):
+        return self.lib.zko_gl_mul(a, b)
+
+    def gl_inv(self, a):
+        return self.lib.zko_gl_inv(a)
+
+    def gl_pow(self, a, e):
+        return self.lib.zko_gl_pow(a, e)
+
+    def root_of_unity(self, k):
+        return self.lib.zko_gl_root_of_unity(k)
+
+    def poseidon_permute(self, st, naive=False):
+        a = np.array(st, dtype=np.uint64)
+        (self.lib.zko_poseidon_permute_naive if naive else self.lib.zko_poseidon_permute)(_ptr(a))
+        return a
+
+    def poseidon_permute_batch(self, states):
+        a = np.ascontiguousarray(states, dtype=np.uint64).copy()
+        self.lib.zko_poseidon_permute_batch(_ptr(a), C.c_size_t(a.size // 12))
+        return a
+
+    def poseidon_witness_row(self, inp, timestamp=0, filt=1):
+        a = np.array(inp, dtype=np.uint64)
+        row = np.zeros(POSEIDON_COLS, dtype=np.uint64)
+        self.lib.zko_poseidon_witness_row(_ptr(a), C.c_uint64(timestamp), C.c_int(filt), _ptr(row))
+        return row
+
+    def hash_no_pad(self, data):
+        a = np.ascontiguousarray(data, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        self.lib.zko_poseidon_hash_no_pad(_ptr(a), C.c_size_t(a.size), _ptr(out))
+        return out
+
+    def hash_or_noop(self, data):
+        a = np.ascontiguousarray(data, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        self.lib.zko_poseidon_hash_or_noop(_ptr(a), C.c_size_t(a.size), _ptr(out))
+        return out
+
+    def two_to_one(self, l, r):
+        l = np.ascontiguousarray(l, dtype=np.uint64)
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        self.lib.zko_poseidon_two_to_one(_ptr(l), _ptr(r), _ptr(out))
+        return out
+
+    def keccakf(self, st):
+        a = np.array(st, dtype=np.uint64)
+        self.lib.zko_keccakf(_ptr(a))
+        return a
+
+    def keccakf_batch(self, states):
+        a = np.ascontiguousarray(states, dtype=np.uint64).copy()
+        self.lib.zko_keccakf_batch(_ptr(a), C.c_size_t(a.size // 25))
+        return a
+
+    def keccak256(self, msg: bytes):
+        out = (C.c_uint8 * 32)()
+        self.lib.zko_keccak256(C.c_char_p(msg), C.c_size_t(len(msg)), out)
+        return bytes(out)
+
+    # ---- NTT / commitment
+    def ntt(self, cols, log_n, inverse=False, coset_shift=0):
+        a = np.ascontiguousarray(cols, dtype=np.uint64).copy()
+        self.lib.zko_ntt(_ptr(a), C.c_size_t(a.size >> log_n), log_n, int(inverse), C.c_uint64(coset_shift))
+        return a
+
+    def batch_from_values(self, values, ncols, log_n, rate_bits=2, cap_height=4):
+        a = np.ascontiguousarray(values, dtype=np.uint64)
+        return OracleBatch(self, self.lib.zko_batch_from_values(_ptr(a), ncols, log_n, rate_bits, cap_height),
+                           ncols, log_n, rate_bits, cap_height)
+
+    def batch_from_coeffs(self, coeffs, ncols, log_n, rate_bits=2, cap_height=4):
+        a = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        return OracleBatch(self, self.lib.zko_batch_from_coeffs(_ptr(a), ncols, log_n, rate_bits, cap_height),
+                           ncols, log_n, rate_bits, cap_height)
+
+    # ---- STARK
+    def standard_config(self):
+        cfg = StarkConfig()
+        self.lib.zko_standard_config(C.byref(cfg))
+        return cfg
+
+    def poseidon_trace(self, seed, num_perms, log_n):
+        out = np.zeros(POSEIDON_COLS << log_n, dtype=np.uint64)
+        self.lib.zko_poseidon_trace(C.c_uint64(seed), C.c_size_t(num_perms), log_n, _ptr(out))
+        return out
+
+    def poseidon_eval_row(self, row, alphas):
+        row = np.ascontiguousarray(row, dtype=np.uint64)
+        al = np.ascontiguousarray(alphas, dtype=np.uint64)
+        out = np.zeros(al.size, dtype=np.uint64)
+        self.lib.zko_poseidon_eval_row(_ptr(row), _ptr(al), C.c_size_t(al.size), _ptr(out))
+        return out
+
+    def quotient_poseidon(self, trace_b, aux_b, num_helpers, alphas):
+        nh = (C.c_uint32 * len(num_helpers))(*num_helpers)
+        al = np.ascontiguousarray(alphas, dtype=np.uint64)
+        out = np.zeros(al.size * (2 << trace_b.log_n), dtype=np.uint64)
+        self.lib.zko_quotient_poseidon(trace_b.h, aux_b.h, nh, len(num_helpers), _ptr(al), C.c_size_t(al.size), _ptr(out))
+        return out
+
+    def proof_words(self, cfg, log_n, ncols, naux, nctl):
+        return self.lib.zko_proof_words(C.byref(cfg), log_n, ncols, naux, nctl)
+
+    def prove(self, trace, log_n, aux, num_helpers, challenger=None, cfg=None, ncols=POSEIDON_COLS, want_stages=False):
+        cfg = cfg or self.standard_config()
+        ch = challenger or Challenger()
+        naux = aux.size >> log_n
+        nh = (C.c_uint32 * len(num_helpers))(*num_helpers)
+        proof = np.zeros(self.proof_words(cfg, log_n, ncols, naux, len(num_helpers)), dtype=np.uint64)
+        stages = (C.c_double * 8)()
+        rc = self.lib.zko_prove_single_table(0, C.byref(cfg), _ptr(np.ascontiguousarray(trace)), ncols, log_n,
+                                             _ptr(np.ascontiguousarray(aux)), naux, nh, len(num_helpers), C.byref(ch),
+                                             _ptr(proof), stages)
+        if rc != 0:
+            raise RuntimeError("oracle prove_single_table failed: %d" % rc)
+        return (proof, list(stages)) if want_stages else proof
+
+    def verify(self, proof, naux, num_helpers, challenger=None, cfg=None, ncols=POSEIDON_COLS):
+        cfg = cfg or self.standard_config()
+        ch = challenger or Challenger()
+        nh = (C.c_uint32 * len(num_helpers))(*num_helpers)
+        return self.lib.zko_verify_single_table(0, C.byref(cfg), _ptr(np.ascontiguousarray(proof)), ncols, naux, nh,
+                                                len(num_helpers), C.byref(ch))
+
+    # ---- challenger
+    def challenger(self):
+        ch = Challenger()
+        self.lib.zko_challenger_init(C.byref(ch))
+        return ch
+
+    def observe(self, ch, elems):
+        a = np.ascontiguousarray(elems, dtype=np.uint64)
+        self.lib.zko_challenger_observe(C.byref(ch), _ptr(a), C.c_size_t(a.size))
+
+    def challenge(self, ch):
+        return self.lib.zko_challenger_get(C.byref(ch))
+
+
+class OracleBatch:
+    def __init__(self, o, h, ncols, log_n, rate_bits, cap_height):
+        self.o, self.h, self.ncols, self.log_n, self.rate_bits, self.cap_height = o, h, ncols, log_n, rate_bits, cap_height
+
+    def __del__(self):
+        if self.h:
+            self.o.lib.zko_batch_free(self.h)
+            self.h = None
+
+    @property
+    def lde_bits(self):
+        return self.log_n + self.rate_bits
+
+    def cap(self):
+        out = np.zeros(4 << self.cap_height, dtype=np.uint64)
+        self.o.lib.zko_batch_cap(self.h, _ptr(out))
+        return out
+
+    def coeffs(self):
+        out = np.zeros(self.ncols << self.log_n, dtype=np.uint64)
+        self.o.lib.zko_batch_coeffs(self.h, _ptr(out))
+        return out
+
+    def lde_row(self, natural_index):
+        out = np.zeros(self.ncols, dtype=np.uint64)
+        self.o.lib.zko_batch_lde_row(self.h, natural_index, _ptr(out))
+        return out
+
+    def leaf(self, i):
+        out = np.zeros(self.ncols, dtype=np.uint64)
+        self.o.lib.zko_batch_leaf(self.h, i, _ptr(out))
+        return out
+
+    def merkle_path(self, i):
+        out = np.zeros(4 * (self.lde_bits - self.cap_height), dtype=np.uint64)
+        self.o.lib.zko_batch_merkle_path(self.h, i, _ptr(out))
+        return out
+
+    def digest_layer(self, level):
+        out = np.zeros(4 << (self.lde_bits - level), dtype=np.uint64)
+        self.o.lib.zko_batch_digest_layer(self.h, level, _ptr(out))
+        return out

@@ -1,0 +1,105 @@
+/* oracle/zkm_oracle.h -- C API of the CPU oracle (libzkm_oracle.so).
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the CPU restatement of the reference's STARK/FRI hot path
+ * (zkMIPS/zkm prover/src/prover.rs:441-789 and the plonky2 0.1.4 internals it calls).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it -- as the checker, never as the
+ * product path.  PARITY STATUS: primitives pinned by known-answer vectors (Poseidon: plonky2 test
+ * vectors; Keccak-f: reference keccak_util.rs:39-59); the plonky2-internal conventions (leaf order,
+ * sponge mode, transcript order, FRI folding, PoW) are RECALLED, not verifiable here ("parity
+ * unpinned" for bytes of caps/FRI); the pipeline is pinned by prove -> verify (restated verifier).
+ *
+ * Conventions: all field elements are canonical uint64_t; matrices are column-major (col*n + row);
+ * F2 elements are two consecutive uint64_t [c0, c1].
+ */
+#ifndef ZKM_ORACLE_H
+#define ZKM_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKO_POSEIDON_COLS 262
+
+/* ---- primitives ---- */
+uint64_t zko_gl_mul(uint64_t a, uint64_t b);
+uint64_t zko_gl_inv(uint64_t a);
+uint64_t zko_gl_pow(uint64_t a, uint64_t e);
+uint64_t zko_gl_root_of_unity(unsigned k);
+void zko_gl2_mul(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]);
+void zko_gl2_inv(const uint64_t a[2], uint64_t out[2]);
+
+void zko_poseidon_permute_naive(uint64_t st[12]);
+void zko_poseidon_permute(uint64_t st[12]);
+void zko_poseidon_permute_batch(uint64_t* states, size_t k);
+void zko_poseidon_witness_row(const uint64_t in[12], uint64_t timestamp, int filter, uint64_t row[ZKO_POSEIDON_COLS]);
+void zko_poseidon_hash_no_pad(const uint64_t* in, size_t len, uint64_t out[4]);
+void zko_poseidon_hash_or_noop(const uint64_t* in, size_t len, uint64_t out[4]);
+void zko_poseidon_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);
+
+void zko_keccakf(uint64_t st[25]);
+void zko_keccakf_batch(uint64_t* states, size_t k);
+void zko_keccak256(const uint8_t* msg, size_t len, uint8_t out[32]);
+
+/* ---- NTT (natural order in and out) ---- */
+void zko_ntt(uint64_t* cols, size_t ncols, unsigned log_n, int inverse, uint64_t coset_shift);
+
+/* ---- polynomial batch commitment == plonky2 PolynomialBatch ---- */
+typedef struct zko_batch zko_batch;
+zko_batch* zko_batch_from_values(const uint64_t* values, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height);
+zko_batch* zko_batch_from_coeffs(const uint64_t* coeffs, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height);
+void zko_batch_free(zko_batch*);
+void zko_batch_cap(const zko_batch*, uint64_t* out);                       /* 2^cap_height x 4 */
+void zko_batch_coeffs(const zko_batch*, uint64_t* out);                    /* ncols x n */
+void zko_batch_lde_row(const zko_batch*, size_t natural_index, uint64_t* out); /* get_lde_values(i, 1) */
+void zko_batch_leaf(const zko_batch*, size_t leaf_index, uint64_t* out);    /* merkle_tree.leaves[i] */
+void zko_batch_merkle_path(const zko_batch*, size_t leaf_index, uint64_t* siblings); /* (lde_bits-cap) x 4 */
+void zko_batch_digest_layer(const zko_batch*, unsigned level, uint64_t* out); /* level 0 = leaf digests */
+
+/* ---- Fiat-Shamir challenger (Poseidon duplex sponge) ---- */
+typedef struct {
+    uint64_t state[12];
+    uint64_t in_buf[8];
+    uint64_t out_buf[8];
+    uint32_t n_in, n_out;
+} zko_challenger;
+void zko_challenger_init(zko_challenger*);
+void zko_challenger_observe(zko_challenger*, const uint64_t* elems, size_t n);
+uint64_t zko_challenger_get(zko_challenger*);
+void zko_challenger_compact(zko_challenger*, uint64_t state_out[12]);
+
+/* ---- synthetic PoseidonStark trace (poseidon_stark.rs:104-160) ---- */
+/* inputs are derived from `seed` with SplitMix64; num_perms real rows (filter=1, timestamp 0), the rest
+ * padded with the default row (permutation of zeros, filter=0).  Output column-major 262 x 2^log_n. */
+void zko_poseidon_trace(uint64_t seed, size_t num_perms, unsigned log_n, uint64_t* out_cols);
+
+/* ---- prove_single_table for PoseidonStark with the benchmark's fake CTL data ---- */
+/* table ids */
+#define ZKO_TABLE_POSEIDON 0
+typedef struct {
+    unsigned rate_bits, cap_height, pow_bits, num_challenges, num_queries, arity_bits, final_poly_bits;
+} zko_stark_config;
+void zko_standard_config(zko_stark_config*);
+
+/* Proof blob layout: see include/zkm_hip.h (shared with the HIP product so they compare bytewise). */
+size_t zko_proof_words(const zko_stark_config*, unsigned log_n, size_t ncols, size_t naux, size_t nctl_zs);
+/* ctl description for the fake-CTL shape: nctl_zs CtlZData, each with num_helpers[i] helper columns and
+ * no column sets; aux = ctl helper columns ++ ctl z columns (column-major naux x n). */
+int zko_prove_single_table(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t ncols, unsigned log_n,
+                           const uint64_t* aux, size_t naux, const uint32_t* num_helpers, size_t nctl_zs,
+                           zko_challenger* challenger, uint64_t* proof_out, double* stage_seconds /* 8 or NULL */);
+/* returns 0 if the proof verifies; otherwise a positive code naming the failed check */
+int zko_verify_single_table(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t ncols, size_t naux,
+                            const uint32_t* num_helpers, size_t nctl_zs, zko_challenger* challenger);
+
+/* quotient stage alone (for stage-level parity): out = num_challenges*2 chunk polys... returns the
+ * num_challenges quotient polys of 2n coefficients each (natural order). */
+void zko_quotient_poseidon(const zko_batch* trace, const zko_batch* aux, const uint32_t* num_helpers, size_t nctl_zs,
+                           const uint64_t* alphas, size_t nalphas, uint64_t* out_coeffs);
+/* constraint evaluation of one row in the base field (check_constraints building block) */
+void zko_poseidon_eval_row(const uint64_t* local, const uint64_t* alphas, size_t nalphas, uint64_t* acc_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
