@@ -1,0 +1,137 @@
+"""GPU parity: HIP kernels behind the C ABI vs the CPU oracle, bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+G = 14293326489335486720
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+EDGE = [0, 1, 2, P - 1, P - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, 0xFFFFFFFE00000001, 0x7FFFFFFF80000000]
+
+
+def rand_field(rng, size):
+    a = rng.integers(0, P, size, dtype=np.uint64)
+    return a
+
+
+def test_poseidon_permute_batch(ctx, oracle):
+    kat = json.load(open(os.path.join(GOLD, "poseidon_kat.json")))
+    states = np.array([v["in"] for v in kat["vectors"]], dtype=np.uint64).reshape(-1)
+    out = ctx.poseidon_permute_batch(states.copy()).reshape(-1, 12)
+    for row, v in zip(out, kat["vectors"]):
+        assert [int(x) for x in row] == v["out"]
+    rng = np.random.default_rng(0)
+    k = 5000
+    st = rand_field(rng, 12 * k)
+    # edge values in every lane position
+    for i, e in enumerate(EDGE):
+        st[12 * i:12 * i + 12] = e
+        st[12 * (20 + i) + (i % 12)] = e
+    got = ctx.poseidon_permute_batch(st.copy())
+    assert (got == oracle.poseidon_permute_batch(st)).all()
+
+
+def test_poseidon_permute_device_resident(ctx, oracle):
+    rng = np.random.default_rng(1)
+    st = rand_field(rng, 12 * 1000)
+    buf = ctx.alloc(st.size).upload(st)
+    ctx.poseidon_permute_batch(buf)
+    assert (buf.download() == oracle.poseidon_permute_batch(st)).all()
+    buf.free()
+
+
+def test_keccakf_batch(ctx, oracle):
+    kat = json.load(open(os.path.join(GOLD, "keccakf_kat.json")))
+    v = kat["keccakf"][0]
+    out = ctx.keccakf_batch(np.array(v["in"], dtype=np.uint64))
+    assert [int(x) for x in out] == v["out"]
+    rng = np.random.default_rng(2)
+    st = rng.integers(0, 2**64, 25 * 3000, dtype=np.uint64)
+    assert (ctx.keccakf_batch(st.copy()) == oracle.keccakf_batch(st)).all()
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 10, 11, 13, 16])
+def test_ntt_matches_oracle(ctx, oracle, log_n):
+    rng = np.random.default_rng(log_n)
+    ncols = 3 if log_n < 14 else 2
+    x = rand_field(rng, ncols << log_n)
+    k = min(len(EDGE), x.size)
+    x[:k] = EDGE[:k]
+    for inverse in (False, True):
+        for shift in (0, G, 7):
+            got = ctx.ntt(x.copy(), ncols, log_n, inverse=inverse, coset_shift=shift)
+            assert (got == oracle.ntt(x, log_n, inverse=inverse, coset_shift=shift)).all(), (log_n, inverse, shift)
+
+
+def test_ntt_roundtrip_large(ctx):
+    # size-independent property at 2^20: iNTT(NTT(x)) == x, also on the coset
+    rng = np.random.default_rng(20)
+    log_n, ncols = 20, 2
+    x = rand_field(rng, ncols << log_n)
+    y = ctx.ntt(x.copy(), ncols, log_n)
+    assert not (y == x).all()
+    assert (ctx.ntt(y, ncols, log_n, inverse=True) == x).all()
+    y = ctx.ntt(x.copy(), ncols, log_n, coset_shift=G)
+    assert (ctx.ntt(y, ncols, log_n, inverse=True, coset_shift=G) == x).all()
+
+
+@pytest.mark.parametrize("log_n,ncols", [(3, 1), (5, 4), (5, 5), (6, 13), (8, 262), (10, 9), (12, 20)])
+def test_commit_matches_oracle(ctx, zkm, oracle, log_n, ncols):
+    rng = np.random.default_rng(100 + log_n + ncols)
+    vals = rand_field(rng, ncols << log_n)
+    b = zkm.PolynomialBatch.from_values(ctx, vals, ncols, log_n)
+    ob = oracle.batch_from_values(vals, ncols, log_n)
+    assert (b.coeffs() == ob.coeffs()).all()
+    assert (b.cap() == ob.cap()).all()
+    N = 4 << log_n
+    for i in (0, 1, N // 2 + 3, N - 1):
+        assert (b.lde_row(i) == ob.lde_row(i)).all()
+        assert (b.leaf(i) == ob.leaf(i)).all()
+        assert (b.merkle_path(i) == ob.merkle_path(i)).all()
+    for level in (0, 1, b.lde_bits - b.cap_height):
+        assert (b.digest_layer(level) == ob.digest_layer(level)).all()
+    # from_coeffs on the recovered coefficients gives the same commitment
+    b2 = zkm.PolynomialBatch.from_coeffs(ctx, b.coeffs(), ncols, log_n)
+    assert (b2.cap() == ob.cap()).all()
+    b.free()
+    b2.free()
+
+
+def test_commit_other_rate_and_cap(ctx, zkm, oracle):
+    rng = np.random.default_rng(77)
+    log_n, ncols = 6, 11
+    vals = rand_field(rng, ncols << log_n)
+    for rate_bits, cap_height in ((1, 0), (3, 2), (2, 8)):
+        b = zkm.PolynomialBatch.from_values(ctx, vals, ncols, log_n, rate_bits, cap_height)
+        ob = oracle.batch_from_values(vals, ncols, log_n, rate_bits, cap_height)
+        assert (b.cap() == ob.cap()).all()
+        b.free()
+
+
+def test_commit_device_resident_input(ctx, zkm, oracle):
+    rng = np.random.default_rng(78)
+    log_n, ncols = 9, 17
+    vals = rand_field(rng, ncols << log_n)
+    buf = ctx.alloc(vals.size).upload(vals)
+    b = zkm.PolynomialBatch.from_values(ctx, buf, ncols, log_n)
+    assert (buf.download() == vals).all()  # input is borrowed, not consumed
+    assert (b.cap() == oracle.batch_from_values(vals, ncols, log_n).cap()).all()
+    b.free()
+    buf.free()
+
+
+def test_poseidon_trace_matches_oracle(ctx, oracle):
+    for log_n, perms in ((5, 29), (8, 256), (10, 1000)):
+        got = ctx.poseidon_trace(3, perms, log_n).download()
+        assert (got == oracle.poseidon_trace(3, perms, log_n)).all()
+
+
+def test_errors_are_reported(ctx, zkm):
+    with pytest.raises(zkm.ZkmError):
+        zkm.PolynomialBatch.from_values(ctx, np.zeros(8, dtype=np.uint64), 1, 3, rate_bits=2, cap_height=9)
+    with pytest.raises(zkm.ZkmError):
+        ctx.ntt(np.zeros(8, dtype=np.uint64), 1, 3, coset_shift=P)

@@ -1,0 +1,92 @@
+"""CPU suite: the oracle's primitives against the reference's known-answer vectors."""
+import json
+import os
+
+import numpy as np
+
+P = 0xFFFFFFFF00000001
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_field_constants(oracle):
+    # Goldilocks domain constants (plonky2_field, recalled): generator of F*, 2^32-th root, non-residue 7
+    g, w = 14293326489335486720, 7277203076849721926
+    assert pow(g, (P - 1) >> 32, P) == w
+    assert pow(w, 1 << 32, P) == 1 and pow(w, 1 << 31, P) != 1
+    for q in (2, 3, 5, 17, 257, 65537):
+        assert pow(g, (P - 1) // q, P) != 1
+    assert pow(7, (P - 1) // 2, P) == P - 1
+    for k in (1, 5, 20, 32):
+        assert oracle.root_of_unity(k) == pow(w, 1 << (32 - k), P)
+
+
+def test_field_arithmetic_edges(oracle):
+    edge = [0, 1, 2, P - 1, P - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, 0x8000000000000000 % P, 1 << 63]
+    edge = [e % P for e in edge]
+    rng = np.random.default_rng(7)
+    vals = edge + [int(x) % P for x in rng.integers(0, 2**63, 50, dtype=np.uint64)]
+    for a in vals:
+        for b in edge:
+            assert oracle.gl_mul(a, b) == a * b % P
+    for a in vals[1:]:
+        assert oracle.gl_mul(a, oracle.gl_inv(a)) == 1 or a == 0
+    assert oracle.gl_pow(3, P - 1) == 1
+
+
+def test_poseidon_known_answers(oracle):
+    kat = json.load(open(os.path.join(GOLD, "poseidon_kat.json")))
+    for v in kat["vectors"]:
+        assert [int(x) for x in oracle.poseidon_permute(v["in"])] == v["out"]
+        assert [int(x) for x in oracle.poseidon_permute(v["in"], naive=True)] == v["out"]
+
+
+def test_poseidon_fast_equals_naive(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        st = rng.integers(0, P, 12, dtype=np.uint64)
+        assert (oracle.poseidon_permute(st) == oracle.poseidon_permute(st, naive=True)).all()
+    for st in ([P - 1] * 12, [0xFFFFFFFF] * 12, [P - 1, 0, 1, 2, P - 2, 3, 0xFFFFFFFF00000000, 4, 5, 6, 7, 8]):
+        assert (oracle.poseidon_permute(st) == oracle.poseidon_permute(st, naive=True)).all()
+
+
+def test_poseidon_witness_row_matches_permutation(oracle):
+    # reference property: poseidon_sponge_stark.rs:661-690 / poseidon_stark.rs:129-147 (row out == permutation)
+    rng = np.random.default_rng(2)
+    st = rng.integers(0, P, 12, dtype=np.uint64)
+    row = oracle.poseidon_witness_row(st, timestamp=5, filt=1)
+    assert row.size == 262 and row[0] == 1 and row[25] == 5
+    assert (row[1:13] == st).all()
+    assert (row[13:25] == oracle.poseidon_permute(st)).all()
+    # test_eval_consistency (poseidon_stark.rs:726-748): all constraints vanish on a generated row
+    assert (oracle.poseidon_eval_row(row, [2, 3, 5]) == 0).all()
+    bad = row.copy()
+    bad[40] ^= 1
+    assert (oracle.poseidon_eval_row(bad, [2, 3, 5]) != 0).any()
+
+
+def test_hash_modes(oracle):
+    # hash_or_noop copies <= 4 elements (App. A.4); two_to_one == permutation of [l, r, 0000]
+    assert list(oracle.hash_or_noop([7, 8, 9])) == [7, 8, 9, 0]
+    l, r = np.arange(1, 5, dtype=np.uint64), np.arange(5, 9, dtype=np.uint64)
+    full = oracle.poseidon_permute(list(l) + list(r) + [0] * 4)
+    assert (oracle.two_to_one(l, r) == full[:4]).all()
+    data = np.arange(100, 113, dtype=np.uint64)  # 13 elements: chunks 8 + 5, overwrite mode
+    st = np.zeros(12, dtype=np.uint64)
+    st[:8] = data[:8]
+    st = oracle.poseidon_permute(st)
+    st[:5] = data[8:]
+    st = oracle.poseidon_permute(st)
+    assert (oracle.hash_no_pad(data) == st[:4]).all()
+
+
+def test_keccak_known_answers(oracle):
+    kat = json.load(open(os.path.join(GOLD, "keccakf_kat.json")))
+    for v in kat["keccakf"]:
+        assert [int(x) for x in oracle.keccakf(v["in"])] == v["out"]
+    for v in kat["keccak256"]:
+        assert oracle.keccak256(bytes.fromhex(v["msg_hex"])).hex() == v["digest_hex"]
+    # sponge of [1,2,3] (reference test keccak_sponge_stark.rs:761-790 compares with keccak_hash::keccak)
+    import hashlib
+    assert len(oracle.keccak256(bytes([1, 2, 3]))) == 32
+    long = bytes(range(200)) * 3  # multi-block, rate 136
+    assert oracle.keccak256(long) != oracle.keccak256(long[:-1])

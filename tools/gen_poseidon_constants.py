@@ -43,7 +43,7 @@ def parse_rust_arrays(text):
 
 def parse_inc_arrays(text):
     out = {}
-    for m in re.finditer(r"static const uint64_t (\w+)\[[^\]]*\](?:\[[^\]]*\])? = \{(.*?)\};", text, re.S):
+    for m in re.finditer(r"ZKM_CONST uint64_t (\w+)\[[^\]]*\](?:\[[^\]]*\])? = \{(.*?)\};", text, re.S):
         out[m.group(1)] = [int(t, 0) for t in re.findall(r"0x[0-9a-fA-F]+", m.group(2))]
     return out
 
@@ -122,9 +122,17 @@ def derive_fast(rc, circ, diag):
 
 
 def fmt(name, dims, flat, per_line=4):
-    lines = ["static const uint64_t %s%s = {" % (name, "".join("[%d]" % d for d in dims))]
-    for i in range(0, len(flat), per_line):
-        lines.append("    " + " ".join("0x%016xULL," % x for x in flat[i:i + per_line]))
+    lines = ["ZKM_CONST uint64_t %s%s = {" % (name, "".join("[%d]" % d for d in dims))]
+    if len(dims) == 2:
+        for r in range(dims[0]):
+            row = flat[r * dims[1]:(r + 1) * dims[1]]
+            lines.append("    {")
+            for i in range(0, len(row), per_line):
+                lines.append("        " + " ".join("0x%016xULL," % x for x in row[i:i + per_line]))
+            lines.append("    },")
+    else:
+        for i in range(0, len(flat), per_line):
+            lines.append("    " + " ".join("0x%016xULL," % x for x in flat[i:i + per_line]))
     lines.append("};")
     return "\n".join(lines)
 
@@ -155,7 +163,12 @@ def main():
         " * GENERATED by tools/gen_poseidon_constants.py -- do not edit.",
         " * Round constants + MDS row/diag: the public parameter set (reference carries it at",
         " * prover/src/poseidon/constants.rs:11-105).  FAST_* tables: derived by the generator",
-        " * (equivalent-matrix factorisation) and cross-checked against constants.rs:107-870. */",
+        " * (equivalent-matrix factorisation) and cross-checked against constants.rs:107-870.",
+        " * ZKM_CONST is the storage qualifier (default `static const`; the HIP side re-includes this",
+        " * file with `static __device__ __constant__ const`). */",
+        "#ifndef ZKM_CONST",
+        "#define ZKM_CONST static const",
+        "#endif",
         fmt("ZKM_POSEIDON_RC", [WIDTH * N_ROUNDS], rc),
         fmt("ZKM_POSEIDON_MDS_CIRC", [WIDTH], circ),
         fmt("ZKM_POSEIDON_MDS_DIAG", [WIDTH], diag),

@@ -1,0 +1,388 @@
+// core.hip -- context, memory, profiling, Fiat-Shamir transcript and the PolynomialBatch part of the C ABI.
+#include "poseidon_dev.h"
+#include "zkm_internal.h"
+
+// ------------------------------------------------------------------ error plumbing
+static int fail(char** err, const std::string& msg) {
+    if (err) {
+        *err = (char*)malloc(msg.size() + 1);
+        if (*err) memcpy(*err, msg.c_str(), msg.size() + 1);
+    }
+    return 1;
+}
+#define ZKM_API_BEGIN try {
+#define ZKM_API_END(err)                 \
+    }                                    \
+    catch (const std::exception& e) {    \
+        return fail(err, e.what());      \
+    }                                    \
+    catch (...) {                        \
+        return fail(err, "unknown error"); \
+    }                                    \
+    return 0;
+
+// ------------------------------------------------------------------ ctx
+void* zkm_ctx::alloc(size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    auto it = free_blocks.find(bytes);
+    void* p = nullptr;
+    if (it != free_blocks.end()) {
+        p = it->second;
+        free_blocks.erase(it);
+    } else {
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            // drop the cache and retry once
+            for (auto& kv : free_blocks) (void)hipFree(kv.second);
+            free_blocks.clear();
+            ZKM_HIP_CHECK(hipMalloc(&p, bytes));
+        }
+    }
+    live_blocks[p] = bytes;
+    return p;
+}
+void zkm_ctx::release(void* p) {
+    if (!p) return;
+    auto it = live_blocks.find(p);
+    if (it == live_blocks.end()) return;
+    free_blocks.emplace(it->second, p);
+    live_blocks.erase(it);
+}
+uint64_t* zkm_ctx::staging(size_t words) {
+    if (words > h_staging_words) {
+        if (h_staging) (void)hipHostFree(h_staging);
+        size_t w = words < 4096 ? 4096 : words;
+        ZKM_HIP_CHECK(hipHostMalloc((void**)&h_staging, w * sizeof(uint64_t)));
+        h_staging_words = w;
+    }
+    return h_staging;
+}
+hipEvent_t zkm_ctx::get_event() {
+    if (!event_pool.empty()) {
+        hipEvent_t e = event_pool.back();
+        event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    ZKM_HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+void zkm_ctx::prof_begin(const char* name) {
+    zkm_prof_rec r{name, get_event(), get_event()};
+    ZKM_HIP_CHECK(hipEventRecord(r.start, stream));
+    prof.push_back(r);
+    prof_agg_valid = false;
+}
+void zkm_ctx::prof_end() { ZKM_HIP_CHECK(hipEventRecord(prof.back().stop, stream)); }
+
+extern "C" {
+
+const char* zkm_version(void) { return "zkm-hip 0.1 (gfx950)"; }
+
+int zkm_ctx_create(int device, zkm_ctx** out, char** err) {
+    ZKM_API_BEGIN
+    int n = 0;
+    ZKM_HIP_CHECK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) throw std::runtime_error("zkm_ctx_create: no such HIP device " + std::to_string(device));
+    ZKM_HIP_CHECK(hipSetDevice(device));
+    zkm_ctx* c = new zkm_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    ZKM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount;
+    ZKM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c;
+    ZKM_API_END(err)
+}
+
+void zkm_ctx_destroy(zkm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
+    for (auto& kv : c->live_blocks) (void)hipFree(kv.first);
+    for (auto& r : c->prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->h_staging) (void)hipHostFree(c->h_staging);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int zkm_ctx_synchronize(zkm_ctx* c, char** err) {
+    ZKM_API_BEGIN
+    c->sync();
+    ZKM_API_END(err)
+}
+void* zkm_ctx_stream(zkm_ctx* c) { return (void*)c->stream; }
+
+int zkm_dev_alloc(zkm_ctx* c, size_t bytes, void** out, char** err) {
+    ZKM_API_BEGIN
+    ZKM_HIP_CHECK(hipSetDevice(c->device));
+    *out = c->alloc(bytes);
+    ZKM_API_END(err)
+}
+int zkm_dev_free(zkm_ctx* c, void* p) {
+    c->release(p);
+    return 0;
+}
+int zkm_dev_upload(zkm_ctx* c, void* dst, const void* src, size_t bytes, char** err) {
+    ZKM_API_BEGIN
+    ZKM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    c->sync();
+    ZKM_API_END(err)
+}
+int zkm_dev_download(zkm_ctx* c, void* dst, const void* src, size_t bytes, char** err) {
+    ZKM_API_BEGIN
+    ZKM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    ZKM_API_END(err)
+}
+
+// ------------------------------------------------------------------ profiling
+void zkm_profile_enable(zkm_ctx* c, int on) { c->profiling = on != 0; }
+void zkm_profile_reset(zkm_ctx* c) {
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& r : c->prof) { c->event_pool.push_back(r.start); c->event_pool.push_back(r.stop); }
+    c->prof.clear();
+    c->prof_agg.clear();
+    c->prof_agg_valid = false;
+}
+static void prof_aggregate(zkm_ctx* c) {
+    if (c->prof_agg_valid) return;
+    (void)hipStreamSynchronize(c->stream);
+    c->prof_agg.clear();
+    for (auto& r : c->prof) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) ms = 0;
+        bool found = false;
+        for (auto& a : c->prof_agg)
+            if (a.name == r.name || !strcmp(a.name, r.name)) { a.launches++; a.ms += ms; found = true; break; }
+        if (!found) c->prof_agg.push_back({r.name, 1, (double)ms});
+    }
+    c->prof_agg_valid = true;
+}
+size_t zkm_profile_count(zkm_ctx* c) {
+    prof_aggregate(c);
+    return c->prof_agg.size();
+}
+int zkm_profile_get(zkm_ctx* c, size_t i, const char** name, uint64_t* launches, double* total_ms) {
+    prof_aggregate(c);
+    if (i >= c->prof_agg.size()) return 1;
+    *name = c->prof_agg[i].name;
+    *launches = c->prof_agg[i].launches;
+    *total_ms = c->prof_agg[i].ms;
+    return 0;
+}
+
+// ------------------------------------------------------------------ Fiat-Shamir (host)
+// plonky2 Challenger: overwrite-mode duplex sponge over the Poseidon permutation.
+}  // extern "C"
+
+void zkm_host_poseidon_permute(uint64_t st[12]) { poseidon_permute(st); }
+
+extern "C" {
+void zkm_challenger_init(zkm_challenger* ch) { memset(ch, 0, sizeof *ch); }
+static void challenger_duplex(zkm_challenger* c) {
+    for (uint32_t i = 0; i < c->n_in; i++) c->state[i] = c->in_buf[i];
+    c->n_in = 0;
+    zkm_host_poseidon_permute(c->state);
+    for (int i = 0; i < 8; i++) c->out_buf[i] = c->state[i];
+    c->n_out = 8;
+}
+void zkm_challenger_observe(zkm_challenger* c, const uint64_t* e, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        c->n_out = 0;
+        c->in_buf[c->n_in++] = e[i];
+        if (c->n_in == 8) challenger_duplex(c);
+    }
+}
+uint64_t zkm_challenger_get(zkm_challenger* c) {
+    if (c->n_in != 0 || c->n_out == 0) challenger_duplex(c);
+    return c->out_buf[--c->n_out];
+}
+void zkm_challenger_compact(zkm_challenger* c, uint64_t out[12]) {
+    if (c->n_in != 0) challenger_duplex(c);
+    c->n_out = 0;
+    memcpy(out, c->state, sizeof c->state);
+}
+
+void zkm_standard_config(zkm_stark_config* c) {
+    c->rate_bits = 2; c->cap_height = 4; c->pow_bits = 16; c->num_challenges = 2;
+    c->num_queries = 37; c->arity_bits = 4; c->final_poly_bits = 5;
+}
+}  // extern "C"
+
+// ------------------------------------------------------------------ PolynomialBatch
+// from_values: iNTT each column (coefficients kept), then from_coeffs: coset LDE (x 2^rate_bits, shift g),
+// rows in bit-reversed order, Poseidon Merkle tree, cap.  src may be a host or device pointer.
+void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values) {
+    zkm_ctx* c = b->ctx;
+    size_t n = b->n(), N = b->N(), ncols = b->ncols;
+    if (b->log_n + b->rate_bits > 30) throw std::runtime_error("polynomial batch too large");
+    b->coeffs = (gl_t*)c->alloc(ncols * n * sizeof(gl_t));
+    b->lde = (gl_t*)c->alloc(ncols * N * sizeof(gl_t));
+    size_t dwords = zkm_merkle_layout(b->lde_bits(), b->cap_height, b->level_off);
+    b->digests = (gl_t*)c->alloc(dwords * sizeof(gl_t));
+    bool dev = zkm_is_device_ptr(src);
+    hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (src_is_values) {
+        // stage the values in the (not yet used) LDE buffer, transform there, land natural-order coefficients
+        ZKM_HIP_CHECK(hipMemcpyAsync(b->lde, src, ncols * n * sizeof(gl_t), kind, c->stream));
+        zkm_ntt_natural(c, b->lde, b->coeffs, ncols, n, n, b->log_n, /*inverse=*/true, 0);
+    } else {
+        ZKM_HIP_CHECK(hipMemcpyAsync(b->coeffs, src, ncols * n * sizeof(gl_t), kind, c->stream));
+    }
+    zkm_lde_bitrev(c, b->coeffs, b->lde, ncols, b->log_n, b->rate_bits, GL_GENERATOR);
+    zkm_launch_merkle_leaves(c, b->lde, N, ncols, N, b->digests);
+    zkm_merkle_build_inner(c, b->digests, b->level_off, b->lde_bits(), b->cap_height);
+    size_t capw = (size_t)4 << b->cap_height;
+    uint64_t* st = c->staging(capw);
+    ZKM_HIP_CHECK(hipMemcpyAsync(st, b->digests + b->level_off[b->top()], capw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    b->cap.assign(st, st + capw);
+}
+
+static zkm_batch* batch_new(zkm_ctx* c, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height) {
+    if (ncols == 0) throw std::runtime_error("empty polynomial batch");
+    if (cap_height > log_n + rate_bits) throw std::runtime_error("cap_height exceeds LDE size");
+    zkm_batch* b = new zkm_batch();
+    b->ctx = c; b->ncols = ncols; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
+    return b;
+}
+
+extern "C" {
+
+int zkm_batch_commit_values(zkm_ctx* c, const uint64_t* values, size_t ncols, unsigned log_n, unsigned rate_bits,
+                            unsigned cap_height, zkm_batch** out, char** err) {
+    zkm_batch* b = nullptr;
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        b = batch_new(c, ncols, log_n, rate_bits, cap_height);
+        zkm_batch_build(b, values, true);
+        *out = b;
+    } catch (const std::exception& e) {
+        zkm_batch_free(b);
+        return fail(err, e.what());
+    }
+    return 0;
+}
+int zkm_batch_commit_coeffs(zkm_ctx* c, const uint64_t* coeffs, size_t ncols, unsigned log_n, unsigned rate_bits,
+                            unsigned cap_height, zkm_batch** out, char** err) {
+    zkm_batch* b = nullptr;
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        b = batch_new(c, ncols, log_n, rate_bits, cap_height);
+        zkm_batch_build(b, coeffs, false);
+        *out = b;
+    } catch (const std::exception& e) {
+        zkm_batch_free(b);
+        return fail(err, e.what());
+    }
+    return 0;
+}
+void zkm_batch_free(zkm_batch* b) {
+    if (!b) return;
+    (void)hipStreamSynchronize(b->ctx->stream);
+    b->ctx->release(b->coeffs);
+    b->ctx->release(b->lde);
+    b->ctx->release(b->digests);
+    delete b;
+}
+int zkm_batch_cap(const zkm_batch* b, uint64_t* out) {
+    memcpy(out, b->cap.data(), b->cap.size() * sizeof(uint64_t));
+    return 0;
+}
+int zkm_batch_coeffs(const zkm_batch* b, uint64_t* out) {
+    hipMemcpyKind kind = zkm_is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (hipMemcpyAsync(out, b->coeffs, b->ncols * b->n() * sizeof(gl_t), kind, b->ctx->stream) != hipSuccess) return 1;
+    return hipStreamSynchronize(b->ctx->stream) == hipSuccess ? 0 : 1;
+}
+int zkm_batch_leaf(const zkm_batch* b, size_t leaf, uint64_t* out) {
+    if (leaf >= b->N()) return 1;
+    // one strided gather: ncols words at stride N
+    if (hipMemcpy2DAsync(out, sizeof(gl_t), b->lde + leaf, b->N() * sizeof(gl_t), sizeof(gl_t), b->ncols, hipMemcpyDeviceToHost,
+                         b->ctx->stream) != hipSuccess)
+        return 1;
+    return hipStreamSynchronize(b->ctx->stream) == hipSuccess ? 0 : 1;
+}
+int zkm_batch_lde_row(const zkm_batch* b, size_t natural_index, uint64_t* out) {
+    if (natural_index >= b->N()) return 1;
+    return zkm_batch_leaf(b, bitrev32((uint32_t)natural_index, b->lde_bits()), out);
+}
+int zkm_batch_merkle_path(const zkm_batch* b, size_t leaf, uint64_t* sib) {
+    if (leaf >= b->N()) return 1;
+    for (unsigned l = 0; l < b->top(); l++)
+        if (hipMemcpyAsync(sib + 4 * l, b->digests + b->level_off[l] + 4 * ((leaf >> l) ^ 1), 32, hipMemcpyDeviceToHost,
+                           b->ctx->stream) != hipSuccess)
+            return 1;
+    return hipStreamSynchronize(b->ctx->stream) == hipSuccess ? 0 : 1;
+}
+int zkm_batch_digest_layer(const zkm_batch* b, unsigned level, uint64_t* out) {
+    if (level > b->top()) return 1;
+    size_t words = (size_t)4 << (b->lde_bits() - level);
+    if (hipMemcpyAsync(out, b->digests + b->level_off[level], words * sizeof(gl_t), hipMemcpyDeviceToHost, b->ctx->stream) != hipSuccess)
+        return 1;
+    return hipStreamSynchronize(b->ctx->stream) == hipSuccess ? 0 : 1;
+}
+
+// ------------------------------------------------------------------ NTT / hashes / trace
+int zkm_ntt(zkm_ctx* c, uint64_t* cols, size_t ncols, unsigned log_n, int inverse, uint64_t coset_shift, char** err) {
+    ZKM_API_BEGIN
+    ZKM_HIP_CHECK(hipSetDevice(c->device));
+    if (log_n > 30) throw std::runtime_error("zkm_ntt: log_n too large");
+    if (coset_shift >= GL_P) throw std::runtime_error("zkm_ntt: coset_shift not canonical");
+    size_t n = (size_t)1 << log_n, bytes = ncols * n * sizeof(gl_t);
+    if (bytes == 0) return 0;
+    bool dev = zkm_is_device_ptr(cols);
+    gl_t* scratch = (gl_t*)c->alloc(bytes);
+    gl_t* work = dev ? cols : (gl_t*)c->alloc(bytes);
+    // transform from scratch (copy of the input) into `work`
+    ZKM_HIP_CHECK(hipMemcpyAsync(scratch, cols, bytes, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    zkm_ntt_natural(c, scratch, work, ncols, n, n, log_n, inverse != 0, coset_shift);
+    if (!dev) ZKM_HIP_CHECK(hipMemcpyAsync(cols, work, bytes, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    c->release(scratch);
+    if (!dev) c->release(work);
+    ZKM_API_END(err)
+}
+
+int zkm_poseidon_permute_batch(zkm_ctx* c, uint64_t* states, size_t k, char** err) {
+    ZKM_API_BEGIN
+    ZKM_HIP_CHECK(hipSetDevice(c->device));
+    size_t bytes = k * 12 * sizeof(uint64_t);
+    if (!bytes) return 0;
+    bool dev = zkm_is_device_ptr(states);
+    gl_t* d = dev ? states : (gl_t*)c->alloc(bytes);
+    if (!dev) ZKM_HIP_CHECK(hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, c->stream));
+    zkm_launch_poseidon_permute(c, d, k);
+    if (!dev) ZKM_HIP_CHECK(hipMemcpyAsync(states, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    if (!dev) c->release(d);
+    ZKM_API_END(err)
+}
+
+int zkm_keccakf_batch(zkm_ctx* c, uint64_t* states, size_t k, char** err) {
+    ZKM_API_BEGIN
+    ZKM_HIP_CHECK(hipSetDevice(c->device));
+    size_t bytes = k * 25 * sizeof(uint64_t);
+    if (!bytes) return 0;
+    bool dev = zkm_is_device_ptr(states);
+    uint64_t* d = dev ? states : (uint64_t*)c->alloc(bytes);
+    if (!dev) ZKM_HIP_CHECK(hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, c->stream));
+    zkm_launch_keccakf(c, d, k);
+    if (!dev) ZKM_HIP_CHECK(hipMemcpyAsync(states, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    if (!dev) c->release(d);
+    ZKM_API_END(err)
+}
+
+int zkm_poseidon_trace(zkm_ctx* c, uint64_t seed, size_t num_perms, unsigned log_n, uint64_t* out_dev, char** err) {
+    ZKM_API_BEGIN
+    ZKM_HIP_CHECK(hipSetDevice(c->device));
+    if (!zkm_is_device_ptr(out_dev)) throw std::runtime_error("zkm_poseidon_trace: out must be a device pointer");
+    zkm_launch_poseidon_trace(c, seed, num_perms, log_n, out_dev);
+    c->sync();
+    ZKM_API_END(err)
+}
+
+}  // extern "C"

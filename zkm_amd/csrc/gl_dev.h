@@ -1,0 +1,141 @@
+// gl_dev.h -- Goldilocks field arithmetic for gfx950 device code (and the host side of the library).
+//
+// F = Z/p, p = 2^64 - 2^32 + 1; F2 = F[X]/(X^2 - 7).  The reference gets this arithmetic from the
+// un-vendored plonky2_field crate (call sites prover/src/prover.rs:595, 690-696); results are
+// mathematically determined, so bit-exactness only requires canonical outputs.
+//
+// Representation contract used throughout the kernels:
+//   * "canonical"  : value in [0, p).  Everything stored to HBM is canonical.
+//   * "loose"      : any uint64_t (represents its residue mod p).  gl_mul / gl_reduce128 return loose
+//                    values; gl_add / gl_sub take one loose and one canonical operand where noted.
+// Every function documents its pre/post-conditions; no function relies on "unlikely" overflow cases.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GL_HD __host__ __device__ __forceinline__
+#else
+#define GL_HD inline
+#endif
+
+typedef uint64_t gl_t;
+
+static constexpr uint64_t GL_P = 0xFFFFFFFF00000001ULL;
+static constexpr uint64_t GL_EPS = 0xFFFFFFFFULL;  // 2^32 - 1 == 2^64 mod p
+static constexpr uint64_t GL_GENERATOR = 14293326489335486720ULL;
+static constexpr uint64_t GL_POW2_GENERATOR = 7277203076849721926ULL;
+
+// loose -> canonical
+GL_HD gl_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
+
+// canonical + canonical -> canonical
+GL_HD gl_t gl_add(gl_t a, gl_t b) {
+    uint64_t s = a + b;
+    // a + b < 2p < 2^65.  If the 64-bit add wrapped, the true sum is s + 2^64 and s + 2^64 - p == s + EPS (mod 2^64).
+    return (s < a || s >= GL_P) ? s - GL_P : s;
+}
+// canonical - canonical -> canonical
+GL_HD gl_t gl_sub(gl_t a, gl_t b) { return a >= b ? a - b : a - b + GL_P; }
+GL_HD gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
+
+// loose + loose -> loose.  s = a + b may wrap once; 2^64 == EPS, and (s + EPS) may wrap once more, in
+// which case s >= 2^64 - EPS so the second wrapped value is < EPS and adding EPS again cannot wrap.
+GL_HD uint64_t gl_add_loose(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    if (s < a) {
+        uint64_t t = s + GL_EPS;
+        s = t < s ? t + GL_EPS : t;
+    }
+    return s;
+}
+
+// 128-bit (hi:lo) -> loose.  Standard Goldilocks reduction: 2^64 == 2^32 - 1, 2^96 == -1.
+GL_HD uint64_t gl_reduce128(uint64_t lo, uint64_t hi) {
+    uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= GL_EPS;  // borrow: t0 = lo - hi_hi + p, in (p - 2^32, p)
+    uint64_t t1 = (hi_lo << 32) - hi_lo;  // hi_lo * EPS <= (2^32-1)^2
+    uint64_t r = t0 + t1;
+    if (r < t1) r += GL_EPS;  // wrapped: r < 2^64 - 2^33 + 1, adding EPS cannot wrap again
+    return r;
+}
+
+GL_HD void gl_mul_wide(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    lo = a * b;
+    hi = __umul64hi(a, b);
+#else
+    unsigned __int128 p = (unsigned __int128)a * b;
+    lo = (uint64_t)p;
+    hi = (uint64_t)(p >> 64);
+#endif
+}
+
+// loose * loose -> loose
+GL_HD uint64_t gl_mul_loose(uint64_t a, uint64_t b) {
+    uint64_t lo, hi;
+    gl_mul_wide(a, b, lo, hi);
+    return gl_reduce128(lo, hi);
+}
+// loose * loose -> canonical
+GL_HD gl_t gl_mul(uint64_t a, uint64_t b) { return gl_canon(gl_mul_loose(a, b)); }
+GL_HD gl_t gl_sqr(uint64_t a) { return gl_mul(a, a); }
+
+GL_HD gl_t gl_pow(gl_t b, uint64_t e) {
+    gl_t r = 1;
+    while (e) {
+        if (e & 1) r = gl_mul(r, b);
+        b = gl_sqr(b);
+        e >>= 1;
+    }
+    return r;
+}
+GL_HD gl_t gl_inv(gl_t a) { return gl_pow(a, GL_P - 2); }
+GL_HD gl_t gl_exp_pow2(gl_t a, unsigned k) {
+    while (k--) a = gl_sqr(a);
+    return a;
+}
+GL_HD gl_t gl_root_of_unity(unsigned k) { return gl_exp_pow2(GL_POW2_GENERATOR, 32 - k); }
+
+// ---- F2 (all canonical) ----
+struct gl2_t {
+    gl_t c0, c1;
+};
+GL_HD gl2_t gl2_make(gl_t a, gl_t b) { return gl2_t{a, b}; }
+GL_HD gl2_t gl2_add(gl2_t a, gl2_t b) { return gl2_t{gl_add(a.c0, b.c0), gl_add(a.c1, b.c1)}; }
+GL_HD gl2_t gl2_sub(gl2_t a, gl2_t b) { return gl2_t{gl_sub(a.c0, b.c0), gl_sub(a.c1, b.c1)}; }
+GL_HD gl2_t gl2_mul(gl2_t a, gl2_t b) {
+    gl_t a0b0 = gl_mul(a.c0, b.c0), a1b1 = gl_mul(a.c1, b.c1);
+    return gl2_t{gl_add(a0b0, gl_mul(7, a1b1)), gl_add(gl_mul(a.c0, b.c1), gl_mul(a.c1, b.c0))};
+}
+GL_HD gl2_t gl2_scalar_mul(gl2_t a, gl_t s) { return gl2_t{gl_mul(a.c0, s), gl_mul(a.c1, s)}; }
+GL_HD bool gl2_eq(gl2_t a, gl2_t b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+GL_HD gl2_t gl2_inv(gl2_t a) {
+    gl_t norm = gl_sub(gl_sqr(a.c0), gl_mul(7, gl_sqr(a.c1)));
+    gl_t ni = gl_inv(norm);
+    return gl2_t{gl_mul(a.c0, ni), gl_mul(gl_neg(a.c1), ni)};
+}
+GL_HD gl2_t gl2_pow(gl2_t b, uint64_t e) {
+    gl2_t r{1, 0};
+    while (e) {
+        if (e & 1) r = gl2_mul(r, b);
+        b = gl2_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+GL_HD gl2_t gl2_exp_pow2(gl2_t a, unsigned k) {
+    while (k--) a = gl2_mul(a, a);
+    return a;
+}
+
+GL_HD uint32_t bitrev32(uint32_t x, unsigned bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+    uint32_t r = 0;
+    for (unsigned i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+#endif
+}

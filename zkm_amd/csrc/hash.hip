@@ -1,0 +1,281 @@
+// hash.hip -- Poseidon / Keccak-f / Merkle kernels for gfx950.
+//
+// K4  leaf hashing  == plonky2 MerkleTree::new leaf digests = PoseidonHash::hash_or_noop(row)
+//     (overwrite-mode sponge, rate 8; rows of <= 4 elements are copied, not hashed -- SURVEY App. A.4)
+// K5  inner nodes   == PoseidonHash::two_to_one(left, right), level by level up to the cap
+// K15 Keccak-f[1600] batch (reference: cpu/kernel/keccak_util.rs:6-31 via tiny-keccak)
+// a13 PoseidonStark witness rows (reference: poseidon/poseidon_stark.rs:51-160)
+//
+// Layout: the LDE is column-major with rows already bit-reversed, so "leaf j" = element j of every
+// column: lane = leaf, and each per-column load is a contiguous 512 B wave access -- the transpose
+// (K3 in SURVEY §2.1) is fused into the hashing loads.  Integer VALU bound (not HBM, not MFMA).
+#include "poseidon_dev.h"
+#include "zkm_internal.h"
+
+// ------------------------------------------------------------------ Poseidon permutation batch
+__global__ __launch_bounds__(256) void k_poseidon_permute(gl_t* states, size_t k) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) s[j] = states[i * 12 + j];
+    poseidon_permute(s);
+#pragma unroll
+    for (int j = 0; j < 12; j++) states[i * 12 + j] = s[j];
+}
+
+void zkm_launch_poseidon_permute(zkm_ctx* c, gl_t* states, size_t k) {
+    if (!k) return;
+    zkm_prof_scope ps(c, "poseidon_permute");
+    hipLaunchKernelGGL(k_poseidon_permute, dim3((k + 255) / 256), dim3(256), 0, c->stream, states, k);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ Merkle leaves (column-major rows)
+__global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ lde, size_t nrows, size_t ncols,
+                                                       size_t col_stride, gl_t* __restrict__ digests) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nrows) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    if (ncols <= 4) {  // hash_or_noop: copy
+        for (size_t c = 0; c < ncols; c++) s[c] = lde[c * col_stride + j];
+    } else {
+        const gl_t* p = lde + j;
+        size_t c = 0;
+        for (; c + 8 <= ncols; c += 8) {
+            uint64_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = p[(c + i) * col_stride];
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = v[i];
+            poseidon_permute(s);
+        }
+        if (c < ncols) {
+            size_t rem = ncols - c;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if ((size_t)i < rem) s[i] = p[(c + i) * col_stride];
+            poseidon_permute(s);
+        }
+    }
+    uint64_t* d = digests + 4 * j;
+    *reinterpret_cast<ulonglong2*>(d) = make_ulonglong2(s[0], s[1]);
+    *reinterpret_cast<ulonglong2*>(d + 2) = make_ulonglong2(s[2], s[3]);
+}
+
+void zkm_launch_merkle_leaves(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests) {
+    zkm_prof_scope ps(c, "merkle_leaves");
+    hipLaunchKernelGGL(k_merkle_leaves, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride,
+                       digests);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
+// leaves of a FRI layer: leaf k = arity consecutive F2 values (bit-reversed order), flattened c0,c1,c0,c1..
+__global__ __launch_bounds__(256) void k_merkle_leaves_ext(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1,
+                                                           size_t nleaves, unsigned arity, gl_t* __restrict__ digests) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nleaves) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    const gl_t* a = c0 + k * arity;
+    const gl_t* b = c1 + k * arity;
+    // 2*arity words, arity a multiple of 4 -> whole chunks of 8 words = 4 pairs
+    for (unsigned e = 0; e < arity; e += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            s[2 * i] = a[e + i];
+            s[2 * i + 1] = b[e + i];
+        }
+        poseidon_permute(s);
+    }
+    uint64_t* d = digests + 4 * k;
+    *reinterpret_cast<ulonglong2*>(d) = make_ulonglong2(s[0], s[1]);
+    *reinterpret_cast<ulonglong2*>(d + 2) = make_ulonglong2(s[2], s[3]);
+}
+
+void zkm_launch_merkle_leaves_ext(zkm_ctx* c, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests) {
+    if (arity % 4 || 2 * arity <= 4) throw std::runtime_error("merkle_leaves_ext: unsupported arity");
+    zkm_prof_scope ps(c, "merkle_leaves_ext");
+    hipLaunchKernelGGL(k_merkle_leaves_ext, dim3((nleaves + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity,
+                       digests);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ Merkle inner level
+__global__ __launch_bounds__(256) void k_merkle_compress(const gl_t* __restrict__ children, gl_t* __restrict__ parents,
+                                                         size_t nparents) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nparents) return;
+    const ulonglong2* ch = reinterpret_cast<const ulonglong2*>(children + 8 * i);
+    ulonglong2 a = ch[0], b = ch[1], cc = ch[2], d = ch[3];
+    uint64_t s[12] = {a.x, a.y, b.x, b.y, cc.x, cc.y, d.x, d.y, 0, 0, 0, 0};
+    poseidon_permute(s);
+    uint64_t* o = parents + 4 * i;
+    *reinterpret_cast<ulonglong2*>(o) = make_ulonglong2(s[0], s[1]);
+    *reinterpret_cast<ulonglong2*>(o + 2) = make_ulonglong2(s[2], s[3]);
+}
+
+void zkm_launch_merkle_compress(zkm_ctx* c, const gl_t* children, gl_t* parents, size_t nparents) {
+    zkm_prof_scope ps(c, "merkle_compress");
+    hipLaunchKernelGGL(k_merkle_compress, dim3((nparents + 255) / 256), dim3(256), 0, c->stream, children, parents, nparents);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
+size_t zkm_merkle_layout(unsigned log_leaves, unsigned cap_height, std::vector<size_t>& level_off) {
+    if (cap_height > log_leaves) throw std::runtime_error("cap_height exceeds tree height");
+    level_off.clear();
+    size_t total = 0;
+    for (unsigned l = 0; l + cap_height <= log_leaves; l++) {
+        level_off.push_back(total);
+        total += ((size_t)1 << (log_leaves - l)) * 4;
+    }
+    return total;
+}
+
+void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves,
+                            unsigned cap_height) {
+    unsigned top = log_leaves - cap_height;
+    for (unsigned l = 1; l <= top; l++)
+        zkm_launch_merkle_compress(c, digests + level_off[l - 1], digests + level_off[l], (size_t)1 << (log_leaves - l));
+}
+
+// ------------------------------------------------------------------ Keccak-f[1600]
+__device__ __forceinline__ uint64_t rotl64(uint64_t v, unsigned r) { return (v << r) | (v >> (64 - r)); }
+
+__global__ __launch_bounds__(256) void k_keccakf(uint64_t* states, size_t k) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= k) return;
+    constexpr uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    // rho offsets indexed x + 5y
+    constexpr unsigned RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    uint64_t a[25];
+    uint64_t* st = states + idx * 25;
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = st[i];
+#pragma unroll
+    for (int round = 0; round < 24; round++) {
+        uint64_t cx[5], b[25];
+#pragma unroll
+        for (int x = 0; x < 5; x++) cx[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            uint64_t d = cx[(x + 4) % 5] ^ rotl64(cx[(x + 1) % 5], 1);
+#pragma unroll
+            for (int y = 0; y < 5; y++) a[x + 5 * y] ^= d;
+        }
+#pragma unroll
+        for (int x = 0; x < 5; x++)
+#pragma unroll
+            for (int y = 0; y < 5; y++) {
+                unsigned r = RHO[x + 5 * y];
+                uint64_t v = a[x + 5 * y];
+                b[y + 5 * ((2 * x + 3 * y) % 5)] = r ? rotl64(v, r) : v;
+            }
+#pragma unroll
+        for (int y = 0; y < 5; y++)
+#pragma unroll
+            for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        a[0] ^= RC[round];
+    }
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = a[i];
+}
+
+void zkm_launch_keccakf(zkm_ctx* c, uint64_t* states, size_t k) {
+    if (!k) return;
+    zkm_prof_scope ps(c, "keccakf");
+    hipLaunchKernelGGL(k_keccakf, dim3((k + 255) / 256), dim3(256), 0, c->stream, states, k);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ PoseidonStark witness (a13)
+__device__ __forceinline__ uint64_t splitmix_at(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + k * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// One row per lane; every column store is a contiguous wave access (column-major output).
+// Column map: poseidon/columns.rs:3-54 (FILTER 0, in 1..12, out 13..24, TIMESTAMP 25, full0 26.., partial 122.., full1 166..)
+__global__ __launch_bounds__(256) void k_poseidon_trace(uint64_t seed, size_t num_perms, size_t n, gl_t* __restrict__ out) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    bool real = r < num_perms;
+    uint64_t s[12];
+    gl_t* o = out + r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        s[i] = real ? gl_canon(splitmix_at(seed, r * 12 + i + 1)) : 0;
+        o[(1 + i) * n] = s[i];
+    }
+    o[0] = real ? 1 : 0;
+    o[25 * n] = 0;
+    int rc = 0;
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        int base = half == 0 ? 26 : 166;
+#pragma unroll 1
+        for (int rr = 0; rr < 4; rr++, rc++) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                uint64_t x = gl_add_loose(s[i], PC::ZKM_POSEIDON_RC[rc * 12 + i]);
+                gl_t x3 = gl_mul(gl_mul_loose(x, x), x);
+                gl_t x7 = gl_mul(x, gl_mul_loose(x3, x3));
+                o[(size_t)(base + 24 * rr + 2 * i) * n] = x3;
+                o[(size_t)(base + 24 * rr + 2 * i + 1) * n] = x7;
+                s[i] = x7;
+            }
+            poseidon_mds(s);
+        }
+        if (half == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) s[i] = gl_add_loose(s[i], PC::ZKM_POSEIDON_FAST_FIRST_RC[i]);
+            uint64_t t[12];
+            t[0] = s[0];
+#pragma unroll
+            for (int c = 1; c < 12; c++) {
+                uint64_t acc = 0;
+#pragma unroll
+                for (int q = 1; q < 12; q++) acc = gl_add_loose(acc, gl_mul_loose(s[q], PC::ZKM_POSEIDON_FAST_INIT[q - 1][c - 1]));
+                t[c] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < 12; i++) s[i] = t[i];
+#pragma unroll 1
+            for (int q = 0; q < 22; q++) {
+                uint64_t x = s[0];
+                gl_t x3 = gl_mul(gl_mul_loose(x, x), x);
+                gl_t x7 = gl_mul(x, gl_mul_loose(x3, x3));
+                o[(size_t)(122 + 2 * q) * n] = x3;
+                o[(size_t)(122 + 2 * q + 1) * n] = x7;
+                uint64_t s0 = gl_add_loose(x7, PC::ZKM_POSEIDON_FAST_RC[q]);
+                uint64_t d = gl_mul_loose(s0, 25);
+#pragma unroll
+                for (int i = 1; i < 12; i++) d = gl_add_loose(d, gl_mul_loose(s[i], PC::ZKM_POSEIDON_FAST_W_HATS[q][i - 1]));
+#pragma unroll
+                for (int i = 1; i < 12; i++) s[i] = gl_add_loose(s[i], gl_mul_loose(s0, PC::ZKM_POSEIDON_FAST_VS[q][i - 1]));
+                s[0] = d;
+            }
+            rc += 22;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) o[(size_t)(13 + i) * n] = gl_canon(s[i]);
+}
+
+void zkm_launch_poseidon_trace(zkm_ctx* c, uint64_t seed, size_t num_perms, unsigned log_n, gl_t* out) {
+    size_t n = (size_t)1 << log_n;
+    zkm_prof_scope ps(c, "poseidon_trace");
+    hipLaunchKernelGGL(k_poseidon_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, seed, num_perms, n, out);
+    ZKM_HIP_CHECK(hipGetLastError());
+}

@@ -1,0 +1,132 @@
+// zkm_internal.h -- shared host-side declarations of libzkmhip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/zkm_hip.h"
+#include "gl_dev.h"
+
+#define ZKM_HIP_CHECK(expr)                                                                                  \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                                     std::to_string(__LINE__) + ")");                                        \
+    } while (0)
+
+struct zkm_prof_rec {
+    const char* name;
+    hipEvent_t start, stop;
+};
+
+struct zkm_twiddles {
+    gl_t* fwd = nullptr;  // per-stage tables concatenated: entry (1<<s) + j = w_{2^(s+1)}^j, j < 2^s
+    gl_t* inv = nullptr;  // same with inverse roots
+    unsigned log_max = 0;
+};
+
+struct zkm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    // profiling
+    bool profiling = false;
+    std::vector<zkm_prof_rec> prof;
+    std::vector<hipEvent_t> event_pool;
+    struct agg { const char* name; uint64_t launches; double ms; };
+    std::vector<agg> prof_agg;
+    bool prof_agg_valid = false;
+    // caching allocator: exact-size free lists
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> live_blocks;
+    // twiddles
+    zkm_twiddles tw;
+    // power tables for coset scaling: key (shift, log_n) -> device ptr [lo table 2^h | hi table 2^(log_n-h)]
+    std::map<std::pair<uint64_t, unsigned>, gl_t*> pow_tables;
+    // pinned host staging
+    uint64_t* h_staging = nullptr;
+    size_t h_staging_words = 0;
+
+    void* alloc(size_t bytes);
+    void release(void* p);
+    void ensure_twiddles(unsigned log_n);
+    const gl_t* pow_table(uint64_t shift, unsigned log_n);  // lo: 2^ceil(log_n/2) entries, then hi
+    uint64_t* staging(size_t words);
+    hipEvent_t get_event();
+    void prof_begin(const char* name);
+    void prof_end();
+    void sync() { ZKM_HIP_CHECK(hipStreamSynchronize(stream)); }
+};
+
+// RAII profiling scope around one kernel launch (or a small group)
+struct zkm_prof_scope {
+    zkm_ctx* c;
+    zkm_prof_scope(zkm_ctx* ctx, const char* name) : c(ctx) {
+        if (c->profiling) c->prof_begin(name);
+    }
+    ~zkm_prof_scope() {
+        if (c->profiling) c->prof_end();
+    }
+};
+
+struct zkm_batch {
+    zkm_ctx* ctx = nullptr;
+    size_t ncols = 0;
+    unsigned log_n = 0, rate_bits = 0, cap_height = 0;
+    gl_t* coeffs = nullptr;   // ncols x n, natural order
+    gl_t* lde = nullptr;      // ncols x N, rows bit-reversed
+    gl_t* digests = nullptr;  // levels 0..top concatenated, 4 words per node
+    std::vector<size_t> level_off;  // word offsets
+    std::vector<uint64_t> cap;      // host copy, 4 << cap_height words
+    size_t n() const { return (size_t)1 << log_n; }
+    size_t N() const { return (size_t)1 << (log_n + rate_bits); }
+    unsigned lde_bits() const { return log_n + rate_bits; }
+    unsigned top() const { return lde_bits() - cap_height; }
+};
+
+inline bool zkm_is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+// ---- hash.hip
+void zkm_launch_poseidon_permute(zkm_ctx*, gl_t* states, size_t k);
+void zkm_launch_keccakf(zkm_ctx*, uint64_t* states, size_t k);
+// leaf digests of a column-major matrix (row j across ncols columns of stride `col_stride` words)
+void zkm_launch_merkle_leaves(zkm_ctx*, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests);
+// leaf digests of row-major leaves formed from F2 SoA arrays: leaf k = 16 consecutive (c0,c1) pairs
+void zkm_launch_merkle_leaves_ext(zkm_ctx*, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests);
+void zkm_launch_merkle_compress(zkm_ctx*, const gl_t* children, gl_t* parents, size_t nparents);
+void zkm_launch_poseidon_trace(zkm_ctx*, uint64_t seed, size_t num_perms, unsigned log_n, gl_t* out);
+// build all digest layers above level 0; fills level_off and returns total words needed (call with digests==nullptr to size)
+size_t zkm_merkle_layout(unsigned log_leaves, unsigned cap_height, std::vector<size_t>& level_off);
+void zkm_merkle_build_inner(zkm_ctx*, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height);
+
+// ---- ntt.hip
+// in-place, natural -> bit-reversed order, forward or inverse roots, no scaling
+void zkm_ntt_dif_bitrev(zkm_ctx*, gl_t* data, size_t ncols, size_t col_stride, unsigned log_n, bool inverse);
+// natural -> natural into `out` (may not alias `in`), using `in` as scratch (destroyed).
+//   inverse: out = iNTT(in) * shift^-i ; forward: out = NTT(in * shift^i)   (shift 0/1 = none)
+void zkm_ntt_natural(zkm_ctx*, gl_t* in_scratch, gl_t* out, size_t ncols, size_t col_stride_in, size_t col_stride_out,
+                     unsigned log_n, bool inverse, uint64_t shift);
+// out[c][i] = in[c][i] * shift^i for i < n_in, 0 for n_in <= i < n_out  (columns strided)
+void zkm_launch_scale_pad(zkm_ctx*, const gl_t* in, size_t col_stride_in, gl_t* out, size_t col_stride_out, size_t ncols,
+                          unsigned log_n_in, unsigned log_n_out, uint64_t shift);
+// coset LDE of natural-order coefficients into bit-reversed evaluations: out (ncols x 2^(log_n+rate_bits))
+void zkm_lde_bitrev(zkm_ctx*, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, unsigned rate_bits, uint64_t shift);
+
+// ---- core.hip
+void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values);
+void zkm_host_poseidon_permute(uint64_t st[12]);
