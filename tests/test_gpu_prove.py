@@ -1,0 +1,129 @@
+"""GPU parity: prove_single_table through the C ABI vs the CPU oracle (bit-exact proofs), and acceptance of
+GPU proofs by the oracle's verifier at sizes the oracle prover cannot reach in seconds."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+def fake_ctl_aux(n):
+    # poseidon_benchmark's fake CTL data (poseidon_stark.rs:786-799): zero helper column + zero Z, per challenge
+    return np.zeros(4 * n, dtype=np.uint64), [1, 1]
+
+
+@pytest.mark.parametrize("log_n", [5, 6, 9])
+def test_quotient_matches_oracle(ctx, zkm, oracle, log_n):
+    n = 1 << log_n
+    trace = oracle.poseidon_trace(11, n - 2, log_n)
+    rng = np.random.default_rng(log_n)
+    # non-trivial aux columns so the CTL terms are exercised (the quotient need not be a polynomial identity here)
+    aux = rng.integers(0, P, 4 * n, dtype=np.uint64)
+    tb = zkm.PolynomialBatch.from_values(ctx, trace, 262, log_n)
+    ab = zkm.PolynomialBatch.from_values(ctx, aux, 4, log_n)
+    otb, oab = oracle.batch_from_values(trace, 262, log_n), oracle.batch_from_values(aux, 4, log_n)
+    alphas = rng.integers(0, P, 2, dtype=np.uint64)
+    got = ctx.quotient(tb, ab, [1, 1], alphas)
+    want = oracle.quotient_poseidon(otb, oab, [1, 1], alphas)
+    assert (got == want).all()
+    # 3 helper columns on one Z, 1 challenge
+    aux5 = rng.integers(0, P, 4 * n, dtype=np.uint64)
+    ab5 = zkm.PolynomialBatch.from_values(ctx, aux5, 4, log_n)
+    got = ctx.quotient(tb, ab5, [3], alphas[:1])
+    want = oracle.quotient_poseidon(otb, oracle.batch_from_values(aux5, 4, log_n), [3], alphas[:1])
+    assert (got == want).all()
+    for b in (tb, ab, ab5):
+        b.free()
+
+
+def test_eval_openings(ctx, zkm, oracle):
+    rng = np.random.default_rng(5)
+    for log_n, ncols in ((3, 2), (8, 5), (15, 3)):
+        n = 1 << log_n
+        vals = rng.integers(0, P, ncols * n, dtype=np.uint64)
+        b = zkm.PolynomialBatch.from_coeffs(ctx, vals, ncols, log_n)
+        zeta = [int(x) for x in rng.integers(0, P, 2, dtype=np.uint64)]
+        got = ctx.eval_openings(b, zeta).reshape(ncols, 2)
+        # Horner in F2 = F[X]/(X^2 - 7) with python ints
+        for c in range(ncols):
+            a0 = a1 = 0
+            for k in range(n - 1, -1, -1):
+                a0, a1 = (a0 * zeta[0] + 7 * a1 * zeta[1] + int(vals[c * n + k])) % P, (a0 * zeta[1] + a1 * zeta[0]) % P
+            assert [int(got[c][0]), int(got[c][1])] == [a0, a1]
+        b.free()
+
+
+@pytest.mark.parametrize("log_n", [5, 7, 8, 10, 12])
+def test_proof_is_bit_exact(ctx, zkm, oracle, log_n):
+    n = 1 << log_n
+    trace = oracle.poseidon_trace(seed=log_n, num_perms=n - 5, log_n=log_n)
+    aux, nh = fake_ctl_aux(n)
+    want = oracle.prove(trace, log_n, aux, nh)
+    got = ctx.prove_single_table(trace, log_n, aux, nh)
+    assert got.size == want.size
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing proof word: %d" % bad[0]
+    assert oracle.verify(got, 4, nh) == 0
+
+
+def test_proof_with_existing_commitment_and_transcript(ctx, zkm, oracle):
+    log_n = 7
+    n = 1 << log_n
+    trace = oracle.poseidon_trace(9, n, log_n)
+    aux, nh = fake_ctl_aux(n)
+    och = oracle.challenger()
+    oracle.observe(och, [5, 6, 7])
+    want = oracle.prove(trace, log_n, aux, nh, challenger=och)
+    tb = zkm.PolynomialBatch.from_values(ctx, trace, 262, log_n)
+    ch = zkm.challenger_new()
+    zkm.challenger_observe(ch, [5, 6, 7])
+    got = ctx.prove_single_table(None, log_n, aux, nh, challenger=ch, trace_batch=tb)
+    assert (got == want).all()
+    assert list(ch.state) == list(och.state) and ch.n_in == och.n_in and ch.n_out == och.n_out
+    tb.free()
+
+
+def test_device_generated_trace_proof_verifies_2_16(ctx, zkm, oracle):
+    # config 1 size (2^16 rows): GPU witness + GPU proof, accepted by the oracle's verifier
+    log_n = 16
+    n = 1 << log_n
+    trace = ctx.poseidon_trace(1, n, log_n)
+    aux = ctx.alloc(4 * n).upload(np.zeros(4 * n, dtype=np.uint64))
+    proof = ctx.prove_single_table(trace, log_n, aux, [1, 1])
+    assert oracle.verify(proof, 4, [1, 1]) == 0
+    bad = proof.copy()
+    bad[2000] ^= 1
+    assert oracle.verify(bad, 4, [1, 1]) != 0
+    trace.free()
+    aux.free()
+
+
+def test_full_size_proof_verifies_2_20(ctx, zkm, oracle):
+    # BASELINE config 2 (2^20 rows x 262 columns): size-independent acceptance check
+    log_n = 20
+    n = 1 << log_n
+    trace = ctx.poseidon_trace(2, n, log_n)
+    aux = ctx.alloc(4 * n).upload(np.zeros(4 * n, dtype=np.uint64))
+    proof = ctx.prove_single_table(trace, log_n, aux, [1, 1])
+    assert oracle.verify(proof, 4, [1, 1]) == 0
+    trace.free()
+    aux.free()
+
+
+def test_invalid_witness_is_rejected(ctx, zkm, oracle):
+    log_n = 6
+    n = 1 << log_n
+    trace = oracle.poseidon_trace(4, n, log_n).copy()
+    trace[50 * n + 7] = (int(trace[50 * n + 7]) + 1) % P
+    aux, nh = fake_ctl_aux(n)
+    got = ctx.prove_single_table(trace, log_n, aux, nh)
+    assert (got == oracle.prove(trace, log_n, aux, nh)).all()  # same bytes as the oracle ...
+    assert oracle.verify(got, 4, nh) != 0                      # ... and rejected like the oracle's
+
+
+def test_bad_arguments(ctx, zkm):
+    n = 32
+    with pytest.raises(zkm.ZkmError):
+        ctx.prove_single_table(np.zeros(262 * n, dtype=np.uint64), 5, np.zeros(3 * n, dtype=np.uint64), [1, 1])
+    with pytest.raises(zkm.ZkmError):
+        ctx.prove_single_table(np.zeros(100 * n, dtype=np.uint64), 5, np.zeros(4 * n, dtype=np.uint64), [1, 1], ncols=100)

@@ -1,20 +1,806 @@
-// stark.hip -- prove_single_table on the GPU (quotient, openings, FRI).  (stage stubs: filled in next)
+// stark.hip -- prove_single_table on the GPU: quotient (K7-K9), openings (K10), FRI (K11-K14), queries.
+//
+// Host orchestration restates /root/reference/prover/src/prover.rs:441-641 (stage and transcript order);
+// the kernels replace the rayon loops of compute_quotient_polys (:700-782), StarkOpeningSet::new
+// (proof.rs:299-334) and plonky2's PolynomialBatch::prove_openings / fri_proof.
+// The Challenger stays on the host (a few hundred field elements per table); only caps, openings,
+// the final polynomial and the query openings cross PCIe.
+#include "poseidon_dev.h"
 #include "zkm_internal.h"
 
-static int fail_ni(char** err, const char* what) {
-    std::string msg = std::string(what) + ": not implemented yet";
-    if (err) { *err = (char*)malloc(msg.size() + 1); if (*err) memcpy(*err, msg.c_str(), msg.size() + 1); }
-    return 2;
+// ------------------------------------------------------------------ proof layout (include/zkm_hip.h)
+struct proof_layout {
+    unsigned log_n, lde_bits, L, cap;
+    size_t W, A, Q, Z, F, C, nq;
+    size_t o_init, o_caps, o_open, o_fri_caps, o_final, o_pow, o_queries, query_words, total;
+};
+
+// FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) (config.rs:25)
+static unsigned fri_num_layers(const zkm_stark_config* c, unsigned degree_bits) {
+    unsigned l = 0, d = degree_bits;
+    while (d > c->final_poly_bits && d + c->rate_bits - c->arity_bits >= c->cap_height) { d -= c->arity_bits; l++; }
+    return l;
 }
+
+static void make_layout(proof_layout& y, const zkm_stark_config* c, unsigned log_n, size_t W, size_t A, size_t Z) {
+    y.log_n = log_n; y.lde_bits = log_n + c->rate_bits; y.cap = c->cap_height;
+    y.W = W; y.A = A; y.Q = (size_t)c->num_challenges * 2; y.Z = Z;
+    y.L = fri_num_layers(c, log_n);
+    y.F = (size_t)1 << (log_n - y.L * c->arity_bits);
+    y.C = (size_t)1 << c->cap_height;
+    y.nq = c->num_queries;
+    size_t o = 16;
+    y.o_init = o; o += 12;
+    y.o_caps = o; o += 3 * y.C * 4;
+    y.o_open = o; o += 4 * W + 4 * A + Z + 2 * y.Q;
+    y.o_fri_caps = o; o += y.L * y.C * 4;
+    y.o_final = o; o += 2 * y.F;
+    y.o_pow = o; o += 1;
+    y.o_queries = o;
+    size_t sib0 = (size_t)(y.lde_bits - y.cap) * 4;
+    size_t q = (W + sib0) + (A + sib0) + (y.Q + sib0);
+    for (unsigned i = 0; i < y.L; i++)
+        q += 2 * ((size_t)1 << c->arity_bits) + (size_t)(y.lde_bits - c->arity_bits * (i + 1) - y.cap) * 4;
+    y.query_words = q;
+    y.total = o + q * y.nq;
+}
+
+// ------------------------------------------------------------------ K7: quotient evaluation, Poseidon table
+// Constraint order = alpha-power order (constraint_consumer.rs:57-62): table constraints
+// (poseidon_stark.rs:554-594), then CTL checks (cross_table_lookup.rs:1067-1118), vanishing_poly.rs:30-45.
+template <int NA>
+struct consumer_t {
+    gl_t alpha[NA], acc[NA];
+    gl_t z_last, l_first, l_last;
+    __device__ __forceinline__ void constraint(gl_t c) {
+#pragma unroll
+        for (int j = 0; j < NA; j++) acc[j] = gl_add(gl_mul(acc[j], alpha[j]), c);
+    }
+    __device__ __forceinline__ void transition(gl_t c) { constraint(gl_mul(c, z_last)); }
+    __device__ __forceinline__ void last_row(gl_t c) { constraint(gl_mul(c, l_last)); }
+    __device__ __forceinline__ void first_row(gl_t c) { constraint(gl_mul(c, l_first)); }
+};
+
+template <int NA>
+__device__ __forceinline__ void sbox_constraints(consumer_t<NA>& k, gl_t in, gl_t inter, gl_t out) {
+    k.constraint(gl_sub(gl_mul(gl_mul(in, in), in), inter));
+    k.constraint(gl_sub(gl_mul(gl_mul(in, inter), inter), out));
+}
+
+__device__ __forceinline__ void mds_canon(gl_t s[12]) {
+    poseidon_mds(s);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+}
+
+// lv(c) = trace LDE value of column c at this thread's row
+template <int NA>
+__device__ void eval_poseidon_constraints(const gl_t* __restrict__ lv, size_t cs, consumer_t<NA>& k) {
+    gl_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = lv[(size_t)(1 + i) * cs];
+    int rc = 0;
+#pragma unroll 1
+    for (int r = 0; r < 4; r++, rc++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            gl_t x = gl_add(s[i], gl_canon(PC::ZKM_POSEIDON_RC[rc * 12 + i]));
+            gl_t tmp = lv[(size_t)(26 + 24 * r + 2 * i) * cs], out = lv[(size_t)(26 + 24 * r + 2 * i + 1) * cs];
+            sbox_constraints(k, x, tmp, out);
+            s[i] = out;
+        }
+        mds_canon(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PC::ZKM_POSEIDON_FAST_FIRST_RC[i]);
+    {
+        gl_t t[12];
+        t[0] = s[0];
+#pragma unroll
+        for (int c = 1; c < 12; c++) {
+            uint64_t acc = 0;
+#pragma unroll
+            for (int r = 1; r < 12; r++) acc = gl_add_loose(acc, gl_mul_loose(s[r], PC::ZKM_POSEIDON_FAST_INIT[r - 1][c - 1]));
+            t[c] = gl_canon(acc);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = t[i];
+    }
+#pragma unroll 1
+    for (int r = 0; r < 22; r++) {
+        gl_t inter = lv[(size_t)(122 + 2 * r) * cs], out = lv[(size_t)(122 + 2 * r + 1) * cs];
+        sbox_constraints(k, s[0], inter, out);
+        gl_t s0 = r < 21 ? gl_add(out, PC::ZKM_POSEIDON_FAST_RC[r]) : out;
+        uint64_t d = gl_mul_loose(s0, 25);
+#pragma unroll
+        for (int i = 1; i < 12; i++) d = gl_add_loose(d, gl_mul_loose(s[i], PC::ZKM_POSEIDON_FAST_W_HATS[r][i - 1]));
+#pragma unroll
+        for (int i = 1; i < 12; i++) s[i] = gl_add(s[i], gl_mul(s0, PC::ZKM_POSEIDON_FAST_VS[r][i - 1]));
+        s[0] = gl_canon(d);
+    }
+    rc += 22;
+#pragma unroll 1
+    for (int r = 0; r < 4; r++, rc++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            gl_t x = gl_add(s[i], gl_canon(PC::ZKM_POSEIDON_RC[rc * 12 + i]));
+            gl_t tmp = lv[(size_t)(166 + 24 * r + 2 * i) * cs], out = lv[(size_t)(166 + 24 * r + 2 * i + 1) * cs];
+            sbox_constraints(k, x, tmp, out);
+            s[i] = out;
+        }
+        mds_canon(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) k.constraint(gl_sub(s[i], lv[(size_t)(13 + i) * cs]));
+}
+
+struct ctl_desc {
+    uint32_t nctl, total_helpers;
+    uint32_t num_helpers[16];
+};
+
+// One thread per point of the quotient domain g<w_2n>, visited in LDE storage order: storage row j < 2n
+// of the 4n-row LDE is natural quotient index i = bitrev_{L-1}(j) (every `step` = 2nd natural LDE row,
+// prover.rs:668-675); "next" is natural +2 in the 2n domain (prover.rs:704) = +4 in the 4n domain.
+template <int NA>
+__global__ __launch_bounds__(256) void k_quotient_poseidon(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux,
+                                                           unsigned log_n, unsigned lde_bits, ctl_desc ctl, const gl_t* alphas,
+                                                           const gl_t* __restrict__ wpow /* w_{4n}^t two-level table */,
+                                                           gl_t gn, gl_t zh_inv0, gl_t zh_inv1, gl_t last, gl_t w_n, gl_t n_inv,
+                                                           gl_t* __restrict__ out) {
+    size_t N = (size_t)1 << lde_bits;
+    size_t size = N >> 1;
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= size) return;
+    uint32_t t = bitrev32((uint32_t)j, lde_bits);  // natural index in the 4n domain (even)
+    uint32_t i = t >> 1;                           // natural index in the 2n quotient domain
+    uint32_t tn = (t + 4) & (uint32_t)(N - 1);
+    size_t jn = bitrev32(tn, lde_bits);
+
+    // x = g * w_{4n}^t
+    unsigned h = (lde_bits + 1) / 2;
+    gl_t x = gl_mul(GL_GENERATOR, gl_mul_loose(wpow[t & ((1u << h) - 1)], wpow[((size_t)1 << h) + (t >> h)]));
+    consumer_t<NA> k;
+#pragma unroll
+    for (int a = 0; a < NA; a++) { k.alpha[a] = alphas[a]; k.acc[a] = 0; }
+    k.z_last = gl_sub(x, last);
+    // Z_H(x) = x^n - 1 = g^n (-1)^i - 1;  L_first = Z_H / (n (x - 1)),  L_last = Z_H / (n (w x - 1))
+    gl_t zh = gl_sub((i & 1) ? gl_neg(gn) : gn, 1);
+    gl_t d0 = gl_sub(x, 1), d1 = gl_sub(gl_mul(w_n, x), 1);
+    gl_t dinv = gl_inv(gl_mul(d0, d1));
+    gl_t zn = gl_mul(zh, n_inv);
+    k.l_first = gl_mul(zn, gl_mul(dinv, d1));
+    k.l_last = gl_mul(zn, gl_mul(dinv, d0));
+
+    eval_poseidon_constraints<NA>(trace + j, N, k);
+
+    // CTL checks, helper-column shape (no column sets): cross_table_lookup.rs:1111-1118
+    uint32_t start = 0;
+    for (uint32_t c = 0; c < ctl.nctl; c++) {
+        gl_t h_sum = 0;
+        for (uint32_t q = 0; q < ctl.num_helpers[c]; q++) h_sum = gl_add(h_sum, aux[(size_t)(start + q) * N + j]);
+        gl_t local_z = aux[(size_t)(ctl.total_helpers + c) * N + j], next_z = aux[(size_t)(ctl.total_helpers + c) * N + jn];
+        k.last_row(gl_sub(local_z, h_sum));
+        k.transition(gl_sub(gl_sub(local_z, next_z), h_sum));
+        start += ctl.num_helpers[c];
+    }
+    gl_t zi = (i & 1) ? zh_inv1 : zh_inv0;
+#pragma unroll
+    for (int a = 0; a < NA; a++) out[(size_t)a * size + i] = gl_mul(k.acc[a], zi);
+}
+
+// quotient polys: d_out = nalphas x 2n natural-order coefficients (device)
+static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_batch* aux, const uint32_t* num_helpers,
+                            size_t nctl, const gl_t* alphas_host, size_t nalphas, gl_t* d_out) {
+    if (table_id != ZKM_TABLE_POSEIDON || trace->ncols != ZKM_POSEIDON_COLS)
+        throw std::runtime_error("zkm_quotient: only the Poseidon table (262 columns) has a constraint kernel");
+    if (trace->rate_bits != 2 || aux->rate_bits != 2 || trace->log_n != aux->log_n)
+        throw std::runtime_error("zkm_quotient: rate_bits must be 2 and the batches must have equal degree");
+    if (nalphas < 1 || nalphas > 2) throw std::runtime_error("zkm_quotient: 1 or 2 challenges supported");
+    if (nctl > 16) throw std::runtime_error("zkm_quotient: too many CTL Zs");
+    ctl_desc ctl{};
+    ctl.nctl = (uint32_t)nctl;
+    for (size_t i = 0; i < nctl; i++) {
+        if (num_helpers[i] == 0) throw std::runtime_error("zkm_quotient: CTLs without helper columns need column sets (not supported)");
+        ctl.num_helpers[i] = num_helpers[i];
+        ctl.total_helpers += num_helpers[i];
+    }
+    if (ctl.total_helpers + nctl != aux->ncols) throw std::runtime_error("zkm_quotient: aux column count does not match the CTL description");
+    unsigned log_n = trace->log_n, lde_bits = log_n + 2, log_q = log_n + 1;
+    size_t size = (size_t)1 << log_q;
+    gl_t w4 = gl_root_of_unity(lde_bits);
+    const gl_t* wpow = c->pow_table(w4, lde_bits);
+    gl_t gn = gl_exp_pow2(GL_GENERATOR, log_n);
+    gl_t zh0 = gl_inv(gl_sub(gn, 1)), zh1 = gl_inv(gl_sub(gl_neg(gn), 1));
+    gl_t w_n = gl_root_of_unity(log_n), last = gl_inv(w_n);
+    gl_t n_inv = gl_inv((gl_t)(((uint64_t)1 << log_n) % GL_P));
+    gl_t* d_alphas = (gl_t*)c->alloc(4 * sizeof(gl_t));
+    ZKM_HIP_CHECK(hipMemcpyAsync(d_alphas, alphas_host, nalphas * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+    gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
+    {
+        zkm_prof_scope ps(c, "quotient_poseidon");
+        dim3 grid((size + 255) / 256), block(256);
+        if (nalphas == 1)
+            hipLaunchKernelGGL(k_quotient_poseidon<1>, grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, ctl, d_alphas,
+                               wpow, gn, zh0, zh1, last, w_n, n_inv, d_vals);
+        else
+            hipLaunchKernelGGL(k_quotient_poseidon<2>, grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, ctl, d_alphas,
+                               wpow, gn, zh0, zh1, last, w_n, n_inv, d_vals);
+        ZKM_HIP_CHECK(hipGetLastError());
+    }
+    // coset_ifft(g) of each challenge's evaluations (prover.rs:784-788)
+    zkm_ntt_natural(c, d_vals, d_out, nalphas, size, size, log_q, true, GL_GENERATOR);
+    c->sync();  // d_alphas / d_vals are recycled below
+    c->release(d_vals);
+    c->release(d_alphas);
+}
+
+// ------------------------------------------------------------------ K10: openings
+// partial[col][chunk] = sum_{k in chunk} c_k z^(k - chunk_start) for z in {zeta, g*zeta}, plus the plain
+// sum (evaluation at 1).  Horner in z^256 per thread over a 256-strided slice, so loads are coalesced.
+#define OPEN_CHUNK_LOG 14
+__global__ __launch_bounds__(256) void k_open_partials(const gl_t* __restrict__ coeffs, unsigned log_n, gl2_t z0, gl2_t z1,
+                                                       gl_t* __restrict__ partial /* [col][chunk][5] */) {
+    __shared__ gl_t red[256 * 5];
+    unsigned chunk_log = log_n < OPEN_CHUNK_LOG ? log_n : OPEN_CHUNK_LOG;
+    size_t chunk_len = (size_t)1 << chunk_log, nchunks = (size_t)1 << (log_n - chunk_log);
+    size_t col = blockIdx.y, chunk = blockIdx.x;
+    const gl_t* p = coeffs + (col << log_n) + chunk * chunk_len;
+    unsigned t = threadIdx.x;
+    gl2_t w0 = gl2_pow(z0, 256), w1 = gl2_pow(z1, 256);
+    gl2_t a0{0, 0}, a1{0, 0};
+    gl_t sum = 0;
+    // elements t, t+256, ... : Horner from the top
+    for (size_t m = chunk_len >> 8; m-- > 0;) {
+        size_t idx = (m << 8) + t;
+        gl_t cv = idx < chunk_len ? p[idx] : 0;
+        a0 = gl2_mul(a0, w0); a0.c0 = gl_add(a0.c0, cv);
+        a1 = gl2_mul(a1, w1); a1.c0 = gl_add(a1.c0, cv);
+        sum = gl_add(sum, cv);
+    }
+    if (chunk_len < 256) {  // tiny polynomials: one element per thread at most
+        gl_t cv = t < chunk_len ? p[t] : 0;
+        a0 = gl2_t{cv, 0}; a1 = gl2_t{cv, 0}; sum = cv;
+    }
+    a0 = gl2_mul(a0, gl2_pow(z0, t));
+    a1 = gl2_mul(a1, gl2_pow(z1, t));
+    red[t * 5 + 0] = a0.c0; red[t * 5 + 1] = a0.c1; red[t * 5 + 2] = a1.c0; red[t * 5 + 3] = a1.c1; red[t * 5 + 4] = sum;
+    __syncthreads();
+    for (unsigned s = 128; s > 0; s >>= 1) {
+        if (t < s)
+            for (int q = 0; q < 5; q++) red[t * 5 + q] = gl_add(red[t * 5 + q], red[(t + s) * 5 + q]);
+        __syncthreads();
+    }
+    if (t < 5) partial[(col * nchunks + chunk) * 5 + t] = red[t];
+}
+
+struct open_vals { gl2_t at_z0, at_z1; gl_t at_one; };
+
+// evaluate every polynomial of the batch at z0, z1 (F2) and 1
+static std::vector<open_vals> eval_batch(zkm_ctx* c, const zkm_batch* b, gl2_t z0, gl2_t z1) {
+    unsigned log_n = b->log_n;
+    unsigned chunk_log = log_n < OPEN_CHUNK_LOG ? log_n : OPEN_CHUNK_LOG;
+    size_t nchunks = (size_t)1 << (log_n - chunk_log), words = b->ncols * nchunks * 5;
+    gl_t* d_part = (gl_t*)c->alloc(words * sizeof(gl_t));
+    {
+        zkm_prof_scope ps(c, "open_partials");
+        hipLaunchKernelGGL(k_open_partials, dim3(nchunks, b->ncols), dim3(256), 0, c->stream, b->coeffs, log_n, z0, z1, d_part);
+        ZKM_HIP_CHECK(hipGetLastError());
+    }
+    std::vector<gl_t> part(words);
+    ZKM_HIP_CHECK(hipMemcpyAsync(part.data(), d_part, words * sizeof(gl_t), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    c->release(d_part);
+    gl2_t s0 = gl2_pow(z0, (uint64_t)1 << chunk_log), s1 = gl2_pow(z1, (uint64_t)1 << chunk_log);
+    std::vector<open_vals> out(b->ncols);
+    for (size_t col = 0; col < b->ncols; col++) {
+        gl2_t a0{0, 0}, a1{0, 0};
+        gl_t sum = 0;
+        for (size_t ch = nchunks; ch-- > 0;) {
+            const gl_t* q = &part[(col * nchunks + ch) * 5];
+            a0 = gl2_add(gl2_mul(a0, s0), gl2_t{q[0], q[1]});
+            a1 = gl2_add(gl2_mul(a1, s1), gl2_t{q[2], q[3]});
+            sum = gl_add(sum, q[4]);
+        }
+        out[col] = open_vals{a0, a1, sum};
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------ K11: FRI batch combination
+// comp1 = sum_{j < W+A} alpha^j p_j (g*zeta batch), comp0 = comp1 + sum_q alpha^(W+A+q) quot_q (zeta batch),
+// comp2 = sum_k alpha^k ctl_z_k (batch at 1)   -- polynomial order of stark.rs:127-148.  One pass over all
+// coefficient polynomials; alpha powers are wave-uniform.
+__global__ __launch_bounds__(256) void k_fri_combine(const gl_t* __restrict__ tc, size_t W, const gl_t* __restrict__ ac, size_t A,
+                                                     const gl_t* __restrict__ qc, size_t Q, size_t ctl_start,
+                                                     const gl_t* __restrict__ apow /* [(W+A+Q)][2] */, size_t n,
+                                                     gl_t* __restrict__ comp /* [3][2][n] */) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gl_t a0 = 0, a1 = 0, z0 = 0, z1 = 0;
+    size_t j = 0;
+    for (size_t cidx = 0; cidx < W; cidx++, j++) {
+        gl_t v = tc[cidx * n + i];
+        a0 = gl_add(a0, gl_mul(v, apow[2 * j]));
+        a1 = gl_add(a1, gl_mul(v, apow[2 * j + 1]));
+    }
+    for (size_t cidx = 0; cidx < A; cidx++, j++) {
+        gl_t v = ac[cidx * n + i];
+        a0 = gl_add(a0, gl_mul(v, apow[2 * j]));
+        a1 = gl_add(a1, gl_mul(v, apow[2 * j + 1]));
+        if (cidx >= ctl_start) {
+            size_t k = cidx - ctl_start;
+            z0 = gl_add(z0, gl_mul(v, apow[2 * k]));
+            z1 = gl_add(z1, gl_mul(v, apow[2 * k + 1]));
+        }
+    }
+    comp[2 * n + i] = a0;
+    comp[3 * n + i] = a1;
+    for (size_t cidx = 0; cidx < Q; cidx++, j++) {
+        gl_t v = qc[cidx * n + i];
+        a0 = gl_add(a0, gl_mul(v, apow[2 * j]));
+        a1 = gl_add(a1, gl_mul(v, apow[2 * j + 1]));
+    }
+    comp[i] = a0;
+    comp[n + i] = a1;
+    comp[4 * n + i] = z0;
+    comp[5 * n + i] = z1;
+}
+
+// divide_by_linear as a hierarchical suffix scan with segments of 64:
+// totals:  out[s] = sum_{k<64} a[64 s + k] z^k
+__global__ void k_seg_totals(const gl_t* __restrict__ a0, const gl_t* __restrict__ a1, size_t m, gl2_t z, gl_t* __restrict__ o0,
+                             gl_t* __restrict__ o1) {
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t nseg = (m + 63) / 64;
+    if (s >= nseg) return;
+    gl2_t acc{0, 0};
+    size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
+    for (size_t k = end; k-- > s * 64;) acc = gl2_add(gl2_mul(acc, z), gl2_t{a0[k], a1[k]});
+    o0[s] = acc.c0;
+    o1[s] = acc.c1;
+}
+// scan:  S[k] = a[k] + z S[k+1] inside each segment, carry-in = upper[s+1] (0 past the end)
+// mode 0: store S;  mode 1 (bottom level): fin[k-1] = fin[k-1] * shift + S[k]  (the dropped remainder is S[0]),
+//         fin[m-1] = fin[m-1] * shift
+__global__ void k_seg_scan(const gl_t* __restrict__ a0, const gl_t* __restrict__ a1, size_t m, gl2_t z, const gl_t* __restrict__ u0,
+                           const gl_t* __restrict__ u1, size_t nupper, gl_t* __restrict__ s0, gl_t* __restrict__ s1, int mode,
+                           gl2_t shift) {
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t nseg = (m + 63) / 64;
+    if (s >= nseg) return;
+    gl2_t acc{0, 0};
+    if (u0 && s + 1 < nupper) acc = gl2_t{u0[s + 1], u1[s + 1]};
+    size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
+    if (mode == 1 && end == m) {
+        gl2_t f = gl2_mul(gl2_t{s0[m - 1], s1[m - 1]}, shift);
+        s0[m - 1] = f.c0;
+        s1[m - 1] = f.c1;
+    }
+    for (size_t k = end; k-- > s * 64;) {
+        acc = gl2_add(gl2_mul(acc, z), gl2_t{a0[k], a1[k]});
+        if (mode == 0) {
+            s0[k] = acc.c0;
+            s1[k] = acc.c1;
+        } else if (k > 0) {
+            gl2_t f = gl2_add(gl2_mul(gl2_t{s0[k - 1], s1[k - 1]}, shift), acc);
+            s0[k - 1] = f.c0;
+            s1[k - 1] = f.c1;
+        }
+    }
+}
+
+// fin = fin * shift + (comp(X) - comp(z)) / (X - z), re-padded to n coefficients
+static void divide_accumulate(zkm_ctx* c, const gl_t* a0, const gl_t* a1, size_t n, gl2_t z, gl2_t shift, gl_t* f0, gl_t* f1) {
+    // build the pyramid of totals
+    struct level { gl_t *t0, *t1; size_t m; gl2_t z; };
+    std::vector<level> lv;
+    lv.push_back(level{const_cast<gl_t*>(a0), const_cast<gl_t*>(a1), n, z});
+    zkm_prof_scope ps(c, "fri_divide_linear");
+    while (lv.back().m > 64) {
+        level& b = lv.back();
+        size_t nseg = (b.m + 63) / 64;
+        gl_t* t0 = (gl_t*)c->alloc(nseg * sizeof(gl_t));
+        gl_t* t1 = (gl_t*)c->alloc(nseg * sizeof(gl_t));
+        hipLaunchKernelGGL(k_seg_totals, dim3((nseg + 63) / 64), dim3(64), 0, c->stream, b.t0, b.t1, b.m, b.z, t0, t1);
+        lv.push_back(level{t0, t1, nseg, gl2_pow(b.z, 64)});
+    }
+    // top-down: suffix values of each level
+    std::vector<std::pair<gl_t*, gl_t*>> S(lv.size(), {nullptr, nullptr});
+    for (size_t l = lv.size(); l-- > 0;) {
+        level& b = lv[l];
+        size_t nseg = (b.m + 63) / 64;
+        const gl_t *u0 = nullptr, *u1 = nullptr;
+        size_t nupper = 0;
+        if (l + 1 < lv.size()) { u0 = S[l + 1].first; u1 = S[l + 1].second; nupper = lv[l + 1].m; }
+        if (l == 0) {
+            hipLaunchKernelGGL(k_seg_scan, dim3((nseg + 63) / 64), dim3(64), 0, c->stream, b.t0, b.t1, b.m, b.z, u0, u1, nupper, f0, f1, 1, shift);
+        } else {
+            S[l].first = (gl_t*)c->alloc(b.m * sizeof(gl_t));
+            S[l].second = (gl_t*)c->alloc(b.m * sizeof(gl_t));
+            hipLaunchKernelGGL(k_seg_scan, dim3((nseg + 63) / 64), dim3(64), 0, c->stream, b.t0, b.t1, b.m, b.z, u0, u1, nupper, S[l].first,
+                               S[l].second, 0, shift);
+        }
+    }
+    ZKM_HIP_CHECK(hipGetLastError());
+    c->sync();
+    for (size_t l = 1; l < lv.size(); l++) {
+        c->release(lv[l].t0); c->release(lv[l].t1);
+        c->release(S[l].first); c->release(S[l].second);
+    }
+}
+
+// ------------------------------------------------------------------ K13: FRI fold
+// c'_j = sum_{i < arity} beta^i c_{arity j + i}   (reduce_with_powers per chunk)
+__global__ __launch_bounds__(256) void k_fri_fold(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nout, unsigned arity,
+                                                  gl2_t beta, gl_t* __restrict__ o0, gl_t* __restrict__ o1) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nout) return;
+    gl2_t acc{0, 0};
+    for (unsigned i = arity; i-- > 0;) acc = gl2_add(gl2_mul(acc, beta), gl2_t{c0[j * arity + i], c1[j * arity + i]});
+    o0[j] = acc.c0;
+    o1[j] = acc.c1;
+}
+
+// ------------------------------------------------------------------ K14: proof of work
+// Smallest candidate w such that Poseidon(state with w written at `pos`)[7] has >= pow_bits leading zeros.
+struct pow_state { uint64_t s[12]; };
+__global__ __launch_bounds__(256) void k_pow_search(pow_state st, unsigned pos, unsigned pow_bits, uint64_t base, unsigned long long* best) {
+    uint64_t w = base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = st.s[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if ((unsigned)i == pos) s[i] = w;
+    poseidon_permute(s);
+    if ((s[7] >> (64 - pow_bits)) == 0) atomicMin(best, (unsigned long long)w);
+}
+
+// ------------------------------------------------------------------ query gather
+struct gather_oracle { const gl_t* lde; const gl_t* digests; uint32_t ncols, nsib; uint64_t N; uint64_t level_off[32]; };
+struct gather_layer { const gl_t *c0, *c1, *digests; uint32_t nsib; uint64_t level_off[32]; };
+struct gather_args {
+    gather_oracle o[3];
+    gather_layer l[8];
+    uint32_t nlayers, arity_bits;
+    uint64_t query_words;
+};
+__global__ void k_gather_queries(gather_args g, const uint64_t* __restrict__ xs, gl_t* __restrict__ out) {
+    uint64_t x = xs[blockIdx.x];
+    gl_t* o = out + (size_t)blockIdx.x * g.query_words;
+    for (int k = 0; k < 3; k++) {
+        const gather_oracle& r = g.o[k];
+        for (uint32_t c = threadIdx.x; c < r.ncols; c += blockDim.x) o[c] = r.lde[(size_t)c * r.N + x];
+        o += r.ncols;
+        for (uint32_t e = threadIdx.x; e < r.nsib * 4; e += blockDim.x) {
+            uint32_t lvl = e >> 2;
+            o[e] = r.digests[r.level_off[lvl] + 4 * ((x >> lvl) ^ 1) + (e & 3)];
+        }
+        o += r.nsib * 4;
+    }
+    uint32_t arity = 1u << g.arity_bits;
+    for (uint32_t l = 0; l < g.nlayers; l++) {
+        const gather_layer& r = g.l[l];
+        x >>= g.arity_bits;
+        for (uint32_t e = threadIdx.x; e < 2 * arity; e += blockDim.x) o[e] = (e & 1) ? r.c1[x * arity + (e >> 1)] : r.c0[x * arity + (e >> 1)];
+        o += 2 * arity;
+        for (uint32_t e = threadIdx.x; e < r.nsib * 4; e += blockDim.x) {
+            uint32_t lvl = e >> 2;
+            o[e] = r.digests[r.level_off[lvl] + 4 * ((x >> lvl) ^ 1) + (e & 3)];
+        }
+        o += r.nsib * 4;
+    }
+}
+
+// ------------------------------------------------------------------ host helpers
+static gl2_t challenger_get_ext(zkm_challenger* ch) {
+    gl_t a = zkm_challenger_get(ch), b = zkm_challenger_get(ch);
+    return gl2_t{a, b};
+}
+
+struct fri_layer {
+    gl_t* values = nullptr;   // [2][len] bit-reversed
+    gl_t* digests = nullptr;
+    std::vector<size_t> level_off;
+    size_t len = 0;
+    unsigned log_leaves = 0;
+};
+
+static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
+                               const zkm_batch* trace_batch, const uint64_t* aux, size_t A, const uint32_t* num_helpers, size_t Z,
+                               zkm_challenger* ch, uint64_t* proof) {
+    if (cfg->rate_bits != 2 || cfg->arity_bits < 2 || cfg->arity_bits > 6 || cfg->pow_bits == 0 || cfg->pow_bits > 32)
+        throw std::runtime_error("zkm_prove_single_table: unsupported FRI configuration");
+    proof_layout y;
+    make_layout(y, cfg, log_n, W, A, Z);
+    if (y.L > 8) throw std::runtime_error("too many FRI layers");
+    size_t n = (size_t)1 << log_n, N = (size_t)1 << y.lde_bits;
+    size_t total_helpers = 0;
+    for (size_t i = 0; i < Z; i++) total_helpers += num_helpers[i];
+    if (A == 0 || total_helpers + Z != A) throw std::runtime_error("No CTL? aux column count does not match the CTL description");  // prover.rs:509
+
+    memset(proof, 0, y.total * sizeof(uint64_t));
+    proof[0] = ZKM_PROOF_MAGIC; proof[1] = log_n; proof[2] = W; proof[3] = A; proof[4] = y.Q; proof[5] = Z; proof[6] = y.cap;
+    proof[7] = y.L; proof[8] = y.F; proof[9] = y.nq; proof[10] = cfg->rate_bits; proof[11] = cfg->arity_bits;
+
+    zkm_batch* own_trace = nullptr;
+    zkm_batch *ab = nullptr, *qb = nullptr;
+    std::vector<fri_layer> layers(y.L);
+    std::vector<void*> scratch;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        zkm_batch_free(own_trace);
+        zkm_batch_free(ab);
+        zkm_batch_free(qb);
+        for (auto& l : layers) { c->release(l.values); c->release(l.digests); }
+        for (void* p : scratch) c->release(p);
+    };
+    try {
+        const zkm_batch* tb = trace_batch;
+        if (!tb) {
+            own_trace = new zkm_batch();
+            own_trace->ctx = c; own_trace->ncols = W; own_trace->log_n = log_n; own_trace->rate_bits = cfg->rate_bits;
+            own_trace->cap_height = cfg->cap_height;
+            zkm_batch_build(own_trace, trace, true);
+            tb = own_trace;
+        }
+        if (tb->ncols != W || tb->log_n != log_n || tb->rate_bits != cfg->rate_bits || tb->cap_height != cfg->cap_height)
+            throw std::runtime_error("trace commitment does not match the table shape / config");
+
+        zkm_challenger_compact(ch, proof + y.o_init);  // :466
+        // auxiliary commitment :511-522
+        ab = new zkm_batch();
+        ab->ctx = c; ab->ncols = A; ab->log_n = log_n; ab->rate_bits = cfg->rate_bits; ab->cap_height = cfg->cap_height;
+        zkm_batch_build(ab, aux, true);
+        uint64_t* caps = proof + y.o_caps;
+        memcpy(caps, tb->cap.data(), y.C * 4 * 8);
+        memcpy(caps + y.C * 4, ab->cap.data(), y.C * 4 * 8);
+        zkm_challenger_observe(ch, caps + y.C * 4, y.C * 4);  // :525
+        gl_t alphas[4];
+        for (unsigned i = 0; i < cfg->num_challenges; i++) alphas[i] = zkm_challenger_get(ch);  // :527
+
+        // quotient :543-587
+        gl_t* d_quot = (gl_t*)c->alloc(cfg->num_challenges * 2 * n * sizeof(gl_t));
+        scratch.push_back(d_quot);
+        quotient_device(c, table_id, tb, ab, num_helpers, Z, alphas, cfg->num_challenges, d_quot);
+        qb = new zkm_batch();
+        qb->ctx = c; qb->ncols = y.Q; qb->log_n = log_n; qb->rate_bits = cfg->rate_bits; qb->cap_height = cfg->cap_height;
+        zkm_batch_build(qb, d_quot, false);  // chunks [q0_lo, q0_hi, q1_lo, q1_hi] == d_quot viewed as Q columns of n
+        memcpy(caps + 2 * y.C * 4, qb->cap.data(), y.C * 4 * 8);
+        zkm_challenger_observe(ch, caps + 2 * y.C * 4, y.C * 4);  // :589
+
+        gl2_t zeta = challenger_get_ext(ch);  // :591
+        gl_t g = gl_root_of_unity(log_n);
+        if (gl2_eq(gl2_exp_pow2(zeta, log_n), gl2_t{1, 0})) throw std::runtime_error("Opening point is in the subgroup.");  // :596-599
+        gl2_t zeta_next = gl2_scalar_mul(zeta, g);
+
+        // openings proof.rs:299-334
+        uint64_t* op = proof + y.o_open;
+        uint64_t *o_local = op, *o_next = op + 2 * W, *o_aux = op + 4 * W, *o_auxn = o_aux + 2 * A, *o_ctl = o_auxn + 2 * A, *o_quot = o_ctl + Z;
+        {
+            auto tv = eval_batch(c, tb, zeta, zeta_next);
+            for (size_t i = 0; i < W; i++) {
+                o_local[2 * i] = tv[i].at_z0.c0; o_local[2 * i + 1] = tv[i].at_z0.c1;
+                o_next[2 * i] = tv[i].at_z1.c0; o_next[2 * i + 1] = tv[i].at_z1.c1;
+            }
+            auto av = eval_batch(c, ab, zeta, zeta_next);
+            for (size_t i = 0; i < A; i++) {
+                o_aux[2 * i] = av[i].at_z0.c0; o_aux[2 * i + 1] = av[i].at_z0.c1;
+                o_auxn[2 * i] = av[i].at_z1.c0; o_auxn[2 * i + 1] = av[i].at_z1.c1;
+                if (i >= total_helpers) o_ctl[i - total_helpers] = av[i].at_one;
+            }
+            auto qv = eval_batch(c, qb, zeta, zeta_next);
+            for (size_t i = 0; i < y.Q; i++) { o_quot[2 * i] = qv[i].at_z0.c0; o_quot[2 * i + 1] = qv[i].at_z0.c1; }
+        }
+        // observe_openings(to_fri_openings) proof.rs:336-367
+        zkm_challenger_observe(ch, o_local, 2 * W);
+        zkm_challenger_observe(ch, o_aux, 2 * A);
+        zkm_challenger_observe(ch, o_quot, 2 * y.Q);
+        zkm_challenger_observe(ch, o_next, 2 * W);
+        zkm_challenger_observe(ch, o_auxn, 2 * A);
+        for (size_t i = 0; i < Z; i++) { uint64_t e[2] = {o_ctl[i], 0}; zkm_challenger_observe(ch, e, 2); }
+
+        // ---- prove_openings (App. A.8)
+        gl2_t alpha = challenger_get_ext(ch);
+        size_t np0 = W + A + y.Q, np1 = W + A, np2 = Z;
+        std::vector<gl_t> apow(2 * (np0 + 1));
+        {
+            gl2_t p{1, 0};
+            for (size_t j = 0; j <= np0; j++) { apow[2 * j] = p.c0; apow[2 * j + 1] = p.c1; p = gl2_mul(p, alpha); }
+        }
+        gl_t* d_apow = (gl_t*)c->alloc(apow.size() * sizeof(gl_t));
+        scratch.push_back(d_apow);
+        ZKM_HIP_CHECK(hipMemcpyAsync(d_apow, apow.data(), apow.size() * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+        gl_t* d_comp = (gl_t*)c->alloc(6 * n * sizeof(gl_t));
+        scratch.push_back(d_comp);
+        {
+            zkm_prof_scope ps(c, "fri_combine");
+            hipLaunchKernelGGL(k_fri_combine, dim3((n + 255) / 256), dim3(256), 0, c->stream, tb->coeffs, W, ab->coeffs, A, qb->coeffs, y.Q,
+                               total_helpers, d_apow, n, d_comp);
+            ZKM_HIP_CHECK(hipGetLastError());
+        }
+        gl_t* d_fin = (gl_t*)c->alloc(2 * n * sizeof(gl_t));  // final poly coefficients [2][n]
+        scratch.push_back(d_fin);
+        ZKM_HIP_CHECK(hipMemsetAsync(d_fin, 0, 2 * n * sizeof(gl_t), c->stream));
+        auto apow_at = [&](size_t j) { return gl2_t{apow[2 * j], apow[2 * j + 1]}; };
+        divide_accumulate(c, d_comp, d_comp + n, n, zeta, apow_at(np0), d_fin, d_fin + n);
+        divide_accumulate(c, d_comp + 2 * n, d_comp + 3 * n, n, zeta_next, apow_at(np1), d_fin, d_fin + n);
+        divide_accumulate(c, d_comp + 4 * n, d_comp + 5 * n, n, gl2_t{1, 0}, apow_at(np2), d_fin, d_fin + n);
+
+        // commit phase: coefficients stay in d_fin (length clen, implicitly zero-padded x4)
+        size_t clen = n;
+        unsigned clog = log_n;
+        gl_t shift = GL_GENERATOR;
+        unsigned arity = 1u << cfg->arity_bits;
+        gl_t* d_coef0 = d_fin;      // c0 array (clen)
+        gl_t* d_coef1 = d_fin + n;  // c1 array
+        for (unsigned l = 0; l < y.L; l++) {
+            fri_layer& fl = layers[l];
+            fl.len = clen << cfg->rate_bits;
+            fl.values = (gl_t*)c->alloc(2 * fl.len * sizeof(gl_t));
+            // values = coset_fft(shift) of the zero-padded coefficients, bit-reversed: two base-field columns
+            // (the two coefficient arrays are contiguous: [c0 | c1], column stride clen)
+            if (d_coef1 != d_coef0 + clen) throw std::runtime_error("internal: FRI coefficient arrays not contiguous");
+            zkm_lde_bitrev(c, d_coef0, fl.values, 2, clog, cfg->rate_bits, shift);
+            fl.log_leaves = clog + cfg->rate_bits - cfg->arity_bits;
+            size_t dwords = zkm_merkle_layout(fl.log_leaves, cfg->cap_height, fl.level_off);
+            fl.digests = (gl_t*)c->alloc(dwords * sizeof(gl_t));
+            zkm_launch_merkle_leaves_ext(c, fl.values, fl.values + fl.len, (size_t)1 << fl.log_leaves, arity, fl.digests);
+            zkm_merkle_build_inner(c, fl.digests, fl.level_off, fl.log_leaves, cfg->cap_height);
+            uint64_t* capo = proof + y.o_fri_caps + l * y.C * 4;
+            ZKM_HIP_CHECK(hipMemcpyAsync(capo, fl.digests + fl.level_off[fl.log_leaves - cfg->cap_height], y.C * 4 * 8, hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+            zkm_challenger_observe(ch, capo, y.C * 4);
+            gl2_t beta = challenger_get_ext(ch);
+            size_t nout = clen >> cfg->arity_bits;
+            gl_t* d_new = (gl_t*)c->alloc(2 * nout * sizeof(gl_t));
+            scratch.push_back(d_new);
+            {
+                zkm_prof_scope ps(c, "fri_fold");
+                hipLaunchKernelGGL(k_fri_fold, dim3((nout + 255) / 256), dim3(256), 0, c->stream, d_coef0, d_coef1, nout, arity, beta, d_new, d_new + nout);
+                ZKM_HIP_CHECK(hipGetLastError());
+            }
+            d_coef0 = d_new;
+            d_coef1 = d_new + nout;
+            clen = nout;
+            clog -= cfg->arity_bits;
+            shift = gl_pow(shift, arity);
+        }
+        if (clen != y.F) throw std::runtime_error("internal: final polynomial length mismatch");
+        {
+            std::vector<gl_t> f(2 * clen);
+            ZKM_HIP_CHECK(hipMemcpyAsync(f.data(), d_coef0, clen * 8, hipMemcpyDeviceToHost, c->stream));
+            ZKM_HIP_CHECK(hipMemcpyAsync(f.data() + clen, d_coef1, clen * 8, hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+            uint64_t* fp = proof + y.o_final;
+            for (size_t i = 0; i < clen; i++) { fp[2 * i] = f[i]; fp[2 * i + 1] = f[clen + i]; }
+            zkm_challenger_observe(ch, fp, 2 * clen);
+        }
+
+        // proof of work (App. A.9), smallest witness
+        {
+            pow_state st;
+            memcpy(st.s, ch->state, sizeof st.s);
+            for (uint32_t i = 0; i < ch->n_in; i++) st.s[i] = ch->in_buf[i];
+            unsigned long long* d_best = (unsigned long long*)c->alloc(8);
+            scratch.push_back(d_best);
+            unsigned long long best = ~0ULL;
+            const uint64_t span = (uint64_t)1 << 20;
+            for (uint64_t base = 0; best == ~0ULL; base += span) {
+                if (base > ((uint64_t)1 << 40)) throw std::runtime_error("Proof of work failed. This is highly unlikely!");
+                ZKM_HIP_CHECK(hipMemsetAsync(d_best, 0xff, 8, c->stream));
+                {
+                    zkm_prof_scope ps(c, "fri_pow_search");
+                    hipLaunchKernelGGL(k_pow_search, dim3(span / 256), dim3(256), 0, c->stream, st, ch->n_in, cfg->pow_bits, base, d_best);
+                    ZKM_HIP_CHECK(hipGetLastError());
+                }
+                ZKM_HIP_CHECK(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c->stream));
+                c->sync();
+            }
+            uint64_t w = best;
+            proof[y.o_pow] = w;
+            zkm_challenger_observe(ch, &w, 1);
+            uint64_t resp = zkm_challenger_get(ch);
+            if ((resp >> (64 - cfg->pow_bits)) != 0) throw std::runtime_error("internal: proof-of-work response check failed");
+        }
+
+        // query rounds
+        {
+            std::vector<uint64_t> xs(y.nq);
+            for (size_t q = 0; q < y.nq; q++) xs[q] = zkm_challenger_get(ch) % N;
+            uint64_t* d_xs = (uint64_t*)c->alloc(y.nq * 8);
+            scratch.push_back(d_xs);
+            ZKM_HIP_CHECK(hipMemcpyAsync(d_xs, xs.data(), y.nq * 8, hipMemcpyHostToDevice, c->stream));
+            gather_args ga{};
+            const zkm_batch* orc[3] = {tb, ab, qb};
+            for (int k = 0; k < 3; k++) {
+                ga.o[k].lde = orc[k]->lde; ga.o[k].digests = orc[k]->digests; ga.o[k].ncols = (uint32_t)orc[k]->ncols;
+                ga.o[k].nsib = y.lde_bits - y.cap; ga.o[k].N = N;
+                for (size_t i = 0; i < orc[k]->level_off.size() && i < 32; i++) ga.o[k].level_off[i] = orc[k]->level_off[i];
+            }
+            for (unsigned l = 0; l < y.L; l++) {
+                ga.l[l].c0 = layers[l].values; ga.l[l].c1 = layers[l].values + layers[l].len; ga.l[l].digests = layers[l].digests;
+                ga.l[l].nsib = layers[l].log_leaves - y.cap;
+                for (size_t i = 0; i < layers[l].level_off.size() && i < 32; i++) ga.l[l].level_off[i] = layers[l].level_off[i];
+            }
+            ga.nlayers = y.L; ga.arity_bits = cfg->arity_bits; ga.query_words = y.query_words;
+            gl_t* d_q = (gl_t*)c->alloc(y.nq * y.query_words * 8);
+            scratch.push_back(d_q);
+            {
+                zkm_prof_scope ps(c, "fri_gather_queries");
+                hipLaunchKernelGGL(k_gather_queries, dim3(y.nq), dim3(256), 0, c->stream, ga, d_xs, d_q);
+                ZKM_HIP_CHECK(hipGetLastError());
+            }
+            ZKM_HIP_CHECK(hipMemcpyAsync(proof + y.o_queries, d_q, y.nq * y.query_words * 8, hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+        }
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+    cleanup();
+}
+
+// ------------------------------------------------------------------ C ABI
+static int fail(char** err, const std::string& msg) {
+    if (err) {
+        *err = (char*)malloc(msg.size() + 1);
+        if (*err) memcpy(*err, msg.c_str(), msg.size() + 1);
+    }
+    return 1;
+}
+
 extern "C" {
-size_t zkm_proof_words(const zkm_stark_config*, unsigned, size_t, size_t, size_t) { return 0; }
-int zkm_prove_single_table(zkm_ctx*, int, const zkm_stark_config*, const uint64_t*, size_t, unsigned, const zkm_batch*,
-                           const uint64_t*, size_t, const uint32_t*, size_t, zkm_challenger*, uint64_t*, char** err) {
-    return fail_ni(err, "zkm_prove_single_table");
+
+size_t zkm_proof_words(const zkm_stark_config* cfg, unsigned log_n, size_t ncols, size_t naux, size_t nctl_zs) {
+    proof_layout y;
+    make_layout(y, cfg, log_n, ncols, naux, nctl_zs);
+    return y.total;
 }
-int zkm_quotient(zkm_ctx*, int, const zkm_batch*, const zkm_batch*, const uint32_t*, size_t, const uint64_t*, size_t, uint64_t*,
-                 char** err) {
-    return fail_ni(err, "zkm_quotient");
+
+int zkm_prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t ncols, unsigned log_n,
+                           const zkm_batch* trace_batch, const uint64_t* aux, size_t naux, const uint32_t* num_helpers, size_t nctl_zs,
+                           zkm_challenger* challenger, uint64_t* proof_out, char** err) {
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!trace && !trace_batch) throw std::runtime_error("zkm_prove_single_table: need trace values or a trace commitment");
+        prove_single_table(c, table_id, cfg, trace, ncols, log_n, trace_batch, aux, naux, num_helpers, nctl_zs, challenger, proof_out);
+    } catch (const std::exception& e) {
+        return fail(err, e.what());
+    }
+    return 0;
 }
-int zkm_eval_openings(zkm_ctx*, const zkm_batch*, const uint64_t*, uint64_t*, char** err) { return fail_ni(err, "zkm_eval_openings"); }
+
+int zkm_quotient(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_batch* aux, const uint32_t* num_helpers, size_t nctl_zs,
+                 const uint64_t* alphas, size_t nalphas, uint64_t* out_coeffs, char** err) {
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        size_t words = nalphas * 2 * trace->n();
+        bool dev = zkm_is_device_ptr(out_coeffs);
+        gl_t* d = dev ? out_coeffs : (gl_t*)c->alloc(words * 8);
+        quotient_device(c, table_id, trace, aux, num_helpers, nctl_zs, alphas, nalphas, d);
+        if (!dev) {
+            ZKM_HIP_CHECK(hipMemcpyAsync(out_coeffs, d, words * 8, hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+            c->release(d);
+        }
+    } catch (const std::exception& e) {
+        return fail(err, e.what());
+    }
+    return 0;
 }
+
+int zkm_eval_openings(zkm_ctx* c, const zkm_batch* b, const uint64_t zeta[2], uint64_t* out, char** err) {
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        gl2_t z{zeta[0], zeta[1]};
+        auto v = eval_batch(c, b, z, z);
+        for (size_t i = 0; i < b->ncols; i++) { out[2 * i] = v[i].at_z0.c0; out[2 * i + 1] = v[i].at_z0.c1; }
+    } catch (const std::exception& e) {
+        return fail(err, e.what());
+    }
+    return 0;
+}
+
+}  // extern "C"
