@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ 
 }
 
 void zkm_launch_merkle_leaves(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests) {
-    zkm_prof_scope ps(c, "merkle_leaves");
+    // rows of <= 4 elements are copied, not hashed (hash_or_noop): profile them under their own name
+    zkm_prof_scope ps(c, ncols <= 4 ? "merkle_leaves_copy" : "merkle_leaves");
     hipLaunchKernelGGL(k_merkle_leaves, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride,
                        digests);
     ZKM_HIP_CHECK(hipGetLastError());
