@@ -90,6 +90,7 @@ int zkm_ctx_create(int device, zkm_ctx** out, char** err) {
     hipDeviceProp_t prop;
     ZKM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
+    c->use_baseline_ntt = getenv("ZKM_BASELINE_NTT") != nullptr;  // A/B switch for profiling
     ZKM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     *out = c;
     ZKM_API_END(err)

@@ -63,6 +63,295 @@ __device__ __forceinline__ gl_t pow_lookup(const gl_t* __restrict__ tab, unsigne
     return gl_mul_loose(tab[i & (((size_t)1 << h) - 1)], tab[((size_t)1 << h) + (i >> h)]);
 }
 
+// ------------------------------------------------------------------ multi-stage LDS pass kernel
+// One launch performs S (3..8) consecutive radix-2 DIF stages of many length-2^S sub-transforms.
+// A workgroup owns a tile of R = 2^S "rows" (the butterfly dimension, element stride sa) x T "columns"
+// (independent sub-transforms, element stride sb); one of the two dimensions is contiguous in HBM and
+// the lanes of a wave run along it for every global access (T*8 B or R*8 B segments).  The tile is
+// staged in LDS ([R][T(+1)]); every thread keeps 8 rows in registers per round and does up to three
+// stages (12 butterflies) between LDS exchanges, with lanes along the T dimension (conflict-free
+// ds_read/write_b64).  Twiddles of all rounds live in registers and are reused for every polynomial
+// column the workgroup loops over, so twiddle traffic is amortised over `cpb` columns.
+//
+// In-place DIF leaves sub-transform outputs bit-reversed along the row dimension; storing LDS row a'
+// at output row bitrev(a') instead (rev_rows) yields natural order for free, which is how the
+// natural->natural transforms (values -> coefficients) avoid a separate permutation pass.
+struct ntt_pass_args {
+    const gl_t* in;
+    gl_t* out;
+    size_t cs_in, cs_out;
+    uint32_t ncols, cpb;
+    uint32_t log_T, tp, n_lo;
+    size_t bi_hi, bi_lo, bo_hi, bo_lo;
+    size_t sa_in, sb_in, sa_out, sb_out;
+    uint32_t in_contig_a, out_contig_a, rev_rows, m;
+    const gl_t* tw;
+    const gl_t* pre_tab;
+    uint32_t pre_log;
+    size_t n_in;
+    gl_t post_scale;
+    const gl_t* post_tab;
+    uint32_t post_log;
+};
+
+template <int S, int K>
+struct ntt_round {
+    static constexpr int st = S - 1 - 3 * K;           // top local stage handled by this round
+    static constexpr int q = st >= 2 ? st - 2 : 0;     // position of the 3 register-resident row bits
+    static constexpr int top = st - q;                 // highest j-bit that is a stage of this round
+    __device__ static __forceinline__ int row(int rg, int j) { return ((rg >> q) << (q + 3)) | (j << q) | (rg & ((1 << q) - 1)); }
+    __device__ static __forceinline__ void load_tw(gl_t (&w)[7], const gl_t* __restrict__ tw, int rg, uint32_t m, size_t i_low) {
+        const int rlow = rg & ((1 << q) - 1);
+#pragma unroll
+        for (int jb = 0; jb < 3; jb++) {
+            if (jb > top) continue;
+            const int sl = q + jb;  // local stage
+            const int base = jb == 2 ? 0 : (jb == 1 ? 4 : 6);
+#pragma unroll
+            for (int jl = 0; jl < (1 << jb); jl++) {
+                size_t amod = (size_t)(rlow | (jl << q));
+                w[base + jl] = tw[((size_t)1 << (sl + m)) + (amod << m) + i_low];
+            }
+        }
+    }
+    __device__ static __forceinline__ void bfly(gl_t& u, gl_t& v, gl_t w) {
+        gl_t t = gl_add(u, v);
+        v = gl_mul(gl_sub(u, v), w);
+        u = t;
+    }
+    __device__ static __forceinline__ void run(gl_t* lds, int tp, int b, int rg, const gl_t (&w)[7]) {
+        gl_t x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = lds[row(rg, j) * tp + b];
+        // sched_barrier keeps the compiler from interleaving all 12 butterflies (which costs >200 VGPRs)
+        if (top >= 2) {
+            bfly(x[0], x[4], w[0]); bfly(x[1], x[5], w[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            bfly(x[2], x[6], w[2]); bfly(x[3], x[7], w[3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (top >= 1) {
+            bfly(x[0], x[2], w[4]); bfly(x[1], x[3], w[5]);
+            __builtin_amdgcn_sched_barrier(0);
+            bfly(x[4], x[6], w[4]); bfly(x[5], x[7], w[5]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bfly(x[0], x[1], w[6]); bfly(x[2], x[3], w[6]);
+        __builtin_amdgcn_sched_barrier(0);
+        bfly(x[4], x[5], w[6]); bfly(x[6], x[7], w[6]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; j++) lds[row(rg, j) * tp + b] = x[j];
+    }
+};
+
+template <int S>
+__global__ __launch_bounds__(1024) void k_ntt_pass(ntt_pass_args p) {
+    extern __shared__ __attribute__((aligned(16))) gl_t lds[];
+    constexpr int R = 1 << S, NR = (S + 2) / 3;
+    const int logT = p.log_T, T = 1 << logT, tp = p.tp;
+    const int nthreads = (R >> 3) << logT;
+    const int tid = threadIdx.x;
+    const int b = tid & (T - 1), rg = tid >> logT;
+    const uint32_t tile = blockIdx.x, t_hi = tile / p.n_lo, t_lo = tile % p.n_lo;
+    const size_t base_in = (size_t)t_hi * p.bi_hi + (size_t)t_lo * p.bi_lo;
+    const size_t base_out = (size_t)t_hi * p.bo_hi + (size_t)t_lo * p.bo_lo;
+    const size_t i_low = p.m ? (((size_t)t_lo << logT) + b) : 0;
+
+    gl_t w0[7], w1[7], w2[7];
+    ntt_round<S, 0>::load_tw(w0, p.tw, rg, p.m, i_low);
+    if (NR > 1) ntt_round<S, (NR > 1 ? 1 : 0)>::load_tw(w1, p.tw, rg, p.m, i_low);
+    if (NR > 2) ntt_round<S, (NR > 2 ? 2 : 0)>::load_tw(w2, p.tw, rg, p.m, i_low);
+
+    const uint32_t col0 = blockIdx.y * p.cpb;
+    const uint32_t col1 = col0 + p.cpb < p.ncols ? col0 + p.cpb : p.ncols;
+    for (uint32_t col = col0; col < col1; col++) {
+        const gl_t* __restrict__ src = p.in + (size_t)col * p.cs_in;
+        gl_t* __restrict__ dst = p.out + (size_t)col * p.cs_out;
+#pragma unroll 4
+        for (int e = 0; e < 8; e++) {
+            int idx = tid + e * nthreads;
+            int a, bb;
+            if (p.in_contig_a) { a = idx & (R - 1); bb = idx >> S; } else { bb = idx & (T - 1); a = idx >> logT; }
+            size_t off = base_in + (size_t)a * p.sa_in + (size_t)bb * p.sb_in;
+            gl_t v = off < p.n_in ? src[off] : 0;
+            if (p.pre_tab) v = gl_mul(v, pow_lookup(p.pre_tab, p.pre_log, off));
+            lds[a * tp + bb] = v;
+        }
+        __syncthreads();
+        ntt_round<S, 0>::run(lds, tp, b, rg, w0);
+        __syncthreads();
+        if (NR > 1) {
+            ntt_round<S, (NR > 1 ? 1 : 0)>::run(lds, tp, b, rg, w1);
+            __syncthreads();
+        }
+        if (NR > 2) {
+            ntt_round<S, (NR > 2 ? 2 : 0)>::run(lds, tp, b, rg, w2);
+            __syncthreads();
+        }
+#pragma unroll 4
+        for (int e = 0; e < 8; e++) {
+            int idx = tid + e * nthreads;
+            int a, bb;
+            if (p.out_contig_a) { a = idx & (R - 1); bb = idx >> S; } else { bb = idx & (T - 1); a = idx >> logT; }
+            gl_t v = lds[a * tp + bb];
+            int a_out = p.rev_rows ? (int)bitrev32((uint32_t)a, S) : a;
+            size_t off = base_out + (size_t)a_out * p.sa_out + (size_t)bb * p.sb_out;
+            if (p.post_scale != 1) v = gl_mul(v, p.post_scale);
+            if (p.post_tab) v = gl_mul(v, pow_lookup(p.post_tab, p.post_log, off));
+            dst[off] = v;
+        }
+        __syncthreads();
+    }
+}
+
+struct ntt_plan {
+    int np;
+    int S[4];
+};
+static ntt_plan make_plan(unsigned L) {
+    ntt_plan pl{};
+    pl.np = (int)((L + 7) / 8);
+    int base = (int)L / pl.np, extra = (int)L % pl.np;
+    for (int i = 0; i < pl.np; i++) pl.S[i] = base + (i < extra ? 1 : 0);
+    return pl;
+}
+
+template <int S>
+static void launch_pass_t(zkm_ctx* c, const ntt_pass_args& a, size_t ntiles) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    int T = 1 << a.log_T;
+    size_t shmem = ((size_t)1 << S) * a.tp * sizeof(gl_t);
+    dim3 grid((unsigned)ntiles, (a.ncols + a.cpb - 1) / a.cpb), block((unsigned)(((1 << S) >> 3) * T));
+    hipLaunchKernelGGL(k_ntt_pass<S>, grid, block, shmem, c->stream, a);
+}
+
+static void launch_pass(zkm_ctx* c, int S, ntt_pass_args a, size_t ntiles, const char* name) {
+    // columns per workgroup: keep >= ~2048 workgroups in flight, amortise twiddle loads
+    size_t want = ((size_t)a.ncols * ntiles) / 2048;
+    a.cpb = (uint32_t)(want < 1 ? 1 : (want > 16 ? 16 : want));
+    if (a.cpb > a.ncols) a.cpb = a.ncols;
+    zkm_prof_scope ps(c, name);
+    switch (S) {
+        case 3: launch_pass_t<3>(c, a, ntiles); break;
+        case 4: launch_pass_t<4>(c, a, ntiles); break;
+        case 5: launch_pass_t<5>(c, a, ntiles); break;
+        case 6: launch_pass_t<6>(c, a, ntiles); break;
+        case 7: launch_pass_t<7>(c, a, ntiles); break;
+        case 8: launch_pass_t<8>(c, a, ntiles); break;
+        default: throw std::runtime_error("ntt pass: unsupported stage count");
+    }
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
+static uint32_t pick_log_T(int S, size_t bdim) {
+    uint32_t lt = 6;  // 64 lanes along the tile's column dimension
+    while (lt > 0 && (((size_t)1 << S) << lt) > 8192) lt--;
+    while (lt > 0 && ((size_t)1 << lt) > bdim) lt--;
+    return lt;
+}
+
+// natural -> bit-reversed, `np` passes over `out`; pass 1 reads `in` (zero-padded beyond n_in, optionally
+// scaled by shift^i), later passes are in place.
+static void ntt_dif_bitrev_fast(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* out, size_t cs_out, size_t ncols, unsigned L,
+                                bool inverse, size_t n_in, unsigned log_n_in, uint64_t shift) {
+    c->ensure_twiddles(L);
+    ntt_plan pl = make_plan(L);
+    const gl_t* tw = inverse ? c->tw.inv : c->tw.fwd;
+    unsigned m = L;
+    for (int p = 0; p < pl.np; p++) {
+        int S = pl.S[p];
+        m -= S;
+        ntt_pass_args a{};
+        a.in = p == 0 ? in : out; a.out = out;
+        a.cs_in = p == 0 ? cs_in : cs_out; a.cs_out = cs_out;
+        a.ncols = (uint32_t)ncols;
+        a.tw = tw; a.m = m; a.post_scale = 1; a.n_in = ~(size_t)0;
+        if (p == 0) {
+            a.n_in = n_in;
+            if (shift > 1) { a.pre_tab = c->pow_table(shift, log_n_in); a.pre_log = log_n_in; }
+        }
+        size_t ntiles;
+        if (m > 0) {  // strided pass: rows at stride 2^m, tile columns contiguous
+            a.log_T = pick_log_T(S, (size_t)1 << m);
+            a.tp = 1u << a.log_T;
+            a.n_lo = (uint32_t)(((size_t)1 << m) >> a.log_T);
+            a.bi_hi = a.bo_hi = (size_t)1 << (S + m);
+            a.bi_lo = a.bo_lo = (size_t)1 << a.log_T;
+            a.sa_in = a.sa_out = (size_t)1 << m; a.sb_in = a.sb_out = 1;
+            ntiles = ((size_t)1 << (L - S - m)) * a.n_lo;
+        } else {  // last pass: rows contiguous, tile columns = consecutive chunks of R
+            size_t nchunks = (size_t)1 << (L - S);
+            a.log_T = pick_log_T(S, nchunks);
+            a.tp = (1u << a.log_T) + 1;
+            a.n_lo = (uint32_t)(nchunks >> a.log_T);
+            a.bi_lo = a.bo_lo = ((size_t)1 << a.log_T) << S;
+            a.sa_in = a.sa_out = 1; a.sb_in = a.sb_out = (size_t)1 << S;
+            a.in_contig_a = a.out_contig_a = 1;
+            ntiles = a.n_lo;
+        }
+        launch_pass(c, S, a, ntiles, m > 0 ? "ntt_pass_strided" : "ntt_pass_contig");
+    }
+}
+
+// natural -> natural (np <= 3).  in may equal scratch.  forward: in * shift^i first; inverse: scaled by
+// n^-1 * shift^-k on the way out.
+static void ntt_natural_fast(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* scratch, size_t cs_s, gl_t* out, size_t cs_out,
+                             size_t ncols, unsigned L, bool inverse, uint64_t shift) {
+    c->ensure_twiddles(L);
+    ntt_plan pl = make_plan(L);
+    const gl_t* tw = inverse ? c->tw.inv : c->tw.fwd;
+    size_t n = (size_t)1 << L;
+    const gl_t* pre = (!inverse && shift > 1) ? c->pow_table(shift, L) : nullptr;
+    const gl_t* post = (inverse && shift > 1) ? c->pow_table(gl_inv(shift), L) : nullptr;
+    gl_t post_scale = inverse ? gl_inv((gl_t)(n % GL_P)) : 1;
+    int np = pl.np;
+    size_t N1 = (size_t)1 << pl.S[0];
+    unsigned m = L;
+    for (int p = 0; p < np; p++) {
+        int S = pl.S[p];
+        m -= S;
+        bool last = p == np - 1;
+        ntt_pass_args a{};
+        a.in = p == 0 ? in : scratch; a.cs_in = p == 0 ? cs_in : cs_s;
+        a.out = last ? out : scratch; a.cs_out = last ? cs_out : cs_s;
+        a.ncols = (uint32_t)ncols; a.tw = tw; a.m = m; a.post_scale = 1; a.n_in = ~(size_t)0; a.rev_rows = 1;
+        if (p == 0 && pre) { a.pre_tab = pre; a.pre_log = L; }
+        if (last) { a.post_scale = post_scale; a.post_tab = post; a.post_log = L; }
+        size_t ntiles;
+        if (!last) {
+            a.log_T = pick_log_T(S, (size_t)1 << m);
+            a.tp = 1u << a.log_T;
+            a.n_lo = (uint32_t)(((size_t)1 << m) >> a.log_T);
+            a.bi_hi = a.bo_hi = (size_t)1 << (S + m);
+            a.bi_lo = a.bo_lo = (size_t)1 << a.log_T;
+            a.sa_in = a.sa_out = (size_t)1 << m; a.sb_in = a.sb_out = 1;
+            ntiles = ((size_t)1 << (L - S - m)) * a.n_lo;
+        } else if (np == 1) {
+            a.log_T = 0; a.tp = 2; a.n_lo = 1;
+            a.sa_in = a.sa_out = 1; a.in_contig_a = a.out_contig_a = 1;
+            ntiles = 1;
+        } else {
+            // transposing last pass: rows = contiguous d_last, tile columns = consecutive k1 (stride n/N1),
+            // t_hi = middle digit (np == 3).  Output index k = k1 + N1*(k_mid + N_mid*k_last).
+            size_t Nl = (size_t)1 << S, M1 = n >> pl.S[0], Nmid = np == 3 ? (size_t)1 << pl.S[1] : 1;
+            a.log_T = pick_log_T(S, N1);
+            a.tp = (1u << a.log_T) + 1;
+            a.n_lo = (uint32_t)(N1 >> a.log_T);
+            a.bi_hi = Nl; a.bi_lo = ((size_t)1 << a.log_T) * M1;
+            a.sa_in = 1; a.sb_in = M1; a.in_contig_a = 1;
+            a.bo_hi = N1; a.bo_lo = (size_t)1 << a.log_T;
+            a.sa_out = N1 * Nmid; a.sb_out = 1; a.out_contig_a = 0;
+            ntiles = Nmid * a.n_lo;
+        }
+        launch_pass(c, S, a, ntiles, last ? "ntt_pass_transpose" : "ntt_pass_strided");
+    }
+}
+
 // ------------------------------------------------------------------ baseline radix-2 kernels
 // One global-memory DIF stage (span h = 2^s): used for the strides that do not fit one workgroup.
 __global__ __launch_bounds__(256) void k_dif_stage(gl_t* __restrict__ data, size_t col_stride, unsigned log_n, unsigned s,
@@ -179,6 +468,10 @@ void zkm_launch_scale_pad(zkm_ctx* c, const gl_t* in, size_t col_stride_in, gl_t
 
 void zkm_lde_bitrev(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, unsigned rate_bits, uint64_t shift) {
     size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    if (log_n + rate_bits >= 3 && !c->use_baseline_ntt) {
+        ntt_dif_bitrev_fast(c, coeffs, n, out, N, ncols, log_n + rate_bits, false, n, log_n, shift);
+        return;
+    }
     zkm_launch_scale_pad(c, coeffs, n, out, N, ncols, log_n, log_n + rate_bits, shift);
     zkm_ntt_dif_bitrev(c, out, ncols, N, log_n + rate_bits, false);
 }
@@ -186,6 +479,10 @@ void zkm_lde_bitrev(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t ncols, uns
 void zkm_ntt_natural(zkm_ctx* c, gl_t* in_scratch, gl_t* out, size_t ncols, size_t col_stride_in, size_t col_stride_out,
                      unsigned log_n, bool inverse, uint64_t shift) {
     size_t n = (size_t)1 << log_n, total = ncols << log_n;
+    if (log_n >= 3 && log_n <= 24 && !c->use_baseline_ntt) {
+        ntt_natural_fast(c, in_scratch, col_stride_in, in_scratch, col_stride_in, out, col_stride_out, ncols, log_n, inverse, shift);
+        return;
+    }
     if (!inverse && shift > 1) zkm_launch_scale_pad(c, in_scratch, col_stride_in, in_scratch, col_stride_in, ncols, log_n, log_n, shift);
     zkm_ntt_dif_bitrev(c, in_scratch, ncols, col_stride_in, log_n, inverse);
     gl_t scale = inverse ? gl_inv((gl_t)(n % GL_P)) : 1;

@@ -36,6 +36,7 @@ struct zkm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
+    bool use_baseline_ntt = false;  // A/B switch: radix-2 one-stage-per-launch kernels
     // profiling
     bool profiling = false;
     std::vector<zkm_prof_rec> prof;
