@@ -1,10 +1,19 @@
 // poseidon_dev.h -- Goldilocks Poseidon permutation (width 12, 4 + 22 + 4 rounds, x^7), device + host.
 //
 // Same function as the reference's in-tree permutation prover/src/poseidon/poseidon_stark.rs:51-95
-// (constant_layer :164-169, sbox_monomial :239-251, mds_layer :310-345, mds_partial_layer_init :392-404,
-// mds_partial_layer_fast :463-487), which is also plonky2 PoseidonHash's permutation (Merkle hasher,
-// Challenger).  One permutation per lane: the 12-word state lives in 24 VGPRs, round constants are
-// wave-uniform and come from the scalar (constant) cache.  No MFMA: this is 64-bit modular integer work.
+// (constant_layer :164-169, sbox_monomial :239-251, mds_layer :310-345), which is also plonky2
+// PoseidonHash's permutation (Merkle hasher, Challenger).  One permutation per lane: the 12-word state
+// lives in 24 VGPRs, round constants are wave-uniform and come from the scalar (constant) cache.
+// No MFMA: this is 64-bit modular integer work.
+//
+// Formulation.  On gfx950 a 32x32->64 multiply-add (v_mad_u64_u32) issues at nearly the rate of an add
+// (profiles/r01_ubench_valu_rates.txt), so the cost of a round is its instruction count, and a full
+// 64x64 modular multiply (4 mads + ~15 carry/reduction instructions) is ~25x the price of a multiply by
+// a 6-bit MDS entry.  The reference's "fast partial round" form (sparse matrices with 64-bit entries,
+// poseidon_stark.rs:463-487) therefore LOSES here: every partial round is done in the textbook form
+// -- s-box on lane 0, dense circulant MDS with 6-bit entries -- and the next round's constants are
+// folded into the MDS accumulators before the single reduction.  Algebraically identical, so outputs are
+// bit-exact (pinned by the plonky2 test vectors and by naive == fast in the oracle).
 //
 // The state is kept "loose" (any uint64 representing its residue) between rounds and canonicalised once
 // on exit -- see gl_dev.h for the overflow arguments of every loose primitive.
@@ -27,8 +36,10 @@ namespace pc_dev {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PC pc_dev
+#define POSEIDON_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define PC pc_host
+#define POSEIDON_SCHED_FENCE() ((void)0)
 #endif
 
 // x^7 on a loose value -> loose
@@ -39,11 +50,13 @@ GL_HD uint64_t poseidon_sbox7(uint64_t x) {
     return gl_mul_loose(x3, x4);
 }
 
-// Circulant MDS (first row CIRC = {17,15,41,16,2,28,13,13,39,18,34,20}, plus 8 on the (0,0) entry).
-// Each output is sum_i c_i * s[(i+r)%12] with c_i < 2^6: split every state word into 32-bit halves,
-// accumulate the halves in two 64-bit sums (each < 2^32 * 264 < 2^41), recombine to a 73-bit value and
-// reduce once.  Inputs loose, outputs loose.
-GL_HD void poseidon_mds(uint64_t s[12]) {
+// Circulant MDS (first row CIRC = {17,15,41,16,2,28,13,13,39,18,34,20}, plus 8 on the (0,0) entry):
+//   out[r] = sum_i CIRC[i] * s[(i+r)%12] + [r==0] 8 s[0] + add[r]
+// Each state word is split into 32-bit halves, the halves are accumulated in two 64-bit sums (each
+// < 2^32 * 264 < 2^41), recombined to a < 2^74 value, the additive constant (next round's constant) is
+// added to that value, and it is reduced once.  Inputs loose, outputs loose.
+template <bool ADD>
+GL_HD void poseidon_mds_add(uint64_t s[12], const uint64_t* add) {
     uint32_t lo[12], hi[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
@@ -66,53 +79,50 @@ GL_HD void poseidon_mds(uint64_t s[12]) {
         // value = al + ah * 2^32  (< 2^74): low 64 bits and the carry-out word
         uint64_t low = al + (ah << 32);
         uint64_t high = (ah >> 32) + (low < al ? 1 : 0);
-        s[r] = gl_reduce128(low, high);
-    }
-}
-
-GL_HD void poseidon_full_round(uint64_t s[12], int round) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add_loose(s[i], PC::ZKM_POSEIDON_RC[round * 12 + i]);
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = poseidon_sbox7(s[i]);
-    poseidon_mds(s);
-}
-
-GL_HD void poseidon_partial_rounds(uint64_t s[12]) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add_loose(s[i], PC::ZKM_POSEIDON_FAST_FIRST_RC[i]);
-    {
-        uint64_t t[12];
-        t[0] = s[0];
-#pragma unroll
-        for (int c = 1; c < 12; c++) {
-            uint64_t acc = 0;
-#pragma unroll
-            for (int r = 1; r < 12; r++) acc = gl_add_loose(acc, gl_mul_loose(s[r], PC::ZKM_POSEIDON_FAST_INIT[r - 1][c - 1]));
-            t[c] = acc;
+        if (ADD) {
+            uint64_t t = low + add[r];
+            high += t < low ? 1 : 0;
+            low = t;
         }
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = t[i];
-    }
-#pragma unroll 1
-    for (int r = 0; r < 22; r++) {
-        uint64_t s0 = gl_add_loose(poseidon_sbox7(s[0]), PC::ZKM_POSEIDON_FAST_RC[r]);
-        uint64_t d = gl_mul_loose(s0, 25);
-#pragma unroll
-        for (int i = 1; i < 12; i++) d = gl_add_loose(d, gl_mul_loose(s[i], PC::ZKM_POSEIDON_FAST_W_HATS[r][i - 1]));
-#pragma unroll
-        for (int i = 1; i < 12; i++) s[i] = gl_add_loose(s[i], gl_mul_loose(s0, PC::ZKM_POSEIDON_FAST_VS[r][i - 1]));
-        s[0] = d;
+        s[r] = gl_reduce128(low, high);
+        if ((r & 3) == 3) POSEIDON_SCHED_FENCE();
     }
 }
+GL_HD void poseidon_mds(uint64_t s[12]) { poseidon_mds_add<false>(s, nullptr); }
 
 // In: any uint64 words (loose).  Out: canonical.
 GL_HD void poseidon_permute(uint64_t s[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add_loose(s[i], PC::ZKM_POSEIDON_RC[i]);
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) poseidon_full_round(s, r);
-    poseidon_partial_rounds(s);
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            s[i] = poseidon_sbox7(s[i]);
+            if ((i & 1) == 1) POSEIDON_SCHED_FENCE();
+        }
+        poseidon_mds_add<true>(s, &PC::ZKM_POSEIDON_RC[(r + 1) * 12]);
+    }
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) poseidon_full_round(s, 26 + r);
+    for (int r = 4; r < 26; r++) {
+        s[0] = poseidon_sbox7(s[0]);
+        poseidon_mds_add<true>(s, &PC::ZKM_POSEIDON_RC[(r + 1) * 12]);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 29; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            s[i] = poseidon_sbox7(s[i]);
+            if ((i & 1) == 1) POSEIDON_SCHED_FENCE();
+        }
+        poseidon_mds_add<true>(s, &PC::ZKM_POSEIDON_RC[(r + 1) * 12]);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        s[i] = poseidon_sbox7(s[i]);
+        if ((i & 1) == 1) POSEIDON_SCHED_FENCE();
+    }
+    poseidon_mds(s);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
