@@ -1,0 +1,19 @@
+#!/bin/bash
+# tools/collect_pmc.sh <tag> -- rocprofv3 profile runs of the bench workload (run on the GPU box via gpurun).
+# Pass 1: kernel trace + stats.  Passes 2..: PMC counters, each in its own run with no trace domains
+# (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950; see MI355X_MICROARCH.md).
+set -u
+TAG=${1:-r01}
+R=$PWD
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE"; do
+  N=$(echo $C | tr ' ' '_')
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- $CMD > $OUT/pmc_$N.log 2>&1
+done
+cd $R
+python tools/summarize_pmc.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
