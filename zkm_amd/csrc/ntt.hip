@@ -119,11 +119,9 @@ struct ntt_round {
         v = gl_mul(gl_sub(u, v), w);
         u = t;
     }
-    __device__ static __forceinline__ void run(gl_t* lds, int tp, int b, int rg, const gl_t (&w)[7]) {
-        gl_t x[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = lds[row(rg, j) * tp + b];
-        // sched_barrier keeps the compiler from interleaving all 12 butterflies (which costs >200 VGPRs)
+    // up to three DIF stages on the 8 register-resident rows; sched_barrier keeps the compiler from
+    // interleaving all 12 butterflies (which costs >200 VGPRs)
+    __device__ static __forceinline__ void compute(gl_t (&x)[8], const gl_t (&w)[7]) {
         if (top >= 2) {
             bfly(x[0], x[4], w[0]); bfly(x[1], x[5], w[1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -140,15 +138,33 @@ struct ntt_round {
         __builtin_amdgcn_sched_barrier(0);
         bfly(x[4], x[5], w[6]); bfly(x[6], x[7], w[6]);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ static __forceinline__ void lds_read(const gl_t* lds, int tp, int b, int rg, gl_t (&x)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = lds[row(rg, j) * tp + b];
+    }
+    __device__ static __forceinline__ void lds_write(gl_t* lds, int tp, int b, int rg, const gl_t (&x)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; j++) lds[row(rg, j) * tp + b] = x[j];
     }
 };
 
-template <int S>
+// IN_A / OUT_A: the butterfly (row) dimension is the contiguous one in HBM on the input / output side.
+// When it is not, the thread's 8 register-resident rows of the first (last) round are exactly what it
+// loads (stores) -- T*8 B contiguous per row across the wave -- so the tile never passes through LDS on
+// that side; LDS is then only the exchange buffer between rounds.
+// PRE / POST: 0 = never, 1 = always, 2 = decided at run time (keeps the scale paths out of the register
+// allocation of the hot variants)
+template <int S, bool IN_A, bool OUT_A, int PRE, int POST>
 __global__ __launch_bounds__(1024) void k_ntt_pass(ntt_pass_args p) {
     extern __shared__ __attribute__((aligned(16))) gl_t lds[];
     constexpr int R = 1 << S, NR = (S + 2) / 3;
+    using R0 = ntt_round<S, 0>;
+    using R1 = ntt_round<S, (NR > 1 ? 1 : 0)>;
+    using R2 = ntt_round<S, (NR > 2 ? 2 : 0)>;
+    using RL = ntt_round<S, NR - 1>;  // last round: q == 0, rows (rg << 3) | j
+    const bool do_pre = PRE == 1 || (PRE == 2 && p.pre_tab != nullptr);
+    const bool do_post = POST == 1 || (POST == 2 && (p.post_scale != 1 || p.post_tab != nullptr));
     const int logT = p.log_T, T = 1 << logT, tp = p.tp;
     const int nthreads = (R >> 3) << logT;
     const int tid = threadIdx.x;
@@ -159,49 +175,98 @@ __global__ __launch_bounds__(1024) void k_ntt_pass(ntt_pass_args p) {
     const size_t i_low = p.m ? (((size_t)t_lo << logT) + b) : 0;
 
     gl_t w0[7], w1[7], w2[7];
-    ntt_round<S, 0>::load_tw(w0, p.tw, rg, p.m, i_low);
-    if (NR > 1) ntt_round<S, (NR > 1 ? 1 : 0)>::load_tw(w1, p.tw, rg, p.m, i_low);
-    if (NR > 2) ntt_round<S, (NR > 2 ? 2 : 0)>::load_tw(w2, p.tw, rg, p.m, i_low);
+    R0::load_tw(w0, p.tw, rg, p.m, i_low);
+    if (NR > 1) R1::load_tw(w1, p.tw, rg, p.m, i_low);
+    if (NR > 2) R2::load_tw(w2, p.tw, rg, p.m, i_low);
+
+    // column-independent offsets
+    // direct input: rows rg + j*(R/8) (== R0::row(rg, j)), column b
+    // (32-bit element offsets: a column holds < 2^29 elements, so the wave-uniform column base stays scalar)
+    const uint32_t in0 = (uint32_t)(base_in + (size_t)rg * p.sa_in + (size_t)b * p.sb_in), in_step = (uint32_t)((size_t)(R >> 3) * p.sa_in);
+    // direct output: rows of the last round, optionally bit-reversed: bitrev((rg<<3)|j) = brev3(j)*(R/8) + bitrev(rg, S-3)
+    const uint32_t out0 = (uint32_t)(base_out + (size_t)(p.rev_rows ? bitrev32((uint32_t)rg, S - 3) : (uint32_t)(rg << 3)) * p.sa_out + (size_t)b * p.sb_out);
+    const uint32_t out_step = (uint32_t)(p.rev_rows ? (size_t)(R >> 3) * p.sa_out : p.sa_out);
 
     const uint32_t col0 = blockIdx.y * p.cpb;
     const uint32_t col1 = col0 + p.cpb < p.ncols ? col0 + p.cpb : p.ncols;
     for (uint32_t col = col0; col < col1; col++) {
         const gl_t* __restrict__ src = p.in + (size_t)col * p.cs_in;
         gl_t* __restrict__ dst = p.out + (size_t)col * p.cs_out;
-#pragma unroll 4
-        for (int e = 0; e < 8; e++) {
-            int idx = tid + e * nthreads;
-            int a, bb;
-            if (p.in_contig_a) { a = idx & (R - 1); bb = idx >> S; } else { bb = idx & (T - 1); a = idx >> logT; }
-            size_t off = base_in + (size_t)a * p.sa_in + (size_t)bb * p.sb_in;
-            gl_t v = off < p.n_in ? src[off] : 0;
-            if (p.pre_tab) v = gl_mul(v, pow_lookup(p.pre_tab, p.pre_log, off));
-            lds[a * tp + bb] = v;
-        }
-        __syncthreads();
-        ntt_round<S, 0>::run(lds, tp, b, rg, w0);
-        __syncthreads();
-        if (NR > 1) {
-            ntt_round<S, (NR > 1 ? 1 : 0)>::run(lds, tp, b, rg, w1);
+        gl_t x[8];
+        if (!IN_A) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint32_t off = in0 + (uint32_t)j * in_step;
+                x[j] = off < p.n_in ? src[off] : 0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_pre) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    x[j] = gl_mul(x[j], pow_lookup(p.pre_tab, p.pre_log, in0 + (uint32_t)j * in_step));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            // transposed staging: lanes run along the contiguous row dimension
+#pragma unroll 2
+            for (int e = 0; e < 8; e++) {
+                int idx = tid + e * nthreads;
+                int a = idx & (R - 1), bb = idx >> S;
+                size_t off = base_in + (size_t)a * p.sa_in + (size_t)bb * p.sb_in;
+                gl_t v = off < p.n_in ? src[off] : 0;
+                if (do_pre) v = gl_mul(v, pow_lookup(p.pre_tab, p.pre_log, off));
+                lds[a * tp + bb] = v;
+            }
             __syncthreads();
+            R0::lds_read(lds, tp, b, rg, x);
+        }
+        R0::compute(x, w0);
+        if (NR > 1) {
+            R0::lds_write(lds, tp, b, rg, x);
+            __syncthreads();
+            R1::lds_read(lds, tp, b, rg, x);
+            R1::compute(x, w1);
         }
         if (NR > 2) {
-            ntt_round<S, (NR > 2 ? 2 : 0)>::run(lds, tp, b, rg, w2);
+            R1::lds_write(lds, tp, b, rg, x);
             __syncthreads();
+            R2::lds_read(lds, tp, b, rg, x);
+            R2::compute(x, w2);
         }
-#pragma unroll 4
-        for (int e = 0; e < 8; e++) {
-            int idx = tid + e * nthreads;
-            int a, bb;
-            if (p.out_contig_a) { a = idx & (R - 1); bb = idx >> S; } else { bb = idx & (T - 1); a = idx >> logT; }
-            gl_t v = lds[a * tp + bb];
-            int a_out = p.rev_rows ? (int)bitrev32((uint32_t)a, S) : a;
-            size_t off = base_out + (size_t)a_out * p.sa_out + (size_t)bb * p.sb_out;
-            if (p.post_scale != 1) v = gl_mul(v, p.post_scale);
-            if (p.post_tab) v = gl_mul(v, pow_lookup(p.post_tab, p.post_log, off));
-            dst[off] = v;
+        if (!OUT_A) {
+            if (do_post) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int jj = p.rev_rows ? (int)(((j & 1) << 2) | (j & 2) | ((j >> 2) & 1)) : j;
+                    if (p.post_scale != 1) x[j] = gl_mul(x[j], p.post_scale);
+                    if (p.post_tab) x[j] = gl_mul(x[j], pow_lookup(p.post_tab, p.post_log, out0 + (uint32_t)jj * out_step));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int jj = p.rev_rows ? (int)(((j & 1) << 2) | (j & 2) | ((j >> 2) & 1)) : j;
+                dst[out0 + (uint32_t)jj * out_step] = x[j];
+            }
+        } else {
+            RL::lds_write(lds, tp, b, rg, x);
+            __syncthreads();
+#pragma unroll 2
+            for (int e = 0; e < 8; e++) {
+                int idx = tid + e * nthreads;
+                int a = idx & (R - 1), bb = idx >> S;
+                gl_t v = lds[a * tp + bb];
+                int a_out = p.rev_rows ? (int)bitrev32((uint32_t)a, S) : a;
+                size_t off = base_out + (size_t)a_out * p.sa_out + (size_t)bb * p.sb_out;
+                if (do_post) {
+                    if (p.post_scale != 1) v = gl_mul(v, p.post_scale);
+                    if (p.post_tab) v = gl_mul(v, pow_lookup(p.post_tab, p.post_log, off));
+                }
+                dst[off] = v;
+            }
         }
-        __syncthreads();
+        if (IN_A || OUT_A || NR > 1) __syncthreads();  // LDS is reused by the next column
     }
 }
 
@@ -217,17 +282,35 @@ static ntt_plan make_plan(unsigned L) {
     return pl;
 }
 
-template <int S>
+template <int S, bool IN_A, bool OUT_A, int PRE, int POST>
 static void launch_pass_t(zkm_ctx* c, const ntt_pass_args& a, size_t ntiles) {
     static bool attr_done = false;
     if (!attr_done) {
-        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass<S, IN_A, OUT_A, PRE, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     int T = 1 << a.log_T;
     size_t shmem = ((size_t)1 << S) * a.tp * sizeof(gl_t);
     dim3 grid((unsigned)ntiles, (a.ncols + a.cpb - 1) / a.cpb), block((unsigned)(((1 << S) >> 3) * T));
-    hipLaunchKernelGGL(k_ntt_pass<S>, grid, block, shmem, c->stream, a);
+    hipLaunchKernelGGL((k_ntt_pass<S, IN_A, OUT_A, PRE, POST>), grid, block, shmem, c->stream, a);
+}
+
+template <int S>
+static void launch_pass_s(zkm_ctx* c, const ntt_pass_args& a, size_t ntiles) {
+    const bool pre = a.pre_tab != nullptr, post = a.post_scale != 1 || a.post_tab != nullptr;
+    if (!a.in_contig_a && !a.out_contig_a) {
+        if (post) throw std::runtime_error("ntt pass: strided pass cannot post-scale");
+        if (pre) launch_pass_t<S, false, false, 1, 0>(c, a, ntiles);
+        else launch_pass_t<S, false, false, 0, 0>(c, a, ntiles);
+    } else if (a.in_contig_a && a.out_contig_a) {
+        launch_pass_t<S, true, true, 2, 2>(c, a, ntiles);
+    } else if (a.in_contig_a && !a.out_contig_a) {
+        if (pre) throw std::runtime_error("ntt pass: transposing pass cannot pre-scale");
+        if (post) launch_pass_t<S, true, false, 0, 1>(c, a, ntiles);
+        else launch_pass_t<S, true, false, 0, 0>(c, a, ntiles);
+    } else {
+        throw std::runtime_error("ntt pass: unsupported layout combination");
+    }
 }
 
 static void launch_pass(zkm_ctx* c, int S, ntt_pass_args a, size_t ntiles, const char* name) {
@@ -237,20 +320,29 @@ static void launch_pass(zkm_ctx* c, int S, ntt_pass_args a, size_t ntiles, const
     if (a.cpb > a.ncols) a.cpb = a.ncols;
     zkm_prof_scope ps(c, name);
     switch (S) {
-        case 3: launch_pass_t<3>(c, a, ntiles); break;
-        case 4: launch_pass_t<4>(c, a, ntiles); break;
-        case 5: launch_pass_t<5>(c, a, ntiles); break;
-        case 6: launch_pass_t<6>(c, a, ntiles); break;
-        case 7: launch_pass_t<7>(c, a, ntiles); break;
-        case 8: launch_pass_t<8>(c, a, ntiles); break;
+        case 3: launch_pass_s<3>(c, a, ntiles); break;
+        case 4: launch_pass_s<4>(c, a, ntiles); break;
+        case 5: launch_pass_s<5>(c, a, ntiles); break;
+        case 6: launch_pass_s<6>(c, a, ntiles); break;
+        case 7: launch_pass_s<7>(c, a, ntiles); break;
+        case 8: launch_pass_s<8>(c, a, ntiles); break;
         default: throw std::runtime_error("ntt pass: unsupported stage count");
     }
     ZKM_HIP_CHECK(hipGetLastError());
 }
 
+static size_t ntt_max_tile_elems() {
+    static size_t v = 0;
+    if (!v) {
+        const char* e = getenv("ZKM_NTT_TILE");  // tuning knob: elements per workgroup tile (threads = tile / 8)
+        v = e ? (size_t)atol(e) : 2048;
+        if (v < 512 || v > 8192) v = 8192;
+    }
+    return v;
+}
 static uint32_t pick_log_T(int S, size_t bdim) {
     uint32_t lt = 6;  // 64 lanes along the tile's column dimension
-    while (lt > 0 && (((size_t)1 << S) << lt) > 8192) lt--;
+    while (lt > 0 && (((size_t)1 << S) << lt) > ntt_max_tile_elems()) lt--;
     while (lt > 0 && ((size_t)1 << lt) > bdim) lt--;
     return lt;
 }
