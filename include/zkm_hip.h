@@ -131,6 +131,66 @@ int zkm_prove_single_table(zkm_ctx* ctx, int table_id, const zkm_stark_config* c
                            const uint32_t* num_helpers, size_t nctl_zs, zkm_challenger* challenger, uint64_t* proof_out,
                            char** err);
 
+
+/* ------------------------------------------------------------------ a3/a7: cross-table lookups, data-driven
+ * Column / Filter / TableWithColumns / CrossTableLookup (prover/src/cross_table_lookup.rs:31-415) restated as
+ * plain arrays so that the same description drives CTL data generation (a3), the CTL constraint checks inside
+ * the quotient kernel (a7) and the verifier. */
+typedef struct {            /* Column<F>: sum_k coeff_k*local[col_k] + sum_k coeff_k*next[col_k] + constant */
+    uint32_t n_local, n_next, term_off, _pad;   /* terms [term_off, +n_local) are local, the next n_next are next-row */
+    uint64_t constant;
+} zkm_column;
+typedef struct {            /* TableWithColumns minus the table id: Vec<Column> + Option<Filter> */
+    uint32_t ncols, col_off;                    /* columns[col_off .. col_off+ncols) */
+    uint32_t has_filter, nprod, prod_off, nconst, const_off, _pad;
+    /* Filter = sum_{k<nprod} columns[filter_idx[prod_off+2k]] * columns[filter_idx[prod_off+2k+1]]
+     *        + sum_{k<nconst} columns[filter_idx[const_off+k]]                       (cross_table_lookup.rs:40-103) */
+} zkm_colset;
+typedef struct {            /* all descriptor arrays of one table (host pointers) */
+    const zkm_column* columns; size_t ncolumns;
+    const uint32_t* term_col; const uint64_t* term_coeff; size_t nterms;
+    const zkm_colset* colsets; size_t ncolsets;
+    const uint32_t* filter_idx; size_t nfilter_idx;
+} zkm_ctl_table;
+typedef struct {            /* CtlZData (cross_table_lookup.rs:424-438) */
+    uint32_t ncolsets, colset_off;              /* colset_ids[colset_off .. +ncolsets) index the table's colsets */
+    uint32_t num_helpers, _pad;                 /* helper columns of this Z: ceil(ncolsets/2) if ncolsets > 1 else 0
+                                                   (the benchmark's fake CTL data has ncolsets == 0, num_helpers == 1) */
+    uint64_t beta, gamma;                       /* GrandProductChallenge */
+} zkm_ctl_z;
+typedef struct { uint32_t table, colset; } zkm_ctl_side;
+typedef struct { uint32_t nlooking, looking_off; zkm_ctl_side looked; } zkm_cross_table_lookup;  /* looking sides: sides[looking_off..] */
+
+/* a3: cross_table_lookup_data for one table (get_helper_cols :709-797, partial_sums :841-872): helper columns and
+ * the upside-down running-sum Z of every CtlZData.  aux_out = all helper columns (zs order) ++ all Z columns,
+ * column-major (sum num_helpers + nzs) x 2^log_n, host or device; trace = ncols x 2^log_n values, host or device. */
+int zkm_ctl_data(zkm_ctx* ctx, const zkm_ctl_table* table, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs,
+                 const uint64_t* trace, size_t ncols, unsigned log_n, uint64_t* aux_out, char** err);
+
+/* prove_single_table with real CTL data: like zkm_prove_single_table, the CtlZData described by (table, zs, colset_ids). */
+int zkm_prove_single_table_ctl(zkm_ctx* ctx, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t ncols,
+                               unsigned log_n, const zkm_batch* trace_batch, const uint64_t* aux, size_t naux,
+                               const zkm_ctl_table* table, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs,
+                               zkm_challenger* challenger, uint64_t* proof_out, char** err);
+
+/* a1: prove_with_traces (prover.rs:130-232): commit every trace, seed the transcript with all trace caps and the
+ * public values, draw the CTL challenges, build every table's CtlData, then prove the tables in order on the shared
+ * transcript.  Output: per-table proof blobs concatenated (offsets in proof_offsets_out[ntables+1]) and the
+ * num_challenges (beta, gamma) pairs. */
+typedef struct {
+    int table_id;
+    const uint64_t* trace;      /* ncols x 2^log_n, host or device */
+    size_t ncols;
+    unsigned log_n;
+    const zkm_ctl_table* ctl;   /* column sets referenced by the cross-table lookups */
+} zkm_table_input;
+size_t zkm_all_proof_words(const zkm_stark_config* cfg, const zkm_table_input* tables, size_t ntables,
+                           const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls, size_t* proof_offsets_out);
+int zkm_prove_with_traces(zkm_ctx* ctx, const zkm_stark_config* cfg, const zkm_table_input* tables, size_t ntables,
+                          const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls,
+                          const uint64_t* public_values, size_t npublic, uint64_t* proofs_out, uint64_t* ctl_challenges_out,
+                          char** err);
+
 /* ------------------------------------------------------------------ stage entry points (parity / reuse)
  * a6: compute_quotient_polys (prover.rs:645-789): nalphas polys of 2n coefficients, natural order;
  * out host or device. */

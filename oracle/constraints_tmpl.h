@@ -91,19 +91,75 @@ static void TNAME(eval_poseidon)(const T* lv, TNAME(consumer) * k) {
     for (int i = 0; i < 12; i++) TNAME(cons)(k, T_SUB(s[i], lv[13 + i]));
 }
 
-/* CTL checks for CtlZData with helper columns and no column sets (the benchmark's fake CTL data,
- * poseidon_stark.rs:786-799): eval_helper_columns emits nothing (columns empty, cross_table_lookup.rs:1021),
- * then last-row and transition checks on Z (:1111-1118). aux = helpers ++ zs. */
-static void TNAME(eval_ctl)(const T* aux_local, const T* aux_next, const uint32_t* num_helpers, size_t nctl,
-                            TNAME(consumer) * k) {
+/* ---- general CTL checks driven by the column-set description ----
+ * Column::eval_with_next cross_table_lookup.rs:292-311, Filter::eval_filter :64-79,
+ * GrandProductChallenge::combine :494-504 (reduce_with_powers(terms, beta) + gamma),
+ * eval_helper_columns :1006-1058, eval_cross_table_lookup_checks :1067-1150.
+ * The benchmark's fake CTL data (poseidon_stark.rs:786-799: helper columns, no column sets) is the
+ * ncolsets == 0 case: eval_helper_columns emits nothing, then the last-row / transition checks on Z. */
+static T TNAME(eval_column)(const zko_ctl_table* t, uint32_t ci, const T* lv, const T* nv) {
+    const zko_column* c = &t->columns[ci];
+    T acc = T_FROMB(0);
+    for (uint32_t k = 0; k < c->n_local; k++) acc = T_ADD(acc, T_MULB(lv[t->term_col[c->term_off + k]], t->term_coeff[c->term_off + k]));
+    for (uint32_t k = 0; k < c->n_next; k++) {
+        uint32_t o = c->term_off + c->n_local + k;
+        acc = T_ADD(acc, T_MULB(nv[t->term_col[o]], t->term_coeff[o]));
+    }
+    return T_ADD(acc, T_FROMB(c->constant));
+}
+static T TNAME(eval_filter)(const zko_ctl_table* t, const zko_colset* cs, const T* lv, const T* nv) {
+    if (!cs->has_filter) return T_FROMB(1);
+    T acc = T_FROMB(0);
+    for (uint32_t k = 0; k < cs->nprod; k++)
+        acc = T_ADD(acc, T_MUL(TNAME(eval_column)(t, t->filter_idx[cs->prod_off + 2 * k], lv, nv),
+                               TNAME(eval_column)(t, t->filter_idx[cs->prod_off + 2 * k + 1], lv, nv)));
+    for (uint32_t k = 0; k < cs->nconst; k++) acc = T_ADD(acc, TNAME(eval_column)(t, t->filter_idx[cs->const_off + k], lv, nv));
+    return acc;
+}
+static T TNAME(combine)(const zko_ctl_table* t, const zko_colset* cs, const T* lv, const T* nv, gl_t beta, gl_t gamma) {
+    T acc = T_FROMB(0);
+    for (uint32_t k = cs->ncols; k-- > 0;) acc = T_ADD(T_MULB(acc, beta), TNAME(eval_column)(t, cs->col_off + k, lv, nv));
+    return T_ADD(acc, T_FROMB(gamma));
+}
+static void TNAME(eval_ctl_general)(const zko_ctl_table* t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t nzs,
+                                    const T* lv, const T* nv, const T* aux_local, const T* aux_next, TNAME(consumer) * k) {
     size_t total_helpers = 0, start = 0;
-    for (size_t i = 0; i < nctl; i++) total_helpers += num_helpers[i];
-    for (size_t i = 0; i < nctl; i++) {
-        T h_sum = T_FROMB(0);
-        for (size_t h = 0; h < num_helpers[i]; h++) h_sum = T_ADD(h_sum, aux_local[start + h]);
+    for (size_t i = 0; i < nzs; i++) total_helpers += zs[i].num_helpers;
+    for (size_t i = 0; i < nzs; i++) {
+        const zko_ctl_z* z = &zs[i];
+        const uint32_t* ids = colset_ids + z->colset_off;
         T local_z = aux_local[total_helpers + i], next_z = aux_next[total_helpers + i];
-        TNAME(cons_last)(k, T_SUB(local_z, h_sum));
-        TNAME(cons_transition)(k, T_SUB(T_SUB(local_z, next_z), h_sum));
-        start += num_helpers[i];
+        if (z->num_helpers) {
+            /* eval_helper_columns: chunks of constraint_degree - 1 = 2 column sets per helper */
+            for (uint32_t j = 0; 2 * j < z->ncolsets; j++) {
+                T h = aux_local[start + j];
+                const zko_colset* c0 = &t->colsets[ids[2 * j]];
+                T combin0 = TNAME(combine)(t, c0, lv, nv, z->beta, z->gamma), f0 = TNAME(eval_filter)(t, c0, lv, nv);
+                if (2 * j + 1 < z->ncolsets) {
+                    const zko_colset* c1 = &t->colsets[ids[2 * j + 1]];
+                    T combin1 = TNAME(combine)(t, c1, lv, nv, z->beta, z->gamma), f1 = TNAME(eval_filter)(t, c1, lv, nv);
+                    TNAME(cons)(k, T_SUB(T_SUB(T_MUL(T_MUL(combin1, combin0), h), T_MUL(f0, combin1)), T_MUL(f1, combin0)));
+                } else {
+                    TNAME(cons)(k, T_SUB(T_MUL(combin0, h), f0));
+                }
+            }
+            T h_sum = T_FROMB(0);
+            for (uint32_t h = 0; h < z->num_helpers; h++) h_sum = T_ADD(h_sum, aux_local[start + h]);
+            TNAME(cons_last)(k, T_SUB(local_z, h_sum));
+            TNAME(cons_transition)(k, T_SUB(T_SUB(local_z, next_z), h_sum));
+        } else if (z->ncolsets > 1) {
+            const zko_colset *c0 = &t->colsets[ids[0]], *c1 = &t->colsets[ids[1]];
+            T combin0 = TNAME(combine)(t, c0, lv, nv, z->beta, z->gamma), combin1 = TNAME(combine)(t, c1, lv, nv, z->beta, z->gamma);
+            T f0 = TNAME(eval_filter)(t, c0, lv, nv), f1 = TNAME(eval_filter)(t, c1, lv, nv);
+            T cc = T_MUL(combin0, combin1), rhs = T_ADD(T_MUL(f0, combin1), T_MUL(f1, combin0));
+            TNAME(cons_last)(k, T_SUB(T_MUL(cc, local_z), rhs));
+            TNAME(cons_transition)(k, T_SUB(T_MUL(cc, T_SUB(local_z, next_z)), rhs));
+        } else {
+            const zko_colset* c0 = &t->colsets[ids[0]];
+            T combin0 = TNAME(combine)(t, c0, lv, nv, z->beta, z->gamma), f0 = TNAME(eval_filter)(t, c0, lv, nv);
+            TNAME(cons_last)(k, T_SUB(T_MUL(combin0, local_z), f0));
+            TNAME(cons_transition)(k, T_SUB(T_MUL(combin0, T_SUB(local_z, next_z)), f0));
+        }
+        start += z->num_helpers;
     }
 }

@@ -205,6 +205,103 @@ class Oracle:
         return self.lib.zko_verify_single_table(0, C.byref(cfg), _ptr(np.ascontiguousarray(proof)), ncols, naux, nh,
                                                 len(num_helpers), C.byref(ch))
 
+    # ---- cross-table lookups / multi-table proofs (descriptor builders live in zkm_amd/ctl.py: pure marshalling)
+    def _ctl_sigs(self):
+        if getattr(self, "_ctl_ready", False):
+            return
+        L = self.lib
+        vp = C.c_void_p
+        L.zko_ctl_data.argtypes = [vp, vp, vp, C.c_size_t, u64p, C.c_size_t, C.c_uint, u64p]
+        L.zko_check_ctls.restype = C.c_int
+        L.zko_check_ctls.argtypes = [vp, C.c_size_t, vp, vp, C.c_size_t]
+        L.zko_prove_single_table_ctl.restype = C.c_int
+        L.zko_prove_single_table_ctl.argtypes = [C.c_int, C.POINTER(StarkConfig), u64p, C.c_size_t, C.c_uint, u64p, C.c_size_t, vp, vp,
+                                                 vp, C.c_size_t, C.POINTER(Challenger), u64p]
+        L.zko_verify_single_table_ctl.restype = C.c_int
+        L.zko_verify_single_table_ctl.argtypes = [C.c_int, C.POINTER(StarkConfig), u64p, C.c_size_t, C.c_size_t, vp, vp, vp,
+                                                  C.c_size_t, C.POINTER(Challenger)]
+        L.zko_all_proof_words.restype = C.c_size_t
+        L.zko_all_proof_words.argtypes = [C.POINTER(StarkConfig), vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.zko_prove_with_traces.restype = C.c_int
+        L.zko_prove_with_traces.argtypes = [C.POINTER(StarkConfig), vp, C.c_size_t, vp, vp, C.c_size_t, u64p, C.c_size_t, u64p, u64p]
+        L.zko_verify_all.restype = C.c_int
+        L.zko_verify_all.argtypes = [C.POINTER(StarkConfig), vp, C.c_size_t, vp, vp, C.c_size_t, u64p, C.c_size_t, u64p, u64p]
+        self._ctl_ready = True
+
+    def ctl_data(self, ctl_table, zs, colset_ids, trace, ncols, log_n):
+        self._ctl_sigs()
+        naux = int(zs["num_helpers"].sum()) + len(zs)
+        aux = np.zeros(naux << log_n, dtype=np.uint64)
+        st = ctl_table.pack()
+        self.lib.zko_ctl_data(C.addressof(st), zs.ctypes.data, colset_ids.ctypes.data, len(zs), _ptr(np.ascontiguousarray(trace)), ncols,
+                              log_n, _ptr(aux))
+        return aux
+
+    def prove_ctl(self, trace, log_n, aux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS):
+        self._ctl_sigs()
+        cfg = cfg or self.standard_config()
+        ch = challenger or Challenger()
+        naux = aux.size >> log_n
+        proof = np.zeros(self.proof_words(cfg, log_n, ncols, naux, len(zs)), dtype=np.uint64)
+        st = ctl_table.pack()
+        rc = self.lib.zko_prove_single_table_ctl(0, C.byref(cfg), _ptr(np.ascontiguousarray(trace)), ncols, log_n,
+                                                 _ptr(np.ascontiguousarray(aux)), naux, C.addressof(st), zs.ctypes.data,
+                                                 colset_ids.ctypes.data, len(zs), C.byref(ch), _ptr(proof))
+        if rc:
+            raise RuntimeError("oracle prove_single_table_ctl failed: %d" % rc)
+        return proof
+
+    def verify_ctl(self, proof, naux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS):
+        self._ctl_sigs()
+        cfg = cfg or self.standard_config()
+        ch = challenger or Challenger()
+        st = ctl_table.pack()
+        return self.lib.zko_verify_single_table_ctl(0, C.byref(cfg), _ptr(np.ascontiguousarray(proof)), ncols, naux, C.addressof(st),
+                                                    zs.ctypes.data, colset_ids.ctypes.data, len(zs), C.byref(ch))
+
+    def _pack_all(self, tables, ctls):
+        from zkm_amd import ctl as zc
+        packed = [(tid, tr.ctypes.data, ncols, log_n, ct) for (tid, tr, ncols, log_n, ct) in tables]
+        tarr, keep = zc.pack_tables(packed)
+        carr, sides = zc.pack_ctls(ctls)
+        return tarr, carr, sides, keep
+
+    def check_ctls(self, tables, ctls):
+        self._ctl_sigs()
+        tarr, carr, sides, keep = self._pack_all(tables, ctls)
+        return self.lib.zko_check_ctls(tarr, len(tables), carr.ctypes.data, sides.ctypes.data, len(carr))
+
+    def all_proof_words(self, tables, ctls, cfg=None):
+        self._ctl_sigs()
+        cfg = cfg or self.standard_config()
+        tarr, carr, sides, keep = self._pack_all(tables, ctls)
+        offs = (C.c_size_t * (len(tables) + 1))()
+        total = self.lib.zko_all_proof_words(C.byref(cfg), tarr, len(tables), carr.ctypes.data, sides.ctypes.data, len(carr), offs)
+        return total, list(offs)
+
+    def prove_with_traces(self, tables, ctls, public_values=(), cfg=None):
+        """tables: list of (table_id, trace ndarray, ncols, log_n, CtlTable); ctls: list of (looking sides, looked side)."""
+        self._ctl_sigs()
+        cfg = cfg or self.standard_config()
+        tarr, carr, sides, keep = self._pack_all(tables, ctls)
+        total, offs = self.all_proof_words(tables, ctls, cfg)
+        proofs = np.zeros(total, dtype=np.uint64)
+        chal = np.zeros(2 * cfg.num_challenges, dtype=np.uint64)
+        pub = np.ascontiguousarray(public_values, dtype=np.uint64)
+        rc = self.lib.zko_prove_with_traces(C.byref(cfg), tarr, len(tables), carr.ctypes.data, sides.ctypes.data, len(carr), _ptr(pub),
+                                            pub.size, _ptr(proofs), _ptr(chal))
+        if rc:
+            raise RuntimeError("oracle prove_with_traces failed: %d" % rc)
+        return proofs, chal, offs
+
+    def verify_all(self, tables, ctls, proofs, challenges, public_values=(), cfg=None):
+        self._ctl_sigs()
+        cfg = cfg or self.standard_config()
+        tarr, carr, sides, keep = self._pack_all(tables, ctls)
+        pub = np.ascontiguousarray(public_values, dtype=np.uint64)
+        return self.lib.zko_verify_all(C.byref(cfg), tarr, len(tables), carr.ctypes.data, sides.ctypes.data, len(carr), _ptr(pub),
+                                       pub.size, _ptr(np.ascontiguousarray(proofs)), _ptr(np.ascontiguousarray(challenges)))
+
     # ---- challenger
     def challenger(self):
         ch = Challenger()

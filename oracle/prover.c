@@ -187,8 +187,26 @@ size_t zko_proof_words(const zko_stark_config* c, unsigned log_n, size_t W, size
 }
 
 /* ------------------------------------------------------------------ quotient (prover.rs:645-789) */
+/* fake-CTL shape (poseidon_benchmark): CtlZData with helper columns and no column sets */
+static zko_ctl_z* fake_zs(const uint32_t* num_helpers, size_t nctl) {
+    zko_ctl_z* zs = (zko_ctl_z*)calloc(nctl ? nctl : 1, sizeof(zko_ctl_z));
+    for (size_t i = 0; i < nctl; i++) zs[i].num_helpers = num_helpers[i];
+    return zs;
+}
+static const zko_ctl_table EMPTY_CTL_TABLE = {0};
+
+static void quotient_generic(const zko_batch* trace, const zko_batch* aux, const zko_ctl_table* ctl_t, const zko_ctl_z* zs,
+                             const uint32_t* colset_ids, size_t nctl, const uint64_t* alphas, size_t nalphas, uint64_t* out);
+
 void zko_quotient_poseidon(const zko_batch* trace, const zko_batch* aux, const uint32_t* num_helpers, size_t nctl,
                            const uint64_t* alphas, size_t nalphas, uint64_t* out) {
+    zko_ctl_z* zs = fake_zs(num_helpers, nctl);
+    quotient_generic(trace, aux, &EMPTY_CTL_TABLE, zs, NULL, nctl, alphas, nalphas, out);
+    free(zs);
+}
+
+static void quotient_generic(const zko_batch* trace, const zko_batch* aux, const zko_ctl_table* ctl_t, const zko_ctl_z* zs,
+                             const uint32_t* colset_ids, size_t nctl, const uint64_t* alphas, size_t nalphas, uint64_t* out) {
     unsigned log_n = zko_batch_log_n(trace), rate_bits = 2, qbits = 1;
     unsigned log_N = log_n + rate_bits, log_q = log_n + qbits;
     size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N, size = (size_t)1 << log_q;
@@ -215,8 +233,8 @@ void zko_quotient_poseidon(const zko_batch* trace, const zko_batch* aux, const u
     gl_t* qv = (gl_t*)malloc(sizeof(gl_t) * nalphas * size);
 #pragma omp parallel
     {
-        gl_t* lv = (gl_t*)malloc(sizeof(gl_t) * (W + 2 * A));
-        gl_t *av = lv + W, *an = av + A;
+        gl_t* lv = (gl_t*)malloc(sizeof(gl_t) * (2 * W + 2 * A));
+        gl_t *av = lv + W, *an = av + A, *nv = an + A;
 #pragma omp for schedule(static)
         for (size_t i = 0; i < size; i++) {
             size_t i_next = (i + next_step) % size;
@@ -229,10 +247,10 @@ void zko_quotient_poseidon(const zko_batch* trace, const zko_batch* aux, const u
             k.z_last = gl_sub(x, last);
             k.l_first = lf[i];
             k.l_last = ll[i];
-            for (size_t c = 0; c < W; c++) lv[c] = tl[c * N + j];
+            for (size_t c = 0; c < W; c++) { lv[c] = tl[c * N + j]; nv[c] = tl[c * N + jn]; }
             for (size_t c = 0; c < A; c++) { av[c] = al[c * N + j]; an[c] = al[c * N + jn]; }
             b_eval_poseidon(lv, &k);
-            b_eval_ctl(av, an, num_helpers, nctl, &k);
+            b_eval_ctl_general(ctl_t, zs, colset_ids, nctl, lv, nv, av, an, &k);
             for (size_t a = 0; a < nalphas; a++) qv[a * size + i] = gl_mul(k.acc[a], zh_inv[i & 1]);
         }
         free(lv);
@@ -273,15 +291,34 @@ typedef struct {
 } fri_layer_t;
 
 /* ------------------------------------------------------------------ prove_single_table */
+static int prove_generic(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
+                         const uint64_t* aux, size_t A, const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids,
+                         size_t Z, zko_challenger* ch, uint64_t* proof, double* stage_s);
+
 int zko_prove_single_table(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
                            const uint64_t* aux, size_t A, const uint32_t* num_helpers, size_t Z,
                            zko_challenger* ch, uint64_t* proof, double* stage_s) {
+    for (size_t i = 0; i < Z; i++) if (!num_helpers[i]) return -2;
+    zko_ctl_z* zs = fake_zs(num_helpers, Z);
+    int rc = prove_generic(table_id, cfg, trace, W, log_n, aux, A, &EMPTY_CTL_TABLE, zs, NULL, Z, ch, proof, stage_s);
+    free(zs);
+    return rc;
+}
+int zko_prove_single_table_ctl(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
+                               const uint64_t* aux, size_t A, const zko_ctl_table* t, const zko_ctl_z* zs,
+                               const uint32_t* colset_ids, size_t Z, zko_challenger* ch, uint64_t* proof) {
+    return prove_generic(table_id, cfg, trace, W, log_n, aux, A, t, zs, colset_ids, Z, ch, proof, NULL);
+}
+
+static int prove_generic(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
+                         const uint64_t* aux, size_t A, const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids,
+                         size_t Z, zko_challenger* ch, uint64_t* proof, double* stage_s) {
     if (table_id != ZKO_TABLE_POSEIDON || W != ZKO_POSEIDON_COLS || cfg->num_challenges > 4) return -1;
     layout_t y;
     layout(&y, cfg, log_n, W, A, Z);
     size_t n = (size_t)1 << log_n, N = (size_t)1 << y.lde_bits;
     size_t total_helpers = 0;
-    for (size_t i = 0; i < Z; i++) { if (!num_helpers[i]) return -2; total_helpers += num_helpers[i]; }
+    for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
     if (total_helpers + Z != A) return -3;
     double t0, ts[8] = {0};
 
@@ -308,7 +345,7 @@ int zko_prove_single_table(int table_id, const zko_stark_config* cfg, const uint
 
     t0 = now_s();
     gl_t* quot = (gl_t*)malloc(sizeof(gl_t) * cfg->num_challenges * 2 * n);
-    zko_quotient_poseidon(tb, ab, num_helpers, Z, alphas, cfg->num_challenges, quot);  /* :543-559 */
+    quotient_generic(tb, ab, ctl_t, zs, colset_ids, Z, alphas, cfg->num_challenges, quot);  /* :543-559 */
     ts[2] = now_s() - t0;
     /* chunks of n coefficients: [q0_lo, q0_hi, q1_lo, q1_hi] == quot viewed as Q columns of n (:560-575) */
     t0 = now_s();
@@ -539,8 +576,24 @@ static gl2_t compute_evaluation(gl_t x, size_t x_in_coset, unsigned arity_bits, 
     return acc;
 }
 
+static int verify_generic(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
+                          const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t Z, zko_challenger* ch);
+
 int zko_verify_single_table(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
                             const uint32_t* num_helpers, size_t Z, zko_challenger* ch) {
+    zko_ctl_z* zs = fake_zs(num_helpers, Z);
+    int rc = verify_generic(table_id, cfg, proof, W, A, &EMPTY_CTL_TABLE, zs, NULL, Z, ch);
+    free(zs);
+    return rc;
+}
+int zko_verify_single_table_ctl(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
+                                const zko_ctl_table* t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t Z,
+                                zko_challenger* ch) {
+    return verify_generic(table_id, cfg, proof, W, A, t, zs, colset_ids, Z, ch);
+}
+
+static int verify_generic(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
+                          const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t Z, zko_challenger* ch) {
     if (table_id != ZKO_TABLE_POSEIDON || W != ZKO_POSEIDON_COLS) return 1;
     if (proof[0] != 0x5a4b4d50524f4f46ULL) return 2;
     unsigned log_n = (unsigned)proof[1];
@@ -551,7 +604,8 @@ int zko_verify_single_table(int table_id, const zko_stark_config* cfg, const uin
         return 3; /* validate_proof_shape verifier.rs:294-342 */
     size_t N = (size_t)1 << y.lde_bits;
     size_t total_helpers = 0;
-    for (size_t i = 0; i < Z; i++) total_helpers += num_helpers[i];
+    for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
+    if (total_helpers + Z != A) return 3;
     size_t arity = (size_t)1 << cfg->arity_bits;
 
     /* the verifier starts from the recorded transcript state (proof.rs:199): the prover's challenger
@@ -590,8 +644,8 @@ int zko_verify_single_table(int table_id, const zko_stark_config* cfg, const uin
     for (size_t q = 0; q < y.nq; q++) xs[q] = zko_challenger_get(ch) % N;
 
     /* ---- constraint check at zeta (verifier.rs:205-264) ---- */
-    gl2_t *lv = (gl2_t*)malloc(sizeof(gl2_t) * (W + 2 * A)), *av = lv + W, *an = av + A;
-    for (size_t c = 0; c < W; c++) lv[c] = gl2_make(o_local[2 * c], o_local[2 * c + 1]);
+    gl2_t *lv = (gl2_t*)malloc(sizeof(gl2_t) * (2 * W + 2 * A)), *av = lv + W, *an = av + A, *nv = an + A;
+    for (size_t c = 0; c < W; c++) { lv[c] = gl2_make(o_local[2 * c], o_local[2 * c + 1]); nv[c] = gl2_make(o_next[2 * c], o_next[2 * c + 1]); }
     for (size_t c = 0; c < A; c++) { av[c] = gl2_make(o_aux[2 * c], o_aux[2 * c + 1]); an[c] = gl2_make(o_auxn[2 * c], o_auxn[2 * c + 1]); }
     gl_t g = gl_root_of_unity(log_n);
     gl2_t zeta_n = gl2_exp_pow2(zeta, log_n);
@@ -608,7 +662,7 @@ int zko_verify_single_table(int table_id, const zko_stark_config* cfg, const uin
     k.l_first = gl2_mul(z_h, gl2_inv(d0));
     k.l_last = gl2_mul(z_h, gl2_inv(d1));
     e_eval_poseidon(lv, &k);
-    e_eval_ctl(av, an, num_helpers, Z, &k);
+    e_eval_ctl_general(ctl_t, zs, colset_ids, Z, lv, nv, av, an, &k);
     for (unsigned i = 0; i < cfg->num_challenges; i++) {
         gl2_t t0 = gl2_make(o_quot[4 * i], o_quot[4 * i + 1]), t1 = gl2_make(o_quot[4 * i + 2], o_quot[4 * i + 3]);
         gl2_t rhs = gl2_mul(z_h, gl2_add(t0, gl2_mul(t1, zeta_n)));

@@ -92,6 +92,42 @@ int zko_prove_single_table(int table_id, const zko_stark_config* cfg, const uint
 int zko_verify_single_table(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t ncols, size_t naux,
                             const uint32_t* num_helpers, size_t nctl_zs, zko_challenger* challenger);
 
+
+/* ---- cross-table lookups: same array layouts as include/zkm_hip.h (declared again: the oracle shares no header
+ * with the product).  Column/Filter/TableWithColumns/CrossTableLookup = cross_table_lookup.rs:31-415. */
+typedef struct { uint32_t n_local, n_next, term_off, _pad; uint64_t constant; } zko_column;
+typedef struct { uint32_t ncols, col_off, has_filter, nprod, prod_off, nconst, const_off, _pad; } zko_colset;
+typedef struct {
+    const zko_column* columns; size_t ncolumns;
+    const uint32_t* term_col; const uint64_t* term_coeff; size_t nterms;
+    const zko_colset* colsets; size_t ncolsets;
+    const uint32_t* filter_idx; size_t nfilter_idx;
+} zko_ctl_table;
+typedef struct { uint32_t ncolsets, colset_off, num_helpers, _pad; uint64_t beta, gamma; } zko_ctl_z;
+typedef struct { uint32_t table, colset; } zko_ctl_side;
+typedef struct { uint32_t nlooking, looking_off; zko_ctl_side looked; } zko_cross_table_lookup;
+typedef struct { int table_id; const uint64_t* trace; size_t ncols; unsigned log_n; const zko_ctl_table* ctl; } zko_table_input;
+
+void zko_ctl_data(const zko_ctl_table* t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, const uint64_t* trace,
+                  size_t ncols, unsigned log_n, uint64_t* aux_out);
+/* check_ctls (cross_table_lookup.rs:1486-1581): 0 if every looking multiset equals its looked multiset */
+int zko_check_ctls(const zko_table_input* tables, size_t ntables, const zko_cross_table_lookup* ctls, const zko_ctl_side* sides, size_t nctls);
+int zko_prove_single_table_ctl(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t ncols, unsigned log_n,
+                               const uint64_t* aux, size_t naux, const zko_ctl_table* t, const zko_ctl_z* zs,
+                               const uint32_t* colset_ids, size_t nzs, zko_challenger* challenger, uint64_t* proof_out);
+int zko_verify_single_table_ctl(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t ncols, size_t naux,
+                                const zko_ctl_table* t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t nzs,
+                                zko_challenger* challenger);
+size_t zko_all_proof_words(const zko_stark_config* cfg, const zko_table_input* tables, size_t ntables,
+                           const zko_cross_table_lookup* ctls, const zko_ctl_side* sides, size_t nctls, size_t* proof_offsets_out);
+int zko_prove_with_traces(const zko_stark_config* cfg, const zko_table_input* tables, size_t ntables,
+                          const zko_cross_table_lookup* ctls, const zko_ctl_side* sides, size_t nctls,
+                          const uint64_t* public_values, size_t npublic, uint64_t* proofs_out, uint64_t* ctl_challenges_out);
+/* verify_proof (verifier.rs:27-176): 0 = accepted */
+int zko_verify_all(const zko_stark_config* cfg, const zko_table_input* tables, size_t ntables,
+                   const zko_cross_table_lookup* ctls, const zko_ctl_side* sides, size_t nctls,
+                   const uint64_t* public_values, size_t npublic, const uint64_t* proofs, const uint64_t* ctl_challenges);
+
 /* quotient stage alone (for stage-level parity): out = num_challenges*2 chunk polys... returns the
  * num_challenges quotient polys of 2n coefficients each (natural order). */
 void zko_quotient_poseidon(const zko_batch* trace, const zko_batch* aux, const uint32_t* num_helpers, size_t nctl_zs,
