@@ -27,7 +27,8 @@ EXPORTS = [
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
-    "zkm_prove_single_table", "zkm_quotient", "zkm_eval_openings", "zkm_profile_enable", "zkm_profile_reset",
+    "zkm_prove_single_table", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_all_proof_words", "zkm_prove_with_traces",
+    "zkm_quotient", "zkm_eval_openings", "zkm_profile_enable", "zkm_profile_reset",
     "zkm_profile_count", "zkm_profile_get", "zkm_version",
 ]
 
@@ -99,6 +100,12 @@ def load():
         "zkm_proof_words": (C.c_size_t, [C.POINTER(StarkConfig), C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t]),
         "zkm_prove_single_table": (C.c_int, [cp, C.c_int, C.POINTER(StarkConfig), cp, C.c_size_t, C.c_uint, cp, cp, C.c_size_t,
                                              C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Challenger), u64p, err]),
+        "zkm_prove_single_table_ctl": (C.c_int, [cp, C.c_int, C.POINTER(StarkConfig), cp, C.c_size_t, C.c_uint, cp, cp, C.c_size_t,
+                                                 cp, cp, cp, C.c_size_t, C.POINTER(Challenger), u64p, err]),
+        "zkm_ctl_data": (C.c_int, [cp, cp, cp, cp, C.c_size_t, cp, C.c_size_t, C.c_uint, cp, err]),
+        "zkm_all_proof_words": (C.c_size_t, [C.POINTER(StarkConfig), cp, C.c_size_t, cp, cp, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "zkm_prove_with_traces": (C.c_int, [cp, C.POINTER(StarkConfig), cp, C.c_size_t, cp, cp, C.c_size_t, u64p, C.c_size_t, u64p,
+                                            u64p, err]),
         "zkm_quotient": (C.c_int, [cp, C.c_int, cp, cp, C.POINTER(C.c_uint32), C.c_size_t, u64p, C.c_size_t, cp, err]),
         "zkm_eval_openings": (C.c_int, [cp, cp, u64p, u64p, err]),
         "zkm_profile_enable": (None, [cp, C.c_int]),
@@ -267,6 +274,54 @@ class Context:
                                              naux, nh, len(num_helpers), C.byref(ch), proof.ctypes.data_as(u64p),
                                              C.byref(err)), err)
         return proof
+
+    # ---- cross-table lookups (descriptor builders: zkm_amd/ctl.py)
+    def ctl_data(self, ctl_table, zs, colset_ids, trace, ncols, log_n, out=None):
+        """cross_table_lookup_data for one table (cross_table_lookup.rs:634-872): helper columns ++ Z columns."""
+        naux = int(zs["num_helpers"].sum()) + len(zs)
+        host_out = out is None
+        if host_out:
+            out = np.zeros(naux << log_n, dtype=np.uint64)
+        st = ctl_table.pack()
+        err = C.c_char_p()
+        _check(self.L.zkm_ctl_data(self.h, C.addressof(st), zs.ctypes.data, colset_ids.ctypes.data, len(zs), _data_ptr(trace), ncols,
+                                   log_n, _data_ptr(out), C.byref(err)), err)
+        return out
+
+    def prove_single_table_ctl(self, trace, log_n, aux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS,
+                               trace_batch=None, table_id=TABLE_POSEIDON):
+        cfg = cfg or self.standard_config()
+        ch = challenger if challenger is not None else Challenger()
+        naux = (aux.size if isinstance(aux, np.ndarray) else aux.words) >> log_n
+        proof = np.zeros(self.proof_words(cfg, log_n, ncols, naux, len(zs)), dtype=np.uint64)
+        st = ctl_table.pack()
+        err = C.c_char_p()
+        _check(self.L.zkm_prove_single_table_ctl(self.h, table_id, C.byref(cfg), _data_ptr(trace) if trace is not None else None, ncols,
+                                                 log_n, trace_batch.h if trace_batch is not None else None, _data_ptr(aux), naux,
+                                                 C.addressof(st), zs.ctypes.data, colset_ids.ctypes.data, len(zs), C.byref(ch),
+                                                 proof.ctypes.data_as(u64p), C.byref(err)), err)
+        return proof
+
+    def prove_with_traces(self, tables, ctls, public_values=(), cfg=None):
+        """prove_with_traces (prover.rs:130-232).  tables: list of (table_id, trace (ndarray | DeviceBuffer), ncols, log_n, CtlTable);
+        ctls: list of (looking=[(table, colset)..], looked=(table, colset)).  Returns (proofs, ctl_challenges, offsets)."""
+        from . import ctl as zc
+        cfg = cfg or self.standard_config()
+        packed = [(tid, _data_ptr(tr).value, ncols, log_n, ct) for (tid, tr, ncols, log_n, ct) in tables]
+        tarr, keep = zc.pack_tables(packed)
+        carr, sides = zc.pack_ctls(ctls)
+        offs = (C.c_size_t * (len(tables) + 1))()
+        total = self.L.zkm_all_proof_words(C.byref(cfg), tarr, len(tables), carr.ctypes.data, sides.ctypes.data, len(carr), offs)
+        if total == 0 and len(tables):
+            raise ZkmError("malformed cross-table lookups")
+        proofs = np.zeros(total, dtype=np.uint64)
+        chal = np.zeros(2 * cfg.num_challenges, dtype=np.uint64)
+        pub = np.ascontiguousarray(public_values, dtype=np.uint64)
+        err = C.c_char_p()
+        _check(self.L.zkm_prove_with_traces(self.h, C.byref(cfg), tarr, len(tables), carr.ctypes.data, sides.ctypes.data, len(carr),
+                                            pub.ctypes.data_as(u64p), pub.size, proofs.ctypes.data_as(u64p), chal.ctypes.data_as(u64p),
+                                            C.byref(err)), err)
+        return proofs, chal, list(offs)
 
     def quotient(self, trace_batch, aux_batch, num_helpers, alphas, table_id=TABLE_POSEIDON):
         nh = (C.c_uint32 * len(num_helpers))(*num_helpers)

@@ -1,0 +1,350 @@
+// ctl.hip -- cross-table lookup data on the GPU (K6 / a3) and the multi-table driver prove_with_traces (a1).
+//
+// Reference: cross_table_lookup_data cross_table_lookup.rs:634-703, get_helper_cols :709-797, partial_sums
+// :841-872 (serial over CTLs and rows in the reference); prove_with_traces prover.rs:130-232.
+// One lane per trace row: evaluate the filter and the challenge-combined column set, invert (Fermat; the
+// reference batch-inverts, the inverse is unique so the bytes agree), accumulate helper columns, then an
+// additive suffix scan produces the upside-down running sum Z.
+#include "ctl_dev.h"
+
+// ------------------------------------------------------------------ descriptor upload + validation
+void ctl_dev_owner::upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs) {
+    c = ctx;
+    static const zkm_ctl_table empty{};
+    if (!t) t = &empty;
+    size_t nids = 0, th = 0;
+    for (size_t i = 0; i < nzs; i++) {
+        if ((size_t)zs[i].colset_off + zs[i].ncolsets > nids) nids = (size_t)zs[i].colset_off + zs[i].ncolsets;
+        uint32_t want = zs[i].ncolsets > 1 ? (zs[i].ncolsets + 1) / 2 : 0;
+        if (zs[i].ncolsets == 0) {
+            if (zs[i].num_helpers == 0) throw std::runtime_error("CTL description: a Z without column sets needs helper columns");
+        } else if (zs[i].num_helpers != want) {
+            throw std::runtime_error("CTL description: num_helpers must be ceil(ncolsets/2) (0 for a single column set)");
+        }
+        th += zs[i].num_helpers;
+    }
+    for (size_t i = 0; i < nids; i++)
+        if (colset_ids[i] >= t->ncolsets) throw std::runtime_error("CTL description: column-set index out of range");
+    for (size_t i = 0; i < t->ncolsets; i++) {
+        const zkm_colset& s = t->colsets[i];
+        if ((size_t)s.col_off + s.ncols > t->ncolumns) throw std::runtime_error("CTL description: column range out of bounds");
+        if (s.has_filter && ((size_t)s.prod_off + 2 * s.nprod > t->nfilter_idx || (size_t)s.const_off + s.nconst > t->nfilter_idx))
+            throw std::runtime_error("CTL description: filter index range out of bounds");
+    }
+    for (size_t i = 0; i < t->nfilter_idx; i++)
+        if (t->filter_idx[i] >= t->ncolumns) throw std::runtime_error("CTL description: filter column index out of range");
+    for (size_t i = 0; i < t->ncolumns; i++)
+        if ((size_t)t->columns[i].term_off + t->columns[i].n_local + t->columns[i].n_next > t->nterms)
+            throw std::runtime_error("CTL description: term range out of bounds");
+    for (size_t i = 0; i < t->nterms; i++)
+        if (t->term_coeff[i] >= GL_P) throw std::runtime_error("CTL description: non-canonical coefficient");
+    // one blob: [columns | term_coeff | colsets | zs | term_col | filter_idx | colset_ids]
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t o_cols = 0, o_coeff = al(o_cols + t->ncolumns * sizeof(zkm_column)), o_sets = al(o_coeff + t->nterms * 8);
+    size_t o_zs = al(o_sets + t->ncolsets * sizeof(zkm_colset)), o_tc = al(o_zs + nzs * sizeof(zkm_ctl_z));
+    size_t o_fi = al(o_tc + t->nterms * 4), o_ids = al(o_fi + t->nfilter_idx * 4), total = al(o_ids + nids * 4) + 16;
+    std::vector<char> h(total, 0);
+    if (t->ncolumns) memcpy(&h[o_cols], t->columns, t->ncolumns * sizeof(zkm_column));
+    if (t->nterms) { memcpy(&h[o_coeff], t->term_coeff, t->nterms * 8); memcpy(&h[o_tc], t->term_col, t->nterms * 4); }
+    if (t->ncolsets) memcpy(&h[o_sets], t->colsets, t->ncolsets * sizeof(zkm_colset));
+    if (nzs) memcpy(&h[o_zs], zs, nzs * sizeof(zkm_ctl_z));
+    if (t->nfilter_idx) memcpy(&h[o_fi], t->filter_idx, t->nfilter_idx * 4);
+    if (nids) memcpy(&h[o_ids], colset_ids, nids * 4);
+    blob = c->alloc(total);
+    ZKM_HIP_CHECK(hipMemcpyAsync(blob, h.data(), total, hipMemcpyHostToDevice, c->stream));
+    c->sync();
+    char* b = (char*)blob;
+    d.columns = (const zkm_column*)(b + o_cols);
+    d.term_coeff = (const uint64_t*)(b + o_coeff);
+    d.colsets = (const zkm_colset*)(b + o_sets);
+    d.zs = (const zkm_ctl_z*)(b + o_zs);
+    d.term_col = (const uint32_t*)(b + o_tc);
+    d.filter_idx = (const uint32_t*)(b + o_fi);
+    d.colset_ids = (const uint32_t*)(b + o_ids);
+    d.nzs = (uint32_t)nzs;
+    d.total_helpers = (uint32_t)th;
+    naux = th + nzs;
+}
+ctl_dev_owner::~ctl_dev_owner() {
+    if (c && blob) {
+        (void)hipStreamSynchronize(c->stream);
+        c->release(blob);
+    }
+}
+
+// ------------------------------------------------------------------ K6 kernels
+// helper columns + per-row sum of all terms of CtlZData `zi`
+__global__ __launch_bounds__(256) void k_ctl_terms(ctl_dev d, uint32_t zi, const gl_t* __restrict__ trace, size_t n,
+                                                   gl_t* __restrict__ helpers /* num_helpers x n or null */, gl_t* __restrict__ hsum,
+                                                   int* __restrict__ bad) {
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const zkm_ctl_z z = d.zs[zi];
+    const uint32_t* ids = d.colset_ids + z.colset_off;
+    const gl_t* lv = trace + row;
+    bool next_ok = row + 1 < n;
+    gl_t total = 0;
+    for (uint32_t j = 0; 2 * j < z.ncolsets; j++) {
+        gl_t h = 0;
+        for (uint32_t e = 0; e < 2 && 2 * j + e < z.ncolsets; e++) {
+            const zkm_colset cs = d.colsets[ids[2 * j + e]];
+            gl_t f = ctl_eval_filter(d, cs, lv, n, 1, next_ok);
+            if (f == 1) {
+                h = gl_add(h, gl_inv(ctl_combine(d, cs, z.beta, z.gamma, lv, n, 1, next_ok)));
+            } else if (f != 0) {
+                *bad = 1;  // "Non-binary filter?" (cross_table_lookup.rs:741)
+            }
+        }
+        if (helpers) helpers[(size_t)j * n + row] = h;
+        total = gl_add(total, h);
+    }
+    hsum[row] = total;
+}
+
+// additive suffix scan, segments of 64:  totals[s] = sum of segment s
+__global__ void k_sum_totals(const gl_t* __restrict__ a, size_t m, gl_t* __restrict__ out) {
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t nseg = (m + 63) / 64;
+    if (s >= nseg) return;
+    size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
+    gl_t acc = 0;
+    for (size_t k = s * 64; k < end; k++) acc = gl_add(acc, a[k]);
+    out[s] = acc;
+}
+// S[k] = a[k] + S[k+1] inside each segment, carry-in = upper[s+1]
+__global__ void k_sum_scan(const gl_t* __restrict__ a, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ out) {
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t nseg = (m + 63) / 64;
+    if (s >= nseg) return;
+    gl_t acc = (upper && s + 1 < nupper) ? upper[s + 1] : 0;
+    size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
+    for (size_t k = end; k-- > s * 64;) {
+        acc = gl_add(acc, a[k]);
+        out[k] = acc;
+    }
+}
+
+// out[k] = sum_{m >= k} a[m]   (out may alias a)
+static void suffix_sum(zkm_ctx* c, const gl_t* a, size_t n, gl_t* out) {
+    struct level { gl_t* t; size_t m; };
+    std::vector<level> lv{{const_cast<gl_t*>(a), n}};
+    while (lv.back().m > 64) {
+        size_t nseg = (lv.back().m + 63) / 64;
+        gl_t* t = (gl_t*)c->alloc(nseg * sizeof(gl_t));
+        hipLaunchKernelGGL(k_sum_totals, dim3((nseg + 63) / 64), dim3(64), 0, c->stream, lv.back().t, lv.back().m, t);
+        lv.push_back({t, nseg});
+    }
+    std::vector<gl_t*> S(lv.size(), nullptr);
+    for (size_t l = lv.size(); l-- > 0;) {
+        size_t nseg = (lv[l].m + 63) / 64;
+        const gl_t* upper = l + 1 < lv.size() ? S[l + 1] : nullptr;
+        size_t nupper = l + 1 < lv.size() ? lv[l + 1].m : 0;
+        S[l] = l == 0 ? out : (gl_t*)c->alloc(lv[l].m * sizeof(gl_t));
+        hipLaunchKernelGGL(k_sum_scan, dim3((nseg + 63) / 64), dim3(64), 0, c->stream, lv[l].t, lv[l].m, upper, nupper, S[l]);
+    }
+    ZKM_HIP_CHECK(hipGetLastError());
+    c->sync();
+    for (size_t l = 1; l < lv.size(); l++) { c->release(lv[l].t); c->release(S[l]); }
+}
+
+// aux (device, naux x n) = helper columns (zs order) ++ Z columns
+void zkm_ctl_data_device(zkm_ctx* c, const ctl_dev_owner& own, const gl_t* d_trace, unsigned log_n, gl_t* d_aux) {
+    size_t n = (size_t)1 << log_n;
+    gl_t* d_hsum = (gl_t*)c->alloc(n * sizeof(gl_t));
+    int* d_bad = (int*)c->alloc(sizeof(int));
+    ZKM_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+    // host copy of num_helpers (the descriptor blob is on the device)
+    std::vector<zkm_ctl_z> zs(own.d.nzs);
+    if (own.d.nzs) ZKM_HIP_CHECK(hipMemcpyAsync(zs.data(), own.d.zs, own.d.nzs * sizeof(zkm_ctl_z), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    size_t hstart = 0;
+    for (uint32_t i = 0; i < own.d.nzs; i++) {
+        gl_t* helpers = zs[i].num_helpers ? d_aux + hstart * n : nullptr;
+        {
+            zkm_prof_scope ps(c, "ctl_terms");
+            hipLaunchKernelGGL(k_ctl_terms, dim3((n + 255) / 256), dim3(256), 0, c->stream, own.d, i, d_trace, n, helpers, d_hsum, d_bad);
+            ZKM_HIP_CHECK(hipGetLastError());
+        }
+        {
+            zkm_prof_scope ps(c, "ctl_suffix_sum");
+            suffix_sum(c, d_hsum, n, d_aux + ((size_t)own.d.total_helpers + i) * n);
+        }
+        hstart += zs[i].num_helpers;
+    }
+    int bad = 0;
+    ZKM_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    c->release(d_hsum);
+    c->release(d_bad);
+    if (bad) throw std::runtime_error("Non-binary filter?");
+}
+
+// ------------------------------------------------------------------ per-table CtlZData lists (cross_table_lookup_data order)
+struct table_zs {
+    std::vector<zkm_ctl_z> zs;
+    std::vector<uint32_t> ids;
+    size_t naux = 0;
+};
+static std::vector<table_zs> derive_zs(size_t ntables, const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls,
+                                       size_t nch, const uint64_t* challenges) {
+    std::vector<table_zs> out(ntables);
+    for (size_t c = 0; c < nctls; c++) {
+        const zkm_ctl_side* lk = sides + ctls[c].looking_off;
+        if (ctls[c].looked.table >= ntables) throw std::runtime_error("CTL: looked table index out of range");
+        // a table's looking entries must be consecutive (the reference groups consecutive runs, :807, but collects
+        // columns over all entries of the table, :656-671 -- the two only agree for consecutive entries)
+        for (uint32_t i = 0; i < ctls[c].nlooking; i++) {
+            if (lk[i].table >= ntables) throw std::runtime_error("CTL: looking table index out of range");
+            for (uint32_t j = i + 1; j < ctls[c].nlooking; j++)
+                if (lk[j].table == lk[i].table && lk[j - 1].table != lk[i].table)
+                    throw std::runtime_error("CTL: looking entries of one table must be consecutive");
+        }
+        for (size_t ch = 0; ch < nch; ch++) {
+            uint64_t beta = challenges ? challenges[2 * ch] : 0, gamma = challenges ? challenges[2 * ch + 1] : 0;
+            for (uint32_t i = 0; i < ctls[c].nlooking;) {
+                uint32_t j = i;
+                while (j < ctls[c].nlooking && lk[j].table == lk[i].table) j++;
+                table_zs& o = out[lk[i].table];
+                zkm_ctl_z z{};
+                z.ncolsets = j - i; z.colset_off = (uint32_t)o.ids.size(); z.beta = beta; z.gamma = gamma;
+                z.num_helpers = (j - i) > 1 ? (j - i + 1) / 2 : 0;
+                for (uint32_t k = i; k < j; k++) o.ids.push_back(lk[k].colset);
+                o.zs.push_back(z);
+                o.naux += z.num_helpers + 1;
+                i = j;
+            }
+            table_zs& o = out[ctls[c].looked.table];
+            zkm_ctl_z z{};
+            z.ncolsets = 1; z.colset_off = (uint32_t)o.ids.size(); z.beta = beta; z.gamma = gamma;
+            o.ids.push_back(ctls[c].looked.colset);
+            o.zs.push_back(z);
+            o.naux += 1;
+        }
+    }
+    return out;
+}
+
+static int fail(char** err, const std::string& msg) {
+    if (err) {
+        *err = (char*)malloc(msg.size() + 1);
+        if (*err) memcpy(*err, msg.c_str(), msg.size() + 1);
+    }
+    return 1;
+}
+
+extern "C" {
+
+int zkm_ctl_data(zkm_ctx* c, const zkm_ctl_table* table, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs,
+                 const uint64_t* trace, size_t ncols, unsigned log_n, uint64_t* aux_out, char** err) {
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        size_t n = (size_t)1 << log_n;
+        ctl_dev_owner own;
+        own.upload(c, table, zs, colset_ids, nzs);
+        for (size_t i = 0; i < (table ? table->nterms : 0); i++)
+            if (table->term_col[i] >= ncols) throw std::runtime_error("CTL description: trace column index out of range");
+        bool tdev = zkm_is_device_ptr(trace), adev = zkm_is_device_ptr(aux_out);
+        gl_t* d_trace = tdev ? const_cast<gl_t*>(trace) : (gl_t*)c->alloc(ncols * n * 8);
+        if (!tdev) ZKM_HIP_CHECK(hipMemcpyAsync(d_trace, trace, ncols * n * 8, hipMemcpyHostToDevice, c->stream));
+        gl_t* d_aux = adev ? aux_out : (gl_t*)c->alloc(own.naux * n * 8);
+        try {
+            zkm_ctl_data_device(c, own, d_trace, log_n, d_aux);
+            if (!adev) ZKM_HIP_CHECK(hipMemcpyAsync(aux_out, d_aux, own.naux * n * 8, hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+        } catch (...) {
+            (void)hipStreamSynchronize(c->stream);
+            if (!tdev) c->release(d_trace);
+            if (!adev) c->release(d_aux);
+            throw;
+        }
+        if (!tdev) c->release(d_trace);
+        if (!adev) c->release(d_aux);
+    } catch (const std::exception& e) {
+        return fail(err, e.what());
+    }
+    return 0;
+}
+
+size_t zkm_all_proof_words(const zkm_stark_config* cfg, const zkm_table_input* tables, size_t ntables,
+                           const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls, size_t* offs) {
+    try {
+        auto tz = derive_zs(ntables, ctls, sides, nctls, cfg->num_challenges, nullptr);
+        size_t total = 0;
+        for (size_t t = 0; t < ntables; t++) {
+            if (offs) offs[t] = total;
+            total += zkm_proof_words(cfg, tables[t].log_n, tables[t].ncols, tz[t].naux, tz[t].zs.size());
+        }
+        if (offs) offs[ntables] = total;
+        return total;
+    } catch (...) {
+        return 0;
+    }
+}
+
+int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_table_input* tables, size_t ntables,
+                          const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls, const uint64_t* pub,
+                          size_t npub, uint64_t* proofs, uint64_t* challenges, char** err) {
+    std::vector<zkm_batch*> commits(ntables, nullptr);
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (cfg->num_challenges > 4) throw std::runtime_error("too many challenges");
+        std::vector<size_t> offs(ntables + 1);
+        if (!zkm_all_proof_words(cfg, tables, ntables, ctls, sides, nctls, offs.data()) && ntables)
+            throw std::runtime_error("zkm_prove_with_traces: malformed cross-table lookups");
+        // "compute all trace commitments" prover.rs:144-167
+        zkm_challenger ch;
+        zkm_challenger_init(&ch);
+        for (size_t t = 0; t < ntables; t++) {
+            char* e = nullptr;
+            if (zkm_batch_commit_values(c, tables[t].trace, tables[t].ncols, tables[t].log_n, cfg->rate_bits, cfg->cap_height, &commits[t], &e)) {
+                std::string msg = e ? e : "commit failed";
+                free(e);
+                throw std::runtime_error(msg);
+            }
+            zkm_challenger_observe(&ch, commits[t]->cap.data(), commits[t]->cap.size());  // :182-185
+        }
+        zkm_challenger_observe(&ch, pub, npub);  // :187 observe_public_values
+        for (unsigned k = 0; k < cfg->num_challenges; k++) {  // :190, beta then gamma (cross_table_lookup.rs:560-566)
+            challenges[2 * k] = zkm_challenger_get(&ch);
+            challenges[2 * k + 1] = zkm_challenger_get(&ch);
+        }
+        auto tz = derive_zs(ntables, ctls, sides, nctls, cfg->num_challenges, challenges);
+        // "compute CTL data" :191-200 + "compute all proofs given commitments" :234-438: tables in order, one transcript
+        for (size_t t = 0; t < ntables; t++) {
+            size_t n = (size_t)1 << tables[t].log_n;
+            ctl_dev_owner own;
+            own.upload(c, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size());
+            bool tdev = zkm_is_device_ptr(tables[t].trace);
+            gl_t* d_trace = tdev ? const_cast<gl_t*>(tables[t].trace) : (gl_t*)c->alloc(tables[t].ncols * n * 8);
+            if (!tdev) ZKM_HIP_CHECK(hipMemcpyAsync(d_trace, tables[t].trace, tables[t].ncols * n * 8, hipMemcpyHostToDevice, c->stream));
+            gl_t* d_aux = (gl_t*)c->alloc((tz[t].naux ? tz[t].naux : 1) * n * 8);
+            int rc = 0;
+            char* e = nullptr;
+            try {
+                zkm_ctl_data_device(c, own, d_trace, tables[t].log_n, d_aux);
+                rc = zkm_prove_single_table_ctl(c, tables[t].table_id, cfg, nullptr, tables[t].ncols, tables[t].log_n, commits[t], d_aux,
+                                                tz[t].naux, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), &ch,
+                                                proofs + offs[t], &e);
+            } catch (...) {
+                (void)hipStreamSynchronize(c->stream);
+                if (!tdev) c->release(d_trace);
+                c->release(d_aux);
+                throw;
+            }
+            if (!tdev) c->release(d_trace);
+            c->release(d_aux);
+            if (rc) {
+                std::string msg = e ? e : "prove_single_table failed";
+                free(e);
+                throw std::runtime_error("table " + std::to_string(t) + ": " + msg);
+            }
+        }
+    } catch (const std::exception& e) {
+        for (auto b : commits) zkm_batch_free(b);
+        return fail(err, e.what());
+    }
+    for (auto b : commits) zkm_batch_free(b);
+    return 0;
+}
+
+}  // extern "C"

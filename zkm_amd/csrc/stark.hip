@@ -6,6 +6,7 @@
 // The Challenger stays on the host (a few hundred field elements per table); only caps, openings,
 // the final polynomial and the query openings cross PCIe.
 #include "poseidon_dev.h"
+#include "ctl_dev.h"
 #include "zkm_internal.h"
 
 // ------------------------------------------------------------------ proof layout (include/zkm_hip.h)
@@ -134,17 +135,57 @@ __device__ void eval_poseidon_constraints(const gl_t* __restrict__ lv, size_t cs
     for (int i = 0; i < 12; i++) k.constraint(gl_sub(s[i], lv[(size_t)(13 + i) * cs]));
 }
 
-struct ctl_desc {
-    uint32_t nctl, total_helpers;
-    uint32_t num_helpers[16];
-};
+// CTL checks driven by the column-set description (eval_helper_columns cross_table_lookup.rs:1006-1058,
+// eval_cross_table_lookup_checks :1067-1150).  The benchmark's fake CTL data (helper columns, no column sets)
+// is the ncolsets == 0 case: only the last-row / transition checks on Z are emitted.
+template <int NA>
+__device__ void eval_ctl_constraints(const ctl_dev& d, const gl_t* __restrict__ tl, size_t N, ptrdiff_t dnext,
+                                     const gl_t* __restrict__ aux, size_t j, size_t jn, consumer_t<NA>& k) {
+    uint32_t start = 0;
+    for (uint32_t i = 0; i < d.nzs; i++) {
+        const zkm_ctl_z z = d.zs[i];
+        const uint32_t* ids = d.colset_ids + z.colset_off;
+        gl_t local_z = aux[(size_t)(d.total_helpers + i) * N + j], next_z = aux[(size_t)(d.total_helpers + i) * N + jn];
+        if (z.num_helpers) {
+            for (uint32_t q = 0; 2 * q < z.ncolsets; q++) {
+                gl_t h = aux[(size_t)(start + q) * N + j];
+                const zkm_colset c0 = d.colsets[ids[2 * q]];
+                gl_t combin0 = ctl_combine(d, c0, z.beta, z.gamma, tl, N, dnext, true), f0 = ctl_eval_filter(d, c0, tl, N, dnext, true);
+                if (2 * q + 1 < z.ncolsets) {
+                    const zkm_colset c1 = d.colsets[ids[2 * q + 1]];
+                    gl_t combin1 = ctl_combine(d, c1, z.beta, z.gamma, tl, N, dnext, true), f1 = ctl_eval_filter(d, c1, tl, N, dnext, true);
+                    k.constraint(gl_sub(gl_sub(gl_mul(gl_mul(combin1, combin0), h), gl_mul(f0, combin1)), gl_mul(f1, combin0)));
+                } else {
+                    k.constraint(gl_sub(gl_mul(combin0, h), f0));
+                }
+            }
+            gl_t h_sum = 0;
+            for (uint32_t q = 0; q < z.num_helpers; q++) h_sum = gl_add(h_sum, aux[(size_t)(start + q) * N + j]);
+            k.last_row(gl_sub(local_z, h_sum));
+            k.transition(gl_sub(gl_sub(local_z, next_z), h_sum));
+        } else if (z.ncolsets > 1) {
+            const zkm_colset c0 = d.colsets[ids[0]], c1 = d.colsets[ids[1]];
+            gl_t combin0 = ctl_combine(d, c0, z.beta, z.gamma, tl, N, dnext, true), combin1 = ctl_combine(d, c1, z.beta, z.gamma, tl, N, dnext, true);
+            gl_t f0 = ctl_eval_filter(d, c0, tl, N, dnext, true), f1 = ctl_eval_filter(d, c1, tl, N, dnext, true);
+            gl_t cc = gl_mul(combin0, combin1), rhs = gl_add(gl_mul(f0, combin1), gl_mul(f1, combin0));
+            k.last_row(gl_sub(gl_mul(cc, local_z), rhs));
+            k.transition(gl_sub(gl_mul(cc, gl_sub(local_z, next_z)), rhs));
+        } else {
+            const zkm_colset c0 = d.colsets[ids[0]];
+            gl_t combin0 = ctl_combine(d, c0, z.beta, z.gamma, tl, N, dnext, true), f0 = ctl_eval_filter(d, c0, tl, N, dnext, true);
+            k.last_row(gl_sub(gl_mul(combin0, local_z), f0));
+            k.transition(gl_sub(gl_mul(combin0, gl_sub(local_z, next_z)), f0));
+        }
+        start += z.num_helpers;
+    }
+}
 
 // One thread per point of the quotient domain g<w_2n>, visited in LDE storage order: storage row j < 2n
 // of the 4n-row LDE is natural quotient index i = bitrev_{L-1}(j) (every `step` = 2nd natural LDE row,
 // prover.rs:668-675); "next" is natural +2 in the 2n domain (prover.rs:704) = +4 in the 4n domain.
 template <int NA>
 __global__ __launch_bounds__(256) void k_quotient_poseidon(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux,
-                                                           unsigned log_n, unsigned lde_bits, ctl_desc ctl, const gl_t* alphas,
+                                                           unsigned log_n, unsigned lde_bits, ctl_dev ctl, const gl_t* alphas,
                                                            const gl_t* __restrict__ wpow /* w_{4n}^t two-level table */,
                                                            gl_t gn, gl_t zh_inv0, gl_t zh_inv1, gl_t last, gl_t w_n, gl_t n_inv,
                                                            gl_t* __restrict__ out) {
@@ -174,38 +215,22 @@ __global__ __launch_bounds__(256) void k_quotient_poseidon(const gl_t* __restric
 
     eval_poseidon_constraints<NA>(trace + j, N, k);
 
-    // CTL checks, helper-column shape (no column sets): cross_table_lookup.rs:1111-1118
-    uint32_t start = 0;
-    for (uint32_t c = 0; c < ctl.nctl; c++) {
-        gl_t h_sum = 0;
-        for (uint32_t q = 0; q < ctl.num_helpers[c]; q++) h_sum = gl_add(h_sum, aux[(size_t)(start + q) * N + j]);
-        gl_t local_z = aux[(size_t)(ctl.total_helpers + c) * N + j], next_z = aux[(size_t)(ctl.total_helpers + c) * N + jn];
-        k.last_row(gl_sub(local_z, h_sum));
-        k.transition(gl_sub(gl_sub(local_z, next_z), h_sum));
-        start += ctl.num_helpers[c];
-    }
+    eval_ctl_constraints<NA>(ctl, trace + j, N, (ptrdiff_t)jn - (ptrdiff_t)j, aux, j, jn, k);
     gl_t zi = (i & 1) ? zh_inv1 : zh_inv0;
 #pragma unroll
     for (int a = 0; a < NA; a++) out[(size_t)a * size + i] = gl_mul(k.acc[a], zi);
 }
 
 // quotient polys: d_out = nalphas x 2n natural-order coefficients (device)
-static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_batch* aux, const uint32_t* num_helpers,
-                            size_t nctl, const gl_t* alphas_host, size_t nalphas, gl_t* d_out) {
+static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_batch* aux, const ctl_dev_owner& own,
+                            const gl_t* alphas_host, size_t nalphas, gl_t* d_out) {
     if (table_id != ZKM_TABLE_POSEIDON || trace->ncols != ZKM_POSEIDON_COLS)
         throw std::runtime_error("zkm_quotient: only the Poseidon table (262 columns) has a constraint kernel");
     if (trace->rate_bits != 2 || aux->rate_bits != 2 || trace->log_n != aux->log_n)
         throw std::runtime_error("zkm_quotient: rate_bits must be 2 and the batches must have equal degree");
     if (nalphas < 1 || nalphas > 2) throw std::runtime_error("zkm_quotient: 1 or 2 challenges supported");
-    if (nctl > 16) throw std::runtime_error("zkm_quotient: too many CTL Zs");
-    ctl_desc ctl{};
-    ctl.nctl = (uint32_t)nctl;
-    for (size_t i = 0; i < nctl; i++) {
-        if (num_helpers[i] == 0) throw std::runtime_error("zkm_quotient: CTLs without helper columns need column sets (not supported)");
-        ctl.num_helpers[i] = num_helpers[i];
-        ctl.total_helpers += num_helpers[i];
-    }
-    if (ctl.total_helpers + nctl != aux->ncols) throw std::runtime_error("zkm_quotient: aux column count does not match the CTL description");
+    if (own.naux != aux->ncols) throw std::runtime_error("zkm_quotient: aux column count does not match the CTL description");
+    const ctl_dev& ctl = own.d;
     unsigned log_n = trace->log_n, lde_bits = log_n + 2, log_q = log_n + 1;
     size_t size = (size_t)1 << log_q;
     gl_t w4 = gl_root_of_unity(lde_bits);
@@ -508,8 +533,8 @@ struct fri_layer {
 };
 
 static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
-                               const zkm_batch* trace_batch, const uint64_t* aux, size_t A, const uint32_t* num_helpers, size_t Z,
-                               zkm_challenger* ch, uint64_t* proof) {
+                               const zkm_batch* trace_batch, const uint64_t* aux, size_t A, const zkm_ctl_table* ctl_table,
+                               const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t Z, zkm_challenger* ch, uint64_t* proof) {
     if (cfg->rate_bits != 2 || cfg->arity_bits < 2 || cfg->arity_bits > 6 || cfg->pow_bits == 0 || cfg->pow_bits > 32)
         throw std::runtime_error("zkm_prove_single_table: unsupported FRI configuration");
     proof_layout y;
@@ -517,8 +542,13 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
     if (y.L > 8) throw std::runtime_error("too many FRI layers");
     size_t n = (size_t)1 << log_n, N = (size_t)1 << y.lde_bits;
     size_t total_helpers = 0;
-    for (size_t i = 0; i < Z; i++) total_helpers += num_helpers[i];
+    for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
     if (A == 0 || total_helpers + Z != A) throw std::runtime_error("No CTL? aux column count does not match the CTL description");  // prover.rs:509
+    ctl_dev_owner own;
+    own.upload(c, ctl_table, zs, colset_ids, Z);
+    if (ctl_table)
+        for (size_t i = 0; i < ctl_table->nterms; i++)
+            if (ctl_table->term_col[i] >= W) throw std::runtime_error("CTL description: trace column index out of range");
 
     memset(proof, 0, y.total * sizeof(uint64_t));
     proof[0] = ZKM_PROOF_MAGIC; proof[1] = log_n; proof[2] = W; proof[3] = A; proof[4] = y.Q; proof[5] = Z; proof[6] = y.cap;
@@ -563,7 +593,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
         // quotient :543-587
         gl_t* d_quot = (gl_t*)c->alloc(cfg->num_challenges * 2 * n * sizeof(gl_t));
         scratch.push_back(d_quot);
-        quotient_device(c, table_id, tb, ab, num_helpers, Z, alphas, cfg->num_challenges, d_quot);
+        quotient_device(c, table_id, tb, ab, own, alphas, cfg->num_challenges, d_quot);
         qb = new zkm_batch();
         qb->ctx = c; qb->ncols = y.Q; qb->log_n = log_n; qb->rate_bits = cfg->rate_bits; qb->cap_height = cfg->cap_height;
         zkm_batch_build(qb, d_quot, false);  // chunks [q0_lo, q0_hi, q1_lo, q1_hi] == d_quot viewed as Q columns of n
@@ -759,27 +789,53 @@ size_t zkm_proof_words(const zkm_stark_config* cfg, unsigned log_n, size_t ncols
     return y.total;
 }
 
-int zkm_prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t ncols, unsigned log_n,
-                           const zkm_batch* trace_batch, const uint64_t* aux, size_t naux, const uint32_t* num_helpers, size_t nctl_zs,
-                           zkm_challenger* challenger, uint64_t* proof_out, char** err) {
+// CtlZData of the benchmark's fake CTL shape: helper columns, no column sets (poseidon_stark.rs:786-799)
+static std::vector<zkm_ctl_z> fake_zs(const uint32_t* num_helpers, size_t n) {
+    std::vector<zkm_ctl_z> zs(n);
+    for (size_t i = 0; i < n; i++) {
+        if (num_helpers[i] == 0) throw std::runtime_error("CTLs without helper columns need column sets: use zkm_prove_single_table_ctl");
+        zs[i] = zkm_ctl_z{0, 0, num_helpers[i], 0, 0, 0};
+    }
+    return zs;
+}
+
+int zkm_prove_single_table_ctl(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t ncols, unsigned log_n,
+                               const zkm_batch* trace_batch, const uint64_t* aux, size_t naux, const zkm_ctl_table* table,
+                               const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, zkm_challenger* challenger,
+                               uint64_t* proof_out, char** err) {
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         if (!trace && !trace_batch) throw std::runtime_error("zkm_prove_single_table: need trace values or a trace commitment");
-        prove_single_table(c, table_id, cfg, trace, ncols, log_n, trace_batch, aux, naux, num_helpers, nctl_zs, challenger, proof_out);
+        prove_single_table(c, table_id, cfg, trace, ncols, log_n, trace_batch, aux, naux, table, zs, colset_ids, nzs, challenger, proof_out);
     } catch (const std::exception& e) {
         return fail(err, e.what());
     }
     return 0;
 }
 
+int zkm_prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t ncols, unsigned log_n,
+                           const zkm_batch* trace_batch, const uint64_t* aux, size_t naux, const uint32_t* num_helpers, size_t nctl_zs,
+                           zkm_challenger* challenger, uint64_t* proof_out, char** err) {
+    try {
+        auto zs = fake_zs(num_helpers, nctl_zs);
+        return zkm_prove_single_table_ctl(c, table_id, cfg, trace, ncols, log_n, trace_batch, aux, naux, nullptr, zs.data(), nullptr,
+                                          nctl_zs, challenger, proof_out, err);
+    } catch (const std::exception& e) {
+        return fail(err, e.what());
+    }
+}
+
 int zkm_quotient(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_batch* aux, const uint32_t* num_helpers, size_t nctl_zs,
                  const uint64_t* alphas, size_t nalphas, uint64_t* out_coeffs, char** err) {
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
+        auto zs = fake_zs(num_helpers, nctl_zs);
+        ctl_dev_owner own;
+        own.upload(c, nullptr, zs.data(), nullptr, nctl_zs);
         size_t words = nalphas * 2 * trace->n();
         bool dev = zkm_is_device_ptr(out_coeffs);
         gl_t* d = dev ? out_coeffs : (gl_t*)c->alloc(words * 8);
-        quotient_device(c, table_id, trace, aux, num_helpers, nctl_zs, alphas, nalphas, d);
+        quotient_device(c, table_id, trace, aux, own, alphas, nalphas, d);
         if (!dev) {
             ZKM_HIP_CHECK(hipMemcpyAsync(out_coeffs, d, words * 8, hipMemcpyDeviceToHost, c->stream));
             c->sync();
