@@ -167,6 +167,16 @@ typedef struct { uint32_t nlooking, looking_off; zkm_ctl_side looked; } zkm_cros
 int zkm_ctl_data(zkm_ctx* ctx, const zkm_ctl_table* table, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs,
                  const uint64_t* trace, size_t ncols, unsigned log_n, uint64_t* aux_out, char** err);
 
+/* a4: lookup_helper_columns (lookup.rs:46-124): logUp helper columns of one Lookup for one challenge --
+ *   h_j[i] = sum over the (<= 2) looking columns f of chunk j of filter_f[i] / (challenge + f[i]),
+ *   Z[0] = 0, Z[i+1] = Z[i] + sum_j h_j[i] - frequencies[i] / (challenge + table[i]).
+ * colset_ids: the nlookup looking columns as single-column sets (column + optional filter); table_col / freq_col:
+ * column indices of Lookup::table_column / frequencies_column.  out = (ceil(nlookup/2) + 1) x 2^log_n: helpers, then Z
+ * (the order prove_single_table appends them, prover.rs:480-493). */
+int zkm_lookup_helper_columns(zkm_ctx* ctx, const zkm_ctl_table* table, const uint32_t* colset_ids, size_t nlookup, uint32_t table_col,
+                              uint32_t freq_col, uint64_t challenge, const uint64_t* trace, size_t ncols, unsigned log_n,
+                              uint64_t* out, char** err);
+
 /* prove_single_table with real CTL data: like zkm_prove_single_table, the CtlZData described by (table, zs, colset_ids). */
 int zkm_prove_single_table_ctl(zkm_ctx* ctx, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t ncols,
                                unsigned log_n, const zkm_batch* trace_batch, const uint64_t* aux, size_t naux,

@@ -89,6 +89,33 @@ void zko_ctl_data(const zko_ctl_table* t, const zko_ctl_z* zs, const uint32_t* c
     free(hsum);
 }
 
+/* lookup_helper_columns lookup.rs:46-124: GrandProductChallenge{beta: 1, gamma: challenge} (:70-73), helper columns by
+ * get_helper_cols, table inverse :100-105, forward running sum Z with Z[0] = 0 (:111-121) */
+void zko_lookup_helper_columns(const zko_ctl_table* t, const uint32_t* colset_ids, size_t nlookup, uint32_t table_col, uint32_t freq_col,
+                               uint64_t challenge, const uint64_t* trace, size_t ncols, unsigned log_n, uint64_t* out) {
+    (void)ncols;
+    size_t n = (size_t)1 << log_n, nh = (nlookup + 1) / 2;
+    gl_t* term = (gl_t*)malloc(sizeof(gl_t) * n);
+    gl_t* hsum = (gl_t*)calloc(n, sizeof(gl_t));
+    for (size_t j = 0; j < nh; j++)
+        for (size_t e = 0; e < 2 && 2 * j + e < nlookup; e++) {
+            inverse_terms(t, &t->colsets[colset_ids[2 * j + e]], 1, challenge, trace, n, term);
+            for (size_t d = 0; d < n; d++) {
+                out[j * n + d] = e ? gl_add(out[j * n + d], term[d]) : term[d];
+                hsum[d] = gl_add(hsum[d], term[d]);
+            }
+        }
+    gl_t* z = out + nh * n;
+    z[0] = 0;
+    for (size_t i = 0; i + 1 < n; i++) {
+        gl_t tinv = gl_inv(gl_add(challenge, col_eval_table(t, table_col, trace, n, i)));
+        gl_t x = gl_sub(hsum[i], gl_mul(col_eval_table(t, freq_col, trace, n, i), tinv));
+        z[i + 1] = gl_add(z[i], x);
+    }
+    free(term);
+    free(hsum);
+}
+
 /* ---- per-table CtlZData lists of a set of cross-table lookups (cross_table_lookup_data order) ---- */
 typedef struct { zko_ctl_z* zs; uint32_t* ids; size_t nzs, nids, naux; } table_zs_t;
 

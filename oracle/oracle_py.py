@@ -212,6 +212,7 @@ class Oracle:
         L = self.lib
         vp = C.c_void_p
         L.zko_ctl_data.argtypes = [vp, vp, vp, C.c_size_t, u64p, C.c_size_t, C.c_uint, u64p]
+        L.zko_lookup_helper_columns.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, u64p, C.c_size_t, C.c_uint, u64p]
         L.zko_check_ctls.restype = C.c_int
         L.zko_check_ctls.argtypes = [vp, C.c_size_t, vp, vp, C.c_size_t]
         L.zko_prove_single_table_ctl.restype = C.c_int
@@ -236,6 +237,15 @@ class Oracle:
         self.lib.zko_ctl_data(C.addressof(st), zs.ctypes.data, colset_ids.ctypes.data, len(zs), _ptr(np.ascontiguousarray(trace)), ncols,
                               log_n, _ptr(aux))
         return aux
+
+    def lookup_helper_columns(self, ctl_table, colset_ids, table_col, freq_col, challenge, trace, ncols, log_n):
+        self._ctl_sigs()
+        ids = np.ascontiguousarray(colset_ids, dtype=np.uint32)
+        out = np.zeros(((len(ids) + 1) // 2 + 1) << log_n, dtype=np.uint64)
+        st = ctl_table.pack()
+        self.lib.zko_lookup_helper_columns(C.addressof(st), ids.ctypes.data, len(ids), table_col, freq_col, C.c_uint64(challenge),
+                                           _ptr(np.ascontiguousarray(trace)), ncols, log_n, _ptr(out))
+        return out
 
     def prove_ctl(self, trace, log_n, aux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS):
         self._ctl_sigs()

@@ -110,6 +110,9 @@ typedef struct { int table_id; const uint64_t* trace; size_t ncols; unsigned log
 
 void zko_ctl_data(const zko_ctl_table* t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, const uint64_t* trace,
                   size_t ncols, unsigned log_n, uint64_t* aux_out);
+/* lookup_helper_columns (lookup.rs:46-124); out = (ceil(nlookup/2) + 1) x n: helper columns then Z */
+void zko_lookup_helper_columns(const zko_ctl_table* t, const uint32_t* colset_ids, size_t nlookup, uint32_t table_col, uint32_t freq_col,
+                               uint64_t challenge, const uint64_t* trace, size_t ncols, unsigned log_n, uint64_t* out);
 /* check_ctls (cross_table_lookup.rs:1486-1581): 0 if every looking multiset equals its looked multiset */
 int zko_check_ctls(const zko_table_input* tables, size_t ntables, const zko_cross_table_lookup* ctls, const zko_ctl_side* sides, size_t nctls);
 int zko_prove_single_table_ctl(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t ncols, unsigned log_n,

@@ -108,3 +108,23 @@ def test_inconsistent_tables_fail_only_the_cross_table_check(ctx, oracle):
     proofs, chal, offs = ctx.prove_with_traces(tables2, ctls)
     rc = oracle.verify_all(tables2, ctls, proofs, chal)
     assert 50 <= rc < 60, rc
+
+
+@pytest.mark.parametrize("nlook", [1, 2, 5])
+def test_lookup_helper_columns_match_oracle(ctx, oracle, nlook):
+    # logUp helper columns (lookup.rs:46-124): parity on arbitrary looking / table / frequency columns
+    log_n = 10
+    trace = oracle.poseidon_trace(8, 700, log_n)
+    t = CtlTable()
+    sets = []
+    for i in range(nlook):
+        c = t.column(local=[(1 + i, 1), (14 + i, 3)], constant=i)
+        f = t.single(0) if i % 2 == 0 else None
+        sets.append(t.colset([c], filter_constants=[f] if f is not None else None))
+    table_col = t.column(local=[(30, 1)], next=[(31, 2)])
+    freq_col = t.single(40)
+    ch = 0xABCDEF0123456789 % P
+    got = ctx.lookup_helper_columns(t, sets, table_col, freq_col, ch, trace, 262, log_n)
+    want = oracle.lookup_helper_columns(t, sets, table_col, freq_col, ch, trace, 262, log_n)
+    assert got.size == ((nlook + 1) // 2 + 1) << log_n
+    assert (got == want).all()

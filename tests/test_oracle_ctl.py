@@ -100,3 +100,26 @@ def test_cross_table_sum_catches_inconsistent_tables(oracle):
     proofs, chal, offs = oracle.prove_with_traces(tables2, ctls)
     rc = oracle.verify_all(tables2, ctls, proofs, chal)
     assert 50 <= rc < 60, rc
+
+
+def test_lookup_helper_columns_definition(oracle):
+    # Z(1) = 0 and Z(gx) = Z(x) + sum h_i(x) - m(x) / (x + t(x))  (lookup.rs:40-44, 111-121)
+    log_n = 4
+    n = 1 << log_n
+    trace = oracle.poseidon_trace(9, 10, log_n)
+    cols = trace.reshape(262, n)
+    t = CtlTable()
+    s0 = t.colset([t.single(1)], filter_constants=[t.single(0)])
+    s1 = t.colset([t.single(2)])
+    s2 = t.colset([t.column(local=[(3, 2)], constant=1)])
+    tc, fc = t.single(5), t.single(0)
+    ch = 12345
+    out = oracle.lookup_helper_columns(t, [s0, s1, s2], tc, fc, ch, trace, 262, log_n).reshape(3, n)
+    inv = lambda x: pow(x % P, P - 2, P)
+    h0 = [((inv(ch + int(cols[1][d])) if cols[0][d] == 1 else 0) + inv(ch + int(cols[2][d]))) % P for d in range(n)]
+    h1 = [inv(ch + 2 * int(cols[3][d]) + 1) for d in range(n)]
+    assert [int(x) for x in out[0]] == h0 and [int(x) for x in out[1]] == h1
+    z = [0]
+    for i in range(n - 1):
+        z.append((z[-1] + h0[i] + h1[i] - int(cols[0][i]) * inv(ch + int(cols[5][i]))) % P)
+    assert [int(x) for x in out[2]] == z

@@ -27,7 +27,7 @@ EXPORTS = [
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
-    "zkm_prove_single_table", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_all_proof_words", "zkm_prove_with_traces",
+    "zkm_prove_single_table", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
     "zkm_quotient", "zkm_eval_openings", "zkm_profile_enable", "zkm_profile_reset",
     "zkm_profile_count", "zkm_profile_get", "zkm_version",
 ]
@@ -103,6 +103,8 @@ def load():
         "zkm_prove_single_table_ctl": (C.c_int, [cp, C.c_int, C.POINTER(StarkConfig), cp, C.c_size_t, C.c_uint, cp, cp, C.c_size_t,
                                                  cp, cp, cp, C.c_size_t, C.POINTER(Challenger), u64p, err]),
         "zkm_ctl_data": (C.c_int, [cp, cp, cp, cp, C.c_size_t, cp, C.c_size_t, C.c_uint, cp, err]),
+        "zkm_lookup_helper_columns": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, cp, C.c_size_t, C.c_uint, cp,
+                                                err]),
         "zkm_all_proof_words": (C.c_size_t, [C.POINTER(StarkConfig), cp, C.c_size_t, cp, cp, C.c_size_t, C.POINTER(C.c_size_t)]),
         "zkm_prove_with_traces": (C.c_int, [cp, C.POINTER(StarkConfig), cp, C.c_size_t, cp, cp, C.c_size_t, u64p, C.c_size_t, u64p,
                                             u64p, err]),
@@ -286,6 +288,16 @@ class Context:
         err = C.c_char_p()
         _check(self.L.zkm_ctl_data(self.h, C.addressof(st), zs.ctypes.data, colset_ids.ctypes.data, len(zs), _data_ptr(trace), ncols,
                                    log_n, _data_ptr(out), C.byref(err)), err)
+        return out
+
+    def lookup_helper_columns(self, ctl_table, colset_ids, table_col, freq_col, challenge, trace, ncols, log_n):
+        """lookup_helper_columns (lookup.rs:46-124) for one Lookup and one challenge: helper columns then Z."""
+        ids = np.ascontiguousarray(colset_ids, dtype=np.uint32)
+        out = np.zeros(((len(ids) + 1) // 2 + 1) << log_n, dtype=np.uint64)
+        st = ctl_table.pack()
+        err = C.c_char_p()
+        _check(self.L.zkm_lookup_helper_columns(self.h, C.addressof(st), ids.ctypes.data, len(ids), table_col, freq_col, challenge,
+                                                _data_ptr(trace), ncols, log_n, _np_ptr(out), C.byref(err)), err)
         return out
 
     def prove_single_table_ctl(self, trace, log_n, aux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS,

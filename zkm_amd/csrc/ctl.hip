@@ -8,14 +8,14 @@
 #include "ctl_dev.h"
 
 // ------------------------------------------------------------------ descriptor upload + validation
-void ctl_dev_owner::upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs) {
+void ctl_dev_owner::upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, bool lookup_mode) {
     c = ctx;
     static const zkm_ctl_table empty{};
     if (!t) t = &empty;
     size_t nids = 0, th = 0;
     for (size_t i = 0; i < nzs; i++) {
         if ((size_t)zs[i].colset_off + zs[i].ncolsets > nids) nids = (size_t)zs[i].colset_off + zs[i].ncolsets;
-        uint32_t want = zs[i].ncolsets > 1 ? (zs[i].ncolsets + 1) / 2 : 0;
+        uint32_t want = (zs[i].ncolsets > 1 || lookup_mode) ? (zs[i].ncolsets + 1) / 2 : 0;
         if (zs[i].ncolsets == 0) {
             if (zs[i].num_helpers == 0) throw std::runtime_error("CTL description: a Z without column sets needs helper columns");
         } else if (zs[i].num_helpers != want) {
@@ -147,6 +147,22 @@ static void suffix_sum(zkm_ctx* c, const gl_t* a, size_t n, gl_t* out) {
     for (size_t l = 1; l < lv.size(); l++) { c->release(lv[l].t); c->release(S[l]); }
 }
 
+// logUp: x[i] = hsum[i] - frequencies[i] / (challenge + table[i])   (lookup.rs:100-116)
+__global__ __launch_bounds__(256) void k_lookup_x(ctl_dev d, uint32_t table_col, uint32_t freq_col, gl_t challenge,
+                                                  const gl_t* __restrict__ trace, size_t n, const gl_t* __restrict__ hsum,
+                                                  gl_t* __restrict__ x) {
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    bool next_ok = row + 1 < n;
+    gl_t tinv = gl_inv(gl_add(challenge, ctl_eval_column(d, table_col, trace + row, n, 1, next_ok)));
+    x[row] = gl_sub(hsum[row], gl_mul(ctl_eval_column(d, freq_col, trace + row, n, 1, next_ok), tinv));
+}
+// exclusive prefix sum from the suffix sums: z[k] = S[0] - S[k]
+__global__ __launch_bounds__(256) void k_prefix_from_suffix(const gl_t* __restrict__ S, size_t n, gl_t* __restrict__ z) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) z[k] = gl_sub(S[0], S[k]);
+}
+
 // aux (device, naux x n) = helper columns (zs order) ++ Z columns
 void zkm_ctl_data_device(zkm_ctx* c, const ctl_dev_owner& own, const gl_t* d_trace, unsigned log_n, gl_t* d_aux) {
     size_t n = (size_t)1 << log_n;
@@ -260,6 +276,61 @@ int zkm_ctl_data(zkm_ctx* c, const zkm_ctl_table* table, const zkm_ctl_z* zs, co
         if (!tdev) c->release(d_trace);
         if (!adev) c->release(d_aux);
     } catch (const std::exception& e) {
+        return fail(err, e.what());
+    }
+    return 0;
+}
+
+int zkm_lookup_helper_columns(zkm_ctx* c, const zkm_ctl_table* table, const uint32_t* colset_ids, size_t nlookup, uint32_t table_col,
+                              uint32_t freq_col, uint64_t challenge, const uint64_t* trace, size_t ncols, unsigned log_n,
+                              uint64_t* out, char** err) {
+    std::vector<void*> tmp;
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!table || nlookup == 0) throw std::runtime_error("zkm_lookup_helper_columns: empty lookup");
+        if (table_col >= table->ncolumns || freq_col >= table->ncolumns) throw std::runtime_error("lookup: column index out of range");
+        if (challenge >= GL_P) throw std::runtime_error("lookup: non-canonical challenge");
+        for (size_t i = 0; i < table->nterms; i++)
+            if (table->term_col[i] >= ncols) throw std::runtime_error("CTL description: trace column index out of range");
+        size_t n = (size_t)1 << log_n, nh = (nlookup + 1) / 2;
+        for (size_t i = 0; i < nlookup; i++)
+            if (colset_ids[i] < table->ncolsets && table->colsets[colset_ids[i]].ncols != 1)
+                throw std::runtime_error("lookup: every looking entry must be a single-column set");
+        zkm_ctl_z z{(uint32_t)nlookup, 0, (uint32_t)nh, 0, 1, challenge};  // GrandProductChallenge{beta: 1, gamma: challenge}
+        ctl_dev_owner own;
+        own.upload(c, table, &z, colset_ids, 1, /*lookup_mode=*/true);
+        bool tdev = zkm_is_device_ptr(trace), odev = zkm_is_device_ptr(out);
+        gl_t* d_trace = tdev ? const_cast<gl_t*>(trace) : (gl_t*)c->alloc(ncols * n * 8);
+        if (!tdev) { tmp.push_back(d_trace); ZKM_HIP_CHECK(hipMemcpyAsync(d_trace, trace, ncols * n * 8, hipMemcpyHostToDevice, c->stream)); }
+        gl_t* d_out = odev ? out : (gl_t*)c->alloc((nh + 1) * n * 8);
+        if (!odev) tmp.push_back(d_out);
+        gl_t* d_hsum = (gl_t*)c->alloc(n * 8);
+        tmp.push_back(d_hsum);
+        gl_t* d_x = (gl_t*)c->alloc(n * 8);
+        tmp.push_back(d_x);
+        int* d_bad = (int*)c->alloc(sizeof(int));
+        tmp.push_back(d_bad);
+        ZKM_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+        {
+            zkm_prof_scope ps(c, "lookup_terms");
+            hipLaunchKernelGGL(k_ctl_terms, dim3((n + 255) / 256), dim3(256), 0, c->stream, own.d, 0u, d_trace, n, d_out, d_hsum, d_bad);
+            hipLaunchKernelGGL(k_lookup_x, dim3((n + 255) / 256), dim3(256), 0, c->stream, own.d, table_col, freq_col, challenge, d_trace, n,
+                               d_hsum, d_x);
+            ZKM_HIP_CHECK(hipGetLastError());
+        }
+        suffix_sum(c, d_x, n, d_hsum);
+        hipLaunchKernelGGL(k_prefix_from_suffix, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_hsum, n, d_out + nh * n);
+        ZKM_HIP_CHECK(hipGetLastError());
+        int bad = 0;
+        ZKM_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        if (!odev) ZKM_HIP_CHECK(hipMemcpyAsync(out, d_out, (nh + 1) * n * 8, hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+        for (void* p : tmp) c->release(p);
+        tmp.clear();
+        if (bad) throw std::runtime_error("Non-binary filter?");
+    } catch (const std::exception& e) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* p : tmp) c->release(p);
         return fail(err, e.what());
     }
     return 0;

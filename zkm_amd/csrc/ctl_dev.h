@@ -55,6 +55,7 @@ struct ctl_dev_owner {
     void* blob = nullptr;
     ctl_dev d{};
     size_t naux = 0;
-    void upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs);
+    // lookup_mode: logUp lookups keep a helper column even for a single looking column (lookup.rs:34-38)
+    void upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, bool lookup_mode = false);
     ~ctl_dev_owner();
 };
