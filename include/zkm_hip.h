@@ -201,6 +201,13 @@ int zkm_prove_with_traces(zkm_ctx* ctx, const zkm_stark_config* cfg, const zkm_t
                           const uint64_t* public_values, size_t npublic, uint64_t* proofs_out, uint64_t* ctl_challenges_out,
                           char** err);
 
+/* a10 alone (BASELINE config 4): PolynomialBatch::prove_openings (call site prover.rs:618-628) for the STARK FRI
+ * instance (stark.rs:91-148: batches at zeta, g*zeta and 1 over the trace / auxiliary / quotient oracles) on three
+ * existing commitments.  Transcript: compact, zeta <- challenger, openings observed (proof.rs:336-367), prove_openings.
+ * The last nctl_zs auxiliary polynomials are the ones opened at 1.  Output: the usual proof blob. */
+int zkm_prove_openings(zkm_ctx* ctx, const zkm_stark_config* cfg, const zkm_batch* trace_batch, const zkm_batch* aux_batch,
+                       const zkm_batch* quot_batch, size_t nctl_zs, zkm_challenger* challenger, uint64_t* proof_out, char** err);
+
 /* ------------------------------------------------------------------ stage entry points (parity / reuse)
  * a6: compute_quotient_polys (prover.rs:645-789): nalphas polys of 2n coefficients, natural order;
  * out host or device. */

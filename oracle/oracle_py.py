@@ -312,6 +312,25 @@ class Oracle:
         return self.lib.zko_verify_all(C.byref(cfg), tarr, len(tables), carr.ctypes.data, sides.ctypes.data, len(carr), _ptr(pub),
                                        pub.size, _ptr(np.ascontiguousarray(proofs)), _ptr(np.ascontiguousarray(challenges)))
 
+    def prove_openings(self, tb, ab, qb, nctl_zs, challenger=None, cfg=None):
+        cfg = cfg or self.standard_config()
+        ch = challenger or Challenger()
+        self.lib.zko_prove_openings.restype = C.c_int
+        self.lib.zko_prove_openings.argtypes = [C.POINTER(StarkConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                C.POINTER(Challenger), u64p]
+        proof = np.zeros(self.proof_words(cfg, tb.log_n, tb.ncols, ab.ncols, nctl_zs), dtype=np.uint64)
+        rc = self.lib.zko_prove_openings(C.byref(cfg), tb.h, ab.h, qb.h, nctl_zs, C.byref(ch), _ptr(proof))
+        if rc:
+            raise RuntimeError("oracle prove_openings failed: %d" % rc)
+        return proof
+
+    def verify_openings(self, proof, ncols, naux, nctl_zs, challenger=None, cfg=None):
+        cfg = cfg or self.standard_config()
+        ch = challenger or Challenger()
+        self.lib.zko_verify_openings.restype = C.c_int
+        self.lib.zko_verify_openings.argtypes = [C.POINTER(StarkConfig), u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(Challenger)]
+        return self.lib.zko_verify_openings(C.byref(cfg), _ptr(np.ascontiguousarray(proof)), ncols, naux, nctl_zs, C.byref(ch))
+
     # ---- challenger
     def challenger(self):
         ch = Challenger()

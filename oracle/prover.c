@@ -294,6 +294,17 @@ typedef struct {
 static int prove_generic(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
                          const uint64_t* aux, size_t A, const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids,
                          size_t Z, zko_challenger* ch, uint64_t* proof, double* stage_s);
+static int prove_generic_ex(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
+                            const uint64_t* aux, size_t A, const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids,
+                            size_t Z, zko_challenger* ch, uint64_t* proof, double* stage_s, zko_batch* tb_in, zko_batch* ab_in,
+                            zko_batch* qb_in);
+
+/* prove_openings alone on three existing commitments (BASELINE config 4): compact, zeta, openings, FRI */
+int zko_prove_openings(const zko_stark_config* cfg, zko_batch* tb, zko_batch* ab, zko_batch* qb, size_t Z, zko_challenger* ch,
+                       uint64_t* proof) {
+    return prove_generic_ex(-1, cfg, NULL, zko_batch_ncols(tb), zko_batch_log_n(tb), NULL, zko_batch_ncols(ab), NULL, NULL, NULL, Z, ch,
+                            proof, NULL, tb, ab, qb);
+}
 
 int zko_prove_single_table(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
                            const uint64_t* aux, size_t A, const uint32_t* num_helpers, size_t Z,
@@ -313,12 +324,26 @@ int zko_prove_single_table_ctl(int table_id, const zko_stark_config* cfg, const 
 static int prove_generic(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
                          const uint64_t* aux, size_t A, const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids,
                          size_t Z, zko_challenger* ch, uint64_t* proof, double* stage_s) {
-    if (table_id != ZKO_TABLE_POSEIDON || W != ZKO_POSEIDON_COLS || cfg->num_challenges > 4) return -1;
+    return prove_generic_ex(table_id, cfg, trace, W, log_n, aux, A, ctl_t, zs, colset_ids, Z, ch, proof, stage_s, NULL, NULL, NULL);
+}
+
+static int prove_generic_ex(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
+                            const uint64_t* aux, size_t A, const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids,
+                            size_t Z, zko_challenger* ch, uint64_t* proof, double* stage_s, zko_batch* tb_in, zko_batch* ab_in,
+                            zko_batch* qb_in) {
+    const int openings_only = tb_in != NULL;
+    if (!openings_only && (table_id != ZKO_TABLE_POSEIDON || W != ZKO_POSEIDON_COLS)) return -1;
+    if (cfg->num_challenges > 4) return -1;
     layout_t y;
     layout(&y, cfg, log_n, W, A, Z);
     size_t n = (size_t)1 << log_n, N = (size_t)1 << y.lde_bits;
     size_t total_helpers = 0;
-    for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
+    if (openings_only) {
+        if (Z > A || zko_batch_ncols(qb_in) != y.Q || zko_batch_log_n(ab_in) != log_n || zko_batch_log_n(qb_in) != log_n) return -3;
+        total_helpers = A - Z;
+    } else {
+        for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
+    }
     if (total_helpers + Z != A) return -3;
     double t0, ts[8] = {0};
 
@@ -326,34 +351,40 @@ static int prove_generic(int table_id, const zko_stark_config* cfg, const uint64
     proof[0] = 0x5a4b4d50524f4f46ULL; proof[1] = log_n; proof[2] = W; proof[3] = A; proof[4] = y.Q; proof[5] = Z;
     proof[6] = y.cap; proof[7] = y.L; proof[8] = y.F; proof[9] = y.nq; proof[10] = cfg->rate_bits; proof[11] = cfg->arity_bits;
 
-    /* trace commitment (done by the caller in the reference, prover.rs:144-167 / poseidon_stark.rs:766-777) */
-    t0 = now_s();
-    zko_batch* tb = zko_batch_from_values(trace, W, log_n, cfg->rate_bits, cfg->cap_height);
-    ts[0] = now_s() - t0;
-
-    zko_challenger_compact(ch, proof + y.o_init);                                   /* :466 */
-
-    t0 = now_s();
-    zko_batch* ab = zko_batch_from_values(aux, A, log_n, cfg->rate_bits, cfg->cap_height); /* :511-522 */
-    ts[1] = now_s() - t0;
+    zko_batch *tb = tb_in, *ab = ab_in, *qb = qb_in;
     uint64_t* caps = proof + y.o_caps;
+    if (!openings_only) {
+        /* trace commitment (done by the caller in the reference, prover.rs:144-167 / poseidon_stark.rs:766-777) */
+        t0 = now_s();
+        tb = zko_batch_from_values(trace, W, log_n, cfg->rate_bits, cfg->cap_height);
+        ts[0] = now_s() - t0;
+    }
+    zko_challenger_compact(ch, proof + y.o_init);                                   /* :466 */
     zko_batch_cap(tb, caps);
-    zko_batch_cap(ab, caps + y.C * 4);
-    zko_challenger_observe(ch, caps + y.C * 4, y.C * 4);                            /* :525 */
-    gl_t alphas[4];
-    for (unsigned i = 0; i < cfg->num_challenges; i++) alphas[i] = zko_challenger_get(ch); /* :527 */
+    if (!openings_only) {
+        t0 = now_s();
+        ab = zko_batch_from_values(aux, A, log_n, cfg->rate_bits, cfg->cap_height); /* :511-522 */
+        ts[1] = now_s() - t0;
+        zko_batch_cap(ab, caps + y.C * 4);
+        zko_challenger_observe(ch, caps + y.C * 4, y.C * 4);                            /* :525 */
+        gl_t alphas[4];
+        for (unsigned i = 0; i < cfg->num_challenges; i++) alphas[i] = zko_challenger_get(ch); /* :527 */
 
-    t0 = now_s();
-    gl_t* quot = (gl_t*)malloc(sizeof(gl_t) * cfg->num_challenges * 2 * n);
-    quotient_generic(tb, ab, ctl_t, zs, colset_ids, Z, alphas, cfg->num_challenges, quot);  /* :543-559 */
-    ts[2] = now_s() - t0;
-    /* chunks of n coefficients: [q0_lo, q0_hi, q1_lo, q1_hi] == quot viewed as Q columns of n (:560-575) */
-    t0 = now_s();
-    zko_batch* qb = zko_batch_from_coeffs(quot, y.Q, log_n, cfg->rate_bits, cfg->cap_height); /* :576-587 */
-    ts[3] = now_s() - t0;
-    free(quot);
-    zko_batch_cap(qb, caps + 2 * y.C * 4);
-    zko_challenger_observe(ch, caps + 2 * y.C * 4, y.C * 4);                        /* :589 */
+        t0 = now_s();
+        gl_t* quot = (gl_t*)malloc(sizeof(gl_t) * cfg->num_challenges * 2 * n);
+        quotient_generic(tb, ab, ctl_t, zs, colset_ids, Z, alphas, cfg->num_challenges, quot);  /* :543-559 */
+        ts[2] = now_s() - t0;
+        /* chunks of n coefficients: [q0_lo, q0_hi, q1_lo, q1_hi] == quot viewed as Q columns of n (:560-575) */
+        t0 = now_s();
+        qb = zko_batch_from_coeffs(quot, y.Q, log_n, cfg->rate_bits, cfg->cap_height); /* :576-587 */
+        ts[3] = now_s() - t0;
+        free(quot);
+        zko_batch_cap(qb, caps + 2 * y.C * 4);
+        zko_challenger_observe(ch, caps + 2 * y.C * 4, y.C * 4);                        /* :589 */
+    } else {
+        zko_batch_cap(ab, caps + y.C * 4);
+        zko_batch_cap(qb, caps + 2 * y.C * 4);
+    }
 
     gl2_t zeta = challenger_get_ext(ch);                                            /* :591 */
     gl_t g = gl_root_of_unity(log_n);
@@ -523,9 +554,11 @@ static int prove_generic(int table_id, const zko_stark_config* cfg, const uint64
     free(layers);
     free(coeffs);
     free(fin);
-    zko_batch_free(tb);
-    zko_batch_free(ab);
-    zko_batch_free(qb);
+    if (!openings_only) {
+        zko_batch_free(tb);
+        zko_batch_free(ab);
+        zko_batch_free(qb);
+    }
     if (stage_s) memcpy(stage_s, ts, sizeof ts);
     return 0;
 }
@@ -579,6 +612,11 @@ static gl2_t compute_evaluation(gl_t x, size_t x_in_coset, unsigned arity_bits, 
 static int verify_generic(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
                           const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t Z, zko_challenger* ch);
 
+/* verifier of zko_prove_openings: transcript replay + verify_fri_proof, no constraint check */
+int zko_verify_openings(const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A, size_t Z, zko_challenger* ch) {
+    return verify_generic(-1, cfg, proof, W, A, NULL, NULL, NULL, Z, ch);
+}
+
 int zko_verify_single_table(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
                             const uint32_t* num_helpers, size_t Z, zko_challenger* ch) {
     zko_ctl_z* zs = fake_zs(num_helpers, Z);
@@ -594,7 +632,8 @@ int zko_verify_single_table_ctl(int table_id, const zko_stark_config* cfg, const
 
 static int verify_generic(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
                           const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t Z, zko_challenger* ch) {
-    if (table_id != ZKO_TABLE_POSEIDON || W != ZKO_POSEIDON_COLS) return 1;
+    const int openings_only = table_id < 0;
+    if (!openings_only && (table_id != ZKO_TABLE_POSEIDON || W != ZKO_POSEIDON_COLS)) return 1;
     if (proof[0] != 0x5a4b4d50524f4f46ULL) return 2;
     unsigned log_n = (unsigned)proof[1];
     layout_t y;
@@ -604,7 +643,8 @@ static int verify_generic(int table_id, const zko_stark_config* cfg, const uint6
         return 3; /* validate_proof_shape verifier.rs:294-342 */
     size_t N = (size_t)1 << y.lde_bits;
     size_t total_helpers = 0;
-    for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
+    if (openings_only) total_helpers = A - Z;
+    else for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
     if (total_helpers + Z != A) return 3;
     size_t arity = (size_t)1 << cfg->arity_bits;
 
@@ -616,10 +656,12 @@ static int verify_generic(int table_id, const zko_stark_config* cfg, const uint6
 
     const uint64_t* caps = proof + y.o_caps;
     /* get_challenges.rs:190-233 */
-    zko_challenger_observe(ch, caps + y.C * 4, y.C * 4);
-    gl_t alphas[4];
-    for (unsigned i = 0; i < cfg->num_challenges; i++) alphas[i] = zko_challenger_get(ch);
-    zko_challenger_observe(ch, caps + 2 * y.C * 4, y.C * 4);
+    gl_t alphas[4] = {0};
+    if (!openings_only) {
+        zko_challenger_observe(ch, caps + y.C * 4, y.C * 4);
+        for (unsigned i = 0; i < cfg->num_challenges; i++) alphas[i] = zko_challenger_get(ch);
+        zko_challenger_observe(ch, caps + 2 * y.C * 4, y.C * 4);
+    }
     gl2_t zeta = challenger_get_ext(ch);
     const uint64_t* op = proof + y.o_open;
     const uint64_t *o_local = op, *o_next = op + 2 * W, *o_aux = op + 4 * W, *o_auxn = o_aux + 2 * A, *o_ctl = o_auxn + 2 * A,
@@ -661,9 +703,11 @@ static int verify_generic(int table_id, const zko_stark_config* cfg, const uint6
     k.z_last = gl2_sub(zeta, gl2_from_base(gl_inv(g)));
     k.l_first = gl2_mul(z_h, gl2_inv(d0));
     k.l_last = gl2_mul(z_h, gl2_inv(d1));
-    e_eval_poseidon(lv, &k);
-    e_eval_ctl_general(ctl_t, zs, colset_ids, Z, lv, nv, av, an, &k);
-    for (unsigned i = 0; i < cfg->num_challenges; i++) {
+    if (!openings_only) {
+        e_eval_poseidon(lv, &k);
+        e_eval_ctl_general(ctl_t, zs, colset_ids, Z, lv, nv, av, an, &k);
+    }
+    for (unsigned i = 0; i < cfg->num_challenges && !openings_only; i++) {
         gl2_t t0 = gl2_make(o_quot[4 * i], o_quot[4 * i + 1]), t1 = gl2_make(o_quot[4 * i + 2], o_quot[4 * i + 3]);
         gl2_t rhs = gl2_mul(z_h, gl2_add(t0, gl2_mul(t1, zeta_n)));
         if (!gl2_eq(k.acc[i], rhs)) { free(lv); return 10; }

@@ -131,6 +131,11 @@ int zko_verify_all(const zko_stark_config* cfg, const zko_table_input* tables, s
                    const zko_cross_table_lookup* ctls, const zko_ctl_side* sides, size_t nctls,
                    const uint64_t* public_values, size_t npublic, const uint64_t* proofs, const uint64_t* ctl_challenges);
 
+/* prove_openings alone on three existing commitments (BASELINE config 4) and its verifier (FRI only) */
+int zko_prove_openings(const zko_stark_config* cfg, zko_batch* tb, zko_batch* ab, zko_batch* qb, size_t nctl_zs, zko_challenger* ch,
+                       uint64_t* proof);
+int zko_verify_openings(const zko_stark_config* cfg, const uint64_t* proof, size_t ncols, size_t naux, size_t nctl_zs, zko_challenger* ch);
+
 /* quotient stage alone (for stage-level parity): out = num_challenges*2 chunk polys... returns the
  * num_challenges quotient polys of 2n coefficients each (natural order). */
 void zko_quotient_poseidon(const zko_batch* trace, const zko_batch* aux, const uint32_t* num_helpers, size_t nctl_zs,

@@ -127,3 +127,51 @@ def test_bad_arguments(ctx, zkm):
         ctx.prove_single_table(np.zeros(262 * n, dtype=np.uint64), 5, np.zeros(3 * n, dtype=np.uint64), [1, 1])
     with pytest.raises(zkm.ZkmError):
         ctx.prove_single_table(np.zeros(100 * n, dtype=np.uint64), 5, np.zeros(4 * n, dtype=np.uint64), [1, 1], ncols=100)
+
+
+@pytest.mark.parametrize("log_n", [5, 9, 13])
+def test_prove_openings_alone_is_bit_exact(ctx, zkm, oracle, log_n):
+    # BASELINE config 4 shape (13 + 4 + 4 polynomials, random), small sizes: GPU == oracle bytes, FRI verifies
+    rng = np.random.default_rng(40 + log_n)
+    n = 1 << log_n
+    tv, av, qc = (rng.integers(0, P, k * n, dtype=np.uint64) for k in (13, 4, 4))
+    otb, oab, oqb = oracle.batch_from_values(tv, 13, log_n), oracle.batch_from_values(av, 4, log_n), oracle.batch_from_coeffs(qc, 4, log_n)
+    tb, ab = zkm.PolynomialBatch.from_values(ctx, tv, 13, log_n), zkm.PolynomialBatch.from_values(ctx, av, 4, log_n)
+    qb = zkm.PolynomialBatch.from_coeffs(ctx, qc, 4, log_n)
+    och, ch = oracle.challenger(), zkm.challenger_new()
+    oracle.observe(och, [42])
+    zkm.challenger_observe(ch, [42])
+    want = oracle.prove_openings(otb, oab, oqb, 2, challenger=och)
+    got = ctx.prove_openings(tb, ab, qb, 2, challenger=ch)
+    assert (got == want).all()
+    vch = oracle.challenger()
+    oracle.observe(vch, [42])
+    assert oracle.verify_openings(got, 13, 4, 2, challenger=vch) == 0
+    for b in (tb, ab, qb):
+        b.free()
+
+
+def test_full_fri_on_2_22_rows_verifies(ctx, zkm, oracle):
+    # BASELINE config 4: full FRI commit + fold on a 2^22-row trace (13 columns + 4 aux + 4 quotient chunks):
+    # final polynomial 2^22 F2 coefficients, LDE 2^24, folds [4,4,4,4,4], final poly 4 coefficients
+    log_n = 22
+    n = 1 << log_n
+    rng = np.random.default_rng(4)
+    def dev_random(cols):
+        buf = ctx.alloc(cols * n)
+        buf.upload(rng.integers(0, P, cols * n, dtype=np.uint64))
+        return buf
+    tvals, avals, qco = dev_random(13), dev_random(4), dev_random(4)
+    tb = zkm.PolynomialBatch.from_values(ctx, tvals, 13, log_n)
+    ab = zkm.PolynomialBatch.from_values(ctx, avals, 4, log_n)
+    qb = zkm.PolynomialBatch.from_coeffs(ctx, qco, 4, log_n)
+    proof = ctx.prove_openings(tb, ab, qb, 2)
+    assert int(proof[7]) == 5 and int(proof[8]) == 4  # 5 FRI layers, 4 final coefficients
+    assert oracle.verify_openings(proof, 13, 4, 2) == 0
+    bad = proof.copy()
+    bad[-5] ^= 1
+    assert oracle.verify_openings(bad, 13, 4, 2) != 0
+    for b in (tb, ab, qb):
+        b.free()
+    for b in (tvals, avals, qco):
+        b.free()

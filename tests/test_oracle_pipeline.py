@@ -101,3 +101,22 @@ def test_transcript_chaining(oracle):
     oracle.observe(ch2, [1, 2, 3])
     assert oracle.verify(proof, 4, [1, 1], challenger=ch2) == 0
     assert oracle.verify(proof, 4, [1, 1], challenger=oracle.challenger()) != 0
+
+
+def test_prove_openings_alone_then_verify(oracle):
+    # BASELINE config 4 shape at a small size: 13 trace columns (MemoryStark width), 4 aux (2 CTL Zs), 4 quotient chunks of
+    # seeded random polynomials; prove_openings on the three commitments, FRI-only verification
+    rng = np.random.default_rng(44)
+    for log_n in (5, 8):
+        n = 1 << log_n
+        tb = oracle.batch_from_values(rng.integers(0, P, 13 * n, dtype=np.uint64), 13, log_n)
+        ab = oracle.batch_from_values(rng.integers(0, P, 4 * n, dtype=np.uint64), 4, log_n)
+        qb = oracle.batch_from_coeffs(rng.integers(0, P, 4 * n, dtype=np.uint64), 4, log_n)
+        proof = oracle.prove_openings(tb, ab, qb, 2)
+        assert oracle.verify_openings(proof, 13, 4, 2) == 0
+        # (the caps are not part of this truncated transcript, so a cap entry no query lands in is unconstrained here;
+        #  in prove_single_table every cap is observed.  Tamper from the openings onwards.)
+        for pos in rng.integers(16 + 12 + 3 * 64, proof.size, 8):
+            bad = proof.copy()
+            bad[pos] = (int(bad[pos]) + 1) % P
+            assert oracle.verify_openings(bad, 13, 4, 2) != 0

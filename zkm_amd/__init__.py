@@ -27,7 +27,7 @@ EXPORTS = [
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
-    "zkm_prove_single_table", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
+    "zkm_prove_single_table", "zkm_prove_openings", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
     "zkm_quotient", "zkm_eval_openings", "zkm_profile_enable", "zkm_profile_reset",
     "zkm_profile_count", "zkm_profile_get", "zkm_version",
 ]
@@ -100,6 +100,7 @@ def load():
         "zkm_proof_words": (C.c_size_t, [C.POINTER(StarkConfig), C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t]),
         "zkm_prove_single_table": (C.c_int, [cp, C.c_int, C.POINTER(StarkConfig), cp, C.c_size_t, C.c_uint, cp, cp, C.c_size_t,
                                              C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Challenger), u64p, err]),
+        "zkm_prove_openings": (C.c_int, [cp, C.POINTER(StarkConfig), cp, cp, cp, C.c_size_t, C.POINTER(Challenger), u64p, err]),
         "zkm_prove_single_table_ctl": (C.c_int, [cp, C.c_int, C.POINTER(StarkConfig), cp, C.c_size_t, C.c_uint, cp, cp, C.c_size_t,
                                                  cp, cp, cp, C.c_size_t, C.POINTER(Challenger), u64p, err]),
         "zkm_ctl_data": (C.c_int, [cp, cp, cp, cp, C.c_size_t, cp, C.c_size_t, C.c_uint, cp, err]),
@@ -334,6 +335,16 @@ class Context:
                                             pub.ctypes.data_as(u64p), pub.size, proofs.ctypes.data_as(u64p), chal.ctypes.data_as(u64p),
                                             C.byref(err)), err)
         return proofs, chal, list(offs)
+
+    def prove_openings(self, trace_batch, aux_batch, quot_batch, nctl_zs, challenger=None, cfg=None):
+        """PolynomialBatch::prove_openings for the STARK FRI instance on three existing commitments (BASELINE config 4)."""
+        cfg = cfg or self.standard_config()
+        ch = challenger if challenger is not None else Challenger()
+        proof = np.zeros(self.proof_words(cfg, trace_batch.log_n, trace_batch.ncols, aux_batch.ncols, nctl_zs), dtype=np.uint64)
+        err = C.c_char_p()
+        _check(self.L.zkm_prove_openings(self.h, C.byref(cfg), trace_batch.h, aux_batch.h, quot_batch.h, nctl_zs, C.byref(ch),
+                                         proof.ctypes.data_as(u64p), C.byref(err)), err)
+        return proof
 
     def quotient(self, trace_batch, aux_batch, num_helpers, alphas, table_id=TABLE_POSEIDON):
         nh = (C.c_uint32 * len(num_helpers))(*num_helpers)

@@ -203,7 +203,8 @@ __global__ __launch_bounds__(1024) void k_ntt_pass(ntt_pass_args p) {
             if (do_pre) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    x[j] = gl_mul(x[j], pow_lookup(p.pre_tab, p.pre_log, in0 + (uint32_t)j * in_step));
+                    const uint32_t off = in0 + (uint32_t)j * in_step;
+                    if (off < p.n_in) x[j] = gl_mul(x[j], pow_lookup(p.pre_tab, p.pre_log, off));  // (the table only covers the unpadded input)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass(ntt_pass_args p) {
                 int a = idx & (R - 1), bb = idx >> S;
                 size_t off = base_in + (size_t)a * p.sa_in + (size_t)bb * p.sb_in;
                 gl_t v = off < p.n_in ? src[off] : 0;
-                if (do_pre) v = gl_mul(v, pow_lookup(p.pre_tab, p.pre_log, off));
+                if (do_pre && off < p.n_in) v = gl_mul(v, pow_lookup(p.pre_tab, p.pre_log, off));
                 lds[a * tp + bb] = v;
             }
             __syncthreads();

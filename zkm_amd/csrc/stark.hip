@@ -534,7 +534,11 @@ struct fri_layer {
 
 static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
                                const zkm_batch* trace_batch, const uint64_t* aux, size_t A, const zkm_ctl_table* ctl_table,
-                               const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t Z, zkm_challenger* ch, uint64_t* proof) {
+                               const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t Z, zkm_challenger* ch, uint64_t* proof,
+                               const zkm_batch* aux_batch_in = nullptr, const zkm_batch* quot_batch_in = nullptr) {
+    // openings-only mode (zkm_prove_openings, BASELINE config 4): the three commitments exist already; the transcript
+    // is compact -> zeta -> openings -> prove_openings
+    const bool openings_only = aux_batch_in != nullptr;
     if (cfg->rate_bits != 2 || cfg->arity_bits < 2 || cfg->arity_bits > 6 || cfg->pow_bits == 0 || cfg->pow_bits > 32)
         throw std::runtime_error("zkm_prove_single_table: unsupported FRI configuration");
     proof_layout y;
@@ -542,11 +546,16 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
     if (y.L > 8) throw std::runtime_error("too many FRI layers");
     size_t n = (size_t)1 << log_n, N = (size_t)1 << y.lde_bits;
     size_t total_helpers = 0;
-    for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
+    if (openings_only) {
+        if (Z > A) throw std::runtime_error("zkm_prove_openings: more CTL Zs than auxiliary polynomials");
+        total_helpers = A - Z;
+    } else {
+        for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
+    }
     if (A == 0 || total_helpers + Z != A) throw std::runtime_error("No CTL? aux column count does not match the CTL description");  // prover.rs:509
     ctl_dev_owner own;
-    own.upload(c, ctl_table, zs, colset_ids, Z);
-    if (ctl_table)
+    if (!openings_only) own.upload(c, ctl_table, zs, colset_ids, Z);
+    if (ctl_table && !openings_only)
         for (size_t i = 0; i < ctl_table->nterms; i++)
             if (ctl_table->term_col[i] >= W) throw std::runtime_error("CTL description: trace column index out of range");
 
@@ -579,26 +588,38 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             throw std::runtime_error("trace commitment does not match the table shape / config");
 
         zkm_challenger_compact(ch, proof + y.o_init);  // :466
-        // auxiliary commitment :511-522
-        ab = new zkm_batch();
-        ab->ctx = c; ab->ncols = A; ab->log_n = log_n; ab->rate_bits = cfg->rate_bits; ab->cap_height = cfg->cap_height;
-        zkm_batch_build(ab, aux, true);
         uint64_t* caps = proof + y.o_caps;
         memcpy(caps, tb->cap.data(), y.C * 4 * 8);
-        memcpy(caps + y.C * 4, ab->cap.data(), y.C * 4 * 8);
-        zkm_challenger_observe(ch, caps + y.C * 4, y.C * 4);  // :525
-        gl_t alphas[4];
-        for (unsigned i = 0; i < cfg->num_challenges; i++) alphas[i] = zkm_challenger_get(ch);  // :527
+        const zkm_batch *abp = aux_batch_in, *qbp = quot_batch_in;
+        if (!openings_only) {
+            // auxiliary commitment :511-522
+            ab = new zkm_batch();
+            ab->ctx = c; ab->ncols = A; ab->log_n = log_n; ab->rate_bits = cfg->rate_bits; ab->cap_height = cfg->cap_height;
+            zkm_batch_build(ab, aux, true);
+            memcpy(caps + y.C * 4, ab->cap.data(), y.C * 4 * 8);
+            zkm_challenger_observe(ch, caps + y.C * 4, y.C * 4);  // :525
+            gl_t alphas[4];
+            for (unsigned i = 0; i < cfg->num_challenges; i++) alphas[i] = zkm_challenger_get(ch);  // :527
 
-        // quotient :543-587
-        gl_t* d_quot = (gl_t*)c->alloc(cfg->num_challenges * 2 * n * sizeof(gl_t));
-        scratch.push_back(d_quot);
-        quotient_device(c, table_id, tb, ab, own, alphas, cfg->num_challenges, d_quot);
-        qb = new zkm_batch();
-        qb->ctx = c; qb->ncols = y.Q; qb->log_n = log_n; qb->rate_bits = cfg->rate_bits; qb->cap_height = cfg->cap_height;
-        zkm_batch_build(qb, d_quot, false);  // chunks [q0_lo, q0_hi, q1_lo, q1_hi] == d_quot viewed as Q columns of n
-        memcpy(caps + 2 * y.C * 4, qb->cap.data(), y.C * 4 * 8);
-        zkm_challenger_observe(ch, caps + 2 * y.C * 4, y.C * 4);  // :589
+            // quotient :543-587
+            gl_t* d_quot = (gl_t*)c->alloc(cfg->num_challenges * 2 * n * sizeof(gl_t));
+            scratch.push_back(d_quot);
+            quotient_device(c, table_id, tb, ab, own, alphas, cfg->num_challenges, d_quot);
+            qb = new zkm_batch();
+            qb->ctx = c; qb->ncols = y.Q; qb->log_n = log_n; qb->rate_bits = cfg->rate_bits; qb->cap_height = cfg->cap_height;
+            zkm_batch_build(qb, d_quot, false);  // chunks [q0_lo, q0_hi, q1_lo, q1_hi] == d_quot viewed as Q columns of n
+            memcpy(caps + 2 * y.C * 4, qb->cap.data(), y.C * 4 * 8);
+            zkm_challenger_observe(ch, caps + 2 * y.C * 4, y.C * 4);  // :589
+            abp = ab;
+            qbp = qb;
+        } else {
+            for (const zkm_batch* b : {abp, qbp})
+                if (!b || b->log_n != log_n || b->rate_bits != cfg->rate_bits || b->cap_height != cfg->cap_height)
+                    throw std::runtime_error("zkm_prove_openings: commitments do not match the table shape / config");
+            if (abp->ncols != A || qbp->ncols != y.Q) throw std::runtime_error("zkm_prove_openings: unexpected number of polynomials");
+            memcpy(caps + y.C * 4, abp->cap.data(), y.C * 4 * 8);
+            memcpy(caps + 2 * y.C * 4, qbp->cap.data(), y.C * 4 * 8);
+        }
 
         gl2_t zeta = challenger_get_ext(ch);  // :591
         gl_t g = gl_root_of_unity(log_n);
@@ -614,13 +635,13 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
                 o_local[2 * i] = tv[i].at_z0.c0; o_local[2 * i + 1] = tv[i].at_z0.c1;
                 o_next[2 * i] = tv[i].at_z1.c0; o_next[2 * i + 1] = tv[i].at_z1.c1;
             }
-            auto av = eval_batch(c, ab, zeta, zeta_next);
+            auto av = eval_batch(c, abp, zeta, zeta_next);
             for (size_t i = 0; i < A; i++) {
                 o_aux[2 * i] = av[i].at_z0.c0; o_aux[2 * i + 1] = av[i].at_z0.c1;
                 o_auxn[2 * i] = av[i].at_z1.c0; o_auxn[2 * i + 1] = av[i].at_z1.c1;
                 if (i >= total_helpers) o_ctl[i - total_helpers] = av[i].at_one;
             }
-            auto qv = eval_batch(c, qb, zeta, zeta_next);
+            auto qv = eval_batch(c, qbp, zeta, zeta_next);
             for (size_t i = 0; i < y.Q; i++) { o_quot[2 * i] = qv[i].at_z0.c0; o_quot[2 * i + 1] = qv[i].at_z0.c1; }
         }
         // observe_openings(to_fri_openings) proof.rs:336-367
@@ -646,7 +667,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
         scratch.push_back(d_comp);
         {
             zkm_prof_scope ps(c, "fri_combine");
-            hipLaunchKernelGGL(k_fri_combine, dim3((n + 255) / 256), dim3(256), 0, c->stream, tb->coeffs, W, ab->coeffs, A, qb->coeffs, y.Q,
+            hipLaunchKernelGGL(k_fri_combine, dim3((n + 255) / 256), dim3(256), 0, c->stream, tb->coeffs, W, abp->coeffs, A, qbp->coeffs, y.Q,
                                total_helpers, d_apow, n, d_comp);
             ZKM_HIP_CHECK(hipGetLastError());
         }
@@ -743,7 +764,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             scratch.push_back(d_xs);
             ZKM_HIP_CHECK(hipMemcpyAsync(d_xs, xs.data(), y.nq * 8, hipMemcpyHostToDevice, c->stream));
             gather_args ga{};
-            const zkm_batch* orc[3] = {tb, ab, qb};
+            const zkm_batch* orc[3] = {tb, abp, qbp};
             for (int k = 0; k < 3; k++) {
                 ga.o[k].lde = orc[k]->lde; ga.o[k].digests = orc[k]->digests; ga.o[k].ncols = (uint32_t)orc[k]->ncols;
                 ga.o[k].nsib = y.lde_bits - y.cap; ga.o[k].N = N;
@@ -807,6 +828,19 @@ int zkm_prove_single_table_ctl(zkm_ctx* c, int table_id, const zkm_stark_config*
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         if (!trace && !trace_batch) throw std::runtime_error("zkm_prove_single_table: need trace values or a trace commitment");
         prove_single_table(c, table_id, cfg, trace, ncols, log_n, trace_batch, aux, naux, table, zs, colset_ids, nzs, challenger, proof_out);
+    } catch (const std::exception& e) {
+        return fail(err, e.what());
+    }
+    return 0;
+}
+
+int zkm_prove_openings(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch* trace_batch, const zkm_batch* aux_batch,
+                       const zkm_batch* quot_batch, size_t nctl_zs, zkm_challenger* challenger, uint64_t* proof_out, char** err) {
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!trace_batch || !aux_batch || !quot_batch) throw std::runtime_error("zkm_prove_openings: three commitments are required");
+        prove_single_table(c, -1, cfg, nullptr, trace_batch->ncols, trace_batch->log_n, trace_batch, nullptr, aux_batch->ncols, nullptr,
+                           nullptr, nullptr, nctl_zs, challenger, proof_out, aux_batch, quot_batch);
     } catch (const std::exception& e) {
         return fail(err, e.what());
     }
