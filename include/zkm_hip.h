@@ -82,6 +82,20 @@ int zkm_keccakf_batch(zkm_ctx* ctx, uint64_t* states, size_t k, char** err);
 #define ZKM_POSEIDON_COLS 262
 int zkm_poseidon_trace(zkm_ctx* ctx, uint64_t seed, size_t num_perms, unsigned log_n, uint64_t* out_dev, char** err);
 
+/* ------------------------------------------------------------------ a12: KeccakSpongeStark witness (BASELINE config 5)
+ * KeccakSpongeStark::generate_trace (keccak_sponge/keccak_sponge_stark.rs:222-251, rows :253-438, column map
+ * keccak_sponge/columns.rs:19-70): 470 columns, one row per 136-byte block (len/136 + 1 rows per operation, pad10*1 on
+ * the final row :334-341), one Keccak-f[1600] per row (:410), padding rows all-zero (:440-444).
+ *   inputs        concatenated input bytes of all operations (host or device)
+ *   input_off     nops + 1 byte offsets into `inputs` (host)
+ *   meta          nops x 4 words (host): context, segment, virt_base, timestamp; word i of the input is read at
+ *                 virt_base + i (contiguous base addresses)
+ * Output: 470 x 2^log_n column-major, device pointer.  Fails if the operations need more than 2^log_n rows or if an
+ * operation is empty (the reference indexes base_address[0]). */
+#define ZKM_KECCAK_SPONGE_COLS 470
+int zkm_keccak_sponge_trace(zkm_ctx* ctx, const uint8_t* inputs, const uint64_t* input_off, const uint64_t* meta, size_t nops,
+                            unsigned log_n, uint64_t* out_dev, size_t* rows_used_out, char** err);
+
 /* ------------------------------------------------------------------ Fiat-Shamir (host)
  * plonky2 Challenger<F, PoseidonHash> (uses at prover.rs:182-190, 466, 524-527, 588-591, 610). */
 typedef struct {

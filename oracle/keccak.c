@@ -73,3 +73,64 @@ void zko_keccak256(const uint8_t* msg, size_t len, uint8_t out[32]) {
     }
     for (int i = 0; i < 32; i++) out[i] = (uint8_t)(st[i / 8] >> (8 * (i % 8)));
 }
+
+/* ---- KeccakSpongeStark witness rows: restates keccak_sponge_stark.rs:253-438 (generate_rows_for_op,
+ * generate_full_input_row, generate_final_row, generate_common_fields) with the column order of columns.rs:19-70. ---- */
+enum { KS_FULL = 0, KS_CONTEXT = 1, KS_SEGMENT = 2, KS_VIRT = 3, KS_TIMESTAMP = 37, KS_LEN = 38, KS_ABSORBED = 39, KS_FINAL_LEN = 40,
+       KS_ORIG_RATE = 176, KS_ORIG_CAP = 210, KS_BLOCK = 226, KS_XORED = 362, KS_PARTIAL = 396, KS_DIGEST = 438 };
+
+size_t zko_keccak_sponge_trace(const uint8_t* inputs, const uint64_t* off, const uint64_t* meta, size_t nops, unsigned log_n, uint64_t* out) {
+    size_t n = (size_t)1 << log_n, rows = 0;
+    for (size_t i = 0; i < nops; i++) {
+        if (off[i + 1] <= off[i]) return 0;
+        rows += (off[i + 1] - off[i]) / 136 + 1;
+    }
+    if (rows > n) return 0;
+    memset(out, 0, sizeof(uint64_t) * ZKO_KECCAK_SPONGE_COLS * n);
+    size_t row = 0;
+    for (size_t op = 0; op < nops; op++) {
+        const uint8_t* msg = inputs + off[op];
+        size_t len = off[op + 1] - off[op], nwords = (len + 3) / 4;
+        uint64_t st[25];
+        memset(st, 0, sizeof st);
+        size_t absorbed = 0;
+        for (;;) {
+            size_t rem = len - absorbed;
+            int full = rem >= 136;
+            uint8_t block[136];
+            memset(block, 0, 136);
+            memcpy(block, msg + absorbed, full ? 136 : rem);
+#define CELL(c) out[(size_t)(c) * n + row]
+            if (full) {
+                CELL(KS_FULL) = 1;
+            } else {
+                if (rem == 135) block[135] = 0x81;
+                else { block[rem] = 1; block[135] = 0x80; }
+                CELL(KS_FINAL_LEN + rem) = 1;
+            }
+            CELL(KS_CONTEXT) = meta[4 * op];
+            CELL(KS_SEGMENT) = meta[4 * op + 1];
+            for (size_t i = 0; i < 34; i++) { size_t w = absorbed / 4 + i; CELL(KS_VIRT + i) = w < nwords ? meta[4 * op + 2] + w : 0; }
+            CELL(KS_TIMESTAMP) = meta[4 * op + 3];
+            CELL(KS_LEN) = len;
+            CELL(KS_ABSORBED) = absorbed;
+            for (int i = 0; i < 34; i++) CELL(KS_ORIG_RATE + i) = (uint32_t)(st[i / 2] >> (32 * (i & 1)));
+            for (int i = 0; i < 16; i++) CELL(KS_ORIG_CAP + i) = (uint32_t)(st[(34 + i) / 2] >> (32 * ((34 + i) & 1)));
+            for (int i = 0; i < 136; i++) CELL(KS_BLOCK + i) = block[i];
+            for (int i = 0; i < 17; i++) {
+                uint64_t w = 0;
+                for (int j = 0; j < 8; j++) w |= (uint64_t)block[8 * i + j] << (8 * j);
+                st[i] ^= w;
+            }
+            for (int i = 0; i < 34; i++) CELL(KS_XORED + i) = (uint32_t)(st[i / 2] >> (32 * (i & 1)));
+            zko_keccakf(st);
+            for (int i = 0; i < 42; i++) CELL(KS_PARTIAL + i) = (uint32_t)(st[(8 + i) / 2] >> (32 * ((8 + i) & 1)));
+            for (int i = 0; i < 32; i++) CELL(KS_DIGEST + i) = (uint8_t)(st[i / 8] >> (8 * (i & 7)));
+#undef CELL
+            row++;
+            if (!full) break;
+            absorbed += 136;
+        }
+    }
+    return rows;
+}

@@ -140,6 +140,19 @@ class Oracle:
         self.lib.zko_keccak256(C.c_char_p(msg), C.c_size_t(len(msg)), out)
         return bytes(out)
 
+    def keccak_sponge_trace(self, inputs, input_off, meta, log_n):
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint8)
+        input_off = np.ascontiguousarray(input_off, dtype=np.uint64)
+        meta = np.ascontiguousarray(meta, dtype=np.uint64)
+        out = np.zeros(470 << log_n, dtype=np.uint64)
+        self.lib.zko_keccak_sponge_trace.restype = C.c_size_t
+        self.lib.zko_keccak_sponge_trace.argtypes = [C.c_void_p, u64p, u64p, C.c_size_t, C.c_uint, u64p]
+        used = self.lib.zko_keccak_sponge_trace(inputs.ctypes.data_as(C.c_void_p), _ptr(input_off), _ptr(meta), input_off.size - 1,
+                                                log_n, _ptr(out))
+        if used == 0 and input_off.size > 1:
+            raise RuntimeError("oracle keccak_sponge_trace: bad operations")
+        return out, used
+
     # ---- NTT / commitment
     def ntt(self, cols, log_n, inverse=False, coset_shift=0):
         a = np.ascontiguousarray(cols, dtype=np.uint64).copy()

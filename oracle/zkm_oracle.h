@@ -41,6 +41,11 @@ void zko_keccakf(uint64_t st[25]);
 void zko_keccakf_batch(uint64_t* states, size_t k);
 void zko_keccak256(const uint8_t* msg, size_t len, uint8_t out[32]);
 
+/* KeccakSpongeStark::generate_trace (keccak_sponge_stark.rs:222-444); out = 470 x 2^log_n column-major; returns rows used, or 0 on error */
+#define ZKO_KECCAK_SPONGE_COLS 470
+size_t zko_keccak_sponge_trace(const uint8_t* inputs, const uint64_t* input_off, const uint64_t* meta, size_t nops, unsigned log_n,
+                               uint64_t* out);
+
 /* ---- NTT (natural order in and out) ---- */
 void zko_ntt(uint64_t* cols, size_t ncols, unsigned log_n, int inverse, uint64_t coset_shift);
 

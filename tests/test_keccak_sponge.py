@@ -1,0 +1,111 @@
+"""KeccakSpongeStark witness generation (a12 / BASELINE config 5): oracle properties on CPU, GPU parity."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.sponge_fixtures import make_ops, ops_for_rows
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+W = 470
+
+
+def final_rows(off):
+    lens = np.diff(off.astype(np.int64))
+    return np.cumsum(lens // 136 + 1) - 1
+
+
+def test_oracle_sponge_rows_digest_and_structure(oracle):
+    # reference property keccak_sponge_stark.rs:761-790: the final row's digest bytes == Keccak-256 of the input
+    kat = json.load(open(os.path.join(GOLD, "keccakf_kat.json")))
+    abc = next(v for v in kat["keccak256"] if v["msg_hex"] == "616263")
+    msgs = [bytes.fromhex(abc["msg_hex"]), bytes([1, 2, 3]), bytes(range(135)), bytes(range(136)), bytes(range(200)) * 3]
+    data = np.frombuffer(b"".join(msgs), dtype=np.uint8)
+    off = np.cumsum([0] + [len(m) for m in msgs]).astype(np.uint64)
+    meta = np.array([[0, 3, 100 * i, 5 + i] for i in range(len(msgs))], dtype=np.uint64).reshape(-1)
+    log_n = 4
+    n = 1 << log_n
+    trace, used = oracle.keccak_sponge_trace(data, off, meta, log_n)
+    cols = trace.reshape(W, n)
+    assert used == sum(len(m) // 136 + 1 for m in msgs)
+    fr = final_rows(off)
+    for i, m in enumerate(msgs):
+        digest = bytes(int(cols[438 + b][fr[i]]) for b in range(32))
+        assert digest == oracle.keccak256(m)
+    assert bytes(int(cols[438 + b][fr[0]]) for b in range(32)).hex() == abc["digest_hex"]
+    # structure: is_full_input_block on non-final rows, one-hot final length, pad10*1, zero padding rows
+    r = 0
+    for i, m in enumerate(msgs):
+        for blk in range(len(m) // 136 + 1):
+            last = blk == len(m) // 136
+            assert cols[0][r] == (0 if last else 1)
+            assert cols[38][r] == len(m) and cols[39][r] == 136 * blk and cols[37][r] == 5 + i
+            assert int(cols[40:176, r].sum()) == (1 if last else 0)
+            if last:
+                rem = len(m) - 136 * blk
+                assert cols[40 + rem][r] == 1
+                assert cols[226 + rem][r] == (0x81 if rem == 135 else 1)
+                assert cols[226 + 135][r] == (0x81 if rem == 135 else 0x80)
+            r += 1
+    assert not cols[:, used:].any()
+    # the 135-byte message puts both pad bits in one byte
+    assert cols[226 + 135][fr[2]] == 0x81
+
+
+def test_oracle_rejects_bad_operations(oracle):
+    data, off, meta, rows = make_ops(1, 10)
+    with pytest.raises(RuntimeError):
+        oracle.keccak_sponge_trace(data, off, meta, 2)  # not enough rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nops,log_n", [(1, 3), (40, 8), (900, 13)])
+def test_gpu_sponge_trace_matches_oracle(ctx, oracle, nops, log_n):
+    data, off, meta, rows = make_ops(nops, nops)
+    want, used = oracle.keccak_sponge_trace(data, off, meta, log_n)
+    buf, gused = ctx.keccak_sponge_trace(data, off, meta, log_n)
+    assert gused == used == rows
+    assert (buf.download() == want).all()
+    buf.free()
+
+
+@pytest.mark.gpu
+def test_gpu_sponge_errors(ctx, zkm):
+    data, off, meta, rows = make_ops(2, 10)
+    with pytest.raises(zkm.ZkmError, match="more rows"):
+        ctx.keccak_sponge_trace(data, off, meta, 2)
+    off2 = off.copy()
+    off2[3] = off2[2]
+    with pytest.raises(zkm.ZkmError, match="empty operation"):
+        ctx.keccak_sponge_trace(data, off2, meta, 10)
+
+
+@pytest.mark.gpu
+def test_config5_sponge_table_2_20_rows_witness_and_commit(ctx, zkm, oracle):
+    # BASELINE config 5: KeccakSponge table, 2^20 rows from seeded random messages, Keccak-f witness kernel + trace
+    # commitment.  Size-independent checks: digests of sampled operations, and a Merkle path of the commitment.
+    log_n = 20
+    n = 1 << log_n
+    data, off, meta, rows, nops = ops_for_rows(5, n)
+    assert rows > 0.97 * n
+    buf, used = ctx.keccak_sponge_trace(data, off, meta, log_n)
+    assert used == rows
+    fr = final_rows(off)
+    rng = np.random.default_rng(55)
+    for i in rng.integers(0, nops, 24):
+        digest = bytes(int(buf.download(1, (438 + b) * n + int(fr[i]))[0]) for b in range(32))
+        assert digest == oracle.keccak256(data[int(off[i]):int(off[i + 1])].tobytes())
+    b = zkm.PolynomialBatch.from_values(ctx, buf, W, log_n)
+    cap = b.cap().reshape(-1, 4)
+    for leaf in (0, 12345, 4 * n - 1):
+        d = oracle.hash_or_noop(b.leaf(leaf))
+        idx = leaf
+        for s in b.merkle_path(leaf).reshape(-1, 4):
+            d = oracle.two_to_one(s, d) if idx & 1 else oracle.two_to_one(d, s)
+            idx >>= 1
+        assert (cap[idx] == d).all()
+    # natural LDE row 0 is the evaluation at the coset shift g: sum_k c_k g^k for one column
+    coeffs = None
+    b.free()
+    buf.free()

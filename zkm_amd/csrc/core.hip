@@ -386,4 +386,47 @@ int zkm_poseidon_trace(zkm_ctx* c, uint64_t seed, size_t num_perms, unsigned log
     ZKM_API_END(err)
 }
 
+int zkm_keccak_sponge_trace(zkm_ctx* c, const uint8_t* inputs, const uint64_t* input_off, const uint64_t* meta, size_t nops,
+                            unsigned log_n, uint64_t* out_dev, size_t* rows_used_out, char** err) {
+    std::vector<void*> tmp;
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!zkm_is_device_ptr(out_dev)) throw std::runtime_error("zkm_keccak_sponge_trace: out must be a device pointer");
+        size_t n = (size_t)1 << log_n;
+        std::vector<uint64_t> row_off(nops + 1, 0);
+        for (size_t i = 0; i < nops; i++) {
+            if (input_off[i + 1] <= input_off[i]) throw std::runtime_error("zkm_keccak_sponge_trace: empty operation (base_address[0] is required)");
+            row_off[i + 1] = row_off[i] + (input_off[i + 1] - input_off[i]) / 136 + 1;
+        }
+        if (row_off[nops] > n) throw std::runtime_error("zkm_keccak_sponge_trace: operations need more rows than 2^log_n");
+        size_t nbytes = nops ? input_off[nops] : 0;
+        bool idev = zkm_is_device_ptr(inputs);
+        const uint8_t* d_in = inputs;
+        if (!idev && nbytes) {
+            void* p = c->alloc(nbytes);
+            tmp.push_back(p);
+            ZKM_HIP_CHECK(hipMemcpyAsync(p, inputs, nbytes, hipMemcpyHostToDevice, c->stream));
+            d_in = (const uint8_t*)p;
+        }
+        uint64_t* d_off = (uint64_t*)c->alloc((nops + 1) * 8);
+        tmp.push_back(d_off);
+        uint64_t* d_meta = (uint64_t*)c->alloc((nops ? nops : 1) * 32);
+        tmp.push_back(d_meta);
+        uint64_t* d_row = (uint64_t*)c->alloc((nops + 1) * 8);
+        tmp.push_back(d_row);
+        ZKM_HIP_CHECK(hipMemcpyAsync(d_off, input_off, (nops + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        if (nops) ZKM_HIP_CHECK(hipMemcpyAsync(d_meta, meta, nops * 32, hipMemcpyHostToDevice, c->stream));
+        ZKM_HIP_CHECK(hipMemcpyAsync(d_row, row_off.data(), (nops + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        zkm_launch_keccak_sponge_trace(c, d_in, d_off, d_meta, d_row, nops, log_n, out_dev);
+        c->sync();
+        if (rows_used_out) *rows_used_out = row_off[nops];
+        for (void* p : tmp) c->release(p);
+    } catch (const std::exception& e) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* p : tmp) c->release(p);
+        return fail(err, e.what());
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -146,9 +146,7 @@ void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>
 // ------------------------------------------------------------------ Keccak-f[1600]
 __device__ __forceinline__ uint64_t rotl64(uint64_t v, unsigned r) { return (v << r) | (v >> (64 - r)); }
 
-__global__ __launch_bounds__(256) void k_keccakf(uint64_t* states, size_t k) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= k) return;
+__device__ __forceinline__ void keccakf_dev(uint64_t (&a)[25]) {
     constexpr uint64_t RC[24] = {
         0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
         0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
@@ -158,10 +156,6 @@ __global__ __launch_bounds__(256) void k_keccakf(uint64_t* states, size_t k) {
         0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
     // rho offsets indexed x + 5y
     constexpr unsigned RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-    uint64_t a[25];
-    uint64_t* st = states + idx * 25;
-#pragma unroll
-    for (int i = 0; i < 25; i++) a[i] = st[i];
 #pragma unroll
     for (int round = 0; round < 24; round++) {
         uint64_t cx[5], b[25];
@@ -187,8 +181,95 @@ __global__ __launch_bounds__(256) void k_keccakf(uint64_t* states, size_t k) {
             for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
         a[0] ^= RC[round];
     }
+}
+
+__global__ __launch_bounds__(256) void k_keccakf(uint64_t* states, size_t k) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= k) return;
+    uint64_t a[25];
+    uint64_t* st = states + idx * 25;
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = st[i];
+    keccakf_dev(a);
 #pragma unroll
     for (int i = 0; i < 25; i++) st[i] = a[i];
+}
+
+// ------------------------------------------------------------------ KeccakSpongeStark witness (a12)
+// One lane per sponge operation (rows of one operation chain through the permutation, keccak_sponge_stark.rs:253-299);
+// column map keccak_sponge/columns.rs:19-70.  The output buffer is zero-filled first; only non-zero cells are stored.
+__global__ __launch_bounds__(128) void k_keccak_sponge_trace(const uint8_t* __restrict__ inputs, const uint64_t* __restrict__ off,
+                                                             const uint64_t* __restrict__ meta, const uint64_t* __restrict__ row_off,
+                                                             size_t nops, size_t n, gl_t* __restrict__ out) {
+    size_t op = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (op >= nops) return;
+    const uint8_t* msg = inputs + off[op];
+    const size_t len = off[op + 1] - off[op], nwords = (len + 3) / 4;
+    const uint64_t ctxv = meta[4 * op], seg = meta[4 * op + 1], vbase = meta[4 * op + 2], ts = meta[4 * op + 3];
+    uint64_t st[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    size_t row = row_off[op], absorbed = 0;
+    for (;;) {
+        const size_t rem = len - absorbed;
+        const bool full = rem >= 136;
+        gl_t* o = out + row;
+        if (full) o[0] = 1;
+        else o[(size_t)(40 + rem) * n] = 1;
+        o[1 * n] = ctxv;
+        o[2 * n] = seg;
+        for (size_t i = 0; i < 34; i++) {
+            size_t w = absorbed / 4 + i;
+            if (w < nwords) o[(3 + i) * n] = vbase + w;
+        }
+        o[37 * n] = ts;
+        o[38 * n] = len;
+        o[39 * n] = absorbed;
+#pragma unroll
+        for (int i = 0; i < 34; i++) o[(size_t)(176 + i) * n] = (uint32_t)(st[i / 2] >> (32 * (i & 1)));
+#pragma unroll
+        for (int i = 0; i < 16; i++) o[(size_t)(210 + i) * n] = (uint32_t)(st[(34 + i) / 2] >> (32 * ((34 + i) & 1)));
+        // block bytes with pad10*1 on the final row (:334-341), absorbed 8 bytes at a time
+#pragma unroll 1
+        for (int i = 0; i < 17; i++) {
+            uint64_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                size_t pos = (size_t)8 * i + j;
+                uint32_t b = pos < rem && (full || pos < rem) ? msg[absorbed + pos] : 0;
+                if (!full) {
+                    if (pos == rem) b = (rem == 135) ? 0x81 : 0x01;
+                    else if (pos == 135) b = 0x80;
+                }
+                if (b) o[(size_t)(226 + pos) * n] = b;
+                w |= (uint64_t)b << (8 * j);
+            }
+            // st[i] ^= w  (static index via a switch-free select chain is costly; use the unrolled xor below)
+#pragma unroll
+            for (int q = 0; q < 17; q++)
+                if (q == i) st[q] ^= w;
+        }
+#pragma unroll
+        for (int i = 0; i < 34; i++) o[(size_t)(362 + i) * n] = (uint32_t)(st[i / 2] >> (32 * (i & 1)));
+        keccakf_dev(st);
+#pragma unroll
+        for (int i = 0; i < 42; i++) o[(size_t)(396 + i) * n] = (uint32_t)(st[(8 + i) / 2] >> (32 * ((8 + i) & 1)));
+#pragma unroll
+        for (int i = 0; i < 32; i++) o[(size_t)(438 + i) * n] = (uint8_t)(st[i / 8] >> (8 * (i & 7)));
+        row++;
+        if (!full) break;
+        absorbed += 136;
+    }
+}
+
+void zkm_launch_keccak_sponge_trace(zkm_ctx* c, const uint8_t* d_inputs, const uint64_t* d_off, const uint64_t* d_meta,
+                                    const uint64_t* d_row_off, size_t nops, unsigned log_n, gl_t* out) {
+    size_t n = (size_t)1 << log_n;
+    ZKM_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)ZKM_KECCAK_SPONGE_COLS * n * sizeof(gl_t), c->stream));
+    if (!nops) return;
+    zkm_prof_scope ps(c, "keccak_sponge_trace");
+    hipLaunchKernelGGL(k_keccak_sponge_trace, dim3((nops + 127) / 128), dim3(128), 0, c->stream, d_inputs, d_off, d_meta, d_row_off, nops, n, out);
+    ZKM_HIP_CHECK(hipGetLastError());
 }
 
 void zkm_launch_keccakf(zkm_ctx* c, uint64_t* states, size_t k) {

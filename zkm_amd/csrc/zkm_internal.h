@@ -111,6 +111,8 @@ void zkm_launch_merkle_leaves(zkm_ctx*, const gl_t* lde, size_t nrows, size_t nc
 void zkm_launch_merkle_leaves_ext(zkm_ctx*, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests);
 void zkm_launch_merkle_compress(zkm_ctx*, const gl_t* children, gl_t* parents, size_t nparents);
 void zkm_launch_poseidon_trace(zkm_ctx*, uint64_t seed, size_t num_perms, unsigned log_n, gl_t* out);
+void zkm_launch_keccak_sponge_trace(zkm_ctx*, const uint8_t* d_inputs, const uint64_t* d_off, const uint64_t* d_meta,
+                                    const uint64_t* d_row_off, size_t nops, unsigned log_n, gl_t* out);
 // build all digest layers above level 0; fills level_off and returns total words needed (call with digests==nullptr to size)
 size_t zkm_merkle_layout(unsigned log_leaves, unsigned cap_height, std::vector<size_t>& level_off);
 void zkm_merkle_build_inner(zkm_ctx*, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height);
