@@ -96,6 +96,14 @@ int zkm_poseidon_trace(zkm_ctx* ctx, uint64_t seed, size_t num_perms, unsigned l
 int zkm_keccak_sponge_trace(zkm_ctx* ctx, const uint8_t* inputs, const uint64_t* input_off, const uint64_t* meta, size_t nops,
                             unsigned log_n, uint64_t* out_dev, size_t* rows_used_out, char** err);
 
+/* ------------------------------------------------------------------ N2: LogicStark witness
+ * LogicStark::generate_trace (logic.rs:150-183) with Operation::into_row (:122-142): 69 columns x 2^log_n rows,
+ * column-major; row r < nops holds operation r (flag column, the 32 little-endian bits of each input, the result),
+ * the remaining rows are zero.  ops = nops x 3 uint32 words {op (0 and, 1 or, 2 xor, 3 nor), input0, input1}, host or
+ * device.  Fails if nops > 2^log_n or an op code is out of range. */
+#define ZKM_LOGIC_COLS 69
+int zkm_logic_trace(zkm_ctx* ctx, const uint32_t* ops, size_t nops, unsigned log_n, uint64_t* out_dev, char** err);
+
 /* ------------------------------------------------------------------ Fiat-Shamir (host)
  * plonky2 Challenger<F, PoseidonHash> (uses at prover.rs:182-190, 466, 524-527, 588-591, 610). */
 typedef struct {
@@ -116,7 +124,14 @@ typedef struct {
 } zkm_stark_config;
 void zkm_standard_config(zkm_stark_config* cfg);
 
+/* Tables with a constraint kernel (the reference's Table enum, all_stark.rs:96-110, has 12):
+ *   POSEIDON       poseidon/poseidon_stark.rs:554-594   262 columns
+ *   LOGIC          logic.rs:199-248                       69 columns
+ *   KECCAK_SPONGE  keccak_sponge_stark.rs:456-567        470 columns */
 #define ZKM_TABLE_POSEIDON 0
+#define ZKM_TABLE_LOGIC 1
+#define ZKM_TABLE_KECCAK_SPONGE 2
+size_t zkm_table_width(int table_id); /* 0 for an unknown id */
 
 /* Proof blob (uint64_t words) -- the fields of StarkProofWithMetadata (proof.rs:178-201) flattened:
  *   [0] magic "ZKMPROOF" [1] degree_bits [2] W trace cols [3] A aux cols [4] Q quotient polys [5] Z ctl zs

@@ -91,6 +91,71 @@ static void TNAME(eval_poseidon)(const T* lv, TNAME(consumer) * k) {
     for (int i = 0; i < 12; i++) TNAME(cons)(k, T_SUB(s[i], lv[13 + i]));
 }
 
+/* ---- LogicStark constraints: logic.rs:199-248 (columns :25-50: IS_AND 0, IS_OR 1, IS_XOR 2, IS_NOR 3, INPUT0 bits 4..35,
+ * INPUT1 bits 36..67, RESULT 68; VAL_BITS = PACKED_LIMB_BITS = 32, PACKED_LEN = 1) ---- */
+static void TNAME(eval_logic)(const T* lv, TNAME(consumer) * k) {
+    T is_and = lv[0], is_or = lv[1], is_xor = lv[2], is_nor = lv[3];
+    T sum_coeff = T_SUB(T_ADD(is_or, is_xor), is_nor);
+    T and_coeff = T_ADD(T_SUB(T_SUB(is_and, is_or), T_MULB(is_xor, 2)), is_nor);
+    T not_coeff = is_nor;
+    for (int i = 4; i < 68; i++) TNAME(cons)(k, T_MUL(lv[i], T_SUB(lv[i], T_FROMB(1))));
+    T x = T_FROMB(0), y = T_FROMB(0), x_land_y = T_FROMB(0);
+    for (int i = 0; i < 32; i++) {
+        x = T_ADD(x, T_MULB(lv[4 + i], (gl_t)1 << i));
+        y = T_ADD(y, T_MULB(lv[36 + i], (gl_t)1 << i));
+        x_land_y = T_ADD(x_land_y, T_MULB(T_MUL(lv[4 + i], lv[36 + i]), (gl_t)1 << i));
+    }
+    T x_op_y = T_ADD(T_ADD(T_MUL(sum_coeff, T_ADD(x, y)), T_MUL(and_coeff, x_land_y)), T_MULB(not_coeff, 0xFFFFFFFFULL));
+    TNAME(cons)(k, T_SUB(lv[68], x_op_y));
+}
+
+/* ---- KeccakSpongeStark constraints: keccak_sponge_stark.rs:456-567 (column map keccak_sponge/columns.rs:19-70:
+ * full 0, context 1, segment 2, virt 3..36, timestamp 37, len 38, already_absorbed 39, is_final_input_len 40..175,
+ * original_rate 176..209, original_capacity 210..225, block_bytes 226..361, xored_rate 362..395,
+ * partial_updated_state 396..437, updated_digest_state_bytes 438..469) ---- */
+static void TNAME(eval_keccak_sponge)(const T* lv, const T* nv, TNAME(consumer) * k) {
+    T one = T_FROMB(1);
+    T full = lv[0];
+    TNAME(cons)(k, T_MUL(full, T_SUB(full, one)));
+    T is_final = T_FROMB(0);
+    for (int i = 0; i < 136; i++) is_final = T_ADD(is_final, lv[40 + i]);
+    TNAME(cons)(k, T_MUL(is_final, T_SUB(is_final, one)));
+    for (int i = 0; i < 136; i++) TNAME(cons)(k, T_MUL(lv[40 + i], T_SUB(lv[40 + i], one)));
+    TNAME(cons)(k, T_MUL(is_final, full));
+    T absorbed = lv[39];
+    TNAME(cons_first)(k, absorbed);
+    for (int i = 0; i < 34; i++) TNAME(cons_first)(k, lv[176 + i]);
+    for (int i = 0; i < 16; i++) TNAME(cons_first)(k, lv[210 + i]);
+    TNAME(cons_transition)(k, T_MUL(is_final, nv[39]));
+    for (int i = 0; i < 34; i++) TNAME(cons_transition)(k, T_MUL(is_final, nv[176 + i]));
+    for (int i = 0; i < 16; i++) TNAME(cons_transition)(k, T_MUL(is_final, nv[210 + i]));
+    TNAME(cons_transition)(k, T_MUL(full, T_SUB(lv[1], nv[1])));
+    TNAME(cons_transition)(k, T_MUL(full, T_SUB(lv[2], nv[2])));
+    TNAME(cons_transition)(k, T_MUL(full, T_SUB(lv[37], nv[37])));
+    for (int l = 0; l < 8; l++) {
+        T cur = lv[438 + 4 * l];
+        for (int i = 1; i < 4; i++) cur = T_ADD(cur, T_MULB(lv[438 + 4 * l + i], (gl_t)1 << (8 * i)));
+        TNAME(cons_transition)(k, T_MUL(full, T_SUB(nv[176 + l], cur)));
+    }
+    for (int i = 0; i < 26; i++) TNAME(cons_transition)(k, T_MUL(full, T_SUB(nv[176 + 8 + i], lv[396 + i])));
+    for (int i = 0; i < 16; i++) TNAME(cons_transition)(k, T_MUL(full, T_SUB(nv[210 + i], lv[396 + 26 + i])));
+    TNAME(cons_transition)(k, T_MUL(full, T_SUB(T_ADD(absorbed, T_FROMB(136)), nv[39])));
+    T is_dummy = T_SUB(T_SUB(one, full), is_final);
+    T next_final = T_FROMB(0);
+    for (int i = 0; i < 136; i++) next_final = T_ADD(next_final, nv[40 + i]);
+    TNAME(cons_transition)(k, T_MUL(is_dummy, T_ADD(nv[0], next_final)));
+    T offset = T_SUB(lv[38], absorbed);
+    for (int i = 0; i < 136; i++) TNAME(cons)(k, T_MUL(lv[40 + i], T_SUB(offset, T_FROMB((gl_t)i))));
+}
+
+/* table dispatch (Table ids of include/zkm_hip.h) */
+static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : 0; }
+static void TNAME(eval_table)(int table_id, const T* lv, const T* nv, TNAME(consumer) * k) {
+    if (table_id == 0) TNAME(eval_poseidon)(lv, k);
+    else if (table_id == 1) TNAME(eval_logic)(lv, k);
+    else TNAME(eval_keccak_sponge)(lv, nv, k);
+}
+
 /* ---- general CTL checks driven by the column-set description ----
  * Column::eval_with_next cross_table_lookup.rs:292-311, Filter::eval_filter :64-79,
  * GrandProductChallenge::combine :494-504 (reduce_with_powers(terms, beta) + gamma),

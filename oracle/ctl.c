@@ -89,6 +89,22 @@ void zko_ctl_data(const zko_ctl_table* t, const zko_ctl_z* zs, const uint32_t* c
     free(hsum);
 }
 
+/* LogicStark witness: Operation::into_row logic.rs:122-142, zero padding rows :155-173 */
+void zko_logic_trace(const uint32_t* ops, size_t nops, unsigned log_n, uint64_t* out) {
+    size_t n = (size_t)1 << log_n;
+    memset(out, 0, sizeof(uint64_t) * 69 * n);
+    for (size_t r = 0; r < nops && r < n; r++) {
+        uint32_t op = ops[3 * r], a = ops[3 * r + 1], b = ops[3 * r + 2];
+        uint32_t res = op == 0 ? (a & b) : op == 1 ? (a | b) : op == 2 ? (a ^ b) : ~(a | b);
+        out[(size_t)op * n + r] = 1;
+        for (int i = 0; i < 32; i++) {
+            out[(size_t)(4 + i) * n + r] = (a >> i) & 1;
+            out[(size_t)(36 + i) * n + r] = (b >> i) & 1;
+        }
+        out[(size_t)68 * n + r] = res;
+    }
+}
+
 /* lookup_helper_columns lookup.rs:46-124: GrandProductChallenge{beta: 1, gamma: challenge} (:70-73), helper columns by
  * get_helper_cols, table inverse :100-105, forward running sum Z with Z[0] = 0 (:111-121) */
 void zko_lookup_helper_columns(const zko_ctl_table* t, const uint32_t* colset_ids, size_t nlookup, uint32_t table_col, uint32_t freq_col,

@@ -194,28 +194,43 @@ class Oracle:
         self.lib.zko_quotient_poseidon(trace_b.h, aux_b.h, nh, len(num_helpers), _ptr(al), C.c_size_t(al.size), _ptr(out))
         return out
 
+    def quotient(self, trace_b, aux_b, num_helpers, alphas, table_id=0):
+        nh = (C.c_uint32 * len(num_helpers))(*num_helpers)
+        al = np.ascontiguousarray(alphas, dtype=np.uint64)
+        out = np.zeros(al.size * (2 << trace_b.log_n), dtype=np.uint64)
+        self.lib.zko_quotient.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p]
+        self.lib.zko_quotient(table_id, trace_b.h, aux_b.h, nh, len(num_helpers), _ptr(al), al.size, _ptr(out))
+        return out
+
     def proof_words(self, cfg, log_n, ncols, naux, nctl):
         return self.lib.zko_proof_words(C.byref(cfg), log_n, ncols, naux, nctl)
 
-    def prove(self, trace, log_n, aux, num_helpers, challenger=None, cfg=None, ncols=POSEIDON_COLS, want_stages=False):
+    def logic_trace(self, ops, log_n):
+        ops = np.ascontiguousarray(ops, dtype=np.uint32).reshape(-1, 3)
+        out = np.zeros(69 << log_n, dtype=np.uint64)
+        self.lib.zko_logic_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, u64p]
+        self.lib.zko_logic_trace(ops.ctypes.data, len(ops), log_n, _ptr(out))
+        return out
+
+    def prove(self, trace, log_n, aux, num_helpers, challenger=None, cfg=None, ncols=POSEIDON_COLS, want_stages=False, table_id=0):
         cfg = cfg or self.standard_config()
         ch = challenger or Challenger()
         naux = aux.size >> log_n
         nh = (C.c_uint32 * len(num_helpers))(*num_helpers)
         proof = np.zeros(self.proof_words(cfg, log_n, ncols, naux, len(num_helpers)), dtype=np.uint64)
         stages = (C.c_double * 8)()
-        rc = self.lib.zko_prove_single_table(0, C.byref(cfg), _ptr(np.ascontiguousarray(trace)), ncols, log_n,
+        rc = self.lib.zko_prove_single_table(table_id, C.byref(cfg), _ptr(np.ascontiguousarray(trace)), ncols, log_n,
                                              _ptr(np.ascontiguousarray(aux)), naux, nh, len(num_helpers), C.byref(ch),
                                              _ptr(proof), stages)
         if rc != 0:
             raise RuntimeError("oracle prove_single_table failed: %d" % rc)
         return (proof, list(stages)) if want_stages else proof
 
-    def verify(self, proof, naux, num_helpers, challenger=None, cfg=None, ncols=POSEIDON_COLS):
+    def verify(self, proof, naux, num_helpers, challenger=None, cfg=None, ncols=POSEIDON_COLS, table_id=0):
         cfg = cfg or self.standard_config()
         ch = challenger or Challenger()
         nh = (C.c_uint32 * len(num_helpers))(*num_helpers)
-        return self.lib.zko_verify_single_table(0, C.byref(cfg), _ptr(np.ascontiguousarray(proof)), ncols, naux, nh,
+        return self.lib.zko_verify_single_table(table_id, C.byref(cfg), _ptr(np.ascontiguousarray(proof)), ncols, naux, nh,
                                                 len(num_helpers), C.byref(ch))
 
     # ---- cross-table lookups / multi-table proofs (descriptor builders live in zkm_amd/ctl.py: pure marshalling)
@@ -260,26 +275,26 @@ class Oracle:
                                            _ptr(np.ascontiguousarray(trace)), ncols, log_n, _ptr(out))
         return out
 
-    def prove_ctl(self, trace, log_n, aux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS):
+    def prove_ctl(self, trace, log_n, aux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS, table_id=0):
         self._ctl_sigs()
         cfg = cfg or self.standard_config()
         ch = challenger or Challenger()
         naux = aux.size >> log_n
         proof = np.zeros(self.proof_words(cfg, log_n, ncols, naux, len(zs)), dtype=np.uint64)
         st = ctl_table.pack()
-        rc = self.lib.zko_prove_single_table_ctl(0, C.byref(cfg), _ptr(np.ascontiguousarray(trace)), ncols, log_n,
+        rc = self.lib.zko_prove_single_table_ctl(table_id, C.byref(cfg), _ptr(np.ascontiguousarray(trace)), ncols, log_n,
                                                  _ptr(np.ascontiguousarray(aux)), naux, C.addressof(st), zs.ctypes.data,
                                                  colset_ids.ctypes.data, len(zs), C.byref(ch), _ptr(proof))
         if rc:
             raise RuntimeError("oracle prove_single_table_ctl failed: %d" % rc)
         return proof
 
-    def verify_ctl(self, proof, naux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS):
+    def verify_ctl(self, proof, naux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS, table_id=0):
         self._ctl_sigs()
         cfg = cfg or self.standard_config()
         ch = challenger or Challenger()
         st = ctl_table.pack()
-        return self.lib.zko_verify_single_table_ctl(0, C.byref(cfg), _ptr(np.ascontiguousarray(proof)), ncols, naux, C.addressof(st),
+        return self.lib.zko_verify_single_table_ctl(table_id, C.byref(cfg), _ptr(np.ascontiguousarray(proof)), ncols, naux, C.addressof(st),
                                                     zs.ctypes.data, colset_ids.ctypes.data, len(zs), C.byref(ch))
 
     def _pack_all(self, tables, ctls):

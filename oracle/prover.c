@@ -195,17 +195,24 @@ static zko_ctl_z* fake_zs(const uint32_t* num_helpers, size_t nctl) {
 }
 static const zko_ctl_table EMPTY_CTL_TABLE = {0};
 
-static void quotient_generic(const zko_batch* trace, const zko_batch* aux, const zko_ctl_table* ctl_t, const zko_ctl_z* zs,
+static void quotient_generic(int table_id, const zko_batch* trace, const zko_batch* aux, const zko_ctl_table* ctl_t, const zko_ctl_z* zs,
                              const uint32_t* colset_ids, size_t nctl, const uint64_t* alphas, size_t nalphas, uint64_t* out);
 
 void zko_quotient_poseidon(const zko_batch* trace, const zko_batch* aux, const uint32_t* num_helpers, size_t nctl,
                            const uint64_t* alphas, size_t nalphas, uint64_t* out) {
     zko_ctl_z* zs = fake_zs(num_helpers, nctl);
-    quotient_generic(trace, aux, &EMPTY_CTL_TABLE, zs, NULL, nctl, alphas, nalphas, out);
+    quotient_generic(ZKO_TABLE_POSEIDON, trace, aux, &EMPTY_CTL_TABLE, zs, NULL, nctl, alphas, nalphas, out);
     free(zs);
 }
 
-static void quotient_generic(const zko_batch* trace, const zko_batch* aux, const zko_ctl_table* ctl_t, const zko_ctl_z* zs,
+void zko_quotient(int table_id, const zko_batch* trace, const zko_batch* aux, const uint32_t* num_helpers, size_t nctl,
+                  const uint64_t* alphas, size_t nalphas, uint64_t* out) {
+    zko_ctl_z* zs = fake_zs(num_helpers, nctl);
+    quotient_generic(table_id, trace, aux, &EMPTY_CTL_TABLE, zs, NULL, nctl, alphas, nalphas, out);
+    free(zs);
+}
+
+static void quotient_generic(int table_id, const zko_batch* trace, const zko_batch* aux, const zko_ctl_table* ctl_t, const zko_ctl_z* zs,
                              const uint32_t* colset_ids, size_t nctl, const uint64_t* alphas, size_t nalphas, uint64_t* out) {
     unsigned log_n = zko_batch_log_n(trace), rate_bits = 2, qbits = 1;
     unsigned log_N = log_n + rate_bits, log_q = log_n + qbits;
@@ -249,7 +256,7 @@ static void quotient_generic(const zko_batch* trace, const zko_batch* aux, const
             k.l_last = ll[i];
             for (size_t c = 0; c < W; c++) { lv[c] = tl[c * N + j]; nv[c] = tl[c * N + jn]; }
             for (size_t c = 0; c < A; c++) { av[c] = al[c * N + j]; an[c] = al[c * N + jn]; }
-            b_eval_poseidon(lv, &k);
+            b_eval_table(table_id, lv, nv, &k);
             b_eval_ctl_general(ctl_t, zs, colset_ids, nctl, lv, nv, av, an, &k);
             for (size_t a = 0; a < nalphas; a++) qv[a * size + i] = gl_mul(k.acc[a], zh_inv[i & 1]);
         }
@@ -332,7 +339,7 @@ static int prove_generic_ex(int table_id, const zko_stark_config* cfg, const uin
                             size_t Z, zko_challenger* ch, uint64_t* proof, double* stage_s, zko_batch* tb_in, zko_batch* ab_in,
                             zko_batch* qb_in) {
     const int openings_only = tb_in != NULL;
-    if (!openings_only && (table_id != ZKO_TABLE_POSEIDON || W != ZKO_POSEIDON_COLS)) return -1;
+    if (!openings_only && (b_table_width(table_id) == 0 || (size_t)b_table_width(table_id) != W)) return -1;
     if (cfg->num_challenges > 4) return -1;
     layout_t y;
     layout(&y, cfg, log_n, W, A, Z);
@@ -372,7 +379,7 @@ static int prove_generic_ex(int table_id, const zko_stark_config* cfg, const uin
 
         t0 = now_s();
         gl_t* quot = (gl_t*)malloc(sizeof(gl_t) * cfg->num_challenges * 2 * n);
-        quotient_generic(tb, ab, ctl_t, zs, colset_ids, Z, alphas, cfg->num_challenges, quot);  /* :543-559 */
+        quotient_generic(table_id, tb, ab, ctl_t, zs, colset_ids, Z, alphas, cfg->num_challenges, quot);  /* :543-559 */
         ts[2] = now_s() - t0;
         /* chunks of n coefficients: [q0_lo, q0_hi, q1_lo, q1_hi] == quot viewed as Q columns of n (:560-575) */
         t0 = now_s();
@@ -633,7 +640,7 @@ int zko_verify_single_table_ctl(int table_id, const zko_stark_config* cfg, const
 static int verify_generic(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
                           const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t Z, zko_challenger* ch) {
     const int openings_only = table_id < 0;
-    if (!openings_only && (table_id != ZKO_TABLE_POSEIDON || W != ZKO_POSEIDON_COLS)) return 1;
+    if (!openings_only && (b_table_width(table_id) == 0 || (size_t)b_table_width(table_id) != W)) return 1;
     if (proof[0] != 0x5a4b4d50524f4f46ULL) return 2;
     unsigned log_n = (unsigned)proof[1];
     layout_t y;
@@ -704,7 +711,7 @@ static int verify_generic(int table_id, const zko_stark_config* cfg, const uint6
     k.l_first = gl2_mul(z_h, gl2_inv(d0));
     k.l_last = gl2_mul(z_h, gl2_inv(d1));
     if (!openings_only) {
-        e_eval_poseidon(lv, &k);
+        e_eval_table(table_id, lv, nv, &k);
         e_eval_ctl_general(ctl_t, zs, colset_ids, Z, lv, nv, av, an, &k);
     }
     for (unsigned i = 0; i < cfg->num_challenges && !openings_only; i++) {

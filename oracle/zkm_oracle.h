@@ -81,6 +81,10 @@ void zko_poseidon_trace(uint64_t seed, size_t num_perms, unsigned log_n, uint64_
 /* ---- prove_single_table for PoseidonStark with the benchmark's fake CTL data ---- */
 /* table ids */
 #define ZKO_TABLE_POSEIDON 0
+#define ZKO_TABLE_LOGIC 1
+#define ZKO_TABLE_KECCAK_SPONGE 2
+/* LogicStark::generate_trace (logic.rs:150-183): ops = nops x (op (0 and, 1 or, 2 xor, 3 nor), in0, in1); out = 69 x 2^log_n */
+void zko_logic_trace(const uint32_t* ops, size_t nops, unsigned log_n, uint64_t* out);
 typedef struct {
     unsigned rate_bits, cap_height, pow_bits, num_challenges, num_queries, arity_bits, final_poly_bits;
 } zko_stark_config;
@@ -143,6 +147,9 @@ int zko_verify_openings(const zko_stark_config* cfg, const uint64_t* proof, size
 
 /* quotient stage alone (for stage-level parity): out = num_challenges*2 chunk polys... returns the
  * num_challenges quotient polys of 2n coefficients each (natural order). */
+/* same for any table with constraints (ZKO_TABLE_*) */
+void zko_quotient(int table_id, const zko_batch* trace, const zko_batch* aux, const uint32_t* num_helpers, size_t nctl_zs,
+                  const uint64_t* alphas, size_t nalphas, uint64_t* out);
 void zko_quotient_poseidon(const zko_batch* trace, const zko_batch* aux, const uint32_t* num_helpers, size_t nctl_zs,
                            const uint64_t* alphas, size_t nalphas, uint64_t* out_coeffs);
 /* constraint evaluation of one row in the base field (check_constraints building block) */

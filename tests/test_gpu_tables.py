@@ -1,0 +1,142 @@
+"""GPU parity for the Logic and KeccakSponge tables (N2): witness generation, quotient kernels, single-table proofs and
+the KeccakSponge -> Logic cross-table lookup (all_stark.rs:340-355), bit-exact against the CPU oracle."""
+import numpy as np
+import pytest
+
+from zkm_amd import tables as T
+
+from . import logic_fixtures
+from .sponge_fixtures import ops_for_rows
+
+pytestmark = pytest.mark.gpu
+EMPTY = np.zeros(0, dtype=np.uint64)
+
+
+def random_logic_ops(seed, k):
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.integers(0, 4, k), rng.integers(0, 1 << 32, k), rng.integers(0, 1 << 32, k)], axis=1).astype(np.uint32)
+
+
+def fake_ctl_aux(log_n, seed=3):
+    """h0, h1 random; Z(w^i) = sum_{k >= i} (h0 + h1)(w^k): passes the last-row / transition checks on Z."""
+    P = 0xFFFFFFFF00000001
+    n = 1 << log_n
+    rng = np.random.default_rng(seed)
+    h = [[int(x) for x in rng.integers(0, 1 << 62, n)] for _ in range(2)]
+    z, acc = [0] * n, 0
+    for i in range(n - 1, -1, -1):
+        acc = (acc + h[0][i] + h[1][i]) % P
+        z[i] = acc
+    return np.array(h[0] + h[1] + z, dtype=np.uint64)
+
+
+def table_trace(oracle, table_id, log_n, seed=2):
+    if table_id == T.TABLE_LOGIC:
+        return oracle.logic_trace(random_logic_ops(seed, (1 << log_n) - 5), log_n)
+    data, off, meta, rows, nops = ops_for_rows(seed, (1 << log_n) - 3)
+    return oracle.keccak_sponge_trace(data, off, meta, log_n)[0]
+
+
+@pytest.mark.parametrize("log_n,k", [(3, 8), (6, 40), (12, 4000), (16, 1 << 16)])
+def test_logic_trace_matches_oracle(ctx, oracle, log_n, k):
+    ops = random_logic_ops(log_n, k)
+    ops[: min(k, 4), 1:] = [[0, 0], [0xFFFFFFFF, 0xFFFFFFFF], [0, 0xFFFFFFFF], [0x80000000, 1]][: min(k, 4)]
+    got = ctx.logic_trace(ops, log_n)
+    assert (got.download() == oracle.logic_trace(ops, log_n)).all()
+    got.free()
+    # device-resident operations
+    d_ops = ctx.alloc((ops.size * 4 + 7) // 8)
+    d_ops.upload(np.frombuffer(ops.tobytes() + b"\0" * (-ops.size * 4 % 8), dtype=np.uint64))
+    import ctypes as C
+    out = ctx.alloc(69 << log_n)
+    err = C.c_char_p()
+    assert ctx.L.zkm_logic_trace(ctx.h, d_ops.ptr, k, log_n, out.ptr, C.byref(err)) == 0
+    assert (out.download() == oracle.logic_trace(ops, log_n)).all()
+
+
+def test_logic_trace_errors(ctx, zkm):
+    with pytest.raises(zkm.ZkmError, match="more operations"):
+        ctx.logic_trace(random_logic_ops(1, 9), 3)
+    bad = random_logic_ops(1, 8)
+    bad[5, 0] = 4
+    with pytest.raises(zkm.ZkmError, match="op code"):
+        ctx.logic_trace(bad, 3)
+    # empty: all-zero padding rows
+    assert not ctx.logic_trace(np.zeros((0, 3), dtype=np.uint32), 3).download().any()
+
+
+@pytest.mark.parametrize("table_id,log_n", [(T.TABLE_LOGIC, 5), (T.TABLE_LOGIC, 11), (T.TABLE_KECCAK_SPONGE, 5),
+                                            (T.TABLE_KECCAK_SPONGE, 10)])
+@pytest.mark.parametrize("nalphas", [1, 2])
+def test_quotient_matches_oracle(ctx, zkm, oracle, table_id, log_n, nalphas):
+    W = T.WIDTH[table_id]
+    trace = table_trace(oracle, table_id, log_n)
+    rng = np.random.default_rng(5)
+    aux = rng.integers(0, 1 << 63, 3 << log_n, dtype=np.uint64)     # 2 helpers + 1 Z (fake CTL data, as the benchmark)
+    alphas = [int(x) for x in rng.integers(1, 1 << 62, nalphas)]
+    tb = zkm.PolynomialBatch.from_values(ctx, trace, W, log_n)
+    ab = zkm.PolynomialBatch.from_values(ctx, aux, 3, log_n)
+    got = ctx.quotient(tb, ab, [2], alphas, table_id=table_id)
+    otb = oracle.batch_from_values(trace, W, log_n)
+    oab = oracle.batch_from_values(aux, 3, log_n)
+    want = oracle.quotient(otb, oab, [2], alphas, table_id=table_id)
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("table_id,log_n", [(T.TABLE_LOGIC, 4), (T.TABLE_LOGIC, 10), (T.TABLE_KECCAK_SPONGE, 4),
+                                            (T.TABLE_KECCAK_SPONGE, 9)])
+def test_single_table_proof_is_bit_exact(ctx, oracle, table_id, log_n):
+    W = T.WIDTH[table_id]
+    trace = table_trace(oracle, table_id, log_n, seed=7)
+    # benchmark-style CTL stand-in (prover.rs:420-438): a Z column consistent with its two helper columns
+    aux = fake_ctl_aux(log_n)
+    want = oracle.prove(trace, log_n, aux, [2], ncols=W, table_id=table_id)
+    got = ctx.prove_single_table(trace, log_n, aux, [2], ncols=W, table_id=table_id)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing word %d" % bad[0]
+    assert oracle.verify(got, 3, [2], ncols=W, table_id=table_id) == 0
+
+
+def test_wrong_width_or_missing_ctl_is_rejected(ctx, zkm, oracle):
+    trace = table_trace(oracle, T.TABLE_LOGIC, 4)
+    aux = fake_ctl_aux(4)
+    with pytest.raises(zkm.ZkmError):
+        ctx.prove_single_table(trace, 4, aux, [2], ncols=69, table_id=T.TABLE_KECCAK_SPONGE)
+    with pytest.raises(zkm.ZkmError):
+        ctx.prove_single_table(trace, 4, aux, [2], ncols=69, table_id=7)
+    with pytest.raises(zkm.ZkmError, match="No CTL"):   # the reference asserts the same (prover.rs:509)
+        ctx.prove_single_table(trace, 4, EMPTY, [], ncols=69, table_id=T.TABLE_LOGIC)
+
+
+@pytest.mark.parametrize("log_sponge", [4, 7])
+def test_sponge_logic_lookup_is_bit_exact_and_verifies(ctx, oracle, log_sponge):
+    tables, ctls, ops = logic_fixtures.build(oracle, log_sponge=log_sponge)
+    # witnesses from the GPU generators match the oracle's
+    tid, sponge, w, ls, cs = tables[0]
+    tid1, logic, w1, ll, cl = tables[1]
+    assert (ctx.logic_trace(ops, ll).download() == logic).all()
+    want, wchal, woffs = oracle.prove_with_traces(tables, ctls)
+    got, chal, offs = ctx.prove_with_traces(tables, ctls)
+    assert offs == woffs and (chal == wchal).all()
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing word %d" % bad[0]
+    assert oracle.verify_all(tables, ctls, got, chal) == 0
+
+
+def test_sponge_logic_lookup_device_resident_large(ctx, oracle):
+    """2^11 sponge rows -> 2^17 Logic rows, all witnesses generated and kept on the device; the oracle verifies."""
+    log_sponge = 11
+    data, off, meta, rows, nops = ops_for_rows(33, (1 << log_sponge) - 2)
+    d_sponge, used = ctx.keccak_sponge_trace(data, off, meta, log_sponge)
+    assert used == rows
+    sponge = d_sponge.download()
+    ops = logic_fixtures.logic_ops_from_sponge(sponge, log_sponge, rows)
+    log_logic = int(np.ceil(np.log2(len(ops))))
+    d_logic = ctx.logic_trace(ops, log_logic)
+    from zkm_amd.ctl import CtlTable
+    cs, cl = CtlTable(), CtlTable()
+    looking, looked = T.ctl_logic_keccak_sponge(0, 1, cs, cl)
+    dev_tables = [(T.TABLE_KECCAK_SPONGE, d_sponge, 470, log_sponge, cs), (T.TABLE_LOGIC, d_logic, 69, log_logic, cl)]
+    proofs, chal, offs = ctx.prove_with_traces(dev_tables, [(looking, looked)])
+    host_tables = [(T.TABLE_KECCAK_SPONGE, sponge, 470, log_sponge, cs), (T.TABLE_LOGIC, d_logic.download(), 69, log_logic, cl)]
+    assert oracle.verify_all(host_tables, [(looking, looked)], proofs, chal) == 0

@@ -1,0 +1,56 @@
+"""Oracle: LogicStark and KeccakSpongeStark constraints (logic.rs:199-248, keccak_sponge_stark.rs:456-567) accept honest
+witnesses, reject corrupted ones, and the KeccakSponge -> Logic cross-table lookup (all_stark.rs:340-355) balances."""
+import numpy as np
+import pytest
+
+from zkm_amd import tables as T
+
+from . import logic_fixtures
+from .sponge_fixtures import ops_for_rows
+
+EMPTY = np.zeros(0, dtype=np.uint64)
+
+
+def test_logic_trace_ops(oracle):
+    rng = np.random.default_rng(1)
+    ops = np.stack([rng.integers(0, 4, 50), rng.integers(0, 1 << 32, 50), rng.integers(0, 1 << 32, 50)], axis=1).astype(np.uint32)
+    tr = oracle.logic_trace(ops, 6).reshape(69, 64)
+    for r, (op, a, b) in enumerate(ops.tolist()):
+        want = [a & b, a | b, a ^ b, ~(a | b) & 0xFFFFFFFF][op]
+        assert int(tr[68, r]) == want
+        assert tr[:4, r].tolist() == [int(op == k) for k in range(4)]
+        assert sum(int(tr[4 + i, r]) << i for i in range(32)) == a
+    assert not tr[:, 50:].any()
+
+
+@pytest.mark.parametrize("table_id,log_n", [(T.TABLE_LOGIC, 6), (T.TABLE_KECCAK_SPONGE, 5)])
+def test_single_table_proof(oracle, table_id, log_n):
+    if table_id == T.TABLE_LOGIC:
+        rng = np.random.default_rng(2)
+        ops = np.stack([rng.integers(0, 4, 40), rng.integers(0, 1 << 32, 40), rng.integers(0, 1 << 32, 40)], axis=1)
+        trace = oracle.logic_trace(ops, log_n)
+    else:
+        data, off, meta, rows, nops = ops_for_rows(9, (1 << log_n) - 3)
+        trace, _ = oracle.keccak_sponge_trace(data, off, meta, log_n)
+    W = T.WIDTH[table_id]
+    proof = oracle.prove(trace, log_n, EMPTY, [], ncols=W, table_id=table_id)
+    assert oracle.verify(proof, 0, [], ncols=W, table_id=table_id) == 0
+    # a corrupted witness cell makes the quotient a non-polynomial: verification must fail
+    bad = trace.copy()
+    col = 68 if table_id == T.TABLE_LOGIC else 39   # RESULT / already_absorbed_bytes
+    bad[col * (1 << log_n) + 1] ^= 1
+    proof = oracle.prove(bad, log_n, EMPTY, [], ncols=W, table_id=table_id)
+    assert oracle.verify(proof, 0, [], ncols=W, table_id=table_id) != 0
+
+
+def test_sponge_logic_ctl(oracle):
+    tables, ctls, ops = logic_fixtures.build(oracle)
+    assert oracle.check_ctls(tables, ctls) == 0
+    proofs, chal, offs = oracle.prove_with_traces(tables, ctls)
+    assert oracle.verify_all(tables, ctls, proofs, chal) == 0
+    # drop one XOR from the Logic table: the lookup no longer balances
+    bad_ops = ops.copy()
+    bad_ops[0, 1] ^= 4
+    tid, tr, w, log_n, ct = tables[1]
+    bad_tables = [tables[0], (tid, oracle.logic_trace(bad_ops, log_n), w, log_n, ct)]
+    assert oracle.check_ctls(bad_tables, ctls) != 0

@@ -19,14 +19,16 @@ _LIB_PATH = os.path.join(_CSRC, "libzkmhip.so")
 P = 0xFFFFFFFF00000001
 POSEIDON_COLS = 262
 KECCAK_SPONGE_COLS = 470
-TABLE_POSEIDON = 0
+LOGIC_COLS = 69
+TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE = 0, 1, 2
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
     "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
     "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_free",
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_leaf", "zkm_batch_merkle_path",
-    "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_challenger_init",
+    "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_logic_trace",
+    "zkm_table_width", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
     "zkm_prove_single_table", "zkm_prove_openings", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
     "zkm_quotient", "zkm_eval_openings", "zkm_profile_enable", "zkm_profile_reset",
@@ -94,6 +96,8 @@ def load():
         "zkm_keccakf_batch": (C.c_int, [cp, cp, C.c_size_t, err]),
         "zkm_poseidon_trace": (C.c_int, [cp, C.c_uint64, C.c_size_t, C.c_uint, cp, err]),
         "zkm_keccak_sponge_trace": (C.c_int, [cp, cp, u64p, u64p, C.c_size_t, C.c_uint, cp, C.POINTER(C.c_size_t), err]),
+        "zkm_logic_trace": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, cp, err]),
+        "zkm_table_width": (C.c_size_t, [C.c_int]),
         "zkm_challenger_init": (None, [C.POINTER(Challenger)]),
         "zkm_challenger_observe": (None, [C.POINTER(Challenger), u64p, C.c_size_t]),
         "zkm_challenger_get": (C.c_uint64, [C.POINTER(Challenger)]),
@@ -254,6 +258,15 @@ class Context:
         _check(self.L.zkm_keccak_sponge_trace(self.h, inputs.ctypes.data_as(C.c_void_p), input_off.ctypes.data_as(u64p),
                                               meta.ctypes.data_as(u64p), nops, log_n, _data_ptr(out), C.byref(used), C.byref(err)), err)
         return out, used.value
+
+    def logic_trace(self, ops, log_n, out=None):
+        """LogicStark::generate_trace on the GPU (logic.rs:150-183).  ops: nops x 3 uint32 (op, input0, input1).
+        Returns a DeviceBuffer of 69 x 2^log_n words."""
+        ops = np.ascontiguousarray(ops, dtype=np.uint32).reshape(-1, 3)
+        out = out or self.alloc(LOGIC_COLS << log_n)
+        err = C.c_char_p()
+        _check(self.L.zkm_logic_trace(self.h, ops.ctypes.data_as(C.c_void_p), len(ops), log_n, _data_ptr(out), C.byref(err)), err)
+        return out
 
     # ---- profiling
     def profile(self, on=True):

@@ -429,4 +429,45 @@ int zkm_keccak_sponge_trace(zkm_ctx* c, const uint8_t* inputs, const uint64_t* i
     return 0;
 }
 
+size_t zkm_table_width(int table_id) {
+    switch (table_id) {
+        case ZKM_TABLE_POSEIDON: return ZKM_POSEIDON_COLS;
+        case ZKM_TABLE_LOGIC: return ZKM_LOGIC_COLS;
+        case ZKM_TABLE_KECCAK_SPONGE: return ZKM_KECCAK_SPONGE_COLS;
+        default: return 0;
+    }
+}
+
+int zkm_logic_trace(zkm_ctx* c, const uint32_t* ops, size_t nops, unsigned log_n, uint64_t* out_dev, char** err) {
+    std::vector<void*> tmp;
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!zkm_is_device_ptr(out_dev)) throw std::runtime_error("zkm_logic_trace: out must be a device pointer");
+        size_t n = (size_t)1 << log_n;
+        if (nops > n) throw std::runtime_error("zkm_logic_trace: more operations than 2^log_n rows");
+        const uint32_t* d_ops = ops;
+        if (nops && !zkm_is_device_ptr(ops)) {
+            void* p = c->alloc(nops * 12);
+            tmp.push_back(p);
+            ZKM_HIP_CHECK(hipMemcpyAsync(p, ops, nops * 12, hipMemcpyHostToDevice, c->stream));
+            d_ops = (const uint32_t*)p;
+        }
+        int* d_bad = (int*)c->alloc(sizeof(int));
+        tmp.push_back(d_bad);
+        ZKM_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+        zkm_launch_logic_trace(c, d_ops, nops, n, out_dev, d_bad);
+        int bad = 0;
+        ZKM_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+        for (void* p : tmp) c->release(p);
+        tmp.clear();
+        if (bad) throw std::runtime_error("zkm_logic_trace: op code out of range (0 and, 1 or, 2 xor, 3 nor)");
+    } catch (const std::exception& e) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* p : tmp) c->release(p);
+        return fail(err, e.what());
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -361,3 +361,33 @@ void zkm_launch_poseidon_trace(zkm_ctx* c, uint64_t seed, size_t num_perms, unsi
     hipLaunchKernelGGL(k_poseidon_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, seed, num_perms, n, out);
     ZKM_HIP_CHECK(hipGetLastError());
 }
+
+// ------------------------------------------------------------------ LogicStark witness (logic.rs:122-183)
+// One thread per row; stores are coalesced per column (column-major).
+__global__ __launch_bounds__(256) void k_logic_trace(const uint32_t* __restrict__ ops, size_t nops, size_t n, gl_t* __restrict__ out,
+                                                     int* __restrict__ bad) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    uint32_t op = 4, a = 0, b = 0, res = 0;
+    if (r < nops) {
+        op = ops[3 * r];
+        a = ops[3 * r + 1];
+        b = ops[3 * r + 2];
+        if (op > 3) { *bad = 1; op = 4; a = b = 0; }
+        else res = op == 0 ? (a & b) : op == 1 ? (a | b) : op == 2 ? (a ^ b) : ~(a | b);
+    }
+#pragma unroll
+    for (uint32_t f = 0; f < 4; f++) out[(size_t)f * n + r] = op == f;
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) {
+        out[(size_t)(4 + i) * n + r] = (a >> i) & 1;
+        out[(size_t)(36 + i) * n + r] = (b >> i) & 1;
+    }
+    out[(size_t)68 * n + r] = res;
+}
+
+void zkm_launch_logic_trace(zkm_ctx* c, const uint32_t* d_ops, size_t nops, size_t n, gl_t* out, int* d_bad) {
+    zkm_prof_scope ps(c, "logic_trace");
+    hipLaunchKernelGGL(k_logic_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_ops, nops, n, out, d_bad);
+    ZKM_HIP_CHECK(hipGetLastError());
+}

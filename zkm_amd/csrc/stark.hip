@@ -135,6 +135,88 @@ __device__ void eval_poseidon_constraints(const gl_t* __restrict__ lv, size_t cs
     for (int i = 0; i < 12; i++) k.constraint(gl_sub(s[i], lv[(size_t)(13 + i) * cs]));
 }
 
+// LogicStark (logic.rs:199-248; columns :25-50).  64 booleanity constraints then the result constraint.
+template <int NA>
+__device__ void eval_logic_constraints(const gl_t* __restrict__ lv, size_t cs, consumer_t<NA>& k) {
+    gl_t is_and = lv[0], is_or = lv[cs], is_xor = lv[2 * cs], is_nor = lv[3 * cs];
+    gl_t sum_coeff = gl_sub(gl_add(is_or, is_xor), is_nor);
+    gl_t and_coeff = gl_add(gl_sub(gl_sub(is_and, is_or), gl_add(is_xor, is_xor)), is_nor);
+    gl_t x = 0, y = 0, x_land_y = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+        gl_t b = lv[(size_t)(4 + i) * cs];
+        k.constraint(gl_mul(b, gl_sub(b, 1)));
+        x = gl_add(x, gl_mul(b, (gl_t)1 << i));
+    }
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+        gl_t b = lv[(size_t)(36 + i) * cs];
+        k.constraint(gl_mul(b, gl_sub(b, 1)));
+        y = gl_add(y, gl_mul(b, (gl_t)1 << i));
+        x_land_y = gl_add(x_land_y, gl_mul(gl_mul(lv[(size_t)(4 + i) * cs], b), (gl_t)1 << i));
+    }
+    gl_t x_op_y = gl_add(gl_add(gl_mul(sum_coeff, gl_add(x, y)), gl_mul(and_coeff, x_land_y)), gl_mul(is_nor, 0xFFFFFFFFULL));
+    k.constraint(gl_sub(lv[(size_t)68 * cs], x_op_y));
+}
+
+// KeccakSpongeStark (keccak_sponge_stark.rs:456-567; columns keccak_sponge/columns.rs:19-70).  nv = lv + dnext.
+template <int NA>
+__device__ void eval_keccak_sponge_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
+    const gl_t* __restrict__ nv = lv + dnext;
+    enum { FULL = 0, CONTEXT = 1, SEGMENT = 2, TIMESTAMP = 37, LEN = 38, ABSORBED = 39, FINAL_LEN = 40, ORIG_RATE = 176,
+           ORIG_CAP = 210, PARTIAL = 396, DIGEST = 438 };
+    gl_t full = lv[FULL];
+    k.constraint(gl_mul(full, gl_sub(full, 1)));
+    gl_t is_final = 0, next_final = 0;
+#pragma unroll 4
+    for (int i = 0; i < 136; i++) {
+        is_final = gl_add(is_final, lv[(size_t)(FINAL_LEN + i) * cs]);
+        next_final = gl_add(next_final, nv[(size_t)(FINAL_LEN + i) * cs]);
+    }
+    k.constraint(gl_mul(is_final, gl_sub(is_final, 1)));
+#pragma unroll 4
+    for (int i = 0; i < 136; i++) {
+        gl_t f = lv[(size_t)(FINAL_LEN + i) * cs];
+        k.constraint(gl_mul(f, gl_sub(f, 1)));
+    }
+    k.constraint(gl_mul(is_final, full));
+    gl_t absorbed = lv[(size_t)ABSORBED * cs];
+    k.first_row(absorbed);
+#pragma unroll 2
+    for (int i = 0; i < 50; i++) k.first_row(lv[(size_t)(ORIG_RATE + i) * cs]);  // original_rate then original_capacity
+    // both scaled by (x - last) inside transition(): fold is_final / full into it once
+    gl_t fin_t = gl_mul(is_final, k.z_last), full_t = gl_mul(full, k.z_last);
+    k.constraint(gl_mul(fin_t, nv[(size_t)ABSORBED * cs]));
+#pragma unroll 2
+    for (int i = 0; i < 50; i++) k.constraint(gl_mul(fin_t, nv[(size_t)(ORIG_RATE + i) * cs]));
+    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)CONTEXT * cs], nv[(size_t)CONTEXT * cs])));
+    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)SEGMENT * cs], nv[(size_t)SEGMENT * cs])));
+    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)TIMESTAMP * cs], nv[(size_t)TIMESTAMP * cs])));
+#pragma unroll 2
+    for (int l = 0; l < 8; l++) {
+        gl_t cur = lv[(size_t)(DIGEST + 4 * l) * cs];
+#pragma unroll
+        for (int i = 1; i < 4; i++) cur = gl_add(cur, gl_mul(lv[(size_t)(DIGEST + 4 * l + i) * cs], (gl_t)1 << (8 * i)));
+        k.constraint(gl_mul(full_t, gl_sub(nv[(size_t)(ORIG_RATE + l) * cs], cur)));
+    }
+#pragma unroll 2
+    for (int i = 0; i < 42; i++)  // rate u32s 8..33 then the 16 capacity u32s are contiguous in both views
+        k.constraint(gl_mul(full_t, gl_sub(nv[(size_t)(ORIG_RATE + 8 + i) * cs], lv[(size_t)(PARTIAL + i) * cs])));
+    k.constraint(gl_mul(full_t, gl_sub(gl_add(absorbed, 136), nv[(size_t)ABSORBED * cs])));
+    gl_t is_dummy = gl_sub(gl_sub(1, full), is_final);
+    k.transition(gl_mul(is_dummy, gl_add(nv[FULL], next_final)));
+    gl_t offset = gl_sub(lv[(size_t)LEN * cs], absorbed);
+#pragma unroll 4
+    for (int i = 0; i < 136; i++) k.constraint(gl_mul(lv[(size_t)(FINAL_LEN + i) * cs], gl_sub(offset, (gl_t)i)));
+}
+
+template <int TABLE, int NA>
+__device__ __forceinline__ void eval_table_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
+    if constexpr (TABLE == ZKM_TABLE_POSEIDON) eval_poseidon_constraints<NA>(lv, cs, k);
+    else if constexpr (TABLE == ZKM_TABLE_LOGIC) eval_logic_constraints<NA>(lv, cs, k);
+    else eval_keccak_sponge_constraints<NA>(lv, cs, dnext, k);
+}
+
 // CTL checks driven by the column-set description (eval_helper_columns cross_table_lookup.rs:1006-1058,
 // eval_cross_table_lookup_checks :1067-1150).  The benchmark's fake CTL data (helper columns, no column sets)
 // is the ncolsets == 0 case: only the last-row / transition checks on Z are emitted.
@@ -183,8 +265,8 @@ __device__ void eval_ctl_constraints(const ctl_dev& d, const gl_t* __restrict__ 
 // One thread per point of the quotient domain g<w_2n>, visited in LDE storage order: storage row j < 2n
 // of the 4n-row LDE is natural quotient index i = bitrev_{L-1}(j) (every `step` = 2nd natural LDE row,
 // prover.rs:668-675); "next" is natural +2 in the 2n domain (prover.rs:704) = +4 in the 4n domain.
-template <int NA>
-__global__ __launch_bounds__(256) void k_quotient_poseidon(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux,
+template <int TABLE, int NA>
+__global__ __launch_bounds__(256) void k_quotient(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux,
                                                            unsigned log_n, unsigned lde_bits, ctl_dev ctl, const gl_t* alphas,
                                                            const gl_t* __restrict__ wpow /* w_{4n}^t two-level table */,
                                                            gl_t gn, gl_t zh_inv0, gl_t zh_inv1, gl_t last, gl_t w_n, gl_t n_inv,
@@ -213,7 +295,7 @@ __global__ __launch_bounds__(256) void k_quotient_poseidon(const gl_t* __restric
     k.l_first = gl_mul(zn, gl_mul(dinv, d1));
     k.l_last = gl_mul(zn, gl_mul(dinv, d0));
 
-    eval_poseidon_constraints<NA>(trace + j, N, k);
+    eval_table_constraints<TABLE, NA>(trace + j, N, (ptrdiff_t)jn - (ptrdiff_t)j, k);
 
     eval_ctl_constraints<NA>(ctl, trace + j, N, (ptrdiff_t)jn - (ptrdiff_t)j, aux, j, jn, k);
     gl_t zi = (i & 1) ? zh_inv1 : zh_inv0;
@@ -224,8 +306,8 @@ __global__ __launch_bounds__(256) void k_quotient_poseidon(const gl_t* __restric
 // quotient polys: d_out = nalphas x 2n natural-order coefficients (device)
 static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_batch* aux, const ctl_dev_owner& own,
                             const gl_t* alphas_host, size_t nalphas, gl_t* d_out) {
-    if (table_id != ZKM_TABLE_POSEIDON || trace->ncols != ZKM_POSEIDON_COLS)
-        throw std::runtime_error("zkm_quotient: only the Poseidon table (262 columns) has a constraint kernel");
+    if (zkm_table_width(table_id) == 0 || trace->ncols != zkm_table_width(table_id))
+        throw std::runtime_error("zkm_quotient: unknown table id, or the trace width does not match the table");
     if (trace->rate_bits != 2 || aux->rate_bits != 2 || trace->log_n != aux->log_n)
         throw std::runtime_error("zkm_quotient: rate_bits must be 2 and the batches must have equal degree");
     if (nalphas < 1 || nalphas > 2) throw std::runtime_error("zkm_quotient: 1 or 2 challenges supported");
@@ -243,14 +325,21 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     ZKM_HIP_CHECK(hipMemcpyAsync(d_alphas, alphas_host, nalphas * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
     gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
     {
-        zkm_prof_scope ps(c, "quotient_poseidon");
+        static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge"};
+        zkm_prof_scope ps(c, names[table_id]);
         dim3 grid((size + 255) / 256), block(256);
-        if (nalphas == 1)
-            hipLaunchKernelGGL(k_quotient_poseidon<1>, grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, ctl, d_alphas,
-                               wpow, gn, zh0, zh1, last, w_n, n_inv, d_vals);
-        else
-            hipLaunchKernelGGL(k_quotient_poseidon<2>, grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, ctl, d_alphas,
-                               wpow, gn, zh0, zh1, last, w_n, n_inv, d_vals);
+#define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
+    hipLaunchKernelGGL((k_quotient<T, NA>), grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, ctl, d_alphas, wpow, \
+                       gn, zh0, zh1, last, w_n, n_inv, d_vals)
+        switch (table_id * 2 + (int)nalphas - 1) {
+            case 0: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON, 1); break;
+            case 1: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON, 2); break;
+            case 2: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_LOGIC, 1); break;
+            case 3: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_LOGIC, 2); break;
+            case 4: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK_SPONGE, 1); break;
+            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK_SPONGE, 2); break;
+        }
+#undef ZKM_LAUNCH_QUOTIENT
         ZKM_HIP_CHECK(hipGetLastError());
     }
     // coset_ifft(g) of each challenge's evaluations (prover.rs:784-788)

@@ -51,6 +51,9 @@ class CtlTable:
     def le_bits(self, cs):
         return self.column(local=[(c, 1 << i) for i, c in enumerate(cs)])
 
+    def le_bytes(self, cs):
+        return self.column(local=[(c, 1 << (8 * i)) for i, c in enumerate(cs)])
+
     def sum(self, cs):
         return self.column(local=[(c, 1) for c in cs])
 
