@@ -96,6 +96,17 @@ int zkm_poseidon_trace(zkm_ctx* ctx, uint64_t seed, size_t num_perms, unsigned l
 int zkm_keccak_sponge_trace(zkm_ctx* ctx, const uint8_t* inputs, const uint64_t* input_off, const uint64_t* meta, size_t nops,
                             unsigned log_n, uint64_t* out_dev, size_t* rows_used_out, char** err);
 
+/* ------------------------------------------------------------------ a12: KeccakStark witness
+ * KeccakStark::generate_trace (keccak/keccak_stark.rs:62-236, register map keccak/columns.rs): 2431 columns, 24 rows per
+ * permutation (round flags, timestamp, the round's input limbs A, and the bit-decomposed theta / rho-pi / chi / iota
+ * intermediates C, C', A', A'', A'''[0,0]); rows past 24*nperms are zero.
+ *   inputs      nperms x 25 u64 permutation inputs, A(x, y) = inputs[p][5y + x] (host or device)
+ *   timestamps  nperms u64 (host or device)
+ * Output: 2431 x 2^log_n column-major, device pointer.  Fails if 24*nperms > 2^log_n. */
+#define ZKM_KECCAK_COLS 2431
+int zkm_keccak_trace(zkm_ctx* ctx, const uint64_t* inputs, const uint64_t* timestamps, size_t nperms, unsigned log_n,
+                     uint64_t* out_dev, char** err);
+
 /* ------------------------------------------------------------------ N2: LogicStark witness
  * LogicStark::generate_trace (logic.rs:150-183) with Operation::into_row (:122-142): 69 columns x 2^log_n rows,
  * column-major; row r < nops holds operation r (flag column, the 32 little-endian bits of each input, the result),
@@ -127,10 +138,12 @@ void zkm_standard_config(zkm_stark_config* cfg);
 /* Tables with a constraint kernel (the reference's Table enum, all_stark.rs:96-110, has 12):
  *   POSEIDON       poseidon/poseidon_stark.rs:554-594   262 columns
  *   LOGIC          logic.rs:199-248                       69 columns
- *   KECCAK_SPONGE  keccak_sponge_stark.rs:456-567        470 columns */
+ *   KECCAK_SPONGE  keccak_sponge_stark.rs:456-567        470 columns
+ *   KECCAK         keccak/keccak_stark.rs:256-413       2431 columns */
 #define ZKM_TABLE_POSEIDON 0
 #define ZKM_TABLE_LOGIC 1
 #define ZKM_TABLE_KECCAK_SPONGE 2
+#define ZKM_TABLE_KECCAK 3
 size_t zkm_table_width(int table_id); /* 0 for an unknown id */
 
 /* Proof blob (uint64_t words) -- the fields of StarkProofWithMetadata (proof.rs:178-201) flattened:

@@ -148,12 +148,95 @@ static void TNAME(eval_keccak_sponge)(const T* lv, const T* nv, TNAME(consumer) 
     for (int i = 0; i < 136; i++) TNAME(cons)(k, T_MUL(lv[40 + i], T_SUB(offset, T_FROMB((gl_t)i))));
 }
 
+/* ---- KeccakStark constraints: keccak/keccak_stark.rs:256-413 (797 = 3 + 320 + 50 + 320 + 50 + 4 + 50), register map
+ * keccak/columns.rs:7-134, xor_gen / xor3_gen / andn_gen keccak/logic.rs:16-54, round-constant bits keccak/constants.rs ---- */
+#ifndef ZKO_KECCAK_REGS
+#define ZKO_KECCAK_REGS
+static const uint8_t KK_R[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};
+static const uint64_t KK_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+enum { KK_TIMESTAMP = 24, KK_A = 25, KK_C = 75, KK_CP = 395, KK_AP = 715, KK_APP = 2315, KK_APP00_BITS = 2365, KK_APPP00 = 2429, KK_COLS = 2431 };
+static inline int kk_a(int x, int y) { return KK_A + (x * 5 + y) * 2; }
+static inline int kk_c(int x, int z) { return KK_C + x * 64 + z; }
+static inline int kk_cp(int x, int z) { return KK_CP + x * 64 + z; }
+static inline int kk_ap(int x, int y, int z) { return KK_AP + x * 320 + y * 64 + z; }
+static inline int kk_b(int x, int y, int z) { int a = (x + 3 * y) % 5, b = x; return kk_ap(a, b, (z + 64 - KK_R[a][b]) % 64); }
+static inline int kk_app(int x, int y) { return KK_APP + x * 10 + y * 2; }
+static inline int kk_appp(int x, int y) { return (x == 0 && y == 0) ? KK_APPP00 : kk_app(x, y); }
+#endif
+static inline T TNAME(xor_gen)(T x, T y) { return T_SUB(T_ADD(x, y), T_MUL(x, T_ADD(y, y))); }
+static inline T TNAME(xor3_gen)(T x, T y, T z) { return TNAME(xor_gen)(x, TNAME(xor_gen)(y, z)); }
+static void TNAME(eval_keccak)(const T* lv, const T* nv, TNAME(consumer) * k) {
+    T one = T_FROMB(1);
+    T filter = lv[23];
+    TNAME(cons)(k, T_MUL(filter, T_SUB(filter, one)));
+    T not_final = T_SUB(one, lv[23]);
+    TNAME(cons)(k, T_MUL(not_final, filter));
+    T sum_flags = T_FROMB(0);
+    for (int i = 0; i < 24; i++) sum_flags = T_ADD(sum_flags, lv[i]);
+    TNAME(cons)(k, T_MUL(T_MUL(sum_flags, not_final), T_SUB(nv[KK_TIMESTAMP], lv[KK_TIMESTAMP])));
+    for (int x = 0; x < 5; x++)
+        for (int z = 0; z < 64; z++) {
+            T xr = TNAME(xor3_gen)(lv[kk_c(x, z)], lv[kk_c((x + 4) % 5, z)], lv[kk_c((x + 1) % 5, (z + 63) % 64)]);
+            TNAME(cons)(k, T_SUB(lv[kk_cp(x, z)], xr));
+        }
+    for (int x = 0; x < 5; x++)
+        for (int y = 0; y < 5; y++)
+            for (int half = 0; half < 2; half++) {
+                T acc = T_FROMB(0);
+                for (int z = 32 * half + 31; z >= 32 * half; z--)
+                    acc = T_ADD(T_ADD(acc, acc), TNAME(xor3_gen)(lv[kk_ap(x, y, z)], lv[kk_c(x, z)], lv[kk_cp(x, z)]));
+                TNAME(cons)(k, T_SUB(acc, lv[kk_a(x, y) + half]));
+            }
+    for (int x = 0; x < 5; x++)
+        for (int z = 0; z < 64; z++) {
+            T sum = T_FROMB(0);
+            for (int i = 0; i < 5; i++) sum = T_ADD(sum, lv[kk_ap(x, i, z)]);
+            T diff = T_SUB(sum, lv[kk_cp(x, z)]);
+            TNAME(cons)(k, T_MUL(T_MUL(diff, T_SUB(diff, T_FROMB(2))), T_SUB(diff, T_FROMB(4))));
+        }
+    for (int x = 0; x < 5; x++)
+        for (int y = 0; y < 5; y++)
+            for (int half = 0; half < 2; half++) {
+                T acc = T_FROMB(0);
+                for (int z = 32 * half + 31; z >= 32 * half; z--) {
+                    T andn = T_MUL(T_SUB(one, lv[kk_b((x + 1) % 5, y, z)]), lv[kk_b((x + 2) % 5, y, z)]);
+                    acc = T_ADD(T_ADD(acc, acc), TNAME(xor_gen)(lv[kk_b(x, y, z)], andn));
+                }
+                TNAME(cons)(k, T_SUB(acc, lv[kk_app(x, y) + half]));
+            }
+    for (int half = 0; half < 2; half++) {
+        T acc = T_FROMB(0);
+        for (int z = 32 * half + 31; z >= 32 * half; z--) acc = T_ADD(T_ADD(acc, acc), lv[KK_APP00_BITS + z]);
+        TNAME(cons)(k, T_SUB(acc, lv[kk_app(0, 0) + half]));
+    }
+    for (int half = 0; half < 2; half++) {
+        T acc = T_FROMB(0);
+        for (int z = 32 * half + 31; z >= 32 * half; z--) {
+            T rc_bit = T_FROMB(0);
+            for (int r = 0; r < 24; r++) rc_bit = T_ADD(rc_bit, T_MULB(lv[r], (KK_RC[r] >> z) & 1));
+            acc = T_ADD(T_ADD(acc, acc), TNAME(xor_gen)(lv[KK_APP00_BITS + z], rc_bit));
+        }
+        TNAME(cons)(k, T_SUB(acc, lv[KK_APPP00 + half]));
+    }
+    T not_last = T_SUB(one, lv[23]);
+    for (int x = 0; x < 5; x++)
+        for (int y = 0; y < 5; y++)
+            for (int half = 0; half < 2; half++)
+                TNAME(cons_transition)(k, T_MUL(not_last, T_SUB(lv[kk_appp(x, y) + half], nv[kk_a(x, y) + half])));
+}
+
 /* table dispatch (Table ids of include/zkm_hip.h) */
-static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : 0; }
+static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : 0; }
 static void TNAME(eval_table)(int table_id, const T* lv, const T* nv, TNAME(consumer) * k) {
     if (table_id == 0) TNAME(eval_poseidon)(lv, k);
     else if (table_id == 1) TNAME(eval_logic)(lv, k);
-    else TNAME(eval_keccak_sponge)(lv, nv, k);
+    else if (table_id == 2) TNAME(eval_keccak_sponge)(lv, nv, k);
+    else TNAME(eval_keccak)(lv, nv, k);
 }
 
 /* ---- general CTL checks driven by the column-set description ----

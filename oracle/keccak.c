@@ -134,3 +134,63 @@ size_t zko_keccak_sponge_trace(const uint8_t* inputs, const uint64_t* off, const
     }
     return rows;
 }
+
+/* ---- KeccakStark witness rows: restates keccak/keccak_stark.rs:62-226 (generate_trace_rows_for_perm,
+ * copy_output_to_input, generate_trace_row_for_round) with the register map of keccak/columns.rs.  24 rows per
+ * permutation; A(x, y) = input[y*5 + x]. ---- */
+static const uint8_t KW_R[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};
+
+size_t zko_keccak_trace(const uint64_t* inputs, const uint64_t* timestamps, size_t nperms, unsigned log_n, uint64_t* out) {
+    size_t n = (size_t)1 << log_n;
+    if (nperms * 24 > n) return 0;
+    memset(out, 0, sizeof(uint64_t) * ZKO_KECCAK_COLS * n);
+    for (size_t p = 0; p < nperms; p++) {
+        uint64_t A[5][5];
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++) A[x][y] = inputs[25 * p + y * 5 + x];
+        for (int round = 0; round < 24; round++) {
+            size_t row = 24 * p + round;
+#define CELL(c) out[(size_t)(c) * n + row]
+            CELL(round) = 1;
+            CELL(24) = timestamps[p];
+            uint64_t C[5], Cp[5], Ap[5][5], App[5][5];
+            for (int x = 0; x < 5; x++) {
+                C[x] = A[x][0] ^ A[x][1] ^ A[x][2] ^ A[x][3] ^ A[x][4];
+                for (int y = 0; y < 5; y++) {
+                    CELL(25 + (x * 5 + y) * 2) = (uint32_t)A[x][y];
+                    CELL(25 + (x * 5 + y) * 2 + 1) = A[x][y] >> 32;
+                }
+            }
+            for (int x = 0; x < 5; x++) Cp[x] = C[x] ^ C[(x + 4) % 5] ^ rotl(C[(x + 1) % 5], 1);
+            for (int x = 0; x < 5; x++)
+                for (int z = 0; z < 64; z++) {
+                    CELL(75 + x * 64 + z) = (C[x] >> z) & 1;
+                    CELL(395 + x * 64 + z) = (Cp[x] >> z) & 1;
+                }
+            for (int x = 0; x < 5; x++)
+                for (int y = 0; y < 5; y++) {
+                    Ap[x][y] = A[x][y] ^ C[x] ^ Cp[x];
+                    for (int z = 0; z < 64; z++) CELL(715 + x * 320 + y * 64 + z) = (Ap[x][y] >> z) & 1;
+                }
+            /* B[x, y] = ROT(A'[(x + 3y) % 5, x], r); A''[x, y] = B[x, y] ^ (~B[x+1, y] & B[x+2, y]) */
+            uint64_t B[5][5];
+            for (int x = 0; x < 5; x++)
+                for (int y = 0; y < 5; y++) { int a = (x + 3 * y) % 5; B[x][y] = rotl(Ap[a][x], KW_R[a][x]); }
+            for (int x = 0; x < 5; x++)
+                for (int y = 0; y < 5; y++) {
+                    App[x][y] = B[x][y] ^ (~B[(x + 1) % 5][y] & B[(x + 2) % 5][y]);
+                    CELL(2315 + x * 10 + y * 2) = (uint32_t)App[x][y];
+                    CELL(2315 + x * 10 + y * 2 + 1) = App[x][y] >> 32;
+                }
+            for (int z = 0; z < 64; z++) CELL(2365 + z) = (App[0][0] >> z) & 1;
+            uint64_t appp = App[0][0] ^ RC[round];
+            CELL(2429) = (uint32_t)appp;
+            CELL(2430) = appp >> 32;
+#undef CELL
+            for (int x = 0; x < 5; x++)
+                for (int y = 0; y < 5; y++) A[x][y] = App[x][y];
+            A[0][0] = appp;
+        }
+    }
+    return nperms * 24;
+}

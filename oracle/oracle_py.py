@@ -205,6 +205,17 @@ class Oracle:
     def proof_words(self, cfg, log_n, ncols, naux, nctl):
         return self.lib.zko_proof_words(C.byref(cfg), log_n, ncols, naux, nctl)
 
+    def keccak_trace(self, inputs, timestamps, log_n):
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1, 25)
+        ts = np.ascontiguousarray(timestamps, dtype=np.uint64)
+        out = np.zeros(2431 << log_n, dtype=np.uint64)
+        self.lib.zko_keccak_trace.restype = C.c_size_t
+        self.lib.zko_keccak_trace.argtypes = [u64p, u64p, C.c_size_t, C.c_uint, u64p]
+        used = self.lib.zko_keccak_trace(_ptr(inputs), _ptr(ts), len(inputs), log_n, _ptr(out))
+        if used == 0 and len(inputs):
+            raise RuntimeError("oracle keccak_trace: permutations do not fit")
+        return out
+
     def logic_trace(self, ops, log_n):
         ops = np.ascontiguousarray(ops, dtype=np.uint32).reshape(-1, 3)
         out = np.zeros(69 << log_n, dtype=np.uint64)

@@ -83,6 +83,11 @@ void zko_poseidon_trace(uint64_t seed, size_t num_perms, unsigned log_n, uint64_
 #define ZKO_TABLE_POSEIDON 0
 #define ZKO_TABLE_LOGIC 1
 #define ZKO_TABLE_KECCAK_SPONGE 2
+#define ZKO_TABLE_KECCAK 3
+#define ZKO_KECCAK_COLS 2431
+/* KeccakStark::generate_trace (keccak/keccak_stark.rs:62-236): inputs = nperms x 25 u64, one timestamp per permutation; out = 2431 x 2^log_n.
+ * Returns the rows used (24 per permutation), 0 if they do not fit. */
+size_t zko_keccak_trace(const uint64_t* inputs, const uint64_t* timestamps, size_t nperms, unsigned log_n, uint64_t* out);
 /* LogicStark::generate_trace (logic.rs:150-183): ops = nops x (op (0 and, 1 or, 2 xor, 3 nor), in0, in1); out = 69 x 2^log_n */
 void zko_logic_trace(const uint32_t* ops, size_t nops, unsigned log_n, uint64_t* out);
 typedef struct {

@@ -34,3 +34,30 @@ def build(oracle, log_sponge=4, seed=21):
     looking, looked = T.ctl_logic_keccak_sponge(0, 1, cs, cl)
     tables = [(T.TABLE_KECCAK_SPONGE, sponge, 470, log_sponge, cs), (T.TABLE_LOGIC, logic, 69, log_logic, cl)]
     return tables, [(looking, looked)], ops
+
+
+def keccak_inputs_from_sponge(sponge_trace, log_n, rows):
+    """The permutation inputs (xored rate ++ original capacity, as u64 words) and timestamps the sponge rows request."""
+    n = 1 << log_n
+    tr = sponge_trace.reshape(T.WIDTH[T.TABLE_KECCAK_SPONGE], n)
+    u32 = np.concatenate([tr[T.KS_XORED:T.KS_XORED + 34, :rows], tr[T.KS_ORIG_CAP:T.KS_ORIG_CAP + 16, :rows]]).T   # rows x 50
+    inputs = (u32[:, 0::2] | (u32[:, 1::2] << np.uint64(32))).astype(np.uint64)
+    return np.ascontiguousarray(inputs), tr[T.KS_TIMESTAMP, :rows].copy()
+
+
+def build3(oracle, log_sponge=3, seed=22):
+    """KeccakSponge + Keccak + Logic with the three cross-table lookups that link them in the reference
+    (all_stark.rs:214-240, 340-355)."""
+    data, off, meta, rows, nops = ops_for_rows(seed, (1 << log_sponge) - 1)
+    sponge, _ = oracle.keccak_sponge_trace(data, off, meta, log_sponge)
+    ops = logic_ops_from_sponge(sponge, log_sponge, rows)
+    log_logic = max(3, int(np.ceil(np.log2(len(ops)))))
+    logic = oracle.logic_trace(ops, log_logic)
+    inputs, ts = keccak_inputs_from_sponge(sponge, log_sponge, rows)
+    log_keccak = int(np.ceil(np.log2(24 * rows)))
+    keccak = oracle.keccak_trace(inputs, ts, log_keccak)
+    cs, cl, ck = CtlTable(), CtlTable(), CtlTable()
+    tables = [(T.TABLE_KECCAK_SPONGE, sponge, 470, log_sponge, cs), (T.TABLE_KECCAK, keccak, 2431, log_keccak, ck),
+              (T.TABLE_LOGIC, logic, 69, log_logic, cl)]
+    ctls = [T.ctl_keccak_inputs(0, 1, cs, ck), T.ctl_keccak_outputs(0, 1, cs, ck), T.ctl_logic_keccak_sponge(0, 2, cs, cl)]
+    return tables, ctls, (ops, inputs, ts)

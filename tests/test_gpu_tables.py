@@ -31,6 +31,10 @@ def fake_ctl_aux(log_n, seed=3):
 
 
 def table_trace(oracle, table_id, log_n, seed=2):
+    if table_id == T.TABLE_KECCAK:
+        k = (1 << log_n) // 24
+        rng = np.random.default_rng(seed)
+        return oracle.keccak_trace(rng.integers(0, 1 << 64, (k, 25), dtype=np.uint64), rng.integers(0, 1 << 30, k), log_n)
     if table_id == T.TABLE_LOGIC:
         return oracle.logic_trace(random_logic_ops(seed, (1 << log_n) - 5), log_n)
     data, off, meta, rows, nops = ops_for_rows(seed, (1 << log_n) - 3)
@@ -65,8 +69,30 @@ def test_logic_trace_errors(ctx, zkm):
     assert not ctx.logic_trace(np.zeros((0, 3), dtype=np.uint32), 3).download().any()
 
 
+@pytest.mark.parametrize("log_n,k", [(5, 1), (7, 5), (10, 42), (13, 300)])
+def test_keccak_trace_matches_oracle(ctx, oracle, log_n, k):
+    rng = np.random.default_rng(log_n)
+    inputs = rng.integers(0, 1 << 64, (k, 25), dtype=np.uint64)
+    inputs[0] = 0
+    ts = rng.integers(0, 1 << 40, k).astype(np.uint64)
+    want = oracle.keccak_trace(inputs, ts, log_n)
+    got = ctx.keccak_trace(inputs, ts, log_n)
+    assert (got.download() == want).all()
+    # device-resident inputs, caller-provided output
+    d_in = ctx.alloc(inputs.size).upload(inputs.reshape(-1))
+    d_ts = ctx.alloc(ts.size).upload(ts)
+    ctx.keccak_trace(d_in, d_ts, log_n, out=got)
+    assert (got.download() == want).all()
+
+
+def test_keccak_trace_errors(ctx, zkm):
+    with pytest.raises(zkm.ZkmError, match="more rows"):
+        ctx.keccak_trace(np.zeros((2, 25), dtype=np.uint64), [1, 2], 5)
+    assert not ctx.keccak_trace(np.zeros((0, 25), dtype=np.uint64), np.zeros(0, dtype=np.uint64), 5).download().any()
+
+
 @pytest.mark.parametrize("table_id,log_n", [(T.TABLE_LOGIC, 5), (T.TABLE_LOGIC, 11), (T.TABLE_KECCAK_SPONGE, 5),
-                                            (T.TABLE_KECCAK_SPONGE, 10)])
+                                            (T.TABLE_KECCAK_SPONGE, 10), (T.TABLE_KECCAK, 5), (T.TABLE_KECCAK, 8)])
 @pytest.mark.parametrize("nalphas", [1, 2])
 def test_quotient_matches_oracle(ctx, zkm, oracle, table_id, log_n, nalphas):
     W = T.WIDTH[table_id]
@@ -84,7 +110,7 @@ def test_quotient_matches_oracle(ctx, zkm, oracle, table_id, log_n, nalphas):
 
 
 @pytest.mark.parametrize("table_id,log_n", [(T.TABLE_LOGIC, 4), (T.TABLE_LOGIC, 10), (T.TABLE_KECCAK_SPONGE, 4),
-                                            (T.TABLE_KECCAK_SPONGE, 9)])
+                                            (T.TABLE_KECCAK_SPONGE, 9), (T.TABLE_KECCAK, 5), (T.TABLE_KECCAK, 8)])
 def test_single_table_proof_is_bit_exact(ctx, oracle, table_id, log_n):
     W = T.WIDTH[table_id]
     trace = table_trace(oracle, table_id, log_n, seed=7)
@@ -140,3 +166,35 @@ def test_sponge_logic_lookup_device_resident_large(ctx, oracle):
     proofs, chal, offs = ctx.prove_with_traces(dev_tables, [(looking, looked)])
     host_tables = [(T.TABLE_KECCAK_SPONGE, sponge, 470, log_sponge, cs), (T.TABLE_LOGIC, d_logic.download(), 69, log_logic, cl)]
     assert oracle.verify_all(host_tables, [(looking, looked)], proofs, chal) == 0
+
+
+def test_sponge_keccak_logic_is_bit_exact_and_verifies(ctx, oracle):
+    """The three tables of the Keccak precompile path with their three lookups (all_stark.rs:214-240, 340-355)."""
+    tables, ctls, (ops, inputs, ts) = logic_fixtures.build3(oracle, log_sponge=4)
+    assert (ctx.keccak_trace(inputs, ts, tables[1][3]).download() == tables[1][1]).all()
+    want, wchal, woffs = oracle.prove_with_traces(tables, ctls)
+    got, chal, offs = ctx.prove_with_traces(tables, ctls)
+    assert offs == woffs and (chal == wchal).all()
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing word %d" % bad[0]
+    assert oracle.verify_all(tables, ctls, got, chal) == 0
+
+
+def test_sponge_keccak_logic_device_resident_large(ctx, oracle):
+    """2^9 sponge rows -> 2^14 Keccak rows (2431 columns) and 2^15 Logic rows, witnesses generated and kept on the device."""
+    log_sponge = 9
+    data, off, meta, rows, nops = ops_for_rows(35, (1 << log_sponge) - 1)
+    d_sponge, used = ctx.keccak_sponge_trace(data, off, meta, log_sponge)
+    sponge = d_sponge.download()
+    ops = logic_fixtures.logic_ops_from_sponge(sponge, log_sponge, rows)
+    inputs, ts = logic_fixtures.keccak_inputs_from_sponge(sponge, log_sponge, rows)
+    log_logic, log_keccak = int(np.ceil(np.log2(len(ops)))), int(np.ceil(np.log2(24 * rows)))
+    d_logic, d_keccak = ctx.logic_trace(ops, log_logic), ctx.keccak_trace(inputs, ts, log_keccak)
+    from zkm_amd.ctl import CtlTable
+    cs, cl, ck = CtlTable(), CtlTable(), CtlTable()
+    ctls = [T.ctl_keccak_inputs(0, 1, cs, ck), T.ctl_keccak_outputs(0, 1, cs, ck), T.ctl_logic_keccak_sponge(0, 2, cs, cl)]
+    dev = [(T.TABLE_KECCAK_SPONGE, d_sponge, 470, log_sponge, cs), (T.TABLE_KECCAK, d_keccak, 2431, log_keccak, ck),
+           (T.TABLE_LOGIC, d_logic, 69, log_logic, cl)]
+    proofs, chal, offs = ctx.prove_with_traces(dev, ctls)
+    host = [(t, b.download(), w, l, c) for (t, b, w, l, c) in dev]
+    assert oracle.verify_all(host, ctls, proofs, chal) == 0

@@ -23,9 +23,32 @@ def test_logic_trace_ops(oracle):
     assert not tr[:, 50:].any()
 
 
-@pytest.mark.parametrize("table_id,log_n", [(T.TABLE_LOGIC, 6), (T.TABLE_KECCAK_SPONGE, 5)])
+def test_keccak_trace_rows(oracle):
+    """keccak_stark.rs:655-686: the output limbs of row 23 are keccakf(input); plus round flags / timestamps / padding."""
+    rng = np.random.default_rng(4)
+    inputs = rng.integers(0, 1 << 64, (5, 25), dtype=np.uint64)
+    ts = np.arange(5, dtype=np.uint64) * 3 + 2
+    n = 128
+    tr = oracle.keccak_trace(inputs, ts, 7).reshape(2431, n)
+    for p in range(5):
+        want = oracle.keccakf(inputs[p])
+        row = 24 * p + 23
+        got = [int(tr[T.kk_reg_output_limb(2 * i), row]) | (int(tr[T.kk_reg_output_limb(2 * i + 1), row]) << 32) for i in range(25)]
+        assert got == [int(x) for x in want]
+        first = [int(tr[T.kk_reg_input_limb(2 * i), 24 * p]) | (int(tr[T.kk_reg_input_limb(2 * i + 1), 24 * p]) << 32) for i in range(25)]
+        assert first == [int(x) for x in inputs[p]]
+        assert (tr[:24, 24 * p:24 * p + 24] == np.eye(24, dtype=np.uint64)).all()
+        assert (tr[24, 24 * p:24 * p + 24] == ts[p]).all()
+    assert not tr[:, 120:].any()
+    assert tr[75:2315].max() == 1    # C, C', A' are bits
+
+
+@pytest.mark.parametrize("table_id,log_n", [(T.TABLE_LOGIC, 6), (T.TABLE_KECCAK_SPONGE, 5), (T.TABLE_KECCAK, 6)])
 def test_single_table_proof(oracle, table_id, log_n):
-    if table_id == T.TABLE_LOGIC:
+    if table_id == T.TABLE_KECCAK:
+        rng = np.random.default_rng(3)
+        trace = oracle.keccak_trace(rng.integers(0, 1 << 64, (2, 25), dtype=np.uint64), [5, 9], log_n)
+    elif table_id == T.TABLE_LOGIC:
         rng = np.random.default_rng(2)
         ops = np.stack([rng.integers(0, 4, 40), rng.integers(0, 1 << 32, 40), rng.integers(0, 1 << 32, 40)], axis=1)
         trace = oracle.logic_trace(ops, log_n)
@@ -37,7 +60,7 @@ def test_single_table_proof(oracle, table_id, log_n):
     assert oracle.verify(proof, 0, [], ncols=W, table_id=table_id) == 0
     # a corrupted witness cell makes the quotient a non-polynomial: verification must fail
     bad = trace.copy()
-    col = 68 if table_id == T.TABLE_LOGIC else 39   # RESULT / already_absorbed_bytes
+    col = {T.TABLE_LOGIC: 68, T.TABLE_KECCAK_SPONGE: 39, T.TABLE_KECCAK: 900}[table_id]   # RESULT / already_absorbed_bytes / an A' bit
     bad[col * (1 << log_n) + 1] ^= 1
     proof = oracle.prove(bad, log_n, EMPTY, [], ncols=W, table_id=table_id)
     assert oracle.verify(proof, 0, [], ncols=W, table_id=table_id) != 0
@@ -53,4 +76,17 @@ def test_sponge_logic_ctl(oracle):
     bad_ops[0, 1] ^= 4
     tid, tr, w, log_n, ct = tables[1]
     bad_tables = [tables[0], (tid, oracle.logic_trace(bad_ops, log_n), w, log_n, ct)]
+    assert oracle.check_ctls(bad_tables, ctls) != 0
+
+
+def test_sponge_keccak_logic_ctls(oracle):
+    tables, ctls, (ops, inputs, ts) = logic_fixtures.build3(oracle)
+    assert oracle.check_ctls(tables, ctls) == 0
+    proofs, chal, offs = oracle.prove_with_traces(tables, ctls)
+    assert oracle.verify_all(tables, ctls, proofs, chal) == 0
+    # a Keccak table that permutes a different input: the inputs lookup no longer balances
+    bad_inputs = inputs.copy()
+    bad_inputs[0, 3] ^= 1
+    tid, tr, w, log_n, ct = tables[1]
+    bad_tables = [tables[0], (tid, oracle.keccak_trace(bad_inputs, ts, log_n), w, log_n, ct), tables[2]]
     assert oracle.check_ctls(bad_tables, ctls) != 0

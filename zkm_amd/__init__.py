@@ -20,14 +20,15 @@ P = 0xFFFFFFFF00000001
 POSEIDON_COLS = 262
 KECCAK_SPONGE_COLS = 470
 LOGIC_COLS = 69
-TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE = 0, 1, 2
+KECCAK_COLS = 2431
+TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK = 0, 1, 2, 3
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
     "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
     "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_free",
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_leaf", "zkm_batch_merkle_path",
-    "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_logic_trace",
+    "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_keccak_trace", "zkm_logic_trace",
     "zkm_table_width", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
     "zkm_prove_single_table", "zkm_prove_openings", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
@@ -96,6 +97,7 @@ def load():
         "zkm_keccakf_batch": (C.c_int, [cp, cp, C.c_size_t, err]),
         "zkm_poseidon_trace": (C.c_int, [cp, C.c_uint64, C.c_size_t, C.c_uint, cp, err]),
         "zkm_keccak_sponge_trace": (C.c_int, [cp, cp, u64p, u64p, C.c_size_t, C.c_uint, cp, C.POINTER(C.c_size_t), err]),
+        "zkm_keccak_trace": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_logic_trace": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_table_width": (C.c_size_t, [C.c_int]),
         "zkm_challenger_init": (None, [C.POINTER(Challenger)]),
@@ -258,6 +260,21 @@ class Context:
         _check(self.L.zkm_keccak_sponge_trace(self.h, inputs.ctypes.data_as(C.c_void_p), input_off.ctypes.data_as(u64p),
                                               meta.ctypes.data_as(u64p), nops, log_n, _data_ptr(out), C.byref(used), C.byref(err)), err)
         return out, used.value
+
+    def keccak_trace(self, inputs, timestamps, log_n, out=None):
+        """KeccakStark::generate_trace on the GPU (keccak/keccak_stark.rs:62-236).  inputs: nperms x 25 uint64, timestamps:
+        nperms uint64 (ndarrays or DeviceBuffers).  Returns a DeviceBuffer of 2431 x 2^log_n words."""
+        if isinstance(inputs, DeviceBuffer):
+            nperms = inputs.words // 25
+        else:
+            inputs = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1, 25)
+            nperms = len(inputs)
+        if not isinstance(timestamps, DeviceBuffer):
+            timestamps = np.ascontiguousarray(timestamps, dtype=np.uint64)
+        out = out or self.alloc(KECCAK_COLS << log_n)
+        err = C.c_char_p()
+        _check(self.L.zkm_keccak_trace(self.h, _data_ptr(inputs), _data_ptr(timestamps), nperms, log_n, _data_ptr(out), C.byref(err)), err)
+        return out
 
     def logic_trace(self, ops, log_n, out=None):
         """LogicStark::generate_trace on the GPU (logic.rs:150-183).  ops: nops x 3 uint32 (op, input0, input1).

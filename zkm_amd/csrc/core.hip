@@ -434,8 +434,37 @@ size_t zkm_table_width(int table_id) {
         case ZKM_TABLE_POSEIDON: return ZKM_POSEIDON_COLS;
         case ZKM_TABLE_LOGIC: return ZKM_LOGIC_COLS;
         case ZKM_TABLE_KECCAK_SPONGE: return ZKM_KECCAK_SPONGE_COLS;
+        case ZKM_TABLE_KECCAK: return ZKM_KECCAK_COLS;
         default: return 0;
     }
+}
+
+int zkm_keccak_trace(zkm_ctx* c, const uint64_t* inputs, const uint64_t* timestamps, size_t nperms, unsigned log_n, uint64_t* out_dev,
+                     char** err) {
+    std::vector<void*> tmp;
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!zkm_is_device_ptr(out_dev)) throw std::runtime_error("zkm_keccak_trace: out must be a device pointer");
+        size_t n = (size_t)1 << log_n;
+        if (nperms * 24 > n) throw std::runtime_error("zkm_keccak_trace: permutations need more rows than 2^log_n (24 each)");
+        auto to_dev = [&](const uint64_t* p, size_t words) -> const uint64_t* {
+            if (!words || zkm_is_device_ptr(p)) return p;
+            void* d = c->alloc(words * 8);
+            tmp.push_back(d);
+            ZKM_HIP_CHECK(hipMemcpyAsync(d, p, words * 8, hipMemcpyHostToDevice, c->stream));
+            return (const uint64_t*)d;
+        };
+        const uint64_t* d_in = to_dev(inputs, nperms * 25);
+        const uint64_t* d_ts = to_dev(timestamps, nperms);
+        zkm_launch_keccak_trace(c, d_in, d_ts, nperms, n, out_dev);
+        c->sync();
+        for (void* p : tmp) c->release(p);
+    } catch (const std::exception& e) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* p : tmp) c->release(p);
+        return fail(err, e.what());
+    }
+    return 0;
 }
 
 int zkm_logic_trace(zkm_ctx* c, const uint32_t* ops, size_t nops, unsigned log_n, uint64_t* out_dev, char** err) {

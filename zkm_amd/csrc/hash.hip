@@ -391,3 +391,106 @@ void zkm_launch_logic_trace(zkm_ctx* c, const uint32_t* d_ops, size_t nops, size
     hipLaunchKernelGGL(k_logic_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_ops, nops, n, out, d_bad);
     ZKM_HIP_CHECK(hipGetLastError());
 }
+
+// ------------------------------------------------------------------ KeccakStark witness (keccak/keccak_stark.rs:62-226)
+// One thread per trace row (permutation p, round r): replays r rounds from the input (at most 23 cheap rounds; the row's
+// 2431 stores dominate), then emits the round's registers.  Consecutive threads own consecutive rows, so every
+// column store is a contiguous 512-byte run per wavefront.  State index: a[x + 5y] = A(x, y).
+__device__ __forceinline__ void keccak_round_dev(uint64_t (&a)[25], uint64_t rc) {
+    uint64_t cx[5], b[25];
+    constexpr unsigned RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+#pragma unroll
+    for (int x = 0; x < 5; x++) cx[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        uint64_t d = cx[(x + 4) % 5] ^ rotl64(cx[(x + 1) % 5], 1);
+#pragma unroll
+        for (int y = 0; y < 5; y++) a[x + 5 * y] ^= d;
+    }
+#pragma unroll
+    for (int x = 0; x < 5; x++)
+#pragma unroll
+        for (int y = 0; y < 5; y++) {
+            unsigned r = RHO[x + 5 * y];
+            uint64_t v = a[x + 5 * y];
+            b[y + 5 * ((2 * x + 3 * y) % 5)] = r ? rotl64(v, r) : v;
+        }
+#pragma unroll
+    for (int y = 0; y < 5; y++)
+#pragma unroll
+        for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+    a[0] ^= rc;
+}
+
+__device__ const uint64_t KECCAK_RC_DEV[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+
+__global__ __launch_bounds__(256) void k_keccak_trace(const uint64_t* __restrict__ inputs, const uint64_t* __restrict__ ts, size_t nperms,
+                                                      size_t n, gl_t* __restrict__ out) {
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    gl_t* o = out + row;
+    size_t p = row / 24;
+    int round = (int)(row - p * 24);
+    if (p >= nperms) {  // padding rows are all-zero (keccak_stark.rs:77-79)
+        for (int c = 0; c < ZKM_KECCAK_COLS; c++) o[(size_t)c * n] = 0;
+        return;
+    }
+    uint64_t a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = inputs[25 * p + i];
+#pragma unroll 1
+    for (int r = 0; r < round; r++) keccak_round_dev(a, KECCAK_RC_DEV[r]);
+    for (int i = 0; i < 24; i++) o[(size_t)i * n] = i == round;
+    o[(size_t)24 * n] = ts[p];
+    uint64_t c[5], cp[5];
+#pragma unroll
+    for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+    for (int x = 0; x < 5; x++) cp[x] = c[x] ^ c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+#pragma unroll
+        for (int y = 0; y < 5; y++) {
+            o[(size_t)(25 + (x * 5 + y) * 2) * n] = (uint32_t)a[x + 5 * y];
+            o[(size_t)(25 + (x * 5 + y) * 2 + 1) * n] = a[x + 5 * y] >> 32;
+        }
+#pragma unroll 8
+        for (int z = 0; z < 64; z++) {
+            o[(size_t)(75 + x * 64 + z) * n] = (c[x] >> z) & 1;
+            o[(size_t)(395 + x * 64 + z) * n] = (cp[x] >> z) & 1;
+        }
+    }
+    // A' = A ^ C ^ C' (theta), written bit by bit; then the round proper gives A'' (before iota) and the iota output
+#pragma unroll
+    for (int x = 0; x < 5; x++)
+#pragma unroll
+        for (int y = 0; y < 5; y++) {
+            uint64_t ap = a[x + 5 * y] ^ c[x] ^ cp[x];
+#pragma unroll 8
+            for (int z = 0; z < 64; z++) o[(size_t)(715 + x * 320 + y * 64 + z) * n] = (ap >> z) & 1;
+        }
+    keccak_round_dev(a, 0);
+#pragma unroll
+    for (int x = 0; x < 5; x++)
+#pragma unroll
+        for (int y = 0; y < 5; y++) {
+            o[(size_t)(2315 + x * 10 + y * 2) * n] = (uint32_t)a[x + 5 * y];
+            o[(size_t)(2315 + x * 10 + y * 2 + 1) * n] = a[x + 5 * y] >> 32;
+        }
+#pragma unroll 8
+    for (int z = 0; z < 64; z++) o[(size_t)(2365 + z) * n] = (a[0] >> z) & 1;
+    uint64_t appp = a[0] ^ KECCAK_RC_DEV[round];
+    o[(size_t)2429 * n] = (uint32_t)appp;
+    o[(size_t)2430 * n] = appp >> 32;
+}
+
+void zkm_launch_keccak_trace(zkm_ctx* c, const uint64_t* d_inputs, const uint64_t* d_ts, size_t nperms, size_t n, gl_t* out) {
+    zkm_prof_scope ps(c, "keccak_trace");
+    hipLaunchKernelGGL(k_keccak_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_inputs, d_ts, nperms, n, out);
+    ZKM_HIP_CHECK(hipGetLastError());
+}

@@ -210,11 +210,144 @@ __device__ void eval_keccak_sponge_constraints(const gl_t* __restrict__ lv, size
     for (int i = 0; i < 136; i++) k.constraint(gl_mul(lv[(size_t)(FINAL_LEN + i) * cs], gl_sub(offset, (gl_t)i)));
 }
 
+// KeccakStark (keccak/keccak_stark.rs:256-413: 3 + 320 + 50 + 320 + 50 + 4 + 50 = 797 constraints over 2431 columns;
+// register map keccak/columns.rs:7-134).  Columns are streamed from HBM in constraint order (each thread owns one
+// row; a wavefront reads 64 consecutive rows of one column = 512 contiguous bytes per load).
+namespace kk {
+enum { TIMESTAMP = 24, A = 25, C = 75, CP = 395, AP = 715, APP = 2315, APP00_BITS = 2365, APPP00 = 2429 };
+__device__ const uint8_t ROT[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};
+__device__ __forceinline__ int reg_a(int x, int y) { return A + (x * 5 + y) * 2; }
+__device__ __forceinline__ int reg_c(int x, int z) { return C + x * 64 + z; }
+__device__ __forceinline__ int reg_cp(int x, int z) { return CP + x * 64 + z; }
+__device__ __forceinline__ int reg_ap(int x, int y, int z) { return AP + x * 320 + y * 64 + z; }
+__device__ __forceinline__ int reg_app(int x, int y) { return APP + x * 10 + y * 2; }
+__device__ __forceinline__ int reg_appp(int x, int y) { return (x == 0 && y == 0) ? (int)APPP00 : reg_app(x, y); }
+__device__ __forceinline__ int mod5(int v) { return v >= 5 ? v - 5 : v; }
+__device__ __forceinline__ gl_t xor_gen(gl_t x, gl_t y) { return gl_sub(gl_add(x, y), gl_mul(x, gl_add(y, y))); }
+}  // namespace kk
+
+template <int NA>
+__device__ void eval_keccak_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
+    using namespace kk;
+    const gl_t* __restrict__ nv = lv + dnext;
+#define LV(c) lv[(size_t)(c) * cs]
+#define NV(c) nv[(size_t)(c) * cs]
+    gl_t final_step = LV(23);
+    k.constraint(gl_mul(final_step, gl_sub(final_step, 1)));
+    gl_t not_final = gl_sub(1, final_step);
+    k.constraint(gl_mul(not_final, final_step));
+    // round flags: their sum, and the round-constant bit sum_r step_r * RC_r[z] for the 7 bit positions RC uses
+    gl_t sum_flags = 0, rc0 = 0, rc1 = 0, rc3 = 0, rc7 = 0, rc15 = 0, rc31 = 0, rc63 = 0;
+    {
+        constexpr uint64_t RC[24] = {
+            0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+            0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+            0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+            0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+            0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+#pragma unroll
+        for (int r = 0; r < 24; r++) {
+            gl_t f = LV(r);
+            sum_flags = gl_add(sum_flags, f);
+            if (RC[r] & 1) rc0 = gl_add(rc0, f);
+            if (RC[r] >> 1 & 1) rc1 = gl_add(rc1, f);
+            if (RC[r] >> 3 & 1) rc3 = gl_add(rc3, f);
+            if (RC[r] >> 7 & 1) rc7 = gl_add(rc7, f);
+            if (RC[r] >> 15 & 1) rc15 = gl_add(rc15, f);
+            if (RC[r] >> 31 & 1) rc31 = gl_add(rc31, f);
+            if (RC[r] >> 63 & 1) rc63 = gl_add(rc63, f);
+        }
+    }
+    k.constraint(gl_mul(gl_mul(sum_flags, not_final), gl_sub(NV(TIMESTAMP), LV(TIMESTAMP))));
+    // C'[x, z] = xor(C[x, z], C[x - 1, z], C[x + 1, z - 1])
+#pragma unroll 1
+    for (int x = 0; x < 5; x++)
+#pragma unroll 2
+        for (int z = 0; z < 64; z++) {
+            gl_t v = xor_gen(LV(reg_c(x, z)), xor_gen(LV(reg_c(mod5(x + 4), z)), LV(reg_c(mod5(x + 1), (z + 63) & 63))));
+            k.constraint(gl_sub(LV(reg_cp(x, z)), v));
+        }
+    // A[x, y] limbs from xor(A'[x, y, z], C[x, z], C'[x, z])
+#pragma unroll 1
+    for (int x = 0; x < 5; x++)
+#pragma unroll 1
+        for (int y = 0; y < 5; y++)
+#pragma unroll 1
+            for (int half = 0; half < 2; half++) {
+                gl_t acc = 0;
+#pragma unroll 2
+                for (int z = 32 * half + 31; z >= 32 * half; z--)
+                    acc = gl_add(gl_add(acc, acc), xor_gen(LV(reg_ap(x, y, z)), xor_gen(LV(reg_c(x, z)), LV(reg_cp(x, z)))));
+                k.constraint(gl_sub(acc, LV(reg_a(x, y) + half)));
+            }
+    // diff = sum_y A'[x, y, z] - C'[x, z] in {0, 2, 4}
+#pragma unroll 1
+    for (int x = 0; x < 5; x++)
+#pragma unroll 2
+        for (int z = 0; z < 64; z++) {
+            gl_t sum = LV(reg_ap(x, 0, z));
+#pragma unroll
+            for (int i = 1; i < 5; i++) sum = gl_add(sum, LV(reg_ap(x, i, z)));
+            gl_t diff = gl_sub(sum, LV(reg_cp(x, z)));
+            k.constraint(gl_mul(gl_mul(diff, gl_sub(diff, 2)), gl_sub(diff, 4)));
+        }
+    // A''[x, y] = xor(B[x, y], andn(B[x + 1, y], B[x + 2, y])), B[x, y, z] = A'[(x + 3y) % 5, x, z - r] (columns.rs:91-105)
+#pragma unroll 1
+    for (int x = 0; x < 5; x++)
+#pragma unroll 1
+        for (int y = 0; y < 5; y++) {
+            int x1 = mod5(x + 1), x2 = mod5(x + 2);
+            int a0 = (x + 3 * y) % 5, a1 = (x1 + 3 * y) % 5, a2 = (x2 + 3 * y) % 5;
+            int base0 = reg_ap(a0, x, 0), base1 = reg_ap(a1, x1, 0), base2 = reg_ap(a2, x2, 0);
+            int r0 = 64 - ROT[a0][x], r1 = 64 - ROT[a1][x1], r2 = 64 - ROT[a2][x2];
+#pragma unroll 1
+            for (int half = 0; half < 2; half++) {
+                gl_t acc = 0;
+#pragma unroll 2
+                for (int z = 32 * half + 31; z >= 32 * half; z--) {
+                    gl_t b0 = LV(base0 + ((z + r0) & 63)), b1 = LV(base1 + ((z + r1) & 63)), b2 = LV(base2 + ((z + r2) & 63));
+                    acc = gl_add(gl_add(acc, acc), xor_gen(b0, gl_mul(gl_sub(1, b1), b2)));
+                }
+                k.constraint(gl_sub(acc, LV(reg_app(x, y) + half)));
+            }
+        }
+    // A''[0, 0] bit decomposition, then the iota output A'''[0, 0] = A''[0, 0] xor RC
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        gl_t acc = 0;
+#pragma unroll 4
+        for (int z = 32 * half + 31; z >= 32 * half; z--) acc = gl_add(gl_add(acc, acc), LV(APP00_BITS + z));
+        k.constraint(gl_sub(acc, LV(reg_app(0, 0) + half)));
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        gl_t acc = 0;
+#pragma unroll 1
+        for (int z = 32 * half + 31; z >= 32 * half; z--) {
+            gl_t rc = z == 0 ? rc0 : z == 1 ? rc1 : z == 3 ? rc3 : z == 7 ? rc7 : z == 15 ? rc15 : z == 31 ? rc31 : z == 63 ? rc63 : 0;
+            acc = gl_add(gl_add(acc, acc), xor_gen(LV(APP00_BITS + z), rc));
+        }
+        k.constraint(gl_sub(acc, LV(APPP00 + half)));
+    }
+    // this round's output is the next row's input unless this is the last round
+    gl_t not_last_t = gl_mul(not_final, k.z_last);
+#pragma unroll 1
+    for (int x = 0; x < 5; x++)
+#pragma unroll 1
+        for (int y = 0; y < 5; y++)
+#pragma unroll
+            for (int half = 0; half < 2; half++)
+                k.constraint(gl_mul(not_last_t, gl_sub(LV(reg_appp(x, y) + half), NV(reg_a(x, y) + half))));
+#undef LV
+#undef NV
+}
+
 template <int TABLE, int NA>
 __device__ __forceinline__ void eval_table_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
     if constexpr (TABLE == ZKM_TABLE_POSEIDON) eval_poseidon_constraints<NA>(lv, cs, k);
     else if constexpr (TABLE == ZKM_TABLE_LOGIC) eval_logic_constraints<NA>(lv, cs, k);
-    else eval_keccak_sponge_constraints<NA>(lv, cs, dnext, k);
+    else if constexpr (TABLE == ZKM_TABLE_KECCAK_SPONGE) eval_keccak_sponge_constraints<NA>(lv, cs, dnext, k);
+    else eval_keccak_constraints<NA>(lv, cs, dnext, k);
 }
 
 // CTL checks driven by the column-set description (eval_helper_columns cross_table_lookup.rs:1006-1058,
@@ -325,7 +458,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     ZKM_HIP_CHECK(hipMemcpyAsync(d_alphas, alphas_host, nalphas * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
     gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
     {
-        static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge"};
+        static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak"};
         zkm_prof_scope ps(c, names[table_id]);
         dim3 grid((size + 255) / 256), block(256);
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
@@ -337,7 +470,9 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             case 2: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_LOGIC, 1); break;
             case 3: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_LOGIC, 2); break;
             case 4: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK_SPONGE, 1); break;
-            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK_SPONGE, 2); break;
+            case 5: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK_SPONGE, 2); break;
+            case 6: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK, 1); break;
+            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK, 2); break;
         }
 #undef ZKM_LAUNCH_QUOTIENT
         ZKM_HIP_CHECK(hipGetLastError());

@@ -134,6 +134,7 @@ void zkm_lde_bitrev(zkm_ctx*, const gl_t* coeffs, gl_t* out, size_t ncols, unsig
 void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values);
 void zkm_host_poseidon_permute(uint64_t st[12]);
 // ---- hash.hip (LogicStark witness)
+void zkm_launch_keccak_trace(zkm_ctx* c, const uint64_t* d_inputs, const uint64_t* d_ts, size_t nperms, size_t n, gl_t* out);
 void zkm_launch_logic_trace(zkm_ctx* c, const uint32_t* d_ops, size_t nops, size_t n, gl_t* out, int* d_bad);
 
 

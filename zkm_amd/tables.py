@@ -8,8 +8,8 @@ include/zkm_hip.h); mirrors
 """
 from .ctl import CtlTable
 
-TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE = 0, 1, 2
-WIDTH = {TABLE_POSEIDON: 262, TABLE_LOGIC: 69, TABLE_KECCAK_SPONGE: 470}
+TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK = 0, 1, 2, 3
+WIDTH = {TABLE_POSEIDON: 262, TABLE_LOGIC: 69, TABLE_KECCAK_SPONGE: 470, TABLE_KECCAK: 2431}
 
 # LogicStark columns (logic.rs:25-50)
 LOGIC_IS_AND, LOGIC_IS_OR, LOGIC_IS_XOR, LOGIC_IS_NOR = 0, 1, 2, 3
@@ -18,7 +18,30 @@ OP_AND, OP_OR, OP_XOR, OP_NOR = 0, 1, 2, 3
 
 # KeccakSpongeStark columns (keccak_sponge/columns.rs:19-70)
 KS_FULL, KS_FINAL_LEN, KS_ORIG_RATE, KS_BLOCK, KS_XORED = 0, 40, 176, 226, 362
+KS_TIMESTAMP, KS_ORIG_CAP, KS_PARTIAL, KS_DIGEST = 37, 210, 396, 438
 KECCAK_RATE_BYTES, KECCAK_RATE_U32S = 136, 34
+
+# KeccakStark registers (keccak/columns.rs:7-134)
+KK_ROUNDS, KK_TIMESTAMP = 24, 24
+
+
+def kk_reg_a(x, y):
+    return 25 + (x * 5 + y) * 2
+
+
+def kk_reg_a_prime_prime_prime(x, y):
+    return 2429 if (x, y) == (0, 0) else 2315 + x * 10 + y * 2
+
+
+def kk_reg_input_limb(i):
+    """reg_input_limb(i): limb i of the y-major 5x5 input (columns.rs:15-27)."""
+    y, x = divmod(i // 2, 5)
+    return kk_reg_a(x, y) + i % 2
+
+
+def kk_reg_output_limb(i):
+    y, x = divmod(i // 2, 5)
+    return kk_reg_a_prime_prime_prime(x, y) + i % 2
 NUM_LOGIC_CTLS = KECCAK_RATE_BYTES // 4   # num_logic_ctls(): U8S_PER_CTL = 4, U32S_PER_CTL = 1
 
 
@@ -48,3 +71,45 @@ def ctl_logic_keccak_sponge(sponge_index, logic_index, sponge_ctl: CtlTable, log
     """The KeccakSponge -> Logic part of all_stark::ctl_logic(): 34 looking column sets, one looked."""
     looking = [(sponge_index, keccak_sponge_looking_logic(sponge_ctl, i)) for i in range(NUM_LOGIC_CTLS)]
     return looking, (logic_index, logic_ctl_data(logic_ctl))
+
+
+def keccak_ctl_data_inputs(t: CtlTable):
+    """keccak_stark::ctl_data_inputs() with ctl_filter_inputs() (keccak_stark.rs:34-50)."""
+    return t.singles_set([kk_reg_input_limb(i) for i in range(50)] + [KK_TIMESTAMP], filter_col=0)
+
+
+def keccak_ctl_data_outputs(t: CtlTable):
+    """keccak_stark::ctl_data_outputs() with ctl_filter_outputs() (keccak_stark.rs:40-54)."""
+    return t.singles_set([kk_reg_output_limb(i) for i in range(50)] + [KK_TIMESTAMP], filter_col=KK_ROUNDS - 1)
+
+
+def _sponge_keccak_filter(t: CtlTable):
+    return t.sum([KS_FULL] + list(range(KS_FINAL_LEN, KS_FINAL_LEN + KECCAK_RATE_BYTES)))
+
+
+def keccak_sponge_looking_keccak_inputs(t: CtlTable):
+    """keccak_sponge_stark::ctl_looking_keccak_inputs() with ctl_looking_keccak_filter() (:53-67, :196-201)."""
+    first = len(t._cols)
+    for c in list(range(KS_XORED, KS_XORED + 34)) + list(range(KS_ORIG_CAP, KS_ORIG_CAP + 16)) + [KS_TIMESTAMP]:
+        t.single(c)
+    return t.colset(range(first, first + 51), filter_constants=[_sponge_keccak_filter(t)])
+
+
+def keccak_sponge_looking_keccak_outputs(t: CtlTable):
+    """keccak_sponge_stark::ctl_looking_keccak_outputs() with ctl_looking_keccak_filter() (:69-89, :196-201)."""
+    first = len(t._cols)
+    for l in range(8):
+        t.le_bytes(range(KS_DIGEST + 4 * l, KS_DIGEST + 4 * l + 4))
+    for c in list(range(KS_PARTIAL, KS_PARTIAL + 42)) + [KS_TIMESTAMP]:
+        t.single(c)
+    return t.colset(range(first, first + 51), filter_constants=[_sponge_keccak_filter(t)])
+
+
+def ctl_keccak_inputs(sponge_index, keccak_index, sponge_ctl, keccak_ctl):
+    """all_stark::ctl_keccak_inputs() (all_stark.rs:214-226)."""
+    return [(sponge_index, keccak_sponge_looking_keccak_inputs(sponge_ctl))], (keccak_index, keccak_ctl_data_inputs(keccak_ctl))
+
+
+def ctl_keccak_outputs(sponge_index, keccak_index, sponge_ctl, keccak_ctl):
+    """all_stark::ctl_keccak_outputs() (all_stark.rs:228-240)."""
+    return [(sponge_index, keccak_sponge_looking_keccak_outputs(sponge_ctl))], (keccak_index, keccak_ctl_data_outputs(keccak_ctl))
