@@ -139,12 +139,19 @@ void zkm_standard_config(zkm_stark_config* cfg);
  *   POSEIDON       poseidon/poseidon_stark.rs:554-594   262 columns
  *   LOGIC          logic.rs:199-248                       69 columns
  *   KECCAK_SPONGE  keccak_sponge_stark.rs:456-567        470 columns
- *   KECCAK         keccak/keccak_stark.rs:256-413       2431 columns */
+ *   KECCAK         keccak/keccak_stark.rs:256-413       2431 columns
+ *   MEMORY         memory/memory_stark.rs:253-341         13 columns, plus the range-check lookup :476-483 */
 #define ZKM_TABLE_POSEIDON 0
 #define ZKM_TABLE_LOGIC 1
 #define ZKM_TABLE_KECCAK_SPONGE 2
 #define ZKM_TABLE_KECCAK 3
+#define ZKM_TABLE_MEMORY 4
+#define ZKM_MEMORY_COLS 13
 size_t zkm_table_width(int table_id); /* 0 for an unknown id */
+/* Auxiliary columns the table's own logUp lookups (Stark::lookups(), lookup.rs:22-40) put in front of the CTL columns:
+ * per lookup and challenge, ceil(columns / 2) helper columns and one Z (stark.rs:217-223).  0 for tables without lookups.
+ * The naux arguments of the prove entry points count the CTL columns only; zkm_proof_words takes the total. */
+size_t zkm_num_lookup_columns(int table_id, const zkm_stark_config* cfg);
 
 /* Proof blob (uint64_t words) -- the fields of StarkProofWithMetadata (proof.rs:178-201) flattened:
  *   [0] magic "ZKMPROOF" [1] degree_bits [2] W trace cols [3] A aux cols [4] Q quotient polys [5] Z ctl zs
@@ -219,11 +226,14 @@ int zkm_lookup_helper_columns(zkm_ctx* ctx, const zkm_ctl_table* table, const ui
                               uint32_t freq_col, uint64_t challenge, const uint64_t* trace, size_t ncols, unsigned log_n,
                               uint64_t* out, char** err);
 
-/* prove_single_table with real CTL data: like zkm_prove_single_table, the CtlZData described by (table, zs, colset_ids). */
+/* prove_single_table with real CTL data: like zkm_prove_single_table, the CtlZData described by (table, zs, colset_ids).
+ * lookup_challenges: for a table with its own lookups (zkm_num_lookup_columns() > 0) the num_challenges lookup challenges --
+ * the betas of the CTL challenges (prover.rs:468-474); the helper columns are computed here (prover.rs:475-493) from the
+ * trace VALUES, so `trace` is required for such tables even when trace_batch is given.  NULL otherwise. */
 int zkm_prove_single_table_ctl(zkm_ctx* ctx, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t ncols,
                                unsigned log_n, const zkm_batch* trace_batch, const uint64_t* aux, size_t naux,
                                const zkm_ctl_table* table, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs,
-                               zkm_challenger* challenger, uint64_t* proof_out, char** err);
+                               const uint64_t* lookup_challenges, zkm_challenger* challenger, uint64_t* proof_out, char** err);
 
 /* a1: prove_with_traces (prover.rs:130-232): commit every trace, seed the transcript with all trace caps and the
  * public values, draw the CTL challenges, build every table's CtlData, then prove the tables in order on the shared

@@ -230,13 +230,91 @@ static void TNAME(eval_keccak)(const T* lv, const T* nv, TNAME(consumer) * k) {
                 TNAME(cons_transition)(k, T_MUL(not_last, T_SUB(lv[kk_appp(x, y) + half], nv[kk_a(x, y) + half])));
 }
 
+/* ---- MemoryStark constraints: memory/memory_stark.rs:253-341 (columns memory/columns.rs: FILTER 0, TIMESTAMP 1, IS_READ 2,
+ * ADDR_CONTEXT 3, ADDR_SEGMENT 4, ADDR_VIRTUAL 5, VALUE 6 (VALUE_LIMBS = 1), CONTEXT/SEGMENT/VIRTUAL_FIRST_CHANGE 7..9,
+ * RANGE_CHECK 10, COUNTER 11, FREQUENCIES 12) ---- */
+static void TNAME(eval_memory)(const T* lv, const T* nv, TNAME(consumer) * k) {
+    T one = T_FROMB(1);
+    T filter = lv[0];
+    TNAME(cons)(k, T_MUL(filter, T_SUB(filter, one)));
+    T cfc = lv[7], sfc = lv[8], vfc = lv[9];
+    T unchanged = T_SUB(T_SUB(T_SUB(one, cfc), sfc), vfc);
+    TNAME(cons)(k, T_MUL(cfc, T_SUB(one, cfc)));
+    TNAME(cons)(k, T_MUL(sfc, T_SUB(one, sfc)));
+    TNAME(cons)(k, T_MUL(vfc, T_SUB(one, vfc)));
+    TNAME(cons)(k, T_MUL(unchanged, T_SUB(one, unchanged)));
+    T dctx = T_SUB(nv[3], lv[3]), dseg = T_SUB(nv[4], lv[4]), dvirt = T_SUB(nv[5], lv[5]);
+    TNAME(cons_transition)(k, T_MUL(sfc, dctx));
+    TNAME(cons_transition)(k, T_MUL(vfc, dctx));
+    TNAME(cons_transition)(k, T_MUL(vfc, dseg));
+    TNAME(cons_transition)(k, T_MUL(unchanged, dctx));
+    TNAME(cons_transition)(k, T_MUL(unchanged, dseg));
+    TNAME(cons_transition)(k, T_MUL(unchanged, dvirt));
+    T computed = T_ADD(T_ADD(T_MUL(cfc, T_SUB(dctx, one)), T_MUL(sfc, T_SUB(dseg, one))),
+                       T_ADD(T_MUL(vfc, T_SUB(dvirt, one)), T_MUL(unchanged, T_SUB(nv[1], lv[1]))));
+    TNAME(cons_transition)(k, T_SUB(lv[10], computed));
+    TNAME(cons_transition)(k, T_MUL(T_MUL(nv[2], unchanged), T_SUB(nv[6], lv[6])));
+}
+
+/* ---- logUp range-check lookups of a table: Stark::lookups() (memory_stark.rs:476-483: RANGE_CHECK in COUNTER with
+ * FREQUENCIES; every reference use is Column::single columns without filters) and eval_packed_lookups_generic
+ * (lookup.rs:138-198).  lk_aux / lk_aux_next = the first num_lookup_columns auxiliary values. ---- */
+#ifndef ZKO_LOOKUP_DEFS
+#define ZKO_LOOKUP_DEFS
+typedef struct { uint32_t ncols; const uint32_t* cols; uint32_t table_col, freq_col; } zko_lookup_def;
+static const uint32_t MEMORY_LOOKUP_COLS[1] = {10};
+static const zko_lookup_def MEMORY_LOOKUPS[1] = {{1, MEMORY_LOOKUP_COLS, 11, 12}};
+static const zko_lookup_def* zko_table_lookups(int table_id, size_t* n) {
+    if (table_id == 4) { *n = 1; return MEMORY_LOOKUPS; }
+    *n = 0;
+    return NULL;
+}
+static size_t zko_table_num_lookup_columns(int table_id, size_t nchallenges) {
+    size_t nl, total = 0;
+    const zko_lookup_def* d = zko_table_lookups(table_id, &nl);
+    for (size_t i = 0; i < nl; i++) total += ((d[i].ncols + 1) / 2 + 1) * nchallenges;
+    return total;
+}
+#endif
+static void TNAME(eval_lookups)(int table_id, const gl_t* challenges, size_t nch, const T* lv, const T* lk_aux, const T* lk_aux_next,
+                                TNAME(consumer) * k) {
+    size_t nl, start = 0;
+    const zko_lookup_def* defs = zko_table_lookups(table_id, &nl);
+    for (size_t l = 0; l < nl; l++) {
+        const zko_lookup_def* d = &defs[l];
+        size_t nh = (d->ncols + 1) / 2;
+        for (size_t c = 0; c < nch; c++) {
+            T ch = T_FROMB(challenges[c]);
+            T hsum = T_FROMB(0);
+            for (size_t q = 0; q < nh; q++) {
+                T h = lk_aux[start + q];
+                T combin0 = T_ADD(lv[d->cols[2 * q]], ch);
+                if (2 * q + 1 < d->ncols) {
+                    T combin1 = T_ADD(lv[d->cols[2 * q + 1]], ch);
+                    TNAME(cons)(k, T_SUB(T_SUB(T_MUL(T_MUL(combin1, combin0), h), combin1), combin0));
+                } else {
+                    TNAME(cons)(k, T_SUB(T_MUL(combin0, h), T_FROMB(1)));
+                }
+                hsum = T_ADD(hsum, h);
+            }
+            T z = lk_aux[start + nh], next_z = lk_aux_next[start + nh];
+            T table_ch = T_ADD(lv[d->table_col], ch);
+            T y = T_SUB(T_MUL(hsum, table_ch), lv[d->freq_col]);
+            TNAME(cons_first)(k, z);
+            TNAME(cons)(k, T_SUB(T_MUL(T_SUB(next_z, z), table_ch), y));
+            start += nh + 1;
+        }
+    }
+}
+
 /* table dispatch (Table ids of include/zkm_hip.h) */
-static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : 0; }
+static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : table_id == 4 ? 13 : 0; }
 static void TNAME(eval_table)(int table_id, const T* lv, const T* nv, TNAME(consumer) * k) {
     if (table_id == 0) TNAME(eval_poseidon)(lv, k);
     else if (table_id == 1) TNAME(eval_logic)(lv, k);
     else if (table_id == 2) TNAME(eval_keccak_sponge)(lv, nv, k);
-    else TNAME(eval_keccak)(lv, nv, k);
+    else if (table_id == 3) TNAME(eval_keccak)(lv, nv, k);
+    else TNAME(eval_memory)(lv, nv, k);
 }
 
 /* ---- general CTL checks driven by the column-set description ----

@@ -105,6 +105,85 @@ void zko_logic_trace(const uint32_t* ops, size_t nops, unsigned log_n, uint64_t*
     }
 }
 
+/* MemoryStark::generate_trace (memory/memory_stark.rs:123-248): sort by (context, segment, virt, timestamp), fill_gaps, pad
+ * with filter-0 reads of the last operation, re-sort, first-change flags and range-check deltas, COUNTER, FREQUENCIES.
+ * ops = nops x 6 words {context, segment, virt, timestamp, is_read, value}; the R0 write rule of into_row (:68-76) applies.
+ * Returns the natural row count (power of two) or 0 when it exceeds 2^log_n or a range check fails. */
+typedef struct { uint64_t ctx, seg, virt, ts, is_read, value, filter, seq; } mem_op;
+static int mem_cmp(const void* a, const void* b) {
+    const mem_op *x = (const mem_op*)a, *y = (const mem_op*)b;
+    if (x->ctx != y->ctx) return x->ctx < y->ctx ? -1 : 1;
+    if (x->seg != y->seg) return x->seg < y->seg ? -1 : 1;
+    if (x->virt != y->virt) return x->virt < y->virt ? -1 : 1;
+    if (x->ts != y->ts) return x->ts < y->ts ? -1 : 1;
+    return x->seq < y->seq ? -1 : x->seq > y->seq; /* sort_by_key is stable */
+}
+static size_t next_pow2(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
+size_t zko_memory_trace(const uint64_t* ops_in, size_t nops, unsigned log_n, uint64_t* out) {
+    size_t n = (size_t)1 << log_n;
+    if (nops == 0) return 0; /* "No memory ops?" :225 */
+    size_t cap = 2 * next_pow2(nops) + 16, cnt = nops;
+    mem_op* ops = (mem_op*)malloc(sizeof(mem_op) * cap);
+    for (size_t i = 0; i < nops; i++) {
+        const uint64_t* o = ops_in + 6 * i;
+        ops[i] = (mem_op){o[0], o[1], o[2], o[3], o[4] != 0, o[5], 1, i};
+    }
+    qsort(ops, cnt, sizeof(mem_op), mem_cmp);
+    /* fill_gaps :180-221 iterates over a clone of the sorted list and appends dummy reads */
+    size_t max_rc = next_pow2(cnt) - 1, base = cnt;
+    for (size_t i = 0; i + 1 < base; i++) {
+        mem_op curr = ops[i], next = ops[i + 1];
+        if (curr.ctx != next.ctx || curr.seg != next.seg) continue;
+        if (curr.virt != next.virt) {
+            while (next.virt - curr.virt - 1 > max_rc) {
+                curr.virt += max_rc + 1;
+                curr.ts = 0; curr.value = 0; curr.is_read = 1; curr.filter = 0;
+                if (cnt == cap) { cap *= 2; ops = (mem_op*)realloc(ops, sizeof(mem_op) * cap); }
+                curr.seq = cnt;
+                ops[cnt++] = curr;
+            }
+        } else {
+            while (next.ts - curr.ts > max_rc) {
+                curr.ts += max_rc;
+                curr.is_read = 1; curr.filter = 0;
+                if (cnt == cap) { cap *= 2; ops = (mem_op*)realloc(ops, sizeof(mem_op) * cap); }
+                curr.seq = cnt;
+                ops[cnt++] = curr;
+            }
+        }
+    }
+    /* pad_memory_ops :223-241: repeat the last operation of the list (filter 0, read) up to a power of two (and to 2^log_n) */
+    size_t natural = next_pow2(cnt);
+    if (natural > n) { free(ops); return 0; }
+    if (n + 1 > cap) { cap = n + 1; ops = (mem_op*)realloc(ops, sizeof(mem_op) * cap); }
+    mem_op pad = ops[cnt - 1];
+    pad.filter = 0; pad.is_read = 1;
+    while (cnt < n) { pad.seq = cnt; ops[cnt++] = pad; }
+    qsort(ops, cnt, sizeof(mem_op), mem_cmp);
+    memset(out, 0, sizeof(uint64_t) * 13 * n);
+    int bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        const mem_op* o = &ops[i];
+        uint64_t value = (!o->is_read && o->ctx == 0 && o->seg == 4 && o->virt == 0) ? 0 : (uint32_t)o->value;
+        out[0 * n + i] = o->filter; out[1 * n + i] = o->ts; out[2 * n + i] = o->is_read; out[3 * n + i] = o->ctx;
+        out[4 * n + i] = o->seg; out[5 * n + i] = o->virt; out[6 * n + i] = value;
+        if (i + 1 < n) { /* generate_first_change_flags_and_rc :83-130 */
+            const mem_op* x = &ops[i + 1];
+            int cfc = o->ctx != x->ctx, sfc = o->seg != x->seg && !cfc, vfc = o->virt != x->virt && !sfc && !cfc;
+            out[7 * n + i] = cfc; out[8 * n + i] = sfc; out[9 * n + i] = vfc;
+            gl_t rc = cfc ? gl_sub(gl_sub(x->ctx, o->ctx), 1) : sfc ? gl_sub(gl_sub(x->seg, o->seg), 1)
+                      : vfc ? gl_sub(gl_sub(x->virt, o->virt), 1) : gl_sub(x->ts, o->ts);
+            out[10 * n + i] = rc;
+            if (rc >= n) bad = 1;
+        }
+        out[11 * n + i] = i; /* COUNTER :161 */
+    }
+    if (!bad)
+        for (size_t i = 0; i < n; i++) out[12 * n + out[10 * n + i]] += 1; /* FREQUENCIES :163-166 */
+    free(ops);
+    return bad ? 0 : natural;
+}
+
 /* lookup_helper_columns lookup.rs:46-124: GrandProductChallenge{beta: 1, gamma: challenge} (:70-73), helper columns by
  * get_helper_cols, table inverse :100-105, forward running sum Z with Z[0] = 0 (:111-121) */
 void zko_lookup_helper_columns(const zko_ctl_table* t, const uint32_t* colset_ids, size_t nlookup, uint32_t table_col, uint32_t freq_col,
@@ -232,7 +311,7 @@ size_t zko_all_proof_words(const zko_stark_config* cfg, const zko_table_input* t
     size_t total = 0;
     for (size_t t = 0; t < ntables; t++) {
         if (offs) offs[t] = total;
-        total += zko_proof_words(cfg, tables[t].log_n, tables[t].ncols, tz[t].naux, tz[t].nzs);
+        total += zko_proof_words(cfg, tables[t].log_n, tables[t].ncols, zko_num_lookup_columns(tables[t].table_id, cfg) + tz[t].naux, tz[t].nzs);
     }
     if (offs) offs[ntables] = total;
     free_zs(tz, ntables);
@@ -269,12 +348,14 @@ int zko_prove_with_traces(const zko_stark_config* cfg, const zko_table_input* ta
     table_zs_t* tz = (table_zs_t*)calloc(ntables, sizeof(table_zs_t));
     derive_zs(ntables, ctls, sides, nctls, cfg->num_challenges, challenges, tz);
     int rc = 0;
+    uint64_t lookup_ch[4]; /* the betas of the CTL challenges (prover.rs:468-474) */
+    for (unsigned c = 0; c < cfg->num_challenges; c++) lookup_ch[c] = challenges[2 * c];
     for (size_t t = 0; t < ntables && !rc; t++) {
         size_t n = (size_t)1 << tables[t].log_n;
         uint64_t* aux = (uint64_t*)calloc(tz[t].naux * n + 1, sizeof(uint64_t));
         zko_ctl_data(tables[t].ctl, tz[t].zs, tz[t].ids, tz[t].nzs, tables[t].trace, tables[t].ncols, tables[t].log_n, aux);
         rc = zko_prove_single_table_ctl(tables[t].table_id, cfg, tables[t].trace, tables[t].ncols, tables[t].log_n, aux, tz[t].naux,
-                                        tables[t].ctl, tz[t].zs, tz[t].ids, tz[t].nzs, &ch, proofs + offs[t]);
+                                        tables[t].ctl, tz[t].zs, tz[t].ids, tz[t].nzs, lookup_ch, &ch, proofs + offs[t]);
         free(aux);
     }
     free_zs(tz, ntables);
@@ -299,9 +380,11 @@ int zko_verify_all(const zko_stark_config* cfg, const zko_table_input* tables, s
     if (challenges_claimed && memcmp(challenges, challenges_claimed, sizeof(uint64_t) * 2 * cfg->num_challenges)) rc = 40;
     table_zs_t* tz = (table_zs_t*)calloc(ntables, sizeof(table_zs_t));
     derive_zs(ntables, ctls, sides, nctls, cfg->num_challenges, challenges, tz);
+    uint64_t lookup_ch[4];
+    for (unsigned c = 0; c < cfg->num_challenges; c++) lookup_ch[c] = challenges[2 * c];
     for (size_t t = 0; t < ntables && !rc; t++) {
         rc = zko_verify_single_table_ctl(tables[t].table_id, cfg, proofs + offs[t], tables[t].ncols, tz[t].naux, tables[t].ctl,
-                                         tz[t].zs, tz[t].ids, tz[t].nzs, &ch);
+                                         tz[t].zs, tz[t].ids, tz[t].nzs, lookup_ch, &ch);
         if (rc) rc += 1000 * (int)(t + 1);
     }
     /* verify_cross_table_lookups: per CTL and challenge, sum of the looking tables' Z(1) == looked Z(1) */
@@ -315,13 +398,13 @@ int zko_verify_all(const zko_stark_config* cfg, const zko_table_input* tables, s
                     uint32_t j = i;
                     while (j < ctls[c].nlooking && lk[j].table == lk[i].table) j++;
                     size_t t = lk[i].table;
-                    size_t W = tables[t].ncols, A = tz[t].naux;
+                    size_t W = tables[t].ncols, A = zko_num_lookup_columns(tables[t].table_id, cfg) + tz[t].naux;
                     const uint64_t* o_ctl = proofs + offs[t] + 16 + 12 + 3 * capw + 4 * W + 4 * A;
                     sum = gl_add(sum, o_ctl[cursor[t]++]);
                     i = j;
                 }
                 size_t t = ctls[c].looked.table;
-                size_t W = tables[t].ncols, A = tz[t].naux;
+                size_t W = tables[t].ncols, A = zko_num_lookup_columns(tables[t].table_id, cfg) + tz[t].naux;
                 const uint64_t* o_ctl = proofs + offs[t] + 16 + 12 + 3 * capw + 4 * W + 4 * A;
                 if (sum != o_ctl[cursor[t]++]) rc = 50 + (int)c;
             }

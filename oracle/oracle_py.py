@@ -256,10 +256,12 @@ class Oracle:
         L.zko_check_ctls.argtypes = [vp, C.c_size_t, vp, vp, C.c_size_t]
         L.zko_prove_single_table_ctl.restype = C.c_int
         L.zko_prove_single_table_ctl.argtypes = [C.c_int, C.POINTER(StarkConfig), u64p, C.c_size_t, C.c_uint, u64p, C.c_size_t, vp, vp,
-                                                 vp, C.c_size_t, C.POINTER(Challenger), u64p]
+                                                 vp, C.c_size_t, u64p, C.POINTER(Challenger), u64p]
+        L.zko_num_lookup_columns.restype = C.c_size_t
+        L.zko_num_lookup_columns.argtypes = [C.c_int, C.POINTER(StarkConfig)]
         L.zko_verify_single_table_ctl.restype = C.c_int
         L.zko_verify_single_table_ctl.argtypes = [C.c_int, C.POINTER(StarkConfig), u64p, C.c_size_t, C.c_size_t, vp, vp, vp,
-                                                  C.c_size_t, C.POINTER(Challenger)]
+                                                  C.c_size_t, u64p, C.POINTER(Challenger)]
         L.zko_all_proof_words.restype = C.c_size_t
         L.zko_all_proof_words.argtypes = [C.POINTER(StarkConfig), vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.zko_prove_with_traces.restype = C.c_int
@@ -286,27 +288,48 @@ class Oracle:
                                            _ptr(np.ascontiguousarray(trace)), ncols, log_n, _ptr(out))
         return out
 
-    def prove_ctl(self, trace, log_n, aux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS, table_id=0):
+    def num_lookup_columns(self, table_id, cfg=None):
+        self._ctl_sigs()
+        cfg = cfg or self.standard_config()
+        return self.lib.zko_num_lookup_columns(table_id, C.byref(cfg))
+
+    def memory_trace(self, ops, log_n):
+        """ops: nops x 6 (context, segment, virt, timestamp, is_read, value).  Returns (13 x 2^log_n trace, natural rows)."""
+        ops = np.ascontiguousarray(ops, dtype=np.uint64).reshape(-1, 6)
+        out = np.zeros(13 << log_n, dtype=np.uint64)
+        self.lib.zko_memory_trace.restype = C.c_size_t
+        self.lib.zko_memory_trace.argtypes = [u64p, C.c_size_t, C.c_uint, u64p]
+        rows = self.lib.zko_memory_trace(_ptr(ops), len(ops), log_n, _ptr(out))
+        if rows == 0:
+            raise RuntimeError("oracle memory_trace: operations do not fit in 2^log_n rows (or a range check failed)")
+        return out, rows
+
+    def prove_ctl(self, trace, log_n, aux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS, table_id=0,
+                  lookup_challenges=None):
         self._ctl_sigs()
         cfg = cfg or self.standard_config()
         ch = challenger or Challenger()
         naux = aux.size >> log_n
-        proof = np.zeros(self.proof_words(cfg, log_n, ncols, naux, len(zs)), dtype=np.uint64)
+        lk = None if lookup_challenges is None else np.ascontiguousarray(lookup_challenges, dtype=np.uint64)
+        proof = np.zeros(self.proof_words(cfg, log_n, ncols, naux + self.num_lookup_columns(table_id, cfg), len(zs)), dtype=np.uint64)
         st = ctl_table.pack()
         rc = self.lib.zko_prove_single_table_ctl(table_id, C.byref(cfg), _ptr(np.ascontiguousarray(trace)), ncols, log_n,
                                                  _ptr(np.ascontiguousarray(aux)), naux, C.addressof(st), zs.ctypes.data,
-                                                 colset_ids.ctypes.data, len(zs), C.byref(ch), _ptr(proof))
+                                                 colset_ids.ctypes.data, len(zs), None if lk is None else _ptr(lk), C.byref(ch), _ptr(proof))
         if rc:
             raise RuntimeError("oracle prove_single_table_ctl failed: %d" % rc)
         return proof
 
-    def verify_ctl(self, proof, naux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS, table_id=0):
+    def verify_ctl(self, proof, naux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS, table_id=0,
+                   lookup_challenges=None):
         self._ctl_sigs()
         cfg = cfg or self.standard_config()
         ch = challenger or Challenger()
+        lk = None if lookup_challenges is None else np.ascontiguousarray(lookup_challenges, dtype=np.uint64)
         st = ctl_table.pack()
         return self.lib.zko_verify_single_table_ctl(table_id, C.byref(cfg), _ptr(np.ascontiguousarray(proof)), ncols, naux, C.addressof(st),
-                                                    zs.ctypes.data, colset_ids.ctypes.data, len(zs), C.byref(ch))
+                                                    zs.ctypes.data, colset_ids.ctypes.data, len(zs), None if lk is None else _ptr(lk),
+                                                    C.byref(ch))
 
     def _pack_all(self, tables, ctls):
         from zkm_amd import ctl as zc

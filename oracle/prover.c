@@ -196,24 +196,28 @@ static zko_ctl_z* fake_zs(const uint32_t* num_helpers, size_t nctl) {
 static const zko_ctl_table EMPTY_CTL_TABLE = {0};
 
 static void quotient_generic(int table_id, const zko_batch* trace, const zko_batch* aux, const zko_ctl_table* ctl_t, const zko_ctl_z* zs,
-                             const uint32_t* colset_ids, size_t nctl, const uint64_t* alphas, size_t nalphas, uint64_t* out);
+                             const uint32_t* colset_ids, size_t nctl, const uint64_t* lookup_ch, const uint64_t* alphas, size_t nalphas,
+                             uint64_t* out);
 
 void zko_quotient_poseidon(const zko_batch* trace, const zko_batch* aux, const uint32_t* num_helpers, size_t nctl,
                            const uint64_t* alphas, size_t nalphas, uint64_t* out) {
     zko_ctl_z* zs = fake_zs(num_helpers, nctl);
-    quotient_generic(ZKO_TABLE_POSEIDON, trace, aux, &EMPTY_CTL_TABLE, zs, NULL, nctl, alphas, nalphas, out);
+    quotient_generic(ZKO_TABLE_POSEIDON, trace, aux, &EMPTY_CTL_TABLE, zs, NULL, nctl, NULL, alphas, nalphas, out);
     free(zs);
 }
 
 void zko_quotient(int table_id, const zko_batch* trace, const zko_batch* aux, const uint32_t* num_helpers, size_t nctl,
                   const uint64_t* alphas, size_t nalphas, uint64_t* out) {
     zko_ctl_z* zs = fake_zs(num_helpers, nctl);
-    quotient_generic(table_id, trace, aux, &EMPTY_CTL_TABLE, zs, NULL, nctl, alphas, nalphas, out);
+    quotient_generic(table_id, trace, aux, &EMPTY_CTL_TABLE, zs, NULL, nctl, NULL, alphas, nalphas, out);
     free(zs);
 }
 
 static void quotient_generic(int table_id, const zko_batch* trace, const zko_batch* aux, const zko_ctl_table* ctl_t, const zko_ctl_z* zs,
-                             const uint32_t* colset_ids, size_t nctl, const uint64_t* alphas, size_t nalphas, uint64_t* out) {
+                             const uint32_t* colset_ids, size_t nctl, const uint64_t* lookup_ch, const uint64_t* alphas, size_t nalphas,
+                             uint64_t* out) {
+    /* auxiliary columns = lookup helper columns, then CTL helper columns, then CTL Zs (prover.rs:495-508) */
+    const size_t NL = lookup_ch ? zko_table_num_lookup_columns(table_id, nalphas) : 0;
     unsigned log_n = zko_batch_log_n(trace), rate_bits = 2, qbits = 1;
     unsigned log_N = log_n + rate_bits, log_q = log_n + qbits;
     size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N, size = (size_t)1 << log_q;
@@ -257,7 +261,8 @@ static void quotient_generic(int table_id, const zko_batch* trace, const zko_bat
             for (size_t c = 0; c < W; c++) { lv[c] = tl[c * N + j]; nv[c] = tl[c * N + jn]; }
             for (size_t c = 0; c < A; c++) { av[c] = al[c * N + j]; an[c] = al[c * N + jn]; }
             b_eval_table(table_id, lv, nv, &k);
-            b_eval_ctl_general(ctl_t, zs, colset_ids, nctl, lv, nv, av, an, &k);
+            if (NL) b_eval_lookups(table_id, lookup_ch, nalphas, lv, av, an, &k);
+            b_eval_ctl_general(ctl_t, zs, colset_ids, nctl, lv, nv, av + NL, an + NL, &k);
             for (size_t a = 0; a < nalphas; a++) qv[a * size + i] = gl_mul(k.acc[a], zh_inv[i & 1]);
         }
         free(lv);
@@ -300,17 +305,17 @@ typedef struct {
 /* ------------------------------------------------------------------ prove_single_table */
 static int prove_generic(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
                          const uint64_t* aux, size_t A, const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids,
-                         size_t Z, zko_challenger* ch, uint64_t* proof, double* stage_s);
+                         size_t Z, const uint64_t* lookup_ch, zko_challenger* ch, uint64_t* proof, double* stage_s);
 static int prove_generic_ex(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
                             const uint64_t* aux, size_t A, const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids,
-                            size_t Z, zko_challenger* ch, uint64_t* proof, double* stage_s, zko_batch* tb_in, zko_batch* ab_in,
-                            zko_batch* qb_in);
+                            size_t Z, const uint64_t* lookup_ch, zko_challenger* ch, uint64_t* proof, double* stage_s, zko_batch* tb_in,
+                            zko_batch* ab_in, zko_batch* qb_in);
 
 /* prove_openings alone on three existing commitments (BASELINE config 4): compact, zeta, openings, FRI */
 int zko_prove_openings(const zko_stark_config* cfg, zko_batch* tb, zko_batch* ab, zko_batch* qb, size_t Z, zko_challenger* ch,
                        uint64_t* proof) {
-    return prove_generic_ex(-1, cfg, NULL, zko_batch_ncols(tb), zko_batch_log_n(tb), NULL, zko_batch_ncols(ab), NULL, NULL, NULL, Z, ch,
-                            proof, NULL, tb, ab, qb);
+    return prove_generic_ex(-1, cfg, NULL, zko_batch_ncols(tb), zko_batch_log_n(tb), NULL, zko_batch_ncols(ab), NULL, NULL, NULL, Z, NULL,
+                            ch, proof, NULL, tb, ab, qb);
 }
 
 int zko_prove_single_table(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
@@ -318,40 +323,83 @@ int zko_prove_single_table(int table_id, const zko_stark_config* cfg, const uint
                            zko_challenger* ch, uint64_t* proof, double* stage_s) {
     for (size_t i = 0; i < Z; i++) if (!num_helpers[i]) return -2;
     zko_ctl_z* zs = fake_zs(num_helpers, Z);
-    int rc = prove_generic(table_id, cfg, trace, W, log_n, aux, A, &EMPTY_CTL_TABLE, zs, NULL, Z, ch, proof, stage_s);
+    int rc = prove_generic(table_id, cfg, trace, W, log_n, aux, A, &EMPTY_CTL_TABLE, zs, NULL, Z, NULL, ch, proof, stage_s);
     free(zs);
     return rc;
 }
 int zko_prove_single_table_ctl(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
                                const uint64_t* aux, size_t A, const zko_ctl_table* t, const zko_ctl_z* zs,
-                               const uint32_t* colset_ids, size_t Z, zko_challenger* ch, uint64_t* proof) {
-    return prove_generic(table_id, cfg, trace, W, log_n, aux, A, t, zs, colset_ids, Z, ch, proof, NULL);
+                               const uint32_t* colset_ids, size_t Z, const uint64_t* lookup_challenges, zko_challenger* ch,
+                               uint64_t* proof) {
+    return prove_generic(table_id, cfg, trace, W, log_n, aux, A, t, zs, colset_ids, Z, lookup_challenges, ch, proof, NULL);
 }
+size_t zko_num_lookup_columns(int table_id, const zko_stark_config* cfg) { return zko_table_num_lookup_columns(table_id, cfg->num_challenges); }
 
 static int prove_generic(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
                          const uint64_t* aux, size_t A, const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids,
-                         size_t Z, zko_challenger* ch, uint64_t* proof, double* stage_s) {
-    return prove_generic_ex(table_id, cfg, trace, W, log_n, aux, A, ctl_t, zs, colset_ids, Z, ch, proof, stage_s, NULL, NULL, NULL);
+                         size_t Z, const uint64_t* lookup_ch, zko_challenger* ch, uint64_t* proof, double* stage_s) {
+    return prove_generic_ex(table_id, cfg, trace, W, log_n, aux, A, ctl_t, zs, colset_ids, Z, lookup_ch, ch, proof, stage_s, NULL, NULL, NULL);
+}
+
+/* lookup_helper_columns (lookup.rs:46-124) for Column::single columns without filters: per pair h = 1/(f0 + x) + 1/(f1 + x),
+ * then Z with Z[0] = 0, Z[i+1] = Z[i] + sum_h(i) - freq(i) / (table(i) + x).  out = (ceil(ncols/2) + 1) columns of n. */
+static void lookup_columns_simple(const zko_lookup_def* d, gl_t x, const uint64_t* trace, size_t n, gl_t* out) {
+    size_t nh = (d->ncols + 1) / 2;
+    memset(out, 0, sizeof(gl_t) * nh * n);
+    for (size_t q = 0; q < d->ncols; q++) {
+        const uint64_t* col = trace + (size_t)d->cols[q] * n;
+        gl_t* h = out + (q / 2) * n;
+        for (size_t i = 0; i < n; i++) h[i] = gl_add(h[i], gl_inv(gl_add(col[i], x)));
+    }
+    gl_t* z = out + nh * n;
+    const uint64_t *tab = trace + (size_t)d->table_col * n, *freq = trace + (size_t)d->freq_col * n;
+    z[0] = 0;
+    for (size_t i = 0; i + 1 < n; i++) {
+        gl_t acc = 0;
+        for (size_t q = 0; q < nh; q++) acc = gl_add(acc, out[q * n + i]);
+        acc = gl_sub(acc, gl_mul(freq[i], gl_inv(gl_add(tab[i], x))));
+        z[i + 1] = gl_add(z[i], acc);
+    }
 }
 
 static int prove_generic_ex(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
-                            const uint64_t* aux, size_t A, const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids,
-                            size_t Z, zko_challenger* ch, uint64_t* proof, double* stage_s, zko_batch* tb_in, zko_batch* ab_in,
-                            zko_batch* qb_in) {
+                            const uint64_t* aux_ctl, size_t A_ctl, const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids,
+                            size_t Z, const uint64_t* lookup_ch, zko_challenger* ch, uint64_t* proof, double* stage_s, zko_batch* tb_in,
+                            zko_batch* ab_in, zko_batch* qb_in) {
     const int openings_only = tb_in != NULL;
     if (!openings_only && (b_table_width(table_id) == 0 || (size_t)b_table_width(table_id) != W)) return -1;
     if (cfg->num_challenges > 4) return -1;
+    /* lookup helper columns come first among the auxiliary polynomials (prover.rs:467-508) */
+    const size_t NL = openings_only ? 0 : zko_table_num_lookup_columns(table_id, cfg->num_challenges);
+    if (NL && !lookup_ch) return -5;
+    if (!NL) lookup_ch = NULL;
+    const size_t A = NL + A_ctl;
     layout_t y;
     layout(&y, cfg, log_n, W, A, Z);
     size_t n = (size_t)1 << log_n, N = (size_t)1 << y.lde_bits;
-    size_t total_helpers = 0;
+    size_t total_helpers = 0; /* index of the first CTL Z among the auxiliary polynomials */
     if (openings_only) {
         if (Z > A || zko_batch_ncols(qb_in) != y.Q || zko_batch_log_n(ab_in) != log_n || zko_batch_log_n(qb_in) != log_n) return -3;
-        total_helpers = A - Z;
     } else {
-        for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
+        size_t ctl_helpers = 0;
+        for (size_t i = 0; i < Z; i++) ctl_helpers += zs[i].num_helpers;
+        if (ctl_helpers + Z != A_ctl) return -3;
     }
-    if (total_helpers + Z != A) return -3;
+    total_helpers = A - Z;
+    const uint64_t* aux = aux_ctl;
+    uint64_t* aux_all = NULL;
+    if (NL) {
+        aux_all = (uint64_t*)malloc(sizeof(uint64_t) * A * n);
+        size_t nl, off = 0;
+        const zko_lookup_def* defs = zko_table_lookups(table_id, &nl);
+        for (size_t l = 0; l < nl; l++)
+            for (unsigned c = 0; c < cfg->num_challenges; c++) {
+                lookup_columns_simple(&defs[l], lookup_ch[c], trace, n, aux_all + off * n);
+                off += (defs[l].ncols + 1) / 2 + 1;
+            }
+        memcpy(aux_all + NL * n, aux_ctl, sizeof(uint64_t) * A_ctl * n);
+        aux = aux_all;
+    }
     double t0, ts[8] = {0};
 
     memset(proof, 0, sizeof(uint64_t) * y.total);
@@ -371,6 +419,7 @@ static int prove_generic_ex(int table_id, const zko_stark_config* cfg, const uin
     if (!openings_only) {
         t0 = now_s();
         ab = zko_batch_from_values(aux, A, log_n, cfg->rate_bits, cfg->cap_height); /* :511-522 */
+        free(aux_all);
         ts[1] = now_s() - t0;
         zko_batch_cap(ab, caps + y.C * 4);
         zko_challenger_observe(ch, caps + y.C * 4, y.C * 4);                            /* :525 */
@@ -379,7 +428,7 @@ static int prove_generic_ex(int table_id, const zko_stark_config* cfg, const uin
 
         t0 = now_s();
         gl_t* quot = (gl_t*)malloc(sizeof(gl_t) * cfg->num_challenges * 2 * n);
-        quotient_generic(table_id, tb, ab, ctl_t, zs, colset_ids, Z, alphas, cfg->num_challenges, quot);  /* :543-559 */
+        quotient_generic(table_id, tb, ab, ctl_t, zs, colset_ids, Z, lookup_ch, alphas, cfg->num_challenges, quot);  /* :543-559 */
         ts[2] = now_s() - t0;
         /* chunks of n coefficients: [q0_lo, q0_hi, q1_lo, q1_hi] == quot viewed as Q columns of n (:560-575) */
         t0 = now_s();
@@ -617,29 +666,34 @@ static gl2_t compute_evaluation(gl_t x, size_t x_in_coset, unsigned arity_bits, 
 }
 
 static int verify_generic(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
-                          const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t Z, zko_challenger* ch);
+                          const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t Z, const uint64_t* lookup_ch,
+                          zko_challenger* ch);
 
 /* verifier of zko_prove_openings: transcript replay + verify_fri_proof, no constraint check */
 int zko_verify_openings(const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A, size_t Z, zko_challenger* ch) {
-    return verify_generic(-1, cfg, proof, W, A, NULL, NULL, NULL, Z, ch);
+    return verify_generic(-1, cfg, proof, W, A, NULL, NULL, NULL, Z, NULL, ch);
 }
 
 int zko_verify_single_table(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
                             const uint32_t* num_helpers, size_t Z, zko_challenger* ch) {
     zko_ctl_z* zs = fake_zs(num_helpers, Z);
-    int rc = verify_generic(table_id, cfg, proof, W, A, &EMPTY_CTL_TABLE, zs, NULL, Z, ch);
+    int rc = verify_generic(table_id, cfg, proof, W, A, &EMPTY_CTL_TABLE, zs, NULL, Z, NULL, ch);
     free(zs);
     return rc;
 }
 int zko_verify_single_table_ctl(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
                                 const zko_ctl_table* t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t Z,
-                                zko_challenger* ch) {
-    return verify_generic(table_id, cfg, proof, W, A, t, zs, colset_ids, Z, ch);
+                                const uint64_t* lookup_challenges, zko_challenger* ch) {
+    return verify_generic(table_id, cfg, proof, W, A, t, zs, colset_ids, Z, lookup_challenges, ch);
 }
 
-static int verify_generic(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A,
-                          const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t Z, zko_challenger* ch) {
+static int verify_generic(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t W, size_t A_ctl,
+                          const zko_ctl_table* ctl_t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t Z, const uint64_t* lookup_ch,
+                          zko_challenger* ch) {
     const int openings_only = table_id < 0;
+    const size_t NL = openings_only ? 0 : zko_table_num_lookup_columns(table_id, cfg->num_challenges);
+    if (NL && !lookup_ch) return 1;
+    const size_t A = NL + A_ctl;
     if (!openings_only && (b_table_width(table_id) == 0 || (size_t)b_table_width(table_id) != W)) return 1;
     if (proof[0] != 0x5a4b4d50524f4f46ULL) return 2;
     unsigned log_n = (unsigned)proof[1];
@@ -649,10 +703,12 @@ static int verify_generic(int table_id, const zko_stark_config* cfg, const uint6
         proof[8] != y.F || proof[9] != y.nq)
         return 3; /* validate_proof_shape verifier.rs:294-342 */
     size_t N = (size_t)1 << y.lde_bits;
-    size_t total_helpers = 0;
-    if (openings_only) total_helpers = A - Z;
-    else for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
-    if (total_helpers + Z != A) return 3;
+    size_t total_helpers = A - Z; /* index of the first CTL Z */
+    if (!openings_only) {
+        size_t ctl_helpers = 0;
+        for (size_t i = 0; i < Z; i++) ctl_helpers += zs[i].num_helpers;
+        if (ctl_helpers + Z != A_ctl) return 3;
+    }
     size_t arity = (size_t)1 << cfg->arity_bits;
 
     /* the verifier starts from the recorded transcript state (proof.rs:199): the prover's challenger
@@ -712,7 +768,8 @@ static int verify_generic(int table_id, const zko_stark_config* cfg, const uint6
     k.l_last = gl2_mul(z_h, gl2_inv(d1));
     if (!openings_only) {
         e_eval_table(table_id, lv, nv, &k);
-        e_eval_ctl_general(ctl_t, zs, colset_ids, Z, lv, nv, av, an, &k);
+        if (NL) e_eval_lookups(table_id, lookup_ch, cfg->num_challenges, lv, av, an, &k);
+        e_eval_ctl_general(ctl_t, zs, colset_ids, Z, lv, nv, av + NL, an + NL, &k);
     }
     for (unsigned i = 0; i < cfg->num_challenges && !openings_only; i++) {
         gl2_t t0 = gl2_make(o_quot[4 * i], o_quot[4 * i + 1]), t1 = gl2_make(o_quot[4 * i + 2], o_quot[4 * i + 3]);

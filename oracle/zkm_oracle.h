@@ -84,6 +84,10 @@ void zko_poseidon_trace(uint64_t seed, size_t num_perms, unsigned log_n, uint64_
 #define ZKO_TABLE_LOGIC 1
 #define ZKO_TABLE_KECCAK_SPONGE 2
 #define ZKO_TABLE_KECCAK 3
+#define ZKO_TABLE_MEMORY 4
+#define ZKO_MEMORY_COLS 13
+/* MemoryStark::generate_trace (memory/memory_stark.rs:123-248); ops = nops x 6 {context, segment, virt, timestamp, is_read, value} */
+size_t zko_memory_trace(const uint64_t* ops, size_t nops, unsigned log_n, uint64_t* out);
 #define ZKO_KECCAK_COLS 2431
 /* KeccakStark::generate_trace (keccak/keccak_stark.rs:62-236): inputs = nperms x 25 u64, one timestamp per permutation; out = 2431 x 2^log_n.
  * Returns the rows used (24 per permutation), 0 if they do not fit. */
@@ -131,10 +135,14 @@ void zko_lookup_helper_columns(const zko_ctl_table* t, const uint32_t* colset_id
 int zko_check_ctls(const zko_table_input* tables, size_t ntables, const zko_cross_table_lookup* ctls, const zko_ctl_side* sides, size_t nctls);
 int zko_prove_single_table_ctl(int table_id, const zko_stark_config* cfg, const uint64_t* trace, size_t ncols, unsigned log_n,
                                const uint64_t* aux, size_t naux, const zko_ctl_table* t, const zko_ctl_z* zs,
-                               const uint32_t* colset_ids, size_t nzs, zko_challenger* challenger, uint64_t* proof_out);
+                               const uint32_t* colset_ids, size_t nzs, const uint64_t* lookup_challenges, zko_challenger* challenger,
+                               uint64_t* proof_out);
+/* lookup helper columns a table's own logUp lookups add in front of the CTL columns (stark.rs:217-223); naux arguments of
+ * the prove / verify entry points count the CTL columns only, zko_proof_words takes the total. */
+size_t zko_num_lookup_columns(int table_id, const zko_stark_config* cfg);
 int zko_verify_single_table_ctl(int table_id, const zko_stark_config* cfg, const uint64_t* proof, size_t ncols, size_t naux,
                                 const zko_ctl_table* t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t nzs,
-                                zko_challenger* challenger);
+                                const uint64_t* lookup_challenges, zko_challenger* challenger);
 size_t zko_all_proof_words(const zko_stark_config* cfg, const zko_table_input* tables, size_t ntables,
                            const zko_cross_table_lookup* ctls, const zko_ctl_side* sides, size_t nctls, size_t* proof_offsets_out);
 int zko_prove_with_traces(const zko_stark_config* cfg, const zko_table_input* tables, size_t ntables,

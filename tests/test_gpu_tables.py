@@ -198,3 +198,49 @@ def test_sponge_keccak_logic_device_resident_large(ctx, oracle):
     proofs, chal, offs = ctx.prove_with_traces(dev, ctls)
     host = [(t, b.download(), w, l, c) for (t, b, w, l, c) in dev]
     assert oracle.verify_all(host, ctls, proofs, chal) == 0
+
+
+@pytest.mark.parametrize("log_n,k", [(8, 200), (12, 3000)])
+def test_memory_table_proof_with_range_check_lookup_is_bit_exact(ctx, zkm, oracle, log_n, k):
+    """MemoryStark: 13 trace columns + the logUp range check (lookup.rs:46-198) whose helper columns the prover builds."""
+    from zkm_amd.ctl import CtlTable, make_zs
+    from .test_oracle_tables import random_memory_ops
+    trace, natural = oracle.memory_trace(random_memory_ops(log_n, k), log_n)
+    assert natural == 1 << log_n
+    t = CtlTable()
+    cs = T.memory_ctl_data(t)
+    zs, ids = make_zs([([cs], 3, 5), ([cs], 7, 11)])
+    aux = ctx.ctl_data(t, zs, ids, trace, 13, log_n)
+    assert (aux == oracle.ctl_data(t, zs, ids, trace, 13, log_n)).all()
+    lk = [0x1234567, 0x89ABCDEF01]
+    want = oracle.prove_ctl(trace, log_n, aux, t, zs, ids, ncols=13, table_id=T.TABLE_MEMORY, lookup_challenges=lk)
+    got = ctx.prove_single_table_ctl(trace, log_n, aux, t, zs, ids, ncols=13, table_id=T.TABLE_MEMORY, lookup_challenges=lk)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing word %d" % bad[0]
+    assert got[3] == 4 + 2    # 2 x (1 helper + 1 Z) lookup columns in front of the 2 CTL Zs
+    assert oracle.verify_ctl(got, 2, t, zs, ids, ncols=13, table_id=T.TABLE_MEMORY, lookup_challenges=lk) == 0
+    # the lookup needs its challenges and the trace values
+    with pytest.raises(zkm.ZkmError, match="lookup challenges"):
+        ctx.prove_single_table_ctl(trace, log_n, aux, t, zs, ids, ncols=13, table_id=T.TABLE_MEMORY)
+    tb = zkm.PolynomialBatch.from_values(ctx, trace, 13, log_n)
+    with pytest.raises(zkm.ZkmError, match="trace values"):
+        ctx.prove_single_table_ctl(None, log_n, aux, t, zs, ids, ncols=13, table_id=T.TABLE_MEMORY, trace_batch=tb, lookup_challenges=lk)
+
+
+def test_precompile_path_four_tables_is_bit_exact_and_verifies(ctx, oracle):
+    """Memory -> KeccakSponge -> (Keccak, Logic): every cross-table lookup the reference defines among these four tables
+    (all_stark.rs:214-240, 340-355, 479-542), including the 136 per-byte memory reads (68 helper columns per challenge)."""
+    tables, ctls, _ = logic_fixtures.build4(oracle, log_sponge=3)
+    want, wchal, woffs = oracle.prove_with_traces(tables, ctls)
+    got, chal, offs = ctx.prove_with_traces(tables, ctls)
+    assert offs == woffs and (chal == wchal).all()
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing word %d" % bad[0]
+    assert oracle.verify_all(tables, ctls, got, chal) == 0
+
+
+def test_precompile_path_four_tables_larger(ctx, oracle):
+    tables, ctls, _ = logic_fixtures.build4(oracle, log_sponge=7, seed=31)
+    assert oracle.check_ctls(tables, ctls) == 0
+    proofs, chal, offs = ctx.prove_with_traces(tables, ctls)
+    assert oracle.verify_all(tables, ctls, proofs, chal) == 0

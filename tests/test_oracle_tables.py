@@ -90,3 +90,76 @@ def test_sponge_keccak_logic_ctls(oracle):
     tid, tr, w, log_n, ct = tables[1]
     bad_tables = [tables[0], (tid, oracle.keccak_trace(bad_inputs, ts, log_n), w, log_n, ct), tables[2]]
     assert oracle.check_ctls(bad_tables, ctls) != 0
+
+
+def random_memory_ops(seed, k):
+    rng = np.random.default_rng(seed)
+    addr = rng.integers(0, 40, k)
+    ops = np.zeros((k, 6), dtype=np.uint64)
+    ops[:, 0] = rng.integers(0, 2, k)          # context
+    ops[:, 1] = rng.integers(0, 5, k)          # segment
+    ops[:, 2] = addr * 4
+    ops[:, 3] = rng.permutation(k) * 3 + 1     # distinct timestamps
+    # reads must return the last written value: replay in timestamp order per address
+    order = np.argsort(ops[:, 3])
+    mem = {}
+    for i in order:
+        key = (int(ops[i, 0]), int(ops[i, 1]), int(ops[i, 2]))
+        if key not in mem or rng.integers(0, 3) == 0:
+            ops[i, 4], ops[i, 5] = 0, rng.integers(0, 1 << 32)
+            mem[key] = int(ops[i, 5])
+            if key == (0, 4, 0):
+                mem[key] = 0                    # writes to R0 are stored as 0 (memory_stark.rs:68-76)
+        else:
+            ops[i, 4], ops[i, 5] = 1, mem[key]
+    return ops
+
+
+def test_memory_trace_and_proof(oracle):
+    ops = random_memory_ops(1, 200)
+    log_n = 8
+    trace, natural = oracle.memory_trace(ops, log_n)
+    assert natural == 256
+    tr = trace.reshape(13, 256)
+    key = [tuple(int(tr[c, i]) for c in (3, 4, 5, 1)) for i in range(256)]
+    assert key == sorted(key)                                   # ordered by (context, segment, virt, timestamp)
+    assert int(tr[0].sum()) == 200                              # every real operation present, padding has filter 0
+    assert (tr[11] == np.arange(256)).all() and int(tr[12].sum()) == 256
+    assert int(tr[10].max()) < 256
+    # single-table proof with the range-check lookup (lookup.rs:138-198): lookup challenges are the CTL betas
+    from zkm_amd.ctl import CtlTable, make_zs
+    t = CtlTable()
+    cs = T.memory_ctl_data(t)
+    zs, ids = make_zs([([cs], 3, 5), ([cs], 7, 11)])
+    aux = oracle.ctl_data(t, zs, ids, trace, 13, log_n)
+    proof = oracle.prove_ctl(trace, log_n, aux, t, zs, ids, ncols=13, table_id=T.TABLE_MEMORY, lookup_challenges=[3, 7])
+    assert oracle.num_lookup_columns(T.TABLE_MEMORY) == 4 and proof[3] == 4 + 2
+    assert oracle.verify_ctl(proof, 2, t, zs, ids, ncols=13, table_id=T.TABLE_MEMORY, lookup_challenges=[3, 7]) == 0
+    assert oracle.verify_ctl(proof, 2, t, zs, ids, ncols=13, table_id=T.TABLE_MEMORY, lookup_challenges=[3, 8]) != 0
+    # a value that breaks read consistency / a range-check value outside the counter range
+    for col, row in ((6, 17), (10, 30)):
+        bad = trace.copy()
+        bad[col * 256 + row] += 1
+        if col == 6:
+            while bad[2 * 256 + row] != 1 or tr[5, row] != tr[5, row - 1]:   # need a read that follows the same address
+                bad[col * 256 + row] -= 1
+                row += 1
+                bad[col * 256 + row] += 1
+        aux = oracle.ctl_data(t, zs, ids, bad, 13, log_n)
+        proof = oracle.prove_ctl(bad, log_n, aux, t, zs, ids, ncols=13, table_id=T.TABLE_MEMORY, lookup_challenges=[3, 7])
+        assert oracle.verify_ctl(proof, 2, t, zs, ids, ncols=13, table_id=T.TABLE_MEMORY, lookup_challenges=[3, 7]) != 0
+
+
+def test_memory_fill_gaps(oracle):
+    # two accesses of one address 10^4 timestamps apart, and two addresses 10^5 words apart: dummy reads bridge both gaps
+    ops = np.array([[0, 1, 8, 5, 0, 77], [0, 1, 8, 10005, 1, 77], [0, 1, 100008, 3, 0, 9], [0, 1, 100008, 4, 1, 9]], dtype=np.uint64)
+    trace, natural = oracle.memory_trace(ops, 16)
+    tr = trace.reshape(13, -1)
+    assert int(tr[0].sum()) == 4 and natural > 4 and int(tr[10].max()) < natural
+
+
+def test_precompile_path_four_tables(oracle):
+    tables, ctls, _ = logic_fixtures.build4(oracle)
+    assert oracle.check_ctls(tables, ctls) == 0
+    proofs, chal, offs = oracle.prove_with_traces(tables, ctls)
+    assert oracle.verify_all(tables, ctls, proofs, chal) == 0

@@ -21,7 +21,7 @@ POSEIDON_COLS = 262
 KECCAK_SPONGE_COLS = 470
 LOGIC_COLS = 69
 KECCAK_COLS = 2431
-TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK = 0, 1, 2, 3
+TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY = 0, 1, 2, 3, 4
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
@@ -29,7 +29,7 @@ EXPORTS = [
     "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_free",
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_keccak_trace", "zkm_logic_trace",
-    "zkm_table_width", "zkm_challenger_init",
+    "zkm_table_width", "zkm_num_lookup_columns", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
     "zkm_prove_single_table", "zkm_prove_openings", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
     "zkm_quotient", "zkm_eval_openings", "zkm_profile_enable", "zkm_profile_reset",
@@ -110,7 +110,8 @@ def load():
                                              C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Challenger), u64p, err]),
         "zkm_prove_openings": (C.c_int, [cp, C.POINTER(StarkConfig), cp, cp, cp, C.c_size_t, C.POINTER(Challenger), u64p, err]),
         "zkm_prove_single_table_ctl": (C.c_int, [cp, C.c_int, C.POINTER(StarkConfig), cp, C.c_size_t, C.c_uint, cp, cp, C.c_size_t,
-                                                 cp, cp, cp, C.c_size_t, C.POINTER(Challenger), u64p, err]),
+                                                 cp, cp, cp, C.c_size_t, u64p, C.POINTER(Challenger), u64p, err]),
+        "zkm_num_lookup_columns": (C.c_size_t, [C.c_int, C.POINTER(StarkConfig)]),
         "zkm_ctl_data": (C.c_int, [cp, cp, cp, cp, C.c_size_t, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_lookup_helper_columns": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, cp, C.c_size_t, C.c_uint, cp,
                                                 err]),
@@ -349,16 +350,20 @@ class Context:
         return out
 
     def prove_single_table_ctl(self, trace, log_n, aux, ctl_table, zs, colset_ids, challenger=None, cfg=None, ncols=POSEIDON_COLS,
-                               trace_batch=None, table_id=TABLE_POSEIDON):
+                               trace_batch=None, table_id=TABLE_POSEIDON, lookup_challenges=None):
+        """lookup_challenges: the CTL betas, required for tables with their own lookups (Memory)."""
         cfg = cfg or self.standard_config()
         ch = challenger if challenger is not None else Challenger()
         naux = (aux.size if isinstance(aux, np.ndarray) else aux.words) >> log_n
-        proof = np.zeros(self.proof_words(cfg, log_n, ncols, naux, len(zs)), dtype=np.uint64)
+        nl = self.L.zkm_num_lookup_columns(table_id, C.byref(cfg))
+        proof = np.zeros(self.proof_words(cfg, log_n, ncols, naux + nl, len(zs)), dtype=np.uint64)
         st = ctl_table.pack()
         err = C.c_char_p()
+        lk = None if lookup_challenges is None else np.ascontiguousarray(lookup_challenges, dtype=np.uint64)
         _check(self.L.zkm_prove_single_table_ctl(self.h, table_id, C.byref(cfg), _data_ptr(trace) if trace is not None else None, ncols,
                                                  log_n, trace_batch.h if trace_batch is not None else None, _data_ptr(aux), naux,
-                                                 C.addressof(st), zs.ctypes.data, colset_ids.ctypes.data, len(zs), C.byref(ch),
+                                                 C.addressof(st), zs.ctypes.data, colset_ids.ctypes.data, len(zs),
+                                                 None if lk is None else lk.ctypes.data_as(u64p), C.byref(ch),
                                                  proof.ctypes.data_as(u64p), C.byref(err)), err)
         return proof
 

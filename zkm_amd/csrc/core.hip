@@ -75,6 +75,16 @@ void zkm_ctx::prof_begin(const char* name) {
 }
 void zkm_ctx::prof_end() { ZKM_HIP_CHECK(hipEventRecord(prof.back().stop, stream)); }
 
+// Stark::lookups() of the tables with constraint kernels.  Memory: RANGE_CHECK (10) looked up in COUNTER (11) with
+// FREQUENCIES (12), memory_stark.rs:476-483.
+static const uint32_t MEMORY_LOOKUP_COLS[1] = {10};
+static const zkm_table_lookup MEMORY_LOOKUPS[1] = {{1, MEMORY_LOOKUP_COLS, 11, 12}};
+const zkm_table_lookup* zkm_table_lookups(int table_id, size_t* n) {
+    if (table_id == ZKM_TABLE_MEMORY) { *n = 1; return MEMORY_LOOKUPS; }
+    *n = 0;
+    return nullptr;
+}
+
 extern "C" {
 
 const char* zkm_version(void) { return "zkm-hip 0.1 (gfx950)"; }
@@ -429,12 +439,20 @@ int zkm_keccak_sponge_trace(zkm_ctx* c, const uint8_t* inputs, const uint64_t* i
     return 0;
 }
 
+size_t zkm_num_lookup_columns(int table_id, const zkm_stark_config* cfg) {
+    size_t nl = 0, total = 0;
+    const zkm_table_lookup* d = zkm_table_lookups(table_id, &nl);
+    for (size_t i = 0; i < nl; i++) total += ((d[i].ncols + 1) / 2 + 1) * cfg->num_challenges;
+    return total;
+}
+
 size_t zkm_table_width(int table_id) {
     switch (table_id) {
         case ZKM_TABLE_POSEIDON: return ZKM_POSEIDON_COLS;
         case ZKM_TABLE_LOGIC: return ZKM_LOGIC_COLS;
         case ZKM_TABLE_KECCAK_SPONGE: return ZKM_KECCAK_SPONGE_COLS;
         case ZKM_TABLE_KECCAK: return ZKM_KECCAK_COLS;
+        case ZKM_TABLE_MEMORY: return ZKM_MEMORY_COLS;
         default: return 0;
     }
 }

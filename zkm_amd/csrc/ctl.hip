@@ -281,29 +281,17 @@ int zkm_ctl_data(zkm_ctx* c, const zkm_ctl_table* table, const zkm_ctl_z* zs, co
     return 0;
 }
 
-int zkm_lookup_helper_columns(zkm_ctx* c, const zkm_ctl_table* table, const uint32_t* colset_ids, size_t nlookup, uint32_t table_col,
-                              uint32_t freq_col, uint64_t challenge, const uint64_t* trace, size_t ncols, unsigned log_n,
-                              uint64_t* out, char** err) {
+}  // extern "C"
+
+// (ceil(nlookup / 2) + 1) columns of n into d_out (device): helper columns then Z (lookup.rs:46-124)
+static void lookup_helper_columns_device(zkm_ctx* c, const zkm_ctl_table* table, const uint32_t* colset_ids, size_t nlookup, uint32_t table_col,
+                                         uint32_t freq_col, uint64_t challenge, const gl_t* d_trace, size_t n, gl_t* d_out) {
     std::vector<void*> tmp;
+    size_t nh = (nlookup + 1) / 2;
+    zkm_ctl_z z{(uint32_t)nlookup, 0, (uint32_t)nh, 0, 1, challenge};  // GrandProductChallenge{beta: 1, gamma: challenge}
+    ctl_dev_owner own;
+    own.upload(c, table, &z, colset_ids, 1, /*lookup_mode=*/true);
     try {
-        ZKM_HIP_CHECK(hipSetDevice(c->device));
-        if (!table || nlookup == 0) throw std::runtime_error("zkm_lookup_helper_columns: empty lookup");
-        if (table_col >= table->ncolumns || freq_col >= table->ncolumns) throw std::runtime_error("lookup: column index out of range");
-        if (challenge >= GL_P) throw std::runtime_error("lookup: non-canonical challenge");
-        for (size_t i = 0; i < table->nterms; i++)
-            if (table->term_col[i] >= ncols) throw std::runtime_error("CTL description: trace column index out of range");
-        size_t n = (size_t)1 << log_n, nh = (nlookup + 1) / 2;
-        for (size_t i = 0; i < nlookup; i++)
-            if (colset_ids[i] < table->ncolsets && table->colsets[colset_ids[i]].ncols != 1)
-                throw std::runtime_error("lookup: every looking entry must be a single-column set");
-        zkm_ctl_z z{(uint32_t)nlookup, 0, (uint32_t)nh, 0, 1, challenge};  // GrandProductChallenge{beta: 1, gamma: challenge}
-        ctl_dev_owner own;
-        own.upload(c, table, &z, colset_ids, 1, /*lookup_mode=*/true);
-        bool tdev = zkm_is_device_ptr(trace), odev = zkm_is_device_ptr(out);
-        gl_t* d_trace = tdev ? const_cast<gl_t*>(trace) : (gl_t*)c->alloc(ncols * n * 8);
-        if (!tdev) { tmp.push_back(d_trace); ZKM_HIP_CHECK(hipMemcpyAsync(d_trace, trace, ncols * n * 8, hipMemcpyHostToDevice, c->stream)); }
-        gl_t* d_out = odev ? out : (gl_t*)c->alloc((nh + 1) * n * 8);
-        if (!odev) tmp.push_back(d_out);
         gl_t* d_hsum = (gl_t*)c->alloc(n * 8);
         tmp.push_back(d_hsum);
         gl_t* d_x = (gl_t*)c->alloc(n * 8);
@@ -323,11 +311,72 @@ int zkm_lookup_helper_columns(zkm_ctx* c, const zkm_ctl_table* table, const uint
         ZKM_HIP_CHECK(hipGetLastError());
         int bad = 0;
         ZKM_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        if (!odev) ZKM_HIP_CHECK(hipMemcpyAsync(out, d_out, (nh + 1) * n * 8, hipMemcpyDeviceToHost, c->stream));
         c->sync();
         for (void* p : tmp) c->release(p);
         tmp.clear();
         if (bad) throw std::runtime_error("Non-binary filter?");
+    } catch (...) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* p : tmp) c->release(p);
+        throw;
+    }
+}
+
+// A table's own logUp lookups (Stark::lookups()): every use in the reference is Column::single columns without filters
+// (memory_stark.rs:476-483, arithmetic_stark.rs:269-276).  Writes zkm_num_lookup_columns() columns of n into d_out:
+// per lookup, per challenge: helper columns then Z (prover.rs:475-493).
+void zkm_table_lookup_columns_device(zkm_ctx* c, int table_id, const uint64_t* challenges, size_t nch, const gl_t* d_trace, size_t n,
+                                     gl_t* d_out) {
+    size_t nl = 0, off = 0;
+    const zkm_table_lookup* defs = zkm_table_lookups(table_id, &nl);
+    for (size_t l = 0; l < nl; l++) {
+        const zkm_table_lookup& d = defs[l];
+        // describe the lookup with the CTL column machinery: ncols single-column sets, then the table / frequencies columns
+        std::vector<zkm_column> cols(d.ncols + 2);
+        std::vector<uint32_t> tc(d.ncols + 2);
+        std::vector<uint64_t> tf(d.ncols + 2, 1);
+        std::vector<zkm_colset> sets(d.ncols);
+        std::vector<uint32_t> ids(d.ncols);
+        for (uint32_t i = 0; i < d.ncols + 2; i++) {
+            tc[i] = i < d.ncols ? d.cols[i] : i == d.ncols ? d.table_col : d.freq_col;
+            cols[i] = zkm_column{1, 0, i, 0, 0};
+            if (i < d.ncols) { sets[i] = zkm_colset{1, i, 0, 0, 0, 0, 0, 0}; ids[i] = i; }
+        }
+        zkm_ctl_table t{cols.data(), cols.size(), tc.data(), tf.data(), tc.size(), sets.data(), sets.size(), nullptr, 0};
+        for (size_t k = 0; k < nch; k++) {
+            lookup_helper_columns_device(c, &t, ids.data(), d.ncols, d.ncols, d.ncols + 1, challenges[k], d_trace, n, d_out + off * n);
+            off += (d.ncols + 1) / 2 + 1;
+        }
+    }
+}
+
+extern "C" {
+
+int zkm_lookup_helper_columns(zkm_ctx* c, const zkm_ctl_table* table, const uint32_t* colset_ids, size_t nlookup, uint32_t table_col,
+                              uint32_t freq_col, uint64_t challenge, const uint64_t* trace, size_t ncols, unsigned log_n,
+                              uint64_t* out, char** err) {
+    std::vector<void*> tmp;
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!table || nlookup == 0) throw std::runtime_error("zkm_lookup_helper_columns: empty lookup");
+        if (table_col >= table->ncolumns || freq_col >= table->ncolumns) throw std::runtime_error("lookup: column index out of range");
+        if (challenge >= GL_P) throw std::runtime_error("lookup: non-canonical challenge");
+        for (size_t i = 0; i < table->nterms; i++)
+            if (table->term_col[i] >= ncols) throw std::runtime_error("CTL description: trace column index out of range");
+        size_t n = (size_t)1 << log_n, nh = (nlookup + 1) / 2;
+        for (size_t i = 0; i < nlookup; i++)
+            if (colset_ids[i] < table->ncolsets && table->colsets[colset_ids[i]].ncols != 1)
+                throw std::runtime_error("lookup: every looking entry must be a single-column set");
+        bool tdev = zkm_is_device_ptr(trace), odev = zkm_is_device_ptr(out);
+        gl_t* d_trace = tdev ? const_cast<gl_t*>(trace) : (gl_t*)c->alloc(ncols * n * 8);
+        if (!tdev) { tmp.push_back(d_trace); ZKM_HIP_CHECK(hipMemcpyAsync(d_trace, trace, ncols * n * 8, hipMemcpyHostToDevice, c->stream)); }
+        gl_t* d_out = odev ? out : (gl_t*)c->alloc((nh + 1) * n * 8);
+        if (!odev) tmp.push_back(d_out);
+        lookup_helper_columns_device(c, table, colset_ids, nlookup, table_col, freq_col, challenge, d_trace, n, d_out);
+        if (!odev) ZKM_HIP_CHECK(hipMemcpyAsync(out, d_out, (nh + 1) * n * 8, hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+        for (void* p : tmp) c->release(p);
+        tmp.clear();
     } catch (const std::exception& e) {
         (void)hipStreamSynchronize(c->stream);
         for (void* p : tmp) c->release(p);
@@ -343,7 +392,8 @@ size_t zkm_all_proof_words(const zkm_stark_config* cfg, const zkm_table_input* t
         size_t total = 0;
         for (size_t t = 0; t < ntables; t++) {
             if (offs) offs[t] = total;
-            total += zkm_proof_words(cfg, tables[t].log_n, tables[t].ncols, tz[t].naux, tz[t].zs.size());
+            total += zkm_proof_words(cfg, tables[t].log_n, tables[t].ncols, zkm_num_lookup_columns(tables[t].table_id, cfg) + tz[t].naux,
+                                     tz[t].zs.size());
         }
         if (offs) offs[ntables] = total;
         return total;
@@ -380,6 +430,8 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
             challenges[2 * k + 1] = zkm_challenger_get(&ch);
         }
         auto tz = derive_zs(ntables, ctls, sides, nctls, cfg->num_challenges, challenges);
+        uint64_t lookup_ch[4];  // the betas of the CTL challenges (prover.rs:468-474)
+        for (unsigned k = 0; k < cfg->num_challenges; k++) lookup_ch[k] = challenges[2 * k];
         // "compute CTL data" :191-200 + "compute all proofs given commitments" :234-438: tables in order, one transcript
         for (size_t t = 0; t < ntables; t++) {
             size_t n = (size_t)1 << tables[t].log_n;
@@ -393,9 +445,9 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
             char* e = nullptr;
             try {
                 zkm_ctl_data_device(c, own, d_trace, tables[t].log_n, d_aux);
-                rc = zkm_prove_single_table_ctl(c, tables[t].table_id, cfg, nullptr, tables[t].ncols, tables[t].log_n, commits[t], d_aux,
-                                                tz[t].naux, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), &ch,
-                                                proofs + offs[t], &e);
+                rc = zkm_prove_single_table_ctl(c, tables[t].table_id, cfg, d_trace, tables[t].ncols, tables[t].log_n, commits[t], d_aux,
+                                                tz[t].naux, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), lookup_ch,
+                                                &ch, proofs + offs[t], &e);
             } catch (...) {
                 (void)hipStreamSynchronize(c->stream);
                 if (!tdev) c->release(d_trace);

@@ -342,12 +342,79 @@ __device__ void eval_keccak_constraints(const gl_t* __restrict__ lv, size_t cs, 
 #undef NV
 }
 
+// MemoryStark (memory/memory_stark.rs:253-341; columns memory/columns.rs, VALUE_LIMBS = 1)
+template <int NA>
+__device__ void eval_memory_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
+    const gl_t* __restrict__ nv = lv + dnext;
+    enum { FILTER = 0, TIMESTAMP = 1, IS_READ = 2, CONTEXT = 3, SEGMENT = 4, VIRTUAL = 5, VALUE = 6, CFC = 7, SFC = 8, VFC = 9, RANGE_CHECK = 10 };
+    gl_t filter = lv[FILTER];
+    k.constraint(gl_mul(filter, gl_sub(filter, 1)));
+    gl_t cfc = lv[CFC * cs], sfc = lv[SFC * cs], vfc = lv[VFC * cs];
+    gl_t unchanged = gl_sub(gl_sub(gl_sub(1, cfc), sfc), vfc);
+    k.constraint(gl_mul(cfc, gl_sub(1, cfc)));
+    k.constraint(gl_mul(sfc, gl_sub(1, sfc)));
+    k.constraint(gl_mul(vfc, gl_sub(1, vfc)));
+    k.constraint(gl_mul(unchanged, gl_sub(1, unchanged)));
+    gl_t dctx = gl_sub(nv[CONTEXT * cs], lv[CONTEXT * cs]), dseg = gl_sub(nv[SEGMENT * cs], lv[SEGMENT * cs]);
+    gl_t dvirt = gl_sub(nv[VIRTUAL * cs], lv[VIRTUAL * cs]);
+    k.transition(gl_mul(sfc, dctx));
+    k.transition(gl_mul(vfc, dctx));
+    k.transition(gl_mul(vfc, dseg));
+    k.transition(gl_mul(unchanged, dctx));
+    k.transition(gl_mul(unchanged, dseg));
+    k.transition(gl_mul(unchanged, dvirt));
+    gl_t computed = gl_add(gl_add(gl_mul(cfc, gl_sub(dctx, 1)), gl_mul(sfc, gl_sub(dseg, 1))),
+                           gl_add(gl_mul(vfc, gl_sub(dvirt, 1)), gl_mul(unchanged, gl_sub(nv[TIMESTAMP * cs], lv[TIMESTAMP * cs]))));
+    k.transition(gl_sub(lv[RANGE_CHECK * cs], computed));
+    k.transition(gl_mul(gl_mul(nv[IS_READ * cs], unchanged), gl_sub(nv[VALUE * cs], lv[VALUE * cs])));
+}
+
+// A table's own logUp lookups (eval_packed_lookups_generic lookup.rs:138-198; helper-column checks eval_helper_columns
+// cross_table_lookup.rs:1006-1058 with beta = 1, gamma = challenge, no filters).  Passed by value: a few words.
+struct lookup_dev {
+    uint32_t nlookups, nch;
+    gl_t challenges[4];
+    struct { uint32_t ncols, col_off, table_col, freq_col; } lk[2];
+    uint32_t cols[24];
+};
+template <int NA>
+__device__ void eval_lookup_constraints(const lookup_dev& d, const gl_t* __restrict__ lv, size_t N, const gl_t* __restrict__ aux,
+                                        size_t j, size_t jn, consumer_t<NA>& k) {
+    uint32_t start = 0;
+    for (uint32_t l = 0; l < d.nlookups; l++) {
+        const uint32_t ncols = d.lk[l].ncols, nh = (ncols + 1) / 2;
+        const uint32_t* cols = d.cols + d.lk[l].col_off;
+        for (uint32_t c = 0; c < d.nch; c++) {
+            const gl_t ch = d.challenges[c];
+            gl_t hsum = 0;
+            for (uint32_t q = 0; q < nh; q++) {
+                gl_t h = aux[(size_t)(start + q) * N + j];
+                gl_t combin0 = gl_add(lv[(size_t)cols[2 * q] * N], ch);
+                if (2 * q + 1 < ncols) {
+                    gl_t combin1 = gl_add(lv[(size_t)cols[2 * q + 1] * N], ch);
+                    k.constraint(gl_sub(gl_sub(gl_mul(gl_mul(combin1, combin0), h), combin1), combin0));
+                } else {
+                    k.constraint(gl_sub(gl_mul(combin0, h), 1));
+                }
+                hsum = gl_add(hsum, h);
+            }
+            gl_t z = aux[(size_t)(start + nh) * N + j], next_z = aux[(size_t)(start + nh) * N + jn];
+            gl_t table_ch = gl_add(lv[(size_t)d.lk[l].table_col * N], ch);
+            gl_t y = gl_sub(gl_mul(hsum, table_ch), lv[(size_t)d.lk[l].freq_col * N]);
+            k.first_row(z);
+            k.constraint(gl_sub(gl_mul(gl_sub(next_z, z), table_ch), y));
+            start += nh + 1;
+        }
+    }
+}
+
 template <int TABLE, int NA>
 __device__ __forceinline__ void eval_table_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
     if constexpr (TABLE == ZKM_TABLE_POSEIDON) eval_poseidon_constraints<NA>(lv, cs, k);
     else if constexpr (TABLE == ZKM_TABLE_LOGIC) eval_logic_constraints<NA>(lv, cs, k);
     else if constexpr (TABLE == ZKM_TABLE_KECCAK_SPONGE) eval_keccak_sponge_constraints<NA>(lv, cs, dnext, k);
-    else eval_keccak_constraints<NA>(lv, cs, dnext, k);
+    else if constexpr (TABLE == ZKM_TABLE_KECCAK) eval_keccak_constraints<NA>(lv, cs, dnext, k);
+    else eval_memory_constraints<NA>(lv, cs, dnext, k);
 }
 
 // CTL checks driven by the column-set description (eval_helper_columns cross_table_lookup.rs:1006-1058,
@@ -400,7 +467,8 @@ __device__ void eval_ctl_constraints(const ctl_dev& d, const gl_t* __restrict__ 
 // prover.rs:668-675); "next" is natural +2 in the 2n domain (prover.rs:704) = +4 in the 4n domain.
 template <int TABLE, int NA>
 __global__ __launch_bounds__(256) void k_quotient(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux,
-                                                           unsigned log_n, unsigned lde_bits, ctl_dev ctl, const gl_t* alphas,
+                                                           unsigned log_n, unsigned lde_bits, ctl_dev ctl, lookup_dev lookups,
+                                                           uint32_t num_lookup_cols, const gl_t* alphas,
                                                            const gl_t* __restrict__ wpow /* w_{4n}^t two-level table */,
                                                            gl_t gn, gl_t zh_inv0, gl_t zh_inv1, gl_t last, gl_t w_n, gl_t n_inv,
                                                            gl_t* __restrict__ out) {
@@ -429,8 +497,9 @@ __global__ __launch_bounds__(256) void k_quotient(const gl_t* __restrict__ trace
     k.l_last = gl_mul(zn, gl_mul(dinv, d0));
 
     eval_table_constraints<TABLE, NA>(trace + j, N, (ptrdiff_t)jn - (ptrdiff_t)j, k);
-
-    eval_ctl_constraints<NA>(ctl, trace + j, N, (ptrdiff_t)jn - (ptrdiff_t)j, aux, j, jn, k);
+    // auxiliary columns: the table's lookup helper columns first, then the CTL helper columns and Zs (prover.rs:495-508)
+    if constexpr (TABLE == ZKM_TABLE_MEMORY) eval_lookup_constraints<NA>(lookups, trace + j, N, aux, j, jn, k);
+    eval_ctl_constraints<NA>(ctl, trace + j, N, (ptrdiff_t)jn - (ptrdiff_t)j, aux + (size_t)num_lookup_cols * N, j, jn, k);
     gl_t zi = (i & 1) ? zh_inv1 : zh_inv0;
 #pragma unroll
     for (int a = 0; a < NA; a++) out[(size_t)a * size + i] = gl_mul(k.acc[a], zi);
@@ -438,13 +507,32 @@ __global__ __launch_bounds__(256) void k_quotient(const gl_t* __restrict__ trace
 
 // quotient polys: d_out = nalphas x 2n natural-order coefficients (device)
 static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_batch* aux, const ctl_dev_owner& own,
-                            const gl_t* alphas_host, size_t nalphas, gl_t* d_out) {
+                            const uint64_t* lookup_challenges, const gl_t* alphas_host, size_t nalphas, gl_t* d_out) {
+    lookup_dev lookups{};
+    uint32_t NL = 0;
+    {
+        size_t nl = 0;
+        const zkm_table_lookup* defs = zkm_table_lookups(table_id, &nl);
+        if (nl && !lookup_challenges) throw std::runtime_error("zkm_quotient: this table has lookups; lookup challenges are required");
+        if (nl > 2) throw std::runtime_error("zkm_quotient: too many lookups");
+        lookups.nlookups = (uint32_t)nl;
+        lookups.nch = (uint32_t)nalphas;
+        uint32_t off = 0;
+        for (size_t l = 0; l < nl; l++) {
+            if (off + defs[l].ncols > 24) throw std::runtime_error("zkm_quotient: too many lookup columns");
+            lookups.lk[l] = {defs[l].ncols, off, defs[l].table_col, defs[l].freq_col};
+            for (uint32_t i = 0; i < defs[l].ncols; i++) lookups.cols[off + i] = defs[l].cols[i];
+            off += defs[l].ncols;
+            NL += ((defs[l].ncols + 1) / 2 + 1) * (uint32_t)nalphas;
+        }
+        for (size_t i = 0; nl && i < nalphas; i++) lookups.challenges[i] = lookup_challenges[i];
+    }
     if (zkm_table_width(table_id) == 0 || trace->ncols != zkm_table_width(table_id))
         throw std::runtime_error("zkm_quotient: unknown table id, or the trace width does not match the table");
     if (trace->rate_bits != 2 || aux->rate_bits != 2 || trace->log_n != aux->log_n)
         throw std::runtime_error("zkm_quotient: rate_bits must be 2 and the batches must have equal degree");
     if (nalphas < 1 || nalphas > 2) throw std::runtime_error("zkm_quotient: 1 or 2 challenges supported");
-    if (own.naux != aux->ncols) throw std::runtime_error("zkm_quotient: aux column count does not match the CTL description");
+    if (own.naux + NL != aux->ncols) throw std::runtime_error("zkm_quotient: aux column count does not match the CTL description");
     const ctl_dev& ctl = own.d;
     unsigned log_n = trace->log_n, lde_bits = log_n + 2, log_q = log_n + 1;
     size_t size = (size_t)1 << log_q;
@@ -458,12 +546,12 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     ZKM_HIP_CHECK(hipMemcpyAsync(d_alphas, alphas_host, nalphas * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
     gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
     {
-        static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak"};
+        static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory"};
         zkm_prof_scope ps(c, names[table_id]);
         dim3 grid((size + 255) / 256), block(256);
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
-    hipLaunchKernelGGL((k_quotient<T, NA>), grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, ctl, d_alphas, wpow, \
-                       gn, zh0, zh1, last, w_n, n_inv, d_vals)
+    hipLaunchKernelGGL((k_quotient<T, NA>), grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, ctl, lookups, NL, d_alphas, \
+                       wpow, gn, zh0, zh1, last, w_n, n_inv, d_vals)
         switch (table_id * 2 + (int)nalphas - 1) {
             case 0: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON, 1); break;
             case 1: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON, 2); break;
@@ -472,7 +560,9 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             case 4: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK_SPONGE, 1); break;
             case 5: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK_SPONGE, 2); break;
             case 6: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK, 1); break;
-            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK, 2); break;
+            case 7: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK, 2); break;
+            case 8: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_MEMORY, 1); break;
+            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_MEMORY, 2); break;
         }
 #undef ZKM_LAUNCH_QUOTIENT
         ZKM_HIP_CHECK(hipGetLastError());
@@ -757,26 +847,34 @@ struct fri_layer {
 };
 
 static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
-                               const zkm_batch* trace_batch, const uint64_t* aux, size_t A, const zkm_ctl_table* ctl_table,
-                               const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t Z, zkm_challenger* ch, uint64_t* proof,
-                               const zkm_batch* aux_batch_in = nullptr, const zkm_batch* quot_batch_in = nullptr) {
+                               const zkm_batch* trace_batch, const uint64_t* aux, size_t A_ctl, const zkm_ctl_table* ctl_table,
+                               const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t Z, const uint64_t* lookup_challenges,
+                               zkm_challenger* ch, uint64_t* proof, const zkm_batch* aux_batch_in = nullptr,
+                               const zkm_batch* quot_batch_in = nullptr) {
     // openings-only mode (zkm_prove_openings, BASELINE config 4): the three commitments exist already; the transcript
     // is compact -> zeta -> openings -> prove_openings
     const bool openings_only = aux_batch_in != nullptr;
     if (cfg->rate_bits != 2 || cfg->arity_bits < 2 || cfg->arity_bits > 6 || cfg->pow_bits == 0 || cfg->pow_bits > 32)
         throw std::runtime_error("zkm_prove_single_table: unsupported FRI configuration");
+    // the table's own lookup helper columns come first among the auxiliary polynomials (prover.rs:467-508)
+    const size_t NL = openings_only ? 0 : zkm_num_lookup_columns(table_id, cfg);
+    if (NL && !lookup_challenges) throw std::runtime_error("this table has lookups: lookup challenges are required");
+    if (NL && !trace) throw std::runtime_error("this table has lookups: the trace values are required to build their helper columns");
+    if (!NL) lookup_challenges = nullptr;
+    const size_t A = NL + A_ctl;
     proof_layout y;
     make_layout(y, cfg, log_n, W, A, Z);
     if (y.L > 8) throw std::runtime_error("too many FRI layers");
     size_t n = (size_t)1 << log_n, N = (size_t)1 << y.lde_bits;
-    size_t total_helpers = 0;
     if (openings_only) {
         if (Z > A) throw std::runtime_error("zkm_prove_openings: more CTL Zs than auxiliary polynomials");
-        total_helpers = A - Z;
     } else {
-        for (size_t i = 0; i < Z; i++) total_helpers += zs[i].num_helpers;
+        size_t ctl_helpers = 0;
+        for (size_t i = 0; i < Z; i++) ctl_helpers += zs[i].num_helpers;
+        if (ctl_helpers + Z != A_ctl) throw std::runtime_error("No CTL? aux column count does not match the CTL description");
     }
-    if (A == 0 || total_helpers + Z != A) throw std::runtime_error("No CTL? aux column count does not match the CTL description");  // prover.rs:509
+    if (A_ctl == 0) throw std::runtime_error("No CTL? aux column count does not match the CTL description");  // prover.rs:509
+    const size_t total_helpers = A - Z;  // index of the first CTL Z among the auxiliary polynomials
     ctl_dev_owner own;
     if (!openings_only) own.upload(c, ctl_table, zs, colset_ids, Z);
     if (ctl_table && !openings_only)
@@ -819,7 +917,23 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             // auxiliary commitment :511-522
             ab = new zkm_batch();
             ab->ctx = c; ab->ncols = A; ab->log_n = log_n; ab->rate_bits = cfg->rate_bits; ab->cap_height = cfg->cap_height;
-            zkm_batch_build(ab, aux, true);
+            if (NL) {
+                // "compute lookup helper columns" :475-493, then the CTL columns behind them
+                gl_t* d_all = (gl_t*)c->alloc(A * n * sizeof(gl_t));
+                scratch.push_back(d_all);
+                const gl_t* d_trace = trace;
+                if (!zkm_is_device_ptr(trace)) {
+                    gl_t* d = (gl_t*)c->alloc(W * n * sizeof(gl_t));
+                    scratch.push_back(d);
+                    ZKM_HIP_CHECK(hipMemcpyAsync(d, trace, W * n * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+                    d_trace = d;
+                }
+                zkm_table_lookup_columns_device(c, table_id, lookup_challenges, cfg->num_challenges, d_trace, n, d_all);
+                ZKM_HIP_CHECK(hipMemcpyAsync(d_all + NL * n, aux, A_ctl * n * sizeof(gl_t), hipMemcpyDefault, c->stream));
+                zkm_batch_build(ab, d_all, true);
+            } else {
+                zkm_batch_build(ab, aux, true);
+            }
             memcpy(caps + y.C * 4, ab->cap.data(), y.C * 4 * 8);
             zkm_challenger_observe(ch, caps + y.C * 4, y.C * 4);  // :525
             gl_t alphas[4];
@@ -828,7 +942,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             // quotient :543-587
             gl_t* d_quot = (gl_t*)c->alloc(cfg->num_challenges * 2 * n * sizeof(gl_t));
             scratch.push_back(d_quot);
-            quotient_device(c, table_id, tb, ab, own, alphas, cfg->num_challenges, d_quot);
+            quotient_device(c, table_id, tb, ab, own, lookup_challenges, alphas, cfg->num_challenges, d_quot);
             qb = new zkm_batch();
             qb->ctx = c; qb->ncols = y.Q; qb->log_n = log_n; qb->rate_bits = cfg->rate_bits; qb->cap_height = cfg->cap_height;
             zkm_batch_build(qb, d_quot, false);  // chunks [q0_lo, q0_hi, q1_lo, q1_hi] == d_quot viewed as Q columns of n
@@ -1046,12 +1160,13 @@ static std::vector<zkm_ctl_z> fake_zs(const uint32_t* num_helpers, size_t n) {
 
 int zkm_prove_single_table_ctl(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t ncols, unsigned log_n,
                                const zkm_batch* trace_batch, const uint64_t* aux, size_t naux, const zkm_ctl_table* table,
-                               const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, zkm_challenger* challenger,
-                               uint64_t* proof_out, char** err) {
+                               const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, const uint64_t* lookup_challenges,
+                               zkm_challenger* challenger, uint64_t* proof_out, char** err) {
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         if (!trace && !trace_batch) throw std::runtime_error("zkm_prove_single_table: need trace values or a trace commitment");
-        prove_single_table(c, table_id, cfg, trace, ncols, log_n, trace_batch, aux, naux, table, zs, colset_ids, nzs, challenger, proof_out);
+        prove_single_table(c, table_id, cfg, trace, ncols, log_n, trace_batch, aux, naux, table, zs, colset_ids, nzs, lookup_challenges,
+                           challenger, proof_out);
     } catch (const std::exception& e) {
         return fail(err, e.what());
     }
@@ -1064,7 +1179,7 @@ int zkm_prove_openings(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch*
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         if (!trace_batch || !aux_batch || !quot_batch) throw std::runtime_error("zkm_prove_openings: three commitments are required");
         prove_single_table(c, -1, cfg, nullptr, trace_batch->ncols, trace_batch->log_n, trace_batch, nullptr, aux_batch->ncols, nullptr,
-                           nullptr, nullptr, nctl_zs, challenger, proof_out, aux_batch, quot_batch);
+                           nullptr, nullptr, nctl_zs, nullptr, challenger, proof_out, aux_batch, quot_batch);
     } catch (const std::exception& e) {
         return fail(err, e.what());
     }
@@ -1077,7 +1192,7 @@ int zkm_prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg
     try {
         auto zs = fake_zs(num_helpers, nctl_zs);
         return zkm_prove_single_table_ctl(c, table_id, cfg, trace, ncols, log_n, trace_batch, aux, naux, nullptr, zs.data(), nullptr,
-                                          nctl_zs, challenger, proof_out, err);
+                                          nctl_zs, nullptr, challenger, proof_out, err);
     } catch (const std::exception& e) {
         return fail(err, e.what());
     }
@@ -1093,7 +1208,7 @@ int zkm_quotient(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_bat
         size_t words = nalphas * 2 * trace->n();
         bool dev = zkm_is_device_ptr(out_coeffs);
         gl_t* d = dev ? out_coeffs : (gl_t*)c->alloc(words * 8);
-        quotient_device(c, table_id, trace, aux, own, alphas, nalphas, d);
+        quotient_device(c, table_id, trace, aux, own, nullptr, alphas, nalphas, d);
         if (!dev) {
             ZKM_HIP_CHECK(hipMemcpyAsync(out_coeffs, d, words * 8, hipMemcpyDeviceToHost, c->stream));
             c->sync();

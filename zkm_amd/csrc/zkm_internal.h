@@ -134,6 +134,11 @@ void zkm_lde_bitrev(zkm_ctx*, const gl_t* coeffs, gl_t* out, size_t ncols, unsig
 void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values);
 void zkm_host_poseidon_permute(uint64_t st[12]);
 // ---- hash.hip (LogicStark witness)
+// ---- tables' own logUp lookups (core.hip: definitions; ctl.hip: helper columns)
+struct zkm_table_lookup { uint32_t ncols; const uint32_t* cols; uint32_t table_col, freq_col; };
+const zkm_table_lookup* zkm_table_lookups(int table_id, size_t* n);
+void zkm_table_lookup_columns_device(zkm_ctx* c, int table_id, const uint64_t* challenges, size_t nch, const gl_t* d_trace, size_t n,
+                                     gl_t* d_out);
 void zkm_launch_keccak_trace(zkm_ctx* c, const uint64_t* d_inputs, const uint64_t* d_ts, size_t nperms, size_t n, gl_t* out);
 void zkm_launch_logic_trace(zkm_ctx* c, const uint32_t* d_ops, size_t nops, size_t n, gl_t* out, int* d_bad);
 

@@ -8,8 +8,8 @@ include/zkm_hip.h); mirrors
 """
 from .ctl import CtlTable
 
-TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK = 0, 1, 2, 3
-WIDTH = {TABLE_POSEIDON: 262, TABLE_LOGIC: 69, TABLE_KECCAK_SPONGE: 470, TABLE_KECCAK: 2431}
+TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY = 0, 1, 2, 3, 4
+WIDTH = {TABLE_POSEIDON: 262, TABLE_LOGIC: 69, TABLE_KECCAK_SPONGE: 470, TABLE_KECCAK: 2431, TABLE_MEMORY: 13}
 
 # LogicStark columns (logic.rs:25-50)
 LOGIC_IS_AND, LOGIC_IS_OR, LOGIC_IS_XOR, LOGIC_IS_NOR = 0, 1, 2, 3
@@ -18,7 +18,11 @@ OP_AND, OP_OR, OP_XOR, OP_NOR = 0, 1, 2, 3
 
 # KeccakSpongeStark columns (keccak_sponge/columns.rs:19-70)
 KS_FULL, KS_FINAL_LEN, KS_ORIG_RATE, KS_BLOCK, KS_XORED = 0, 40, 176, 226, 362
+KS_CONTEXT, KS_SEGMENT, KS_VIRT = 1, 2, 3
 KS_TIMESTAMP, KS_ORIG_CAP, KS_PARTIAL, KS_DIGEST = 37, 210, 396, 438
+
+# MemoryStark columns (memory/columns.rs)
+MEM_FILTER, MEM_TIMESTAMP, MEM_IS_READ, MEM_CONTEXT, MEM_SEGMENT, MEM_VIRTUAL, MEM_VALUE = 0, 1, 2, 3, 4, 5, 6
 KECCAK_RATE_BYTES, KECCAK_RATE_U32S = 136, 34
 
 # KeccakStark registers (keccak/columns.rs:7-134)
@@ -113,3 +117,31 @@ def ctl_keccak_inputs(sponge_index, keccak_index, sponge_ctl, keccak_ctl):
 def ctl_keccak_outputs(sponge_index, keccak_index, sponge_ctl, keccak_ctl):
     """all_stark::ctl_keccak_outputs() (all_stark.rs:228-240)."""
     return [(sponge_index, keccak_sponge_looking_keccak_outputs(sponge_ctl))], (keccak_index, keccak_ctl_data_outputs(keccak_ctl))
+
+
+def memory_ctl_data(t: CtlTable):
+    """memory_stark::ctl_data() with ctl_filter() (memory_stark.rs:32-43; VALUE_LIMBS = 1)."""
+    return t.singles_set([MEM_IS_READ, MEM_CONTEXT, MEM_SEGMENT, MEM_VIRTUAL, MEM_VALUE, MEM_TIMESTAMP], filter_col=MEM_FILTER)
+
+
+def keccak_sponge_looking_memory(t: CtlTable, i):
+    """keccak_sponge_stark::ctl_looking_memory(i) with ctl_looking_memory_filter(i) (:91-124, :174-186): byte i of the block
+    is read as part of the big-endian word at virt[i / 4]."""
+    start = (i // 4) * 4
+    first = t.constant(1)                                                      # is_read
+    t.single(KS_CONTEXT)
+    t.single(KS_SEGMENT)
+    t.single(KS_VIRT + i // 4)
+    t.le_bytes([KS_BLOCK + start + 3, KS_BLOCK + start + 2, KS_BLOCK + start + 1, KS_BLOCK + start])
+    t.single(KS_TIMESTAMP)
+    if i == KECCAK_RATE_BYTES - 1:
+        f = t.single(KS_FULL)
+    else:
+        f = t.sum([KS_FULL] + list(range(KS_FINAL_LEN + i + 1, KS_FINAL_LEN + KECCAK_RATE_BYTES)))
+    return t.colset(range(first, first + 6), filter_constants=[f])
+
+
+def ctl_memory_keccak_sponge(sponge_index, memory_index, sponge_ctl, memory_ctl):
+    """The KeccakSponge part of all_stark::ctl_memory() (all_stark.rs:479-542): 136 looking column sets."""
+    looking = [(sponge_index, keccak_sponge_looking_memory(sponge_ctl, i)) for i in range(KECCAK_RATE_BYTES)]
+    return looking, (memory_index, memory_ctl_data(memory_ctl))
