@@ -121,6 +121,42 @@ def derive_fast(rc, circ, diag):
     return first_round, scalars, vs, w_hats, init
 
 
+def derive_fused(rc, circ, diag):
+    """Tables for the fused partial rounds of the HIP permutation (poseidon_dev.h): the linear layers of three
+    consecutive rounds are applied as ONE matrix M^3 whose entries are still small integers (< 2^25, NOT reduced
+    mod p), so a row is 24 multiply-adds of 32-bit halves into two 64-bit accumulators.  Groups: 7 x 3 MDS layers
+    (rounds 3..23) and one group of 2 (rounds 24, 25).  Per group: c1 / c2 = the constants added to lane 0 after the
+    first / second layer, c3 = the constant vector after the last layer (canonical mod p)."""
+    M = [[circ[(c - r) % WIDTH] + (diag[r] if r == c else 0) for c in range(WIDTH)] for r in range(WIDTH)]
+    imul = lambda a, b: [[sum(a[i][t] * b[t][j] for t in range(WIDTH)) for j in range(WIDTH)] for i in range(WIDTH)]
+    M2 = imul(M, M)
+    M3 = imul(M2, M)
+    for i in range(WIDTH):  # 64-bit accumulators must not overflow: (row sum + delta coefficients) * (2^32 - 1) < 2^64
+        assert sum(M3[i]) + M2[i][0] + M[i][0] < 1 << 32 and sum(M2[i]) + M[i][0] < 1 << 32
+    K = lambda r: rc[r * WIDTH:(r + 1) * WIDTH]
+    add = lambda a, b: [(x + y) % P for x, y in zip(a, b)]
+    c1, c2, c3 = [], [], []
+    for g in range(7):
+        rho = 3 + 3 * g
+        k1, k2, k3 = K(rho + 1), K(rho + 2), K(rho + 3)
+        c1.append(k1[0])
+        c2.append(add(mat_vec(M, k1), k2)[0])
+        c3.append(add(add(mat_vec(M2, k1), mat_vec(M, k2)), k3))
+    k1, k2 = K(25), K(26)
+    c1.append(k1[0])
+    c2.append(0)
+    c3.append(add(mat_vec(M, k1), k2))
+    return M2, M3, c1, c2, c3
+
+
+def fmt32(name, rows):
+    lines = ["ZKM_CONSTEXPR uint32_t %s[%d][%d] = {" % (name, len(rows), len(rows[0]))]
+    for r in rows:
+        lines.append("    {" + ", ".join("%du" % x for x in r) + "},")
+    lines.append("};")
+    return "\n".join(lines)
+
+
 def fmt(name, dims, flat, per_line=4):
     lines = ["ZKM_CONST uint64_t %s%s = {" % (name, "".join("[%d]" % d for d in dims))]
     if len(dims) == 2:
@@ -158,6 +194,7 @@ def main():
         assert flat(init) == ref["FAST_PARTIAL_ROUND_INITIAL_MATRIX"], "initial matrix mismatch"
         checked = True
 
+    M2, M3, fc1, fc2, fc3 = derive_fused(rc, circ, diag)
     body = [
         "/* Goldilocks Poseidon (width 12, 4+22+4 rounds, x^7) parameter tables.",
         " * GENERATED by tools/gen_poseidon_constants.py -- do not edit.",
@@ -177,6 +214,16 @@ def main():
         fmt("ZKM_POSEIDON_FAST_VS", [N_PARTIAL, WIDTH - 1], [x for r in vs for x in r], 4),
         fmt("ZKM_POSEIDON_FAST_W_HATS", [N_PARTIAL, WIDTH - 1], [x for r in w_hats for x in r], 4),
         fmt("ZKM_POSEIDON_FAST_INIT", [WIDTH - 1, WIDTH - 1], [x for r in init for x in r], 4),
+        "/* fused partial rounds (tools/gen_poseidon_constants.py derive_fused): integer powers of the MDS matrix and the",
+        " * per-group constants; ZKM_CONSTEXPR = compile-time table (`static constexpr` in C++, `static const` in C) */",
+        "#ifndef ZKM_CONSTEXPR",
+        "#define ZKM_CONSTEXPR static const",
+        "#endif",
+        fmt32("ZKM_POSEIDON_M2", M2),
+        fmt32("ZKM_POSEIDON_M3", M3),
+        fmt("ZKM_POSEIDON_FUSED_C1", [8], fc1),
+        fmt("ZKM_POSEIDON_FUSED_C2", [8], fc2),
+        fmt("ZKM_POSEIDON_FUSED_C3", [8, WIDTH], [x for r in fc3 for x in r], 4),
         "",
     ]
     text = "\n".join(body)

@@ -15,11 +15,24 @@
 // folded into the MDS accumulators before the single reduction.  Algebraically identical, so outputs are
 // bit-exact (pinned by the plonky2 test vectors and by naive == fast in the oracle).
 //
+// Partial rounds, fused three at a time.  Between two lane-0 s-boxes the state only goes through linear maps, and the
+// integer powers of the MDS matrix stay small: the entries of M^3 are < 2^21 and its row sums < 2^25, so a row of M^3
+// applied to 32-bit halves still fits the same pair of 64-bit accumulators (24 multiply-adds) as a row of M.  With
+// delta_k = sbox(a_k[0]) - a_k[0] the three rounds
+//     a1 = M x + K1,   a2 = M (a1 + e0 delta1) + K2,   a3 = M (a2 + e0 delta2) + K3
+// become  a1[0] = M[0,:] x + c1,   a2[0] = M^2[0,:] x + M[0,0] delta1 + c2,
+//         a3 = M^3 x + M^2[:,0] delta1 + M[:,0] delta2 + c3          (c1, c2, c3 precomputed from the round constants)
+// i.e. two single-row products and ONE dense product instead of three dense products: 23 linear layers (round 3's
+// MDS and the 22 partial rounds) cost 8 dense products.  Tables: tools/gen_poseidon_constants.py derive_fused (which
+// also asserts the no-overflow bound).  Algebraically identical to the reference's rounds, so outputs are bit-exact.
+//
 // The state is kept "loose" (any uint64 representing its residue) between rounds and canonicalised once
 // on exit -- see gl_dev.h for the overflow arguments of every loose primitive.
 #pragma once
 #include "gl_dev.h"
 
+#undef ZKM_CONSTEXPR
+#define ZKM_CONSTEXPR static constexpr
 namespace pc_host {
 #undef ZKM_CONST
 #define ZKM_CONST static const
@@ -33,6 +46,7 @@ namespace pc_dev {
 }  // namespace pc_dev
 #endif
 #undef ZKM_CONST
+#undef ZKM_CONSTEXPR
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PC pc_dev
@@ -90,12 +104,89 @@ GL_HD void poseidon_mds_add(uint64_t s[12], const uint64_t* add) {
 }
 GL_HD void poseidon_mds(uint64_t s[12]) { poseidon_mds_add<false>(s, nullptr); }
 
+// al + 2^32 ah + add -> loose, for al, ah < 2^63 (so the carry word is < 2^32 and 2^64 == EPS needs one multiply-free step)
+GL_HD uint64_t poseidon_fold(uint64_t al, uint64_t ah, uint64_t add) {
+    uint64_t low = al + (ah << 32);
+    uint64_t high = (ah >> 32) + (low < al ? 1 : 0);
+    uint64_t t = low + add;
+    high += t < low ? 1 : 0;
+    uint64_t t1 = (high << 32) - high;  // high * EPS, high < 2^32
+    uint64_t r = t + t1;
+    if (r < t1) r += GL_EPS;  // wrapped once: r < t1 <= 2^64 - 2^33 + 1, adding EPS cannot wrap again
+    return r;
+}
+// sbox(a) - a mod p, loose -> loose
+GL_HD uint64_t poseidon_sbox_delta(uint64_t a) {
+    uint64_t neg = GL_P - gl_canon(a);  // in (0, p]
+    return gl_add_loose(poseidon_sbox7(a), neg);
+}
+GL_HD constexpr uint32_t poseidon_m1(int i, int j) {
+    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    return C[(j - i + 12) % 12] + ((i == 0 && j == 0) ? 8u : 0u);
+}
+
+// T linear layers (T = 3 or 2) with the T - 1 lane-0 s-boxes between them; c3 = constants after the last layer.
+template <int T>
+GL_HD void poseidon_partial_group(uint64_t s[12], uint64_t c1, uint64_t c2, const uint64_t* c3) {
+    uint32_t lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        lo[i] = (uint32_t)s[i];
+        hi[i] = (uint32_t)(s[i] >> 32);
+    }
+    uint64_t al = 0, ah = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        al += (uint64_t)lo[j] * poseidon_m1(0, j);
+        ah += (uint64_t)hi[j] * poseidon_m1(0, j);
+    }
+    const uint64_t d1 = poseidon_sbox_delta(poseidon_fold(al, ah, c1));
+    const uint32_t d1l = (uint32_t)d1, d1h = (uint32_t)(d1 >> 32);
+    uint32_t d2l = 0, d2h = 0;
+    POSEIDON_SCHED_FENCE();
+    if (T == 3) {
+        al = (uint64_t)d1l * poseidon_m1(0, 0);
+        ah = (uint64_t)d1h * poseidon_m1(0, 0);
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            al += (uint64_t)lo[j] * PC::ZKM_POSEIDON_M2[0][j];
+            ah += (uint64_t)hi[j] * PC::ZKM_POSEIDON_M2[0][j];
+        }
+        const uint64_t d2 = poseidon_sbox_delta(poseidon_fold(al, ah, c2));
+        d2l = (uint32_t)d2;
+        d2h = (uint32_t)(d2 >> 32);
+        POSEIDON_SCHED_FENCE();
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        if (T == 3) {
+            al = (uint64_t)d1l * PC::ZKM_POSEIDON_M2[i][0] + (uint64_t)d2l * poseidon_m1(i, 0);
+            ah = (uint64_t)d1h * PC::ZKM_POSEIDON_M2[i][0] + (uint64_t)d2h * poseidon_m1(i, 0);
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                al += (uint64_t)lo[j] * PC::ZKM_POSEIDON_M3[i][j];
+                ah += (uint64_t)hi[j] * PC::ZKM_POSEIDON_M3[i][j];
+            }
+        } else {
+            al = (uint64_t)d1l * poseidon_m1(i, 0);
+            ah = (uint64_t)d1h * poseidon_m1(i, 0);
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                al += (uint64_t)lo[j] * PC::ZKM_POSEIDON_M2[i][j];
+                ah += (uint64_t)hi[j] * PC::ZKM_POSEIDON_M2[i][j];
+            }
+        }
+        s[i] = poseidon_fold(al, ah, c3[i]);
+        if ((i & 1) == 1) POSEIDON_SCHED_FENCE();
+    }
+}
+
 // In: any uint64 words (loose).  Out: canonical.
 GL_HD void poseidon_permute(uint64_t s[12]) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_add_loose(s[i], PC::ZKM_POSEIDON_RC[i]);
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 3; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             s[i] = poseidon_sbox7(s[i]);
@@ -103,11 +194,17 @@ GL_HD void poseidon_permute(uint64_t s[12]) {
         }
         poseidon_mds_add<true>(s, &PC::ZKM_POSEIDON_RC[(r + 1) * 12]);
     }
-#pragma unroll 1
-    for (int r = 4; r < 26; r++) {
-        s[0] = poseidon_sbox7(s[0]);
-        poseidon_mds_add<true>(s, &PC::ZKM_POSEIDON_RC[(r + 1) * 12]);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {  // round 3's s-boxes; its MDS opens the first fused group
+        s[i] = poseidon_sbox7(s[i]);
+        if ((i & 1) == 1) POSEIDON_SCHED_FENCE();
     }
+#pragma unroll 1
+    for (int g = 0; g < 7; g++) {  // MDS of rounds 3g+3 .. 3g+5 and the s-boxes of rounds 3g+4, 3g+5; then round 3g+6's
+        poseidon_partial_group<3>(s, PC::ZKM_POSEIDON_FUSED_C1[g], PC::ZKM_POSEIDON_FUSED_C2[g], PC::ZKM_POSEIDON_FUSED_C3[g]);
+        s[0] = poseidon_sbox7(s[0]);
+    }
+    poseidon_partial_group<2>(s, PC::ZKM_POSEIDON_FUSED_C1[7], 0, PC::ZKM_POSEIDON_FUSED_C3[7]);  // MDS of rounds 24, 25
 #pragma unroll 1
     for (int r = 26; r < 29; r++) {
 #pragma unroll
