@@ -1,0 +1,67 @@
+// tools/ubench3.hip -- x^7 s-box throughput for different 64x64 modular-multiply formulations (development aid).
+// 12 independent chains per lane, as in the Poseidon full rounds.  Prints ms and s-boxes/s.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../zkm_amd/csrc/gl_dev.h"
+#define ITERS 256
+
+__device__ __forceinline__ uint64_t mul_old(uint64_t a, uint64_t b) { return gl_reduce128(a * b, __umul64hi(a, b)); }
+__device__ __forceinline__ uint64_t mul_new(uint64_t a, uint64_t b) { return gl_mul_loose(a, b); }
+__device__ __forceinline__ uint64_t sqr_new(uint64_t a) { return gl_mul_loose(a, a); }
+// kA: chained mads with zero-extended addends
+__device__ __forceinline__ uint64_t mul_a(uint64_t a, uint64_t b) {
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint64_t p00 = (uint64_t)al * bl;
+    uint64_t t = (uint64_t)al * bh + (p00 >> 32);
+    uint64_t u = (uint64_t)ah * bl + (uint32_t)t;
+    uint64_t hi = (uint64_t)ah * bh + ((t >> 32) + (u >> 32));
+    uint64_t lo = (u << 32) | (uint32_t)p00;
+    return gl_reduce128(lo, hi);
+}
+template <int V>
+__device__ __forceinline__ uint64_t sbox(uint64_t x) {
+    if (V == 0) { uint64_t x2 = mul_old(x, x), x4 = mul_old(x2, x2), x3 = mul_old(x, x2); return mul_old(x3, x4); }
+    if (V == 1) { uint64_t x2 = mul_new(x, x), x4 = mul_new(x2, x2), x3 = mul_new(x, x2); return mul_new(x3, x4); }
+    if (V == 2) { uint64_t x2 = sqr_new(x), x4 = sqr_new(x2), x3 = mul_new(x, x2); return mul_new(x3, x4); }
+    { uint64_t x2 = mul_a(x, x), x4 = mul_a(x2, x2), x3 = mul_a(x, x2); return mul_a(x3, x4); }
+}
+template <int V, bool FENCE>
+__global__ __launch_bounds__(256) void k(uint64_t* out, uint64_t seed) {
+    uint32_t lane = threadIdx.x + blockIdx.x * blockDim.x;
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = seed * (lane + 3) + i;
+#pragma unroll 1
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            s[i] = sbox<V>(s[i]);
+            if (FENCE && (i & 1)) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc ^= s[i];
+    out[lane] = acc;
+}
+template <int V, bool FENCE> static void run(const char* name, uint64_t* d) {
+    const int blocks = 256 * 16, threads = 256;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<V, FENCE>), dim3(blocks), dim3(threads), 0, 0, d, 0x1234567ULL); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 4; r++) hipLaunchKernelGGL((k<V, FENCE>), dim3(blocks), dim3(threads), 0, 0, d, 0x1234567ULL);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 4;
+    double n = (double)blocks * threads * ITERS * 12;
+    uint64_t h; hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    printf("%-28s %8.3f ms  %7.2f G sbox/s  (check %016llx)\n", name, ms, n / ms / 1e6, (unsigned long long)h);
+}
+int main() {
+    uint64_t* d; hipMalloc(&d, 256 * 16 * 256 * 8);
+    run<0, true>("old (a*b, umul64hi) fence", d); run<0, false>("old nofence", d);
+    run<1, true>("new shared products fence", d); run<1, false>("new nofence", d);
+    run<2, true>("new + squarings fence", d); run<2, false>("new + squarings nofence", d);
+    run<3, true>("chained zext addends fence", d); run<3, false>("chained nofence", d);
+    return 0;
+}

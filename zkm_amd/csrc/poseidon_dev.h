@@ -64,6 +64,17 @@ GL_HD uint64_t poseidon_sbox7(uint64_t x) {
     return gl_mul_loose(x3, x4);
 }
 
+// al + 2^32 ah + add -> loose, for al, ah < 2^63 (so the carry word is < 2^32 and 2^64 == EPS needs one multiply-free step)
+GL_HD uint64_t poseidon_fold(uint64_t al, uint64_t ah, uint64_t add) {
+    uint64_t low = al + (ah << 32);
+    uint64_t high = (ah >> 32) + (low < al ? 1 : 0);
+    uint64_t t = low + add;
+    high += t < low ? 1 : 0;
+    uint64_t t1 = (high << 32) - high;  // high * EPS, high < 2^32
+    uint64_t r = t + t1;
+    if (r < t1) r += GL_EPS;  // wrapped once: r < t1 <= 2^64 - 2^33 + 1, adding EPS cannot wrap again
+    return r;
+}
 // Circulant MDS (first row CIRC = {17,15,41,16,2,28,13,13,39,18,34,20}, plus 8 on the (0,0) entry):
 //   out[r] = sum_i CIRC[i] * s[(i+r)%12] + [r==0] 8 s[0] + add[r]
 // Each state word is split into 32-bit halves, the halves are accumulated in two 64-bit sums (each
@@ -90,31 +101,12 @@ GL_HD void poseidon_mds_add(uint64_t s[12], const uint64_t* add) {
             al += (uint64_t)lo[0] * 8u;
             ah += (uint64_t)hi[0] * 8u;
         }
-        // value = al + ah * 2^32  (< 2^74): low 64 bits and the carry-out word
-        uint64_t low = al + (ah << 32);
-        uint64_t high = (ah >> 32) + (low < al ? 1 : 0);
-        if (ADD) {
-            uint64_t t = low + add[r];
-            high += t < low ? 1 : 0;
-            low = t;
-        }
-        s[r] = gl_reduce128(low, high);
+        s[r] = poseidon_fold(al, ah, ADD ? add[r] : 0);  // al + 2^32 ah + add < 2^74, reduced once
         if ((r & 3) == 3) POSEIDON_SCHED_FENCE();
     }
 }
 GL_HD void poseidon_mds(uint64_t s[12]) { poseidon_mds_add<false>(s, nullptr); }
 
-// al + 2^32 ah + add -> loose, for al, ah < 2^63 (so the carry word is < 2^32 and 2^64 == EPS needs one multiply-free step)
-GL_HD uint64_t poseidon_fold(uint64_t al, uint64_t ah, uint64_t add) {
-    uint64_t low = al + (ah << 32);
-    uint64_t high = (ah >> 32) + (low < al ? 1 : 0);
-    uint64_t t = low + add;
-    high += t < low ? 1 : 0;
-    uint64_t t1 = (high << 32) - high;  // high * EPS, high < 2^32
-    uint64_t r = t + t1;
-    if (r < t1) r += GL_EPS;  // wrapped once: r < t1 <= 2^64 - 2^33 + 1, adding EPS cannot wrap again
-    return r;
-}
 // sbox(a) - a mod p, loose -> loose
 GL_HD uint64_t poseidon_sbox_delta(uint64_t a) {
     uint64_t neg = GL_P - gl_canon(a);  // in (0, p]
