@@ -19,8 +19,39 @@ __device__ __forceinline__ uint64_t mul_a(uint64_t a, uint64_t b) {
     uint64_t lo = (u << 32) | (uint32_t)p00;
     return gl_reduce128(lo, hi);
 }
+__device__ __forceinline__ uint64_t red4(uint64_t lo, uint64_t hi) {
+    uint64_t hi_hi = hi >> 32; uint32_t hi_lo = (uint32_t)hi;
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= GL_EPS;
+    uint64_t r = (uint64_t)hi_lo * 0xFFFFFFFFu + t0;
+    if (r < t0) r += GL_EPS;
+    return r;
+}
+__device__ __forceinline__ uint64_t red5(uint64_t lo, uint64_t hi) {
+    uint64_t hi_hi = hi >> 32; uint32_t hi_lo = (uint32_t)hi;
+    uint64_t t0 = lo - hi_hi;
+    t0 -= (lo < hi_hi) ? GL_EPS : 0;
+    uint64_t r = (uint64_t)hi_lo * 0xFFFFFFFFu + t0;
+    r += (r < t0) ? GL_EPS : 0;
+    return r;
+}
+// borrow detected on the high word only: lo < hi_hi (< 2^32) iff lo_hi == 0 && lo_lo < hi_hi
+__device__ __forceinline__ uint64_t red6(uint64_t lo, uint64_t hi) {
+    uint32_t h1 = (uint32_t)(hi >> 32), h0 = (uint32_t)hi;
+    uint64_t t0 = lo - h1;
+    uint32_t m = (uint32_t)((int32_t)((uint32_t)(t0 >> 32) & ~(uint32_t)(lo >> 32)) >> 31);  // borrow <=> high word went 0 -> 0xFFFFFFFF
+    t0 -= m;   // m = 0xFFFFFFFF = EPS on borrow
+    uint64_t r = (uint64_t)h0 * 0xFFFFFFFFu + t0;
+    r += (r < t0) ? GL_EPS : 0;
+    return r;
+}
+template <int R> __device__ __forceinline__ uint64_t mul_r(uint64_t a, uint64_t b) {
+    uint64_t lo, hi; gl_mul_wide(a, b, lo, hi);
+    return R == 4 ? red4(lo, hi) : R == 5 ? red5(lo, hi) : red6(lo, hi);
+}
 template <int V>
 __device__ __forceinline__ uint64_t sbox(uint64_t x) {
+    if (V >= 4) { uint64_t x2 = mul_r<V>(x, x), x4 = mul_r<V>(x2, x2), x3 = mul_r<V>(x, x2); return mul_r<V>(x3, x4); }
     if (V == 0) { uint64_t x2 = mul_old(x, x), x4 = mul_old(x2, x2), x3 = mul_old(x, x2); return mul_old(x3, x4); }
     if (V == 1) { uint64_t x2 = mul_new(x, x), x4 = mul_new(x2, x2), x3 = mul_new(x, x2); return mul_new(x3, x4); }
     if (V == 2) { uint64_t x2 = sqr_new(x), x4 = sqr_new(x2), x3 = mul_new(x, x2); return mul_new(x3, x4); }
@@ -63,5 +94,6 @@ int main() {
     run<1, true>("new shared products fence", d); run<1, false>("new nofence", d);
     run<2, true>("new + squarings fence", d); run<2, false>("new + squarings nofence", d);
     run<3, true>("chained zext addends fence", d); run<3, false>("chained nofence", d);
+    run<4, true>("chained + mad-fused reduce", d); run<5, true>("chained + select-EPS reduce", d); run<6, true>("chained + sign-mask borrow", d);
     return 0;
 }

@@ -50,14 +50,18 @@ GL_HD uint64_t gl_add_loose(uint64_t a, uint64_t b) {
     return s;
 }
 
-// 128-bit (hi:lo) -> loose.  Standard Goldilocks reduction: 2^64 == 2^32 - 1, 2^96 == -1.
+// 128-bit (hi:lo) -> loose.  Standard Goldilocks reduction: 2^64 == 2^32 - 1, 2^96 == -1, written for gfx950 issue costs
+// (tools/ubench3.hip: compare + select chains are the expensive part of a modmul, moves and plain 32-bit ops are cheap):
+//   t0 = lo - h1           borrow <=> lo < h1 < 2^32 <=> the high word went from 0 to 0xFFFFFFFF; the borrow mask
+//                          (0xFFFFFFFF == EPS) is taken from the sign of (t0_hi & ~lo_hi) and subtracted: t0 in (p - 2^32, p)
+//   r  = h0 * EPS + t0     one multiply-add; if it wrapped, r < 2^64 - 2^33 + 1 and adding EPS cannot wrap again
 GL_HD uint64_t gl_reduce128(uint64_t lo, uint64_t hi) {
-    uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
-    uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS;  // borrow: t0 = lo - hi_hi + p, in (p - 2^32, p)
-    uint64_t t1 = (hi_lo << 32) - hi_lo;  // hi_lo * EPS <= (2^32-1)^2
-    uint64_t r = t0 + t1;
-    if (r < t1) r += GL_EPS;  // wrapped: r < 2^64 - 2^33 + 1, adding EPS cannot wrap again
+    uint32_t h1 = (uint32_t)(hi >> 32), h0 = (uint32_t)hi;
+    uint64_t t0 = lo - h1;
+    uint32_t m = (uint32_t)((int32_t)((uint32_t)(t0 >> 32) & ~(uint32_t)(lo >> 32)) >> 31);
+    t0 -= m;
+    uint64_t r = (uint64_t)h0 * 0xFFFFFFFFu + t0;
+    r += (r < t0) ? GL_EPS : 0;
     return r;
 }
 
