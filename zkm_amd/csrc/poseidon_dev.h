@@ -64,22 +64,23 @@ GL_HD uint64_t poseidon_sbox7(uint64_t x) {
     return gl_mul_loose(x3, x4);
 }
 
-// al + 2^32 ah + add -> loose, for al, ah < 2^63 (so the carry word is < 2^32 and 2^64 == EPS needs one multiply-free step)
-GL_HD uint64_t poseidon_fold(uint64_t al, uint64_t ah, uint64_t add) {
-    uint64_t low = al + (ah << 32);
-    uint64_t high = (ah >> 32) + (low < al ? 1 : 0);
-    uint64_t t = low + add;
-    high += t < low ? 1 : 0;
-    uint64_t t1 = (high << 32) - high;  // high * EPS, high < 2^32
-    uint64_t r = t + t1;
-    if (r < t1) r += GL_EPS;  // wrapped once: r < t1 <= 2^64 - 2^33 + 1, adding EPS cannot wrap again
-    return r;
+// al + 2^32 ah -> loose, for al, ah < 2^59.  No compares: the carries are produced as VALUES.
+//   2^32 ah = 2^64 ah_hi + 2^32 ah_lo == EPS ah_hi + 2^32 ah_lo;   s1 = al + EPS ah_hi < 2^60 (one multiply-add);
+//   hs = s1_hi + ah_lo is a 33-bit number whose top bit c again weighs 2^64 == EPS;  result = (hs_lo32 : s1_lo) + EPS c,
+//   which cannot wrap (c = 1 implies hs_lo32 < 2^28).
+// Additive constants are folded in by starting the accumulators at (const_lo, const_hi).
+GL_HD uint64_t poseidon_fold(uint64_t al, uint64_t ah) {
+    uint64_t s1 = (uint64_t)(uint32_t)(ah >> 32) * 0xFFFFFFFFu + al;
+    uint64_t hs = (uint64_t)(uint32_t)ah + (s1 >> 32);
+    uint64_t base = (hs << 32) | (uint32_t)s1;
+    return (uint64_t)(uint32_t)(hs >> 32) * 0xFFFFFFFFu + base;
 }
+
 // Circulant MDS (first row CIRC = {17,15,41,16,2,28,13,13,39,18,34,20}, plus 8 on the (0,0) entry):
 //   out[r] = sum_i CIRC[i] * s[(i+r)%12] + [r==0] 8 s[0] + add[r]
-// Each state word is split into 32-bit halves, the halves are accumulated in two 64-bit sums (each
-// < 2^32 * 264 < 2^41), recombined to a < 2^74 value, the additive constant (next round's constant) is
-// added to that value, and it is reduced once.  Inputs loose, outputs loose.
+// Each state word is split into 32-bit halves, the halves are accumulated in two 64-bit sums that start at the halves of
+// the additive constant (next round's constant) and stay < 2^32 * 265 < 2^41, and the pair is folded once (poseidon_fold).
+// Inputs loose, outputs loose.
 template <bool ADD>
 GL_HD void poseidon_mds_add(uint64_t s[12], const uint64_t* add) {
     uint32_t lo[12], hi[12];
@@ -91,7 +92,7 @@ GL_HD void poseidon_mds_add(uint64_t s[12], const uint64_t* add) {
     constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
 #pragma unroll
     for (int r = 0; r < 12; r++) {
-        uint64_t al = 0, ah = 0;
+        uint64_t al = ADD ? (uint64_t)(uint32_t)add[r] : 0, ah = ADD ? add[r] >> 32 : 0;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             al += (uint64_t)lo[(i + r) % 12] * C[i];
@@ -101,7 +102,7 @@ GL_HD void poseidon_mds_add(uint64_t s[12], const uint64_t* add) {
             al += (uint64_t)lo[0] * 8u;
             ah += (uint64_t)hi[0] * 8u;
         }
-        s[r] = poseidon_fold(al, ah, ADD ? add[r] : 0);  // al + 2^32 ah + add < 2^74, reduced once
+        s[r] = poseidon_fold(al, ah);
         if ((r & 3) == 3) POSEIDON_SCHED_FENCE();
     }
 }
@@ -126,25 +127,25 @@ GL_HD void poseidon_partial_group(uint64_t s[12], uint64_t c1, uint64_t c2, cons
         lo[i] = (uint32_t)s[i];
         hi[i] = (uint32_t)(s[i] >> 32);
     }
-    uint64_t al = 0, ah = 0;
+    uint64_t al = (uint32_t)c1, ah = c1 >> 32;
 #pragma unroll
     for (int j = 0; j < 12; j++) {
         al += (uint64_t)lo[j] * poseidon_m1(0, j);
         ah += (uint64_t)hi[j] * poseidon_m1(0, j);
     }
-    const uint64_t d1 = poseidon_sbox_delta(poseidon_fold(al, ah, c1));
+    const uint64_t d1 = poseidon_sbox_delta(poseidon_fold(al, ah));
     const uint32_t d1l = (uint32_t)d1, d1h = (uint32_t)(d1 >> 32);
     uint32_t d2l = 0, d2h = 0;
     POSEIDON_SCHED_FENCE();
     if (T == 3) {
-        al = (uint64_t)d1l * poseidon_m1(0, 0);
-        ah = (uint64_t)d1h * poseidon_m1(0, 0);
+        al = (uint64_t)d1l * poseidon_m1(0, 0) + (uint32_t)c2;
+        ah = (uint64_t)d1h * poseidon_m1(0, 0) + (c2 >> 32);
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             al += (uint64_t)lo[j] * PC::ZKM_POSEIDON_M2[0][j];
             ah += (uint64_t)hi[j] * PC::ZKM_POSEIDON_M2[0][j];
         }
-        const uint64_t d2 = poseidon_sbox_delta(poseidon_fold(al, ah, c2));
+        const uint64_t d2 = poseidon_sbox_delta(poseidon_fold(al, ah));
         d2l = (uint32_t)d2;
         d2h = (uint32_t)(d2 >> 32);
         POSEIDON_SCHED_FENCE();
@@ -152,23 +153,23 @@ GL_HD void poseidon_partial_group(uint64_t s[12], uint64_t c1, uint64_t c2, cons
 #pragma unroll
     for (int i = 0; i < 12; i++) {
         if (T == 3) {
-            al = (uint64_t)d1l * PC::ZKM_POSEIDON_M2[i][0] + (uint64_t)d2l * poseidon_m1(i, 0);
-            ah = (uint64_t)d1h * PC::ZKM_POSEIDON_M2[i][0] + (uint64_t)d2h * poseidon_m1(i, 0);
+            al = (uint64_t)d1l * PC::ZKM_POSEIDON_M2[i][0] + (uint64_t)d2l * poseidon_m1(i, 0) + (uint32_t)c3[i];
+            ah = (uint64_t)d1h * PC::ZKM_POSEIDON_M2[i][0] + (uint64_t)d2h * poseidon_m1(i, 0) + (c3[i] >> 32);
 #pragma unroll
             for (int j = 0; j < 12; j++) {
                 al += (uint64_t)lo[j] * PC::ZKM_POSEIDON_M3[i][j];
                 ah += (uint64_t)hi[j] * PC::ZKM_POSEIDON_M3[i][j];
             }
         } else {
-            al = (uint64_t)d1l * poseidon_m1(i, 0);
-            ah = (uint64_t)d1h * poseidon_m1(i, 0);
+            al = (uint64_t)d1l * poseidon_m1(i, 0) + (uint32_t)c3[i];
+            ah = (uint64_t)d1h * poseidon_m1(i, 0) + (c3[i] >> 32);
 #pragma unroll
             for (int j = 0; j < 12; j++) {
                 al += (uint64_t)lo[j] * PC::ZKM_POSEIDON_M2[i][j];
                 ah += (uint64_t)hi[j] * PC::ZKM_POSEIDON_M2[i][j];
             }
         }
-        s[i] = poseidon_fold(al, ah, c3[i]);
+        s[i] = poseidon_fold(al, ah);
         if ((i & 1) == 1) POSEIDON_SCHED_FENCE();
     }
 }
