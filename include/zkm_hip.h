@@ -82,6 +82,21 @@ int zkm_keccakf_batch(zkm_ctx* ctx, uint64_t* states, size_t k, char** err);
 #define ZKM_POSEIDON_COLS 262
 int zkm_poseidon_trace(zkm_ctx* ctx, uint64_t seed, size_t num_perms, unsigned log_n, uint64_t* out_dev, char** err);
 
+/* PoseidonStark::generate_trace for explicit permutation inputs: inputs = num_perms x 12 field elements, one timestamp each
+ * (host or device); rows past num_perms are the default row (FILTER 0).  This is the table the PoseidonSponge rows look up
+ * (all_stark.rs:169-195). */
+int zkm_poseidon_trace_inputs(zkm_ctx* ctx, const uint64_t* inputs, const uint64_t* timestamps, size_t num_perms, unsigned log_n,
+                              uint64_t* out_dev, char** err);
+
+/* ------------------------------------------------------------------ N2: PoseidonSpongeStark witness
+ * PoseidonSpongeStark::generate_trace (poseidon_sponge/poseidon_sponge_stark.rs:186-381, column map poseidon_sponge/columns.rs:17-66):
+ * 110 columns, one row per 32-byte block (len/32 + 1 rows per operation, pad10*1 on the final row), the block's eight
+ * little-endian u32 words overwrite the rate, one Poseidon permutation per row; padding rows all-zero.  Operation
+ * arguments as zkm_keccak_sponge_trace. */
+#define ZKM_POSEIDON_SPONGE_COLS 110
+int zkm_poseidon_sponge_trace(zkm_ctx* ctx, const uint8_t* inputs, const uint64_t* input_off, const uint64_t* meta, size_t nops,
+                              unsigned log_n, uint64_t* out_dev, size_t* rows_used_out, char** err);
+
 /* ------------------------------------------------------------------ a12: KeccakSpongeStark witness (BASELINE config 5)
  * KeccakSpongeStark::generate_trace (keccak_sponge/keccak_sponge_stark.rs:222-251, rows :253-438, column map
  * keccak_sponge/columns.rs:19-70): 470 columns, one row per 136-byte block (len/136 + 1 rows per operation, pad10*1 on
@@ -140,12 +155,14 @@ void zkm_standard_config(zkm_stark_config* cfg);
  *   LOGIC          logic.rs:199-248                       69 columns
  *   KECCAK_SPONGE  keccak_sponge_stark.rs:456-567        470 columns
  *   KECCAK         keccak/keccak_stark.rs:256-413       2431 columns
- *   MEMORY         memory/memory_stark.rs:253-341         13 columns, plus the range-check lookup :476-483 */
+ *   MEMORY         memory/memory_stark.rs:253-341         13 columns, plus the range-check lookup :476-483
+ *   POSEIDON_SPONGE poseidon_sponge/poseidon_sponge_stark.rs:383-478  110 columns */
 #define ZKM_TABLE_POSEIDON 0
 #define ZKM_TABLE_LOGIC 1
 #define ZKM_TABLE_KECCAK_SPONGE 2
 #define ZKM_TABLE_KECCAK 3
 #define ZKM_TABLE_MEMORY 4
+#define ZKM_TABLE_POSEIDON_SPONGE 5
 #define ZKM_MEMORY_COLS 13
 size_t zkm_table_width(int table_id); /* 0 for an unknown id */
 /* Auxiliary columns the table's own logUp lookups (Stark::lookups(), lookup.rs:22-40) put in front of the CTL columns:

@@ -230,6 +230,36 @@ static void TNAME(eval_keccak)(const T* lv, const T* nv, TNAME(consumer) * k) {
                 TNAME(cons_transition)(k, T_MUL(not_last, T_SUB(lv[kk_appp(x, y) + half], nv[kk_a(x, y) + half])));
 }
 
+/* ---- PoseidonSpongeStark constraints: poseidon_sponge/poseidon_sponge_stark.rs:383-478 (column map poseidon_sponge/columns.rs:17-66:
+ * full 0, context 1, segment 2, virt 3..10, timestamp 11, len 12, already_absorbed 13, is_final_input_len 14..45, original_rate 46..53,
+ * original_capacity 54..57, block_bytes 58..89, new_rate 90..97, partial_updated_state 98..105, updated_digest_state 106..109) ---- */
+static void TNAME(eval_poseidon_sponge)(const T* lv, const T* nv, TNAME(consumer) * k) {
+    T one = T_FROMB(1);
+    T full = lv[0];
+    TNAME(cons)(k, T_MUL(full, T_SUB(full, one)));
+    T is_final = T_FROMB(0), next_final = T_FROMB(0);
+    for (int i = 0; i < 32; i++) { is_final = T_ADD(is_final, lv[14 + i]); next_final = T_ADD(next_final, nv[14 + i]); }
+    TNAME(cons)(k, T_MUL(is_final, T_SUB(is_final, one)));
+    for (int i = 0; i < 32; i++) TNAME(cons)(k, T_MUL(lv[14 + i], T_SUB(lv[14 + i], one)));
+    TNAME(cons)(k, T_MUL(is_final, full));
+    T absorbed = lv[13];
+    TNAME(cons_first)(k, absorbed);
+    for (int i = 0; i < 12; i++) TNAME(cons_first)(k, lv[46 + i]);     /* original_rate then original_capacity */
+    TNAME(cons_transition)(k, T_MUL(is_final, nv[13]));
+    for (int i = 0; i < 12; i++) TNAME(cons_transition)(k, T_MUL(is_final, nv[46 + i]));
+    TNAME(cons_transition)(k, T_MUL(full, T_SUB(lv[1], nv[1])));
+    TNAME(cons_transition)(k, T_MUL(full, T_SUB(lv[2], nv[2])));
+    TNAME(cons_transition)(k, T_MUL(full, T_SUB(lv[11], nv[11])));
+    for (int i = 0; i < 4; i++) TNAME(cons_transition)(k, T_MUL(full, T_SUB(nv[46 + i], lv[106 + i])));
+    for (int i = 0; i < 4; i++) TNAME(cons_transition)(k, T_MUL(full, T_SUB(nv[50 + i], lv[98 + i])));
+    for (int i = 0; i < 4; i++) TNAME(cons_transition)(k, T_MUL(full, T_SUB(nv[54 + i], lv[102 + i])));
+    TNAME(cons_transition)(k, T_MUL(full, T_SUB(T_ADD(absorbed, T_FROMB(32)), nv[13])));
+    T is_dummy = T_SUB(T_SUB(one, full), is_final);
+    TNAME(cons_transition)(k, T_MUL(is_dummy, T_ADD(nv[0], next_final)));
+    T offset = T_SUB(lv[12], absorbed);
+    for (int i = 0; i < 32; i++) TNAME(cons)(k, T_MUL(lv[14 + i], T_SUB(offset, T_FROMB((gl_t)i))));
+}
+
 /* ---- MemoryStark constraints: memory/memory_stark.rs:253-341 (columns memory/columns.rs: FILTER 0, TIMESTAMP 1, IS_READ 2,
  * ADDR_CONTEXT 3, ADDR_SEGMENT 4, ADDR_VIRTUAL 5, VALUE 6 (VALUE_LIMBS = 1), CONTEXT/SEGMENT/VIRTUAL_FIRST_CHANGE 7..9,
  * RANGE_CHECK 10, COUNTER 11, FREQUENCIES 12) ---- */
@@ -308,13 +338,14 @@ static void TNAME(eval_lookups)(int table_id, const gl_t* challenges, size_t nch
 }
 
 /* table dispatch (Table ids of include/zkm_hip.h) */
-static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : table_id == 4 ? 13 : 0; }
+static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : table_id == 4 ? 13 : table_id == 5 ? 110 : 0; }
 static void TNAME(eval_table)(int table_id, const T* lv, const T* nv, TNAME(consumer) * k) {
     if (table_id == 0) TNAME(eval_poseidon)(lv, k);
     else if (table_id == 1) TNAME(eval_logic)(lv, k);
     else if (table_id == 2) TNAME(eval_keccak_sponge)(lv, nv, k);
     else if (table_id == 3) TNAME(eval_keccak)(lv, nv, k);
-    else TNAME(eval_memory)(lv, nv, k);
+    else if (table_id == 4) TNAME(eval_memory)(lv, nv, k);
+    else TNAME(eval_poseidon_sponge)(lv, nv, k);
 }
 
 /* ---- general CTL checks driven by the column-set description ----

@@ -153,6 +153,27 @@ class Oracle:
             raise RuntimeError("oracle keccak_sponge_trace: bad operations")
         return out, used
 
+    def poseidon_sponge_trace(self, inputs, input_off, meta, log_n):
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint8)
+        input_off = np.ascontiguousarray(input_off, dtype=np.uint64)
+        meta = np.ascontiguousarray(meta, dtype=np.uint64)
+        out = np.zeros(110 << log_n, dtype=np.uint64)
+        self.lib.zko_poseidon_sponge_trace.restype = C.c_size_t
+        self.lib.zko_poseidon_sponge_trace.argtypes = [C.c_void_p, u64p, u64p, C.c_size_t, C.c_uint, u64p]
+        used = self.lib.zko_poseidon_sponge_trace(inputs.ctypes.data_as(C.c_void_p), _ptr(input_off), _ptr(meta), input_off.size - 1,
+                                                  log_n, _ptr(out))
+        if used == 0 and input_off.size > 1:
+            raise RuntimeError("oracle poseidon_sponge_trace: bad operations")
+        return out, used
+
+    def poseidon_trace_inputs(self, inputs, timestamps, log_n):
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1, 12)
+        ts = np.ascontiguousarray(timestamps, dtype=np.uint64)
+        out = np.zeros(POSEIDON_COLS << log_n, dtype=np.uint64)
+        self.lib.zko_poseidon_trace_inputs.argtypes = [u64p, u64p, C.c_size_t, C.c_uint, u64p]
+        self.lib.zko_poseidon_trace_inputs(_ptr(inputs), _ptr(ts), len(inputs), log_n, _ptr(out))
+        return out
+
     # ---- NTT / commitment
     def ntt(self, cols, log_n, inverse=False, coset_shift=0):
         a = np.ascontiguousarray(cols, dtype=np.uint64).copy()

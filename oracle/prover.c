@@ -128,6 +128,75 @@ void zko_poseidon_trace(uint64_t seed, size_t num_perms, unsigned log_n, uint64_
     }
 }
 
+/* PoseidonStark::generate_trace (poseidon_stark.rs:104-160) for explicit (input, timestamp) pairs */
+void zko_poseidon_trace_inputs(const uint64_t* inputs, const uint64_t* timestamps, size_t num_perms, unsigned log_n, uint64_t* out) {
+    size_t n = (size_t)1 << log_n;
+    uint64_t zero_in[12] = {0}, def_row[ZKO_POSEIDON_COLS];
+    zko_poseidon_witness_row(zero_in, 0, 0, def_row);
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < n; r++) {
+        uint64_t row[ZKO_POSEIDON_COLS];
+        const uint64_t* src = def_row;
+        if (r < num_perms) {
+            zko_poseidon_witness_row(inputs + 12 * r, timestamps[r], 1, row);
+            src = row;
+        }
+        for (size_t c = 0; c < ZKO_POSEIDON_COLS; c++) out[c * n + r] = src[c];
+    }
+}
+
+/* PoseidonSpongeStark::generate_trace (poseidon_sponge_stark.rs:186-381): one row per 32-byte block (len/32 + 1 rows per
+ * operation, pad10*1 on the final row), the block's 8 little-endian u32 words overwrite the rate, one Poseidon permutation per
+ * row; padding rows are zero.  Operation layout as zko_keccak_sponge_trace. */
+size_t zko_poseidon_sponge_trace(const uint8_t* inputs, const uint64_t* off, const uint64_t* meta, size_t nops, unsigned log_n, uint64_t* out) {
+    size_t n = (size_t)1 << log_n, rows = 0;
+    for (size_t i = 0; i < nops; i++) {
+        if (off[i + 1] <= off[i]) return 0;
+        rows += (off[i + 1] - off[i]) / 32 + 1;
+    }
+    if (rows > n) return 0;
+    memset(out, 0, sizeof(uint64_t) * 110 * n);
+    size_t row = 0;
+    for (size_t op = 0; op < nops; op++) {
+        const uint8_t* msg = inputs + off[op];
+        size_t len = off[op + 1] - off[op], nwords = (len + 3) / 4, absorbed = 0;
+        uint64_t st[12] = {0};
+        for (;;) {
+            size_t rem = len - absorbed;
+            int full = rem >= 32;
+            uint8_t block[32] = {0};
+            memcpy(block, msg + absorbed, full ? 32 : rem);
+#define CELL(c) out[(size_t)(c) * n + row]
+            if (full) CELL(0) = 1;
+            else {
+                if (rem == 31) block[31] = 0x81;
+                else { block[rem] = 1; block[31] = 0x80; }
+                CELL(14 + rem) = 1;
+            }
+            CELL(1) = meta[4 * op];
+            CELL(2) = meta[4 * op + 1];
+            for (size_t i = 0; i < 8; i++) { size_t w = absorbed / 4 + i; CELL(3 + i) = w < nwords ? meta[4 * op + 2] + w : 0; }
+            CELL(11) = meta[4 * op + 3];
+            CELL(12) = len;
+            CELL(13) = absorbed;
+            for (int i = 0; i < 12; i++) CELL(46 + i) = st[i];
+            for (int i = 0; i < 32; i++) CELL(58 + i) = block[i];
+            for (int i = 0; i < 8; i++) {
+                st[i] = (uint64_t)block[4 * i] | ((uint64_t)block[4 * i + 1] << 8) | ((uint64_t)block[4 * i + 2] << 16) | ((uint64_t)block[4 * i + 3] << 24);
+                CELL(90 + i) = st[i];
+            }
+            zko_poseidon_permute(st);
+            for (int i = 0; i < 8; i++) CELL(98 + i) = st[4 + i];
+            for (int i = 0; i < 4; i++) CELL(106 + i) = st[i];
+#undef CELL
+            row++;
+            if (!full) break;
+            absorbed += 32;
+        }
+    }
+    return rows;
+}
+
 void zko_poseidon_eval_row(const uint64_t* local, const uint64_t* alphas, size_t nalphas, uint64_t* acc_out) {
     b_consumer k;
     memset(&k, 0, sizeof k);

@@ -85,6 +85,10 @@ void zko_poseidon_trace(uint64_t seed, size_t num_perms, unsigned log_n, uint64_
 #define ZKO_TABLE_KECCAK_SPONGE 2
 #define ZKO_TABLE_KECCAK 3
 #define ZKO_TABLE_MEMORY 4
+#define ZKO_TABLE_POSEIDON_SPONGE 5
+#define ZKO_POSEIDON_SPONGE_COLS 110
+void zko_poseidon_trace_inputs(const uint64_t* inputs, const uint64_t* timestamps, size_t num_perms, unsigned log_n, uint64_t* out);
+size_t zko_poseidon_sponge_trace(const uint8_t* inputs, const uint64_t* input_off, const uint64_t* meta, size_t nops, unsigned log_n, uint64_t* out);
 #define ZKO_MEMORY_COLS 13
 /* MemoryStark::generate_trace (memory/memory_stark.rs:123-248); ops = nops x 6 {context, segment, virt, timestamp, is_read, value} */
 size_t zko_memory_trace(const uint64_t* ops, size_t nops, unsigned log_n, uint64_t* out);

@@ -63,6 +63,71 @@ def build3(oracle, log_sponge=3, seed=22):
     return tables, ctls, (ops, inputs, ts)
 
 
+def memory_ops_from_poseidon_sponge(trace, log_n, rows):
+    """Memory reads requested by PoseidonSponge rows (poseidon_sponge_stark.rs:63-104, :120-134)."""
+    n = 1 << log_n
+    tr = trace.reshape(T.WIDTH[T.TABLE_POSEIDON_SPONGE], n)
+    ops = []
+    for r in range(rows):
+        full = int(tr[T.PS_FULL, r])
+        rem = 32 if full else int(np.argmax(tr[T.PS_FINAL_LEN:T.PS_FINAL_LEN + 32, r]))
+        for i in range(rem):
+            s = (i // 4) * 4
+            b = [int(tr[T.PS_BLOCK + s + j, r]) for j in range(4)]
+            ops.append((int(tr[T.PS_CONTEXT, r]), int(tr[T.PS_SEGMENT, r]), int(tr[T.PS_VIRT + i // 4, r]), int(tr[T.PS_TIMESTAMP, r]), 1,
+                        (b[0] << 24) | (b[1] << 16) | (b[2] << 8) | b[3]))
+    return np.array(ops, dtype=np.uint64).reshape(-1, 6)
+
+
+def poseidon_inputs_from_sponge(trace, log_n, rows):
+    n = 1 << log_n
+    tr = trace.reshape(T.WIDTH[T.TABLE_POSEIDON_SPONGE], n)
+    inputs = np.concatenate([tr[T.PS_NEW_RATE:T.PS_NEW_RATE + 8, :rows], tr[T.PS_ORIG_CAP:T.PS_ORIG_CAP + 4, :rows]]).T
+    return np.ascontiguousarray(inputs), tr[T.PS_TIMESTAMP, :rows].copy()
+
+
+def poseidon_sponge_ops(seed, target_rows, max_len=200):
+    rng = np.random.default_rng(seed)
+    nops = max(1, target_rows // 5)
+    while True:
+        lens = rng.integers(1, max_len, nops)
+        rows = int(np.sum(lens // 32 + 1))
+        if rows <= target_rows:
+            break
+        nops = max(1, int(nops * 0.9))
+    off = np.zeros(nops + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    data = rng.integers(0, 256, int(off[-1]), dtype=np.uint8)
+    meta = np.zeros((nops, 4), dtype=np.uint64)
+    meta[:, 1] = 2
+    meta[:, 2] = (1 << 20) + np.arange(nops) * 64      # disjoint word ranges, apart from the Keccak fixtures'
+    meta[:, 3] = np.arange(nops) * 5 + 3
+    return data, off, meta.reshape(-1), rows, nops
+
+
+def build_poseidon_path(oracle, log_sponge=4, seed=41):
+    """Memory + PoseidonSponge + Poseidon with the lookups the reference defines among them
+    (all_stark.rs:169-195, 487-493)."""
+    data, off, meta, rows, nops = poseidon_sponge_ops(seed, (1 << log_sponge) - 1)
+    sponge, used = oracle.poseidon_sponge_trace(data, off, meta, log_sponge)
+    assert used == rows
+    inputs, ts = poseidon_inputs_from_sponge(sponge, log_sponge, rows)
+    log_pos = max(3, int(np.ceil(np.log2(rows))))
+    poseidon = oracle.poseidon_trace_inputs(inputs, ts, log_pos)
+    mem_ops = memory_ops_from_poseidon_sponge(sponge, log_sponge, rows)
+    log_mem = int(np.ceil(np.log2(len(mem_ops)))) + 1
+    memory, natural = oracle.memory_trace(mem_ops, log_mem)
+    if natural < (1 << log_mem):
+        log_mem -= 1
+        memory, natural = oracle.memory_trace(mem_ops, log_mem)
+    cs, cp, cm = CtlTable(), CtlTable(), CtlTable()
+    tables = [(T.TABLE_POSEIDON_SPONGE, sponge, 110, log_sponge, cs), (T.TABLE_POSEIDON, poseidon, 262, log_pos, cp),
+              (T.TABLE_MEMORY, memory, 13, log_mem, cm)]
+    ctls = [T.ctl_poseidon_inputs(0, 1, cs, cp), T.ctl_poseidon_outputs(0, 1, cs, cp),
+            (T.memory_lookers_poseidon_sponge(0, cs), (2, T.memory_ctl_data(cm)))]
+    return tables, ctls, (data, off, meta, inputs, ts, mem_ops)
+
+
 def memory_ops_from_sponge(sponge_trace, log_n, rows):
     """The memory reads the sponge rows request (keccak_sponge_stark.rs:91-124, :174-186): one per input byte, each
     carrying the big-endian word that holds the byte.  Returns nops x 6 (context, segment, virt, timestamp, is_read, value)."""

@@ -244,3 +244,55 @@ def test_precompile_path_four_tables_larger(ctx, oracle):
     assert oracle.check_ctls(tables, ctls) == 0
     proofs, chal, offs = ctx.prove_with_traces(tables, ctls)
     assert oracle.verify_all(tables, ctls, proofs, chal) == 0
+
+
+@pytest.mark.parametrize("log_sponge", [4, 9])
+def test_poseidon_sponge_path_is_bit_exact_and_verifies(ctx, oracle, log_sponge):
+    """Memory -> PoseidonSponge -> Poseidon: witnesses from the GPU generators, proofs bit-exact, oracle verify_proof accepts
+    (all_stark.rs:169-195, 487-493)."""
+    tables, ctls, (data, off, meta, inputs, ts, mem_ops) = logic_fixtures.build_poseidon_path(oracle, log_sponge=log_sponge)
+    d_sponge, used = ctx.poseidon_sponge_trace(data, off, meta, log_sponge)
+    assert (d_sponge.download() == tables[0][1]).all()
+    assert (ctx.poseidon_trace_inputs(inputs, ts, tables[1][3]).download() == tables[1][1]).all()
+    got, chal, offs = ctx.prove_with_traces(tables, ctls)
+    if log_sponge <= 6:
+        want, wchal, woffs = oracle.prove_with_traces(tables, ctls)
+        assert offs == woffs and (chal == wchal).all()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "first differing word %d" % bad[0]
+    assert oracle.verify_all(tables, ctls, got, chal) == 0
+
+
+def test_poseidon_sponge_single_table_quotient(ctx, zkm, oracle):
+    tables, ctls, _ = logic_fixtures.build_poseidon_path(oracle, log_sponge=6)
+    tid, trace, W, log_n, cs = tables[0]
+    aux = fake_ctl_aux(log_n)
+    want = oracle.prove(trace, log_n, aux, [2], ncols=W, table_id=tid)
+    got = ctx.prove_single_table(trace, log_n, aux, [2], ncols=W, table_id=tid)
+    assert (got == want).all()
+    assert oracle.verify(got, 3, [2], ncols=W, table_id=tid) == 0
+
+
+def test_both_precompile_paths_share_the_memory_table(ctx, oracle):
+    """Six tables in one proof: Memory is looked up by both sponges (168 looking column sets -> 84 helper columns per
+    challenge), as in all_stark::ctl_memory."""
+    from zkm_amd.ctl import CtlTable
+    kt, kctls, (ops, kin, kts, kmem) = logic_fixtures.build4(oracle, log_sponge=3)
+    pt, pctls, (data, off, meta, pin, pts, pmem) = logic_fixtures.build_poseidon_path(oracle, log_sponge=4)
+    mem_ops = np.concatenate([kmem, pmem])
+    log_mem = int(np.ceil(np.log2(len(mem_ops)))) + 1
+    memory, natural = oracle.memory_trace(mem_ops, log_mem)
+    if natural < (1 << log_mem):
+        log_mem -= 1
+        memory, natural = oracle.memory_trace(mem_ops, log_mem)
+    cks, ck, cl, cps, cp, cm = (CtlTable() for _ in range(6))
+    tables = [(kt[0][0], kt[0][1], 470, kt[0][3], cks), (kt[1][0], kt[1][1], 2431, kt[1][3], ck), (kt[2][0], kt[2][1], 69, kt[2][3], cl),
+              (pt[0][0], pt[0][1], 110, pt[0][3], cps), (pt[1][0], pt[1][1], 262, pt[1][3], cp), (T.TABLE_MEMORY, memory, 13, log_mem, cm)]
+    ctls = [T.ctl_poseidon_inputs(3, 4, cps, cp), T.ctl_poseidon_outputs(3, 4, cps, cp),
+            T.ctl_keccak_inputs(0, 1, cks, ck), T.ctl_keccak_outputs(0, 1, cks, ck), T.ctl_logic_keccak_sponge(0, 2, cks, cl),
+            (T.memory_lookers_keccak_sponge(0, cks) + T.memory_lookers_poseidon_sponge(3, cps), (5, T.memory_ctl_data(cm)))]
+    assert oracle.check_ctls(tables, ctls) == 0
+    want, wchal, woffs = oracle.prove_with_traces(tables, ctls)
+    got, chal, offs = ctx.prove_with_traces(tables, ctls)
+    assert offs == woffs and (chal == wchal).all() and (got == want).all()
+    assert oracle.verify_all(tables, ctls, got, chal) == 0

@@ -163,3 +163,37 @@ def test_precompile_path_four_tables(oracle):
     assert oracle.check_ctls(tables, ctls) == 0
     proofs, chal, offs = oracle.prove_with_traces(tables, ctls)
     assert oracle.verify_all(tables, ctls, proofs, chal) == 0
+
+
+def test_poseidon_sponge_trace_and_path(oracle):
+    tables, ctls, (data, off, meta, inputs, ts, mem_ops) = logic_fixtures.build_poseidon_path(oracle)
+    tid, sponge, w, log_n, cs = tables[0]
+    tr = sponge.reshape(110, -1)
+    # the digest of every operation's last row is the Poseidon sponge hash of its input (poseidon_sponge_stark.rs:143-166)
+    row = 0
+    for op in range(len(off) - 1):
+        msg = bytes(data[int(off[op]):int(off[op + 1])])
+        row += len(msg) // 32
+        padded = bytearray(msg) + bytearray((len(msg) // 32 + 1) * 32 - len(msg))
+        if len(msg) % 32 == 31:
+            padded[len(msg)] = 0x81
+        else:
+            padded[len(msg)] = 1
+            padded[-1] = 0x80
+        st = [0] * 12
+        for b in range(0, len(padded), 32):
+            st[:8] = [int.from_bytes(padded[b + 4 * i:b + 4 * i + 4], "little") for i in range(8)]
+            st = [int(x) for x in oracle.poseidon_permute(st)]
+        assert [int(x) for x in tr[106:110, row]] == st[:4]
+        row += 1
+    assert oracle.check_ctls(tables, ctls) == 0
+    proofs, chal, offs = oracle.prove_with_traces(tables, ctls)
+    assert oracle.verify_all(tables, ctls, proofs, chal) == 0
+    # a sponge row whose output does not continue into the next row breaks a transition constraint
+    bad = sponge.copy()
+    n = 1 << log_n
+    full_rows = np.nonzero(tr[0])[0]
+    bad[106 * n + int(full_rows[0])] ^= 1
+    aux_tables = [(tid, bad, w, log_n, cs)] + tables[1:]
+    proofs, chal, offs = oracle.prove_with_traces(aux_tables, ctls)
+    assert oracle.verify_all(aux_tables, ctls, proofs, chal) != 0

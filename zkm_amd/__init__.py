@@ -21,7 +21,8 @@ POSEIDON_COLS = 262
 KECCAK_SPONGE_COLS = 470
 LOGIC_COLS = 69
 KECCAK_COLS = 2431
-TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY = 0, 1, 2, 3, 4
+POSEIDON_SPONGE_COLS = 110
+TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY, TABLE_POSEIDON_SPONGE = 0, 1, 2, 3, 4, 5
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
@@ -29,6 +30,7 @@ EXPORTS = [
     "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_free",
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_keccak_trace", "zkm_logic_trace",
+    "zkm_poseidon_sponge_trace", "zkm_poseidon_trace_inputs",
     "zkm_table_width", "zkm_num_lookup_columns", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
     "zkm_prove_single_table", "zkm_prove_openings", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
@@ -97,6 +99,8 @@ def load():
         "zkm_keccakf_batch": (C.c_int, [cp, cp, C.c_size_t, err]),
         "zkm_poseidon_trace": (C.c_int, [cp, C.c_uint64, C.c_size_t, C.c_uint, cp, err]),
         "zkm_keccak_sponge_trace": (C.c_int, [cp, cp, u64p, u64p, C.c_size_t, C.c_uint, cp, C.POINTER(C.c_size_t), err]),
+        "zkm_poseidon_sponge_trace": (C.c_int, [cp, cp, u64p, u64p, C.c_size_t, C.c_uint, cp, C.POINTER(C.c_size_t), err]),
+        "zkm_poseidon_trace_inputs": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_keccak_trace": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_logic_trace": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_table_width": (C.c_size_t, [C.c_int]),
@@ -261,6 +265,30 @@ class Context:
         _check(self.L.zkm_keccak_sponge_trace(self.h, inputs.ctypes.data_as(C.c_void_p), input_off.ctypes.data_as(u64p),
                                               meta.ctypes.data_as(u64p), nops, log_n, _data_ptr(out), C.byref(used), C.byref(err)), err)
         return out, used.value
+
+    def poseidon_sponge_trace(self, inputs, input_off, meta, log_n, out=None):
+        """PoseidonSpongeStark::generate_trace on the GPU (poseidon_sponge_stark.rs:186-381); arguments as keccak_sponge_trace.
+        Returns (DeviceBuffer of 110 x 2^log_n words, rows used)."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint8)
+        input_off = np.ascontiguousarray(input_off, dtype=np.uint64)
+        meta = np.ascontiguousarray(meta, dtype=np.uint64)
+        out = out or self.alloc(POSEIDON_SPONGE_COLS << log_n)
+        used = C.c_size_t()
+        err = C.c_char_p()
+        _check(self.L.zkm_poseidon_sponge_trace(self.h, inputs.ctypes.data_as(C.c_void_p), input_off.ctypes.data_as(u64p),
+                                                meta.ctypes.data_as(u64p), input_off.size - 1, log_n, _data_ptr(out), C.byref(used),
+                                                C.byref(err)), err)
+        return out, used.value
+
+    def poseidon_trace_inputs(self, inputs, timestamps, log_n, out=None):
+        """PoseidonStark::generate_trace for explicit inputs (num_perms x 12) and timestamps; DeviceBuffer of 262 x 2^log_n."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1, 12)
+        timestamps = np.ascontiguousarray(timestamps, dtype=np.uint64)
+        out = out or self.alloc(POSEIDON_COLS << log_n)
+        err = C.c_char_p()
+        _check(self.L.zkm_poseidon_trace_inputs(self.h, _data_ptr(inputs), _data_ptr(timestamps), len(inputs), log_n, _data_ptr(out),
+                                                C.byref(err)), err)
+        return out
 
     def keccak_trace(self, inputs, timestamps, log_n, out=None):
         """KeccakStark::generate_trace on the GPU (keccak/keccak_stark.rs:62-236).  inputs: nperms x 25 uint64, timestamps:

@@ -391,24 +391,25 @@ int zkm_poseidon_trace(zkm_ctx* c, uint64_t seed, size_t num_perms, unsigned log
     ZKM_API_BEGIN
     ZKM_HIP_CHECK(hipSetDevice(c->device));
     if (!zkm_is_device_ptr(out_dev)) throw std::runtime_error("zkm_poseidon_trace: out must be a device pointer");
-    zkm_launch_poseidon_trace(c, seed, num_perms, log_n, out_dev);
+    zkm_launch_poseidon_trace(c, seed, nullptr, nullptr, num_perms, log_n, out_dev);
     c->sync();
     ZKM_API_END(err)
 }
 
-int zkm_keccak_sponge_trace(zkm_ctx* c, const uint8_t* inputs, const uint64_t* input_off, const uint64_t* meta, size_t nops,
-                            unsigned log_n, uint64_t* out_dev, size_t* rows_used_out, char** err) {
+// shared host side of the two sponge witness generators: rows per operation = len / rate + 1
+static int sponge_trace(zkm_ctx* c, const char* what, size_t rate, bool poseidon, const uint8_t* inputs, const uint64_t* input_off,
+                        const uint64_t* meta, size_t nops, unsigned log_n, uint64_t* out_dev, size_t* rows_used_out, char** err) {
     std::vector<void*> tmp;
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
-        if (!zkm_is_device_ptr(out_dev)) throw std::runtime_error("zkm_keccak_sponge_trace: out must be a device pointer");
+        if (!zkm_is_device_ptr(out_dev)) throw std::runtime_error(std::string(what) + ": out must be a device pointer");
         size_t n = (size_t)1 << log_n;
         std::vector<uint64_t> row_off(nops + 1, 0);
         for (size_t i = 0; i < nops; i++) {
-            if (input_off[i + 1] <= input_off[i]) throw std::runtime_error("zkm_keccak_sponge_trace: empty operation (base_address[0] is required)");
-            row_off[i + 1] = row_off[i] + (input_off[i + 1] - input_off[i]) / 136 + 1;
+            if (input_off[i + 1] <= input_off[i]) throw std::runtime_error(std::string(what) + ": empty operation (base_address[0] is required)");
+            row_off[i + 1] = row_off[i] + (input_off[i + 1] - input_off[i]) / rate + 1;
         }
-        if (row_off[nops] > n) throw std::runtime_error("zkm_keccak_sponge_trace: operations need more rows than 2^log_n");
+        if (row_off[nops] > n) throw std::runtime_error(std::string(what) + ": operations need more rows than 2^log_n");
         size_t nbytes = nops ? input_off[nops] : 0;
         bool idev = zkm_is_device_ptr(inputs);
         const uint8_t* d_in = inputs;
@@ -427,9 +428,48 @@ int zkm_keccak_sponge_trace(zkm_ctx* c, const uint8_t* inputs, const uint64_t* i
         ZKM_HIP_CHECK(hipMemcpyAsync(d_off, input_off, (nops + 1) * 8, hipMemcpyHostToDevice, c->stream));
         if (nops) ZKM_HIP_CHECK(hipMemcpyAsync(d_meta, meta, nops * 32, hipMemcpyHostToDevice, c->stream));
         ZKM_HIP_CHECK(hipMemcpyAsync(d_row, row_off.data(), (nops + 1) * 8, hipMemcpyHostToDevice, c->stream));
-        zkm_launch_keccak_sponge_trace(c, d_in, d_off, d_meta, d_row, nops, log_n, out_dev);
+        if (poseidon) zkm_launch_poseidon_sponge_trace(c, d_in, d_off, d_meta, d_row, nops, log_n, out_dev);
+        else zkm_launch_keccak_sponge_trace(c, d_in, d_off, d_meta, d_row, nops, log_n, out_dev);
         c->sync();
         if (rows_used_out) *rows_used_out = row_off[nops];
+        for (void* p : tmp) c->release(p);
+    } catch (const std::exception& e) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* p : tmp) c->release(p);
+        return fail(err, e.what());
+    }
+    return 0;
+}
+
+int zkm_keccak_sponge_trace(zkm_ctx* c, const uint8_t* inputs, const uint64_t* input_off, const uint64_t* meta, size_t nops,
+                            unsigned log_n, uint64_t* out_dev, size_t* rows_used_out, char** err) {
+    return sponge_trace(c, "zkm_keccak_sponge_trace", 136, false, inputs, input_off, meta, nops, log_n, out_dev, rows_used_out, err);
+}
+
+int zkm_poseidon_sponge_trace(zkm_ctx* c, const uint8_t* inputs, const uint64_t* input_off, const uint64_t* meta, size_t nops,
+                              unsigned log_n, uint64_t* out_dev, size_t* rows_used_out, char** err) {
+    return sponge_trace(c, "zkm_poseidon_sponge_trace", 32, true, inputs, input_off, meta, nops, log_n, out_dev, rows_used_out, err);
+}
+
+int zkm_poseidon_trace_inputs(zkm_ctx* c, const uint64_t* inputs, const uint64_t* timestamps, size_t num_perms, unsigned log_n,
+                              uint64_t* out_dev, char** err) {
+    std::vector<void*> tmp;
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!zkm_is_device_ptr(out_dev)) throw std::runtime_error("zkm_poseidon_trace_inputs: out must be a device pointer");
+        if (num_perms > ((size_t)1 << log_n)) throw std::runtime_error("zkm_poseidon_trace_inputs: more permutations than 2^log_n rows");
+        if (num_perms && (!inputs || !timestamps)) throw std::runtime_error("zkm_poseidon_trace_inputs: inputs and timestamps are required");
+        auto to_dev = [&](const uint64_t* p, size_t words) -> const uint64_t* {
+            if (!words || zkm_is_device_ptr(p)) return p;
+            void* d = c->alloc(words * 8);
+            tmp.push_back(d);
+            ZKM_HIP_CHECK(hipMemcpyAsync(d, p, words * 8, hipMemcpyHostToDevice, c->stream));
+            return (const uint64_t*)d;
+        };
+        const uint64_t* d_in = to_dev(inputs, num_perms * 12);
+        const uint64_t* d_ts = to_dev(timestamps, num_perms);
+        zkm_launch_poseidon_trace(c, 0, num_perms ? d_in : nullptr, num_perms ? d_ts : nullptr, num_perms, log_n, out_dev);
+        c->sync();
         for (void* p : tmp) c->release(p);
     } catch (const std::exception& e) {
         (void)hipStreamSynchronize(c->stream);
@@ -453,6 +493,7 @@ size_t zkm_table_width(int table_id) {
         case ZKM_TABLE_KECCAK_SPONGE: return ZKM_KECCAK_SPONGE_COLS;
         case ZKM_TABLE_KECCAK: return ZKM_KECCAK_COLS;
         case ZKM_TABLE_MEMORY: return ZKM_MEMORY_COLS;
+        case ZKM_TABLE_POSEIDON_SPONGE: return ZKM_POSEIDON_SPONGE_COLS;
         default: return 0;
     }
 }

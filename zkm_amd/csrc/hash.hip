@@ -289,7 +289,8 @@ __device__ __forceinline__ uint64_t splitmix_at(uint64_t seed, uint64_t k) {
 
 // One row per lane; every column store is a contiguous wave access (column-major output).
 // Column map: poseidon/columns.rs:3-54 (FILTER 0, in 1..12, out 13..24, TIMESTAMP 25, full0 26.., partial 122.., full1 166..)
-__global__ __launch_bounds__(256) void k_poseidon_trace(uint64_t seed, size_t num_perms, size_t n, gl_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_poseidon_trace(uint64_t seed, const uint64_t* __restrict__ inputs, const uint64_t* __restrict__ ts,
+                                                        size_t num_perms, size_t n, gl_t* __restrict__ out) {
     size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     bool real = r < num_perms;
@@ -297,11 +298,11 @@ __global__ __launch_bounds__(256) void k_poseidon_trace(uint64_t seed, size_t nu
     gl_t* o = out + r;
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        s[i] = real ? gl_canon(splitmix_at(seed, r * 12 + i + 1)) : 0;
+        s[i] = !real ? 0 : inputs ? gl_canon(inputs[r * 12 + i]) : gl_canon(splitmix_at(seed, r * 12 + i + 1));
         o[(1 + i) * n] = s[i];
     }
     o[0] = real ? 1 : 0;
-    o[25 * n] = 0;
+    o[25 * n] = (real && ts) ? ts[r] : 0;
     int rc = 0;
 #pragma unroll 1
     for (int half = 0; half < 2; half++) {
@@ -355,10 +356,11 @@ __global__ __launch_bounds__(256) void k_poseidon_trace(uint64_t seed, size_t nu
     for (int i = 0; i < 12; i++) o[(size_t)(13 + i) * n] = gl_canon(s[i]);
 }
 
-void zkm_launch_poseidon_trace(zkm_ctx* c, uint64_t seed, size_t num_perms, unsigned log_n, gl_t* out) {
+void zkm_launch_poseidon_trace(zkm_ctx* c, uint64_t seed, const uint64_t* inputs, const uint64_t* ts, size_t num_perms, unsigned log_n,
+                               gl_t* out) {
     size_t n = (size_t)1 << log_n;
     zkm_prof_scope ps(c, "poseidon_trace");
-    hipLaunchKernelGGL(k_poseidon_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, seed, num_perms, n, out);
+    hipLaunchKernelGGL(k_poseidon_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, seed, inputs, ts, num_perms, n, out);
     ZKM_HIP_CHECK(hipGetLastError());
 }
 
@@ -492,5 +494,75 @@ __global__ __launch_bounds__(256) void k_keccak_trace(const uint64_t* __restrict
 void zkm_launch_keccak_trace(zkm_ctx* c, const uint64_t* d_inputs, const uint64_t* d_ts, size_t nperms, size_t n, gl_t* out) {
     zkm_prof_scope ps(c, "keccak_trace");
     hipLaunchKernelGGL(k_keccak_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_inputs, d_ts, nperms, n, out);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ PoseidonSpongeStark witness (poseidon_sponge_stark.rs:186-381)
+// One lane per sponge operation, as k_keccak_sponge_trace; column map poseidon_sponge/columns.rs:17-66.  The output buffer is
+// zero-filled first; only non-zero cells are stored.
+__global__ __launch_bounds__(128) void k_poseidon_sponge_trace(const uint8_t* __restrict__ inputs, const uint64_t* __restrict__ off,
+                                                               const uint64_t* __restrict__ meta, const uint64_t* __restrict__ row_off,
+                                                               size_t nops, size_t n, gl_t* __restrict__ out) {
+    size_t op = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (op >= nops) return;
+    const uint8_t* msg = inputs + off[op];
+    const size_t len = off[op + 1] - off[op], nwords = (len + 3) / 4;
+    const uint64_t ctxv = meta[4 * op], seg = meta[4 * op + 1], vbase = meta[4 * op + 2], ts = meta[4 * op + 3];
+    uint64_t st[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = 0;
+    size_t row = row_off[op], absorbed = 0;
+    for (;;) {
+        const size_t rem = len - absorbed;
+        const bool full = rem >= 32;
+        gl_t* o = out + row;
+        if (full) o[0] = 1;
+        else o[(size_t)(14 + rem) * n] = 1;
+        o[1 * n] = ctxv;
+        o[2 * n] = seg;
+        for (size_t i = 0; i < 8; i++) {
+            size_t w = absorbed / 4 + i;
+            if (w < nwords) o[(3 + i) * n] = vbase + w;
+        }
+        o[11 * n] = ts;
+        o[12 * n] = len;
+        o[13 * n] = absorbed;
+#pragma unroll
+        for (int i = 0; i < 12; i++) o[(size_t)(46 + i) * n] = st[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                size_t pos = (size_t)4 * i + j;
+                uint32_t b = pos < rem ? msg[absorbed + pos] : 0;
+                if (!full) {
+                    if (pos == rem) b = (rem == 31) ? 0x81 : 0x01;
+                    else if (pos == 31) b = 0x80;
+                }
+                if (b) o[(size_t)(58 + pos) * n] = b;
+                w |= (uint64_t)b << (8 * j);
+            }
+            st[i] = w;
+            o[(size_t)(90 + i) * n] = w;
+        }
+        poseidon_permute(st);
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[(size_t)(98 + i) * n] = st[4 + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[(size_t)(106 + i) * n] = st[i];
+        row++;
+        if (!full) break;
+        absorbed += 32;
+    }
+}
+
+void zkm_launch_poseidon_sponge_trace(zkm_ctx* c, const uint8_t* d_inputs, const uint64_t* d_off, const uint64_t* d_meta,
+                                      const uint64_t* d_row_off, size_t nops, unsigned log_n, gl_t* out) {
+    size_t n = (size_t)1 << log_n;
+    ZKM_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)ZKM_POSEIDON_SPONGE_COLS * n * sizeof(gl_t), c->stream));
+    if (!nops) return;
+    zkm_prof_scope ps(c, "poseidon_sponge_trace");
+    hipLaunchKernelGGL(k_poseidon_sponge_trace, dim3((nops + 127) / 128), dim3(128), 0, c->stream, d_inputs, d_off, d_meta, d_row_off, nops, n, out);
     ZKM_HIP_CHECK(hipGetLastError());
 }

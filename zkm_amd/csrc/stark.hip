@@ -342,6 +342,50 @@ __device__ void eval_keccak_constraints(const gl_t* __restrict__ lv, size_t cs, 
 #undef NV
 }
 
+// PoseidonSpongeStark (poseidon_sponge/poseidon_sponge_stark.rs:383-478; columns poseidon_sponge/columns.rs:17-66)
+template <int NA>
+__device__ void eval_poseidon_sponge_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
+    const gl_t* __restrict__ nv = lv + dnext;
+    enum { FULL = 0, CONTEXT = 1, SEGMENT = 2, TIMESTAMP = 11, LEN = 12, ABSORBED = 13, FINAL_LEN = 14, ORIG = 46, PARTIAL = 98, DIGEST = 106 };
+    gl_t full = lv[FULL];
+    k.constraint(gl_mul(full, gl_sub(full, 1)));
+    gl_t is_final = 0, next_final = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+        is_final = gl_add(is_final, lv[(size_t)(FINAL_LEN + i) * cs]);
+        next_final = gl_add(next_final, nv[(size_t)(FINAL_LEN + i) * cs]);
+    }
+    k.constraint(gl_mul(is_final, gl_sub(is_final, 1)));
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+        gl_t f = lv[(size_t)(FINAL_LEN + i) * cs];
+        k.constraint(gl_mul(f, gl_sub(f, 1)));
+    }
+    k.constraint(gl_mul(is_final, full));
+    gl_t absorbed = lv[(size_t)ABSORBED * cs];
+    k.first_row(absorbed);
+#pragma unroll 2
+    for (int i = 0; i < 12; i++) k.first_row(lv[(size_t)(ORIG + i) * cs]);  // original_rate then original_capacity
+    gl_t fin_t = gl_mul(is_final, k.z_last), full_t = gl_mul(full, k.z_last);
+    k.constraint(gl_mul(fin_t, nv[(size_t)ABSORBED * cs]));
+#pragma unroll 2
+    for (int i = 0; i < 12; i++) k.constraint(gl_mul(fin_t, nv[(size_t)(ORIG + i) * cs]));
+    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)CONTEXT * cs], nv[(size_t)CONTEXT * cs])));
+    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)SEGMENT * cs], nv[(size_t)SEGMENT * cs])));
+    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)TIMESTAMP * cs], nv[(size_t)TIMESTAMP * cs])));
+#pragma unroll 2
+    for (int i = 0; i < 4; i++) k.constraint(gl_mul(full_t, gl_sub(nv[(size_t)(ORIG + i) * cs], lv[(size_t)(DIGEST + i) * cs])));
+#pragma unroll 2
+    for (int i = 0; i < 8; i++)  // rate words 4..7 then the 4 capacity words are contiguous in both views
+        k.constraint(gl_mul(full_t, gl_sub(nv[(size_t)(ORIG + 4 + i) * cs], lv[(size_t)(PARTIAL + i) * cs])));
+    k.constraint(gl_mul(full_t, gl_sub(gl_add(absorbed, 32), nv[(size_t)ABSORBED * cs])));
+    gl_t is_dummy = gl_sub(gl_sub(1, full), is_final);
+    k.transition(gl_mul(is_dummy, gl_add(nv[FULL], next_final)));
+    gl_t offset = gl_sub(lv[(size_t)LEN * cs], absorbed);
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) k.constraint(gl_mul(lv[(size_t)(FINAL_LEN + i) * cs], gl_sub(offset, (gl_t)i)));
+}
+
 // MemoryStark (memory/memory_stark.rs:253-341; columns memory/columns.rs, VALUE_LIMBS = 1)
 template <int NA>
 __device__ void eval_memory_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
@@ -414,7 +458,8 @@ __device__ __forceinline__ void eval_table_constraints(const gl_t* __restrict__ 
     else if constexpr (TABLE == ZKM_TABLE_LOGIC) eval_logic_constraints<NA>(lv, cs, k);
     else if constexpr (TABLE == ZKM_TABLE_KECCAK_SPONGE) eval_keccak_sponge_constraints<NA>(lv, cs, dnext, k);
     else if constexpr (TABLE == ZKM_TABLE_KECCAK) eval_keccak_constraints<NA>(lv, cs, dnext, k);
-    else eval_memory_constraints<NA>(lv, cs, dnext, k);
+    else if constexpr (TABLE == ZKM_TABLE_MEMORY) eval_memory_constraints<NA>(lv, cs, dnext, k);
+    else eval_poseidon_sponge_constraints<NA>(lv, cs, dnext, k);
 }
 
 // CTL checks driven by the column-set description (eval_helper_columns cross_table_lookup.rs:1006-1058,
@@ -546,7 +591,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     ZKM_HIP_CHECK(hipMemcpyAsync(d_alphas, alphas_host, nalphas * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
     gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
     {
-        static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory"};
+        static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory", "quotient_poseidon_sponge"};
         zkm_prof_scope ps(c, names[table_id]);
         dim3 grid((size + 255) / 256), block(256);
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
@@ -562,7 +607,9 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             case 6: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK, 1); break;
             case 7: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_KECCAK, 2); break;
             case 8: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_MEMORY, 1); break;
-            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_MEMORY, 2); break;
+            case 9: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_MEMORY, 2); break;
+            case 10: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON_SPONGE, 1); break;
+            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON_SPONGE, 2); break;
         }
 #undef ZKM_LAUNCH_QUOTIENT
         ZKM_HIP_CHECK(hipGetLastError());

@@ -110,7 +110,10 @@ void zkm_launch_merkle_leaves(zkm_ctx*, const gl_t* lde, size_t nrows, size_t nc
 // leaf digests of row-major leaves formed from F2 SoA arrays: leaf k = 16 consecutive (c0,c1) pairs
 void zkm_launch_merkle_leaves_ext(zkm_ctx*, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests);
 void zkm_launch_merkle_compress(zkm_ctx*, const gl_t* children, gl_t* parents, size_t nparents);
-void zkm_launch_poseidon_trace(zkm_ctx*, uint64_t seed, size_t num_perms, unsigned log_n, gl_t* out);
+void zkm_launch_poseidon_trace(zkm_ctx*, uint64_t seed, const uint64_t* d_inputs, const uint64_t* d_ts, size_t num_perms, unsigned log_n,
+                               gl_t* out);
+void zkm_launch_poseidon_sponge_trace(zkm_ctx*, const uint8_t* d_inputs, const uint64_t* d_off, const uint64_t* d_meta,
+                                      const uint64_t* d_row_off, size_t nops, unsigned log_n, gl_t* out);
 void zkm_launch_keccak_sponge_trace(zkm_ctx*, const uint8_t* d_inputs, const uint64_t* d_off, const uint64_t* d_meta,
                                     const uint64_t* d_row_off, size_t nops, unsigned log_n, gl_t* out);
 // build all digest layers above level 0; fills level_off and returns total words needed (call with digests==nullptr to size)

@@ -8,8 +8,8 @@ include/zkm_hip.h); mirrors
 """
 from .ctl import CtlTable
 
-TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY = 0, 1, 2, 3, 4
-WIDTH = {TABLE_POSEIDON: 262, TABLE_LOGIC: 69, TABLE_KECCAK_SPONGE: 470, TABLE_KECCAK: 2431, TABLE_MEMORY: 13}
+TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY, TABLE_POSEIDON_SPONGE = 0, 1, 2, 3, 4, 5
+WIDTH = {TABLE_POSEIDON: 262, TABLE_LOGIC: 69, TABLE_KECCAK_SPONGE: 470, TABLE_KECCAK: 2431, TABLE_MEMORY: 13, TABLE_POSEIDON_SPONGE: 110}
 
 # LogicStark columns (logic.rs:25-50)
 LOGIC_IS_AND, LOGIC_IS_OR, LOGIC_IS_XOR, LOGIC_IS_NOR = 0, 1, 2, 3
@@ -20,6 +20,12 @@ OP_AND, OP_OR, OP_XOR, OP_NOR = 0, 1, 2, 3
 KS_FULL, KS_FINAL_LEN, KS_ORIG_RATE, KS_BLOCK, KS_XORED = 0, 40, 176, 226, 362
 KS_CONTEXT, KS_SEGMENT, KS_VIRT = 1, 2, 3
 KS_TIMESTAMP, KS_ORIG_CAP, KS_PARTIAL, KS_DIGEST = 37, 210, 396, 438
+
+# PoseidonStark columns (poseidon/columns.rs:3-54) and PoseidonSpongeStark columns (poseidon_sponge/columns.rs:17-66)
+POS_FILTER, POS_IN, POS_OUT, POS_TIMESTAMP = 0, 1, 13, 25
+PS_FULL, PS_CONTEXT, PS_SEGMENT, PS_VIRT, PS_TIMESTAMP, PS_LEN, PS_ABSORBED, PS_FINAL_LEN = 0, 1, 2, 3, 11, 12, 13, 14
+PS_ORIG_RATE, PS_ORIG_CAP, PS_BLOCK, PS_NEW_RATE, PS_PARTIAL, PS_DIGEST = 46, 54, 58, 90, 98, 106
+POSEIDON_RATE_BYTES = 32
 
 # MemoryStark columns (memory/columns.rs)
 MEM_FILTER, MEM_TIMESTAMP, MEM_IS_READ, MEM_CONTEXT, MEM_SEGMENT, MEM_VIRTUAL, MEM_VALUE = 0, 1, 2, 3, 4, 5, 6
@@ -145,3 +151,68 @@ def ctl_memory_keccak_sponge(sponge_index, memory_index, sponge_ctl, memory_ctl)
     """The KeccakSponge part of all_stark::ctl_memory() (all_stark.rs:479-542): 136 looking column sets."""
     looking = [(sponge_index, keccak_sponge_looking_memory(sponge_ctl, i)) for i in range(KECCAK_RATE_BYTES)]
     return looking, (memory_index, memory_ctl_data(memory_ctl))
+
+
+def poseidon_ctl_data_inputs(t: CtlTable):
+    """poseidon_stark::ctl_data_inputs() with ctl_filter_inputs() (poseidon_stark.rs:29-45)."""
+    return t.singles_set(list(range(POS_IN, POS_IN + 12)) + [POS_TIMESTAMP], filter_col=POS_FILTER)
+
+
+def poseidon_ctl_data_outputs(t: CtlTable):
+    """poseidon_stark::ctl_data_outputs() with ctl_filter_outputs() (poseidon_stark.rs:36-49)."""
+    return t.singles_set(list(range(POS_OUT, POS_OUT + 12)) + [POS_TIMESTAMP], filter_col=POS_FILTER)
+
+
+def _poseidon_sponge_filter(t: CtlTable):
+    return t.sum([PS_FULL] + list(range(PS_FINAL_LEN, PS_FINAL_LEN + POSEIDON_RATE_BYTES)))
+
+
+def poseidon_sponge_looking_poseidon_inputs(t: CtlTable):
+    """poseidon_sponge_stark::ctl_looking_poseidon_inputs() with ctl_looking_poseidon_filter() (:44-51, :136-141)."""
+    first = len(t._cols)
+    for c in list(range(PS_NEW_RATE, PS_NEW_RATE + 8)) + list(range(PS_ORIG_CAP, PS_ORIG_CAP + 4)) + [PS_TIMESTAMP]:
+        t.single(c)
+    return t.colset(range(first, first + 13), filter_constants=[_poseidon_sponge_filter(t)])
+
+
+def poseidon_sponge_looking_poseidon_outputs(t: CtlTable):
+    """poseidon_sponge_stark::ctl_looking_poseidon_outputs() with ctl_looking_poseidon_filter() (:53-61, :136-141)."""
+    first = len(t._cols)
+    for c in list(range(PS_DIGEST, PS_DIGEST + 4)) + list(range(PS_PARTIAL, PS_PARTIAL + 8)) + [PS_TIMESTAMP]:
+        t.single(c)
+    return t.colset(range(first, first + 13), filter_constants=[_poseidon_sponge_filter(t)])
+
+
+def poseidon_sponge_looking_memory(t: CtlTable, i):
+    """poseidon_sponge_stark::ctl_looking_memory(i) with ctl_looking_memory_filter(i) (:63-104, :120-134)."""
+    start = (i // 4) * 4
+    first = t.constant(1)
+    t.single(PS_CONTEXT)
+    t.single(PS_SEGMENT)
+    t.single(PS_VIRT + i // 4)
+    t.le_bytes([PS_BLOCK + start + 3, PS_BLOCK + start + 2, PS_BLOCK + start + 1, PS_BLOCK + start])
+    t.single(PS_TIMESTAMP)
+    if i == POSEIDON_RATE_BYTES - 1:
+        f = t.single(PS_FULL)
+    else:
+        f = t.sum([PS_FULL] + list(range(PS_FINAL_LEN + i + 1, PS_FINAL_LEN + POSEIDON_RATE_BYTES)))
+    return t.colset(range(first, first + 6), filter_constants=[f])
+
+
+def ctl_poseidon_inputs(sponge_index, poseidon_index, sponge_ctl, poseidon_ctl):
+    """all_stark::ctl_poseidon_inputs() (all_stark.rs:169-181)."""
+    return [(sponge_index, poseidon_sponge_looking_poseidon_inputs(sponge_ctl))], (poseidon_index, poseidon_ctl_data_inputs(poseidon_ctl))
+
+
+def ctl_poseidon_outputs(sponge_index, poseidon_index, sponge_ctl, poseidon_ctl):
+    """all_stark::ctl_poseidon_outputs() (all_stark.rs:183-195)."""
+    return [(sponge_index, poseidon_sponge_looking_poseidon_outputs(sponge_ctl))], (poseidon_index, poseidon_ctl_data_outputs(poseidon_ctl))
+
+
+def memory_lookers_poseidon_sponge(sponge_index, sponge_ctl):
+    """The PoseidonSponge part of all_stark::ctl_memory() (all_stark.rs:487-493): 32 looking column sets."""
+    return [(sponge_index, poseidon_sponge_looking_memory(sponge_ctl, i)) for i in range(POSEIDON_RATE_BYTES)]
+
+
+def memory_lookers_keccak_sponge(sponge_index, sponge_ctl):
+    return [(sponge_index, keccak_sponge_looking_memory(sponge_ctl, i)) for i in range(KECCAK_RATE_BYTES)]
