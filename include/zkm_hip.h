@@ -122,6 +122,20 @@ int zkm_keccak_sponge_trace(zkm_ctx* ctx, const uint8_t* inputs, const uint64_t*
 int zkm_keccak_trace(zkm_ctx* ctx, const uint64_t* inputs, const uint64_t* timestamps, size_t nperms, unsigned log_n,
                      uint64_t* out_dev, char** err);
 
+/* ------------------------------------------------------------------ N2: SHA-256 message-schedule witnesses
+ * ShaExtendStark::generate_trace (sha_extend/sha_extend_stark.rs:121-236): 78 columns, one row per schedule step; inputs =
+ * nrows x 16 bytes (w[i-15], w[i-2], w[i-16], w[i-7] as little-endian byte quadruples), one timestamp per row; rows past
+ * nrows are zero.
+ * ShaExtendSpongeStark::generate_trace (sha_extend_sponge/sha_extend_sponge_stark.rs:131-215) for nblocks complete schedules:
+ * 76 columns, 48 rows per block; w16 = nblocks x 16 uint32 words w[0..15]; meta = nblocks x 4 {context, segment, address of
+ * w[0], timestamp of round 0}; word j lives at address + 4 j and round r is stamped timestamp + 20 r (2 * NUM_CHANNELS). */
+#define ZKM_SHA_EXTEND_COLS 78
+#define ZKM_SHA_EXTEND_SPONGE_COLS 76
+int zkm_sha_extend_trace(zkm_ctx* ctx, const uint8_t* inputs, const uint64_t* timestamps, size_t nrows, unsigned log_n, uint64_t* out_dev,
+                         char** err);
+int zkm_sha_extend_sponge_trace(zkm_ctx* ctx, const uint32_t* w16, const uint64_t* meta, size_t nblocks, unsigned log_n, uint64_t* out_dev,
+                                char** err);
+
 /* ------------------------------------------------------------------ N2: LogicStark witness
  * LogicStark::generate_trace (logic.rs:150-183) with Operation::into_row (:122-142): 69 columns x 2^log_n rows,
  * column-major; row r < nops holds operation r (flag column, the 32 little-endian bits of each input, the result),
@@ -156,13 +170,17 @@ void zkm_standard_config(zkm_stark_config* cfg);
  *   KECCAK_SPONGE  keccak_sponge_stark.rs:456-567        470 columns
  *   KECCAK         keccak/keccak_stark.rs:256-413       2431 columns
  *   MEMORY         memory/memory_stark.rs:253-341         13 columns, plus the range-check lookup :476-483
- *   POSEIDON_SPONGE poseidon_sponge/poseidon_sponge_stark.rs:383-478  110 columns */
+ *   POSEIDON_SPONGE poseidon_sponge/poseidon_sponge_stark.rs:383-478  110 columns
+ *   SHA_EXTEND     sha_extend/sha_extend_stark.rs:238-317              78 columns
+ *   SHA_EXTEND_SPONGE sha_extend_sponge/sha_extend_sponge_stark.rs:220-330  76 columns */
 #define ZKM_TABLE_POSEIDON 0
 #define ZKM_TABLE_LOGIC 1
 #define ZKM_TABLE_KECCAK_SPONGE 2
 #define ZKM_TABLE_KECCAK 3
 #define ZKM_TABLE_MEMORY 4
 #define ZKM_TABLE_POSEIDON_SPONGE 5
+#define ZKM_TABLE_SHA_EXTEND 6
+#define ZKM_TABLE_SHA_EXTEND_SPONGE 7
 #define ZKM_MEMORY_COLS 13
 size_t zkm_table_width(int table_id); /* 0 for an unknown id */
 /* Auxiliary columns the table's own logUp lookups (Stark::lookups(), lookup.rs:22-40) put in front of the CTL columns:

@@ -260,6 +260,63 @@ static void TNAME(eval_poseidon_sponge)(const T* lv, const T* nv, TNAME(consumer
     for (int i = 0; i < 32; i++) TNAME(cons)(k, T_MUL(lv[14 + i], T_SUB(offset, T_FROMB((gl_t)i))));
 }
 
+/* ---- ShaExtendStark constraints: sha_extend/sha_extend_stark.rs:238-317 with rotate_right.rs:29-62, shift_right.rs:29-60,
+ * wrapping_add_4.rs:35-78.  Columns (sha_extend/columns.rs:8-36): w_i value 0..3 carry 4..7, w_i_minus_15 8..11, w_i_minus_2 12..15,
+ * w_i_minus_16 16..19, w_i_minus_7 20..23, s_0_inter 24..27, s_0 28..31, s_1_inter 32..35, s_1 36..39, rotate/shift ops
+ * (value[4], shift, carry): rr_7 40, rr_18 46, rr_17 52, rr_19 58, rs_10 64, rs_3 70; timestamp 76, is_real_round 77 ---- */
+static inline T TNAME(le4)(const T* b) {
+    return T_ADD(T_ADD(b[0], T_MULB(b[1], 1u << 8)), T_ADD(T_MULB(b[2], 1u << 16), T_MULB(b[3], 1u << 24)));
+}
+static void TNAME(sha_rot)(const T* in, const T* op, unsigned r, int is_shift, TNAME(consumer) * k) {
+    T out = TNAME(le4)(op), inv = TNAME(le4)(in), shift = op[4], carry = op[5];
+    if (is_shift) TNAME(cons)(k, T_SUB(out, shift));
+    else TNAME(cons)(k, T_SUB(T_SUB(out, T_MULB(carry, (gl_t)1 << (32 - r))), shift));
+    TNAME(cons)(k, T_SUB(T_SUB(inv, T_MULB(shift, (gl_t)1 << r)), carry));
+}
+static void TNAME(eval_sha_extend)(const T* lv, TNAME(consumer) * k) {
+    TNAME(sha_rot)(lv + 8, lv + 40, 7, 0, k);
+    TNAME(sha_rot)(lv + 8, lv + 46, 18, 0, k);
+    TNAME(sha_rot)(lv + 12, lv + 52, 17, 0, k);
+    TNAME(sha_rot)(lv + 12, lv + 58, 19, 0, k);
+    TNAME(sha_rot)(lv + 8, lv + 70, 3, 1, k);
+    TNAME(sha_rot)(lv + 12, lv + 64, 10, 1, k);
+    /* w_i = s_1 + w_i_minus_7 + s_0 + w_i_minus_16, every constraint times is_real_round */
+    T real = lv[77], one = T_FROMB(1);
+    const T *a = lv + 36, *b = lv + 20, *c = lv + 28, *d = lv + 16, *val = lv, *cy = lv + 4;
+    for (int i = 0; i < 4; i++) TNAME(cons)(k, T_MUL(T_MUL(cy[i], T_SUB(one, cy[i])), real));
+    TNAME(cons)(k, T_MUL(T_SUB(T_ADD(T_ADD(cy[0], cy[1]), T_ADD(cy[2], cy[3])), one), real));
+    T carry = T_ADD(T_ADD(cy[1], T_MULB(cy[2], 2)), T_MULB(cy[3], 3));
+    T sum = T_FROMB(0);
+    for (int i = 3; i >= 0; i--) sum = T_ADD(T_MULB(sum, 1u << 8), T_ADD(T_ADD(a[i], b[i]), T_ADD(c[i], d[i])));
+    TNAME(cons)(k, T_MUL(T_SUB(T_SUB(sum, T_MULB(carry, (gl_t)1 << 32)), TNAME(le4)(val)), real));
+}
+
+/* ---- ShaExtendSpongeStark constraints: sha_extend_sponge/sha_extend_sponge_stark.rs:220-330.  Columns
+ * (sha_extend_sponge/columns.rs:7-33): round 0..47, w_i_minus_15 48..51, w_i_minus_2 52..55, w_i_minus_16 56..59, w_i_minus_7 60..63,
+ * w_i 64..67, input_virt 68..71, output_virt 72, context 73, segment 74, timestamp 75.  NUM_CHANNELS = 10 (cpu/membus.rs:10-32) ---- */
+static void TNAME(eval_sha_extend_sponge)(const T* lv, const T* nv, TNAME(consumer) * k) {
+    T one = T_FROMB(1);
+    for (int i = 0; i < 48; i++) TNAME(cons)(k, T_MUL(lv[i], T_SUB(lv[i], one)));
+    T is_final = lv[47];
+    TNAME(cons)(k, T_MUL(is_final, T_SUB(is_final, one)));
+    T not_final = T_SUB(one, is_final);
+    T sum = T_FROMB(0), lidx = T_FROMB(0), nidx = T_FROMB(0);
+    for (int i = 0; i < 48; i++) {
+        sum = T_ADD(sum, lv[i]);
+        lidx = T_ADD(lidx, T_MULB(lv[i], (gl_t)i));
+        nidx = T_ADD(nidx, T_MULB(nv[i], (gl_t)i));
+    }
+    T g = T_MUL(sum, not_final);
+    TNAME(cons)(k, T_MUL(g, T_SUB(T_SUB(nv[75], lv[75]), T_FROMB(20))));
+    TNAME(cons)(k, T_MUL(g, T_SUB(T_SUB(nidx, lidx), one)));
+    for (int i = 0; i < 4; i++) TNAME(cons)(k, T_MUL(g, T_SUB(T_SUB(nv[68 + i], lv[68 + i]), T_FROMB(4))));
+    TNAME(cons)(k, T_MUL(g, T_SUB(T_SUB(nv[72], lv[72]), T_FROMB(4))));
+    TNAME(cons)(k, T_MUL(sum, T_SUB(T_SUB(lv[68], lv[70]), T_FROMB(4))));
+    TNAME(cons)(k, T_MUL(sum, T_SUB(T_SUB(lv[69], lv[70]), T_FROMB(56))));
+    TNAME(cons)(k, T_MUL(sum, T_SUB(T_SUB(lv[71], lv[70]), T_FROMB(36))));
+    TNAME(cons)(k, T_MUL(sum, T_SUB(T_SUB(lv[72], lv[70]), T_FROMB(64))));
+}
+
 /* ---- MemoryStark constraints: memory/memory_stark.rs:253-341 (columns memory/columns.rs: FILTER 0, TIMESTAMP 1, IS_READ 2,
  * ADDR_CONTEXT 3, ADDR_SEGMENT 4, ADDR_VIRTUAL 5, VALUE 6 (VALUE_LIMBS = 1), CONTEXT/SEGMENT/VIRTUAL_FIRST_CHANGE 7..9,
  * RANGE_CHECK 10, COUNTER 11, FREQUENCIES 12) ---- */
@@ -338,14 +395,16 @@ static void TNAME(eval_lookups)(int table_id, const gl_t* challenges, size_t nch
 }
 
 /* table dispatch (Table ids of include/zkm_hip.h) */
-static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : table_id == 4 ? 13 : table_id == 5 ? 110 : 0; }
+static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : table_id == 4 ? 13 : table_id == 5 ? 110 : table_id == 6 ? 78 : table_id == 7 ? 76 : 0; }
 static void TNAME(eval_table)(int table_id, const T* lv, const T* nv, TNAME(consumer) * k) {
     if (table_id == 0) TNAME(eval_poseidon)(lv, k);
     else if (table_id == 1) TNAME(eval_logic)(lv, k);
     else if (table_id == 2) TNAME(eval_keccak_sponge)(lv, nv, k);
     else if (table_id == 3) TNAME(eval_keccak)(lv, nv, k);
     else if (table_id == 4) TNAME(eval_memory)(lv, nv, k);
-    else TNAME(eval_poseidon_sponge)(lv, nv, k);
+    else if (table_id == 5) TNAME(eval_poseidon_sponge)(lv, nv, k);
+    else if (table_id == 6) TNAME(eval_sha_extend)(lv, k);
+    else TNAME(eval_sha_extend_sponge)(lv, nv, k);
 }
 
 /* ---- general CTL checks driven by the column-set description ----

@@ -194,3 +194,77 @@ size_t zko_keccak_trace(const uint64_t* inputs, const uint64_t* timestamps, size
     }
     return nperms * 24;
 }
+
+/* ---- SHA-256 message-schedule tables ---- */
+static inline uint32_t rotr32(uint32_t x, unsigned r) { return (x >> r) | (x << (32 - r)); }
+static void put_le4(uint64_t* out, size_t n, size_t row, int col, uint32_t v) {
+    for (int j = 0; j < 4; j++) out[(size_t)(col + j) * n + row] = (v >> (8 * j)) & 0xFF;
+}
+static void put_rot(uint64_t* out, size_t n, size_t row, int col, uint32_t in, unsigned r, int is_shift) {
+    /* RotateRightOp / ShiftRightOp::generate_trace (rotate_right.rs:15-27, shift_right.rs:15-27), shr_carry :108-117 */
+    uint32_t shift = in >> r, carry = (uint32_t)(((uint64_t)in << (32 - r)) & 0xFFFFFFFFu) >> (32 - r);
+    put_le4(out, n, row, col, is_shift ? shift : rotr32(in, r));
+    out[(size_t)(col + 4) * n + row] = shift;
+    out[(size_t)(col + 5) * n + row] = carry;
+}
+/* ShaExtendStark::generate_trace (sha_extend/sha_extend_stark.rs:121-236): inputs = k x 16 bytes (w[i-15], w[i-2], w[i-16], w[i-7],
+ * little-endian bytes of each word), one timestamp per row; padding rows zero. */
+void zko_sha_extend_trace(const uint8_t* inputs, const uint64_t* timestamps, size_t k, unsigned log_n, uint64_t* out) {
+    size_t n = (size_t)1 << log_n;
+    memset(out, 0, sizeof(uint64_t) * 78 * n);
+    for (size_t r = 0; r < k && r < n; r++) {
+        uint32_t w[4];
+        for (int q = 0; q < 4; q++) { memcpy(&w[q], inputs + 16 * r + 4 * q, 4); put_le4(out, n, r, 8 + 4 * q, w[q]); }
+        uint32_t w15 = w[0], w2 = w[1], w16 = w[2], w7 = w[3];
+        put_rot(out, n, r, 40, w15, 7, 0);
+        put_rot(out, n, r, 46, w15, 18, 0);
+        put_rot(out, n, r, 70, w15, 3, 1);
+        uint32_t s0i = rotr32(w15, 7) ^ rotr32(w15, 18), s0 = s0i ^ (w15 >> 3);
+        put_le4(out, n, r, 24, s0i);
+        put_le4(out, n, r, 28, s0);
+        put_rot(out, n, r, 52, w2, 17, 0);
+        put_rot(out, n, r, 58, w2, 19, 0);
+        put_rot(out, n, r, 64, w2, 10, 1);
+        uint32_t s1i = rotr32(w2, 17) ^ rotr32(w2, 19), s1 = s1i ^ (w2 >> 10);
+        put_le4(out, n, r, 32, s1i);
+        put_le4(out, n, r, 36, s1);
+        uint64_t wide = (uint64_t)s1 + w7 + s0 + w16;
+        put_le4(out, n, r, 0, (uint32_t)wide);
+        out[(size_t)(4 + (wide >> 32)) * n + r] = 1;
+        out[(size_t)76 * n + r] = timestamps[r];
+        out[(size_t)77 * n + r] = 1;
+    }
+}
+/* ShaExtendSpongeStark::generate_trace (sha_extend_sponge_stark.rs:131-215) for k complete message schedules: w16 = k x 16
+ * words w[0..15]; meta = k x 4 {context, segment, address of w[0], timestamp of round 0}; word j lives at address + 4 j; round i
+ * (row 48 e + i) reads w[i+1], w[i+14], w[i], w[i+9], writes w[i+16] and is stamped timestamp + 20 i (2 * NUM_CHANNELS). */
+size_t zko_sha_extend_sponge_trace(const uint32_t* w16, const uint64_t* meta, size_t k, unsigned log_n, uint64_t* out) {
+    size_t n = (size_t)1 << log_n;
+    if (48 * k > n) return 0;
+    memset(out, 0, sizeof(uint64_t) * 76 * n);
+    for (size_t e = 0; e < k; e++) {
+        uint32_t w[64];
+        memcpy(w, w16 + 16 * e, 64);
+        for (int i = 16; i < 64; i++) {
+            uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+            uint32_t s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = s1 + w[i - 16] + s0 + w[i - 7];
+        }
+        for (int rd = 0; rd < 48; rd++) {
+            size_t row = 48 * e + rd;
+            int i = rd + 16;
+            out[(size_t)rd * n + row] = 1;
+            const int src[4] = {i - 15, i - 2, i - 16, i - 7};
+            for (int q = 0; q < 4; q++) {
+                put_le4(out, n, row, 48 + 4 * q, w[src[q]]);
+                out[(size_t)(68 + q) * n + row] = meta[4 * e + 2] + 4 * (uint64_t)src[q];
+            }
+            put_le4(out, n, row, 64, w[i]);
+            out[(size_t)72 * n + row] = meta[4 * e + 2] + 4 * (uint64_t)i;
+            out[(size_t)73 * n + row] = meta[4 * e];
+            out[(size_t)74 * n + row] = meta[4 * e + 1];
+            out[(size_t)75 * n + row] = meta[4 * e + 3] + 20 * (uint64_t)rd;
+        }
+    }
+    return 48 * k;
+}

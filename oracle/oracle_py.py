@@ -174,6 +174,25 @@ class Oracle:
         self.lib.zko_poseidon_trace_inputs(_ptr(inputs), _ptr(ts), len(inputs), log_n, _ptr(out))
         return out
 
+    def sha_extend_trace(self, inputs, timestamps, log_n):
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint8).reshape(-1, 16)
+        ts = np.ascontiguousarray(timestamps, dtype=np.uint64)
+        out = np.zeros(78 << log_n, dtype=np.uint64)
+        self.lib.zko_sha_extend_trace.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_uint, u64p]
+        self.lib.zko_sha_extend_trace(inputs.ctypes.data, _ptr(ts), len(inputs), log_n, _ptr(out))
+        return out
+
+    def sha_extend_sponge_trace(self, w16, meta, log_n):
+        w16 = np.ascontiguousarray(w16, dtype=np.uint32).reshape(-1, 16)
+        meta = np.ascontiguousarray(meta, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(76 << log_n, dtype=np.uint64)
+        self.lib.zko_sha_extend_sponge_trace.restype = C.c_size_t
+        self.lib.zko_sha_extend_sponge_trace.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_uint, u64p]
+        used = self.lib.zko_sha_extend_sponge_trace(w16.ctypes.data, _ptr(meta), len(w16), log_n, _ptr(out))
+        if used == 0 and len(w16):
+            raise RuntimeError("oracle sha_extend_sponge_trace: rounds do not fit")
+        return out, used
+
     # ---- NTT / commitment
     def ntt(self, cols, log_n, inverse=False, coset_shift=0):
         a = np.ascontiguousarray(cols, dtype=np.uint64).copy()

@@ -171,3 +171,48 @@ def build4(oracle, log_sponge=3, seed=23):
     ctls = [T.ctl_keccak_inputs(0, 1, cs, ck), T.ctl_keccak_outputs(0, 1, cs, ck), T.ctl_logic_keccak_sponge(0, 2, cs, cl),
             T.ctl_memory_keccak_sponge(0, 3, cs, cm)]
     return tables, ctls, (ops, inputs, ts, mem_ops)
+
+
+def build_sha_extend_path(oracle, nblocks=1, seed=51):
+    """Memory + ShaExtendSponge + ShaExtend + Logic: SHA-256 message schedules with the lookups the reference defines among
+    these tables (all_stark.rs:256-282, 356-385, 503-509)."""
+    rng = np.random.default_rng(seed)
+    w16 = rng.integers(0, 1 << 32, (nblocks, 16), dtype=np.uint64).astype(np.uint32)
+    meta = np.zeros((nblocks, 4), dtype=np.uint64)
+    meta[:, 1] = 1
+    meta[:, 2] = (1 << 22) + np.arange(nblocks) * 1024
+    meta[:, 3] = 7 + np.arange(nblocks) * 2000
+    log_s = int(np.ceil(np.log2(48 * nblocks + 1)))
+    sponge, used = oracle.sha_extend_sponge_trace(w16, meta, log_s)
+    n = 1 << log_s
+    tr = sponge.reshape(76, n)
+    rows = 48 * nblocks
+    inputs = tr[T.SES_W15:T.SES_W15 + 16, :rows].T.astype(np.uint8)
+    ts = tr[T.SES_TIMESTAMP, :rows].copy()
+    extend = oracle.sha_extend_trace(inputs, ts, log_s)
+    ex = extend.reshape(78, n)
+    le = lambda c, r: sum(int(ex[c + j, r]) << (8 * j) for j in range(4))
+    ops, mem = [], []
+    for r in range(rows):
+        for a, b in ((T.SE_RR7, T.SE_RR18), (T.SE_S0_INTER, T.SE_RS3), (T.SE_RR17, T.SE_RR19), (T.SE_S1_INTER, T.SE_RS10)):
+            ops.append((T.OP_XOR, le(a, r), le(b, r)))
+        for q in range(4):
+            val = sum(int(tr[T.SES_W15 + 4 * q + j, r]) << (8 * j) for j in range(4))
+            mem += [(int(tr[T.SES_CONTEXT, r]), int(tr[T.SES_SEGMENT, r]), int(tr[T.SES_IN_VIRT + q, r]), int(tr[T.SES_TIMESTAMP, r]), 1, val)] * 4
+    ops = np.array(ops, dtype=np.uint32)
+    np.random.default_rng(seed + 1).shuffle(ops, axis=0)
+    log_logic = int(np.ceil(np.log2(len(ops))))
+    logic = oracle.logic_trace(ops, log_logic)
+    mem_ops = np.array(mem, dtype=np.uint64).reshape(-1, 6)
+    log_mem = int(np.ceil(np.log2(len(mem_ops)))) + 1
+    memory, natural = oracle.memory_trace(mem_ops, log_mem)
+    if natural < (1 << log_mem):
+        log_mem -= 1
+        memory, natural = oracle.memory_trace(mem_ops, log_mem)
+    cs, ce, cl, cm = CtlTable(), CtlTable(), CtlTable(), CtlTable()
+    tables = [(T.TABLE_SHA_EXTEND_SPONGE, sponge, 76, log_s, cs), (T.TABLE_SHA_EXTEND, extend, 78, log_s, ce),
+              (T.TABLE_LOGIC, logic, 69, log_logic, cl), (T.TABLE_MEMORY, memory, 13, log_mem, cm)]
+    ctls = [T.ctl_sha_extend_inputs(0, 1, cs, ce), T.ctl_sha_extend_outputs(0, 1, cs, ce),
+            (T.logic_lookers_sha_extend(1, ce), (2, T.logic_ctl_data(cl))),
+            (T.memory_lookers_sha_extend_sponge(0, cs), (3, T.memory_ctl_data(cm)))]
+    return tables, ctls, (w16, meta, inputs, ts, ops, mem_ops)

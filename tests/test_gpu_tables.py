@@ -296,3 +296,37 @@ def test_both_precompile_paths_share_the_memory_table(ctx, oracle):
     got, chal, offs = ctx.prove_with_traces(tables, ctls)
     assert offs == woffs and (chal == wchal).all() and (got == want).all()
     assert oracle.verify_all(tables, ctls, got, chal) == 0
+
+
+@pytest.mark.parametrize("nblocks", [1, 20])
+def test_sha_extend_path_is_bit_exact_and_verifies(ctx, oracle, nblocks):
+    """Memory -> ShaExtendSponge -> ShaExtend -> Logic: SHA-256 message schedules (all_stark.rs:256-282, 356-385, 503-509)."""
+    tables, ctls, (w16, meta, inputs, ts, ops, mem_ops) = logic_fixtures.build_sha_extend_path(oracle, nblocks=nblocks)
+    log_s = tables[0][3]
+    assert (ctx.sha_extend_sponge_trace(w16, meta, log_s).download() == tables[0][1]).all()
+    assert (ctx.sha_extend_trace(inputs, ts, log_s).download() == tables[1][1]).all()
+    got, chal, offs = ctx.prove_with_traces(tables, ctls)
+    if nblocks == 1:
+        want, wchal, woffs = oracle.prove_with_traces(tables, ctls)
+        assert offs == woffs and (chal == wchal).all()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "first differing word %d" % bad[0]
+    assert oracle.verify_all(tables, ctls, got, chal) == 0
+
+
+@pytest.mark.parametrize("t_idx", [0, 1])
+def test_sha_extend_single_table_proofs(ctx, oracle, t_idx):
+    tables, ctls, _ = logic_fixtures.build_sha_extend_path(oracle, nblocks=2)
+    tid, trace, W, log_n, cs = tables[t_idx]
+    aux = fake_ctl_aux(log_n)
+    want = oracle.prove(trace, log_n, aux, [2], ncols=W, table_id=tid)
+    got = ctx.prove_single_table(trace, log_n, aux, [2], ncols=W, table_id=tid)
+    assert (got == want).all()
+    assert oracle.verify(got, 3, [2], ncols=W, table_id=tid) == 0
+
+
+def test_sha_extend_trace_errors(ctx, zkm):
+    with pytest.raises(zkm.ZkmError, match="48 each"):
+        ctx.sha_extend_sponge_trace(np.zeros((2, 16), dtype=np.uint32), np.zeros((2, 4), dtype=np.uint64), 6)
+    with pytest.raises(zkm.ZkmError, match="more rows"):
+        ctx.sha_extend_trace(np.zeros((9, 16), dtype=np.uint8), np.zeros(9, dtype=np.uint64), 3)

@@ -197,3 +197,29 @@ def test_poseidon_sponge_trace_and_path(oracle):
     aux_tables = [(tid, bad, w, log_n, cs)] + tables[1:]
     proofs, chal, offs = oracle.prove_with_traces(aux_tables, ctls)
     assert oracle.verify_all(aux_tables, ctls, proofs, chal) != 0
+
+
+def test_sha_extend_path(oracle):
+    import hashlib, struct
+    tables, ctls, (w16, meta, inputs, ts, ops, mem_ops) = logic_fixtures.build_sha_extend_path(oracle)
+    # the 48 output words are the SHA-256 message schedule w[16..63] of the block
+    tr = tables[0][1].reshape(76, -1)
+    w = [int(x) for x in w16[0]]
+    rotr = lambda x, r: ((x >> r) | (x << (32 - r))) & 0xFFFFFFFF
+    for i in range(16, 64):
+        s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3)
+        s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10)
+        w.append((w[i - 16] + s0 + w[i - 7] + s1) & 0xFFFFFFFF)
+        assert sum(int(tr[64 + j, i - 16]) << (8 * j) for j in range(4)) == w[i]
+    assert oracle.check_ctls(tables, ctls) == 0
+    proofs, chal, offs = oracle.prove_with_traces(tables, ctls)
+    assert oracle.verify_all(tables, ctls, proofs, chal) == 0
+    # a wrong carry flag in the ShaExtend table / a skipped round in the sponge table
+    for t_idx, col in ((1, 4), (0, 75)):
+        tid, trace, width, log_n, ct = tables[t_idx]
+        bad = trace.copy()
+        bad[col * (1 << log_n) + 5] += 1
+        bt = list(tables)
+        bt[t_idx] = (tid, bad, width, log_n, ct)
+        proofs, chal, offs = oracle.prove_with_traces(bt, ctls)
+        assert oracle.verify_all(bt, ctls, proofs, chal) != 0

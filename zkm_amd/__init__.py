@@ -23,6 +23,7 @@ LOGIC_COLS = 69
 KECCAK_COLS = 2431
 POSEIDON_SPONGE_COLS = 110
 TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY, TABLE_POSEIDON_SPONGE = 0, 1, 2, 3, 4, 5
+TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE = 6, 7
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
@@ -30,7 +31,7 @@ EXPORTS = [
     "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_free",
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_keccak_trace", "zkm_logic_trace",
-    "zkm_poseidon_sponge_trace", "zkm_poseidon_trace_inputs",
+    "zkm_poseidon_sponge_trace", "zkm_poseidon_trace_inputs", "zkm_sha_extend_trace", "zkm_sha_extend_sponge_trace",
     "zkm_table_width", "zkm_num_lookup_columns", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
     "zkm_prove_single_table", "zkm_prove_openings", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
@@ -101,6 +102,8 @@ def load():
         "zkm_keccak_sponge_trace": (C.c_int, [cp, cp, u64p, u64p, C.c_size_t, C.c_uint, cp, C.POINTER(C.c_size_t), err]),
         "zkm_poseidon_sponge_trace": (C.c_int, [cp, cp, u64p, u64p, C.c_size_t, C.c_uint, cp, C.POINTER(C.c_size_t), err]),
         "zkm_poseidon_trace_inputs": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
+        "zkm_sha_extend_trace": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
+        "zkm_sha_extend_sponge_trace": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_keccak_trace": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_logic_trace": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_table_width": (C.c_size_t, [C.c_int]),
@@ -288,6 +291,26 @@ class Context:
         err = C.c_char_p()
         _check(self.L.zkm_poseidon_trace_inputs(self.h, _data_ptr(inputs), _data_ptr(timestamps), len(inputs), log_n, _data_ptr(out),
                                                 C.byref(err)), err)
+        return out
+
+    def sha_extend_trace(self, inputs, timestamps, log_n, out=None):
+        """ShaExtendStark::generate_trace on the GPU: inputs nrows x 16 bytes, one timestamp per row; 78 x 2^log_n words."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint8).reshape(-1, 16)
+        timestamps = np.ascontiguousarray(timestamps, dtype=np.uint64)
+        out = out or self.alloc(78 << log_n)
+        err = C.c_char_p()
+        _check(self.L.zkm_sha_extend_trace(self.h, inputs.ctypes.data_as(C.c_void_p), _data_ptr(timestamps), len(inputs), log_n,
+                                           _data_ptr(out), C.byref(err)), err)
+        return out
+
+    def sha_extend_sponge_trace(self, w16, meta, log_n, out=None):
+        """ShaExtendSpongeStark::generate_trace on the GPU for complete schedules: w16 nblocks x 16 uint32, meta nblocks x 4."""
+        w16 = np.ascontiguousarray(w16, dtype=np.uint32).reshape(-1, 16)
+        meta = np.ascontiguousarray(meta, dtype=np.uint64).reshape(-1, 4)
+        out = out or self.alloc(76 << log_n)
+        err = C.c_char_p()
+        _check(self.L.zkm_sha_extend_sponge_trace(self.h, w16.ctypes.data_as(C.c_void_p), _data_ptr(meta), len(w16), log_n,
+                                                  _data_ptr(out), C.byref(err)), err)
         return out
 
     def keccak_trace(self, inputs, timestamps, log_n, out=None):

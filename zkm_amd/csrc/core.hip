@@ -494,8 +494,61 @@ size_t zkm_table_width(int table_id) {
         case ZKM_TABLE_KECCAK: return ZKM_KECCAK_COLS;
         case ZKM_TABLE_MEMORY: return ZKM_MEMORY_COLS;
         case ZKM_TABLE_POSEIDON_SPONGE: return ZKM_POSEIDON_SPONGE_COLS;
+        case ZKM_TABLE_SHA_EXTEND: return ZKM_SHA_EXTEND_COLS;
+        case ZKM_TABLE_SHA_EXTEND_SPONGE: return ZKM_SHA_EXTEND_SPONGE_COLS;
         default: return 0;
     }
+}
+
+// host -> device staging of small argument arrays for the witness entry points
+static const void* stage_arg(zkm_ctx* c, std::vector<void*>& tmp, const void* p, size_t bytes) {
+    if (!bytes || zkm_is_device_ptr(p)) return p;
+    void* d = c->alloc(bytes);
+    tmp.push_back(d);
+    ZKM_HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream));
+    return d;
+}
+
+int zkm_sha_extend_trace(zkm_ctx* c, const uint8_t* inputs, const uint64_t* timestamps, size_t nrows, unsigned log_n, uint64_t* out_dev,
+                         char** err) {
+    std::vector<void*> tmp;
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!zkm_is_device_ptr(out_dev)) throw std::runtime_error("zkm_sha_extend_trace: out must be a device pointer");
+        size_t n = (size_t)1 << log_n;
+        if (nrows > n) throw std::runtime_error("zkm_sha_extend_trace: more rows than 2^log_n");
+        const uint8_t* d_in = (const uint8_t*)stage_arg(c, tmp, inputs, nrows * 16);
+        const uint64_t* d_ts = (const uint64_t*)stage_arg(c, tmp, timestamps, nrows * 8);
+        zkm_launch_sha_extend_trace(c, d_in, d_ts, nrows, n, out_dev);
+        c->sync();
+        for (void* p : tmp) c->release(p);
+    } catch (const std::exception& e) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* p : tmp) c->release(p);
+        return fail(err, e.what());
+    }
+    return 0;
+}
+
+int zkm_sha_extend_sponge_trace(zkm_ctx* c, const uint32_t* w16, const uint64_t* meta, size_t nblocks, unsigned log_n, uint64_t* out_dev,
+                                char** err) {
+    std::vector<void*> tmp;
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!zkm_is_device_ptr(out_dev)) throw std::runtime_error("zkm_sha_extend_sponge_trace: out must be a device pointer");
+        size_t n = (size_t)1 << log_n;
+        if (48 * nblocks > n) throw std::runtime_error("zkm_sha_extend_sponge_trace: message schedules need more rows than 2^log_n (48 each)");
+        const uint32_t* d_w = (const uint32_t*)stage_arg(c, tmp, w16, nblocks * 64);
+        const uint64_t* d_meta = (const uint64_t*)stage_arg(c, tmp, meta, nblocks * 32);
+        zkm_launch_sha_extend_sponge_trace(c, d_w, d_meta, nblocks, n, out_dev);
+        c->sync();
+        for (void* p : tmp) c->release(p);
+    } catch (const std::exception& e) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* p : tmp) c->release(p);
+        return fail(err, e.what());
+    }
+    return 0;
 }
 
 int zkm_keccak_trace(zkm_ctx* c, const uint64_t* inputs, const uint64_t* timestamps, size_t nperms, unsigned log_n, uint64_t* out_dev,

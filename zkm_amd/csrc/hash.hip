@@ -566,3 +566,105 @@ void zkm_launch_poseidon_sponge_trace(zkm_ctx* c, const uint8_t* d_inputs, const
     hipLaunchKernelGGL(k_poseidon_sponge_trace, dim3((nops + 127) / 128), dim3(128), 0, c->stream, d_inputs, d_off, d_meta, d_row_off, nops, n, out);
     ZKM_HIP_CHECK(hipGetLastError());
 }
+
+// ------------------------------------------------------------------ SHA-256 message-schedule witnesses
+// ShaExtendStark::generate_trace (sha_extend/sha_extend_stark.rs:121-236) and ShaExtendSpongeStark::generate_trace
+// (sha_extend_sponge/sha_extend_sponge_stark.rs:131-215).  One thread per row, column-major coalesced stores.
+__device__ __forceinline__ uint32_t rotr32_dev(uint32_t x, unsigned r) { return (x >> r) | (x << (32 - r)); }
+__device__ __forceinline__ void put_le4_dev(gl_t* o, size_t n, int col, uint32_t v) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[(size_t)(col + j) * n] = (v >> (8 * j)) & 0xFF;
+}
+__device__ __forceinline__ void put_rot_dev(gl_t* o, size_t n, int col, uint32_t in, unsigned r, bool is_shift) {
+    uint32_t shift = in >> r, carry = in & ((1u << r) - 1);
+    put_le4_dev(o, n, col, is_shift ? shift : rotr32_dev(in, r));
+    o[(size_t)(col + 4) * n] = shift;
+    o[(size_t)(col + 5) * n] = carry;
+}
+__global__ __launch_bounds__(256) void k_sha_extend_trace(const uint8_t* __restrict__ inputs, const uint64_t* __restrict__ ts, size_t k,
+                                                          size_t n, gl_t* __restrict__ out) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    gl_t* o = out + r;
+    if (r >= k) {
+        for (int c = 0; c < ZKM_SHA_EXTEND_COLS; c++) o[(size_t)c * n] = 0;
+        return;
+    }
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint8_t* b = inputs + 16 * r + 4 * q;
+        w[q] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        put_le4_dev(o, n, 8 + 4 * q, w[q]);
+    }
+    const uint32_t w15 = w[0], w2 = w[1], w16 = w[2], w7 = w[3];
+    put_rot_dev(o, n, 40, w15, 7, false);
+    put_rot_dev(o, n, 46, w15, 18, false);
+    put_rot_dev(o, n, 70, w15, 3, true);
+    const uint32_t s0i = rotr32_dev(w15, 7) ^ rotr32_dev(w15, 18), s0 = s0i ^ (w15 >> 3);
+    put_le4_dev(o, n, 24, s0i);
+    put_le4_dev(o, n, 28, s0);
+    put_rot_dev(o, n, 52, w2, 17, false);
+    put_rot_dev(o, n, 58, w2, 19, false);
+    put_rot_dev(o, n, 64, w2, 10, true);
+    const uint32_t s1i = rotr32_dev(w2, 17) ^ rotr32_dev(w2, 19), s1 = s1i ^ (w2 >> 10);
+    put_le4_dev(o, n, 32, s1i);
+    put_le4_dev(o, n, 36, s1);
+    const uint64_t wide = (uint64_t)s1 + w7 + s0 + w16;
+    put_le4_dev(o, n, 0, (uint32_t)wide);
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) o[(size_t)(4 + c) * n] = (uint32_t)(wide >> 32) == c;
+    o[(size_t)76 * n] = ts[r];
+    o[(size_t)77 * n] = 1;
+}
+
+// row = 48 e + round; the thread recomputes the schedule of its block up to its round (at most 48 cheap steps)
+__global__ __launch_bounds__(256) void k_sha_extend_sponge_trace(const uint32_t* __restrict__ w16, const uint64_t* __restrict__ meta, size_t k,
+                                                                 size_t n, gl_t* __restrict__ out) {
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    gl_t* o = out + row;
+    size_t e = row / 48;
+    int rd = (int)(row - e * 48);
+    if (e >= k) {
+        for (int c = 0; c < ZKM_SHA_EXTEND_SPONGE_COLS; c++) o[(size_t)c * n] = 0;
+        return;
+    }
+    uint32_t w[16];  // sliding window: w[j & 15] holds word j
+#pragma unroll
+    for (int j = 0; j < 16; j++) w[j] = w16[16 * e + j];
+    uint32_t in[4] = {0, 0, 0, 0}, outw = 0;
+    for (int i = 16; i <= rd + 16; i++) {
+        uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15], w16v = w[(i - 16) & 15], w7 = w[(i - 7) & 15];
+        uint32_t s0 = rotr32_dev(w15, 7) ^ rotr32_dev(w15, 18) ^ (w15 >> 3);
+        uint32_t s1 = rotr32_dev(w2, 17) ^ rotr32_dev(w2, 19) ^ (w2 >> 10);
+        outw = s1 + w16v + s0 + w7;
+        in[0] = w15; in[1] = w2; in[2] = w16v; in[3] = w7;
+        w[i & 15] = outw;
+    }
+    for (int i = 0; i < 48; i++) o[(size_t)i * n] = i == rd;
+    const int i = rd + 16;
+    const int src[4] = {i - 15, i - 2, i - 16, i - 7};
+    const uint64_t base = meta[4 * e + 2];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        put_le4_dev(o, n, 48 + 4 * q, in[q]);
+        o[(size_t)(68 + q) * n] = base + 4 * (uint64_t)src[q];
+    }
+    put_le4_dev(o, n, 64, outw);
+    o[(size_t)72 * n] = base + 4 * (uint64_t)i;
+    o[(size_t)73 * n] = meta[4 * e];
+    o[(size_t)74 * n] = meta[4 * e + 1];
+    o[(size_t)75 * n] = meta[4 * e + 3] + 20 * (uint64_t)rd;
+}
+
+void zkm_launch_sha_extend_trace(zkm_ctx* c, const uint8_t* d_inputs, const uint64_t* d_ts, size_t k, size_t n, gl_t* out) {
+    zkm_prof_scope ps(c, "sha_extend_trace");
+    hipLaunchKernelGGL(k_sha_extend_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_inputs, d_ts, k, n, out);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+void zkm_launch_sha_extend_sponge_trace(zkm_ctx* c, const uint32_t* d_w16, const uint64_t* d_meta, size_t k, size_t n, gl_t* out) {
+    zkm_prof_scope ps(c, "sha_extend_sponge_trace");
+    hipLaunchKernelGGL(k_sha_extend_sponge_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_w16, d_meta, k, n, out);
+    ZKM_HIP_CHECK(hipGetLastError());
+}

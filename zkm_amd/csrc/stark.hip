@@ -386,6 +386,70 @@ __device__ void eval_poseidon_sponge_constraints(const gl_t* __restrict__ lv, si
     for (int i = 0; i < 32; i++) k.constraint(gl_mul(lv[(size_t)(FINAL_LEN + i) * cs], gl_sub(offset, (gl_t)i)));
 }
 
+// ShaExtendStark (sha_extend/sha_extend_stark.rs:238-317; rotate_right.rs:29-62, shift_right.rs:29-60, wrapping_add_4.rs:35-78)
+__device__ __forceinline__ gl_t sha_le4(const gl_t* __restrict__ b, size_t cs) {
+    return gl_add(gl_add(b[0], gl_mul(b[cs], 1u << 8)), gl_add(gl_mul(b[2 * cs], 1u << 16), gl_mul(b[3 * cs], 1u << 24)));
+}
+template <int NA>
+__device__ __forceinline__ void sha_rot_constraints(const gl_t* __restrict__ in, const gl_t* __restrict__ op, size_t cs, unsigned r,
+                                                    bool is_shift, consumer_t<NA>& k) {
+    gl_t out = sha_le4(op, cs), inv = sha_le4(in, cs), shift = op[4 * cs], carry = op[5 * cs];
+    if (is_shift) k.constraint(gl_sub(out, shift));
+    else k.constraint(gl_sub(gl_sub(out, gl_mul(carry, (gl_t)1 << (32 - r))), shift));
+    k.constraint(gl_sub(gl_sub(inv, gl_mul(shift, (gl_t)1 << r)), carry));
+}
+template <int NA>
+__device__ void eval_sha_extend_constraints(const gl_t* __restrict__ lv, size_t cs, consumer_t<NA>& k) {
+    sha_rot_constraints<NA>(lv + 8 * cs, lv + 40 * cs, cs, 7, false, k);
+    sha_rot_constraints<NA>(lv + 8 * cs, lv + 46 * cs, cs, 18, false, k);
+    sha_rot_constraints<NA>(lv + 12 * cs, lv + 52 * cs, cs, 17, false, k);
+    sha_rot_constraints<NA>(lv + 12 * cs, lv + 58 * cs, cs, 19, false, k);
+    sha_rot_constraints<NA>(lv + 8 * cs, lv + 70 * cs, cs, 3, true, k);
+    sha_rot_constraints<NA>(lv + 12 * cs, lv + 64 * cs, cs, 10, true, k);
+    gl_t real = lv[77 * cs];
+    const gl_t *a = lv + 36 * cs, *b = lv + 20 * cs, *c = lv + 28 * cs, *d = lv + 16 * cs, *cy = lv + 4 * cs;
+    gl_t c0 = cy[0], c1 = cy[cs], c2 = cy[2 * cs], c3 = cy[3 * cs];
+    k.constraint(gl_mul(gl_mul(c0, gl_sub(1, c0)), real));
+    k.constraint(gl_mul(gl_mul(c1, gl_sub(1, c1)), real));
+    k.constraint(gl_mul(gl_mul(c2, gl_sub(1, c2)), real));
+    k.constraint(gl_mul(gl_mul(c3, gl_sub(1, c3)), real));
+    k.constraint(gl_mul(gl_sub(gl_add(gl_add(c0, c1), gl_add(c2, c3)), 1), real));
+    gl_t carry = gl_add(gl_add(c1, gl_add(c2, c2)), gl_mul(c3, 3));
+    gl_t sum = 0;
+#pragma unroll
+    for (int i = 3; i >= 0; i--)
+        sum = gl_add(gl_mul(sum, 1u << 8), gl_add(gl_add(a[(size_t)i * cs], b[(size_t)i * cs]), gl_add(c[(size_t)i * cs], d[(size_t)i * cs])));
+    k.constraint(gl_mul(gl_sub(gl_sub(sum, gl_mul(carry, (gl_t)1 << 32)), sha_le4(lv, cs)), real));
+}
+
+// ShaExtendSpongeStark (sha_extend_sponge/sha_extend_sponge_stark.rs:220-330); NUM_CHANNELS = 10 (cpu/membus.rs:10-32)
+template <int NA>
+__device__ void eval_sha_extend_sponge_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
+    const gl_t* __restrict__ nv = lv + dnext;
+    gl_t sum = 0, lidx = 0, nidx = 0;
+#pragma unroll 4
+    for (int i = 0; i < 48; i++) {
+        gl_t f = lv[(size_t)i * cs];
+        k.constraint(gl_mul(f, gl_sub(f, 1)));
+        sum = gl_add(sum, f);
+        lidx = gl_add(lidx, gl_mul(f, (gl_t)i));
+        nidx = gl_add(nidx, gl_mul(nv[(size_t)i * cs], (gl_t)i));
+    }
+    gl_t is_final = lv[(size_t)47 * cs];
+    k.constraint(gl_mul(is_final, gl_sub(is_final, 1)));
+    gl_t g = gl_mul(sum, gl_sub(1, is_final));
+    k.constraint(gl_mul(g, gl_sub(gl_sub(nv[(size_t)75 * cs], lv[(size_t)75 * cs]), 20)));
+    k.constraint(gl_mul(g, gl_sub(gl_sub(nidx, lidx), 1)));
+#pragma unroll
+    for (int i = 0; i < 5; i++)  // the four input addresses, then the output address
+        k.constraint(gl_mul(g, gl_sub(gl_sub(nv[(size_t)(68 + i) * cs], lv[(size_t)(68 + i) * cs]), 4)));
+    gl_t a16 = lv[(size_t)70 * cs];
+    k.constraint(gl_mul(sum, gl_sub(gl_sub(lv[(size_t)68 * cs], a16), 4)));
+    k.constraint(gl_mul(sum, gl_sub(gl_sub(lv[(size_t)69 * cs], a16), 56)));
+    k.constraint(gl_mul(sum, gl_sub(gl_sub(lv[(size_t)71 * cs], a16), 36)));
+    k.constraint(gl_mul(sum, gl_sub(gl_sub(lv[(size_t)72 * cs], a16), 64)));
+}
+
 // MemoryStark (memory/memory_stark.rs:253-341; columns memory/columns.rs, VALUE_LIMBS = 1)
 template <int NA>
 __device__ void eval_memory_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
@@ -459,7 +523,9 @@ __device__ __forceinline__ void eval_table_constraints(const gl_t* __restrict__ 
     else if constexpr (TABLE == ZKM_TABLE_KECCAK_SPONGE) eval_keccak_sponge_constraints<NA>(lv, cs, dnext, k);
     else if constexpr (TABLE == ZKM_TABLE_KECCAK) eval_keccak_constraints<NA>(lv, cs, dnext, k);
     else if constexpr (TABLE == ZKM_TABLE_MEMORY) eval_memory_constraints<NA>(lv, cs, dnext, k);
-    else eval_poseidon_sponge_constraints<NA>(lv, cs, dnext, k);
+    else if constexpr (TABLE == ZKM_TABLE_POSEIDON_SPONGE) eval_poseidon_sponge_constraints<NA>(lv, cs, dnext, k);
+    else if constexpr (TABLE == ZKM_TABLE_SHA_EXTEND) eval_sha_extend_constraints<NA>(lv, cs, k);
+    else eval_sha_extend_sponge_constraints<NA>(lv, cs, dnext, k);
 }
 
 // CTL checks driven by the column-set description (eval_helper_columns cross_table_lookup.rs:1006-1058,
@@ -591,7 +657,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     ZKM_HIP_CHECK(hipMemcpyAsync(d_alphas, alphas_host, nalphas * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
     gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
     {
-        static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory", "quotient_poseidon_sponge"};
+        static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory", "quotient_poseidon_sponge", "quotient_sha_extend", "quotient_sha_extend_sponge"};
         zkm_prof_scope ps(c, names[table_id]);
         dim3 grid((size + 255) / 256), block(256);
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
@@ -609,7 +675,11 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             case 8: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_MEMORY, 1); break;
             case 9: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_MEMORY, 2); break;
             case 10: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON_SPONGE, 1); break;
-            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON_SPONGE, 2); break;
+            case 11: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON_SPONGE, 2); break;
+            case 12: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_EXTEND, 1); break;
+            case 13: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_EXTEND, 2); break;
+            case 14: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_EXTEND_SPONGE, 1); break;
+            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_EXTEND_SPONGE, 2); break;
         }
 #undef ZKM_LAUNCH_QUOTIENT
         ZKM_HIP_CHECK(hipGetLastError());

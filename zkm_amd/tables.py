@@ -9,7 +9,9 @@ include/zkm_hip.h); mirrors
 from .ctl import CtlTable
 
 TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY, TABLE_POSEIDON_SPONGE = 0, 1, 2, 3, 4, 5
-WIDTH = {TABLE_POSEIDON: 262, TABLE_LOGIC: 69, TABLE_KECCAK_SPONGE: 470, TABLE_KECCAK: 2431, TABLE_MEMORY: 13, TABLE_POSEIDON_SPONGE: 110}
+TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE = 6, 7
+WIDTH = {TABLE_POSEIDON: 262, TABLE_LOGIC: 69, TABLE_KECCAK_SPONGE: 470, TABLE_KECCAK: 2431, TABLE_MEMORY: 13, TABLE_POSEIDON_SPONGE: 110,
+         TABLE_SHA_EXTEND: 78, TABLE_SHA_EXTEND_SPONGE: 76}
 
 # LogicStark columns (logic.rs:25-50)
 LOGIC_IS_AND, LOGIC_IS_OR, LOGIC_IS_XOR, LOGIC_IS_NOR = 0, 1, 2, 3
@@ -26,6 +28,12 @@ POS_FILTER, POS_IN, POS_OUT, POS_TIMESTAMP = 0, 1, 13, 25
 PS_FULL, PS_CONTEXT, PS_SEGMENT, PS_VIRT, PS_TIMESTAMP, PS_LEN, PS_ABSORBED, PS_FINAL_LEN = 0, 1, 2, 3, 11, 12, 13, 14
 PS_ORIG_RATE, PS_ORIG_CAP, PS_BLOCK, PS_NEW_RATE, PS_PARTIAL, PS_DIGEST = 46, 54, 58, 90, 98, 106
 POSEIDON_RATE_BYTES = 32
+
+# ShaExtendStark (sha_extend/columns.rs:8-36) and ShaExtendSpongeStark (sha_extend_sponge/columns.rs:7-33) columns
+SE_W_I, SE_W15, SE_W2, SE_W16, SE_W7, SE_S0_INTER, SE_S0, SE_S1_INTER, SE_S1 = 0, 8, 12, 16, 20, 24, 28, 32, 36
+SE_RR7, SE_RR18, SE_RR17, SE_RR19, SE_RS10, SE_RS3, SE_TIMESTAMP, SE_IS_REAL = 40, 46, 52, 58, 64, 70, 76, 77
+SES_ROUND, SES_W15, SES_W2, SES_W16, SES_W7, SES_W_I, SES_IN_VIRT, SES_OUT_VIRT, SES_CONTEXT, SES_SEGMENT, SES_TIMESTAMP = (
+    0, 48, 52, 56, 60, 64, 68, 72, 73, 74, 75)
 
 # MemoryStark columns (memory/columns.rs)
 MEM_FILTER, MEM_TIMESTAMP, MEM_IS_READ, MEM_CONTEXT, MEM_SEGMENT, MEM_VIRTUAL, MEM_VALUE = 0, 1, 2, 3, 4, 5, 6
@@ -216,3 +224,77 @@ def memory_lookers_poseidon_sponge(sponge_index, sponge_ctl):
 
 def memory_lookers_keccak_sponge(sponge_index, sponge_ctl):
     return [(sponge_index, keccak_sponge_looking_memory(sponge_ctl, i)) for i in range(KECCAK_RATE_BYTES)]
+
+
+def sha_extend_ctl_data_inputs(t: CtlTable):
+    """sha_extend_stark::ctl_data_inputs() with ctl_filter() (sha_extend_stark.rs:31-45, :110-114)."""
+    cols = list(range(SE_W15, SE_W15 + 4)) + list(range(SE_W2, SE_W2 + 4)) + list(range(SE_W16, SE_W16 + 4)) + list(range(SE_W7, SE_W7 + 4))
+    return t.singles_set(cols + [SE_TIMESTAMP], filter_col=SE_IS_REAL)
+
+
+def sha_extend_ctl_data_outputs(t: CtlTable):
+    """sha_extend_stark::ctl_data_outputs() with ctl_filter() (sha_extend_stark.rs:47-52)."""
+    return t.singles_set(list(range(SE_W_I, SE_W_I + 4)) + [SE_TIMESTAMP], filter_col=SE_IS_REAL)
+
+
+def sha_extend_looking_logic(t: CtlTable, which):
+    """ctl_s_0_inter / s_0 / s_1_inter / s_1 _looking_logic() with ctl_filter() (sha_extend_stark.rs:54-108): an XOR of two
+    little-endian byte quadruples."""
+    in0, in1, out = {"s_0_inter": (SE_RR7, SE_RR18, SE_S0_INTER), "s_0": (SE_S0_INTER, SE_RS3, SE_S0),
+                     "s_1_inter": (SE_RR17, SE_RR19, SE_S1_INTER), "s_1": (SE_S1_INTER, SE_RS10, SE_S1)}[which]
+    first = t.constant(0b100110 << 6)
+    for c in (in0, in1, out):
+        t.le_bytes(range(c, c + 4))
+    f = t.single(SE_IS_REAL)
+    return t.colset(range(first, first + 4), filter_constants=[f])
+
+
+def _ses_filter(t: CtlTable):
+    return t.sum(range(SES_ROUND, SES_ROUND + 48))
+
+
+def sha_extend_sponge_looking_inputs(t: CtlTable):
+    """sha_extend_sponge_stark::ctl_looking_sha_extend_inputs() with ctl_looking_sha_extend_filter() (:31-45, :106-110)."""
+    first = len(t._cols)
+    for c in list(range(SES_W15, SES_W15 + 16)) + [SES_TIMESTAMP]:
+        t.single(c)
+    return t.colset(range(first, first + 17), filter_constants=[_ses_filter(t)])
+
+
+def sha_extend_sponge_looking_outputs(t: CtlTable):
+    first = len(t._cols)
+    for c in list(range(SES_W_I, SES_W_I + 4)) + [SES_TIMESTAMP]:
+        t.single(c)
+    return t.colset(range(first, first + 5), filter_constants=[_ses_filter(t)])
+
+
+def sha_extend_sponge_looking_memory(t: CtlTable, i):
+    """sha_extend_sponge_stark::ctl_looking_memory(i) (:67-104): byte i belongs to input word i / 4, read as a little-endian u32."""
+    q = i // 4
+    first = t.constant(1)
+    t.single(SES_CONTEXT)
+    t.single(SES_SEGMENT)
+    t.single(SES_IN_VIRT + q)
+    t.le_bytes(range(SES_W15 + 4 * q, SES_W15 + 4 * q + 4))
+    t.single(SES_TIMESTAMP)
+    return t.colset(range(first, first + 6), filter_constants=[_ses_filter(t)])
+
+
+def ctl_sha_extend_inputs(sponge_index, extend_index, sponge_ctl, extend_ctl):
+    """all_stark::ctl_sha_extend_inputs() (all_stark.rs:256-268)."""
+    return [(sponge_index, sha_extend_sponge_looking_inputs(sponge_ctl))], (extend_index, sha_extend_ctl_data_inputs(extend_ctl))
+
+
+def ctl_sha_extend_outputs(sponge_index, extend_index, sponge_ctl, extend_ctl):
+    """all_stark::ctl_sha_extend_outputs() (all_stark.rs:270-282)."""
+    return [(sponge_index, sha_extend_sponge_looking_outputs(sponge_ctl))], (extend_index, sha_extend_ctl_data_outputs(extend_ctl))
+
+
+def logic_lookers_sha_extend(extend_index, extend_ctl):
+    """The ShaExtend part of all_stark::ctl_logic() (all_stark.rs:356-385), in the reference's order."""
+    return [(extend_index, sha_extend_looking_logic(extend_ctl, w)) for w in ("s_0_inter", "s_0", "s_1_inter", "s_1")]
+
+
+def memory_lookers_sha_extend_sponge(sponge_index, sponge_ctl):
+    """The ShaExtendSponge part of all_stark::ctl_memory() (all_stark.rs:503-509): 16 looking column sets."""
+    return [(sponge_index, sha_extend_sponge_looking_memory(sponge_ctl, i)) for i in range(16)]
