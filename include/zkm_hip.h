@@ -136,6 +136,19 @@ int zkm_sha_extend_trace(zkm_ctx* ctx, const uint8_t* inputs, const uint64_t* ti
 int zkm_sha_extend_sponge_trace(zkm_ctx* ctx, const uint32_t* w16, const uint64_t* meta, size_t nblocks, unsigned log_n, uint64_t* out_dev,
                                 char** err);
 
+/* SHA-256 compression witnesses for ncomp compressions: hx = ncomp x 8 words (a..h before the block), w = ncomp x 64 schedule
+ * words, meta = ncomp x 8 {context, segment, address of hx[0], timestamp, address of w[0], segment of w, context of w, unused}.
+ * ShaCompressStark::generate_trace (sha_compress/sha_compress_stark.rs:227-400; rows as emitted by witness/util.rs:605-690):
+ * 224 columns, 65 rows per compression -- rounds 0..63 on the running state with w_i and K_i, then the final state with
+ * w_i = k_i = 0.  ShaCompressSpongeStark::generate_trace (sha_compress_sponge/sha_compress_sponge_stark.rs:118-230): 127
+ * columns, one row per compression (hx, the compressed state, hx + state with carry flags, addresses). */
+#define ZKM_SHA_COMPRESS_COLS 224
+#define ZKM_SHA_COMPRESS_SPONGE_COLS 127
+int zkm_sha_compress_trace(zkm_ctx* ctx, const uint32_t* hx, const uint32_t* w, const uint64_t* meta, size_t ncomp, unsigned log_n,
+                           uint64_t* out_dev, char** err);
+int zkm_sha_compress_sponge_trace(zkm_ctx* ctx, const uint32_t* hx, const uint32_t* w, const uint64_t* meta, size_t ncomp, unsigned log_n,
+                                  uint64_t* out_dev, char** err);
+
 /* ------------------------------------------------------------------ N2: LogicStark witness
  * LogicStark::generate_trace (logic.rs:150-183) with Operation::into_row (:122-142): 69 columns x 2^log_n rows,
  * column-major; row r < nops holds operation r (flag column, the 32 little-endian bits of each input, the result),
@@ -172,7 +185,9 @@ void zkm_standard_config(zkm_stark_config* cfg);
  *   MEMORY         memory/memory_stark.rs:253-341         13 columns, plus the range-check lookup :476-483
  *   POSEIDON_SPONGE poseidon_sponge/poseidon_sponge_stark.rs:383-478  110 columns
  *   SHA_EXTEND     sha_extend/sha_extend_stark.rs:238-317              78 columns
- *   SHA_EXTEND_SPONGE sha_extend_sponge/sha_extend_sponge_stark.rs:220-330  76 columns */
+ *   SHA_EXTEND_SPONGE sha_extend_sponge/sha_extend_sponge_stark.rs:220-330  76 columns
+ *   SHA_COMPRESS   sha_compress/sha_compress_stark.rs:402-606         224 columns
+ *   SHA_COMPRESS_SPONGE sha_compress_sponge/sha_compress_sponge_stark.rs:233-268  127 columns */
 #define ZKM_TABLE_POSEIDON 0
 #define ZKM_TABLE_LOGIC 1
 #define ZKM_TABLE_KECCAK_SPONGE 2
@@ -181,6 +196,8 @@ void zkm_standard_config(zkm_stark_config* cfg);
 #define ZKM_TABLE_POSEIDON_SPONGE 5
 #define ZKM_TABLE_SHA_EXTEND 6
 #define ZKM_TABLE_SHA_EXTEND_SPONGE 7
+#define ZKM_TABLE_SHA_COMPRESS 8
+#define ZKM_TABLE_SHA_COMPRESS_SPONGE 9
 #define ZKM_MEMORY_COLS 13
 size_t zkm_table_width(int table_id); /* 0 for an unknown id */
 /* Auxiliary columns the table's own logUp lookups (Stark::lookups(), lookup.rs:22-40) put in front of the CTL columns:

@@ -317,6 +317,87 @@ static void TNAME(eval_sha_extend_sponge)(const T* lv, const T* nv, TNAME(consum
     TNAME(cons)(k, T_MUL(sum, T_SUB(T_SUB(lv[72], lv[70]), T_FROMB(64))));
 }
 
+/* ---- ShaCompressStark constraints: sha_compress/sha_compress_stark.rs:402-606 (rotate_right.rs:29-62, not_operation.rs:23-34,
+ * wrapping_add_5.rs:37-83, wrapping_add_2.rs:34-67, logic.rs:7-16).  Columns (sha_compress/columns.rs:9-55): state 0..31 (a..h, 4
+ * little-endian bytes each), e_not 32, w_i 36, k_i 40, s_1_inter 44, s_1 48, e_and_f 52, e_not_and_g 56, ch 60, s_0_inter 64, s_0 68,
+ * a_and_b 72, a_and_c 76, b_and_c 80, maj_inter 84, maj 88, rotations (value[4], shift, carry) e_rr_6 92, e_rr_11 98, e_rr_25 104,
+ * a_rr_2 110, a_rr_13 116, a_rr_22 122, temp2 (value[4], carry[2]) 128, d_add_temp1 134, temp1_add_temp2 140, timestamp 146,
+ * segment 147, context 148, w_i_virt 149, temp1 (value[4], carry[5]) 150, round 159..223 (NUM_COMPRESS_ROWS = 65) ---- */
+#ifndef ZKO_SHA_K
+#define ZKO_SHA_K
+static const uint32_t ZKO_SHA256_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+#endif
+/* wrapping add of `nin` byte quadruples: op = value[4] then carry[ncarry]; every constraint is multiplied by `gate` */
+static void TNAME(sha_wadd)(const T* const* in, int nin, const T* op, int ncarry, T gate, TNAME(consumer) * k) {
+    T one = T_FROMB(1), csum = T_FROMB(0), carry = T_FROMB(0);
+    for (int i = 0; i < ncarry; i++) {
+        TNAME(cons)(k, T_MUL(gate, T_MUL(op[4 + i], T_SUB(one, op[4 + i]))));
+        csum = T_ADD(csum, op[4 + i]);
+        if (i) carry = T_ADD(carry, T_MULB(op[4 + i], (gl_t)i));
+    }
+    TNAME(cons)(k, T_MUL(gate, T_SUB(csum, one)));
+    T sum = T_FROMB(0);
+    for (int b = 3; b >= 0; b--) {
+        T s = in[0][b];
+        for (int q = 1; q < nin; q++) s = T_ADD(s, in[q][b]);
+        sum = T_ADD(T_MULB(sum, 1u << 8), s);
+    }
+    TNAME(cons)(k, T_MUL(gate, T_SUB(T_SUB(sum, T_MULB(carry, (gl_t)1 << 32)), TNAME(le4)(op))));
+}
+static void TNAME(eval_sha_compress)(const T* lv, const T* nv, TNAME(consumer) * k) {
+    T one = T_FROMB(1);
+    T is_final = lv[159 + 64];
+    TNAME(cons)(k, T_MUL(is_final, T_SUB(is_final, one)));
+    T not_final = T_SUB(one, is_final);
+    T sum = T_FROMB(0);
+    for (int i = 0; i < 65; i++) sum = T_ADD(sum, lv[159 + i]);
+    TNAME(cons)(k, T_MUL(sum, T_SUB(sum, one)));
+    T g = T_MUL(sum, not_final);
+    for (int i = 0; i < 4; i++) {
+        T kb = T_FROMB(0);
+        for (int j = 0; j < 64; j++) kb = T_ADD(kb, T_MULB(lv[159 + j], (ZKO_SHA256_K[j] >> (8 * i)) & 0xFF));
+        TNAME(cons)(k, T_MUL(g, T_SUB(lv[40 + i], kb)));
+    }
+    TNAME(sha_rot)(lv + 16, lv + 92, 6, 0, k);
+    TNAME(sha_rot)(lv + 16, lv + 98, 11, 0, k);
+    TNAME(sha_rot)(lv + 16, lv + 104, 25, 0, k);
+    TNAME(sha_rot)(lv + 0, lv + 110, 2, 0, k);
+    TNAME(sha_rot)(lv + 0, lv + 116, 13, 0, k);
+    TNAME(sha_rot)(lv + 0, lv + 122, 22, 0, k);
+    for (int i = 0; i < 4; i++) TNAME(cons)(k, T_MUL(sum, T_SUB(T_ADD(lv[16 + i], lv[32 + i]), T_FROMB(255))));
+    { const T* in[5] = {lv + 28, lv + 48, lv + 60, lv + 40, lv + 36}; TNAME(sha_wadd)(in, 5, lv + 150, 5, sum, k); }   /* temp1 = h + s_1 + ch + k_i + w_i */
+    { const T* in[2] = {lv + 68, lv + 88}; TNAME(sha_wadd)(in, 2, lv + 128, 2, sum, k); }                               /* temp2 = s_0 + maj */
+    { const T* in[2] = {lv + 12, lv + 150}; TNAME(sha_wadd)(in, 2, lv + 134, 2, sum, k); }                              /* d + temp1 */
+    { const T* in[2] = {lv + 150, lv + 128}; TNAME(sha_wadd)(in, 2, lv + 140, 2, sum, k); }                             /* temp1 + temp2 */
+    TNAME(cons)(k, T_MUL(g, T_SUB(nv[146], lv[146])));
+    TNAME(cons)(k, T_MUL(g, T_SUB(T_SUB(nv[149], lv[149]), T_FROMB(4))));
+    for (int i = 0; i < 4; i++) TNAME(cons)(k, T_MUL(g, T_SUB(lv[140 + i], nv[0 + i])));       /* temp1 + temp2 = next a */
+    for (int w = 0; w < 3; w++)                                                                  /* a, b, c -> next b, c, d */
+        for (int i = 0; i < 4; i++) TNAME(cons)(k, T_MUL(g, T_SUB(lv[4 * w + i], nv[4 * (w + 1) + i])));
+    for (int i = 0; i < 4; i++) TNAME(cons)(k, T_MUL(g, T_SUB(lv[134 + i], nv[16 + i])));      /* d + temp1 = next e */
+    for (int w = 4; w < 7; w++)                                                                  /* e, f, g -> next f, g, h */
+        for (int i = 0; i < 4; i++) TNAME(cons)(k, T_MUL(g, T_SUB(lv[4 * w + i], nv[4 * (w + 1) + i])));
+}
+
+/* ---- ShaCompressSpongeStark constraints: sha_compress_sponge/sha_compress_sponge_stark.rs:233-268.  Columns
+ * (sha_compress_sponge/columns.rs:7-27): hx 0..31, output_state 32..63, output_hx[8] x (value[4], carry[2]) 64..111, hx_virt 112..119,
+ * w_start_virt 120, timestamp 121, context 122, segment 123, w_start_segment 124, w_start_context 125, is_real_round 126 ---- */
+static void TNAME(eval_sha_compress_sponge)(const T* lv, TNAME(consumer) * k) {
+    T one = T_FROMB(1), real = lv[126];
+    TNAME(cons)(k, T_MUL(real, T_SUB(real, one)));
+    for (int i = 0; i < 7; i++) TNAME(cons)(k, T_MUL(real, T_SUB(T_SUB(lv[113 + i], lv[112 + i]), T_FROMB(4))));
+    for (int i = 0; i < 8; i++) {
+        const T* in[2] = {lv + 4 * i, lv + 32 + 4 * i};
+        TNAME(sha_wadd)(in, 2, lv + 64 + 6 * i, 2, real, k);
+    }
+}
+
 /* ---- MemoryStark constraints: memory/memory_stark.rs:253-341 (columns memory/columns.rs: FILTER 0, TIMESTAMP 1, IS_READ 2,
  * ADDR_CONTEXT 3, ADDR_SEGMENT 4, ADDR_VIRTUAL 5, VALUE 6 (VALUE_LIMBS = 1), CONTEXT/SEGMENT/VIRTUAL_FIRST_CHANGE 7..9,
  * RANGE_CHECK 10, COUNTER 11, FREQUENCIES 12) ---- */
@@ -395,7 +476,7 @@ static void TNAME(eval_lookups)(int table_id, const gl_t* challenges, size_t nch
 }
 
 /* table dispatch (Table ids of include/zkm_hip.h) */
-static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : table_id == 4 ? 13 : table_id == 5 ? 110 : table_id == 6 ? 78 : table_id == 7 ? 76 : 0; }
+static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : table_id == 4 ? 13 : table_id == 5 ? 110 : table_id == 6 ? 78 : table_id == 7 ? 76 : table_id == 8 ? 224 : table_id == 9 ? 127 : 0; }
 static void TNAME(eval_table)(int table_id, const T* lv, const T* nv, TNAME(consumer) * k) {
     if (table_id == 0) TNAME(eval_poseidon)(lv, k);
     else if (table_id == 1) TNAME(eval_logic)(lv, k);
@@ -404,7 +485,9 @@ static void TNAME(eval_table)(int table_id, const T* lv, const T* nv, TNAME(cons
     else if (table_id == 4) TNAME(eval_memory)(lv, nv, k);
     else if (table_id == 5) TNAME(eval_poseidon_sponge)(lv, nv, k);
     else if (table_id == 6) TNAME(eval_sha_extend)(lv, k);
-    else TNAME(eval_sha_extend_sponge)(lv, nv, k);
+    else if (table_id == 7) TNAME(eval_sha_extend_sponge)(lv, nv, k);
+    else if (table_id == 8) TNAME(eval_sha_compress)(lv, nv, k);
+    else TNAME(eval_sha_compress_sponge)(lv, k);
 }
 
 /* ---- general CTL checks driven by the column-set description ----

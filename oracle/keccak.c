@@ -268,3 +268,95 @@ size_t zko_sha_extend_sponge_trace(const uint32_t* w16, const uint64_t* meta, si
     }
     return 48 * k;
 }
+
+/* ---- SHA-256 compression tables ---- */
+static const uint32_t KW_SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static void put_wadd(uint64_t* out, size_t n, size_t row, int col, uint64_t wide) {
+    put_le4(out, n, row, col, (uint32_t)wide);
+    out[(size_t)(col + 4 + (wide >> 32)) * n + row] = 1;
+}
+/* One SHA-256 round on (a..h) with message word w and constant kc; returns temp1, temp2 through pointers */
+static void sha_round(uint32_t s[8], uint32_t w, uint32_t kc) {
+    uint32_t a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
+    uint32_t s1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25), ch = (e & f) ^ (~e & g);
+    uint32_t t1 = h + s1 + ch + kc + w;
+    uint32_t s0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22), maj = (a & b) ^ (a & c) ^ (b & c);
+    uint32_t t2 = s0 + maj;
+    s[7] = g; s[6] = f; s[5] = e; s[4] = d + t1; s[3] = c; s[2] = b; s[1] = a; s[0] = t1 + t2;
+}
+/* ShaCompressStark::generate_trace (sha_compress/sha_compress_stark.rs:227-400) for k compressions as the witness generator emits
+ * them (witness/util.rs:605-690): 65 rows each -- rounds 0..63 on the running state with w_i, K_i, and a 65th row holding the final
+ * state with w_i = k_i = 0.  hx = k x 8 words, w = k x 64 words, meta = k x 8 {context, segment, hx address, timestamp,
+ * w address, w segment, w context, unused}. */
+size_t zko_sha_compress_trace(const uint32_t* hx, const uint32_t* w, const uint64_t* meta, size_t k, unsigned log_n, uint64_t* out) {
+    size_t n = (size_t)1 << log_n;
+    if (65 * k > n) return 0;
+    memset(out, 0, sizeof(uint64_t) * 224 * n);
+    for (size_t e_ = 0; e_ < k; e_++) {
+        uint32_t s[8];
+        memcpy(s, hx + 8 * e_, 32);
+        for (int rd = 0; rd < 65; rd++) {
+            size_t row = 65 * e_ + rd;
+            uint32_t wi = rd < 64 ? w[64 * e_ + rd] : 0, ki = rd < 64 ? KW_SHA_K[rd] : 0;
+            uint32_t a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
+            for (int q = 0; q < 8; q++) put_le4(out, n, row, 4 * q, s[q]);
+            put_le4(out, n, row, 32, ~e);
+            put_le4(out, n, row, 36, wi);
+            put_le4(out, n, row, 40, ki);
+            uint32_t s1i = rotr32(e, 6) ^ rotr32(e, 11), s1 = s1i ^ rotr32(e, 25);
+            uint32_t eaf = e & f, eng = ~e & g, ch = eaf ^ eng;
+            put_le4(out, n, row, 44, s1i); put_le4(out, n, row, 48, s1); put_le4(out, n, row, 52, eaf);
+            put_le4(out, n, row, 56, eng); put_le4(out, n, row, 60, ch);
+            uint32_t s0i = rotr32(a, 2) ^ rotr32(a, 13), s0 = s0i ^ rotr32(a, 22);
+            uint32_t ab = a & b, ac = a & c, bc = b & c, maji = ab ^ ac, maj = maji ^ bc;
+            put_le4(out, n, row, 64, s0i); put_le4(out, n, row, 68, s0); put_le4(out, n, row, 72, ab); put_le4(out, n, row, 76, ac);
+            put_le4(out, n, row, 80, bc); put_le4(out, n, row, 84, maji); put_le4(out, n, row, 88, maj);
+            put_rot(out, n, row, 92, e, 6, 0); put_rot(out, n, row, 98, e, 11, 0); put_rot(out, n, row, 104, e, 25, 0);
+            put_rot(out, n, row, 110, a, 2, 0); put_rot(out, n, row, 116, a, 13, 0); put_rot(out, n, row, 122, a, 22, 0);
+            uint64_t t1w = (uint64_t)h + s1 + ch + ki + wi;
+            uint32_t t1 = (uint32_t)t1w;
+            uint64_t t2w = (uint64_t)s0 + maj;
+            uint32_t t2 = (uint32_t)t2w;
+            put_wadd(out, n, row, 150, t1w);
+            put_wadd(out, n, row, 128, t2w);
+            put_wadd(out, n, row, 134, (uint64_t)d + t1);
+            put_wadd(out, n, row, 140, (uint64_t)t1 + t2);
+            out[(size_t)146 * n + row] = meta[8 * e_ + 3];
+            out[(size_t)147 * n + row] = meta[8 * e_ + 5];
+            out[(size_t)148 * n + row] = meta[8 * e_ + 6];
+            out[(size_t)149 * n + row] = meta[8 * e_ + 4] + 4 * (uint64_t)rd;
+            out[(size_t)(159 + rd) * n + row] = 1;
+            if (rd < 64) sha_round(s, wi, ki);
+        }
+    }
+    return 65 * k;
+}
+/* ShaCompressSpongeStark::generate_trace (sha_compress_sponge/sha_compress_sponge_stark.rs:118-230): one row per compression */
+void zko_sha_compress_sponge_trace(const uint32_t* hx, const uint32_t* w, const uint64_t* meta, size_t k, unsigned log_n, uint64_t* out) {
+    size_t n = (size_t)1 << log_n;
+    memset(out, 0, sizeof(uint64_t) * 127 * n);
+    for (size_t r = 0; r < k && r < n; r++) {
+        uint32_t s[8];
+        memcpy(s, hx + 8 * r, 32);
+        for (int i = 0; i < 64; i++) sha_round(s, w[64 * r + i], KW_SHA_K[i]);
+        for (int q = 0; q < 8; q++) {
+            put_le4(out, n, r, 4 * q, hx[8 * r + q]);
+            put_le4(out, n, r, 32 + 4 * q, s[q]);
+            put_wadd(out, n, r, 64 + 6 * q, (uint64_t)hx[8 * r + q] + s[q]);
+            out[(size_t)(112 + q) * n + r] = meta[8 * r + 2] + 4 * (uint64_t)q;
+        }
+        out[(size_t)120 * n + r] = meta[8 * r + 4];
+        out[(size_t)121 * n + r] = meta[8 * r + 3];
+        out[(size_t)122 * n + r] = meta[8 * r];
+        out[(size_t)123 * n + r] = meta[8 * r + 1];
+        out[(size_t)124 * n + r] = meta[8 * r + 5];
+        out[(size_t)125 * n + r] = meta[8 * r + 6];
+        out[(size_t)126 * n + r] = 1;
+    }
+}

@@ -193,6 +193,30 @@ class Oracle:
             raise RuntimeError("oracle sha_extend_sponge_trace: rounds do not fit")
         return out, used
 
+    def _sha_compress_args(self, hx, w, meta):
+        hx = np.ascontiguousarray(hx, dtype=np.uint32).reshape(-1, 8)
+        w = np.ascontiguousarray(w, dtype=np.uint32).reshape(-1, 64)
+        meta = np.ascontiguousarray(meta, dtype=np.uint64).reshape(-1, 8)
+        assert len(hx) == len(w) == len(meta)
+        return hx, w, meta
+
+    def sha_compress_trace(self, hx, w, meta, log_n):
+        hx, w, meta = self._sha_compress_args(hx, w, meta)
+        out = np.zeros(224 << log_n, dtype=np.uint64)
+        self.lib.zko_sha_compress_trace.restype = C.c_size_t
+        self.lib.zko_sha_compress_trace.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, C.c_uint, u64p]
+        used = self.lib.zko_sha_compress_trace(hx.ctypes.data, w.ctypes.data, _ptr(meta), len(hx), log_n, _ptr(out))
+        if used == 0 and len(hx):
+            raise RuntimeError("oracle sha_compress_trace: rounds do not fit")
+        return out
+
+    def sha_compress_sponge_trace(self, hx, w, meta, log_n):
+        hx, w, meta = self._sha_compress_args(hx, w, meta)
+        out = np.zeros(127 << log_n, dtype=np.uint64)
+        self.lib.zko_sha_compress_sponge_trace.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, C.c_uint, u64p]
+        self.lib.zko_sha_compress_sponge_trace(hx.ctypes.data, w.ctypes.data, _ptr(meta), len(hx), log_n, _ptr(out))
+        return out
+
     # ---- NTT / commitment
     def ntt(self, cols, log_n, inverse=False, coset_shift=0):
         a = np.ascontiguousarray(cols, dtype=np.uint64).copy()

@@ -216,3 +216,49 @@ def build_sha_extend_path(oracle, nblocks=1, seed=51):
             (T.logic_lookers_sha_extend(1, ce), (2, T.logic_ctl_data(cl))),
             (T.memory_lookers_sha_extend_sponge(0, cs), (3, T.memory_ctl_data(cm)))]
     return tables, ctls, (w16, meta, inputs, ts, ops, mem_ops)
+
+
+def build_sha_compress_path(oracle, ncomp=1, seed=61):
+    """Memory + ShaCompressSponge + ShaCompress + Logic: SHA-256 compressions with the lookups the reference defines among
+    these tables (all_stark.rs:298-324, 387-470, 511-525)."""
+    rng = np.random.default_rng(seed)
+    hx = rng.integers(0, 1 << 32, (ncomp, 8), dtype=np.uint64).astype(np.uint32)
+    w = rng.integers(0, 1 << 32, (ncomp, 64), dtype=np.uint64).astype(np.uint32)
+    meta = np.zeros((ncomp, 8), dtype=np.uint64)
+    meta[:, 1] = 0                                        # hx: context 0, segment Code (witness/operation.rs:1318)
+    meta[:, 2] = (1 << 23) + np.arange(ncomp) * 2048      # hx address
+    meta[:, 3] = 30 + np.arange(ncomp) * 10               # timestamp
+    meta[:, 4] = (1 << 23) + np.arange(ncomp) * 2048 + 512  # w address
+    log_c = int(np.ceil(np.log2(65 * ncomp + 1)))
+    log_s = max(3, int(np.ceil(np.log2(ncomp + 1))))
+    compress = oracle.sha_compress_trace(hx, w, meta, log_c)
+    sponge = oracle.sha_compress_sponge_trace(hx, w, meta, log_s)
+    n = 1 << log_c
+    tr = compress.reshape(224, n)
+    le = lambda c, r: sum(int(tr[c + j, r]) << (8 * j) for j in range(4))
+    ops, mem = [], []
+    for e in range(ncomp):
+        for q in range(8):
+            mem += [(int(meta[e, 0]), int(meta[e, 1]), int(meta[e, 2]) + 4 * q, int(meta[e, 3]), 1, int(hx[e, q]))] * 4
+        for rd in range(64):
+            r = 65 * e + rd
+            for opcode, in0, in1, res in T.SHA_COMPRESS_LOGIC:
+                ops.append((T.OP_XOR if opcode == (0b100110 << 6) else T.OP_AND, le(in0, r), le(in1, r)))
+            mem += [(int(meta[e, 6]), int(meta[e, 5]), int(meta[e, 4]) + 4 * rd, int(meta[e, 3]), 1, int(w[e, rd]))] * 4
+    ops = np.array(ops, dtype=np.uint32)
+    np.random.default_rng(seed + 1).shuffle(ops, axis=0)
+    log_logic = int(np.ceil(np.log2(len(ops))))
+    logic = oracle.logic_trace(ops, log_logic)
+    mem_ops = np.array(mem, dtype=np.uint64).reshape(-1, 6)
+    log_mem = int(np.ceil(np.log2(len(mem_ops)))) + 1
+    memory, natural = oracle.memory_trace(mem_ops, log_mem)
+    if natural < (1 << log_mem):
+        log_mem -= 1
+        memory, natural = oracle.memory_trace(mem_ops, log_mem)
+    cs, cc, cl, cm = CtlTable(), CtlTable(), CtlTable(), CtlTable()
+    tables = [(T.TABLE_SHA_COMPRESS_SPONGE, sponge, 127, log_s, cs), (T.TABLE_SHA_COMPRESS, compress, 224, log_c, cc),
+              (T.TABLE_LOGIC, logic, 69, log_logic, cl), (T.TABLE_MEMORY, memory, 13, log_mem, cm)]
+    ctls = [T.ctl_sha_compress_inputs(0, 1, cs, cc), T.ctl_sha_compress_outputs(0, 1, cs, cc),
+            (T.logic_lookers_sha_compress(1, cc), (2, T.logic_ctl_data(cl))),
+            (T.memory_lookers_sha_compress_sponge(0, cs) + T.memory_lookers_sha_compress(1, cc), (3, T.memory_ctl_data(cm)))]
+    return tables, ctls, (hx, w, meta, ops, mem_ops)

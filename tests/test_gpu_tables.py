@@ -330,3 +330,29 @@ def test_sha_extend_trace_errors(ctx, zkm):
         ctx.sha_extend_sponge_trace(np.zeros((2, 16), dtype=np.uint32), np.zeros((2, 4), dtype=np.uint64), 6)
     with pytest.raises(zkm.ZkmError, match="more rows"):
         ctx.sha_extend_trace(np.zeros((9, 16), dtype=np.uint8), np.zeros(9, dtype=np.uint64), 3)
+
+
+@pytest.mark.parametrize("ncomp", [1, 9])
+def test_sha_compress_path_is_bit_exact_and_verifies(ctx, oracle, ncomp):
+    """Memory -> ShaCompressSponge -> ShaCompress -> Logic: SHA-256 compressions (all_stark.rs:298-324, 387-470, 511-525)."""
+    tables, ctls, (hx, w, meta, ops, mem_ops) = logic_fixtures.build_sha_compress_path(oracle, ncomp=ncomp)
+    assert (ctx.sha_compress_sponge_trace(hx, w, meta, tables[0][3]).download() == tables[0][1]).all()
+    assert (ctx.sha_compress_trace(hx, w, meta, tables[1][3]).download() == tables[1][1]).all()
+    got, chal, offs = ctx.prove_with_traces(tables, ctls)
+    if ncomp == 1:
+        want, wchal, woffs = oracle.prove_with_traces(tables, ctls)
+        assert offs == woffs and (chal == wchal).all()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "first differing word %d" % bad[0]
+    assert oracle.verify_all(tables, ctls, got, chal) == 0
+
+
+@pytest.mark.parametrize("t_idx", [0, 1])
+def test_sha_compress_single_table_proofs(ctx, oracle, t_idx):
+    tables, ctls, _ = logic_fixtures.build_sha_compress_path(oracle, ncomp=3)
+    tid, trace, W, log_n, cs = tables[t_idx]
+    aux = fake_ctl_aux(log_n)
+    want = oracle.prove(trace, log_n, aux, [2], ncols=W, table_id=tid)
+    got = ctx.prove_single_table(trace, log_n, aux, [2], ncols=W, table_id=tid)
+    assert (got == want).all()
+    assert oracle.verify(got, 3, [2], ncols=W, table_id=tid) == 0

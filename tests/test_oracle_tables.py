@@ -223,3 +223,33 @@ def test_sha_extend_path(oracle):
         bt[t_idx] = (tid, bad, width, log_n, ct)
         proofs, chal, offs = oracle.prove_with_traces(bt, ctls)
         assert oracle.verify_all(bt, ctls, proofs, chal) != 0
+
+
+def test_sha_compress_path(oracle):
+    import hashlib, struct
+    tables, ctls, (hx, w, meta, ops, mem_ops) = logic_fixtures.build_sha_compress_path(oracle)
+    # with the SHA-256 IV and the schedule of a one-block message, output_hx is the SHA-256 digest
+    iv = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+    msg = b"abc"
+    block = msg + b"\x80" + b"\0" * (55 - len(msg)) + struct.pack(">Q", 8 * len(msg))
+    ws = list(struct.unpack(">16I", block))
+    rotr = lambda x, r: ((x >> r) | (x << (32 - r))) & 0xFFFFFFFF
+    for i in range(16, 64):
+        s0 = rotr(ws[i - 15], 7) ^ rotr(ws[i - 15], 18) ^ (ws[i - 15] >> 3)
+        s1 = rotr(ws[i - 2], 17) ^ rotr(ws[i - 2], 19) ^ (ws[i - 2] >> 10)
+        ws.append((ws[i - 16] + s0 + ws[i - 7] + s1) & 0xFFFFFFFF)
+    tr = oracle.sha_compress_sponge_trace([iv], [ws], np.zeros((1, 8), dtype=np.uint64), 3).reshape(127, 8)
+    digest = b"".join(struct.pack(">I", sum(int(tr[64 + 6 * q + j, 0]) << (8 * j) for j in range(4))) for q in range(8))
+    assert digest == hashlib.sha256(msg).digest()
+    assert oracle.check_ctls(tables, ctls) == 0
+    proofs, chal, offs = oracle.prove_with_traces(tables, ctls)
+    assert oracle.verify_all(tables, ctls, proofs, chal) == 0
+    # a corrupted chained state byte in the compress table / a wrong carry flag in the sponge table
+    for t_idx, col, row in ((1, 5, 7), (0, 68, 0)):
+        tid, trace, width, log_n, ct = tables[t_idx]
+        bad = trace.copy()
+        bad[col * (1 << log_n) + row] ^= 1
+        bt = list(tables)
+        bt[t_idx] = (tid, bad, width, log_n, ct)
+        proofs, chal, offs = oracle.prove_with_traces(bt, ctls)
+        assert oracle.verify_all(bt, ctls, proofs, chal) != 0

@@ -23,7 +23,7 @@ LOGIC_COLS = 69
 KECCAK_COLS = 2431
 POSEIDON_SPONGE_COLS = 110
 TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY, TABLE_POSEIDON_SPONGE = 0, 1, 2, 3, 4, 5
-TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE = 6, 7
+TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRESS_SPONGE = 6, 7, 8, 9
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
@@ -32,6 +32,7 @@ EXPORTS = [
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_keccak_trace", "zkm_logic_trace",
     "zkm_poseidon_sponge_trace", "zkm_poseidon_trace_inputs", "zkm_sha_extend_trace", "zkm_sha_extend_sponge_trace",
+    "zkm_sha_compress_trace", "zkm_sha_compress_sponge_trace",
     "zkm_table_width", "zkm_num_lookup_columns", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
     "zkm_prove_single_table", "zkm_prove_openings", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
@@ -104,6 +105,8 @@ def load():
         "zkm_poseidon_trace_inputs": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_sha_extend_trace": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_sha_extend_sponge_trace": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
+        "zkm_sha_compress_trace": (C.c_int, [cp, cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
+        "zkm_sha_compress_sponge_trace": (C.c_int, [cp, cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_keccak_trace": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_logic_trace": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_table_width": (C.c_size_t, [C.c_int]),
@@ -312,6 +315,24 @@ class Context:
         _check(self.L.zkm_sha_extend_sponge_trace(self.h, w16.ctypes.data_as(C.c_void_p), _data_ptr(meta), len(w16), log_n,
                                                   _data_ptr(out), C.byref(err)), err)
         return out
+
+    def _sha_compress(self, fn, cols, hx, w, meta, log_n, out):
+        hx = np.ascontiguousarray(hx, dtype=np.uint32).reshape(-1, 8)
+        w = np.ascontiguousarray(w, dtype=np.uint32).reshape(-1, 64)
+        meta = np.ascontiguousarray(meta, dtype=np.uint64).reshape(-1, 8)
+        out = out or self.alloc(cols << log_n)
+        err = C.c_char_p()
+        _check(fn(self.h, hx.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), _data_ptr(meta), len(hx), log_n, _data_ptr(out),
+                  C.byref(err)), err)
+        return out
+
+    def sha_compress_trace(self, hx, w, meta, log_n, out=None):
+        """ShaCompressStark::generate_trace on the GPU: 65 rows per compression, 224 x 2^log_n words."""
+        return self._sha_compress(self.L.zkm_sha_compress_trace, 224, hx, w, meta, log_n, out)
+
+    def sha_compress_sponge_trace(self, hx, w, meta, log_n, out=None):
+        """ShaCompressSpongeStark::generate_trace on the GPU: one row per compression, 127 x 2^log_n words."""
+        return self._sha_compress(self.L.zkm_sha_compress_sponge_trace, 127, hx, w, meta, log_n, out)
 
     def keccak_trace(self, inputs, timestamps, log_n, out=None):
         """KeccakStark::generate_trace on the GPU (keccak/keccak_stark.rs:62-236).  inputs: nperms x 25 uint64, timestamps:

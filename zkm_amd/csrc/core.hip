@@ -496,6 +496,8 @@ size_t zkm_table_width(int table_id) {
         case ZKM_TABLE_POSEIDON_SPONGE: return ZKM_POSEIDON_SPONGE_COLS;
         case ZKM_TABLE_SHA_EXTEND: return ZKM_SHA_EXTEND_COLS;
         case ZKM_TABLE_SHA_EXTEND_SPONGE: return ZKM_SHA_EXTEND_SPONGE_COLS;
+        case ZKM_TABLE_SHA_COMPRESS: return ZKM_SHA_COMPRESS_COLS;
+        case ZKM_TABLE_SHA_COMPRESS_SPONGE: return ZKM_SHA_COMPRESS_SPONGE_COLS;
         default: return 0;
     }
 }
@@ -549,6 +551,37 @@ int zkm_sha_extend_sponge_trace(zkm_ctx* c, const uint32_t* w16, const uint64_t*
         return fail(err, e.what());
     }
     return 0;
+}
+
+static int sha_compress_trace(zkm_ctx* c, bool sponge, const uint32_t* hx, const uint32_t* w, const uint64_t* meta, size_t ncomp,
+                              unsigned log_n, uint64_t* out_dev, char** err) {
+    std::vector<void*> tmp;
+    const char* what = sponge ? "zkm_sha_compress_sponge_trace" : "zkm_sha_compress_trace";
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!zkm_is_device_ptr(out_dev)) throw std::runtime_error(std::string(what) + ": out must be a device pointer");
+        size_t n = (size_t)1 << log_n;
+        if ((sponge ? 1 : 65) * ncomp > n) throw std::runtime_error(std::string(what) + ": compressions need more rows than 2^log_n");
+        const uint32_t* d_hx = (const uint32_t*)stage_arg(c, tmp, hx, ncomp * 32);
+        const uint32_t* d_w = (const uint32_t*)stage_arg(c, tmp, w, ncomp * 256);
+        const uint64_t* d_meta = (const uint64_t*)stage_arg(c, tmp, meta, ncomp * 64);
+        zkm_launch_sha_compress_trace(c, sponge, d_hx, d_w, d_meta, ncomp, n, out_dev);
+        c->sync();
+        for (void* p : tmp) c->release(p);
+    } catch (const std::exception& e) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* p : tmp) c->release(p);
+        return fail(err, e.what());
+    }
+    return 0;
+}
+int zkm_sha_compress_trace(zkm_ctx* c, const uint32_t* hx, const uint32_t* w, const uint64_t* meta, size_t ncomp, unsigned log_n,
+                           uint64_t* out_dev, char** err) {
+    return sha_compress_trace(c, false, hx, w, meta, ncomp, log_n, out_dev, err);
+}
+int zkm_sha_compress_sponge_trace(zkm_ctx* c, const uint32_t* hx, const uint32_t* w, const uint64_t* meta, size_t ncomp, unsigned log_n,
+                                  uint64_t* out_dev, char** err) {
+    return sha_compress_trace(c, true, hx, w, meta, ncomp, log_n, out_dev, err);
 }
 
 int zkm_keccak_trace(zkm_ctx* c, const uint64_t* inputs, const uint64_t* timestamps, size_t nperms, unsigned log_n, uint64_t* out_dev,

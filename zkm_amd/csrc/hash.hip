@@ -668,3 +668,105 @@ void zkm_launch_sha_extend_sponge_trace(zkm_ctx* c, const uint32_t* d_w16, const
     hipLaunchKernelGGL(k_sha_extend_sponge_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_w16, d_meta, k, n, out);
     ZKM_HIP_CHECK(hipGetLastError());
 }
+
+// ------------------------------------------------------------------ SHA-256 compression witnesses
+// ShaCompressStark::generate_trace (sha_compress/sha_compress_stark.rs:227-400, rows as emitted by witness/util.rs:605-690: 65 per
+// compression) and ShaCompressSpongeStark::generate_trace (sha_compress_sponge_stark.rs:118-230).  One thread per row; the thread
+// replays the rounds before its own (at most 64 cheap steps).
+__device__ const uint32_t SHA256_K_WIT[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+__device__ __forceinline__ void sha_round_dev(uint32_t (&s)[8], uint32_t w, uint32_t kc) {
+    uint32_t a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
+    uint32_t t1 = h + (rotr32_dev(e, 6) ^ rotr32_dev(e, 11) ^ rotr32_dev(e, 25)) + ((e & f) ^ (~e & g)) + kc + w;
+    uint32_t t2 = (rotr32_dev(a, 2) ^ rotr32_dev(a, 13) ^ rotr32_dev(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+    s[7] = g; s[6] = f; s[5] = e; s[4] = d + t1; s[3] = c; s[2] = b; s[1] = a; s[0] = t1 + t2;
+}
+template <int NC>
+__device__ __forceinline__ void put_wadd_dev(gl_t* o, size_t n, int col, uint64_t wide) {
+    put_le4_dev(o, n, col, (uint32_t)wide);
+#pragma unroll
+    for (uint32_t c = 0; c < NC; c++) o[(size_t)(col + 4 + c) * n] = (uint32_t)(wide >> 32) == c;
+}
+__global__ __launch_bounds__(256) void k_sha_compress_trace(const uint32_t* __restrict__ hx, const uint32_t* __restrict__ w,
+                                                            const uint64_t* __restrict__ meta, size_t k, size_t n, gl_t* __restrict__ out) {
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    gl_t* o = out + row;
+    size_t e_ = row / 65;
+    int rd = (int)(row - e_ * 65);
+    if (e_ >= k) {
+        for (int c = 0; c < ZKM_SHA_COMPRESS_COLS; c++) o[(size_t)c * n] = 0;
+        return;
+    }
+    uint32_t s[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) s[q] = hx[8 * e_ + q];
+    for (int i = 0; i < rd; i++) sha_round_dev(s, w[64 * e_ + i], SHA256_K_WIT[i]);
+    const uint32_t wi = rd < 64 ? w[64 * e_ + rd] : 0, ki = rd < 64 ? SHA256_K_WIT[rd] : 0;
+    const uint32_t a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
+#pragma unroll
+    for (int q = 0; q < 8; q++) put_le4_dev(o, n, 4 * q, s[q]);
+    put_le4_dev(o, n, 32, ~e);
+    put_le4_dev(o, n, 36, wi);
+    put_le4_dev(o, n, 40, ki);
+    const uint32_t s1i = rotr32_dev(e, 6) ^ rotr32_dev(e, 11), s1 = s1i ^ rotr32_dev(e, 25), eaf = e & f, eng = ~e & g, ch = eaf ^ eng;
+    put_le4_dev(o, n, 44, s1i); put_le4_dev(o, n, 48, s1); put_le4_dev(o, n, 52, eaf); put_le4_dev(o, n, 56, eng); put_le4_dev(o, n, 60, ch);
+    const uint32_t s0i = rotr32_dev(a, 2) ^ rotr32_dev(a, 13), s0 = s0i ^ rotr32_dev(a, 22);
+    const uint32_t ab = a & b, ac = a & c, bc = b & c, maji = ab ^ ac, maj = maji ^ bc;
+    put_le4_dev(o, n, 64, s0i); put_le4_dev(o, n, 68, s0); put_le4_dev(o, n, 72, ab); put_le4_dev(o, n, 76, ac);
+    put_le4_dev(o, n, 80, bc); put_le4_dev(o, n, 84, maji); put_le4_dev(o, n, 88, maj);
+    put_rot_dev(o, n, 92, e, 6, false); put_rot_dev(o, n, 98, e, 11, false); put_rot_dev(o, n, 104, e, 25, false);
+    put_rot_dev(o, n, 110, a, 2, false); put_rot_dev(o, n, 116, a, 13, false); put_rot_dev(o, n, 122, a, 22, false);
+    const uint64_t t1w = (uint64_t)h + s1 + ch + ki + wi, t2w = (uint64_t)s0 + maj;
+    const uint32_t t1 = (uint32_t)t1w, t2 = (uint32_t)t2w;
+    put_wadd_dev<5>(o, n, 150, t1w);
+    put_wadd_dev<2>(o, n, 128, t2w);
+    put_wadd_dev<2>(o, n, 134, (uint64_t)d + t1);
+    put_wadd_dev<2>(o, n, 140, (uint64_t)t1 + t2);
+    o[(size_t)146 * n] = meta[8 * e_ + 3];
+    o[(size_t)147 * n] = meta[8 * e_ + 5];
+    o[(size_t)148 * n] = meta[8 * e_ + 6];
+    o[(size_t)149 * n] = meta[8 * e_ + 4] + 4 * (uint64_t)rd;
+    for (int i = 0; i < 65; i++) o[(size_t)(159 + i) * n] = i == rd;
+}
+__global__ __launch_bounds__(256) void k_sha_compress_sponge_trace(const uint32_t* __restrict__ hx, const uint32_t* __restrict__ w,
+                                                                   const uint64_t* __restrict__ meta, size_t k, size_t n,
+                                                                   gl_t* __restrict__ out) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    gl_t* o = out + r;
+    if (r >= k) {
+        for (int c = 0; c < ZKM_SHA_COMPRESS_SPONGE_COLS; c++) o[(size_t)c * n] = 0;
+        return;
+    }
+    uint32_t s[8], h0[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) s[q] = h0[q] = hx[8 * r + q];
+    for (int i = 0; i < 64; i++) sha_round_dev(s, w[64 * r + i], SHA256_K_WIT[i]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        put_le4_dev(o, n, 4 * q, h0[q]);
+        put_le4_dev(o, n, 32 + 4 * q, s[q]);
+        put_wadd_dev<2>(o, n, 64 + 6 * q, (uint64_t)h0[q] + s[q]);
+        o[(size_t)(112 + q) * n] = meta[8 * r + 2] + 4 * (uint64_t)q;
+    }
+    o[(size_t)120 * n] = meta[8 * r + 4];
+    o[(size_t)121 * n] = meta[8 * r + 3];
+    o[(size_t)122 * n] = meta[8 * r];
+    o[(size_t)123 * n] = meta[8 * r + 1];
+    o[(size_t)124 * n] = meta[8 * r + 5];
+    o[(size_t)125 * n] = meta[8 * r + 6];
+    o[(size_t)126 * n] = 1;
+}
+void zkm_launch_sha_compress_trace(zkm_ctx* c, bool sponge, const uint32_t* d_hx, const uint32_t* d_w, const uint64_t* d_meta, size_t k,
+                                   size_t n, gl_t* out) {
+    zkm_prof_scope ps(c, sponge ? "sha_compress_sponge_trace" : "sha_compress_trace");
+    if (sponge) hipLaunchKernelGGL(k_sha_compress_sponge_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_hx, d_w, d_meta, k, n, out);
+    else hipLaunchKernelGGL(k_sha_compress_trace, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_hx, d_w, d_meta, k, n, out);
+    ZKM_HIP_CHECK(hipGetLastError());
+}

@@ -450,6 +450,96 @@ __device__ void eval_sha_extend_sponge_constraints(const gl_t* __restrict__ lv, 
     k.constraint(gl_mul(sum, gl_sub(gl_sub(lv[(size_t)72 * cs], a16), 64)));
 }
 
+// ShaCompressStark (sha_compress/sha_compress_stark.rs:402-606) and ShaCompressSpongeStark (sha_compress_sponge_stark.rs:233-268)
+__device__ const uint32_t SHA256_K_DEV[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+// wrapping add of NIN byte quadruples (column offsets in[]) into op = value[4], carry[NC]; every constraint times gate
+template <int NA, int NIN, int NC>
+__device__ __forceinline__ void sha_wadd_constraints(const gl_t* __restrict__ lv, size_t cs, const int (&in)[NIN], int op, gl_t gate,
+                                                     consumer_t<NA>& k) {
+    gl_t csum = 0, carry = 0;
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        gl_t c = lv[(size_t)(op + 4 + i) * cs];
+        k.constraint(gl_mul(gate, gl_mul(c, gl_sub(1, c))));
+        csum = gl_add(csum, c);
+        if (i) carry = gl_add(carry, gl_mul(c, (gl_t)i));
+    }
+    k.constraint(gl_mul(gate, gl_sub(csum, 1)));
+    gl_t sum = 0;
+#pragma unroll
+    for (int b = 3; b >= 0; b--) {
+        gl_t s = lv[(size_t)(in[0] + b) * cs];
+#pragma unroll
+        for (int q = 1; q < NIN; q++) s = gl_add(s, lv[(size_t)(in[q] + b) * cs]);
+        sum = gl_add(gl_mul(sum, 1u << 8), s);
+    }
+    k.constraint(gl_mul(gate, gl_sub(gl_sub(sum, gl_mul(carry, (gl_t)1 << 32)), sha_le4(lv + (size_t)op * cs, cs))));
+}
+template <int NA>
+__device__ void eval_sha_compress_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
+    const gl_t* __restrict__ nv = lv + dnext;
+    enum { ROUND = 159, TIMESTAMP = 146, W_VIRT = 149 };
+    gl_t is_final = lv[(size_t)(ROUND + 64) * cs];
+    k.constraint(gl_mul(is_final, gl_sub(is_final, 1)));
+    gl_t sum = is_final, kb[4] = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int j = 0; j < 64; j++) {
+        gl_t f = lv[(size_t)(ROUND + j) * cs];
+        sum = gl_add(sum, f);
+        uint32_t kc = SHA256_K_DEV[j];
+#pragma unroll
+        for (int i = 0; i < 4; i++) kb[i] = gl_add(kb[i], gl_mul(f, (kc >> (8 * i)) & 0xFF));
+    }
+    k.constraint(gl_mul(sum, gl_sub(sum, 1)));
+    gl_t g = gl_mul(sum, gl_sub(1, is_final));
+#pragma unroll
+    for (int i = 0; i < 4; i++) k.constraint(gl_mul(g, gl_sub(lv[(size_t)(40 + i) * cs], kb[i])));
+    sha_rot_constraints<NA>(lv + 16 * cs, lv + 92 * cs, cs, 6, false, k);
+    sha_rot_constraints<NA>(lv + 16 * cs, lv + 98 * cs, cs, 11, false, k);
+    sha_rot_constraints<NA>(lv + 16 * cs, lv + 104 * cs, cs, 25, false, k);
+    sha_rot_constraints<NA>(lv, lv + 110 * cs, cs, 2, false, k);
+    sha_rot_constraints<NA>(lv, lv + 116 * cs, cs, 13, false, k);
+    sha_rot_constraints<NA>(lv, lv + 122 * cs, cs, 22, false, k);
+#pragma unroll
+    for (int i = 0; i < 4; i++) k.constraint(gl_mul(sum, gl_sub(gl_add(lv[(size_t)(16 + i) * cs], lv[(size_t)(32 + i) * cs]), 255)));
+    { const int in[5] = {28, 48, 60, 40, 36}; sha_wadd_constraints<NA, 5, 5>(lv, cs, in, 150, sum, k); }  // temp1 = h + s_1 + ch + k_i + w_i
+    { const int in[2] = {68, 88}; sha_wadd_constraints<NA, 2, 2>(lv, cs, in, 128, sum, k); }              // temp2 = s_0 + maj
+    { const int in[2] = {12, 150}; sha_wadd_constraints<NA, 2, 2>(lv, cs, in, 134, sum, k); }             // d + temp1
+    { const int in[2] = {150, 128}; sha_wadd_constraints<NA, 2, 2>(lv, cs, in, 140, sum, k); }            // temp1 + temp2
+    k.constraint(gl_mul(g, gl_sub(nv[(size_t)TIMESTAMP * cs], lv[(size_t)TIMESTAMP * cs])));
+    k.constraint(gl_mul(g, gl_sub(gl_sub(nv[(size_t)W_VIRT * cs], lv[(size_t)W_VIRT * cs]), 4)));
+#pragma unroll
+    for (int i = 0; i < 4; i++) k.constraint(gl_mul(g, gl_sub(lv[(size_t)(140 + i) * cs], nv[(size_t)i * cs])));
+#pragma unroll 1
+    for (int w = 0; w < 3; w++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) k.constraint(gl_mul(g, gl_sub(lv[(size_t)(4 * w + i) * cs], nv[(size_t)(4 * (w + 1) + i) * cs])));
+#pragma unroll
+    for (int i = 0; i < 4; i++) k.constraint(gl_mul(g, gl_sub(lv[(size_t)(134 + i) * cs], nv[(size_t)(16 + i) * cs])));
+#pragma unroll 1
+    for (int w = 4; w < 7; w++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) k.constraint(gl_mul(g, gl_sub(lv[(size_t)(4 * w + i) * cs], nv[(size_t)(4 * (w + 1) + i) * cs])));
+}
+template <int NA>
+__device__ void eval_sha_compress_sponge_constraints(const gl_t* __restrict__ lv, size_t cs, consumer_t<NA>& k) {
+    gl_t real = lv[(size_t)126 * cs];
+    k.constraint(gl_mul(real, gl_sub(real, 1)));
+#pragma unroll
+    for (int i = 0; i < 7; i++) k.constraint(gl_mul(real, gl_sub(gl_sub(lv[(size_t)(113 + i) * cs], lv[(size_t)(112 + i) * cs]), 4)));
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) {
+        const int in[2] = {4 * i, 32 + 4 * i};
+        sha_wadd_constraints<NA, 2, 2>(lv, cs, in, 64 + 6 * i, real, k);
+    }
+}
+
 // MemoryStark (memory/memory_stark.rs:253-341; columns memory/columns.rs, VALUE_LIMBS = 1)
 template <int NA>
 __device__ void eval_memory_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
@@ -525,7 +615,9 @@ __device__ __forceinline__ void eval_table_constraints(const gl_t* __restrict__ 
     else if constexpr (TABLE == ZKM_TABLE_MEMORY) eval_memory_constraints<NA>(lv, cs, dnext, k);
     else if constexpr (TABLE == ZKM_TABLE_POSEIDON_SPONGE) eval_poseidon_sponge_constraints<NA>(lv, cs, dnext, k);
     else if constexpr (TABLE == ZKM_TABLE_SHA_EXTEND) eval_sha_extend_constraints<NA>(lv, cs, k);
-    else eval_sha_extend_sponge_constraints<NA>(lv, cs, dnext, k);
+    else if constexpr (TABLE == ZKM_TABLE_SHA_EXTEND_SPONGE) eval_sha_extend_sponge_constraints<NA>(lv, cs, dnext, k);
+    else if constexpr (TABLE == ZKM_TABLE_SHA_COMPRESS) eval_sha_compress_constraints<NA>(lv, cs, dnext, k);
+    else eval_sha_compress_sponge_constraints<NA>(lv, cs, k);
 }
 
 // CTL checks driven by the column-set description (eval_helper_columns cross_table_lookup.rs:1006-1058,
@@ -657,7 +749,8 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     ZKM_HIP_CHECK(hipMemcpyAsync(d_alphas, alphas_host, nalphas * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
     gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
     {
-        static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory", "quotient_poseidon_sponge", "quotient_sha_extend", "quotient_sha_extend_sponge"};
+        static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory", "quotient_poseidon_sponge", "quotient_sha_extend", "quotient_sha_extend_sponge", "quotient_sha_compress",
+                                            "quotient_sha_compress_sponge"};
         zkm_prof_scope ps(c, names[table_id]);
         dim3 grid((size + 255) / 256), block(256);
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
@@ -679,7 +772,11 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             case 12: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_EXTEND, 1); break;
             case 13: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_EXTEND, 2); break;
             case 14: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_EXTEND_SPONGE, 1); break;
-            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_EXTEND_SPONGE, 2); break;
+            case 15: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_EXTEND_SPONGE, 2); break;
+            case 16: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_COMPRESS, 1); break;
+            case 17: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_COMPRESS, 2); break;
+            case 18: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_COMPRESS_SPONGE, 1); break;
+            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_COMPRESS_SPONGE, 2); break;
         }
 #undef ZKM_LAUNCH_QUOTIENT
         ZKM_HIP_CHECK(hipGetLastError());

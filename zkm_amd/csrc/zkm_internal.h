@@ -144,6 +144,8 @@ void zkm_table_lookup_columns_device(zkm_ctx* c, int table_id, const uint64_t* c
                                      gl_t* d_out);
 void zkm_launch_sha_extend_trace(zkm_ctx* c, const uint8_t* d_inputs, const uint64_t* d_ts, size_t k, size_t n, gl_t* out);
 void zkm_launch_sha_extend_sponge_trace(zkm_ctx* c, const uint32_t* d_w16, const uint64_t* d_meta, size_t k, size_t n, gl_t* out);
+void zkm_launch_sha_compress_trace(zkm_ctx* c, bool sponge, const uint32_t* d_hx, const uint32_t* d_w, const uint64_t* d_meta, size_t k,
+                                   size_t n, gl_t* out);
 void zkm_launch_keccak_trace(zkm_ctx* c, const uint64_t* d_inputs, const uint64_t* d_ts, size_t nperms, size_t n, gl_t* out);
 void zkm_launch_logic_trace(zkm_ctx* c, const uint32_t* d_ops, size_t nops, size_t n, gl_t* out, int* d_bad);
 

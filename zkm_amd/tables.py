@@ -9,9 +9,9 @@ include/zkm_hip.h); mirrors
 from .ctl import CtlTable
 
 TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY, TABLE_POSEIDON_SPONGE = 0, 1, 2, 3, 4, 5
-TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE = 6, 7
+TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRESS_SPONGE = 6, 7, 8, 9
 WIDTH = {TABLE_POSEIDON: 262, TABLE_LOGIC: 69, TABLE_KECCAK_SPONGE: 470, TABLE_KECCAK: 2431, TABLE_MEMORY: 13, TABLE_POSEIDON_SPONGE: 110,
-         TABLE_SHA_EXTEND: 78, TABLE_SHA_EXTEND_SPONGE: 76}
+         TABLE_SHA_EXTEND: 78, TABLE_SHA_EXTEND_SPONGE: 76, TABLE_SHA_COMPRESS: 224, TABLE_SHA_COMPRESS_SPONGE: 127}
 
 # LogicStark columns (logic.rs:25-50)
 LOGIC_IS_AND, LOGIC_IS_OR, LOGIC_IS_XOR, LOGIC_IS_NOR = 0, 1, 2, 3
@@ -34,6 +34,14 @@ SE_W_I, SE_W15, SE_W2, SE_W16, SE_W7, SE_S0_INTER, SE_S0, SE_S1_INTER, SE_S1 = 0
 SE_RR7, SE_RR18, SE_RR17, SE_RR19, SE_RS10, SE_RS3, SE_TIMESTAMP, SE_IS_REAL = 40, 46, 52, 58, 64, 70, 76, 77
 SES_ROUND, SES_W15, SES_W2, SES_W16, SES_W7, SES_W_I, SES_IN_VIRT, SES_OUT_VIRT, SES_CONTEXT, SES_SEGMENT, SES_TIMESTAMP = (
     0, 48, 52, 56, 60, 64, 68, 72, 73, 74, 75)
+
+# ShaCompressStark (sha_compress/columns.rs:9-55) and ShaCompressSpongeStark (sha_compress_sponge/columns.rs:7-27) columns
+SC_STATE, SC_E_NOT, SC_W_I, SC_K_I, SC_S1_INTER, SC_S1, SC_E_AND_F, SC_ENOT_AND_G, SC_CH = 0, 32, 36, 40, 44, 48, 52, 56, 60
+SC_S0_INTER, SC_S0, SC_A_AND_B, SC_A_AND_C, SC_B_AND_C, SC_MAJ_INTER, SC_MAJ = 64, 68, 72, 76, 80, 84, 88
+SC_E_RR6, SC_E_RR11, SC_E_RR25, SC_A_RR2, SC_A_RR13, SC_A_RR22 = 92, 98, 104, 110, 116, 122
+SC_TIMESTAMP, SC_SEGMENT, SC_CONTEXT, SC_W_I_VIRT, SC_ROUND = 146, 147, 148, 149, 159
+SCS_HX, SCS_OUT_STATE, SCS_OUT_HX, SCS_HX_VIRT, SCS_W_VIRT, SCS_TIMESTAMP, SCS_CONTEXT, SCS_SEGMENT = 0, 32, 64, 112, 120, 121, 122, 123
+SCS_W_SEGMENT, SCS_W_CONTEXT, SCS_IS_REAL = 124, 125, 126
 
 # MemoryStark columns (memory/columns.rs)
 MEM_FILTER, MEM_TIMESTAMP, MEM_IS_READ, MEM_CONTEXT, MEM_SEGMENT, MEM_VIRTUAL, MEM_VALUE = 0, 1, 2, 3, 4, 5, 6
@@ -298,3 +306,92 @@ def logic_lookers_sha_extend(extend_index, extend_ctl):
 def memory_lookers_sha_extend_sponge(sponge_index, sponge_ctl):
     """The ShaExtendSponge part of all_stark::ctl_memory() (all_stark.rs:503-509): 16 looking column sets."""
     return [(sponge_index, sha_extend_sponge_looking_memory(sponge_ctl, i)) for i in range(16)]
+
+
+def sha_compress_ctl_data_inputs(t: CtlTable):
+    """sha_compress_stark::ctl_data_inputs() with ctl_filter_inputs() (sha_compress_stark.rs:39-50, :213-217)."""
+    return t.singles_set(list(range(SC_STATE, SC_STATE + 32)) + [SC_TIMESTAMP, SC_SEGMENT, SC_CONTEXT, SC_W_I_VIRT], filter_col=SC_ROUND)
+
+
+def sha_compress_ctl_data_outputs(t: CtlTable):
+    """sha_compress_stark::ctl_data_outputs() with ctl_filter_outputs() (sha_compress_stark.rs:52-57, :219-223)."""
+    return t.singles_set(list(range(SC_STATE, SC_STATE + 32)) + [SC_TIMESTAMP], filter_col=SC_ROUND + 64)
+
+
+# (opcode, input 0, input 1, output) of the twelve logic lookups of a compression round, in the order of all_stark.rs:387-470
+_XOR, _AND = 0b100110 << 6, 0b100100 << 6
+SHA_COMPRESS_LOGIC = [
+    (_XOR, SC_E_RR6, SC_E_RR11, SC_S1_INTER), (_XOR, SC_S1_INTER, SC_E_RR25, SC_S1), (_AND, SC_STATE + 16, SC_STATE + 20, SC_E_AND_F),
+    (_AND, SC_E_NOT, SC_STATE + 24, SC_ENOT_AND_G), (_XOR, SC_E_AND_F, SC_ENOT_AND_G, SC_CH), (_XOR, SC_A_RR2, SC_A_RR13, SC_S0_INTER),
+    (_XOR, SC_S0_INTER, SC_A_RR22, SC_S0), (_AND, SC_STATE, SC_STATE + 4, SC_A_AND_B), (_AND, SC_STATE, SC_STATE + 8, SC_A_AND_C),
+    (_AND, SC_STATE + 4, SC_STATE + 8, SC_B_AND_C), (_XOR, SC_A_AND_B, SC_A_AND_C, SC_MAJ_INTER), (_XOR, SC_MAJ_INTER, SC_B_AND_C, SC_MAJ)]
+
+
+def _sc_round_filter(t: CtlTable):
+    """ctl_logic_filter(): rounds 0..63 (sha_compress_stark.rs:225-229)."""
+    return t.sum(range(SC_ROUND, SC_ROUND + 64))
+
+
+def logic_lookers_sha_compress(index, t: CtlTable):
+    """The ShaCompress part of all_stark::ctl_logic() (all_stark.rs:387-470; columns sha_compress_stark.rs:59-191)."""
+    out = []
+    for opcode, in0, in1, res in SHA_COMPRESS_LOGIC:
+        first = t.constant(opcode)
+        for c in (in0, in1, res):
+            t.le_bytes(range(c, c + 4))
+        out.append((index, t.colset(range(first, first + 4), filter_constants=[_sc_round_filter(t)])))
+    return out
+
+
+def memory_lookers_sha_compress(index, t: CtlTable):
+    """The ShaCompress part of all_stark::ctl_memory() (all_stark.rs:519-525): w_i is read four times per round."""
+    out = []
+    for _ in range(4):
+        first = t.constant(1)
+        t.single(SC_CONTEXT)
+        t.single(SC_SEGMENT)
+        t.single(SC_W_I_VIRT)
+        t.le_bytes(range(SC_W_I, SC_W_I + 4))
+        t.single(SC_TIMESTAMP)
+        out.append((index, t.colset(range(first, first + 6), filter_constants=[_sc_round_filter(t)])))
+    return out
+
+
+def sha_compress_sponge_looking_inputs(t: CtlTable):
+    """sha_compress_sponge_stark::ctl_looking_sha_compress_inputs() with ctl_looking_sha_compress_filter() (:29-39, :81-86)."""
+    first = len(t._cols)
+    for c in list(range(SCS_HX, SCS_HX + 32)) + [SCS_TIMESTAMP, SCS_W_SEGMENT, SCS_W_CONTEXT, SCS_W_VIRT]:
+        t.single(c)
+    return t.colset(range(first, first + 36), filter_constants=[t.single(SCS_IS_REAL)])
+
+
+def sha_compress_sponge_looking_outputs(t: CtlTable):
+    first = len(t._cols)
+    for c in list(range(SCS_OUT_STATE, SCS_OUT_STATE + 32)) + [SCS_TIMESTAMP]:
+        t.single(c)
+    return t.colset(range(first, first + 33), filter_constants=[t.single(SCS_IS_REAL)])
+
+
+def memory_lookers_sha_compress_sponge(index, t: CtlTable):
+    """The ShaCompressSponge part of all_stark::ctl_memory() (all_stark.rs:511-517; columns sha_compress_sponge_stark.rs:63-79)."""
+    out = []
+    for i in range(32):
+        q = i // 4
+        first = t.constant(1)
+        t.single(SCS_CONTEXT)
+        t.single(SCS_SEGMENT)
+        t.single(SCS_HX_VIRT + q)
+        t.le_bytes(range(SCS_HX + 4 * q, SCS_HX + 4 * q + 4))
+        t.single(SCS_TIMESTAMP)
+        out.append((index, t.colset(range(first, first + 6), filter_constants=[t.single(SCS_IS_REAL)])))
+    return out
+
+
+def ctl_sha_compress_inputs(sponge_index, compress_index, sponge_ctl, compress_ctl):
+    """all_stark::ctl_sha_compress_inputs() (all_stark.rs:298-310)."""
+    return [(sponge_index, sha_compress_sponge_looking_inputs(sponge_ctl))], (compress_index, sha_compress_ctl_data_inputs(compress_ctl))
+
+
+def ctl_sha_compress_outputs(sponge_index, compress_index, sponge_ctl, compress_ctl):
+    """all_stark::ctl_sha_compress_outputs() (all_stark.rs:312-324)."""
+    return [(sponge_index, sha_compress_sponge_looking_outputs(sponge_ctl))], (compress_index, sha_compress_ctl_data_outputs(compress_ctl))
