@@ -152,19 +152,12 @@ static void TNAME(eval_keccak_sponge)(const T* lv, const T* nv, TNAME(consumer) 
  * keccak/columns.rs:7-134, xor_gen / xor3_gen / andn_gen keccak/logic.rs:16-54, round-constant bits keccak/constants.rs ---- */
 #ifndef ZKO_KECCAK_REGS
 #define ZKO_KECCAK_REGS
-static const uint8_t KK_R[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};
-static const uint64_t KK_RC[24] = {
-    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
-    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
-    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
-    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
 enum { KK_TIMESTAMP = 24, KK_A = 25, KK_C = 75, KK_CP = 395, KK_AP = 715, KK_APP = 2315, KK_APP00_BITS = 2365, KK_APPP00 = 2429, KK_COLS = 2431 };
 static inline int kk_a(int x, int y) { return KK_A + (x * 5 + y) * 2; }
 static inline int kk_c(int x, int z) { return KK_C + x * 64 + z; }
 static inline int kk_cp(int x, int z) { return KK_CP + x * 64 + z; }
 static inline int kk_ap(int x, int y, int z) { return KK_AP + x * 320 + y * 64 + z; }
-static inline int kk_b(int x, int y, int z) { int a = (x + 3 * y) % 5, b = x; return kk_ap(a, b, (z + 64 - KK_R[a][b]) % 64); }
+static inline int kk_b(int x, int y, int z) { int a = (x + 3 * y) % 5, b = x; return kk_ap(a, b, (z + 64 - ZKO_KECCAK_R[a][b]) % 64); }
 static inline int kk_app(int x, int y) { return KK_APP + x * 10 + y * 2; }
 static inline int kk_appp(int x, int y) { return (x == 0 && y == 0) ? KK_APPP00 : kk_app(x, y); }
 #endif
@@ -218,7 +211,7 @@ static void TNAME(eval_keccak)(const T* lv, const T* nv, TNAME(consumer) * k) {
         T acc = T_FROMB(0);
         for (int z = 32 * half + 31; z >= 32 * half; z--) {
             T rc_bit = T_FROMB(0);
-            for (int r = 0; r < 24; r++) rc_bit = T_ADD(rc_bit, T_MULB(lv[r], (KK_RC[r] >> z) & 1));
+            for (int r = 0; r < 24; r++) rc_bit = T_ADD(rc_bit, T_MULB(lv[r], (ZKO_KECCAK_RC[r] >> z) & 1));
             acc = T_ADD(T_ADD(acc, acc), TNAME(xor_gen)(lv[KK_APP00_BITS + z], rc_bit));
         }
         TNAME(cons)(k, T_SUB(acc, lv[KK_APPP00 + half]));
@@ -323,16 +316,6 @@ static void TNAME(eval_sha_extend_sponge)(const T* lv, const T* nv, TNAME(consum
  * a_and_b 72, a_and_c 76, b_and_c 80, maj_inter 84, maj 88, rotations (value[4], shift, carry) e_rr_6 92, e_rr_11 98, e_rr_25 104,
  * a_rr_2 110, a_rr_13 116, a_rr_22 122, temp2 (value[4], carry[2]) 128, d_add_temp1 134, temp1_add_temp2 140, timestamp 146,
  * segment 147, context 148, w_i_virt 149, temp1 (value[4], carry[5]) 150, round 159..223 (NUM_COMPRESS_ROWS = 65) ---- */
-#ifndef ZKO_SHA_K
-#define ZKO_SHA_K
-static const uint32_t ZKO_SHA256_K[64] = {
-    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
-    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
-    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
-    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
-    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
-    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-#endif
 /* wrapping add of `nin` byte quadruples: op = value[4] then carry[ncarry]; every constraint is multiplied by `gate` */
 static void TNAME(sha_wadd)(const T* const* in, int nin, const T* op, int ncarry, T gate, TNAME(consumer) * k) {
     T one = T_FROMB(1), csum = T_FROMB(0), carry = T_FROMB(0);

@@ -10,14 +10,8 @@
  */
 #include <string.h>
 #include "zkm_oracle.h"
+#include "hash_constants.h"
 
-static const uint64_t RC[24] = {
-    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
-    0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
-    0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
-    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
-    0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
 
 /* rho rotation offsets indexed [x + 5*y] */
 static const unsigned RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
@@ -37,7 +31,7 @@ void zko_keccakf(uint64_t a[25]) {
             for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl(a[x + 5 * y], RHO[x + 5 * y]);
         for (int y = 0; y < 5; y++)
             for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
-        a[0] ^= RC[round];
+        a[0] ^= ZKO_KECCAK_RC[round];
     }
 }
 
@@ -138,7 +132,6 @@ size_t zko_keccak_sponge_trace(const uint8_t* inputs, const uint64_t* off, const
 /* ---- KeccakStark witness rows: restates keccak/keccak_stark.rs:62-226 (generate_trace_rows_for_perm,
  * copy_output_to_input, generate_trace_row_for_round) with the register map of keccak/columns.rs.  24 rows per
  * permutation; A(x, y) = input[y*5 + x]. ---- */
-static const uint8_t KW_R[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};
 
 size_t zko_keccak_trace(const uint64_t* inputs, const uint64_t* timestamps, size_t nperms, unsigned log_n, uint64_t* out) {
     size_t n = (size_t)1 << log_n;
@@ -175,7 +168,7 @@ size_t zko_keccak_trace(const uint64_t* inputs, const uint64_t* timestamps, size
             /* B[x, y] = ROT(A'[(x + 3y) % 5, x], r); A''[x, y] = B[x, y] ^ (~B[x+1, y] & B[x+2, y]) */
             uint64_t B[5][5];
             for (int x = 0; x < 5; x++)
-                for (int y = 0; y < 5; y++) { int a = (x + 3 * y) % 5; B[x][y] = rotl(Ap[a][x], KW_R[a][x]); }
+                for (int y = 0; y < 5; y++) { int a = (x + 3 * y) % 5; B[x][y] = rotl(Ap[a][x], ZKO_KECCAK_R[a][x]); }
             for (int x = 0; x < 5; x++)
                 for (int y = 0; y < 5; y++) {
                     App[x][y] = B[x][y] ^ (~B[(x + 1) % 5][y] & B[(x + 2) % 5][y]);
@@ -183,7 +176,7 @@ size_t zko_keccak_trace(const uint64_t* inputs, const uint64_t* timestamps, size
                     CELL(2315 + x * 10 + y * 2 + 1) = App[x][y] >> 32;
                 }
             for (int z = 0; z < 64; z++) CELL(2365 + z) = (App[0][0] >> z) & 1;
-            uint64_t appp = App[0][0] ^ RC[round];
+            uint64_t appp = App[0][0] ^ ZKO_KECCAK_RC[round];
             CELL(2429) = (uint32_t)appp;
             CELL(2430) = appp >> 32;
 #undef CELL
@@ -270,13 +263,6 @@ size_t zko_sha_extend_sponge_trace(const uint32_t* w16, const uint64_t* meta, si
 }
 
 /* ---- SHA-256 compression tables ---- */
-static const uint32_t KW_SHA_K[64] = {
-    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
-    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
-    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
-    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
-    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
-    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 static void put_wadd(uint64_t* out, size_t n, size_t row, int col, uint64_t wide) {
     put_le4(out, n, row, col, (uint32_t)wide);
     out[(size_t)(col + 4 + (wide >> 32)) * n + row] = 1;
@@ -303,7 +289,7 @@ size_t zko_sha_compress_trace(const uint32_t* hx, const uint32_t* w, const uint6
         memcpy(s, hx + 8 * e_, 32);
         for (int rd = 0; rd < 65; rd++) {
             size_t row = 65 * e_ + rd;
-            uint32_t wi = rd < 64 ? w[64 * e_ + rd] : 0, ki = rd < 64 ? KW_SHA_K[rd] : 0;
+            uint32_t wi = rd < 64 ? w[64 * e_ + rd] : 0, ki = rd < 64 ? ZKO_SHA256_K[rd] : 0;
             uint32_t a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
             for (int q = 0; q < 8; q++) put_le4(out, n, row, 4 * q, s[q]);
             put_le4(out, n, row, 32, ~e);
@@ -344,7 +330,7 @@ void zko_sha_compress_sponge_trace(const uint32_t* hx, const uint32_t* w, const 
     for (size_t r = 0; r < k && r < n; r++) {
         uint32_t s[8];
         memcpy(s, hx + 8 * r, 32);
-        for (int i = 0; i < 64; i++) sha_round(s, w[64 * r + i], KW_SHA_K[i]);
+        for (int i = 0; i < 64; i++) sha_round(s, w[64 * r + i], ZKO_SHA256_K[i]);
         for (int q = 0; q < 8; q++) {
             put_le4(out, n, r, 4 * q, hx[8 * r + q]);
             put_le4(out, n, r, 32 + 4 * q, s[q]);

@@ -18,6 +18,7 @@
 #include <string.h>
 #include <time.h>
 #include "zkm_oracle.h"
+#include "hash_constants.h"
 #include "gl.h"
 #include "poseidon_constants.inc"
 

@@ -5,9 +5,8 @@
 // (proof.rs:299-334) and plonky2's PolynomialBatch::prove_openings / fri_proof.
 // The Challenger stays on the host (a few hundred field elements per table); only caps, openings,
 // the final polynomial and the query openings cross PCIe.
-#include "poseidon_dev.h"
+#include "constraints_dev.h"
 #include "ctl_dev.h"
-#include "zkm_internal.h"
 
 // ------------------------------------------------------------------ proof layout (include/zkm_hip.h)
 struct proof_layout {
@@ -46,580 +45,9 @@ static void make_layout(proof_layout& y, const zkm_stark_config* c, unsigned log
     y.total = o + q * y.nq;
 }
 
-// ------------------------------------------------------------------ K7: quotient evaluation, Poseidon table
-// Constraint order = alpha-power order (constraint_consumer.rs:57-62): table constraints
-// (poseidon_stark.rs:554-594), then CTL checks (cross_table_lookup.rs:1067-1118), vanishing_poly.rs:30-45.
-template <int NA>
-struct consumer_t {
-    gl_t alpha[NA], acc[NA];
-    gl_t z_last, l_first, l_last;
-    __device__ __forceinline__ void constraint(gl_t c) {
-#pragma unroll
-        for (int j = 0; j < NA; j++) acc[j] = gl_add(gl_mul(acc[j], alpha[j]), c);
-    }
-    __device__ __forceinline__ void transition(gl_t c) { constraint(gl_mul(c, z_last)); }
-    __device__ __forceinline__ void last_row(gl_t c) { constraint(gl_mul(c, l_last)); }
-    __device__ __forceinline__ void first_row(gl_t c) { constraint(gl_mul(c, l_first)); }
-};
-
-template <int NA>
-__device__ __forceinline__ void sbox_constraints(consumer_t<NA>& k, gl_t in, gl_t inter, gl_t out) {
-    k.constraint(gl_sub(gl_mul(gl_mul(in, in), in), inter));
-    k.constraint(gl_sub(gl_mul(gl_mul(in, inter), inter), out));
-}
-
-__device__ __forceinline__ void mds_canon(gl_t s[12]) {
-    poseidon_mds(s);
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
-}
-
-// lv(c) = trace LDE value of column c at this thread's row
-template <int NA>
-__device__ void eval_poseidon_constraints(const gl_t* __restrict__ lv, size_t cs, consumer_t<NA>& k) {
-    gl_t s[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = lv[(size_t)(1 + i) * cs];
-    int rc = 0;
-#pragma unroll 1
-    for (int r = 0; r < 4; r++, rc++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            gl_t x = gl_add(s[i], gl_canon(PC::ZKM_POSEIDON_RC[rc * 12 + i]));
-            gl_t tmp = lv[(size_t)(26 + 24 * r + 2 * i) * cs], out = lv[(size_t)(26 + 24 * r + 2 * i + 1) * cs];
-            sbox_constraints(k, x, tmp, out);
-            s[i] = out;
-        }
-        mds_canon(s);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PC::ZKM_POSEIDON_FAST_FIRST_RC[i]);
-    {
-        gl_t t[12];
-        t[0] = s[0];
-#pragma unroll
-        for (int c = 1; c < 12; c++) {
-            uint64_t acc = 0;
-#pragma unroll
-            for (int r = 1; r < 12; r++) acc = gl_add_loose(acc, gl_mul_loose(s[r], PC::ZKM_POSEIDON_FAST_INIT[r - 1][c - 1]));
-            t[c] = gl_canon(acc);
-        }
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = t[i];
-    }
-#pragma unroll 1
-    for (int r = 0; r < 22; r++) {
-        gl_t inter = lv[(size_t)(122 + 2 * r) * cs], out = lv[(size_t)(122 + 2 * r + 1) * cs];
-        sbox_constraints(k, s[0], inter, out);
-        gl_t s0 = r < 21 ? gl_add(out, PC::ZKM_POSEIDON_FAST_RC[r]) : out;
-        uint64_t d = gl_mul_loose(s0, 25);
-#pragma unroll
-        for (int i = 1; i < 12; i++) d = gl_add_loose(d, gl_mul_loose(s[i], PC::ZKM_POSEIDON_FAST_W_HATS[r][i - 1]));
-#pragma unroll
-        for (int i = 1; i < 12; i++) s[i] = gl_add(s[i], gl_mul(s0, PC::ZKM_POSEIDON_FAST_VS[r][i - 1]));
-        s[0] = gl_canon(d);
-    }
-    rc += 22;
-#pragma unroll 1
-    for (int r = 0; r < 4; r++, rc++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            gl_t x = gl_add(s[i], gl_canon(PC::ZKM_POSEIDON_RC[rc * 12 + i]));
-            gl_t tmp = lv[(size_t)(166 + 24 * r + 2 * i) * cs], out = lv[(size_t)(166 + 24 * r + 2 * i + 1) * cs];
-            sbox_constraints(k, x, tmp, out);
-            s[i] = out;
-        }
-        mds_canon(s);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; i++) k.constraint(gl_sub(s[i], lv[(size_t)(13 + i) * cs]));
-}
-
-// LogicStark (logic.rs:199-248; columns :25-50).  64 booleanity constraints then the result constraint.
-template <int NA>
-__device__ void eval_logic_constraints(const gl_t* __restrict__ lv, size_t cs, consumer_t<NA>& k) {
-    gl_t is_and = lv[0], is_or = lv[cs], is_xor = lv[2 * cs], is_nor = lv[3 * cs];
-    gl_t sum_coeff = gl_sub(gl_add(is_or, is_xor), is_nor);
-    gl_t and_coeff = gl_add(gl_sub(gl_sub(is_and, is_or), gl_add(is_xor, is_xor)), is_nor);
-    gl_t x = 0, y = 0, x_land_y = 0;
-#pragma unroll 4
-    for (int i = 0; i < 32; i++) {
-        gl_t b = lv[(size_t)(4 + i) * cs];
-        k.constraint(gl_mul(b, gl_sub(b, 1)));
-        x = gl_add(x, gl_mul(b, (gl_t)1 << i));
-    }
-#pragma unroll 4
-    for (int i = 0; i < 32; i++) {
-        gl_t b = lv[(size_t)(36 + i) * cs];
-        k.constraint(gl_mul(b, gl_sub(b, 1)));
-        y = gl_add(y, gl_mul(b, (gl_t)1 << i));
-        x_land_y = gl_add(x_land_y, gl_mul(gl_mul(lv[(size_t)(4 + i) * cs], b), (gl_t)1 << i));
-    }
-    gl_t x_op_y = gl_add(gl_add(gl_mul(sum_coeff, gl_add(x, y)), gl_mul(and_coeff, x_land_y)), gl_mul(is_nor, 0xFFFFFFFFULL));
-    k.constraint(gl_sub(lv[(size_t)68 * cs], x_op_y));
-}
-
-// KeccakSpongeStark (keccak_sponge_stark.rs:456-567; columns keccak_sponge/columns.rs:19-70).  nv = lv + dnext.
-template <int NA>
-__device__ void eval_keccak_sponge_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
-    const gl_t* __restrict__ nv = lv + dnext;
-    enum { FULL = 0, CONTEXT = 1, SEGMENT = 2, TIMESTAMP = 37, LEN = 38, ABSORBED = 39, FINAL_LEN = 40, ORIG_RATE = 176,
-           ORIG_CAP = 210, PARTIAL = 396, DIGEST = 438 };
-    gl_t full = lv[FULL];
-    k.constraint(gl_mul(full, gl_sub(full, 1)));
-    gl_t is_final = 0, next_final = 0;
-#pragma unroll 4
-    for (int i = 0; i < 136; i++) {
-        is_final = gl_add(is_final, lv[(size_t)(FINAL_LEN + i) * cs]);
-        next_final = gl_add(next_final, nv[(size_t)(FINAL_LEN + i) * cs]);
-    }
-    k.constraint(gl_mul(is_final, gl_sub(is_final, 1)));
-#pragma unroll 4
-    for (int i = 0; i < 136; i++) {
-        gl_t f = lv[(size_t)(FINAL_LEN + i) * cs];
-        k.constraint(gl_mul(f, gl_sub(f, 1)));
-    }
-    k.constraint(gl_mul(is_final, full));
-    gl_t absorbed = lv[(size_t)ABSORBED * cs];
-    k.first_row(absorbed);
-#pragma unroll 2
-    for (int i = 0; i < 50; i++) k.first_row(lv[(size_t)(ORIG_RATE + i) * cs]);  // original_rate then original_capacity
-    // both scaled by (x - last) inside transition(): fold is_final / full into it once
-    gl_t fin_t = gl_mul(is_final, k.z_last), full_t = gl_mul(full, k.z_last);
-    k.constraint(gl_mul(fin_t, nv[(size_t)ABSORBED * cs]));
-#pragma unroll 2
-    for (int i = 0; i < 50; i++) k.constraint(gl_mul(fin_t, nv[(size_t)(ORIG_RATE + i) * cs]));
-    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)CONTEXT * cs], nv[(size_t)CONTEXT * cs])));
-    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)SEGMENT * cs], nv[(size_t)SEGMENT * cs])));
-    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)TIMESTAMP * cs], nv[(size_t)TIMESTAMP * cs])));
-#pragma unroll 2
-    for (int l = 0; l < 8; l++) {
-        gl_t cur = lv[(size_t)(DIGEST + 4 * l) * cs];
-#pragma unroll
-        for (int i = 1; i < 4; i++) cur = gl_add(cur, gl_mul(lv[(size_t)(DIGEST + 4 * l + i) * cs], (gl_t)1 << (8 * i)));
-        k.constraint(gl_mul(full_t, gl_sub(nv[(size_t)(ORIG_RATE + l) * cs], cur)));
-    }
-#pragma unroll 2
-    for (int i = 0; i < 42; i++)  // rate u32s 8..33 then the 16 capacity u32s are contiguous in both views
-        k.constraint(gl_mul(full_t, gl_sub(nv[(size_t)(ORIG_RATE + 8 + i) * cs], lv[(size_t)(PARTIAL + i) * cs])));
-    k.constraint(gl_mul(full_t, gl_sub(gl_add(absorbed, 136), nv[(size_t)ABSORBED * cs])));
-    gl_t is_dummy = gl_sub(gl_sub(1, full), is_final);
-    k.transition(gl_mul(is_dummy, gl_add(nv[FULL], next_final)));
-    gl_t offset = gl_sub(lv[(size_t)LEN * cs], absorbed);
-#pragma unroll 4
-    for (int i = 0; i < 136; i++) k.constraint(gl_mul(lv[(size_t)(FINAL_LEN + i) * cs], gl_sub(offset, (gl_t)i)));
-}
-
-// KeccakStark (keccak/keccak_stark.rs:256-413: 3 + 320 + 50 + 320 + 50 + 4 + 50 = 797 constraints over 2431 columns;
-// register map keccak/columns.rs:7-134).  Columns are streamed from HBM in constraint order (each thread owns one
-// row; a wavefront reads 64 consecutive rows of one column = 512 contiguous bytes per load).
-namespace kk {
-enum { TIMESTAMP = 24, A = 25, C = 75, CP = 395, AP = 715, APP = 2315, APP00_BITS = 2365, APPP00 = 2429 };
-__device__ const uint8_t ROT[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};
-__device__ __forceinline__ int reg_a(int x, int y) { return A + (x * 5 + y) * 2; }
-__device__ __forceinline__ int reg_c(int x, int z) { return C + x * 64 + z; }
-__device__ __forceinline__ int reg_cp(int x, int z) { return CP + x * 64 + z; }
-__device__ __forceinline__ int reg_ap(int x, int y, int z) { return AP + x * 320 + y * 64 + z; }
-__device__ __forceinline__ int reg_app(int x, int y) { return APP + x * 10 + y * 2; }
-__device__ __forceinline__ int reg_appp(int x, int y) { return (x == 0 && y == 0) ? (int)APPP00 : reg_app(x, y); }
-__device__ __forceinline__ int mod5(int v) { return v >= 5 ? v - 5 : v; }
-__device__ __forceinline__ gl_t xor_gen(gl_t x, gl_t y) { return gl_sub(gl_add(x, y), gl_mul(x, gl_add(y, y))); }
-}  // namespace kk
-
-template <int NA>
-__device__ void eval_keccak_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
-    using namespace kk;
-    const gl_t* __restrict__ nv = lv + dnext;
-#define LV(c) lv[(size_t)(c) * cs]
-#define NV(c) nv[(size_t)(c) * cs]
-    gl_t final_step = LV(23);
-    k.constraint(gl_mul(final_step, gl_sub(final_step, 1)));
-    gl_t not_final = gl_sub(1, final_step);
-    k.constraint(gl_mul(not_final, final_step));
-    // round flags: their sum, and the round-constant bit sum_r step_r * RC_r[z] for the 7 bit positions RC uses
-    gl_t sum_flags = 0, rc0 = 0, rc1 = 0, rc3 = 0, rc7 = 0, rc15 = 0, rc31 = 0, rc63 = 0;
-    {
-        constexpr uint64_t RC[24] = {
-            0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
-            0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
-            0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
-            0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-            0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-#pragma unroll
-        for (int r = 0; r < 24; r++) {
-            gl_t f = LV(r);
-            sum_flags = gl_add(sum_flags, f);
-            if (RC[r] & 1) rc0 = gl_add(rc0, f);
-            if (RC[r] >> 1 & 1) rc1 = gl_add(rc1, f);
-            if (RC[r] >> 3 & 1) rc3 = gl_add(rc3, f);
-            if (RC[r] >> 7 & 1) rc7 = gl_add(rc7, f);
-            if (RC[r] >> 15 & 1) rc15 = gl_add(rc15, f);
-            if (RC[r] >> 31 & 1) rc31 = gl_add(rc31, f);
-            if (RC[r] >> 63 & 1) rc63 = gl_add(rc63, f);
-        }
-    }
-    k.constraint(gl_mul(gl_mul(sum_flags, not_final), gl_sub(NV(TIMESTAMP), LV(TIMESTAMP))));
-    // C'[x, z] = xor(C[x, z], C[x - 1, z], C[x + 1, z - 1])
-#pragma unroll 1
-    for (int x = 0; x < 5; x++)
-#pragma unroll 2
-        for (int z = 0; z < 64; z++) {
-            gl_t v = xor_gen(LV(reg_c(x, z)), xor_gen(LV(reg_c(mod5(x + 4), z)), LV(reg_c(mod5(x + 1), (z + 63) & 63))));
-            k.constraint(gl_sub(LV(reg_cp(x, z)), v));
-        }
-    // A[x, y] limbs from xor(A'[x, y, z], C[x, z], C'[x, z])
-#pragma unroll 1
-    for (int x = 0; x < 5; x++)
-#pragma unroll 1
-        for (int y = 0; y < 5; y++)
-#pragma unroll 1
-            for (int half = 0; half < 2; half++) {
-                gl_t acc = 0;
-#pragma unroll 2
-                for (int z = 32 * half + 31; z >= 32 * half; z--)
-                    acc = gl_add(gl_add(acc, acc), xor_gen(LV(reg_ap(x, y, z)), xor_gen(LV(reg_c(x, z)), LV(reg_cp(x, z)))));
-                k.constraint(gl_sub(acc, LV(reg_a(x, y) + half)));
-            }
-    // diff = sum_y A'[x, y, z] - C'[x, z] in {0, 2, 4}
-#pragma unroll 1
-    for (int x = 0; x < 5; x++)
-#pragma unroll 2
-        for (int z = 0; z < 64; z++) {
-            gl_t sum = LV(reg_ap(x, 0, z));
-#pragma unroll
-            for (int i = 1; i < 5; i++) sum = gl_add(sum, LV(reg_ap(x, i, z)));
-            gl_t diff = gl_sub(sum, LV(reg_cp(x, z)));
-            k.constraint(gl_mul(gl_mul(diff, gl_sub(diff, 2)), gl_sub(diff, 4)));
-        }
-    // A''[x, y] = xor(B[x, y], andn(B[x + 1, y], B[x + 2, y])), B[x, y, z] = A'[(x + 3y) % 5, x, z - r] (columns.rs:91-105)
-#pragma unroll 1
-    for (int x = 0; x < 5; x++)
-#pragma unroll 1
-        for (int y = 0; y < 5; y++) {
-            int x1 = mod5(x + 1), x2 = mod5(x + 2);
-            int a0 = (x + 3 * y) % 5, a1 = (x1 + 3 * y) % 5, a2 = (x2 + 3 * y) % 5;
-            int base0 = reg_ap(a0, x, 0), base1 = reg_ap(a1, x1, 0), base2 = reg_ap(a2, x2, 0);
-            int r0 = 64 - ROT[a0][x], r1 = 64 - ROT[a1][x1], r2 = 64 - ROT[a2][x2];
-#pragma unroll 1
-            for (int half = 0; half < 2; half++) {
-                gl_t acc = 0;
-#pragma unroll 2
-                for (int z = 32 * half + 31; z >= 32 * half; z--) {
-                    gl_t b0 = LV(base0 + ((z + r0) & 63)), b1 = LV(base1 + ((z + r1) & 63)), b2 = LV(base2 + ((z + r2) & 63));
-                    acc = gl_add(gl_add(acc, acc), xor_gen(b0, gl_mul(gl_sub(1, b1), b2)));
-                }
-                k.constraint(gl_sub(acc, LV(reg_app(x, y) + half)));
-            }
-        }
-    // A''[0, 0] bit decomposition, then the iota output A'''[0, 0] = A''[0, 0] xor RC
-#pragma unroll 1
-    for (int half = 0; half < 2; half++) {
-        gl_t acc = 0;
-#pragma unroll 4
-        for (int z = 32 * half + 31; z >= 32 * half; z--) acc = gl_add(gl_add(acc, acc), LV(APP00_BITS + z));
-        k.constraint(gl_sub(acc, LV(reg_app(0, 0) + half)));
-    }
-#pragma unroll 1
-    for (int half = 0; half < 2; half++) {
-        gl_t acc = 0;
-#pragma unroll 1
-        for (int z = 32 * half + 31; z >= 32 * half; z--) {
-            gl_t rc = z == 0 ? rc0 : z == 1 ? rc1 : z == 3 ? rc3 : z == 7 ? rc7 : z == 15 ? rc15 : z == 31 ? rc31 : z == 63 ? rc63 : 0;
-            acc = gl_add(gl_add(acc, acc), xor_gen(LV(APP00_BITS + z), rc));
-        }
-        k.constraint(gl_sub(acc, LV(APPP00 + half)));
-    }
-    // this round's output is the next row's input unless this is the last round
-    gl_t not_last_t = gl_mul(not_final, k.z_last);
-#pragma unroll 1
-    for (int x = 0; x < 5; x++)
-#pragma unroll 1
-        for (int y = 0; y < 5; y++)
-#pragma unroll
-            for (int half = 0; half < 2; half++)
-                k.constraint(gl_mul(not_last_t, gl_sub(LV(reg_appp(x, y) + half), NV(reg_a(x, y) + half))));
-#undef LV
-#undef NV
-}
-
-// PoseidonSpongeStark (poseidon_sponge/poseidon_sponge_stark.rs:383-478; columns poseidon_sponge/columns.rs:17-66)
-template <int NA>
-__device__ void eval_poseidon_sponge_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
-    const gl_t* __restrict__ nv = lv + dnext;
-    enum { FULL = 0, CONTEXT = 1, SEGMENT = 2, TIMESTAMP = 11, LEN = 12, ABSORBED = 13, FINAL_LEN = 14, ORIG = 46, PARTIAL = 98, DIGEST = 106 };
-    gl_t full = lv[FULL];
-    k.constraint(gl_mul(full, gl_sub(full, 1)));
-    gl_t is_final = 0, next_final = 0;
-#pragma unroll 4
-    for (int i = 0; i < 32; i++) {
-        is_final = gl_add(is_final, lv[(size_t)(FINAL_LEN + i) * cs]);
-        next_final = gl_add(next_final, nv[(size_t)(FINAL_LEN + i) * cs]);
-    }
-    k.constraint(gl_mul(is_final, gl_sub(is_final, 1)));
-#pragma unroll 4
-    for (int i = 0; i < 32; i++) {
-        gl_t f = lv[(size_t)(FINAL_LEN + i) * cs];
-        k.constraint(gl_mul(f, gl_sub(f, 1)));
-    }
-    k.constraint(gl_mul(is_final, full));
-    gl_t absorbed = lv[(size_t)ABSORBED * cs];
-    k.first_row(absorbed);
-#pragma unroll 2
-    for (int i = 0; i < 12; i++) k.first_row(lv[(size_t)(ORIG + i) * cs]);  // original_rate then original_capacity
-    gl_t fin_t = gl_mul(is_final, k.z_last), full_t = gl_mul(full, k.z_last);
-    k.constraint(gl_mul(fin_t, nv[(size_t)ABSORBED * cs]));
-#pragma unroll 2
-    for (int i = 0; i < 12; i++) k.constraint(gl_mul(fin_t, nv[(size_t)(ORIG + i) * cs]));
-    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)CONTEXT * cs], nv[(size_t)CONTEXT * cs])));
-    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)SEGMENT * cs], nv[(size_t)SEGMENT * cs])));
-    k.constraint(gl_mul(full_t, gl_sub(lv[(size_t)TIMESTAMP * cs], nv[(size_t)TIMESTAMP * cs])));
-#pragma unroll 2
-    for (int i = 0; i < 4; i++) k.constraint(gl_mul(full_t, gl_sub(nv[(size_t)(ORIG + i) * cs], lv[(size_t)(DIGEST + i) * cs])));
-#pragma unroll 2
-    for (int i = 0; i < 8; i++)  // rate words 4..7 then the 4 capacity words are contiguous in both views
-        k.constraint(gl_mul(full_t, gl_sub(nv[(size_t)(ORIG + 4 + i) * cs], lv[(size_t)(PARTIAL + i) * cs])));
-    k.constraint(gl_mul(full_t, gl_sub(gl_add(absorbed, 32), nv[(size_t)ABSORBED * cs])));
-    gl_t is_dummy = gl_sub(gl_sub(1, full), is_final);
-    k.transition(gl_mul(is_dummy, gl_add(nv[FULL], next_final)));
-    gl_t offset = gl_sub(lv[(size_t)LEN * cs], absorbed);
-#pragma unroll 4
-    for (int i = 0; i < 32; i++) k.constraint(gl_mul(lv[(size_t)(FINAL_LEN + i) * cs], gl_sub(offset, (gl_t)i)));
-}
-
-// ShaExtendStark (sha_extend/sha_extend_stark.rs:238-317; rotate_right.rs:29-62, shift_right.rs:29-60, wrapping_add_4.rs:35-78)
-__device__ __forceinline__ gl_t sha_le4(const gl_t* __restrict__ b, size_t cs) {
-    return gl_add(gl_add(b[0], gl_mul(b[cs], 1u << 8)), gl_add(gl_mul(b[2 * cs], 1u << 16), gl_mul(b[3 * cs], 1u << 24)));
-}
-template <int NA>
-__device__ __forceinline__ void sha_rot_constraints(const gl_t* __restrict__ in, const gl_t* __restrict__ op, size_t cs, unsigned r,
-                                                    bool is_shift, consumer_t<NA>& k) {
-    gl_t out = sha_le4(op, cs), inv = sha_le4(in, cs), shift = op[4 * cs], carry = op[5 * cs];
-    if (is_shift) k.constraint(gl_sub(out, shift));
-    else k.constraint(gl_sub(gl_sub(out, gl_mul(carry, (gl_t)1 << (32 - r))), shift));
-    k.constraint(gl_sub(gl_sub(inv, gl_mul(shift, (gl_t)1 << r)), carry));
-}
-template <int NA>
-__device__ void eval_sha_extend_constraints(const gl_t* __restrict__ lv, size_t cs, consumer_t<NA>& k) {
-    sha_rot_constraints<NA>(lv + 8 * cs, lv + 40 * cs, cs, 7, false, k);
-    sha_rot_constraints<NA>(lv + 8 * cs, lv + 46 * cs, cs, 18, false, k);
-    sha_rot_constraints<NA>(lv + 12 * cs, lv + 52 * cs, cs, 17, false, k);
-    sha_rot_constraints<NA>(lv + 12 * cs, lv + 58 * cs, cs, 19, false, k);
-    sha_rot_constraints<NA>(lv + 8 * cs, lv + 70 * cs, cs, 3, true, k);
-    sha_rot_constraints<NA>(lv + 12 * cs, lv + 64 * cs, cs, 10, true, k);
-    gl_t real = lv[77 * cs];
-    const gl_t *a = lv + 36 * cs, *b = lv + 20 * cs, *c = lv + 28 * cs, *d = lv + 16 * cs, *cy = lv + 4 * cs;
-    gl_t c0 = cy[0], c1 = cy[cs], c2 = cy[2 * cs], c3 = cy[3 * cs];
-    k.constraint(gl_mul(gl_mul(c0, gl_sub(1, c0)), real));
-    k.constraint(gl_mul(gl_mul(c1, gl_sub(1, c1)), real));
-    k.constraint(gl_mul(gl_mul(c2, gl_sub(1, c2)), real));
-    k.constraint(gl_mul(gl_mul(c3, gl_sub(1, c3)), real));
-    k.constraint(gl_mul(gl_sub(gl_add(gl_add(c0, c1), gl_add(c2, c3)), 1), real));
-    gl_t carry = gl_add(gl_add(c1, gl_add(c2, c2)), gl_mul(c3, 3));
-    gl_t sum = 0;
-#pragma unroll
-    for (int i = 3; i >= 0; i--)
-        sum = gl_add(gl_mul(sum, 1u << 8), gl_add(gl_add(a[(size_t)i * cs], b[(size_t)i * cs]), gl_add(c[(size_t)i * cs], d[(size_t)i * cs])));
-    k.constraint(gl_mul(gl_sub(gl_sub(sum, gl_mul(carry, (gl_t)1 << 32)), sha_le4(lv, cs)), real));
-}
-
-// ShaExtendSpongeStark (sha_extend_sponge/sha_extend_sponge_stark.rs:220-330); NUM_CHANNELS = 10 (cpu/membus.rs:10-32)
-template <int NA>
-__device__ void eval_sha_extend_sponge_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
-    const gl_t* __restrict__ nv = lv + dnext;
-    gl_t sum = 0, lidx = 0, nidx = 0;
-#pragma unroll 4
-    for (int i = 0; i < 48; i++) {
-        gl_t f = lv[(size_t)i * cs];
-        k.constraint(gl_mul(f, gl_sub(f, 1)));
-        sum = gl_add(sum, f);
-        lidx = gl_add(lidx, gl_mul(f, (gl_t)i));
-        nidx = gl_add(nidx, gl_mul(nv[(size_t)i * cs], (gl_t)i));
-    }
-    gl_t is_final = lv[(size_t)47 * cs];
-    k.constraint(gl_mul(is_final, gl_sub(is_final, 1)));
-    gl_t g = gl_mul(sum, gl_sub(1, is_final));
-    k.constraint(gl_mul(g, gl_sub(gl_sub(nv[(size_t)75 * cs], lv[(size_t)75 * cs]), 20)));
-    k.constraint(gl_mul(g, gl_sub(gl_sub(nidx, lidx), 1)));
-#pragma unroll
-    for (int i = 0; i < 5; i++)  // the four input addresses, then the output address
-        k.constraint(gl_mul(g, gl_sub(gl_sub(nv[(size_t)(68 + i) * cs], lv[(size_t)(68 + i) * cs]), 4)));
-    gl_t a16 = lv[(size_t)70 * cs];
-    k.constraint(gl_mul(sum, gl_sub(gl_sub(lv[(size_t)68 * cs], a16), 4)));
-    k.constraint(gl_mul(sum, gl_sub(gl_sub(lv[(size_t)69 * cs], a16), 56)));
-    k.constraint(gl_mul(sum, gl_sub(gl_sub(lv[(size_t)71 * cs], a16), 36)));
-    k.constraint(gl_mul(sum, gl_sub(gl_sub(lv[(size_t)72 * cs], a16), 64)));
-}
-
-// ShaCompressStark (sha_compress/sha_compress_stark.rs:402-606) and ShaCompressSpongeStark (sha_compress_sponge_stark.rs:233-268)
-__device__ const uint32_t SHA256_K_DEV[64] = {
-    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
-    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
-    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
-    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
-    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
-    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-// wrapping add of NIN byte quadruples (column offsets in[]) into op = value[4], carry[NC]; every constraint times gate
-template <int NA, int NIN, int NC>
-__device__ __forceinline__ void sha_wadd_constraints(const gl_t* __restrict__ lv, size_t cs, const int (&in)[NIN], int op, gl_t gate,
-                                                     consumer_t<NA>& k) {
-    gl_t csum = 0, carry = 0;
-#pragma unroll
-    for (int i = 0; i < NC; i++) {
-        gl_t c = lv[(size_t)(op + 4 + i) * cs];
-        k.constraint(gl_mul(gate, gl_mul(c, gl_sub(1, c))));
-        csum = gl_add(csum, c);
-        if (i) carry = gl_add(carry, gl_mul(c, (gl_t)i));
-    }
-    k.constraint(gl_mul(gate, gl_sub(csum, 1)));
-    gl_t sum = 0;
-#pragma unroll
-    for (int b = 3; b >= 0; b--) {
-        gl_t s = lv[(size_t)(in[0] + b) * cs];
-#pragma unroll
-        for (int q = 1; q < NIN; q++) s = gl_add(s, lv[(size_t)(in[q] + b) * cs]);
-        sum = gl_add(gl_mul(sum, 1u << 8), s);
-    }
-    k.constraint(gl_mul(gate, gl_sub(gl_sub(sum, gl_mul(carry, (gl_t)1 << 32)), sha_le4(lv + (size_t)op * cs, cs))));
-}
-template <int NA>
-__device__ void eval_sha_compress_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
-    const gl_t* __restrict__ nv = lv + dnext;
-    enum { ROUND = 159, TIMESTAMP = 146, W_VIRT = 149 };
-    gl_t is_final = lv[(size_t)(ROUND + 64) * cs];
-    k.constraint(gl_mul(is_final, gl_sub(is_final, 1)));
-    gl_t sum = is_final, kb[4] = {0, 0, 0, 0};
-#pragma unroll 4
-    for (int j = 0; j < 64; j++) {
-        gl_t f = lv[(size_t)(ROUND + j) * cs];
-        sum = gl_add(sum, f);
-        uint32_t kc = SHA256_K_DEV[j];
-#pragma unroll
-        for (int i = 0; i < 4; i++) kb[i] = gl_add(kb[i], gl_mul(f, (kc >> (8 * i)) & 0xFF));
-    }
-    k.constraint(gl_mul(sum, gl_sub(sum, 1)));
-    gl_t g = gl_mul(sum, gl_sub(1, is_final));
-#pragma unroll
-    for (int i = 0; i < 4; i++) k.constraint(gl_mul(g, gl_sub(lv[(size_t)(40 + i) * cs], kb[i])));
-    sha_rot_constraints<NA>(lv + 16 * cs, lv + 92 * cs, cs, 6, false, k);
-    sha_rot_constraints<NA>(lv + 16 * cs, lv + 98 * cs, cs, 11, false, k);
-    sha_rot_constraints<NA>(lv + 16 * cs, lv + 104 * cs, cs, 25, false, k);
-    sha_rot_constraints<NA>(lv, lv + 110 * cs, cs, 2, false, k);
-    sha_rot_constraints<NA>(lv, lv + 116 * cs, cs, 13, false, k);
-    sha_rot_constraints<NA>(lv, lv + 122 * cs, cs, 22, false, k);
-#pragma unroll
-    for (int i = 0; i < 4; i++) k.constraint(gl_mul(sum, gl_sub(gl_add(lv[(size_t)(16 + i) * cs], lv[(size_t)(32 + i) * cs]), 255)));
-    { const int in[5] = {28, 48, 60, 40, 36}; sha_wadd_constraints<NA, 5, 5>(lv, cs, in, 150, sum, k); }  // temp1 = h + s_1 + ch + k_i + w_i
-    { const int in[2] = {68, 88}; sha_wadd_constraints<NA, 2, 2>(lv, cs, in, 128, sum, k); }              // temp2 = s_0 + maj
-    { const int in[2] = {12, 150}; sha_wadd_constraints<NA, 2, 2>(lv, cs, in, 134, sum, k); }             // d + temp1
-    { const int in[2] = {150, 128}; sha_wadd_constraints<NA, 2, 2>(lv, cs, in, 140, sum, k); }            // temp1 + temp2
-    k.constraint(gl_mul(g, gl_sub(nv[(size_t)TIMESTAMP * cs], lv[(size_t)TIMESTAMP * cs])));
-    k.constraint(gl_mul(g, gl_sub(gl_sub(nv[(size_t)W_VIRT * cs], lv[(size_t)W_VIRT * cs]), 4)));
-#pragma unroll
-    for (int i = 0; i < 4; i++) k.constraint(gl_mul(g, gl_sub(lv[(size_t)(140 + i) * cs], nv[(size_t)i * cs])));
-#pragma unroll 1
-    for (int w = 0; w < 3; w++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) k.constraint(gl_mul(g, gl_sub(lv[(size_t)(4 * w + i) * cs], nv[(size_t)(4 * (w + 1) + i) * cs])));
-#pragma unroll
-    for (int i = 0; i < 4; i++) k.constraint(gl_mul(g, gl_sub(lv[(size_t)(134 + i) * cs], nv[(size_t)(16 + i) * cs])));
-#pragma unroll 1
-    for (int w = 4; w < 7; w++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) k.constraint(gl_mul(g, gl_sub(lv[(size_t)(4 * w + i) * cs], nv[(size_t)(4 * (w + 1) + i) * cs])));
-}
-template <int NA>
-__device__ void eval_sha_compress_sponge_constraints(const gl_t* __restrict__ lv, size_t cs, consumer_t<NA>& k) {
-    gl_t real = lv[(size_t)126 * cs];
-    k.constraint(gl_mul(real, gl_sub(real, 1)));
-#pragma unroll
-    for (int i = 0; i < 7; i++) k.constraint(gl_mul(real, gl_sub(gl_sub(lv[(size_t)(113 + i) * cs], lv[(size_t)(112 + i) * cs]), 4)));
-#pragma unroll 1
-    for (int i = 0; i < 8; i++) {
-        const int in[2] = {4 * i, 32 + 4 * i};
-        sha_wadd_constraints<NA, 2, 2>(lv, cs, in, 64 + 6 * i, real, k);
-    }
-}
-
-// MemoryStark (memory/memory_stark.rs:253-341; columns memory/columns.rs, VALUE_LIMBS = 1)
-template <int NA>
-__device__ void eval_memory_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
-    const gl_t* __restrict__ nv = lv + dnext;
-    enum { FILTER = 0, TIMESTAMP = 1, IS_READ = 2, CONTEXT = 3, SEGMENT = 4, VIRTUAL = 5, VALUE = 6, CFC = 7, SFC = 8, VFC = 9, RANGE_CHECK = 10 };
-    gl_t filter = lv[FILTER];
-    k.constraint(gl_mul(filter, gl_sub(filter, 1)));
-    gl_t cfc = lv[CFC * cs], sfc = lv[SFC * cs], vfc = lv[VFC * cs];
-    gl_t unchanged = gl_sub(gl_sub(gl_sub(1, cfc), sfc), vfc);
-    k.constraint(gl_mul(cfc, gl_sub(1, cfc)));
-    k.constraint(gl_mul(sfc, gl_sub(1, sfc)));
-    k.constraint(gl_mul(vfc, gl_sub(1, vfc)));
-    k.constraint(gl_mul(unchanged, gl_sub(1, unchanged)));
-    gl_t dctx = gl_sub(nv[CONTEXT * cs], lv[CONTEXT * cs]), dseg = gl_sub(nv[SEGMENT * cs], lv[SEGMENT * cs]);
-    gl_t dvirt = gl_sub(nv[VIRTUAL * cs], lv[VIRTUAL * cs]);
-    k.transition(gl_mul(sfc, dctx));
-    k.transition(gl_mul(vfc, dctx));
-    k.transition(gl_mul(vfc, dseg));
-    k.transition(gl_mul(unchanged, dctx));
-    k.transition(gl_mul(unchanged, dseg));
-    k.transition(gl_mul(unchanged, dvirt));
-    gl_t computed = gl_add(gl_add(gl_mul(cfc, gl_sub(dctx, 1)), gl_mul(sfc, gl_sub(dseg, 1))),
-                           gl_add(gl_mul(vfc, gl_sub(dvirt, 1)), gl_mul(unchanged, gl_sub(nv[TIMESTAMP * cs], lv[TIMESTAMP * cs]))));
-    k.transition(gl_sub(lv[RANGE_CHECK * cs], computed));
-    k.transition(gl_mul(gl_mul(nv[IS_READ * cs], unchanged), gl_sub(nv[VALUE * cs], lv[VALUE * cs])));
-}
-
-// A table's own logUp lookups (eval_packed_lookups_generic lookup.rs:138-198; helper-column checks eval_helper_columns
-// cross_table_lookup.rs:1006-1058 with beta = 1, gamma = challenge, no filters).  Passed by value: a few words.
-struct lookup_dev {
-    uint32_t nlookups, nch;
-    gl_t challenges[4];
-    struct { uint32_t ncols, col_off, table_col, freq_col; } lk[2];
-    uint32_t cols[24];
-};
-template <int NA>
-__device__ void eval_lookup_constraints(const lookup_dev& d, const gl_t* __restrict__ lv, size_t N, const gl_t* __restrict__ aux,
-                                        size_t j, size_t jn, consumer_t<NA>& k) {
-    uint32_t start = 0;
-    for (uint32_t l = 0; l < d.nlookups; l++) {
-        const uint32_t ncols = d.lk[l].ncols, nh = (ncols + 1) / 2;
-        const uint32_t* cols = d.cols + d.lk[l].col_off;
-        for (uint32_t c = 0; c < d.nch; c++) {
-            const gl_t ch = d.challenges[c];
-            gl_t hsum = 0;
-            for (uint32_t q = 0; q < nh; q++) {
-                gl_t h = aux[(size_t)(start + q) * N + j];
-                gl_t combin0 = gl_add(lv[(size_t)cols[2 * q] * N], ch);
-                if (2 * q + 1 < ncols) {
-                    gl_t combin1 = gl_add(lv[(size_t)cols[2 * q + 1] * N], ch);
-                    k.constraint(gl_sub(gl_sub(gl_mul(gl_mul(combin1, combin0), h), combin1), combin0));
-                } else {
-                    k.constraint(gl_sub(gl_mul(combin0, h), 1));
-                }
-                hsum = gl_add(hsum, h);
-            }
-            gl_t z = aux[(size_t)(start + nh) * N + j], next_z = aux[(size_t)(start + nh) * N + jn];
-            gl_t table_ch = gl_add(lv[(size_t)d.lk[l].table_col * N], ch);
-            gl_t y = gl_sub(gl_mul(hsum, table_ch), lv[(size_t)d.lk[l].freq_col * N]);
-            k.first_row(z);
-            k.constraint(gl_sub(gl_mul(gl_sub(next_z, z), table_ch), y));
-            start += nh + 1;
-        }
-    }
-}
-
-template <int TABLE, int NA>
-__device__ __forceinline__ void eval_table_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
-    if constexpr (TABLE == ZKM_TABLE_POSEIDON) eval_poseidon_constraints<NA>(lv, cs, k);
-    else if constexpr (TABLE == ZKM_TABLE_LOGIC) eval_logic_constraints<NA>(lv, cs, k);
-    else if constexpr (TABLE == ZKM_TABLE_KECCAK_SPONGE) eval_keccak_sponge_constraints<NA>(lv, cs, dnext, k);
-    else if constexpr (TABLE == ZKM_TABLE_KECCAK) eval_keccak_constraints<NA>(lv, cs, dnext, k);
-    else if constexpr (TABLE == ZKM_TABLE_MEMORY) eval_memory_constraints<NA>(lv, cs, dnext, k);
-    else if constexpr (TABLE == ZKM_TABLE_POSEIDON_SPONGE) eval_poseidon_sponge_constraints<NA>(lv, cs, dnext, k);
-    else if constexpr (TABLE == ZKM_TABLE_SHA_EXTEND) eval_sha_extend_constraints<NA>(lv, cs, k);
-    else if constexpr (TABLE == ZKM_TABLE_SHA_EXTEND_SPONGE) eval_sha_extend_sponge_constraints<NA>(lv, cs, dnext, k);
-    else if constexpr (TABLE == ZKM_TABLE_SHA_COMPRESS) eval_sha_compress_constraints<NA>(lv, cs, dnext, k);
-    else eval_sha_compress_sponge_constraints<NA>(lv, cs, k);
-}
-
+// ------------------------------------------------------------------ K7: quotient evaluation
+// Table constraints live in constraints_dev.h; constraint order = alpha-power order (constraint_consumer.rs:57-62): table
+// constraints, then the table's lookups, then the CTL checks (vanishing_poly.rs:17-46).
 // CTL checks driven by the column-set description (eval_helper_columns cross_table_lookup.rs:1006-1058,
 // eval_cross_table_lookup_checks :1067-1150).  The benchmark's fake CTL data (helper columns, no column sets)
 // is the ncolsets == 0 case: only the last-row / transition checks on Z are emitted.
