@@ -50,6 +50,19 @@ GL_HD uint64_t gl_add_loose(uint64_t a, uint64_t b) {
     return s;
 }
 
+// loose + canonical -> loose (one correction: a + b < 2^64 + p, so after a wrap s <= p - 2 and s + EPS < 2^64)
+GL_HD uint64_t gl_add_lc(uint64_t a, gl_t b) {
+    uint64_t s = a + b;
+    s += (s < a) ? GL_EPS : 0;
+    return s;
+}
+// loose - canonical -> loose (one correction: after a borrow d = a - b + 2^64 >= 2^64 - (p - 1) = 2^32 > EPS)
+GL_HD uint64_t gl_sub_lc(uint64_t a, gl_t b) {
+    uint64_t d = a - b;
+    d -= (a < b) ? GL_EPS : 0;
+    return d;
+}
+
 // 128-bit (hi:lo) -> loose.  Standard Goldilocks reduction: 2^64 == 2^32 - 1, 2^96 == -1, written for gfx950 issue costs
 // (tools/ubench3.hip: compare + select chains are the expensive part of a modmul, moves and plain 32-bit ops are cheap):
 //   t0 = lo - h1           borrow <=> lo < h1 < 2^32 <=> the high word went from 0 to 0xFFFFFFFF; the borrow mask

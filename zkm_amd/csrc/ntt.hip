@@ -85,6 +85,8 @@ struct ntt_pass_args {
     size_t bi_hi, bi_lo, bo_hi, bo_lo;
     size_t sa_in, sb_in, sa_out, sb_out;
     uint32_t in_contig_a, out_contig_a, rev_rows, m;
+    uint32_t zero_padded;  // first pass of a x4 zero-padded transform: rows >= 2^S / 4 of every tile are zero
+    uint32_t canon_out;  // last pass of a transform: outputs must be canonical (intermediate passes may store loose words)
     const gl_t* tw;
     const gl_t* pre_tab;
     uint32_t pre_log;
@@ -115,8 +117,11 @@ struct ntt_round {
         }
     }
     __device__ static __forceinline__ void bfly(gl_t& u, gl_t& v, gl_t w) {
-        gl_t t = gl_add(u, v);
-        v = gl_mul(gl_sub(u, v), w);
+        // loose arithmetic inside a pass: only v is canonicalised (one compare), the sum / difference take one correction
+        // each and the product is not canonicalised at all; the last pass canonicalises on the way out (canon_out)
+        const gl_t vc = gl_canon(v);
+        const uint64_t t = gl_add_lc(u, vc);
+        v = gl_mul_loose(gl_sub_lc(u, vc), w);
         u = t;
     }
     // up to three DIF stages on the 8 register-resident rows; sched_barrier keeps the compiler from
@@ -139,6 +144,20 @@ struct ntt_round {
         bfly(x[4], x[5], w[6]); bfly(x[6], x[7], w[6]);
         __builtin_amdgcn_sched_barrier(0);
     }
+    // First round of a x4 zero-padded transform (coset LDE): only x[0], x[1] are non-zero, so the first two stages are
+    // plain twiddle multiplications -- bfly(u, 0) = (u, u w) -- 6 products instead of 8 butterflies.
+    __device__ static __forceinline__ void compute_zero_padded(gl_t (&x)[8], const gl_t (&w)[7]) {
+        x[4] = gl_mul_loose(x[0], w[0]); x[5] = gl_mul_loose(x[1], w[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        x[2] = gl_mul_loose(x[0], w[4]); x[3] = gl_mul_loose(x[1], w[5]);
+        __builtin_amdgcn_sched_barrier(0);
+        x[6] = gl_mul_loose(x[4], w[4]); x[7] = gl_mul_loose(x[5], w[5]);
+        __builtin_amdgcn_sched_barrier(0);
+        bfly(x[0], x[1], w[6]); bfly(x[2], x[3], w[6]);
+        __builtin_amdgcn_sched_barrier(0);
+        bfly(x[4], x[5], w[6]); bfly(x[6], x[7], w[6]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __device__ static __forceinline__ void lds_read(const gl_t* lds, int tp, int b, int rg, gl_t (&x)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = lds[row(rg, j) * tp + b];
@@ -156,7 +175,7 @@ struct ntt_round {
 // PRE / POST: 0 = never, 1 = always, 2 = decided at run time (keeps the scale paths out of the register
 // allocation of the hot variants)
 template <int S, bool IN_A, bool OUT_A, int PRE, int POST>
-__global__ __launch_bounds__(1024) void k_ntt_pass(ntt_pass_args p) {
+__global__ __launch_bounds__(512) void k_ntt_pass(ntt_pass_args p) {
     extern __shared__ __attribute__((aligned(16))) gl_t lds[];
     constexpr int R = 1 << S, NR = (S + 2) / 3;
     using R0 = ntt_round<S, 0>;
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass(ntt_pass_args p) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const uint32_t off = in0 + (uint32_t)j * in_step;
-                    if (off < p.n_in) x[j] = gl_mul(x[j], pow_lookup(p.pre_tab, p.pre_log, off));  // (the table only covers the unpadded input)
+                    if (off < p.n_in) x[j] = gl_mul_loose(x[j], pow_lookup(p.pre_tab, p.pre_log, off));  // (the table only covers the unpadded input)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -216,13 +235,14 @@ __global__ __launch_bounds__(1024) void k_ntt_pass(ntt_pass_args p) {
                 int a = idx & (R - 1), bb = idx >> S;
                 size_t off = base_in + (size_t)a * p.sa_in + (size_t)bb * p.sb_in;
                 gl_t v = off < p.n_in ? src[off] : 0;
-                if (do_pre && off < p.n_in) v = gl_mul(v, pow_lookup(p.pre_tab, p.pre_log, off));
+                if (do_pre && off < p.n_in) v = gl_mul_loose(v, pow_lookup(p.pre_tab, p.pre_log, off));
                 lds[a * tp + bb] = v;
             }
             __syncthreads();
             R0::lds_read(lds, tp, b, rg, x);
         }
-        R0::compute(x, w0);
+        if (!IN_A && S >= 3 && p.zero_padded) R0::compute_zero_padded(x, w0);
+        else R0::compute(x, w0);
         if (NR > 1) {
             R0::lds_write(lds, tp, b, rg, x);
             __syncthreads();
@@ -245,6 +265,10 @@ __global__ __launch_bounds__(1024) void k_ntt_pass(ntt_pass_args p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (p.canon_out) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) x[j] = gl_canon(x[j]);
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int jj = p.rev_rows ? (int)(((j & 1) << 2) | (j & 2) | ((j >> 2) & 1)) : j;
@@ -264,6 +288,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass(ntt_pass_args p) {
                     if (p.post_scale != 1) v = gl_mul(v, p.post_scale);
                     if (p.post_tab) v = gl_mul(v, pow_lookup(p.post_tab, p.post_log, off));
                 }
+                if (p.canon_out) v = gl_canon(v);
                 dst[off] = v;
             }
         }
@@ -337,7 +362,7 @@ static size_t ntt_max_tile_elems() {
     if (!v) {
         const char* e = getenv("ZKM_NTT_TILE");  // tuning knob: elements per workgroup tile (threads = tile / 8)
         v = e ? (size_t)atol(e) : 2048;
-        if (v < 512 || v > 8192) v = 8192;
+        if (v < 512 || v > 4096) v = 4096;  // threads = tile / 8 <= 512 (the kernel's launch bound)
     }
     return v;
 }
@@ -367,6 +392,7 @@ static void ntt_dif_bitrev_fast(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* 
         if (p == 0) {
             a.n_in = n_in;
             if (shift > 1) { a.pre_tab = c->pow_table(shift, log_n_in); a.pre_log = log_n_in; }
+            a.zero_padded = m > 0 && S >= 3 && n_in * 4 == ((size_t)1 << L);
         }
         size_t ntiles;
         if (m > 0) {  // strided pass: rows at stride 2^m, tile columns contiguous
@@ -387,6 +413,7 @@ static void ntt_dif_bitrev_fast(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* 
             a.in_contig_a = a.out_contig_a = 1;
             ntiles = a.n_lo;
         }
+        a.canon_out = m == 0;
         launch_pass(c, S, a, ntiles, m > 0 ? "ntt_pass_strided" : "ntt_pass_contig");
     }
 }
@@ -441,6 +468,7 @@ static void ntt_natural_fast(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* scr
             a.sa_out = N1 * Nmid; a.sb_out = 1; a.out_contig_a = 0;
             ntiles = Nmid * a.n_lo;
         }
+        a.canon_out = last;
         launch_pass(c, S, a, ntiles, last ? "ntt_pass_transpose" : "ntt_pass_strided");
     }
 }
