@@ -217,42 +217,72 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
 }
 
 // ------------------------------------------------------------------ K10: openings
-// partial[col][chunk] = sum_{k in chunk} c_k z^(k - chunk_start) for z in {zeta, g*zeta}, plus the plain
-// sum (evaluation at 1).  Horner in z^256 per thread over a 256-strided slice, so loads are coalesced.
+// partial[col][chunk] = sum_{k in chunk} c_k z^(k - chunk_start) for z in {zeta, g*zeta}, plus the plain sum (evaluation
+// at 1).  The coefficients are base-field elements, so with a table of the powers z^k = (a_k, b_k) of the chunk (shared by
+// every column and chunk; 4 x 2^14 words, L2-resident) each coefficient costs four BASE multiplications -- sum c_k a_k,
+// sum c_k b_k for the two points -- instead of two extension-field Horner steps, and the sums are accumulated lazily
+// (64-bit wrapping adds with a wrap counter, 2^64 == EPS applied once at the end).  A workgroup handles OPEN_CPB columns
+// of one chunk so a power is loaded once per OPEN_CPB coefficients; all loads are coalesced.
 #define OPEN_CHUNK_LOG 14
-__global__ __launch_bounds__(256) void k_open_partials(const gl_t* __restrict__ coeffs, unsigned log_n, gl2_t z0, gl2_t z1,
-                                                       gl_t* __restrict__ partial /* [col][chunk][5] */) {
+#define OPEN_CPB 4
+__global__ __launch_bounds__(256) void k_open_powers(gl2_t z0, gl2_t z1, unsigned chunk_len, gl_t* __restrict__ pw /* [4][chunk_len] */) {
+    unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= chunk_len) return;
+    gl2_t p0 = gl2_pow(z0, k), p1 = gl2_pow(z1, k);
+    pw[k] = p0.c0; pw[chunk_len + k] = p0.c1; pw[2 * chunk_len + k] = p1.c0; pw[3 * chunk_len + k] = p1.c1;
+}
+struct lazy_sum {
+    uint64_t lo;
+    uint32_t wraps;
+    __device__ __forceinline__ void add(uint64_t v) {
+        lo += v;
+        wraps += lo < v;
+    }
+    __device__ __forceinline__ gl_t value() const {  // lo + wraps 2^64 == lo + wraps EPS (wraps < 2^32: one multiply-add)
+        uint64_t r = (uint64_t)wraps * 0xFFFFFFFFu + lo;
+        r += (r < lo) ? GL_EPS : 0;
+        return gl_canon(r);
+    }
+};
+__global__ __launch_bounds__(256) void k_open_partials(const gl_t* __restrict__ coeffs, unsigned log_n, size_t ncols,
+                                                       const gl_t* __restrict__ pw, gl_t* __restrict__ partial /* [col][chunk][5] */) {
     __shared__ gl_t red[256 * 5];
-    unsigned chunk_log = log_n < OPEN_CHUNK_LOG ? log_n : OPEN_CHUNK_LOG;
-    size_t chunk_len = (size_t)1 << chunk_log, nchunks = (size_t)1 << (log_n - chunk_log);
-    size_t col = blockIdx.y, chunk = blockIdx.x;
-    const gl_t* p = coeffs + (col << log_n) + chunk * chunk_len;
-    unsigned t = threadIdx.x;
-    gl2_t w0 = gl2_pow(z0, 256), w1 = gl2_pow(z1, 256);
-    gl2_t a0{0, 0}, a1{0, 0};
-    gl_t sum = 0;
-    // elements t, t+256, ... : Horner from the top
-    for (size_t m = chunk_len >> 8; m-- > 0;) {
-        size_t idx = (m << 8) + t;
-        gl_t cv = idx < chunk_len ? p[idx] : 0;
-        a0 = gl2_mul(a0, w0); a0.c0 = gl_add(a0.c0, cv);
-        a1 = gl2_mul(a1, w1); a1.c0 = gl_add(a1.c0, cv);
-        sum = gl_add(sum, cv);
+    const unsigned chunk_log = log_n < OPEN_CHUNK_LOG ? log_n : OPEN_CHUNK_LOG;
+    const size_t chunk_len = (size_t)1 << chunk_log, nchunks = (size_t)1 << (log_n - chunk_log);
+    const size_t col0 = (size_t)blockIdx.y * OPEN_CPB, chunk = blockIdx.x;
+    const unsigned t = threadIdx.x;
+    lazy_sum acc[OPEN_CPB][5];
+#pragma unroll
+    for (int c = 0; c < OPEN_CPB; c++)
+#pragma unroll
+        for (int q = 0; q < 5; q++) acc[c][q] = lazy_sum{0, 0};
+    for (size_t idx = t; idx < chunk_len; idx += 256) {
+        gl_t p[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) p[q] = pw[(size_t)q * chunk_len + idx];
+#pragma unroll
+        for (int c = 0; c < OPEN_CPB; c++) {
+            // (columns past the end of the batch read column ncols - 1 again; their sums are never stored)
+            const size_t col = col0 + c < ncols ? col0 + c : ncols - 1;
+            const gl_t cv = coeffs[(col << log_n) + chunk * chunk_len + idx];
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[c][q].add(gl_mul_loose(cv, p[q]));
+            acc[c][4].add(cv);
+        }
     }
-    if (chunk_len < 256) {  // tiny polynomials: one element per thread at most
-        gl_t cv = t < chunk_len ? p[t] : 0;
-        a0 = gl2_t{cv, 0}; a1 = gl2_t{cv, 0}; sum = cv;
-    }
-    a0 = gl2_mul(a0, gl2_pow(z0, t));
-    a1 = gl2_mul(a1, gl2_pow(z1, t));
-    red[t * 5 + 0] = a0.c0; red[t * 5 + 1] = a0.c1; red[t * 5 + 2] = a1.c0; red[t * 5 + 3] = a1.c1; red[t * 5 + 4] = sum;
-    __syncthreads();
-    for (unsigned s = 128; s > 0; s >>= 1) {
-        if (t < s)
-            for (int q = 0; q < 5; q++) red[t * 5 + q] = gl_add(red[t * 5 + q], red[(t + s) * 5 + q]);
+#pragma unroll
+    for (int c = 0; c < OPEN_CPB; c++) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) red[t * 5 + q] = acc[c][q].value();
+        __syncthreads();
+        for (unsigned s = 128; s > 0; s >>= 1) {
+            if (t < s)
+                for (int q = 0; q < 5; q++) red[t * 5 + q] = gl_add(red[t * 5 + q], red[(t + s) * 5 + q]);
+            __syncthreads();
+        }
+        if (t < 5 && col0 + c < ncols) partial[((col0 + c) * nchunks + chunk) * 5 + t] = red[t];
         __syncthreads();
     }
-    if (t < 5) partial[(col * nchunks + chunk) * 5 + t] = red[t];
 }
 
 struct open_vals { gl2_t at_z0, at_z1; gl_t at_one; };
@@ -263,15 +293,20 @@ static std::vector<open_vals> eval_batch(zkm_ctx* c, const zkm_batch* b, gl2_t z
     unsigned chunk_log = log_n < OPEN_CHUNK_LOG ? log_n : OPEN_CHUNK_LOG;
     size_t nchunks = (size_t)1 << (log_n - chunk_log), words = b->ncols * nchunks * 5;
     gl_t* d_part = (gl_t*)c->alloc(words * sizeof(gl_t));
+    const unsigned chunk_len = 1u << chunk_log;
+    gl_t* d_pw = (gl_t*)c->alloc((size_t)4 * chunk_len * sizeof(gl_t));
     {
         zkm_prof_scope ps(c, "open_partials");
-        hipLaunchKernelGGL(k_open_partials, dim3(nchunks, b->ncols), dim3(256), 0, c->stream, b->coeffs, log_n, z0, z1, d_part);
+        hipLaunchKernelGGL(k_open_powers, dim3((chunk_len + 255) / 256), dim3(256), 0, c->stream, z0, z1, chunk_len, d_pw);
+        hipLaunchKernelGGL(k_open_partials, dim3(nchunks, (b->ncols + OPEN_CPB - 1) / OPEN_CPB), dim3(256), 0, c->stream, b->coeffs, log_n,
+                           b->ncols, d_pw, d_part);
         ZKM_HIP_CHECK(hipGetLastError());
     }
     std::vector<gl_t> part(words);
     ZKM_HIP_CHECK(hipMemcpyAsync(part.data(), d_part, words * sizeof(gl_t), hipMemcpyDeviceToHost, c->stream));
     c->sync();
     c->release(d_part);
+    c->release(d_pw);
     gl2_t s0 = gl2_pow(z0, (uint64_t)1 << chunk_log), s1 = gl2_pow(z1, (uint64_t)1 << chunk_log);
     std::vector<open_vals> out(b->ncols);
     for (size_t col = 0; col < b->ncols; col++) {
