@@ -187,7 +187,9 @@ void zkm_standard_config(zkm_stark_config* cfg);
  *   SHA_EXTEND     sha_extend/sha_extend_stark.rs:238-317              78 columns
  *   SHA_EXTEND_SPONGE sha_extend_sponge/sha_extend_sponge_stark.rs:220-330  76 columns
  *   SHA_COMPRESS   sha_compress/sha_compress_stark.rs:402-606         224 columns
- *   SHA_COMPRESS_SPONGE sha_compress_sponge/sha_compress_sponge_stark.rs:233-268  127 columns */
+ *   SHA_COMPRESS_SPONGE sha_compress_sponge/sha_compress_sponge_stark.rs:233-268  127 columns
+ *   ARITHMETIC     arithmetic/arithmetic_stark.rs:214-240 and its nine operation modules, 54 columns, plus the 18-column range-check lookup
+ *                  :269-276 (at least 2^16 rows); rows come from the CPU-side witness generator (no witness kernel) */
 #define ZKM_TABLE_POSEIDON 0
 #define ZKM_TABLE_LOGIC 1
 #define ZKM_TABLE_KECCAK_SPONGE 2
@@ -198,6 +200,8 @@ void zkm_standard_config(zkm_stark_config* cfg);
 #define ZKM_TABLE_SHA_EXTEND_SPONGE 7
 #define ZKM_TABLE_SHA_COMPRESS 8
 #define ZKM_TABLE_SHA_COMPRESS_SPONGE 9
+#define ZKM_TABLE_ARITHMETIC 10
+#define ZKM_ARITHMETIC_COLS 54
 #define ZKM_MEMORY_COLS 13
 size_t zkm_table_width(int table_id); /* 0 for an unknown id */
 /* Auxiliary columns the table's own logUp lookups (Stark::lookups(), lookup.rs:22-40) put in front of the CTL columns:

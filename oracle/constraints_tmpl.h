@@ -381,6 +381,201 @@ static void TNAME(eval_sha_compress_sponge)(const T* lv, TNAME(consumer) * k) {
     }
 }
 
+/* ---- ArithmeticStark constraints: arithmetic/arithmetic_stark.rs:214-240 -> mul.rs:109-190, mult.rs:115-262, addcy.rs:41-160,
+ * slt.rs:50-120, lui.rs:31-49, div.rs:264-560, shift.rs:52-96, sra.rs:66-133, lo_hi.rs:23-36.  N_LIMBS = 2 (16-bit limbs of 32-bit
+ * registers).  Columns (arithmetic/columns.rs): 26 operation flags 0..25; shared columns 26..43 (INPUT_REGISTER_0 26, _1 28, _2 30,
+ * OUTPUT_REGISTER 32 (= OUTPUT_REGISTER_LO), AUX_INPUT_REGISTER_0 34 (= OUTPUT_REGISTER_HI), _1 36, _2 38, QUOT_ABS 40, REM_ABS 42;
+ * MULT_AUX_LO 36..39, MULT_AUX_HI 40..43); RANGE_COUNTER 44, RC_FREQUENCIES 45, AUX_EXTRA 46..53.  Second-row (nv) registers of the
+ * two-row operations: MODULAR_OUT_AUX_RED 26, MODULAR_MOD_IS_ZERO 28, MODULAR_AUX_INPUT_LO 29..31, _HI 32..34,
+ * MODULAR_DIV_DENOM_IS_ZERO 35. ---- */
+#ifndef ZKO_ARITH_COLS
+#define ZKO_ARITH_COLS
+enum { AR_ADD = 0, AR_ADDU, AR_ADDI, AR_ADDIU, AR_SUB, AR_SUBU, AR_MULT, AR_MULTU, AR_MUL, AR_DIV, AR_DIVU, AR_SLLV, AR_SRLV, AR_SRAV, AR_SLL, AR_SRL,
+       AR_SRA, AR_SLT, AR_SLTU, AR_SLTI, AR_SLTIU, AR_LUI, AR_MFHI, AR_MTHI, AR_MFLO, AR_MTLO,
+       AR_IN0 = 26, AR_IN1 = 28, AR_IN2 = 30, AR_OUT = 32, AR_AUX0 = 34, AR_AUX1 = 36, AR_AUX2 = 38, AR_QUOT_ABS = 40, AR_REM_ABS = 42,
+       AR_MULT_AUX_LO = 36, AR_MULT_AUX_HI = 40, AR_RANGE_COUNTER = 44, AR_RC_FREQ = 45, AR_AUX_EXTRA = 46,
+       AR_NV_RED = 26, AR_NV_MOD_IS_ZERO = 28, AR_NV_AUX_LO = 29, AR_NV_AUX_HI = 32, AR_NV_DENOM_IS_ZERO = 35 };
+#define ZKO_INV_65536 18446462594437939201ULL /* addcy.rs:41 GOLDILOCKS_INVERSE_65536 */
+#endif
+/* eval_packed_generic_addcy addcy.rs:43-93: x + y == z + cy 2^32 limb by limb */
+static void TNAME(ar_addcy)(TNAME(consumer) * k, T filter, const T* x, const T* y, const T* z, const T* given_cy, int two_row) {
+    T cy = T_FROMB(0), ovf = T_FROMB(65536);
+    for (int i = 0; i < 2; i++) {
+        T t = T_SUB(T_ADD(T_ADD(cy, x[i]), y[i]), z[i]);
+        T c = T_MUL(T_MUL(filter, t), T_SUB(ovf, t));
+        if (two_row) TNAME(cons_transition)(k, c); else TNAME(cons)(k, c);
+        cy = T_MULB(t, ZKO_INV_65536);
+    }
+    if (two_row) {
+        TNAME(cons_transition)(k, T_MUL(filter, T_SUB(cy, given_cy[0])));
+        TNAME(cons_transition)(k, T_MUL(filter, given_cy[1]));
+    } else {
+        TNAME(cons)(k, T_MUL(T_MUL(filter, given_cy[0]), T_SUB(given_cy[0], T_FROMB(1))));
+        TNAME(cons)(k, T_MUL(filter, T_SUB(cy, given_cy[0])));
+        TNAME(cons)(k, T_MUL(filter, given_cy[1]));
+    }
+}
+/* eval_packed_generic_mul mul.rs:109-135: left * right == out + (x - 2^16) aux(x) at x = 2^16, low two limbs */
+static void TNAME(ar_mul)(const T* lv, T filter, const T* l, const T* r, TNAME(consumer) * k) {
+    T aux[2], cp[2];
+    for (int i = 0; i < 2; i++) aux[i] = T_SUB(T_ADD(lv[AR_AUX0 + i], T_MULB(lv[AR_AUX1 + i], 65536)), T_FROMB(1 << 20));
+    cp[0] = T_SUB(T_MUL(l[0], r[0]), lv[AR_OUT]);
+    cp[1] = T_SUB(T_ADD(T_MUL(l[0], r[1]), T_MUL(l[1], r[0])), lv[AR_OUT + 1]);
+    cp[0] = T_ADD(cp[0], T_MULB(aux[0], 65536));                       /* minus pol_adjoin_root: res[0] = -base aux[0] */
+    cp[1] = T_SUB(cp[1], T_SUB(aux[0], T_MULB(aux[1], 65536)));        /* res[1] = aux[0] - base aux[1] */
+    for (int i = 0; i < 2; i++) TNAME(cons)(k, T_MUL(filter, cp[i]));
+}
+/* eval_packed_generic_mult_helper mult.rs:236-262 on 4-limb operands */
+static void TNAME(ar_mult_helper)(const T* lv, T filter, const T* l, const T* r, TNAME(consumer) * k) {
+    T aux[4], cp[4];
+    for (int i = 0; i < 4; i++) aux[i] = T_SUB(T_ADD(lv[AR_MULT_AUX_LO + i], T_MULB(lv[AR_MULT_AUX_HI + i], 65536)), T_FROMB(1 << 20));
+    for (int d = 0; d < 4; d++) {
+        T s = T_FROMB(0);
+        for (int i = 0; i <= d; i++) s = T_ADD(s, T_MUL(l[i], r[d - i]));
+        cp[d] = T_SUB(s, lv[AR_OUT + d]);
+    }
+    cp[0] = T_ADD(cp[0], T_MULB(aux[0], 65536));
+    for (int d = 1; d < 4; d++) cp[d] = T_SUB(cp[d], T_SUB(aux[d - 1], T_MULB(aux[d], 65536)));
+    for (int d = 0; d < 4; d++) TNAME(cons)(k, T_MUL(filter, cp[d]));
+}
+/* eval_packed_div_helper div.rs:509-541 with modular_constr_poly :325-380 and check_reduced :300-323 */
+static void TNAME(ar_div_helper)(const T* lv, const T* nv, TNAME(consumer) * k, T filter, int num, int den, int quo, int rem) {
+    T one = T_FROMB(1);
+    TNAME(cons_last)(k, filter);
+    T miz = nv[AR_NV_MOD_IS_ZERO];
+    TNAME(cons_transition)(k, T_MUL(filter, T_SUB(T_MUL(miz, miz), miz)));
+    T modulus[2] = {lv[den], lv[den + 1]}, output[2] = {lv[rem], lv[rem + 1]};
+    TNAME(cons_transition)(k, T_MUL(T_MUL(filter, T_ADD(modulus[0], modulus[1])), miz));
+    modulus[0] = T_ADD(modulus[0], miz);
+    T ddz = nv[AR_NV_DENOM_IS_ZERO];
+    T shr_div = T_ADD(T_ADD(T_ADD(lv[AR_DIV], lv[AR_DIVU]), T_ADD(lv[AR_SRL], lv[AR_SRLV])), T_ADD(lv[AR_SRA], lv[AR_SRAV]));
+    TNAME(cons_transition)(k, T_MUL(filter, T_SUB(T_MUL(miz, shr_div), ddz)));
+    output[0] = T_ADD(output[0], ddz);
+    {
+        T less[2] = {T_SUB(one, T_MUL(miz, shr_div)), T_FROMB(0)};
+        TNAME(ar_addcy)(k, filter, modulus, nv + AR_NV_RED, output, less, 1);
+    }
+    output[0] = T_SUB(output[0], ddz);
+    T q[4] = {lv[quo], lv[quo + 1], T_FROMB(0), T_FROMB(0)}, prod[5];
+    for (int d = 0; d < 5; d++) prod[d] = T_FROMB(0);
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 2; j++) prod[i + j] = T_ADD(prod[i + j], T_MUL(q[i], modulus[j]));
+    TNAME(cons_transition)(k, T_MUL(filter, prod[4]));
+    T cp[4] = {T_ADD(prod[0], output[0]), T_ADD(prod[1], output[1]), prod[2], prod[3]}, aux[4];
+    for (int i = 0; i < 3; i++) aux[i] = T_ADD(T_SUB(nv[AR_NV_AUX_LO + i], T_FROMB(1 << 20)), T_MULB(nv[AR_NV_AUX_HI + i], 65536));
+    aux[3] = T_FROMB(0);
+    cp[0] = T_SUB(cp[0], T_MULB(aux[0], 65536));                       /* plus pol_adjoin_root(aux, base) */
+    for (int d = 1; d < 4; d++) cp[d] = T_ADD(cp[d], T_SUB(aux[d - 1], T_MULB(aux[d], 65536)));
+    cp[0] = T_SUB(cp[0], lv[num]);
+    cp[1] = T_SUB(cp[1], lv[num + 1]);
+    for (int d = 0; d < 4; d++) TNAME(cons_transition)(k, T_MUL(filter, cp[d]));
+}
+/* check_abs of eval_packed_div div.rs:400-430; returns is_neg */
+static T TNAME(ar_check_abs)(const T* lv, const T* nv, TNAME(consumer) * k, T filter, int input, int abs_col, int sum_col, int neg_col, int borrow_col) {
+    T one = T_FROMB(1), ovf = T_FROMB(65536);
+    T is_neg = nv[neg_col];
+    TNAME(cons_transition)(k, T_MUL(T_MUL(filter, is_neg), T_SUB(one, is_neg)));
+    TNAME(cons_transition)(k, T_MUL(filter, T_SUB(T_SUB(T_ADD(lv[input + 1], T_FROMB(32768)), nv[sum_col]), T_MUL(is_neg, ovf))));
+    T b = nv[borrow_col];
+    TNAME(cons_transition)(k, T_MUL(T_MUL(filter, b), T_SUB(one, b)));
+    T neg_in[2] = {T_SUB(T_MUL(b, ovf), lv[input]), T_SUB(T_SUB(ovf, lv[input + 1]), b)};
+    for (int i = 0; i < 2; i++)
+        TNAME(cons_transition)(k, T_MUL(filter, T_SUB(T_ADD(T_MUL(is_neg, neg_in[i]), T_MUL(T_SUB(one, is_neg), lv[input + i])), lv[abs_col + i])));
+    return is_neg;
+}
+static void TNAME(eval_arithmetic)(const T* lv, const T* nv, TNAME(consumer) * k) {
+    T one = T_FROMB(1), ovf = T_FROMB(65536);
+    /* range counter arithmetic_stark.rs:224-230 */
+    T rc1 = lv[AR_RANGE_COUNTER], incr = T_SUB(nv[AR_RANGE_COUNTER], rc1);
+    TNAME(cons_first)(k, rc1);
+    TNAME(cons_transition)(k, T_SUB(T_MUL(incr, incr), incr));
+    TNAME(cons_last)(k, T_SUB(rc1, T_FROMB(65535)));
+    /* mul */
+    TNAME(ar_mul)(lv, lv[AR_MUL], lv + AR_IN0, lv + AR_IN1, k);
+    /* mult (signed, then unsigned) mult.rs:115-234 */
+    {
+        T f = lv[AR_MULT], l[4], r[4];
+        for (int s = 0; s < 2; s++) {
+            T is_neg = lv[AR_AUX_EXTRA + s], in_hi = lv[(s ? AR_IN1 : AR_IN0) + 1], sum = lv[AR_IN2 + s];
+            TNAME(cons)(k, T_MUL(T_MUL(f, is_neg), T_SUB(one, is_neg)));
+            TNAME(cons)(k, T_MUL(f, T_SUB(T_SUB(T_ADD(in_hi, T_FROMB(32768)), sum), T_MUL(is_neg, ovf))));
+            T* dst = s ? r : l;
+            dst[0] = lv[(s ? AR_IN1 : AR_IN0)]; dst[1] = in_hi; dst[2] = dst[3] = T_MULB(is_neg, 65535);
+        }
+        TNAME(ar_mult_helper)(lv, f, l, r, k);
+        T lu[4] = {lv[AR_IN0], lv[AR_IN0 + 1], T_FROMB(0), T_FROMB(0)}, ru[4] = {lv[AR_IN1], lv[AR_IN1 + 1], T_FROMB(0), T_FROMB(0)};
+        TNAME(ar_mult_helper)(lv, lv[AR_MULTU], lu, ru, k);
+    }
+    /* addcy addcy.rs:142-160 (ADDU and SUBU rows are not constrained there) */
+    TNAME(ar_addcy)(k, lv[AR_ADD], lv + AR_IN0, lv + AR_IN1, lv + AR_OUT, lv + AR_AUX0, 0);
+    TNAME(ar_addcy)(k, lv[AR_SUB], lv + AR_IN1, lv + AR_OUT, lv + AR_IN0, lv + AR_AUX0, 0);
+    TNAME(ar_addcy)(k, lv[AR_ADDI], lv + AR_IN0, lv + AR_IN1, lv + AR_OUT, lv + AR_AUX0, 0);
+    TNAME(ar_addcy)(k, lv[AR_ADDIU], lv + AR_IN0, lv + AR_IN1, lv + AR_OUT, lv + AR_AUX0, 0);
+    /* slt slt.rs:50-120: x = in1, y = aux (diff), z = in0, given_cy = AUX_INPUT_REGISTER_1, rd = OUTPUT_REGISTER */
+    {
+        T f = T_ADD(T_ADD(lv[AR_SLT], lv[AR_SLTU]), T_ADD(lv[AR_SLTI], lv[AR_SLTIU])), sign = T_ADD(lv[AR_SLT], lv[AR_SLTI]);
+        const T *x = lv + AR_IN1, *y = lv + AR_AUX0, *z = lv + AR_IN0, *gc = lv + AR_AUX1, *rd = lv + AR_OUT;
+        T cy = T_FROMB(0);
+        for (int i = 0; i < 2; i++) {
+            T t = T_SUB(T_ADD(T_ADD(cy, x[i]), y[i]), z[i]);
+            TNAME(cons)(k, T_MUL(T_MUL(f, t), T_SUB(ovf, t)));
+            cy = T_MULB(t, ZKO_INV_65536);
+        }
+        TNAME(cons)(k, T_MUL(T_MUL(f, gc[0]), T_SUB(gc[0], one)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, T_SUB(cy, gc[0])), T_SUB(one, sign)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, gc[1]), T_SUB(T_SUB(one, cy), gc[0])));
+        TNAME(cons_transition)(k, T_MUL(f, T_SUB(rd[0], gc[0])));
+        TNAME(cons)(k, T_MUL(T_MUL(f, gc[1]), T_SUB(one, sign)));
+        TNAME(cons_transition)(k, T_MUL(f, rd[1]));
+    }
+    /* lui */
+    TNAME(ar_mul)(lv, lv[AR_LUI], lv + AR_IN0, lv + AR_IN1, k);
+    /* div: unsigned, then signed div.rs:382-507 */
+    TNAME(ar_div_helper)(lv, nv, k, lv[AR_DIVU], AR_IN0, AR_IN1, AR_OUT, AR_AUX0);
+    {
+        T f = lv[AR_DIV];
+        T n0 = TNAME(ar_check_abs)(lv, nv, k, f, AR_IN0, AR_IN2, AR_NV_DENOM_IS_ZERO + 1, AR_NV_DENOM_IS_ZERO + 5, AR_NV_DENOM_IS_ZERO + 6);
+        T n1 = TNAME(ar_check_abs)(lv, nv, k, f, AR_IN1, AR_AUX2, AR_NV_DENOM_IS_ZERO + 2, AR_NV_DENOM_IS_ZERO + 7, AR_NV_DENOM_IS_ZERO + 8);
+        T nq = TNAME(ar_check_abs)(lv, nv, k, f, AR_OUT, AR_QUOT_ABS, AR_NV_DENOM_IS_ZERO + 3, AR_RC_FREQ + 1, AR_RC_FREQ + 2);
+        T nr = TNAME(ar_check_abs)(lv, nv, k, f, AR_AUX0, AR_REM_ABS, AR_NV_DENOM_IS_ZERO + 4, AR_RC_FREQ + 3, AR_RC_FREQ + 4);
+        T same = nv[AR_RC_FREQ + 5];
+        TNAME(cons_transition)(k, T_MUL(f, T_SUB(T_SUB(T_ADD(n0, n1), T_MULB(T_MUL(n0, n1), 2)), same)));
+        TNAME(cons_transition)(k, T_MUL(T_MUL(f, T_SUB(nq, same)), T_ADD(lv[AR_OUT], lv[AR_OUT + 1])));
+        TNAME(cons_transition)(k, T_MUL(T_MUL(f, T_SUB(nr, n0)), T_ADD(lv[AR_AUX0], lv[AR_AUX0 + 1])));
+        TNAME(ar_div_helper)(lv, nv, k, f, AR_IN2, AR_AUX2, AR_QUOT_ABS, AR_REM_ABS);
+    }
+    /* shift: sll = input * (1 << shift), srl = input / (1 << shift) shift.rs:52-96 */
+    TNAME(ar_mul)(lv, T_ADD(lv[AR_SLL], lv[AR_SLLV]), lv + AR_IN1, lv + AR_IN2, k);
+    TNAME(ar_div_helper)(lv, nv, k, T_ADD(lv[AR_SRL], lv[AR_SRLV]), AR_IN1, AR_IN2, AR_OUT, AR_AUX0);
+    /* sra sra.rs:66-133 */
+    {
+        T f = T_ADD(lv[AR_SRA], lv[AR_SRAV]), shift = lv[AR_IN0];
+        TNAME(cons_transition)(k, T_MUL(f, lv[AR_IN0 + 1]));
+        T is_neg = lv[AR_AUX2 + 3];
+        TNAME(cons_transition)(k, T_MUL(T_MUL(f, is_neg), T_SUB(one, is_neg)));
+        TNAME(cons_transition)(k, T_MUL(f, T_SUB(T_SUB(T_ADD(lv[AR_IN1 + 1], T_FROMB(32768)), lv[AR_AUX2 + 2]), T_MUL(is_neg, ovf))));
+        T shift_sq = nv[AR_AUX2 + 2];
+        TNAME(cons_transition)(k, T_MUL(f, T_SUB(shift_sq, T_MUL(shift, shift))));
+        T acc = T_FROMB(0);
+        for (int i = 0; i < 16; i++) {                                  /* pairs of coefficients from the top: (c_{31-2i}, c_{30-2i}) */
+            T w = i < 8 ? lv[AR_AUX_EXTRA + i] : nv[AR_AUX_EXTRA + i - 8];
+            T v = T_ADD(T_ADD(T_MUL(acc, shift_sq), T_MULB(shift, ZKM_ARITH_SIGN_EXTEND_POLY[31 - 2 * i])), T_FROMB(ZKM_ARITH_SIGN_EXTEND_POLY[30 - 2 * i]));
+            TNAME(cons_transition)(k, T_MUL(f, T_SUB(v, w)));
+            acc = w;
+        }
+        T acc_lo = nv[AR_AUX2], acc_hi = nv[AR_AUX2 + 1];
+        TNAME(cons_transition)(k, T_MUL(f, T_SUB(T_ADD(T_MUL(acc_hi, ovf), acc_lo), acc)));
+        TNAME(ar_div_helper)(lv, nv, k, f, AR_IN1, AR_IN2, AR_AUX2, AR_AUX0);
+        TNAME(cons_transition)(k, T_MUL(f, T_SUB(T_ADD(lv[AR_AUX2], T_MUL(acc_lo, is_neg)), lv[AR_OUT])));
+        TNAME(cons_transition)(k, T_MUL(f, T_SUB(T_ADD(lv[AR_AUX2 + 1], T_MUL(acc_hi, is_neg)), lv[AR_OUT + 1])));
+    }
+    /* lo_hi */
+    {
+        T f = T_ADD(T_ADD(lv[AR_MFHI], lv[AR_MTHI]), T_ADD(lv[AR_MFLO], lv[AR_MTLO]));
+        for (int i = 0; i < 2; i++) TNAME(cons)(k, T_MUL(f, T_SUB(lv[AR_IN0 + i], lv[AR_OUT + i])));
+    }
+}
+
 /* ---- MemoryStark constraints: memory/memory_stark.rs:253-341 (columns memory/columns.rs: FILTER 0, TIMESTAMP 1, IS_READ 2,
  * ADDR_CONTEXT 3, ADDR_SEGMENT 4, ADDR_VIRTUAL 5, VALUE 6 (VALUE_LIMBS = 1), CONTEXT/SEGMENT/VIRTUAL_FIRST_CHANGE 7..9,
  * RANGE_CHECK 10, COUNTER 11, FREQUENCIES 12) ---- */
@@ -415,8 +610,12 @@ static void TNAME(eval_memory)(const T* lv, const T* nv, TNAME(consumer) * k) {
 typedef struct { uint32_t ncols; const uint32_t* cols; uint32_t table_col, freq_col; } zko_lookup_def;
 static const uint32_t MEMORY_LOOKUP_COLS[1] = {10};
 static const zko_lookup_def MEMORY_LOOKUPS[1] = {{1, MEMORY_LOOKUP_COLS, 11, 12}};
+/* ArithmeticStark::lookups() arithmetic_stark.rs:269-276: the 18 shared columns in RANGE_COUNTER with RC_FREQUENCIES */
+static const uint32_t ARITH_LOOKUP_COLS[18] = {26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43};
+static const zko_lookup_def ARITH_LOOKUPS[1] = {{18, ARITH_LOOKUP_COLS, 44, 45}};
 static const zko_lookup_def* zko_table_lookups(int table_id, size_t* n) {
     if (table_id == 4) { *n = 1; return MEMORY_LOOKUPS; }
+    if (table_id == 10) { *n = 1; return ARITH_LOOKUPS; }
     *n = 0;
     return NULL;
 }
@@ -459,7 +658,7 @@ static void TNAME(eval_lookups)(int table_id, const gl_t* challenges, size_t nch
 }
 
 /* table dispatch (Table ids of include/zkm_hip.h) */
-static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : table_id == 4 ? 13 : table_id == 5 ? 110 : table_id == 6 ? 78 : table_id == 7 ? 76 : table_id == 8 ? 224 : table_id == 9 ? 127 : 0; }
+static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : table_id == 4 ? 13 : table_id == 5 ? 110 : table_id == 6 ? 78 : table_id == 7 ? 76 : table_id == 8 ? 224 : table_id == 9 ? 127 : table_id == 10 ? 54 : 0; }
 static void TNAME(eval_table)(int table_id, const T* lv, const T* nv, TNAME(consumer) * k) {
     if (table_id == 0) TNAME(eval_poseidon)(lv, k);
     else if (table_id == 1) TNAME(eval_logic)(lv, k);
@@ -470,7 +669,8 @@ static void TNAME(eval_table)(int table_id, const T* lv, const T* nv, TNAME(cons
     else if (table_id == 6) TNAME(eval_sha_extend)(lv, k);
     else if (table_id == 7) TNAME(eval_sha_extend_sponge)(lv, nv, k);
     else if (table_id == 8) TNAME(eval_sha_compress)(lv, nv, k);
-    else TNAME(eval_sha_compress_sponge)(lv, k);
+    else if (table_id == 9) TNAME(eval_sha_compress_sponge)(lv, k);
+    else TNAME(eval_arithmetic)(lv, nv, k);
 }
 
 /* ---- general CTL checks driven by the column-set description ----

@@ -19,6 +19,7 @@
 #include <time.h>
 #include "zkm_oracle.h"
 #include "hash_constants.h"
+#include "arith_constants.inc"
 #include "gl.h"
 #include "poseidon_constants.inc"
 

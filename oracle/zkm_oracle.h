@@ -90,6 +90,7 @@ void zko_poseidon_trace(uint64_t seed, size_t num_perms, unsigned log_n, uint64_
 #define ZKO_TABLE_SHA_EXTEND_SPONGE 7
 #define ZKO_TABLE_SHA_COMPRESS 8
 #define ZKO_TABLE_SHA_COMPRESS_SPONGE 9
+#define ZKO_TABLE_ARITHMETIC 10
 size_t zko_sha_compress_trace(const uint32_t* hx, const uint32_t* w, const uint64_t* meta, size_t k, unsigned log_n, uint64_t* out);
 void zko_sha_compress_sponge_trace(const uint32_t* hx, const uint32_t* w, const uint64_t* meta, size_t k, unsigned log_n, uint64_t* out);
 void zko_sha_extend_trace(const uint8_t* inputs, const uint64_t* timestamps, size_t k, unsigned log_n, uint64_t* out);

@@ -356,3 +356,43 @@ def test_sha_compress_single_table_proofs(ctx, oracle, t_idx):
     got = ctx.prove_single_table(trace, log_n, aux, [2], ncols=W, table_id=tid)
     assert (got == want).all()
     assert oracle.verify(got, 3, [2], ncols=W, table_id=tid) == 0
+
+
+def test_arithmetic_table_proof_is_bit_exact(ctx, zkm, oracle):
+    """ArithmeticStark: all 26 operations + the 18-column range-check lookup (20 lookup columns built on the GPU), bit-exact
+    against the oracle; corrupted rows of every constraint family are rejected by the oracle's verifier on GPU proofs too."""
+    from zkm_amd.ctl import CtlTable, make_zs
+    from . import arith_fixtures as A
+    log_n, n = 16, 1 << 16
+    ops = A.random_ops(1, 200)
+    trace = A.generate_trace(ops)
+    t = CtlTable()
+    cs = T.arithmetic_ctl_rows(t)          # the column set the CPU table looks up (arithmetic_stark.rs:66-126)
+    zs, ids = make_zs([([cs], 3, 5), ([cs], 7, 11)])
+    aux = ctx.ctl_data(t, zs, ids, trace, 54, log_n)
+    assert (aux == oracle.ctl_data(t, zs, ids, trace, 54, log_n)).all()
+    lk = [0x1234567, 0x89ABCDEF01]
+    want = oracle.prove_ctl(trace, log_n, aux, t, zs, ids, ncols=54, table_id=T.TABLE_ARITHMETIC, lookup_challenges=lk)
+    got = ctx.prove_single_table_ctl(trace, log_n, aux, t, zs, ids, ncols=54, table_id=T.TABLE_ARITHMETIC, lookup_challenges=lk)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing word %d" % bad[0]
+    assert got[3] == 20 + 2
+    assert oracle.verify_ctl(got, 2, t, zs, ids, ncols=54, table_id=T.TABLE_ARITHMETIC, lookup_challenges=lk) == 0
+    first_row, r = {}, 0
+    for op, a, b in ops:
+        first_row.setdefault(op, r)
+        r += 2 if op in (A.IS_DIV, A.IS_DIVU, A.IS_SRL, A.IS_SRLV, A.IS_SRA, A.IS_SRAV) else 1
+    cases = [(A.IS_ADD, A.OUT, 0), (A.IS_SUB, A.AUX0, 0), (A.IS_MUL, A.OUT + 1, 0), (A.IS_MULT, A.OUT_HI, 0), (A.IS_MULTU, A.OUT_LO, 0),
+             (A.IS_SLT, A.OUT, 0), (A.IS_SLTU, A.AUX0, 0), (A.IS_LUI, A.OUT + 1, 0), (A.IS_DIVU, A.OUT_HI, 0), (A.IS_DIV, A.QUOT_ABS, 0),
+             (A.IS_DIV, A.NV_DENOM_IS_ZERO + 5, 1), (A.IS_SLL, A.OUT, 0), (A.IS_SRL, A.OUT, 0), (A.IS_SRA, A.OUT + 1, 0), (A.IS_SRAV, A.AUX_EXTRA + 3, 1),
+             (A.IS_MFLO, A.OUT, 0), (A.IS_ADDI, A.OUT, 0), (A.IS_SLTI, A.AUX1, 0), (A.IS_SLLV, A.AUX0, 0), (A.IS_SRLV, A.AUX0, 0)]
+    for op, col, second in cases:
+        badt = trace.copy()
+        idx = col * n + first_row[op] + second
+        badt[idx] = (int(badt[idx]) + 1) & 0xFFFF if col < A.RANGE_COUNTER else int(badt[idx]) + 1
+        tr = badt.reshape(54, n)
+        tr[A.RC_FREQ] = 0
+        tr[A.RC_FREQ] += np.bincount(tr[26:44].reshape(-1).astype(np.int64), minlength=n)[:n].astype(np.uint64)
+        aux2 = ctx.ctl_data(t, zs, ids, badt, 54, log_n)
+        p2 = ctx.prove_single_table_ctl(badt, log_n, aux2, t, zs, ids, ncols=54, table_id=T.TABLE_ARITHMETIC, lookup_challenges=lk)
+        assert oracle.verify_ctl(p2, 2, t, zs, ids, ncols=54, table_id=T.TABLE_ARITHMETIC, lookup_challenges=lk) != 0, (op, col)

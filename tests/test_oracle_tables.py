@@ -253,3 +253,45 @@ def test_sha_compress_path(oracle):
         bt[t_idx] = (tid, bad, width, log_n, ct)
         proofs, chal, offs = oracle.prove_with_traces(bt, ctls)
         assert oracle.verify_all(bt, ctls, proofs, chal) != 0
+
+
+def _arith_proof_ok(oracle, trace, log_n=16):
+    from zkm_amd.ctl import CtlTable, make_zs
+    t = CtlTable()
+    cs = T.arithmetic_ctl_rows(t)          # the column set the CPU table looks up (arithmetic_stark.rs:66-126)
+    zs, ids = make_zs([([cs], 3, 5), ([cs], 7, 11)])
+    aux = oracle.ctl_data(t, zs, ids, trace, 54, log_n)
+    proof = oracle.prove_ctl(trace, log_n, aux, t, zs, ids, ncols=54, table_id=T.TABLE_ARITHMETIC, lookup_challenges=[3, 7])
+    return oracle.verify_ctl(proof, 2, t, zs, ids, ncols=54, table_id=T.TABLE_ARITHMETIC, lookup_challenges=[3, 7]) == 0
+
+
+def test_arithmetic_table_all_operations(oracle):
+    """ArithmeticStark (arithmetic_stark.rs:214-276): all 26 operations, the 2^16-row range-check lookup over the 18 shared columns
+    (20 lookup columns in front of the CTL columns), and one corrupted cell per constraint family is rejected."""
+    from . import arith_fixtures as A
+    assert oracle.num_lookup_columns(T.TABLE_ARITHMETIC) == 20
+    ops = A.random_ops(1, 200)
+    trace = A.generate_trace(ops)
+    assert _arith_proof_ok(oracle, trace)
+    n = 1 << 16
+    # row of the first operation of each kind, then flip a witness cell that only that operation's constraints see
+    first_row, r = {}, 0
+    for op, a, b in ops:
+        first_row.setdefault(op, r)
+        r += 2 if op in (A.IS_DIV, A.IS_DIVU, A.IS_SRL, A.IS_SRLV, A.IS_SRA, A.IS_SRAV) else 1
+    cases = [(A.IS_ADD, A.OUT, 0), (A.IS_SUB, A.AUX0, 0), (A.IS_MUL, A.OUT + 1, 0), (A.IS_MULT, A.OUT_HI, 0), (A.IS_MULTU, A.OUT_LO, 0),
+             (A.IS_SLT, A.OUT, 0), (A.IS_SLTU, A.AUX0, 0), (A.IS_LUI, A.OUT + 1, 0), (A.IS_DIVU, A.OUT_HI, 0), (A.IS_DIV, A.QUOT_ABS, 0),
+             (A.IS_DIV, A.NV_DENOM_IS_ZERO + 5, 1), (A.IS_SLL, A.OUT, 0), (A.IS_SRL, A.OUT, 0), (A.IS_SRA, A.OUT + 1, 0), (A.IS_SRAV, A.AUX_EXTRA + 3, 1),
+             (A.IS_MFLO, A.OUT, 0)]
+    for op, col, second in cases[::3]:       # every third case here (each is a full 2^16-row proof); the rest run in the GPU parity test
+        bad = trace.copy()
+        idx = col * n + first_row[op] + second
+        bad[idx] = (int(bad[idx]) + 1) & 0xFFFF if col < A.RANGE_COUNTER else int(bad[idx]) + 1
+        tr = bad.reshape(54, n)
+        tr[A.RC_FREQ] = 0
+        tr[A.RC_FREQ] += np.bincount(tr[26:44].reshape(-1).astype(np.int64), minlength=n)[:n].astype(np.uint64)   # keep the lookup consistent
+        assert not _arith_proof_ok(oracle, bad), "corruption of op %d col %d accepted" % (op, col)
+    # a value outside the 16-bit range fails the lookup even when no operation flag is set on its row
+    bad = trace.copy()
+    bad[30 * n + 40000] = 1 << 16
+    assert not _arith_proof_ok(oracle, bad)

@@ -558,6 +558,224 @@ __device__ void eval_lookup_constraints(const lookup_dev& d, const gl_t* __restr
     }
 }
 
+// ArithmeticStark (arithmetic/arithmetic_stark.rs:214-240 and the nine operation modules it calls; N_LIMBS = 2).  The oracle's
+// TNAME(eval_arithmetic) documents the column map; this is the same sequence of constraints on LDE columns.
+namespace arith {
+enum { ADD = 0, ADDU, ADDI, ADDIU, SUB, SUBU, MULT, MULTU, MUL, DIV, DIVU, SLLV, SRLV, SRAV, SLL, SRL, SRA, SLT, SLTU, SLTI, SLTIU, LUI, MFHI, MTHI,
+       MFLO, MTLO, IN0 = 26, IN1 = 28, IN2 = 30, OUT = 32, AUX0 = 34, AUX1 = 36, AUX2 = 38, QUOT_ABS = 40, REM_ABS = 42, MULT_AUX_LO = 36,
+       MULT_AUX_HI = 40, RANGE_COUNTER = 44, RC_FREQ = 45, AUX_EXTRA = 46, NV_RED = 26, NV_MOD_IS_ZERO = 28, NV_AUX_LO = 29, NV_AUX_HI = 32,
+       NV_DENOM_IS_ZERO = 35 };
+constexpr gl_t INV_65536 = 18446462594437939201ULL;  // addcy.rs:41
+#undef ZKM_CONST
+#define ZKM_CONST static __device__ const
+#include "arith_constants.inc"
+#undef ZKM_CONST
+
+// local / next row accessors of one thread
+struct frame {
+    const gl_t* __restrict__ lv;
+    const gl_t* __restrict__ nv;
+    size_t cs;
+    __device__ __forceinline__ gl_t L(int c) const { return lv[(size_t)c * cs]; }
+    __device__ __forceinline__ gl_t N(int c) const { return nv[(size_t)c * cs]; }
+};
+template <int NA>
+__device__ __forceinline__ void emit(consumer_t<NA>& k, gl_t c, bool two_row) {
+    if (two_row) k.transition(c); else k.constraint(c);
+}
+// eval_packed_generic_addcy addcy.rs:43-93 (x + y == z + cy 2^32)
+template <int NA>
+__device__ void addcy(consumer_t<NA>& k, gl_t filter, const gl_t (&x)[2], const gl_t (&y)[2], const gl_t (&z)[2], const gl_t (&given_cy)[2],
+                      bool two_row) {
+    gl_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        gl_t t = gl_sub(gl_add(gl_add(cy, x[i]), y[i]), z[i]);
+        emit(k, gl_mul(gl_mul(filter, t), gl_sub(65536, t)), two_row);
+        cy = gl_mul(t, INV_65536);
+    }
+    if (two_row) {
+        k.transition(gl_mul(filter, gl_sub(cy, given_cy[0])));
+        k.transition(gl_mul(filter, given_cy[1]));
+    } else {
+        k.constraint(gl_mul(gl_mul(filter, given_cy[0]), gl_sub(given_cy[0], 1)));
+        k.constraint(gl_mul(filter, gl_sub(cy, given_cy[0])));
+        k.constraint(gl_mul(filter, given_cy[1]));
+    }
+}
+// eval_packed_generic_mul mul.rs:109-135
+template <int NA>
+__device__ void mul(const frame& f, gl_t filter, int l, int r, consumer_t<NA>& k) {
+    gl_t aux[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) aux[i] = gl_sub(gl_add(f.L(AUX0 + i), gl_mul(f.L(AUX1 + i), 65536)), 1 << 20);
+    gl_t l0 = f.L(l), l1 = f.L(l + 1), r0 = f.L(r), r1 = f.L(r + 1);
+    gl_t c0 = gl_add(gl_sub(gl_mul(l0, r0), f.L(OUT)), gl_mul(aux[0], 65536));
+    gl_t c1 = gl_sub(gl_sub(gl_add(gl_mul(l0, r1), gl_mul(l1, r0)), f.L(OUT + 1)), gl_sub(aux[0], gl_mul(aux[1], 65536)));
+    k.constraint(gl_mul(filter, c0));
+    k.constraint(gl_mul(filter, c1));
+}
+// eval_packed_generic_mult_helper mult.rs:236-262
+template <int NA>
+__device__ void mult_helper(const frame& f, gl_t filter, const gl_t (&l)[4], const gl_t (&r)[4], consumer_t<NA>& k) {
+    gl_t aux[4], cp[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) aux[i] = gl_sub(gl_add(f.L(MULT_AUX_LO + i), gl_mul(f.L(MULT_AUX_HI + i), 65536)), 1 << 20);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        gl_t s = 0;
+#pragma unroll
+        for (int i = 0; i <= d; i++) s = gl_add(s, gl_mul(l[i], r[d - i]));
+        cp[d] = gl_sub(s, f.L(OUT + d));
+    }
+    cp[0] = gl_add(cp[0], gl_mul(aux[0], 65536));
+#pragma unroll
+    for (int d = 1; d < 4; d++) cp[d] = gl_sub(cp[d], gl_sub(aux[d - 1], gl_mul(aux[d], 65536)));
+#pragma unroll
+    for (int d = 0; d < 4; d++) k.constraint(gl_mul(filter, cp[d]));
+}
+// eval_packed_div_helper div.rs:509-541 (modular_constr_poly :325-380, check_reduced :300-323)
+template <int NA>
+__device__ void div_helper(const frame& f, consumer_t<NA>& k, gl_t filter, int num, int den, int quo, int rem) {
+    k.last_row(filter);
+    gl_t miz = f.N(NV_MOD_IS_ZERO);
+    k.transition(gl_mul(filter, gl_sub(gl_mul(miz, miz), miz)));
+    gl_t modulus[2] = {f.L(den), f.L(den + 1)}, output[2] = {f.L(rem), f.L(rem + 1)};
+    k.transition(gl_mul(gl_mul(filter, gl_add(modulus[0], modulus[1])), miz));
+    modulus[0] = gl_add(modulus[0], miz);
+    gl_t ddz = f.N(NV_DENOM_IS_ZERO);
+    gl_t shr_div = gl_add(gl_add(gl_add(f.L(DIV), f.L(DIVU)), gl_add(f.L(SRL), f.L(SRLV))), gl_add(f.L(SRA), f.L(SRAV)));
+    k.transition(gl_mul(filter, gl_sub(gl_mul(miz, shr_div), ddz)));
+    output[0] = gl_add(output[0], ddz);
+    {
+        const gl_t less[2] = {gl_sub(1, gl_mul(miz, shr_div)), 0}, red[2] = {f.N(NV_RED), f.N(NV_RED + 1)};
+        addcy(k, filter, modulus, red, output, less, true);
+    }
+    output[0] = gl_sub(output[0], ddz);
+    const gl_t q0 = f.L(quo), q1 = f.L(quo + 1);  // quot = [q0, q1, 0, 0]
+    gl_t prod[4] = {gl_mul(q0, modulus[0]), gl_add(gl_mul(q0, modulus[1]), gl_mul(q1, modulus[0])), gl_mul(q1, modulus[1]), 0};
+    k.transition(0);  // filter * prod[4], which is identically zero for a two-limb quotient
+    gl_t cp[4] = {gl_add(prod[0], output[0]), gl_add(prod[1], output[1]), prod[2], prod[3]}, aux[4];
+#pragma unroll
+    for (int i = 0; i < 3; i++) aux[i] = gl_add(gl_sub(f.N(NV_AUX_LO + i), 1 << 20), gl_mul(f.N(NV_AUX_HI + i), 65536));
+    aux[3] = 0;
+    cp[0] = gl_sub(cp[0], gl_mul(aux[0], 65536));
+#pragma unroll
+    for (int d = 1; d < 4; d++) cp[d] = gl_add(cp[d], gl_sub(aux[d - 1], gl_mul(aux[d], 65536)));
+    cp[0] = gl_sub(cp[0], f.L(num));
+    cp[1] = gl_sub(cp[1], f.L(num + 1));
+#pragma unroll
+    for (int d = 0; d < 4; d++) k.transition(gl_mul(filter, cp[d]));
+}
+// check_abs of eval_packed_div div.rs:400-430
+template <int NA>
+__device__ gl_t check_abs(const frame& f, consumer_t<NA>& k, gl_t filter, int input, int abs_col, int sum_col, int neg_col, int borrow_col) {
+    gl_t is_neg = f.N(neg_col);
+    k.transition(gl_mul(gl_mul(filter, is_neg), gl_sub(1, is_neg)));
+    k.transition(gl_mul(filter, gl_sub(gl_sub(gl_add(f.L(input + 1), 32768), f.N(sum_col)), gl_mul(is_neg, 65536))));
+    gl_t b = f.N(borrow_col);
+    k.transition(gl_mul(gl_mul(filter, b), gl_sub(1, b)));
+    const gl_t neg_in[2] = {gl_sub(gl_mul(b, 65536), f.L(input)), gl_sub(gl_sub(65536, f.L(input + 1)), b)};
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+        k.transition(gl_mul(filter, gl_sub(gl_add(gl_mul(is_neg, neg_in[i]), gl_mul(gl_sub(1, is_neg), f.L(input + i))), f.L(abs_col + i))));
+    return is_neg;
+}
+}  // namespace arith
+
+template <int NA>
+__device__ void eval_arithmetic_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
+    using namespace arith;
+    const frame f{lv, lv + dnext, cs};
+    gl_t rc1 = f.L(RANGE_COUNTER), incr = gl_sub(f.N(RANGE_COUNTER), rc1);
+    k.first_row(rc1);
+    k.transition(gl_sub(gl_mul(incr, incr), incr));
+    k.last_row(gl_sub(rc1, 65535));
+    mul(f, f.L(MUL), IN0, IN1, k);
+    {   // mult.rs:115-234: signed (sign-extended operands), then unsigned
+        gl_t ff = f.L(MULT), l[4], r[4];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            gl_t is_neg = f.L(AUX_EXTRA + s), in_hi = f.L((s ? IN1 : IN0) + 1), sum = f.L(IN2 + s);
+            k.constraint(gl_mul(gl_mul(ff, is_neg), gl_sub(1, is_neg)));
+            k.constraint(gl_mul(ff, gl_sub(gl_sub(gl_add(in_hi, 32768), sum), gl_mul(is_neg, 65536))));
+            gl_t pad = gl_mul(is_neg, 65535);
+            if (s) { r[0] = f.L(IN1); r[1] = in_hi; r[2] = r[3] = pad; }
+            else { l[0] = f.L(IN0); l[1] = in_hi; l[2] = l[3] = pad; }
+        }
+        mult_helper(f, ff, l, r, k);
+        const gl_t lu[4] = {l[0], l[1], 0, 0}, ru[4] = {r[0], r[1], 0, 0};
+        mult_helper(f, f.L(MULTU), lu, ru, k);
+    }
+    {   // addcy.rs:142-160 (ADDU / SUBU rows are not constrained by the reference)
+        const gl_t in0[2] = {f.L(IN0), f.L(IN0 + 1)}, in1[2] = {f.L(IN1), f.L(IN1 + 1)}, out[2] = {f.L(OUT), f.L(OUT + 1)};
+        const gl_t aux[2] = {f.L(AUX0), f.L(AUX0 + 1)};
+        addcy(k, f.L(ADD), in0, in1, out, aux, false);
+        addcy(k, f.L(SUB), in1, out, in0, aux, false);
+        addcy(k, f.L(ADDI), in0, in1, out, aux, false);
+        addcy(k, f.L(ADDIU), in0, in1, out, aux, false);
+        // slt.rs:50-120: x = in1, y = diff (AUX0), z = in0, given_cy = AUX1, rd = OUT
+        gl_t fl = gl_add(gl_add(f.L(SLT), f.L(SLTU)), gl_add(f.L(SLTI), f.L(SLTIU))), sign = gl_add(f.L(SLT), f.L(SLTI));
+        const gl_t gc[2] = {f.L(AUX1), f.L(AUX1 + 1)};
+        gl_t cy = 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            gl_t t = gl_sub(gl_add(gl_add(cy, in1[i]), aux[i]), in0[i]);
+            k.constraint(gl_mul(gl_mul(fl, t), gl_sub(65536, t)));
+            cy = gl_mul(t, INV_65536);
+        }
+        k.constraint(gl_mul(gl_mul(fl, gc[0]), gl_sub(gc[0], 1)));
+        k.constraint(gl_mul(gl_mul(fl, gl_sub(cy, gc[0])), gl_sub(1, sign)));
+        k.constraint(gl_mul(gl_mul(fl, gc[1]), gl_sub(gl_sub(1, cy), gc[0])));
+        k.transition(gl_mul(fl, gl_sub(out[0], gc[0])));
+        k.constraint(gl_mul(gl_mul(fl, gc[1]), gl_sub(1, sign)));
+        k.transition(gl_mul(fl, out[1]));
+    }
+    mul(f, f.L(LUI), IN0, IN1, k);
+    div_helper(f, k, f.L(DIVU), IN0, IN1, OUT, AUX0);
+    {   // signed division div.rs:387-507
+        gl_t ff = f.L(DIV);
+        gl_t n0 = check_abs(f, k, ff, IN0, IN2, NV_DENOM_IS_ZERO + 1, NV_DENOM_IS_ZERO + 5, NV_DENOM_IS_ZERO + 6);
+        gl_t n1 = check_abs(f, k, ff, IN1, AUX2, NV_DENOM_IS_ZERO + 2, NV_DENOM_IS_ZERO + 7, NV_DENOM_IS_ZERO + 8);
+        gl_t nq = check_abs(f, k, ff, OUT, QUOT_ABS, NV_DENOM_IS_ZERO + 3, RC_FREQ + 1, RC_FREQ + 2);
+        gl_t nr = check_abs(f, k, ff, AUX0, REM_ABS, NV_DENOM_IS_ZERO + 4, RC_FREQ + 3, RC_FREQ + 4);
+        gl_t same = f.N(RC_FREQ + 5);
+        k.transition(gl_mul(ff, gl_sub(gl_sub(gl_add(n0, n1), gl_mul(gl_mul(n0, n1), 2)), same)));
+        k.transition(gl_mul(gl_mul(ff, gl_sub(nq, same)), gl_add(f.L(OUT), f.L(OUT + 1))));
+        k.transition(gl_mul(gl_mul(ff, gl_sub(nr, n0)), gl_add(f.L(AUX0), f.L(AUX0 + 1))));
+        div_helper(f, k, ff, IN2, AUX2, QUOT_ABS, REM_ABS);
+    }
+    mul(f, gl_add(f.L(SLL), f.L(SLLV)), IN1, IN2, k);
+    div_helper(f, k, gl_add(f.L(SRL), f.L(SRLV)), IN1, IN2, OUT, AUX0);
+    {   // sra.rs:66-133
+        gl_t ff = gl_add(f.L(SRA), f.L(SRAV)), shift = f.L(IN0);
+        k.transition(gl_mul(ff, f.L(IN0 + 1)));
+        gl_t is_neg = f.L(AUX2 + 3);
+        k.transition(gl_mul(gl_mul(ff, is_neg), gl_sub(1, is_neg)));
+        k.transition(gl_mul(ff, gl_sub(gl_sub(gl_add(f.L(IN1 + 1), 32768), f.L(AUX2 + 2)), gl_mul(is_neg, 65536))));
+        gl_t shift_sq = f.N(AUX2 + 2);
+        k.transition(gl_mul(ff, gl_sub(shift_sq, gl_mul(shift, shift))));
+        gl_t acc = 0;
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) {
+            gl_t w = i < 8 ? f.L(AUX_EXTRA + i) : f.N(AUX_EXTRA + i - 8);
+            gl_t v = gl_add(gl_add(gl_mul(acc, shift_sq), gl_mul(shift, ZKM_ARITH_SIGN_EXTEND_POLY[31 - 2 * i])), ZKM_ARITH_SIGN_EXTEND_POLY[30 - 2 * i]);
+            k.transition(gl_mul(ff, gl_sub(v, w)));
+            acc = w;
+        }
+        gl_t acc_lo = f.N(AUX2), acc_hi = f.N(AUX2 + 1);
+        k.transition(gl_mul(ff, gl_sub(gl_add(gl_mul(acc_hi, 65536), acc_lo), acc)));
+        div_helper(f, k, ff, IN1, IN2, AUX2, AUX0);
+        k.transition(gl_mul(ff, gl_sub(gl_add(f.L(AUX2), gl_mul(acc_lo, is_neg)), f.L(OUT))));
+        k.transition(gl_mul(ff, gl_sub(gl_add(f.L(AUX2 + 1), gl_mul(acc_hi, is_neg)), f.L(OUT + 1))));
+    }
+    {   // lo_hi.rs:23-36
+        gl_t ff = gl_add(gl_add(f.L(MFHI), f.L(MTHI)), gl_add(f.L(MFLO), f.L(MTLO)));
+        k.constraint(gl_mul(ff, gl_sub(f.L(IN0), f.L(OUT))));
+        k.constraint(gl_mul(ff, gl_sub(f.L(IN0 + 1), f.L(OUT + 1))));
+    }
+}
+
 template <int TABLE, int NA>
 __device__ __forceinline__ void eval_table_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
     if constexpr (TABLE == ZKM_TABLE_POSEIDON) eval_poseidon_constraints<NA>(lv, cs, k);
@@ -569,6 +787,7 @@ __device__ __forceinline__ void eval_table_constraints(const gl_t* __restrict__ 
     else if constexpr (TABLE == ZKM_TABLE_SHA_EXTEND) eval_sha_extend_constraints<NA>(lv, cs, k);
     else if constexpr (TABLE == ZKM_TABLE_SHA_EXTEND_SPONGE) eval_sha_extend_sponge_constraints<NA>(lv, cs, dnext, k);
     else if constexpr (TABLE == ZKM_TABLE_SHA_COMPRESS) eval_sha_compress_constraints<NA>(lv, cs, dnext, k);
-    else eval_sha_compress_sponge_constraints<NA>(lv, cs, k);
+    else if constexpr (TABLE == ZKM_TABLE_SHA_COMPRESS_SPONGE) eval_sha_compress_sponge_constraints<NA>(lv, cs, k);
+    else eval_arithmetic_constraints<NA>(lv, cs, dnext, k);
 }
 

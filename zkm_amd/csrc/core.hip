@@ -79,8 +79,12 @@ void zkm_ctx::prof_end() { ZKM_HIP_CHECK(hipEventRecord(prof.back().stop, stream
 // FREQUENCIES (12), memory_stark.rs:476-483.
 static const uint32_t MEMORY_LOOKUP_COLS[1] = {10};
 static const zkm_table_lookup MEMORY_LOOKUPS[1] = {{1, MEMORY_LOOKUP_COLS, 11, 12}};
+// Arithmetic: the 18 shared columns (26..43) looked up in RANGE_COUNTER (44) with RC_FREQUENCIES (45), arithmetic_stark.rs:269-276.
+static const uint32_t ARITH_LOOKUP_COLS[18] = {26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43};
+static const zkm_table_lookup ARITH_LOOKUPS[1] = {{18, ARITH_LOOKUP_COLS, 44, 45}};
 const zkm_table_lookup* zkm_table_lookups(int table_id, size_t* n) {
     if (table_id == ZKM_TABLE_MEMORY) { *n = 1; return MEMORY_LOOKUPS; }
+    if (table_id == ZKM_TABLE_ARITHMETIC) { *n = 1; return ARITH_LOOKUPS; }
     *n = 0;
     return nullptr;
 }
@@ -498,6 +502,7 @@ size_t zkm_table_width(int table_id) {
         case ZKM_TABLE_SHA_EXTEND_SPONGE: return ZKM_SHA_EXTEND_SPONGE_COLS;
         case ZKM_TABLE_SHA_COMPRESS: return ZKM_SHA_COMPRESS_COLS;
         case ZKM_TABLE_SHA_COMPRESS_SPONGE: return ZKM_SHA_COMPRESS_SPONGE_COLS;
+        case ZKM_TABLE_ARITHMETIC: return ZKM_ARITHMETIC_COLS;
         default: return 0;
     }
 }

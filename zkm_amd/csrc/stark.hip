@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_quotient(const gl_t* __restrict__ trace
 
     eval_table_constraints<TABLE, NA>(trace + j, N, (ptrdiff_t)jn - (ptrdiff_t)j, k);
     // auxiliary columns: the table's lookup helper columns first, then the CTL helper columns and Zs (prover.rs:495-508)
-    if constexpr (TABLE == ZKM_TABLE_MEMORY) eval_lookup_constraints<NA>(lookups, trace + j, N, aux, j, jn, k);
+    if constexpr (TABLE == ZKM_TABLE_MEMORY || TABLE == ZKM_TABLE_ARITHMETIC) eval_lookup_constraints<NA>(lookups, trace + j, N, aux, j, jn, k);
     eval_ctl_constraints<NA>(ctl, trace + j, N, (ptrdiff_t)jn - (ptrdiff_t)j, aux + (size_t)num_lookup_cols * N, j, jn, k);
     gl_t zi = (i & 1) ? zh_inv1 : zh_inv0;
 #pragma unroll
@@ -178,7 +178,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
     {
         static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory", "quotient_poseidon_sponge", "quotient_sha_extend", "quotient_sha_extend_sponge", "quotient_sha_compress",
-                                            "quotient_sha_compress_sponge"};
+                                            "quotient_sha_compress_sponge", "quotient_arithmetic"};
         zkm_prof_scope ps(c, names[table_id]);
         dim3 grid((size + 255) / 256), block(256);
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
@@ -204,7 +204,9 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             case 16: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_COMPRESS, 1); break;
             case 17: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_COMPRESS, 2); break;
             case 18: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_COMPRESS_SPONGE, 1); break;
-            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_COMPRESS_SPONGE, 2); break;
+            case 19: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_COMPRESS_SPONGE, 2); break;
+            case 20: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_ARITHMETIC, 1); break;
+            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_ARITHMETIC, 2); break;
         }
 #undef ZKM_LAUNCH_QUOTIENT
         ZKM_HIP_CHECK(hipGetLastError());

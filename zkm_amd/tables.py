@@ -9,9 +9,9 @@ include/zkm_hip.h); mirrors
 from .ctl import CtlTable
 
 TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY, TABLE_POSEIDON_SPONGE = 0, 1, 2, 3, 4, 5
-TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRESS_SPONGE = 6, 7, 8, 9
+TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRESS_SPONGE, TABLE_ARITHMETIC = 6, 7, 8, 9, 10
 WIDTH = {TABLE_POSEIDON: 262, TABLE_LOGIC: 69, TABLE_KECCAK_SPONGE: 470, TABLE_KECCAK: 2431, TABLE_MEMORY: 13, TABLE_POSEIDON_SPONGE: 110,
-         TABLE_SHA_EXTEND: 78, TABLE_SHA_EXTEND_SPONGE: 76, TABLE_SHA_COMPRESS: 224, TABLE_SHA_COMPRESS_SPONGE: 127}
+         TABLE_SHA_EXTEND: 78, TABLE_SHA_EXTEND_SPONGE: 76, TABLE_SHA_COMPRESS: 224, TABLE_SHA_COMPRESS_SPONGE: 127, TABLE_ARITHMETIC: 54}
 
 # LogicStark columns (logic.rs:25-50)
 LOGIC_IS_AND, LOGIC_IS_OR, LOGIC_IS_XOR, LOGIC_IS_NOR = 0, 1, 2, 3
@@ -395,3 +395,23 @@ def ctl_sha_compress_inputs(sponge_index, compress_index, sponge_ctl, compress_c
 def ctl_sha_compress_outputs(sponge_index, compress_index, sponge_ctl, compress_ctl):
     """all_stark::ctl_sha_compress_outputs() (all_stark.rs:312-324)."""
     return [(sponge_index, sha_compress_sponge_looking_outputs(sponge_ctl))], (compress_index, sha_compress_ctl_data_outputs(compress_ctl))
+
+
+# ArithmeticStark (arithmetic/columns.rs): operation flags 0..25, 16-bit limb registers
+ARITH_IN0, ARITH_IN1, ARITH_OUT = 26, 28, 32
+ARITH_COMBINED_OPS = [(0, 0b100000 << 6), (1, 0b100001 << 6), (2, 0b001000), (3, 0b001001), (4, 0b100010 << 6), (5, 0b100011 << 6),
+                      (6, 0b011000 << 6), (7, 0b011001 << 6), (8, 0b011100 + (0b000010 << 6)), (9, 0b011010 << 6), (10, 0b011011 << 6),
+                      (11, 0b000100 << 6), (12, 0b000110 << 6), (13, 0b000111 << 6), (14, 0), (15, 0b000010 << 6), (16, 0b000011 << 6),
+                      (17, 0b101010 << 6), (18, 0b101011 << 6), (19, 0b001010), (20, 0b001011), (21, 0b001111), (22, 0b010000 << 6),
+                      (23, 0b010001 << 6), (24, 0b010010 << 6), (25, 0b010011 << 6)]
+
+
+def arithmetic_ctl_rows(t: CtlTable):
+    """arithmetic_stark::ctl_arithmetic_rows() (arithmetic_stark.rs:26-126): the opcode combination, then INPUT_REGISTER_0,
+    INPUT_REGISTER_1 and OUTPUT_REGISTER as 32-bit values (limb0 + 2^16 limb1); filter = sum of the 26 flags.  The CPU table is the
+    only looker (all_stark.rs:156-164), so this set is exercised on its own until the CPU table has a kernel."""
+    first = t.column(local=[(c, code) for c, code in ARITH_COMBINED_OPS])
+    for reg in (ARITH_IN0, ARITH_IN1, ARITH_OUT):
+        t.column(local=[(reg, 1), (reg + 1, 1 << 16)])
+    f = t.sum([c for c, _ in ARITH_COMBINED_OPS])
+    return t.colset(range(first, first + 4), filter_constants=[f])
