@@ -396,3 +396,84 @@ def test_arithmetic_table_proof_is_bit_exact(ctx, zkm, oracle):
         aux2 = ctx.ctl_data(t, zs, ids, badt, 54, log_n)
         p2 = ctx.prove_single_table_ctl(badt, log_n, aux2, t, zs, ids, ncols=54, table_id=T.TABLE_ARITHMETIC, lookup_challenges=lk)
         assert oracle.verify_ctl(p2, 2, t, zs, ids, ncols=54, table_id=T.TABLE_ARITHMETIC, lookup_challenges=lk) != 0, (op, col)
+
+
+def test_eleven_tables_in_one_proof(ctx, oracle):
+    """Every table with a constraint kernel in ONE prove_with_traces call on one transcript: the Keccak, Poseidon, SHA-extend and
+    SHA-compress paths share the Logic and Memory tables exactly as in all_stark::ctl_logic / ctl_memory (minus the CPU lookers), and
+    the Arithmetic table rides along with its own column set.  GPU proof == oracle proof, and verify_proof accepts."""
+    from zkm_amd.ctl import CtlTable
+    from . import arith_fixtures as A
+    kt, _, (kops, kin, kts, kmem) = logic_fixtures.build4(oracle, log_sponge=3)
+    pt, _, (pdata, poff, pmeta, pin, pts, pmem) = logic_fixtures.build_poseidon_path(oracle, log_sponge=4)
+    et, _, (ew16, emeta, ein, ets, eops, emem) = logic_fixtures.build_sha_extend_path(oracle, nblocks=1)
+    ct, _, (chx, cw, cmeta, cops, cmem) = logic_fixtures.build_sha_compress_path(oracle, ncomp=1)
+
+    def memory_table(ops):
+        log_m = int(np.ceil(np.log2(len(ops)))) + 1
+        tr, natural = oracle.memory_trace(ops, log_m)
+        if natural < (1 << log_m):
+            log_m -= 1
+            tr, natural = oracle.memory_trace(ops, log_m)
+        return tr, log_m
+    memory, log_mem = memory_table(np.concatenate([kmem, pmem, emem, cmem]))
+    lops = np.concatenate([kops, eops, cops])
+    np.random.default_rng(77).shuffle(lops, axis=0)
+    log_logic = int(np.ceil(np.log2(len(lops))))
+    logic = oracle.logic_trace(lops, log_logic)
+    arith = A.generate_trace(A.random_ops(5, 60))
+    c = [CtlTable() for _ in range(11)]
+    KS, KK, PS, PO, SES, SE, SCS, SC, LO, ME, AR = range(11)
+    tables = [(kt[0][0], kt[0][1], 470, kt[0][3], c[KS]), (kt[1][0], kt[1][1], 2431, kt[1][3], c[KK]),
+              (pt[0][0], pt[0][1], 110, pt[0][3], c[PS]), (pt[1][0], pt[1][1], 262, pt[1][3], c[PO]),
+              (et[0][0], et[0][1], 76, et[0][3], c[SES]), (et[1][0], et[1][1], 78, et[1][3], c[SE]),
+              (ct[0][0], ct[0][1], 127, ct[0][3], c[SCS]), (ct[1][0], ct[1][1], 224, ct[1][3], c[SC]),
+              (T.TABLE_LOGIC, logic, 69, log_logic, c[LO]), (T.TABLE_MEMORY, memory, 13, log_mem, c[ME]), (T.TABLE_ARITHMETIC, arith, 54, 16, c[AR])]
+    arith_set = T.arithmetic_ctl_rows(c[AR])
+    logic_lookers = [(KS, T.keccak_sponge_looking_logic(c[KS], i)) for i in range(T.NUM_LOGIC_CTLS)] + T.logic_lookers_sha_extend(SE, c[SE]) + \
+        T.logic_lookers_sha_compress(SC, c[SC])
+    memory_lookers = T.memory_lookers_keccak_sponge(KS, c[KS]) + T.memory_lookers_poseidon_sponge(PS, c[PS]) + \
+        T.memory_lookers_sha_extend_sponge(SES, c[SES]) + T.memory_lookers_sha_compress_sponge(SCS, c[SCS]) + T.memory_lookers_sha_compress(SC, c[SC])
+    ctls = [T.ctl_poseidon_inputs(PS, PO, c[PS], c[PO]), T.ctl_poseidon_outputs(PS, PO, c[PS], c[PO]),
+            T.ctl_keccak_inputs(KS, KK, c[KS], c[KK]), T.ctl_keccak_outputs(KS, KK, c[KS], c[KK]),
+            T.ctl_sha_extend_inputs(SES, SE, c[SES], c[SE]), T.ctl_sha_extend_outputs(SES, SE, c[SES], c[SE]),
+            T.ctl_sha_compress_inputs(SCS, SC, c[SCS], c[SC]), T.ctl_sha_compress_outputs(SCS, SC, c[SCS], c[SC]),
+            (logic_lookers, (LO, T.logic_ctl_data(c[LO]))), (memory_lookers, (ME, T.memory_ctl_data(c[ME]))),
+            ([(AR, arith_set)], (AR, T.arithmetic_ctl_rows(c[AR])))]     # stand-in for ctl_arithmetic: the table looks itself up
+    assert oracle.check_ctls(tables, ctls) == 0
+    want, wchal, woffs = oracle.prove_with_traces(tables, ctls, public_values=[1, 2, 3])
+    got, chal, offs = ctx.prove_with_traces(tables, ctls, public_values=[1, 2, 3])
+    assert offs == woffs and (chal == wchal).all()
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing word %d" % bad[0]
+    assert oracle.verify_all(tables, ctls, got, chal, public_values=[1, 2, 3]) == 0
+
+
+@pytest.mark.parametrize("table_id,log_n", [(T.TABLE_KECCAK, 15), (T.TABLE_SHA_COMPRESS, 17), (T.TABLE_SHA_EXTEND, 18), (T.TABLE_POSEIDON_SPONGE, 18)])
+def test_large_tables_gpu_proof_verifies(ctx, oracle, table_id, log_n):
+    """Sizes the oracle would take minutes to prove: witness and proof on the GPU, the oracle only verifies (openings, constraint
+    identity at zeta, FRI)."""
+    rng = np.random.default_rng(log_n)
+    n = 1 << log_n
+    if table_id == T.TABLE_KECCAK:
+        k = n // 24
+        trace = ctx.keccak_trace(rng.integers(0, 1 << 64, (k, 25), dtype=np.uint64), rng.integers(0, 1 << 30, k), log_n)
+    elif table_id == T.TABLE_SHA_COMPRESS:
+        k = n // 65
+        meta = np.zeros((k, 8), dtype=np.uint64)
+        meta[:, 2], meta[:, 3], meta[:, 4] = np.arange(k) * 4096, np.arange(k) + 5, np.arange(k) * 4096 + 1024
+        trace = ctx.sha_compress_trace(rng.integers(0, 1 << 32, (k, 8), dtype=np.uint64), rng.integers(0, 1 << 32, (k, 64), dtype=np.uint64), meta, log_n)
+    elif table_id == T.TABLE_SHA_EXTEND:
+        trace = ctx.sha_extend_trace(rng.integers(0, 256, (n - 9, 16), dtype=np.uint8), np.arange(n - 9) + 1, log_n)
+    else:
+        data, off, meta, rows, nops = logic_fixtures.poseidon_sponge_ops(3, n - 5)
+        trace, used = ctx.poseidon_sponge_trace(data, off, meta, log_n)
+        assert used == rows
+    W = T.WIDTH[table_id]
+    aux = fake_ctl_aux(log_n) if log_n <= 16 else None
+    if aux is None:   # the Python stand-in is too slow beyond 2^16 rows: zeros are a valid helper / Z pair too
+        aux = np.zeros(3 << log_n, dtype=np.uint64)
+    proof = ctx.prove_single_table(trace, log_n, aux, [2], ncols=W, table_id=table_id)
+    assert oracle.verify(proof, 3, [2], ncols=W, table_id=table_id) == 0
+    proof[len(proof) // 2] ^= 1
+    assert oracle.verify(proof, 3, [2], ncols=W, table_id=table_id) != 0
