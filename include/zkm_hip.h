@@ -33,6 +33,9 @@ void zkm_ctx_destroy(zkm_ctx* ctx);
 int zkm_ctx_synchronize(zkm_ctx* ctx, char** err);
 /* the hipStream_t every kernel of this context is launched on (for event timing by the host) */
 void* zkm_ctx_stream(zkm_ctx* ctx);
+/* Device memory held by the context's caching allocator: bytes in live allocations (DeviceBuffers, batches, scratch of a call in
+ * flight) and bytes cached for reuse (freed on zkm_ctx_destroy, or when an allocation would otherwise fail). */
+void zkm_ctx_memory(const zkm_ctx* ctx, size_t* live_bytes, size_t* cached_bytes);
 int zkm_dev_alloc(zkm_ctx* ctx, size_t bytes, void** out, char** err);
 int zkm_dev_free(zkm_ctx* ctx, void* p);
 int zkm_dev_upload(zkm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, char** err);

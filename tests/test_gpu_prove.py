@@ -175,3 +175,30 @@ def test_full_fri_on_2_22_rows_verifies(ctx, zkm, oracle):
         b.free()
     for b in (tvals, avals, qco):
         b.free()
+
+
+def test_no_device_memory_is_leaked(zkm, oracle):
+    """Live allocator bytes return to the baseline after proofs, multi-table proofs and failing calls (every error path releases
+    its scratch); only the reuse cache grows."""
+    from zkm_amd import tables as T
+    from . import logic_fixtures
+    c = zkm.Context(0)
+    trace = oracle.poseidon_trace(3, 100, 7)
+    aux = np.zeros(4 << 7, dtype=np.uint64)
+    c.prove_single_table(trace, 7, aux, [1, 1])          # warm up: twiddles / power tables stay resident by design
+    base, _ = c.memory()
+    for _ in range(3):
+        c.prove_single_table(trace, 7, aux, [1, 1])
+    with pytest.raises(zkm.ZkmError):
+        c.prove_single_table(trace, 7, aux, [1, 1], table_id=99)
+    with pytest.raises(zkm.ZkmError):
+        c.prove_single_table(trace, 7, np.zeros(3 << 7, dtype=np.uint64), [1, 1])        # aux does not match the CTL description
+    t4, c4, _ = logic_fixtures.build4(oracle, log_sponge=3)
+    c.prove_with_traces(t4, c4)
+    base2, _ = c.memory()
+    c.prove_with_traces(t4, c4)
+    live, cached = c.memory()
+    assert live == base2, (base, base2, live)
+    # the only growth between the first baseline and now is resident tables (twiddles / powers for the new sizes)
+    assert base2 - base < 64 << 20
+    c.close()

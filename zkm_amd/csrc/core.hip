@@ -130,6 +130,14 @@ int zkm_ctx_synchronize(zkm_ctx* c, char** err) {
 }
 void* zkm_ctx_stream(zkm_ctx* c) { return (void*)c->stream; }
 
+void zkm_ctx_memory(const zkm_ctx* c, size_t* live_bytes, size_t* cached_bytes) {
+    size_t live = 0, cached = 0;
+    for (auto& kv : c->live_blocks) live += kv.second;
+    for (auto& kv : c->free_blocks) cached += kv.first;
+    if (live_bytes) *live_bytes = live;
+    if (cached_bytes) *cached_bytes = cached;
+}
+
 int zkm_dev_alloc(zkm_ctx* c, size_t bytes, void** out, char** err) {
     ZKM_API_BEGIN
     ZKM_HIP_CHECK(hipSetDevice(c->device));
