@@ -227,6 +227,36 @@ size_t zkm_num_lookup_columns(int table_id, const zkm_stark_config* cfg);
 #define ZKM_PROOF_MAGIC 0x5a4b4d50524f4f46ULL
 size_t zkm_proof_words(const zkm_stark_config* cfg, unsigned log_n, size_t ncols, size_t naux, size_t nctl_zs);
 
+/* N4, proof hand-off: word offsets of every field of a proof blob, read from the blob's own header, so the caller can rebuild
+ * StarkProofWithMetadata (proof.rs:178-201), StarkOpeningSet (:281-297) and plonky2's FriProof with plain slice copies.  F2 values
+ * are pairs of consecutive words (c0, c1); digests are 4 words.  Returns 0, or nonzero if the header is not a proof header. */
+typedef struct {
+    uint64_t degree_bits, trace_cols, aux_cols, quotient_polys, ctl_zs, cap_height, fri_layers, final_poly_len, num_queries, rate_bits,
+        arity_bits;
+    size_t total_words;
+    size_t init_challenger_state;                 /* 12 words */
+    size_t trace_cap, aux_cap, quotient_cap;      /* 2^cap_height digests each */
+    size_t local_values, next_values;             /* trace_cols F2 values each */
+    size_t aux_polys, aux_polys_next;             /* aux_cols F2 values each */
+    size_t ctl_zs_first;                          /* ctl_zs base-field words */
+    size_t quotient_polys_open;                   /* quotient_polys F2 values */
+    size_t commit_phase_merkle_caps;              /* fri_layers x 2^cap_height digests */
+    size_t final_poly;                            /* final_poly_len F2 coefficients */
+    size_t pow_witness;                           /* 1 word */
+    size_t query_round_proofs, query_round_words; /* num_queries rounds of query_round_words words, see zkm_proof_query_layout */
+} zkm_proof_layout;
+int zkm_proof_get_layout(const uint64_t* proof, zkm_proof_layout* out);
+/* Offsets inside ONE query round (relative to query_round_proofs + q * query_round_words):
+ *   oracle o in {0 trace, 1 aux, 2 quotient}: evals at oracle_evals[o] (oracle_cols[o] base-field words), Merkle siblings at
+ *   oracle_siblings[o] (initial_siblings digests) -- FriInitialTreeProof;
+ *   layer i < fri_layers: 2^arity_bits F2 evals at layer_evals[i], layer_siblings_count[i] digests at layer_siblings[i] -- FriQueryStep.
+ * Arrays are sized for at most 16 layers.  recover_degree_bits (proof.rs:205-212) reads initial_siblings + cap_height - rate_bits. */
+typedef struct {
+    size_t oracle_evals[3], oracle_cols[3], oracle_siblings[3], initial_siblings;
+    size_t layer_evals[16], layer_siblings[16], layer_siblings_count[16];
+} zkm_proof_query_layout;
+int zkm_proof_get_query_layout(const uint64_t* proof, zkm_proof_query_layout* out);
+
 /* prove_single_table (prover.rs:441-641) for table `table_id`.
  *   trace       ncols x 2^log_n trace values (host or device) -- used only if trace_batch is NULL
  *   trace_batch optional existing commitment of the trace (prover.rs:445); NULL = commit here
@@ -322,6 +352,29 @@ int zkm_prove_openings(zkm_ctx* ctx, const zkm_stark_config* cfg, const zkm_batc
 /* ------------------------------------------------------------------ stage entry points (parity / reuse)
  * a6: compute_quotient_polys (prover.rs:645-789): nalphas polys of 2n coefficients, natural order;
  * out host or device. */
+/* ------------------------------------------------------------------ N3: trace ingest
+ * A segment's traces as one file / memory image, the hand-off from the CPU-side witness generator (generate_traces,
+ * witness/traces.rs:230-320 returns [Vec<PolynomialValues<F>>; 12]; each table is written column-major as util.rs:37-46 lays it
+ * out).  All integers little-endian uint64 unless noted:
+ *   [0] magic "ZKMTRACE"  [1] version 1  [2] ntables  [3] npublic  [4] nctls  [5] nsides  [6..7] 0
+ *   public values[npublic]
+ *   per table (8 words): table_id, ncols, log_n, data offset (words from file start), ncolumns, nterms, ncolsets, nfilter_idx
+ *   per table, its column-set description: columns[ncolumns] (zkm_column, 3 words each), term_col[nterms] (uint32, padded to 8 B),
+ *       term_coeff[nterms], colsets[ncolsets] (zkm_colset, 4 words each), filter_idx[nfilter_idx] (uint32, padded to 8 B)
+ *   cross-table lookups[nctls] (zkm_cross_table_lookup, 2 words each), sides[nsides] (zkm_ctl_side, 1 word each)
+ *   trace data: per table ncols x 2^log_n canonical field elements
+ * zkm_segment_image_words sizes an image; zkm_segment_image_write fills one from the in-memory description (traces must be host
+ * pointers); zkm_prove_segment_image proves straight from an image (e.g. an mmap of the file): the traces are uploaded table by
+ * table, never copied on the host. */
+size_t zkm_segment_image_words(const zkm_table_input* tables, size_t ntables, const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides,
+                               size_t nctls, size_t npublic);
+int zkm_segment_image_write(const zkm_table_input* tables, size_t ntables, const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides,
+                            size_t nctls, const uint64_t* public_values, size_t npublic, uint64_t* image_out, char** err);
+/* proofs_out / ctl_challenges_out as zkm_prove_with_traces; *proof_words_out receives the total; pass proofs_out = NULL to query
+ * the size first (returns 0 and only fills *proof_words_out and proof_offsets_out[ntables + 1] if non-NULL). */
+int zkm_prove_segment_image(zkm_ctx* ctx, const zkm_stark_config* cfg, const uint64_t* image, size_t image_words, uint64_t* proofs_out,
+                            size_t* proof_words_out, size_t* proof_offsets_out, uint64_t* ctl_challenges_out, char** err);
+
 int zkm_quotient(zkm_ctx* ctx, int table_id, const zkm_batch* trace, const zkm_batch* aux, const uint32_t* num_helpers,
                  size_t nctl_zs, const uint64_t* alphas, size_t nalphas, uint64_t* out_coeffs, char** err);
 /* a9: StarkOpeningSet::new building block (proof.rs:299-334): p(zeta) in F2 for every polynomial of the

@@ -1,0 +1,106 @@
+"""Data formats either side of the proving path: field offsets of a proof blob and the ZKMTRACE segment image.
+CPU tests use proofs made by the oracle; the GPU test proves from an image and compares with the in-memory path and the oracle."""
+import numpy as np
+import pytest
+
+from tests.ctl_fixtures import build
+
+
+def fake_aux(oracle, log_n, helpers=2):
+    rng = np.random.default_rng(5)
+    return rng.integers(0, 2**63, (helpers + 1) << log_n, dtype=np.uint64) % np.uint64(0xFFFFFFFF00000001)
+
+
+def test_proof_layout_describes_an_oracle_proof(zkm, oracle):
+    log_n = 5
+    trace = oracle.poseidon_trace(3, 20, log_n)
+    aux = fake_aux(oracle, log_n)
+    proof, stages = oracle.prove(trace, log_n, aux, [2], want_stages=True)
+    lay, q = zkm.proof_layout(proof)
+    cfg = oracle.standard_config()
+    assert lay.total_words == proof.size
+    assert (lay.degree_bits, lay.trace_cols, lay.aux_cols, lay.ctl_zs) == (log_n, 262, 3, 1)
+    assert lay.quotient_polys == 2 * cfg.num_challenges and lay.cap_height == cfg.cap_height and lay.num_queries == cfg.num_queries
+    # recover_degree_bits (proof.rs:205-212)
+    assert q.initial_siblings + lay.cap_height - lay.rate_bits == log_n
+    # the caps at the reported offsets are the caps of the three committed batches
+    tb = oracle.batch_from_values(trace, 262, log_n)
+    cap = np.asarray(tb.cap()).reshape(-1)
+    assert (proof[lay.trace_cap:lay.trace_cap + cap.size] == cap).all()
+    ab = oracle.batch_from_values(aux, 3, log_n)
+    cap = np.asarray(ab.cap()).reshape(-1)
+    assert (proof[lay.aux_cap:lay.aux_cap + cap.size] == cap).all()
+    # first query round: the trace leaf and its Merkle path authenticate against the trace cap
+    base = lay.query_round_proofs
+    leaf = proof[base + q.oracle_evals[0]: base + q.oracle_evals[0] + 262]
+    sib = proof[base + q.oracle_siblings[0]: base + q.oracle_siblings[0] + 4 * q.initial_siblings].reshape(-1, 4)
+    found = False
+    lde = 1 << (log_n + int(lay.rate_bits))
+    for i in range(lde):
+        if (np.asarray(tb.leaf(i)) == leaf).all():
+            assert (np.asarray(tb.merkle_path(i)).reshape(-1, 4) == sib).all()
+            found = True
+            break
+    assert found
+    # the fields tile the blob without gaps, in order
+    order = [16, lay.init_challenger_state, lay.trace_cap, lay.aux_cap, lay.quotient_cap, lay.local_values, lay.next_values, lay.aux_polys,
+             lay.aux_polys_next, lay.ctl_zs_first, lay.quotient_polys_open, lay.commit_phase_merkle_caps, lay.final_poly, lay.pow_witness,
+             lay.query_round_proofs]
+    assert order == sorted(order) and order[0] == order[1]
+    assert lay.query_round_proofs + lay.num_queries * lay.query_round_words == proof.size
+    assert lay.pow_witness + 1 == lay.query_round_proofs
+    with pytest.raises(zkm.ZkmError):
+        zkm.proof_layout(np.zeros(64, dtype=np.uint64))
+
+
+def parse_image(img):
+    assert img[0] == int.from_bytes(b"ZKMTRACE", "little") and img[1] == 1
+    nt, npub = int(img[2]), int(img[3])
+    pub = img[8:8 + npub]
+    recs = img[8 + npub: 8 + npub + 8 * nt].reshape(nt, 8)
+    return pub, recs
+
+
+def test_segment_image_round_trip_and_sizing(zkm, oracle):
+    tables, ctls = build(oracle)
+    pub = [9, 8, 7]
+    img = zkm.segment_image(tables, ctls, public_values=pub)
+    got_pub, recs = parse_image(img)
+    assert list(got_pub) == pub
+    for (tid, tr, ncols, log_n, ct), r in zip(tables, recs):
+        assert (int(r[0]), int(r[1]), int(r[2])) == (tid, ncols, log_n)
+        off = int(r[3])
+        assert (img[off: off + (ncols << log_n)] == np.asarray(tr).reshape(-1)).all()
+    # sizing from the image alone (no GPU) agrees with the in-memory sizing
+    import ctypes as C
+    lib = zkm.load()
+    cfg = zkm.StarkConfig()
+    lib.zkm_standard_config(C.byref(cfg))
+    offs = (C.c_size_t * (len(tables) + 1))()
+    total = C.c_size_t()
+    err = C.c_char_p()
+    u64p = C.POINTER(C.c_uint64)
+    assert lib.zkm_prove_segment_image(None, C.byref(cfg), img.ctypes.data_as(u64p), img.size, None, C.byref(total), offs, None, C.byref(err)) == 0
+    wtotal, woffs = oracle.all_proof_words(tables, ctls)
+    assert total.value == wtotal and list(offs) == list(woffs)
+    # truncated or foreign images are rejected with a message
+    for bad, n in ((img, img.size - 1), (img, 12), (np.zeros(32, dtype=np.uint64), 32)):
+        err = C.c_char_p()
+        assert lib.zkm_prove_segment_image(None, C.byref(cfg), bad.ctypes.data_as(u64p), n, None, C.byref(total), offs, None, C.byref(err)) != 0
+        assert b"zkm_prove_segment_image" in err.value
+
+
+@pytest.mark.gpu
+def test_prove_from_image_equals_in_memory_path(ctx, zkm, oracle):
+    tables, ctls = build(oracle)
+    pub = [9, 8, 7]
+    img = zkm.segment_image(tables, ctls, public_values=pub)
+    got, chal, offs = ctx.prove_segment_image(img)
+    want, wchal, woffs = ctx.prove_with_traces(tables, ctls, public_values=pub)
+    assert offs == woffs and (chal == wchal).all() and (got == want).all()
+    ref, rchal, _ = oracle.prove_with_traces(tables, ctls, public_values=pub)
+    assert (got == ref).all()
+    assert oracle.verify_all(tables, ctls, got, chal, public_values=pub) == 0
+    for k in range(len(tables)):
+        lay, _ = zkm.proof_layout(got[offs[k]:offs[k + 1]])
+        assert lay.total_words == offs[k + 1] - offs[k] and lay.degree_bits == tables[k][3]

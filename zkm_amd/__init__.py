@@ -36,6 +36,7 @@ EXPORTS = [
     "zkm_table_width", "zkm_num_lookup_columns", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
     "zkm_prove_single_table", "zkm_prove_openings", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
+    "zkm_proof_get_layout", "zkm_proof_get_query_layout", "zkm_segment_image_words", "zkm_segment_image_write", "zkm_prove_segment_image",
     "zkm_quotient", "zkm_eval_openings", "zkm_profile_enable", "zkm_profile_reset",
     "zkm_profile_count", "zkm_profile_get", "zkm_version",
 ]
@@ -58,6 +59,23 @@ class Challenger(C.Structure):
     """plonky2 Challenger<F, PoseidonHash> state (host side)."""
     _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("out_buf", C.c_uint64 * 8),
                 ("n_in", C.c_uint32), ("n_out", C.c_uint32)]
+
+
+class ProofLayout(C.Structure):
+    """zkm_proof_layout (include/zkm_hip.h): word offsets of the fields of one proof blob."""
+    _fields_ = [(n, C.c_uint64) for n in ("degree_bits", "trace_cols", "aux_cols", "quotient_polys", "ctl_zs", "cap_height", "fri_layers",
+                                          "final_poly_len", "num_queries", "rate_bits", "arity_bits")] + \
+               [(n, C.c_size_t) for n in ("total_words", "init_challenger_state", "trace_cap", "aux_cap", "quotient_cap", "local_values",
+                                          "next_values", "aux_polys", "aux_polys_next", "ctl_zs_first", "quotient_polys_open",
+                                          "commit_phase_merkle_caps", "final_poly", "pow_witness", "query_round_proofs",
+                                          "query_round_words")]
+
+
+class ProofQueryLayout(C.Structure):
+    """zkm_proof_query_layout: offsets inside one FRI query round."""
+    _fields_ = [("oracle_evals", C.c_size_t * 3), ("oracle_cols", C.c_size_t * 3), ("oracle_siblings", C.c_size_t * 3),
+                ("initial_siblings", C.c_size_t), ("layer_evals", C.c_size_t * 16), ("layer_siblings", C.c_size_t * 16),
+                ("layer_siblings_count", C.c_size_t * 16)]
 
 
 class StarkConfig(C.Structure):
@@ -129,6 +147,12 @@ def load():
         "zkm_all_proof_words": (C.c_size_t, [C.POINTER(StarkConfig), cp, C.c_size_t, cp, cp, C.c_size_t, C.POINTER(C.c_size_t)]),
         "zkm_prove_with_traces": (C.c_int, [cp, C.POINTER(StarkConfig), cp, C.c_size_t, cp, cp, C.c_size_t, u64p, C.c_size_t, u64p,
                                             u64p, err]),
+        "zkm_proof_get_layout": (C.c_int, [u64p, C.POINTER(ProofLayout)]),
+        "zkm_proof_get_query_layout": (C.c_int, [u64p, C.POINTER(ProofQueryLayout)]),
+        "zkm_segment_image_words": (C.c_size_t, [cp, C.c_size_t, cp, cp, C.c_size_t, C.c_size_t]),
+        "zkm_segment_image_write": (C.c_int, [cp, C.c_size_t, cp, cp, C.c_size_t, u64p, C.c_size_t, u64p, err]),
+        "zkm_prove_segment_image": (C.c_int, [cp, C.POINTER(StarkConfig), u64p, C.c_size_t, u64p, C.POINTER(C.c_size_t),
+                                              C.POINTER(C.c_size_t), u64p, err]),
         "zkm_quotient": (C.c_int, [cp, C.c_int, cp, cp, C.POINTER(C.c_uint32), C.c_size_t, u64p, C.c_size_t, cp, err]),
         "zkm_eval_openings": (C.c_int, [cp, cp, u64p, u64p, err]),
         "zkm_profile_enable": (None, [cp, C.c_int]),
@@ -467,6 +491,22 @@ class Context:
                                             C.byref(err)), err)
         return proofs, chal, list(offs)
 
+    def prove_segment_image(self, image, cfg=None):
+        """Prove every table of a ZKMTRACE segment image (see segment_image()).  Returns (proofs, ctl_challenges, offsets)."""
+        cfg = cfg or self.standard_config()
+        image = np.ascontiguousarray(image, dtype=np.uint64)
+        ntables = int(image[2]) if image.size > 2 else 0
+        offs = (C.c_size_t * (ntables + 1))()
+        total = C.c_size_t()
+        err = C.c_char_p()
+        _check(self.L.zkm_prove_segment_image(self.h, C.byref(cfg), image.ctypes.data_as(u64p), image.size, None, C.byref(total), offs,
+                                              None, C.byref(err)), err)
+        proofs = np.zeros(total.value, dtype=np.uint64)
+        chal = np.zeros(2 * cfg.num_challenges, dtype=np.uint64)
+        _check(self.L.zkm_prove_segment_image(self.h, C.byref(cfg), image.ctypes.data_as(u64p), image.size, proofs.ctypes.data_as(u64p),
+                                              C.byref(total), offs, chal.ctypes.data_as(u64p), C.byref(err)), err)
+        return proofs, chal, list(offs)
+
     def prove_openings(self, trace_batch, aux_batch, quot_batch, nctl_zs, challenger=None, cfg=None):
         """PolynomialBatch::prove_openings for the STARK FRI instance on three existing commitments (BASELINE config 4)."""
         cfg = cfg or self.standard_config()
@@ -576,3 +616,32 @@ def challenger_observe(ch, elems):
 
 def challenger_get(ch):
     return load().zkm_challenger_get(C.byref(ch))
+
+
+def proof_layout(proof):
+    """Field offsets of a proof blob (zkm_proof_get_layout / zkm_proof_get_query_layout).  No GPU needed."""
+    L = load()
+    proof = np.ascontiguousarray(proof, dtype=np.uint64)
+    lay, q = ProofLayout(), ProofQueryLayout()
+    if L.zkm_proof_get_layout(proof.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(lay)) or \
+            L.zkm_proof_get_query_layout(proof.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(q)):
+        raise ZkmError("not a proof blob")
+    return lay, q
+
+
+def segment_image(tables, ctls, public_values=()):
+    """Serialise a segment (host traces + cross-table lookups, same arguments as Context.prove_with_traces) into one ZKMTRACE image
+    (zkm_segment_image_write).  No GPU needed."""
+    from . import ctl as zc
+    L = load()
+    packed = [(tid, _data_ptr(tr).value, ncols, log_n, ct) for (tid, tr, ncols, log_n, ct) in tables]
+    tarr, keep = zc.pack_tables(packed)
+    carr, sides = zc.pack_ctls(ctls)
+    pub = np.ascontiguousarray(public_values, dtype=np.uint64)
+    words = L.zkm_segment_image_words(tarr, len(tables), carr.ctypes.data, sides.ctypes.data, len(carr), pub.size)
+    img = np.zeros(words, dtype=np.uint64)
+    err = C.c_char_p()
+    u64p = C.POINTER(C.c_uint64)
+    _check(L.zkm_segment_image_write(tarr, len(tables), carr.ctypes.data, sides.ctypes.data, len(carr), pub.ctypes.data_as(u64p), pub.size,
+                                     img.ctypes.data_as(u64p), C.byref(err)), err)
+    return img
