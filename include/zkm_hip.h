@@ -204,7 +204,9 @@ void zkm_standard_config(zkm_stark_config* cfg);
 #define ZKM_TABLE_SHA_COMPRESS 8
 #define ZKM_TABLE_SHA_COMPRESS_SPONGE 9
 #define ZKM_TABLE_ARITHMETIC 10
+#define ZKM_TABLE_CPU 11
 #define ZKM_ARITHMETIC_COLS 54
+#define ZKM_CPU_COLS 259
 #define ZKM_MEMORY_COLS 13
 size_t zkm_table_width(int table_id); /* 0 for an unknown id */
 /* Auxiliary columns the table's own logUp lookups (Stark::lookups(), lookup.rs:22-40) put in front of the CTL columns:

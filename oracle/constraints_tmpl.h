@@ -21,9 +21,15 @@ typedef struct {
     gl_t alphas[4];
     T acc[4];
     T z_last, l_first, l_last;
+    T* rec; /* debugging aid: when set, every emitted constraint value is also stored here (zko_debug_constraints) */
+    size_t nrec, rec_cap;
 } TNAME(consumer);
 
 static inline void TNAME(cons)(TNAME(consumer) * k, T c) {
+    if (k->rec) {
+        if (k->nrec < k->rec_cap) k->rec[k->nrec] = c;
+        k->nrec++;
+    }
     for (size_t j = 0; j < k->nalphas; j++) k->acc[j] = T_ADD(T_MULB(k->acc[j], k->alphas[j]), c);
 }
 static inline void TNAME(cons_transition)(TNAME(consumer) * k, T c) { TNAME(cons)(k, T_MUL(c, k->z_last)); }
@@ -658,7 +664,487 @@ static void TNAME(eval_lookups)(int table_id, const gl_t* challenges, size_t nch
 }
 
 /* table dispatch (Table ids of include/zkm_hip.h) */
-static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : table_id == 4 ? 13 : table_id == 5 ? 110 : table_id == 6 ? 78 : table_id == 7 ? 76 : table_id == 8 ? 224 : table_id == 9 ? 127 : table_id == 10 ? 54 : 0; }
+/* ---- CpuStark constraints: cpu/cpu_stark.rs:260-285, in emission order: bootstrap_kernel.rs:308-353, decode.rs:66-100,
+ * jumps.rs (jump/jumpi/jumpdirect, branch), membus.rs:35-48, memio.rs (load :175-437, store :738-961), shift.rs:18-124,
+ * count.rs:10-75, syscall.rs:12-232, bits.rs:9-64, misc.rs (rdhwr, condmov, teq, ext, ror, ins, maddu).
+ * Column map (cpu/columns/mod.rs:62-96, ops.rs:10-45, general.rs): 0 is_bootstrap_kernel, 1 is_exit_kernel, 2 context,
+ * 3 code_context, 4 program_counter, 5 next_program_counter, 6 is_kernel_mode, 7..39 op flags, 40..49 branch view,
+ * 50 opcode_bits[6], 56 rs_bits[5], 61 rt_bits[5], 66 rd_bits[5], 71 shamt_bits[5], 76 func_bits[6], 82..85 sponge flags,
+ * 86..187 general (union), 188..203 memio, 204 clock, 205 + 6 i memory channel i (used, is_read, context, segment, virtual,
+ * value), 9 channels. ---- */
+#ifndef ZKO_CPU_ENUMS
+#define ZKO_CPU_ENUMS
+enum { CPU_OP = 7, CPU_BR = 40, CPU_OPC = 50, CPU_RS = 56, CPU_RT = 61, CPU_RD = 66, CPU_SHAMT = 71, CPU_FUNC = 76, CPU_GEN = 86,
+       CPU_MEMIO = 188, CPU_CLOCK = 204, CPU_CH0 = 205 };
+enum { OPF_BINARY = 7, OPF_BINARY_IMM, OPF_EQ_ISZERO, OPF_LOGIC, OPF_LOGIC_IMM, OPF_MOVZ, OPF_MOVN, OPF_CLZ, OPF_CLO, OPF_SHIFT,
+       OPF_SHIFT_IMM, OPF_KECCAK_GENERAL, OPF_JUMPS, OPF_JUMPI, OPF_JUMPDIRECT, OPF_BRANCH, OPF_PC, OPF_GET_CONTEXT, OPF_SET_CONTEXT,
+       OPF_EXIT_KERNEL, OPF_M_OP_LOAD, OPF_M_OP_STORE, OPF_NOP, OPF_EXT, OPF_INS, OPF_MADDU, OPF_RDHWR, OPF_SIGNEXT8, OPF_SIGNEXT16,
+       OPF_SWAPHALF, OPF_TEQ, OPF_ROR, OPF_SYSCALL };
+#endif
+#define CPU_USED(i) lv[CPU_CH0 + 6 * (i)]
+#define CPU_ISREAD(i) lv[CPU_CH0 + 6 * (i) + 1]
+#define CPU_CTX(i) lv[CPU_CH0 + 6 * (i) + 2]
+#define CPU_SEG(i) lv[CPU_CH0 + 6 * (i) + 3]
+#define CPU_VIRT(i) lv[CPU_CH0 + 6 * (i) + 4]
+#define CPU_VAL(i) lv[CPU_CH0 + 6 * (i) + 5]
+
+/* util.rs:15-21 limb_from_bits_le */
+static T TNAME(le_sum)(const T* bits, int n) {
+    T acc = T_FROMB(0);
+    for (int i = 0; i < n; i++) acc = T_ADD(acc, T_MULB(bits[i], (gl_t)1 << i));
+    return acc;
+}
+static void TNAME(cpy)(T* dst, const T* src, int n) {
+    for (int i = 0; i < n; i++) dst[i] = src[i];
+}
+static void TNAME(zero32)(T* a) {
+    for (int i = 0; i < 32; i++) a[i] = T_FROMB(0);
+}
+/* memio.rs:40-48 */
+static void TNAME(sext)(T* a, int n) {
+    for (int i = n; i < 32; i++) a[i] = a[n - 1];
+}
+/* offset field insn[15:0] as 32 little-endian bits, sign-extended when `se` (memio.rs:17-25; jumps.rs:77-83, 296-302 use it
+ * shifted left by two) */
+static void TNAME(cpu_imm_bits)(const T* lv, T* out, int shift) {
+    TNAME(zero32)(out);
+    TNAME(cpy)(out + shift, lv + CPU_FUNC, 6);
+    TNAME(cpy)(out + shift + 6, lv + CPU_SHAMT, 5);
+    TNAME(cpy)(out + shift + 11, lv + CPU_RD, 5);
+    for (int i = shift + 16; i < 32; i++) out[i] = lv[CPU_RD + 4];
+}
+/* memio.rs:65-77 */
+static void TNAME(half_word)(TNAME(consumer) * k, T op, const T* rs, T mem, T v1, T v0) {
+    T a = T_MUL(T_SUB(rs[1], T_FROMB(1)), T_SUB(mem, v0));
+    T b = T_MUL(rs[1], T_SUB(mem, v1));
+    TNAME(cons)(k, T_MUL(op, T_ADD(a, b)));
+}
+/* memio.rs:106-129; v00 .. v11 indexed by (rs[0], rs[1]) as in the reference's mem_val_{rs0}_{rs1} */
+static void TNAME(byte_sel)(TNAME(consumer) * k, const T* lv, T op, const T* rs, T mem, T v00, T v10, T v01, T v11) {
+    T prod = T_MUL(rs[0], rs[1]), aux = lv[CPU_GEN + 96];
+    TNAME(cons)(k, T_MUL(op, T_SUB(prod, aux)));
+    T one = T_FROMB(1);
+    T sum = T_MUL(T_SUB(mem, v00), T_ADD(T_SUB(T_SUB(aux, rs[1]), rs[0]), one));
+    sum = T_ADD(sum, T_MUL(T_SUB(mem, v10), T_SUB(aux, rs[0])));
+    sum = T_ADD(sum, T_MUL(T_SUB(mem, v01), T_SUB(aux, rs[1])));
+    sum = T_ADD(sum, T_MUL(T_SUB(mem, v11), aux));
+    TNAME(cons)(k, T_MUL(sum, op));
+}
+
+static void TNAME(cpu_memio)(const T* lv, TNAME(consumer) * k, int store) {
+    const T one = T_FROMB(1);
+    T filter = T_MUL(lv[store ? OPF_M_OP_STORE : OPF_M_OP_LOAD], lv[CPU_OPC + 5]);
+    T aux_filter = lv[CPU_MEMIO + 15];
+    TNAME(cons)(k, T_MUL(filter, T_SUB(one, aux_filter)));
+    TNAME(cons)(k, T_MUL(filter, T_SUB(CPU_SEG(0), T_FROMB(4))));
+    TNAME(cons)(k, T_MUL(filter, T_SUB(CPU_SEG(1), T_FROMB(4))));
+    T rs = CPU_VAL(0), rt = CPU_VAL(1), mem = CPU_VAL(3);
+    const T *rsl = lv + CPU_GEN, *rtl = lv + CPU_GEN + 32, *ml = lv + CPU_GEN + 64;
+    T off[32];
+    TNAME(cpu_imm_bits)(lv, off, 0);
+    T virt_raw = T_ADD(rs, TNAME(le_sum)(off, 32));
+    T rs_from_bits = TNAME(le_sum)(rsl, 32);
+    TNAME(cons)(k, T_MUL(T_MUL(aux_filter, T_SUB(rs_from_bits, virt_raw)), T_SUB(T_ADD(rs_from_bits, T_FROMB(1ULL << 32)), virt_raw)));
+    TNAME(cons)(k, T_MUL(filter, T_SUB(TNAME(le_sum)(rtl, 32), rt)));
+    T tmp[32];
+    TNAME(cpy)(tmp, rsl, 32);
+    tmp[0] = tmp[1] = T_FROMB(0);
+    TNAME(cons)(k, T_MUL(filter, T_SUB(TNAME(le_sum)(tmp, 32), CPU_VIRT(2))));
+    T a[32], b[32], c[32], d[32];
+#define CPU_SUM4() TNAME(le_sum)(a, 32), TNAME(le_sum)(b, 32), TNAME(le_sum)(c, 32), TNAME(le_sum)(d, 32)
+#define CPU_Z4() TNAME(zero32)(a), TNAME(zero32)(b), TNAME(zero32)(c), TNAME(zero32)(d)
+    if (!store) {
+        /* LH */
+        TNAME(zero32)(a); TNAME(cpy)(a, ml, 16); TNAME(sext)(a, 16);          /* rs[1] == 1 */
+        TNAME(zero32)(b); TNAME(cpy)(b, ml + 16, 16); TNAME(sext)(b, 16);     /* rs[1] == 0 */
+        TNAME(half_word)(k, lv[CPU_MEMIO + 0], rsl, mem, TNAME(le_sum)(a, 32), TNAME(le_sum)(b, 32));
+        /* LWL: a = 0_0, b = 1_0, c = 0_1, d = 1_1 */
+        CPU_Z4();
+        TNAME(cpy)(a, ml, 32);
+        TNAME(cpy)(b, rtl, 8); TNAME(cpy)(b + 8, ml, 24);
+        TNAME(cpy)(c, rtl, 16); TNAME(cpy)(c + 16, ml, 16);
+        TNAME(cpy)(d, rtl, 24); TNAME(cpy)(d + 24, ml, 8);
+        TNAME(byte_sel)(k, lv, lv[CPU_MEMIO + 1], rsl, mem, CPU_SUM4());
+        /* LW */
+        TNAME(cons)(k, T_MUL(lv[CPU_MEMIO + 2], T_SUB(mem, TNAME(le_sum)(ml, 32))));
+        /* LBU */
+        CPU_Z4();
+        TNAME(cpy)(a, ml + 24, 8); TNAME(cpy)(b, ml + 16, 8); TNAME(cpy)(c, ml + 8, 8); TNAME(cpy)(d, ml, 8);
+        TNAME(byte_sel)(k, lv, lv[CPU_MEMIO + 3], rsl, mem, CPU_SUM4());
+        /* LHU */
+        TNAME(zero32)(a); TNAME(cpy)(a, ml, 16);
+        TNAME(zero32)(b); TNAME(cpy)(b, ml + 16, 16);
+        TNAME(half_word)(k, lv[CPU_MEMIO + 4], rsl, mem, TNAME(le_sum)(a, 32), TNAME(le_sum)(b, 32));
+        /* LWR */
+        CPU_Z4();
+        TNAME(cpy)(a + 8, rtl + 8, 24); TNAME(cpy)(a, ml + 24, 8);
+        TNAME(cpy)(b + 16, rtl + 16, 16); TNAME(cpy)(b, ml + 16, 16);
+        TNAME(cpy)(c + 24, rtl + 24, 8); TNAME(cpy)(c, ml + 8, 24);
+        TNAME(cpy)(d, ml, 32);
+        TNAME(byte_sel)(k, lv, lv[CPU_MEMIO + 5], rsl, mem, CPU_SUM4());
+        /* LL */
+        TNAME(cons)(k, T_MUL(lv[CPU_MEMIO + 11], T_SUB(mem, TNAME(le_sum)(ml, 32))));
+        /* LB */
+        CPU_Z4();
+        TNAME(cpy)(a, ml + 24, 8); TNAME(cpy)(b, ml + 16, 8); TNAME(cpy)(c, ml + 8, 8); TNAME(cpy)(d, ml, 8);
+        TNAME(sext)(a, 8); TNAME(sext)(b, 8); TNAME(sext)(c, 8); TNAME(sext)(d, 8);
+        TNAME(byte_sel)(k, lv, lv[CPU_MEMIO + 14], rsl, mem, CPU_SUM4());
+    } else {
+        /* SB */
+        CPU_Z4();
+        TNAME(cpy)(a + 24, rtl, 8); TNAME(cpy)(a, ml, 24);
+        TNAME(cpy)(b + 24, ml + 24, 8); TNAME(cpy)(b + 16, rtl, 8); TNAME(cpy)(b, ml, 16);
+        TNAME(cpy)(c + 16, ml + 16, 16); TNAME(cpy)(c + 8, rtl, 8); TNAME(cpy)(c, ml, 8);
+        TNAME(cpy)(d, rtl, 8); TNAME(cpy)(d + 8, ml + 8, 24);
+        TNAME(byte_sel)(k, lv, lv[CPU_MEMIO + 6], rsl, mem, CPU_SUM4());
+        /* SH: a = rs[1] == 1, b = rs[1] == 0 */
+        TNAME(zero32)(a); TNAME(cpy)(a, rtl, 16); TNAME(cpy)(a + 16, ml + 16, 16);
+        TNAME(zero32)(b); TNAME(cpy)(b + 16, rtl, 16); TNAME(cpy)(b, ml, 16);
+        TNAME(half_word)(k, lv[CPU_MEMIO + 7], rsl, mem, TNAME(le_sum)(a, 32), TNAME(le_sum)(b, 32));
+        /* SWL */
+        CPU_Z4();
+        TNAME(cpy)(a, rtl, 32);
+        TNAME(cpy)(b, rtl + 8, 24); TNAME(cpy)(b + 24, ml + 24, 8);
+        TNAME(cpy)(c, rtl + 16, 16); TNAME(cpy)(c + 16, ml + 16, 16);
+        TNAME(cpy)(d, rtl + 24, 8); TNAME(cpy)(d + 8, ml + 8, 24);
+        TNAME(byte_sel)(k, lv, lv[CPU_MEMIO + 8], rsl, mem, CPU_SUM4());
+        /* SW */
+        TNAME(cons)(k, T_MUL(lv[CPU_MEMIO + 9], T_SUB(mem, TNAME(le_sum)(rtl, 32))));
+        /* SWR */
+        CPU_Z4();
+        TNAME(cpy)(a + 24, rtl, 8); TNAME(cpy)(a, ml, 24);
+        TNAME(cpy)(b + 16, rtl, 16); TNAME(cpy)(b, ml, 16);
+        TNAME(cpy)(c + 8, rtl, 24); TNAME(cpy)(c, ml, 8);
+        TNAME(cpy)(d, rtl, 32);
+        TNAME(byte_sel)(k, lv, lv[CPU_MEMIO + 10], rsl, mem, CPU_SUM4());
+        /* SC, SDC1 */
+        TNAME(cons)(k, T_MUL(lv[CPU_MEMIO + 12], T_SUB(mem, TNAME(le_sum)(rtl, 32))));
+        TNAME(cons)(k, T_MUL(lv[CPU_MEMIO + 13], mem));
+    }
+    for (int ch = 6; ch < 8; ch++) TNAME(cons)(k, T_MUL(filter, CPU_USED(ch)));
+#undef CPU_SUM4
+#undef CPU_Z4
+}
+
+static void TNAME(eval_cpu)(const T* lv, const T* nv, TNAME(consumer) * k) {
+    const T one = T_FROMB(1);
+    const gl_t P32 = 1ULL << 32;
+    /* -- bootstrap_kernel.rs:308-353 */
+    T boot = lv[0], dboot = T_SUB(nv[0], lv[0]);
+    TNAME(cons_first)(k, T_SUB(boot, one));
+    TNAME(cons_last)(k, boot);
+    TNAME(cons_transition)(k, T_MUL(dboot, T_ADD(dboot, one)));
+    for (int i = 0; i < 9; i++) {
+        T f = T_MUL(boot, CPU_USED(i));
+        TNAME(cons)(k, T_MUL(f, CPU_CTX(i)));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_SEG(i), T_FROMB(0))));
+    }
+    for (int i = 0; i < 9; i++) TNAME(cons_transition)(k, T_MUL(dboot, CPU_USED(i)));
+    /* -- decode.rs:66-100 */
+    TNAME(cons)(k, T_MUL(lv[6], T_SUB(lv[6], one)));
+    for (int i = 0; i < 6; i++) TNAME(cons)(k, T_MUL(lv[CPU_OPC + i], T_SUB(lv[CPU_OPC + i], one)));
+    static const int flags[15] = {OPF_EQ_ISZERO, OPF_KECCAK_GENERAL, OPF_JUMPS, OPF_BRANCH, OPF_PC, OPF_GET_CONTEXT, OPF_SET_CONTEXT,
+                                  OPF_EXIT_KERNEL, OPF_LOGIC, OPF_BINARY, OPF_BINARY_IMM, OPF_SHIFT, OPF_SHIFT_IMM, OPF_M_OP_LOAD,
+                                  OPF_M_OP_STORE};
+    T flag_sum = T_FROMB(0);
+    for (int i = 0; i < 15; i++) {
+        TNAME(cons)(k, T_MUL(lv[flags[i]], T_SUB(lv[flags[i]], one)));
+        flag_sum = T_ADD(flag_sum, lv[flags[i]]);
+    }
+    TNAME(cons)(k, T_MUL(flag_sum, T_SUB(flag_sum, one)));
+    /* -- jumps.rs eval_packed_jump_jumpi */
+    {
+        T is_jump = lv[OPF_JUMPS], is_jumpi = lv[OPF_JUMPI], is_jd = lv[OPF_JUMPDIRECT];
+        T is_link = T_MUL(is_jump, lv[CPU_FUNC]), is_linki = T_MUL(is_jumpi, lv[CPU_OPC]);
+        TNAME(cons)(k, T_MUL(is_jump, T_SUB(nv[5], CPU_VAL(0))));
+        TNAME(cons)(k, T_MUL(is_jump, T_SUB(TNAME(le_sum)(lv + CPU_RS, 5), CPU_VIRT(0))));
+        T imm[32];
+        TNAME(zero32)(imm);
+        TNAME(cpy)(imm + 2, lv + CPU_FUNC, 6);
+        TNAME(cpy)(imm + 8, lv + CPU_SHAMT, 5);
+        TNAME(cpy)(imm + 13, lv + CPU_RD, 5);
+        TNAME(cpy)(imm + 18, lv + CPU_RT, 5);
+        TNAME(cpy)(imm + 23, lv + CPU_RS, 5);
+        T jump_dest = T_ADD(CPU_VAL(2), TNAME(le_sum)(imm, 28));
+        TNAME(cons)(k, T_MUL(is_jumpi, T_SUB(nv[5], jump_dest)));
+        T aux = CPU_VAL(2);
+        TNAME(cpu_imm_bits)(lv, imm, 2);
+        TNAME(cons)(k, T_MUL(is_jd, T_SUB(aux, TNAME(le_sum)(imm, 32))));
+        T dst = T_ADD(T_ADD(lv[4], T_FROMB(4)), aux);
+        TNAME(cons)(k, T_MUL(T_MUL(is_jd, T_SUB(nv[5], dst)), T_SUB(T_ADD(nv[5], T_FROMB(P32)), dst)));
+        T links = T_ADD(T_ADD(is_link, is_linki), is_jd);
+        TNAME(cons)(k, T_MUL(links, T_SUB(T_ADD(lv[4], T_FROMB(8)), CPU_VAL(1))));
+        TNAME(cons)(k, T_MUL(is_link, T_SUB(CPU_VIRT(1), TNAME(le_sum)(lv + CPU_RD, 5))));
+        TNAME(cons)(k, T_MUL(T_ADD(is_linki, is_jd), T_SUB(CPU_VIRT(1), T_FROMB(31))));
+    }
+    /* -- jumps.rs eval_packed_branch */
+    {
+        const T* br = lv + CPU_BR; /* should_jump, gt, lt, eq, is_gt, is_lt, is_eq, is_ge, is_le, is_ne */
+        T filter = lv[OPF_BRANCH], sj = br[0];
+        T is_gt = br[4], is_lt = br[5], is_eq = br[6], is_ge = br[7], is_le = br[8], is_ne = br[9];
+        T norm = T_ADD(T_ADD(T_ADD(is_eq, is_ne), is_le), is_gt), special = T_ADD(is_ge, is_lt);
+        T src1 = CPU_VAL(0), src2 = CPU_VAL(1), aux1 = CPU_VAL(2), aux2 = CPU_VAL(3), aux3 = CPU_VAL(4), aux4 = CPU_VAL(5);
+        const gl_t inv32 = 18446744065119617026ULL; /* 2^-32, jumps.rs:15 */
+        TNAME(cons)(k, T_MUL(sj, T_SUB(one, sj)));
+        TNAME(cons)(k, T_MUL(sj, T_SUB(one, filter)));
+        TNAME(cons)(k, T_MUL(filter, T_SUB(one, T_ADD(norm, special))));
+        TNAME(cons)(k, T_MUL(filter, T_SUB(one, T_ADD(T_ADD(br[2], br[1]), br[3]))));
+        T off[32];
+        TNAME(cpu_imm_bits)(lv, off, 2);
+        TNAME(cons)(k, T_MUL(filter, T_SUB(aux4, TNAME(le_sum)(off, 32))));
+        T dst = T_ADD(T_ADD(lv[4], T_FROMB(4)), aux4);
+        TNAME(cons)(k, T_MUL(T_MUL(sj, T_SUB(nv[5], dst)), T_SUB(T_ADD(nv[5], T_FROMB(P32)), dst)));
+        TNAME(cons)(k, T_MUL(T_MUL(filter, T_SUB(one, sj)), T_SUB(nv[5], T_ADD(lv[4], T_FROMB(8)))));
+        T d1 = T_SUB(T_ADD(aux1, src2), src1), d2 = T_SUB(T_ADD(aux2, src1), src2);
+        TNAME(cons)(k, T_MUL(T_MUL(filter, d1), T_SUB(d1, T_FROMB(P32))));
+        TNAME(cons)(k, T_MUL(T_MUL(filter, d2), T_SUB(d2, T_FROMB(P32))));
+        TNAME(cons)(k, T_MUL(T_MUL(filter, aux1), T_SUB(T_ADD(aux1, aux2), T_FROMB(P32))));
+        TNAME(cons)(k, T_MUL(T_MUL(filter, aux3), T_SUB(one, aux3)));
+        TNAME(cons)(k, T_MUL(filter, T_SUB(CPU_VIRT(0), TNAME(le_sum)(lv + CPU_RS, 5))));
+        TNAME(cons)(k, T_MUL(norm, T_SUB(CPU_VIRT(1), TNAME(le_sum)(lv + CPU_RT, 5))));
+        TNAME(cons)(k, T_MUL(T_MUL(special, CPU_VIRT(1)), T_SUB(one, CPU_VIRT(1))));
+        T ca = T_SUB(T_ADD(src2, aux1), src1);
+        TNAME(cons)(k, T_MUL(T_MUL(filter, ca), T_SUB(T_FROMB(P32), ca)));
+        T lt = T_MULB(ca, inv32);
+        TNAME(cons)(k, T_MUL(br[2], T_SUB(one, lt)));
+        T cb = T_SUB(T_ADD(src1, aux2), src2);
+        TNAME(cons)(k, T_MUL(T_MUL(filter, cb), T_SUB(T_FROMB(P32), cb)));
+        T gt = T_MULB(cb, inv32);
+        TNAME(cons)(k, T_MUL(br[1], T_SUB(one, gt)));
+        T ne = T_ADD(lt, gt);
+        TNAME(cons)(k, T_MUL(br[3], ne));
+        T na3 = T_SUB(one, aux3);
+        T lt2 = T_ADD(T_MUL(br[2], na3), T_MUL(T_SUB(one, br[2]), aux3));
+        T gt2 = T_ADD(T_MUL(br[1], na3), T_MUL(T_SUB(one, br[1]), aux3));
+        T nf = T_SUB(one, filter);
+        TNAME(cons)(k, T_MUL(is_eq, nf));
+        TNAME(cons)(k, T_MUL(is_eq, T_SUB(sj, T_SUB(one, ne))));
+        TNAME(cons)(k, T_MUL(is_ne, nf));
+        TNAME(cons)(k, T_MUL(is_ne, T_SUB(sj, ne)));
+        TNAME(cons)(k, T_MUL(is_le, nf));
+        TNAME(cons)(k, T_MUL(is_le, T_SUB(sj, T_SUB(one, gt2))));
+        TNAME(cons)(k, T_MUL(is_ge, nf));
+        TNAME(cons)(k, T_MUL(is_ge, T_SUB(sj, T_SUB(one, lt2))));
+        TNAME(cons)(k, T_MUL(is_gt, nf));
+        TNAME(cons)(k, T_MUL(is_gt, T_SUB(sj, gt2)));
+        TNAME(cons)(k, T_MUL(is_lt, nf));
+        TNAME(cons)(k, T_MUL(is_lt, T_SUB(sj, lt2)));
+    }
+    /* -- membus.rs:35-48 */
+    TNAME(cons)(k, T_SUB(lv[3], T_MUL(T_SUB(one, lv[6]), lv[2])));
+    for (int i = 0; i < 9; i++) TNAME(cons)(k, T_MUL(CPU_USED(i), T_SUB(CPU_USED(i), one)));
+    /* -- memio.rs */
+    TNAME(cpu_memio)(lv, k, 0);
+    TNAME(cpu_memio)(lv, k, 1);
+    /* -- shift.rs:18-124 (variable, then immediate); two_exp = channel 3 */
+    for (int imm = 0; imm < 2; imm++) {
+        T is_shift = lv[imm ? OPF_SHIFT_IMM : OPF_SHIFT];
+        T disp = imm ? TNAME(le_sum)(lv + CPU_SHAMT, 5) : CPU_VAL(0);
+        TNAME(cons)(k, T_MUL(T_MUL(is_shift, CPU_USED(3)), T_SUB(CPU_ISREAD(3), one)));
+        TNAME(cons)(k, T_MUL(is_shift, CPU_CTX(3)));
+        TNAME(cons)(k, T_MUL(is_shift, T_SUB(CPU_SEG(3), T_FROMB(3))));
+        TNAME(cons)(k, T_MUL(is_shift, T_SUB(CPU_VIRT(3), disp)));
+    }
+    /* -- count.rs:10-75 (CLZ / CLO) */
+    {
+        T fz = lv[OPF_CLZ], fo = lv[OPF_CLO], f = T_ADD(fo, fz);
+        TNAME(cons)(k, T_MUL(f, T_SUB(TNAME(le_sum)(lv + CPU_OPC, 6), T_FROMB(0x1c))));
+        T func = TNAME(le_sum)(lv + CPU_FUNC, 6);
+        TNAME(cons)(k, T_MUL(fz, T_SUB(func, T_FROMB(0x20))));
+        TNAME(cons)(k, T_MUL(fo, T_SUB(func, T_FROMB(0x21))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(0), TNAME(le_sum)(lv + CPU_RS, 5))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(1), TNAME(le_sum)(lv + CPU_RD, 5))));
+        const T *bits = lv + CPU_GEN, *eqs = lv + CPU_GEN + 32, *invs = lv + CPU_GEN + 64;
+        for (int i = 0; i < 32; i++) TNAME(cons)(k, T_MUL(T_MUL(f, bits[i]), T_SUB(one, bits[i])));
+        T sum = TNAME(le_sum)(bits, 32), rs = CPU_VAL(0), rd = CPU_VAL(1);
+        TNAME(cons)(k, T_MUL(fz, T_SUB(rs, sum)));
+        TNAME(cons)(k, T_MUL(fo, T_SUB(T_SUB(T_FROMB(0xffffffffULL), rs), sum)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, bits[31]), rd));
+        int j = 0;
+        for (int i = 30; i >= 0; i--) {
+            T partial = TNAME(le_sum)(bits + i, 32 - i);
+            T diff = T_SUB(partial, one);
+            TNAME(cons)(k, T_MUL(T_MUL(f, diff), eqs[j]));
+            TNAME(cons)(k, T_MUL(f, T_SUB(T_ADD(T_MUL(diff, invs[j]), eqs[j]), one)));
+            TNAME(cons)(k, T_MUL(T_MUL(f, eqs[j]), T_SUB(rd, T_FROMB(31 - i))));
+            j++;
+            if (i == 0) {
+                TNAME(cons)(k, T_MUL(T_MUL(f, partial), eqs[j]));
+                TNAME(cons)(k, T_MUL(f, T_SUB(T_ADD(T_MUL(partial, invs[j]), eqs[j]), one)));
+                TNAME(cons)(k, T_MUL(T_MUL(f, eqs[j]), T_SUB(rd, T_FROMB(32))));
+            }
+        }
+    }
+    /* -- syscall.rs:12-232 */
+    {
+        T f = lv[OPF_SYSCALL];
+        T a0 = CPU_VAL(1), a1 = CPU_VAL(2), a2 = CPU_VAL(3), v0 = T_FROMB(0), v1 = T_FROMB(0);
+        const T *cond = lv + CPU_GEN, *sysnum = lv + CPU_GEN + 12, *a0f = lv + CPU_GEN + 24;
+        T sc_a1 = lv[CPU_GEN + 27];
+        T result_v0 = CPU_VAL(4), result_v1 = CPU_VAL(5);
+        T is_sysmap = sysnum[1], sz_nz = sc_a1, sz_zero = sysnum[10], sz = a1, sz_mid = sysnum[9];
+        T a0_zero = a0f[0], a0_nz = a0f[2], heap0 = CPU_VAL(6), result_heap = CPU_VAL(7);
+        TNAME(cons)(k, T_MUL(f, T_SUB(cond[0], T_MUL(is_sysmap, a0_zero))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(cond[1], T_MUL(cond[0], sz_nz))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[1]), T_SUB(T_ADD(heap0, sz_mid), result_heap)));
+        TNAME(cons)(k, T_MUL(f, T_SUB(cond[2], T_MUL(cond[0], sz_zero))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[2]), T_SUB(T_ADD(heap0, sz), result_heap)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[0]), T_SUB(heap0, result_v0)));
+        TNAME(cons)(k, T_MUL(f, T_SUB(cond[3], T_MUL(is_sysmap, a0_nz))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[3]), T_SUB(a0, result_v0)));
+        T is_brk = sysnum[2], brk_gt = cond[10], brk_le = cond[11], initial_brk = CPU_VAL(6);
+        TNAME(cons)(k, T_MUL(T_MUL(f, is_brk), T_SUB(one, T_ADD(brk_gt, brk_le))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, brk_gt), T_SUB(a0, result_v0)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, brk_le), T_SUB(initial_brk, result_v0)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, is_brk), T_SUB(v1, result_v1)));
+        T is_clone = sysnum[3];
+        TNAME(cons)(k, T_MUL(T_MUL(f, is_clone), T_SUB(one, result_v0)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, is_clone), T_SUB(v1, result_v1)));
+        T is_read = sysnum[5], bad_v0 = T_FROMB(0xFFFFFFFFULL), bad_v1 = T_FROMB(9);
+        TNAME(cons)(k, T_MUL(f, T_SUB(cond[4], T_MUL(is_read, a0f[2]))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[4]), T_SUB(bad_v0, result_v0)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[4]), T_SUB(bad_v1, result_v1)));
+        TNAME(cons)(k, T_MUL(f, T_SUB(cond[5], T_MUL(is_read, a0f[0]))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[5]), T_SUB(v0, result_v0)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[5]), T_SUB(v1, result_v1)));
+        T is_write = sysnum[6];
+        TNAME(cons)(k, T_MUL(f, T_SUB(cond[6], T_MUL(is_write, a0f[2]))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[6]), T_SUB(bad_v0, result_v0)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[6]), T_SUB(bad_v1, result_v1)));
+        TNAME(cons)(k, T_MUL(f, T_SUB(cond[7], T_MUL(is_write, a0f[1]))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[7]), T_SUB(a2, result_v0)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[7]), T_SUB(v1, result_v1)));
+        T is_fcntl = sysnum[7];
+        TNAME(cons)(k, T_MUL(f, T_SUB(cond[8], T_MUL(is_fcntl, a0f[0]))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[8]), T_SUB(T_FROMB(0), result_v0)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[8]), T_SUB(v1, result_v1)));
+        TNAME(cons)(k, T_MUL(f, T_SUB(cond[9], T_MUL(is_fcntl, a0f[1]))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[9]), T_SUB(one, result_v0)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, cond[9]), T_SUB(v1, result_v1)));
+        T rest = T_SUB(T_SUB(is_fcntl, cond[8]), cond[9]);
+        TNAME(cons)(k, T_MUL(f, T_SUB(rest, T_MUL(is_fcntl, a0f[2]))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, rest), T_SUB(bad_v0, result_v0)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, rest), T_SUB(bad_v1, result_v1)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, sysnum[8]), T_SUB(a0, CPU_VAL(6))));
+    }
+    /* -- bits.rs:9-64 (SEB, SEH, WSBH) */
+    {
+        T seh = lv[OPF_SIGNEXT16], seb = lv[OPF_SIGNEXT8], wsbh = lv[OPF_SWAPHALF];
+        T f = T_ADD(T_ADD(seh, seb), wsbh);
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(0), TNAME(le_sum)(lv + CPU_RT, 5))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(1), TNAME(le_sum)(lv + CPU_RD, 5))));
+        const T* bits = lv + CPU_GEN + 32; /* io().rt_le */
+        for (int i = 0; i < 32; i++) TNAME(cons)(k, T_MUL(T_MUL(f, bits[i]), T_SUB(one, bits[i])));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VAL(0), TNAME(le_sum)(bits, 32))));
+        T rd = CPU_VAL(1), r[32];
+        for (int i = 0; i < 32; i++) r[i] = bits[7];
+        TNAME(cpy)(r, bits, 7);
+        TNAME(cons)(k, T_MUL(seb, T_SUB(rd, TNAME(le_sum)(r, 32))));
+        for (int i = 0; i < 32; i++) r[i] = bits[15];
+        TNAME(cpy)(r, bits, 15);
+        TNAME(cons)(k, T_MUL(seh, T_SUB(rd, TNAME(le_sum)(r, 32))));
+        TNAME(cpy)(r, bits + 8, 8); TNAME(cpy)(r + 8, bits, 8); TNAME(cpy)(r + 16, bits + 24, 8); TNAME(cpy)(r + 24, bits + 16, 8);
+        TNAME(cons)(k, T_MUL(wsbh, T_SUB(rd, TNAME(le_sum)(r, 32))));
+    }
+    /* -- misc.rs */
+    const T *m_rs = lv + CPU_GEN, *m_msb = lv + CPU_GEN + 32, *m_lsb = lv + CPU_GEN + 64;
+    T auxm = lv[CPU_GEN + 96], auxl = lv[CPU_GEN + 97], auxs = lv[CPU_GEN + 98];
+    { /* rdhwr :10-45 */
+        T f = lv[OPF_RDHWR], rd_index = lv[CPU_GEN + 99], eq0 = lv[CPU_GEN + 100], eq29 = lv[CPU_GEN + 101];
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(0), TNAME(le_sum)(lv + CPU_RT, 5))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(rd_index, TNAME(le_sum)(lv + CPU_RD, 5))));
+        T rt_val = CPU_VAL(0), local_user = CPU_VAL(1);
+        TNAME(cons)(k, T_MUL(T_MUL(f, eq0), rd_index));
+        TNAME(cons)(k, T_MUL(T_MUL(f, eq0), T_SUB(rt_val, one)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, eq29), T_SUB(rd_index, T_FROMB(29))));
+        TNAME(cons)(k, T_MUL(T_MUL(f, eq29), T_SUB(rt_val, local_user)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, T_SUB(T_SUB(one, eq29), eq0)), rt_val));
+    }
+    { /* condmov :108-146 */
+        T rs = CPU_VAL(0), rt = CPU_VAL(1), rd = CPU_VAL(2), out = CPU_VAL(3), mov = CPU_VAL(4);
+        T movn = lv[OPF_MOVN], movz = lv[OPF_MOVZ], f = T_ADD(movn, movz);
+        T is_ne = T_MUL(lv[CPU_GEN], rt), is_eq = T_SUB(one, is_ne), no_mov = T_SUB(one, mov);
+        TNAME(cons)(k, T_MUL(movn, T_SUB(mov, is_ne)));
+        TNAME(cons)(k, T_MUL(movz, T_SUB(mov, is_eq)));
+        TNAME(cons)(k, T_MUL(T_MUL(f, mov), no_mov));
+        TNAME(cons)(k, T_MUL(f, T_SUB(out, T_ADD(T_MUL(mov, rs), T_MUL(no_mov, rd)))));
+    }
+    { /* teq :197-226 */
+        T f = lv[OPF_TEQ];
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(1), TNAME(le_sum)(lv + CPU_RT, 5))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(0), TNAME(le_sum)(lv + CPU_RS, 5))));
+        T is_ne = T_MUL(T_SUB(CPU_VAL(0), CPU_VAL(1)), lv[CPU_GEN]);
+        TNAME(cons)(k, T_MUL(f, T_SUB(one, is_ne)));
+    }
+    { /* ext :266-317 */
+        T f = lv[OPF_EXT];
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(1), TNAME(le_sum)(lv + CPU_RT, 5))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(0), TNAME(le_sum)(lv + CPU_RS, 5))));
+        T msbd = TNAME(le_sum)(lv + CPU_RD, 5), lsb = TNAME(le_sum)(lv + CPU_SHAMT, 5), msb = T_ADD(lsb, msbd);
+        TNAME(cons)(k, T_MUL(f, T_SUB(T_ADD(T_MUL(CPU_VAL(1), auxs), auxl), auxm)));
+        for (int i = 0; i < 32; i++) {
+            T mpartial = TNAME(le_sum)(m_rs, i + 1), lpartial = TNAME(le_sum)(m_rs, i);
+            T fm = T_MUL(f, m_msb[i]), fl = T_MUL(f, m_lsb[i]);
+            TNAME(cons)(k, T_MUL(fm, T_SUB(msb, T_FROMB(i))));
+            TNAME(cons)(k, T_MUL(fm, T_SUB(auxm, mpartial)));
+            TNAME(cons)(k, T_MUL(fl, T_SUB(lsb, T_FROMB(i))));
+            TNAME(cons)(k, T_MUL(fl, T_SUB(auxl, lpartial)));
+            TNAME(cons)(k, T_MUL(fl, T_SUB(auxs, T_FROMB((gl_t)1 << i))));
+        }
+    }
+    { /* ror :563-604 */
+        T f = lv[OPF_ROR];
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(1), TNAME(le_sum)(lv + CPU_RD, 5))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(0), TNAME(le_sum)(lv + CPU_RT, 5))));
+        T sa = TNAME(le_sum)(lv + CPU_SHAMT, 5), rd_result = CPU_VAL(1), r[32];
+        for (int i = 0; i < 32; i++) {
+            TNAME(cpy)(r, m_rs + i, 32 - i);
+            TNAME(cpy)(r + 32 - i, m_rs, i);
+            T fs = T_MUL(f, m_lsb[i]);
+            TNAME(cons)(k, T_MUL(fs, T_SUB(sa, T_FROMB(i))));
+            TNAME(cons)(k, T_MUL(fs, T_SUB(rd_result, TNAME(le_sum)(r, 32))));
+        }
+    }
+    { /* ins :397-467 */
+        T f = lv[OPF_INS];
+        T rt_src = TNAME(le_sum)(lv + CPU_RT, 5);
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(1), rt_src)));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(2), rt_src)));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(0), TNAME(le_sum)(lv + CPU_RS, 5))));
+        T msb = TNAME(le_sum)(lv + CPU_RD, 5), lsb = TNAME(le_sum)(lv + CPU_SHAMT, 5);
+        TNAME(cons)(k, T_MUL(f, T_SUB(T_SUB(CPU_VAL(2), auxm), T_MUL(auxl, auxs))));
+        for (int i = 0; i < 32; i++) {
+            T fm = T_MUL(f, m_msb[i]), fl = T_MUL(f, m_lsb[i]);
+            TNAME(cons)(k, T_MUL(fl, T_SUB(lsb, T_FROMB(i))));
+            TNAME(cons)(k, T_MUL(fl, T_SUB(auxs, T_FROMB((gl_t)1 << i))));
+            TNAME(cons)(k, T_MUL(fm, T_SUB(T_SUB(msb, lsb), T_FROMB(i))));
+            TNAME(cons)(k, T_MUL(fm, T_SUB(auxl, TNAME(le_sum)(m_rs, i + 1))));
+        }
+    }
+    { /* maddu :659-726 */
+        T f = lv[OPF_MADDU];
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(0), TNAME(le_sum)(lv + CPU_RS, 5))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(1), TNAME(le_sum)(lv + CPU_RT, 5))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(2), T_FROMB(33))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(4), T_FROMB(33))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(3), T_FROMB(32))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(CPU_VIRT(5), T_FROMB(32))));
+        T result = T_ADD(T_MULB(CPU_VAL(4), P32), CPU_VAL(5));
+        T mul = T_MUL(CPU_VAL(0), CPU_VAL(1));
+        T addend = T_ADD(T_MULB(CPU_VAL(2), P32), CPU_VAL(3));
+        T carry = auxm, overflow = T_MULB(carry, P32);
+        TNAME(cons)(k, T_MUL(T_MUL(f, carry), T_SUB(carry, T_FROMB(P32))));
+        TNAME(cons)(k, T_MUL(f, T_SUB(T_SUB(T_ADD(mul, addend), overflow), result)));
+    }
+}
+#undef CPU_USED
+#undef CPU_ISREAD
+#undef CPU_CTX
+#undef CPU_SEG
+#undef CPU_VIRT
+#undef CPU_VAL
+
+static int TNAME(table_width)(int table_id) { return table_id == 0 ? 262 : table_id == 1 ? 69 : table_id == 2 ? 470 : table_id == 3 ? 2431 : table_id == 4 ? 13 : table_id == 5 ? 110 : table_id == 6 ? 78 : table_id == 7 ? 76 : table_id == 8 ? 224 : table_id == 9 ? 127 : table_id == 10 ? 54 : table_id == 11 ? 259 : 0; }
 static void TNAME(eval_table)(int table_id, const T* lv, const T* nv, TNAME(consumer) * k) {
     if (table_id == 0) TNAME(eval_poseidon)(lv, k);
     else if (table_id == 1) TNAME(eval_logic)(lv, k);
@@ -670,7 +1156,8 @@ static void TNAME(eval_table)(int table_id, const T* lv, const T* nv, TNAME(cons
     else if (table_id == 7) TNAME(eval_sha_extend_sponge)(lv, nv, k);
     else if (table_id == 8) TNAME(eval_sha_compress)(lv, nv, k);
     else if (table_id == 9) TNAME(eval_sha_compress_sponge)(lv, k);
-    else TNAME(eval_arithmetic)(lv, nv, k);
+    else if (table_id == 10) TNAME(eval_arithmetic)(lv, nv, k);
+    else TNAME(eval_cpu)(lv, nv, k);
 }
 
 /* ---- general CTL checks driven by the column-set description ----

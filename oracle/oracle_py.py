@@ -244,6 +244,23 @@ class Oracle:
         self.lib.zko_poseidon_trace(C.c_uint64(seed), C.c_size_t(num_perms), log_n, _ptr(out))
         return out
 
+    def debug_constraints(self, table_id, trace, ncols, log_n):
+        """(constraints per row, first failing (row, constraint index) or None) on the plain trace rows."""
+        br, bi = C.c_long(), C.c_long()
+        self.lib.zko_debug_constraints.restype = C.c_long
+        self.lib.zko_debug_constraints.argtypes = [C.c_int, u64p, C.c_size_t, C.c_uint, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        n = self.lib.zko_debug_constraints(table_id, _ptr(np.ascontiguousarray(trace, dtype=np.uint64)), ncols, log_n, C.byref(br), C.byref(bi))
+        return n, (None if br.value < 0 else (br.value, bi.value))
+
+    def row_constraints(self, table_id, lv, nv, is_first=False, is_last=False):
+        """Values of every constraint of table `table_id` on one (local, next) row pair."""
+        self.lib.zko_debug_row_constraints.restype = C.c_long
+        self.lib.zko_debug_row_constraints.argtypes = [C.c_int, u64p, u64p, C.c_int, C.c_int, u64p, C.c_size_t]
+        out = np.zeros(8192, dtype=np.uint64)
+        n = self.lib.zko_debug_row_constraints(table_id, _ptr(np.ascontiguousarray(lv, dtype=np.uint64)),
+                                               _ptr(np.ascontiguousarray(nv, dtype=np.uint64)), int(is_first), int(is_last), _ptr(out), out.size)
+        return out[:n]
+
     def poseidon_eval_row(self, row, alphas):
         row = np.ascontiguousarray(row, dtype=np.uint64)
         al = np.ascontiguousarray(alphas, dtype=np.uint64)

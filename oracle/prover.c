@@ -209,6 +209,40 @@ void zko_poseidon_eval_row(const uint64_t* local, const uint64_t* alphas, size_t
     for (size_t j = 0; j < nalphas; j++) acc_out[j] = k.acc[j];
 }
 
+/* Evaluate table `table_id`'s constraints on the rows of a trace (row r with next row r+1 mod n; transition constraints are
+ * switched off on the last row, first/last-row constraints on only there) and report the first nonzero one.
+ * Returns the number of constraints per row; *bad_row = -1 if every constraint vanishes on every row. */
+long zko_debug_constraints(int table_id, const uint64_t* trace, size_t W, unsigned log_n, long* bad_row, long* bad_index) {
+    size_t n = (size_t)1 << log_n;
+    gl_t *lv = malloc(W * 8), *nv = malloc(W * 8), *rec = malloc(8192 * 8);
+    long count = 0;
+    *bad_row = -1; *bad_index = -1;
+    for (size_t r = 0; r < n && *bad_row < 0; r++) {
+        for (size_t c = 0; c < W; c++) { lv[c] = trace[c * n + r]; nv[c] = trace[c * n + (r + 1) % n]; }
+        b_consumer k;
+        memset(&k, 0, sizeof k);
+        k.z_last = r != n - 1; k.l_first = r == 0; k.l_last = r == n - 1;
+        k.rec = rec; k.rec_cap = 8192;
+        b_eval_table(table_id, lv, nv, &k);
+        count = (long)k.nrec;
+        for (size_t i = 0; i < k.nrec && i < 8192; i++)
+            if (gl_canon(rec[i]) != 0) { *bad_row = (long)r; *bad_index = (long)i; break; }
+    }
+    free(lv); free(nv); free(rec);
+    return count;
+}
+
+/* All constraint values of one row pair (trace-domain flags as in zko_debug_constraints); returns the number of constraints. */
+long zko_debug_row_constraints(int table_id, const uint64_t* lv, const uint64_t* nv, int is_first, int is_last, uint64_t* out, size_t cap) {
+    b_consumer k;
+    memset(&k, 0, sizeof k);
+    k.z_last = !is_last; k.l_first = is_first; k.l_last = is_last;
+    k.rec = out; k.rec_cap = cap;
+    b_eval_table(table_id, lv, nv, &k);
+    for (size_t i = 0; i < k.nrec && i < cap; i++) out[i] = gl_canon(out[i]);
+    return (long)k.nrec;
+}
+
 /* ------------------------------------------------------------------ config */
 void zko_standard_config(zko_stark_config* c) {
     c->rate_bits = 2; c->cap_height = 4; c->pow_bits = 16; c->num_challenges = 2;

@@ -179,6 +179,8 @@ void zko_quotient(int table_id, const zko_batch* trace, const zko_batch* aux, co
 void zko_quotient_poseidon(const zko_batch* trace, const zko_batch* aux, const uint32_t* num_helpers, size_t nctl_zs,
                            const uint64_t* alphas, size_t nalphas, uint64_t* out_coeffs);
 /* constraint evaluation of one row in the base field (check_constraints building block) */
+long zko_debug_constraints(int table_id, const uint64_t* trace, size_t W, unsigned log_n, long* bad_row, long* bad_index);
+long zko_debug_row_constraints(int table_id, const uint64_t* lv, const uint64_t* nv, int is_first, int is_last, uint64_t* out, size_t cap);
 void zko_poseidon_eval_row(const uint64_t* local, const uint64_t* alphas, size_t nalphas, uint64_t* acc_out);
 
 #ifdef __cplusplus

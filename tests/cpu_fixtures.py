@@ -1,0 +1,579 @@
+"""Witness generator for the CPU table (test infrastructure).
+
+A small MIPS machine that executes a list of instructions and fills CpuColumnsView rows the way the reference's witness generators
+do (witness/operation.rs, witness/util.rs: register reads/writes through the general-purpose memory channels, scratch values written
+to register 0 with `used = 0`, branch auxiliaries, bit decompositions in the shared `general` columns ...), restated from the
+column definitions in cpu/columns/{mod,ops,general}.rs and from what the constraints in cpu/*.rs require.  Alongside the rows it
+records the memory operations (timestamp = clock * NUM_CHANNELS, witness/memory.rs:79-95), the logic operations and the
+arithmetic operations, i.e. what the Memory / Logic / Arithmetic tables must contain for the cross-table lookups to hold.
+"""
+import numpy as np
+
+P = 0xFFFFFFFF00000001
+W = 259
+NUM_CHANNELS = 10
+SEG_CODE, SEG_SHIFT, SEG_REG = 0, 3, 4
+
+# column map (cpu/columns/mod.rs:62-96)
+IS_BOOT, IS_EXIT, CONTEXT, CODE_CONTEXT, PC, NEXT_PC, KERNEL = range(7)
+OPS = ["binary_op", "binary_imm_op", "eq_iszero", "logic_op", "logic_imm_op", "movz_op", "movn_op", "clz_op", "clo_op", "shift",
+       "shift_imm", "keccak_general", "jumps", "jumpi", "jumpdirect", "branch", "pc", "get_context", "set_context", "exit_kernel",
+       "m_op_load", "m_op_store", "nop", "ext", "ins", "maddu", "rdhwr", "signext8", "signext16", "swaphalf", "teq", "ror", "syscall"]
+OP = {n: 7 + i for i, n in enumerate(OPS)}
+BR = {n: 40 + i for i, n in enumerate(["should_jump", "gt", "lt", "eq", "is_gt", "is_lt", "is_eq", "is_ge", "is_le", "is_ne"])}
+OPCODE_BITS, RS_BITS, RT_BITS, RD_BITS, SHAMT_BITS, FUNC_BITS = 50, 56, 61, 66, 71, 76
+GEN = 86
+MEMIO = {n: 188 + i for i, n in enumerate(["lh", "lwl", "lw", "lbu", "lhu", "lwr", "sb", "sh", "swl", "sw", "swr", "ll", "sc", "sdc1",
+                                           "lb", "aux_filter"])}
+CLOCK = 204
+CH0 = 205
+
+
+def ch(i, f):
+    return CH0 + 6 * i + f  # f: 0 used, 1 is_read, 2 context, 3 segment, 4 virtual, 5 value
+
+
+def inv(x):
+    x %= P
+    return pow(x, P - 2, P) if x else 0
+
+
+def bits(v, n=32):
+    return [(v >> i) & 1 for i in range(n)]
+
+
+def sext(v, n):
+    v &= (1 << n) - 1
+    return (v | (0xFFFFFFFF << n)) & 0xFFFFFFFF if v >> (n - 1) else v
+
+
+def enc_r(op, rs, rt, rd, sa, fn):
+    return (op << 26) | (rs << 21) | (rt << 16) | (rd << 11) | (sa << 6) | fn
+
+
+def enc_i(op, rs, rt, imm):
+    return (op << 26) | (rs << 21) | (rt << 16) | (imm & 0xFFFF)
+
+
+class Machine:
+    def __init__(self, boot_words=((0x100, 0x11), (0x104, 0x22), (0x108, 0x33))):
+        self.rows, self.mem_ops, self.logic_ops, self.arith_ops = [], [], [], []
+        self.regs = [0] * 39
+        self.mem = {}
+        self.pc, self.npc = 0x1000, 0x1004
+        self.boot(boot_words)
+
+    # ---------------------------------------------------------------- helpers
+    @property
+    def clock(self):
+        return len(self.rows)
+
+    def new_row(self, insn=None):
+        r = [0] * W
+        r[CLOCK] = self.clock
+        r[KERNEL] = 1
+        r[PC], r[NEXT_PC] = self.pc, self.npc
+        if insn is not None:
+            for base, lo, n in ((OPCODE_BITS, 26, 6), (RS_BITS, 21, 5), (RT_BITS, 16, 5), (RD_BITS, 11, 5), (SHAMT_BITS, 6, 5),
+                                (FUNC_BITS, 0, 6)):
+                for i in range(n):
+                    r[base + i] = (insn >> (lo + i)) & 1
+        return r
+
+    def channel(self, r, i, used, is_read, seg, virt, value, ctx=0):
+        r[ch(i, 0)], r[ch(i, 1)], r[ch(i, 2)], r[ch(i, 3)], r[ch(i, 4)], r[ch(i, 5)] = used, is_read, ctx, seg, virt, value & 0xFFFFFFFF
+        if used:
+            self.mem_ops.append((is_read, ctx, seg, virt, value & 0xFFFFFFFF, r[CLOCK] * NUM_CHANNELS))
+
+    def reg_read(self, r, i, reg):
+        v = self.regs[reg]
+        self.channel(r, i, 1, 1, SEG_REG, reg, v)
+        return v
+
+    def reg_write(self, r, i, reg, value):
+        value &= 0xFFFFFFFF
+        if reg:
+            self.regs[reg] = value
+        self.channel(r, i, 1 if reg else 0, 0, SEG_REG, reg, value)  # util.rs:198-204: writes to r0 are not memory operations
+
+    def mem_read(self, r, i, virt, seg=SEG_CODE):
+        v = self.mem.get((seg, virt), (1 << virt) & 0xFFFFFFFF if seg == SEG_SHIFT and virt < 32 else 0)
+        self.mem[(seg, virt)] = v
+        self.channel(r, i, 1, 1, seg, virt, v)
+        return v
+
+    def mem_write(self, r, i, virt, value, seg=SEG_CODE):
+        self.mem[(seg, virt)] = value & 0xFFFFFFFF
+        self.channel(r, i, 1, 0, seg, virt, value)
+
+    def push(self, r, target=None):
+        """Append the row and advance (pc, next_pc) with the branch-delay-slot rule: pc <- next_pc, next_pc <- target or +4."""
+        self.rows.append(r)
+        self.pc, self.npc = self.npc, (self.npc + 4) & 0xFFFFFFFF if target is None else target & 0xFFFFFFFF
+
+    def boot(self, words):
+        # bootstrap_kernel.rs: rows with is_bootstrap_kernel = 1 write the kernel image to (context 0, Segment::Code); the last of
+        # them uses no channel.
+        for k in range(0, len(words), 3):
+            r = self.new_row()
+            r[IS_BOOT] = 1
+            for i, (a, v) in enumerate(words[k:k + 3]):
+                self.mem_write(r, i, a, v)
+            self.rows.append(r)
+        r = self.new_row()
+        r[IS_BOOT] = 1
+        self.rows.append(r)
+
+    # ---------------------------------------------------------------- instructions
+    def binary(self, name, rs, rt, rd, func, result_fn):
+        """ADD/ADDU/SUB/... (generate_binary_arithmetic_op): channels 0, 1 read rs, rt; channel 2 writes rd."""
+        insn = enc_r(0, rs, rt, rd, 0, func)
+        r = self.new_row(insn)
+        r[OP["binary_op"]] = 1
+        a, b = self.reg_read(r, 0, rs), self.reg_read(r, 1, rt)
+        out = result_fn(a, b) & 0xFFFFFFFF
+        self.reg_write(r, 2, rd, out)
+        self.arith_ops.append((name, a, b, out, func << 6))
+        self.push(r)
+
+    def binary_imm(self, name, op, rs, rt, imm, result_fn):
+        """ADDI/ADDIU/SLTI/SLTIU (generate_binary_arithmetic_imm_op): channel 1 holds the sign-extended immediate as a write to rt."""
+        r = self.new_row(enc_i(op, rs, rt, imm))
+        r[OP["binary_imm_op"]] = 1
+        a = self.reg_read(r, 0, rs)
+        b = sext(imm, 16)
+        self.reg_write(r, 1, rt, b)
+        out = result_fn(a, b) & 0xFFFFFFFF
+        self.reg_write(r, 2, rt, out)
+        self.arith_ops.append((name, a, b, out, op))
+        self.push(r)
+
+    def logic(self, name, rs, rt, rd):
+        func = {"and": 0x24, "or": 0x25, "xor": 0x26, "nor": 0x27}[name]
+        r = self.new_row(enc_r(0, rs, rt, rd, 0, func))
+        r[OP["logic_op"]] = 1
+        a, b = self.reg_read(r, 0, rs), self.reg_read(r, 1, rt)
+        out = {"and": a & b, "or": a | b, "xor": a ^ b, "nor": ~(a | b) & 0xFFFFFFFF}[name]
+        self.reg_write(r, 2, rd, out)
+        self.logic_ops.append((name, a, b, out))
+        self.push(r)
+
+    def nop(self):
+        r = self.new_row(0)
+        r[OP["nop"]] = 1
+        self.push(r)
+
+    def jr(self, rs, rd=None):
+        """JR / JALR (jumps.rs:20-40, 106-121)."""
+        link = rd is not None
+        r = self.new_row(enc_r(0, rs, 0, rd or 0, 0, 9 if link else 8))
+        r[OP["jumps"]] = 1
+        target = self.reg_read(r, 0, rs)
+        if link:
+            self.reg_write(r, 1, rd, self.pc + 8)
+        self.push(r, target)
+
+    def j(self, index, link=False):
+        """J / JAL (jumps.rs:42-60): channel 2 carries pc[31:28] << 28."""
+        r = self.new_row((3 if link else 2) << 26 | (index & 0x3FFFFFF))
+        r[OP["jumpi"]] = 1
+        remain = self.npc & 0xF0000000
+        self.channel(r, 2, 0, 0, 0, 0, remain)
+        if link:
+            self.reg_write(r, 1, 31, self.pc + 8)
+        self.push(r, remain + ((index & 0x3FFFFFF) << 2))
+
+    def bal(self, offset):
+        """BAL (jumps.rs:62-90): channel 2 carries the sign-extended offset << 2; $31 <- pc + 8."""
+        r = self.new_row(enc_i(1, 0, 0x11, offset))
+        r[OP["jumpdirect"]] = 1
+        aux = (sext(offset, 16) << 2) & 0xFFFFFFFF
+        self.channel(r, 2, 0, 0, 0, 0, aux)
+        self.reg_write(r, 1, 31, self.pc + 8)
+        self.push(r, self.pc + 4 + aux)
+
+    def branch(self, kind, rs, rt, offset):
+        """BEQ BNE BLEZ BGTZ BLTZ BGEZ (generate_branch, operation.rs:501-568)."""
+        op, rtf, flag = {"eq": (4, rt, "is_eq"), "ne": (5, rt, "is_ne"), "le": (6, 0, "is_le"), "gt": (7, 0, "is_gt"),
+                         "lt": (1, 0, "is_lt"), "ge": (1, 1, "is_ge")}[kind]
+        r = self.new_row(enc_i(op, rs, rtf, offset))
+        r[OP["branch"]] = 1
+        r[BR[flag]] = 1
+        s1 = self.reg_read(r, 0, rs)
+        s2 = self.reg_read(r, 1, rtf if kind in ("eq", "ne") else (rtf if self.regs[rtf] == 0 else 0))
+        i1, i2 = s1 - (s1 >> 31 << 32), s2 - (s2 >> 31 << 32)
+        taken = {"eq": i1 == i2, "ne": i1 != i2, "le": i1 <= i2, "gt": i1 > i2, "lt": i1 < i2, "ge": i1 >= i2}[kind]
+        r[BR["eq"]], r[BR["gt"]], r[BR["lt"]] = int(s1 == s2), int(s1 > s2), int(s1 < s2)
+        aux4 = (sext(offset, 16) << 2) & 0xFFFFFFFF
+        for i, v in enumerate(((s1 - s2) & 0xFFFFFFFF, (s2 - s1) & 0xFFFFFFFF, int(((s1 ^ s2) & 0x80000000) > 0), aux4)):
+            self.reg_write(r, 2 + i, 0, v)
+        r[BR["should_jump"]] = int(taken)
+        self.push(r, self.pc + 4 + aux4 if taken else self.pc + 8)
+
+    def load(self, kind, rs, rt, offset):
+        """LB LH LWL LW LBU LHU LWR LL (generate_mload_general): channels 0, 1 read rs, rt; 2 reads the word; 3 writes rt."""
+        op = {"lb": 0x20, "lh": 0x21, "lwl": 0x22, "lw": 0x23, "lbu": 0x24, "lhu": 0x25, "lwr": 0x26, "ll": 0x30}[kind]
+        r = self.new_row(enc_i(op, rs, rt, offset))
+        r[OP["m_op_load"]] = 1
+        r[MEMIO[kind]] = r[MEMIO["aux_filter"]] = 1
+        a, b = self.reg_read(r, 0, rs), self.reg_read(r, 1, rt)
+        raw = (a + sext(offset, 16)) & 0xFFFFFFFF
+        m = self.mem_read(r, 2, raw & 0xFFFFFFFC)
+        s = raw & 3
+        if kind == "lb":
+            v = sext((m >> (24 - s * 8)) & 0xFF, 8)
+        elif kind == "lbu":
+            v = (m >> (24 - s * 8)) & 0xFF
+        elif kind == "lh":
+            v = sext((m >> (16 - (s & 2) * 8)) & 0xFFFF, 16)
+        elif kind == "lhu":
+            v = (m >> (16 - (s & 2) * 8)) & 0xFFFF
+        elif kind == "lwl":
+            mask = (0xFFFFFFFF << (s * 8)) & 0xFFFFFFFF
+            v = (b & ~mask & 0xFFFFFFFF) | ((m << (s * 8)) & 0xFFFFFFFF)
+        elif kind == "lwr":
+            mask = 0xFFFFFFFF >> (24 - s * 8)
+            v = (b & ~mask & 0xFFFFFFFF) | (m >> (24 - s * 8))
+        else:
+            v = m
+        self.reg_write(r, 3, rt, v)
+        self.io_bits(r, raw, b, m)
+        self.push(r)
+
+    def store(self, kind, rs, rt, offset):
+        """SB SH SWL SW SWR SC (generate_mstore_general): channel 2 reads the old word, channel 3 writes the new one."""
+        op = {"sb": 0x28, "sh": 0x29, "swl": 0x2A, "sw": 0x2B, "swr": 0x2E, "sc": 0x38}[kind]
+        r = self.new_row(enc_i(op, rs, rt, offset))
+        r[OP["m_op_store"]] = 1
+        r[MEMIO[kind]] = r[MEMIO["aux_filter"]] = 1
+        a, b = self.reg_read(r, 0, rs), self.reg_read(r, 1, rt)
+        raw = (a + sext(offset, 16)) & 0xFFFFFFFF
+        virt = raw & 0xFFFFFFFC
+        m = self.mem_read(r, 2, virt)
+        s = raw & 3
+        if kind == "sb":
+            sh = 24 - s * 8
+            v = (m & ~(0xFF << sh) & 0xFFFFFFFF) | ((b & 0xFF) << sh)
+        elif kind == "sh":
+            sh = 16 - (s & 2) * 8
+            v = (m & ~(0xFFFF << sh) & 0xFFFFFFFF) | ((b & 0xFFFF) << sh)
+        elif kind == "swl":
+            mask = 0xFFFFFFFF >> (s * 8)
+            v = (m & ~mask & 0xFFFFFFFF) | (b >> (s * 8))
+        elif kind == "swr":
+            sh = 24 - s * 8
+            mask = (0xFFFFFFFF << sh) & 0xFFFFFFFF
+            v = (m & ~mask & 0xFFFFFFFF) | ((b << sh) & 0xFFFFFFFF)
+        else:
+            v = b
+        self.mem_write(r, 3, virt, v)
+        self.io_bits(r, raw, b, m)
+        self.push(r)
+
+    def io_bits(self, r, rs_val, rt_val, mem_val):
+        for i in range(32):
+            r[GEN + i], r[GEN + 32 + i], r[GEN + 64 + i] = (rs_val >> i) & 1, (rt_val >> i) & 1, (mem_val >> i) & 1
+        r[GEN + 96] = (rs_val & 1) * ((rs_val >> 1) & 1)
+
+    def shift_imm(self, name, rt, rd, sa):
+        """SLL SRL SRA (generate_shift_imm): channel 1 reads rt, channel 0 carries the shift amount, channel 3 reads 2^sa from
+        the shift table, channel 2 writes rd."""
+        func = {"sll": 0, "srl": 2, "sra": 3}[name]
+        r = self.new_row(enc_r(0, 0, rt, rd, sa, func))
+        r[OP["shift_imm"]] = 1
+        a = self.reg_read(r, 1, rt)
+        self.channel(r, 0, 0, 0, 0, 0, sa)
+        self.mem_read(r, 3, sa, SEG_SHIFT)
+        out = self.shift_result(name, a, sa)
+        self.reg_write(r, 2, rd, out)
+        self.arith_ops.append((name, a, sa, out, func << 6))
+        self.push(r)
+
+    def shift_var(self, name, rs, rt, rd):
+        """SLLV SRLV SRAV (generate_sllv ...): channel 0 reads rs (the displacement), channel 1 rt."""
+        func = {"sllv": 4, "srlv": 6, "srav": 7}[name]
+        r = self.new_row(enc_r(0, rs, rt, rd, 0, func))
+        r[OP["shift"]] = 1
+        d, a = self.reg_read(r, 0, rs), self.reg_read(r, 1, rt)
+        self.mem_read(r, 3, d, SEG_SHIFT)
+        out = self.shift_result(name[:3], a, d & 31)
+        self.reg_write(r, 2, rd, out)
+        self.arith_ops.append((name, a, d, out, func << 6))
+        self.push(r)
+
+    @staticmethod
+    def shift_result(name, a, sa):
+        if name == "sll":
+            return (a << sa) & 0xFFFFFFFF
+        if name == "srl":
+            return a >> sa
+        return ((a - (a >> 31 << 32)) >> sa) & 0xFFFFFFFF
+
+    def count(self, name, rs, rd):
+        """CLZ / CLO (count.rs)."""
+        r = self.new_row(enc_r(0x1C, rs, 0, rd, 0, 0x20 if name == "clz" else 0x21))
+        r[OP[name + "_op"]] = 1
+        a = self.reg_read(r, 0, rs)
+        x = a if name == "clz" else a ^ 0xFFFFFFFF
+        out = 32 - x.bit_length()
+        self.reg_write(r, 1, rd, out)
+        for i in range(32):
+            r[GEN + i] = (x >> i) & 1
+        j = 0
+        for i in range(30, -1, -1):
+            partial = x >> i
+            r[GEN + 32 + j], r[GEN + 64 + j] = int(partial == 1), inv(partial - 1)
+            j += 1
+        r[GEN + 32 + j], r[GEN + 64 + j] = int(x == 0), inv(x)
+        self.push(r)
+
+    def signext(self, name, rt, rd):
+        """SEB SEH WSBH (bits.rs)."""
+        sa, flag = {"seb": (0x10, "signext8"), "seh": (0x18, "signext16"), "wsbh": (0x02, "swaphalf")}[name]
+        r = self.new_row(enc_r(0x1F, 0, rt, rd, sa, 0x20))
+        r[OP[flag]] = 1
+        a = self.reg_read(r, 0, rt)
+        out = sext(a, 8) if name == "seb" else sext(a, 16) if name == "seh" else \
+            ((a & 0xFF00FF00) >> 8) | ((a & 0x00FF00FF) << 8)
+        self.reg_write(r, 1, rd, out)
+        for i in range(32):
+            r[GEN + 32 + i] = (a >> i) & 1
+        self.push(r)
+
+    def rdhwr(self, rt, rd):
+        r = self.new_row(enc_r(0x1F, 0, rt, rd, 0, 0x3B))
+        r[OP["rdhwr"]] = 1
+        local_user = self.regs[38]
+        out = 1 if rd == 0 else local_user if rd == 29 else 0
+        self.reg_write(r, 0, rt, out)
+        if rd == 29:
+            self.reg_read(r, 1, 38)
+        r[GEN + 99], r[GEN + 100], r[GEN + 101] = rd, int(rd == 0), int(rd == 29)
+        self.push(r)
+
+    def condmov(self, name, rs, rt, rd):
+        """MOVN / MOVZ (generate_cond_mov_op)."""
+        r = self.new_row(enc_r(0, rs, rt, rd, 0, 0x0B if name == "movn" else 0x0A))
+        r[OP[name + "_op"]] = 1
+        a, b, c = self.reg_read(r, 0, rs), self.reg_read(r, 1, rt), self.reg_read(r, 2, rd)
+        mov = int(b != 0) if name == "movn" else int(b == 0)
+        self.reg_write(r, 3, rd, a if mov else c)
+        self.channel(r, 4, 0, 0, 0, 0, mov)
+        r[GEN] = inv(b)
+        self.push(r)
+
+    def teq(self, rs, rt):
+        r = self.new_row(enc_r(0, rs, rt, 0, 0, 0x34))
+        r[OP["teq"]] = 1
+        a, b = self.reg_read(r, 0, rs), self.reg_read(r, 1, rt)
+        assert a != b
+        r[GEN] = inv(a - b)
+        self.push(r)
+
+    def ext(self, rs, rt, lsb, size):
+        """EXT rt, rs, lsb, size (generate_extract)."""
+        msbd = size - 1
+        r = self.new_row(enc_r(0x1F, rs, rt, msbd, lsb, 0))
+        r[OP["ext"]] = 1
+        a = self.reg_read(r, 0, rs)
+        out = (a >> lsb) & ((1 << size) - 1)
+        self.reg_write(r, 1, rt, out)
+        msb = lsb + msbd
+        for i in range(32):
+            r[GEN + i] = (a >> i) & 1
+        r[GEN + 32 + msb] = 1
+        r[GEN + 64 + lsb] = 1
+        r[GEN + 96], r[GEN + 97], r[GEN + 98] = a & ((1 << (msb + 1)) - 1), a & ((1 << lsb) - 1), 1 << lsb
+        self.push(r)
+
+    def ins(self, rs, rt, lsb, size):
+        """INS rt, rs, lsb, size (generate_insert)."""
+        msb = lsb + size - 1
+        r = self.new_row(enc_r(0x1F, rs, rt, msb, lsb, 4))
+        r[OP["ins"]] = 1
+        a, b = self.reg_read(r, 0, rs), self.reg_read(r, 1, rt)
+        mask = (1 << size) - 1
+        out = (b & ~(mask << lsb) & 0xFFFFFFFF) | ((a & mask) << lsb)
+        self.reg_write(r, 2, rt, out)
+        for i in range(32):
+            r[GEN + i] = (a >> i) & 1
+        r[GEN + 32 + size - 1] = 1
+        r[GEN + 64 + lsb] = 1
+        r[GEN + 96], r[GEN + 97], r[GEN + 98] = b & ~(mask << lsb) & 0xFFFFFFFF, a & mask, 1 << lsb
+        self.push(r)
+
+    def ror(self, rt, rd, sa):
+        """ROTR rd, rt, sa (generate_ror)."""
+        r = self.new_row(enc_r(0, 1, rt, rd, sa, 2))
+        r[OP["ror"]] = 1
+        a = self.reg_read(r, 0, rt)
+        out = ((a >> sa) | (a << (32 - sa))) & 0xFFFFFFFF
+        self.reg_write(r, 1, rd, out)
+        for i in range(32):
+            r[GEN + i] = (a >> i) & 1
+        r[GEN + 64 + sa] = 1
+        self.push(r)
+
+    def maddu(self, rs, rt):
+        r = self.new_row(enc_r(0x1C, rs, rt, 0, 0, 1))
+        r[OP["maddu"]] = 1
+        a, b = self.reg_read(r, 0, rs), self.reg_read(r, 1, rt)
+        hi, lo = self.reg_read(r, 2, 33), self.reg_read(r, 3, 32)
+        total = a * b + (hi << 32) + lo
+        carry = total >> 64
+        total &= (1 << 64) - 1
+        self.reg_write(r, 4, 33, total >> 32)
+        self.reg_write(r, 5, 32, total & 0xFFFFFFFF)
+        r[GEN + 96] = carry << 32
+        self.push(r)
+
+    def syscall(self, kind):
+        """SYSCALL (syscall.rs:12-232); `kind` picks the branch, the argument registers must have been prepared accordingly."""
+        r = self.new_row(0xC)
+        r[OP["syscall"]] = 1
+        self.reg_read(r, 0, 2)
+        a0, a1, a2 = self.reg_read(r, 1, 4), self.reg_read(r, 2, 5), self.reg_read(r, 3, 6)
+        cond, sysnum, a0f, a1f = GEN, GEN + 12, GEN + 24, GEN + 27
+        v0, v1 = 0, 0
+        r[a0f + 0], r[a0f + 1] = int(a0 == 0), int(a0 in (1, 2))
+        r[a0f + 2] = int(not (r[a0f] or r[a0f + 1]))
+        if kind == "mmap":
+            r[sysnum + 1] = 1
+            heap = self.reg_read(r, 6, 34)
+            r[a0f + 2] = int(a0 != 0)
+            if a0 == 0:
+                mid = a1 & 0xFFF
+                r[cond + 0] = 1
+                r[a1f], r[sysnum + 10] = int(mid != 0), int(mid == 0)
+                size = a1 if mid == 0 else (a1 + 0x1000 - mid) & 0xFFFFFFFF
+                r[sysnum + 9] = size if mid else 0
+                r[cond + 1], r[cond + 2] = int(mid != 0), int(mid == 0)
+                v0 = heap
+                self.reg_write(r, 7, 34, heap + size)
+            else:
+                r[cond + 3] = 1
+                v0 = a0
+        elif kind == "brk":
+            r[sysnum + 2] = 1
+            brk = self.reg_read(r, 6, 37)
+            gt = a0 > brk
+            r[cond + 10], r[cond + 11] = int(gt), int(not gt)
+            v0 = a0 if gt else brk
+        elif kind == "clone":
+            r[sysnum + 3] = 1
+            v0 = 1
+        elif kind == "read":
+            r[sysnum + 5] = 1
+            r[a0f + 2] = int(a0 != 0)
+            r[cond + 4], r[cond + 5] = int(a0 != 0), int(a0 == 0)
+            v0, v1 = (0, 0) if a0 == 0 else (0xFFFFFFFF, 9)
+        elif kind == "write":
+            r[sysnum + 6] = 1
+            ok = a0 in (1, 2)
+            r[a0f + 2] = int(not ok)
+            r[cond + 6], r[cond + 7] = int(not ok), int(ok)
+            v0, v1 = (a2, 0) if ok else (0xFFFFFFFF, 9)
+        elif kind == "fcntl":
+            r[sysnum + 7] = 1
+            r[cond + 8], r[cond + 9] = int(a0 == 0), int(a0 in (1, 2))
+            v0, v1 = (0, 0) if a0 == 0 else (1, 0) if a0 in (1, 2) else (0xFFFFFFFF, 9)
+        elif kind == "set_thread_area":
+            r[sysnum + 8] = 1
+            self.reg_write(r, 6, 38, a0)
+        self.reg_write(r, 4, 2, v0)
+        self.reg_write(r, 5, 7, v1)
+        self.push(r)
+
+    def set_reg(self, reg, value):
+        """LUI + ORI would do this in a real program; the tests load registers through `binary_imm` / direct state edits before
+        the first use so that the first memory operation on the register is this write."""
+        r = self.new_row(0)
+        r[OP["nop"]] = 1
+        self.reg_write(r, 0, reg, value)
+        self.push(r)
+
+    # ---------------------------------------------------------------- output
+    def trace(self, log_n):
+        n = 1 << log_n
+        assert len(self.rows) <= n
+        t = np.zeros((W, n), dtype=np.uint64)
+        for i, r in enumerate(self.rows):
+            t[:, i] = np.array([v % P for v in r], dtype=np.uint64)
+        return t.reshape(-1)
+
+
+def sample_program(m):
+    """Every instruction class the CPU constraints speak about, with operands that exercise each alignment / branch outcome."""
+    vals = {8: 0x12345678, 9: 0x9ABCDEF0, 10: 0x00000005, 11: 0xFFFFFFFB, 12: 0x00000100, 13: 0, 14: 0x80000000, 15: 0x0000F00F}
+    for reg, v in vals.items():
+        m.set_reg(reg, v)
+    m.binary("addu", 8, 9, 16, 0x21, lambda a, b: a + b)
+    m.binary("subu", 8, 9, 17, 0x23, lambda a, b: a - b)
+    m.binary_imm("addiu", 9, 8, 18, 0xFFF0, lambda a, b: a + b)
+    for name in ("and", "or", "xor", "nor"):
+        m.logic(name, 8, 9, 19)
+    m.shift_imm("sll", 8, 16, 7)
+    m.shift_imm("srl", 9, 16, 31)
+    m.shift_imm("sra", 9, 16, 4)
+    m.shift_var("sllv", 10, 8, 16)
+    m.shift_var("srlv", 10, 9, 16)
+    m.shift_var("srav", 10, 9, 16)
+    for kind, rs, rt in (("eq", 8, 8), ("eq", 8, 9), ("ne", 8, 9), ("ne", 9, 9), ("le", 11, 0), ("le", 13, 0), ("le", 10, 0),
+                         ("gt", 10, 0), ("gt", 11, 0), ("lt", 11, 0), ("lt", 10, 0), ("ge", 10, 0), ("ge", 14, 0), ("ge", 13, 0)):
+        m.branch(kind, rs, rt, 0x0010 if rs != 11 else 0xFFF0)
+        m.nop()
+    m.set_reg(20, 0x2000)
+    m.jr(20)
+    m.nop()
+    m.set_reg(20, 0x3000)
+    m.jr(20, rd=21)
+    m.nop()
+    m.j(0x0123456)
+    m.nop()
+    m.j(0x0000400, link=True)
+    m.nop()
+    m.bal(0x0008)
+    m.nop()
+    m.bal(0xFFF8)
+    m.nop()
+    m.set_reg(22, 0x100)
+    for kind in ("sw", "sb", "sh", "swl", "swr", "sc"):
+        for off in (0, 1, 2, 3):
+            m.store(kind, 22, 8 if off & 1 else 9, off)
+    for kind in ("lw", "lb", "lbu", "lh", "lhu", "lwl", "lwr", "ll"):
+        for off in (0, 1, 2, 3):
+            m.load(kind, 22, 23, off)
+    m.set_reg(22, 0x10C)
+    m.load("lw", 22, 23, 0xFFF4)  # negative offset: 0x10C - 12 = 0x100
+    for reg in (8, 13, 14, 10, 11, 15):
+        m.count("clz", reg, 24)
+        m.count("clo", reg, 24)
+    for name in ("seb", "seh", "wsbh"):
+        m.signext(name, 9, 24)
+        m.signext(name, 8, 24)
+    m.set_reg(38, 0xCAFE)
+    for rd in (0, 29, 5):
+        m.rdhwr(24, rd)
+    for name in ("movn", "movz"):
+        m.condmov(name, 8, 10, 24)
+        m.condmov(name, 9, 13, 24)
+    m.teq(8, 9)
+    for lsb, size in ((0, 32), (0, 1), (31, 1), (4, 8), (12, 20), (7, 13)):
+        m.ext(9, 24, lsb, size)
+        m.ins(8, 24, lsb, size)
+    for sa in (0, 1, 13, 31):
+        m.ror(9, 24, sa)
+    m.set_reg(33, 0xFFFFFFFF)
+    m.set_reg(32, 0xFFFFFFFF)
+    m.maddu(11, 11)   # overflows 64 bits
+    m.maddu(10, 12)
+    for kind, a0, a1 in (("mmap", 0, 0x1234), ("mmap", 0, 0x3000), ("mmap", 0x5000, 0x10), ("brk", 0x7FFFFFFF, 0), ("brk", 1, 0),
+                         ("clone", 0, 0), ("read", 0, 0), ("read", 3, 0), ("write", 1, 0), ("write", 2, 0), ("write", 7, 0),
+                         ("fcntl", 0, 0), ("fcntl", 1, 0), ("fcntl", 9, 0), ("set_thread_area", 0x77, 0), ("other", 0, 0)):
+        m.set_reg(4, a0)
+        m.set_reg(5, a1)
+        m.set_reg(6, 0x40)
+        m.set_reg(37, 0x40000000)
+        m.syscall(kind)
+    m.nop()
+    return m

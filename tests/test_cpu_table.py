@@ -1,0 +1,106 @@
+"""CpuStark (cpu/cpu_stark.rs:260-285, 741 constraints): the oracle's restatement vanishes on rows produced the way the reference's
+witness generators fill them (tests/cpu_fixtures.py: every instruction class the constraints mention), every constraint is live
+(some single-cell corruption makes it nonzero), and the proof of the table verifies; the GPU kernel is bit-exact against it."""
+import numpy as np
+import pytest
+
+from zkm_amd import tables as T
+from . import cpu_fixtures as CF
+from .test_gpu_tables import fake_ctl_aux
+
+P = 0xFFFFFFFF00000001
+LOG_N = 8
+
+
+@pytest.fixture(scope="module")
+def machine():
+    return CF.sample_program(CF.Machine())
+
+
+def test_cpu_constraints_vanish_on_generated_rows(oracle, machine):
+    trace = machine.trace(LOG_N)
+    count, bad = oracle.debug_constraints(T.TABLE_CPU, trace, 259, LOG_N)
+    assert count == 741 and bad is None
+    flags = trace.reshape(259, -1)[7:40].sum(axis=1)
+    exercised = {n for n, c in zip(CF.OPS, flags) if c}
+    assert exercised >= {"binary_op", "binary_imm_op", "logic_op", "movz_op", "movn_op", "clz_op", "clo_op", "shift", "shift_imm", "jumps",
+                         "jumpi", "jumpdirect", "branch", "m_op_load", "m_op_store", "nop", "ext", "ins", "maddu", "rdhwr", "signext8",
+                         "signext16", "swaphalf", "teq", "ror", "syscall"}
+
+
+def test_every_cpu_constraint_is_live(oracle, machine):
+    """Single-cell corruptions (+1 and +2^32) of the generated rows: every constraint except the channel-3..8 bootstrap address
+    checks (the fixture boots through channels 0..2) and the last-row check becomes nonzero for at least one of them."""
+    n = 1 << LOG_N
+    rows = machine.trace(LOG_N).reshape(259, n).T.copy()
+    live = np.zeros(741, dtype=bool)
+    for r in range(len(machine.rows)):
+        for c in range(259):
+            old = rows[r, c]
+            for delta in (1, 1 << 32):
+                rows[r, c] = (int(old) + delta) % P
+                live |= oracle.row_constraints(T.TABLE_CPU, rows[r], rows[(r + 1) % n], r == 0, r == n - 1) != 0
+                if r:
+                    live |= oracle.row_constraints(T.TABLE_CPU, rows[r - 1], rows[r], r == 1, False) != 0
+            rows[r, c] = old
+    dead = set(np.nonzero(~live)[0].tolist())
+    assert dead <= {1} | set(range(9, 21)), sorted(dead)
+
+
+def test_cpu_table_proof_verifies_and_rejects_corruption(oracle, machine):
+    trace = machine.trace(LOG_N)
+    aux = fake_ctl_aux(LOG_N)
+    proof = oracle.prove(trace, LOG_N, aux, [2], ncols=259, table_id=T.TABLE_CPU)
+    assert oracle.verify(proof, 3, [2], ncols=259, table_id=T.TABLE_CPU) == 0
+    n = 1 << LOG_N
+    t = trace.reshape(259, n)
+    cases = []
+    for name in ("branch", "m_op_load", "m_op_store", "syscall", "ext", "ins", "ror", "maddu", "clz_op", "jumps", "signext8"):
+        r = int(np.nonzero(t[CF.OP[name]])[0][0])
+        cases.append((name, CF.ch({"syscall": 4, "ins": 2, "jumps": 0}.get(name, 1), 5), r))          # a channel value the instruction constrains
+    cases.append(("boot", CF.IS_BOOT, 0))
+    for name, col, r in cases:
+        bad = trace.copy()
+        bad[col * n + r] = (int(bad[col * n + r]) + 1) % P
+        p2 = oracle.prove(bad, LOG_N, aux, [2], ncols=259, table_id=T.TABLE_CPU)
+        assert oracle.verify(p2, 3, [2], ncols=259, table_id=T.TABLE_CPU) != 0, name
+
+
+@pytest.mark.gpu
+def test_cpu_quotient_and_proof_are_bit_exact(ctx, zkm, oracle, machine):
+    trace = machine.trace(LOG_N)
+    aux = fake_ctl_aux(LOG_N)
+    want = oracle.prove(trace, LOG_N, aux, [2], ncols=259, table_id=T.TABLE_CPU)
+    got = ctx.prove_single_table(trace, LOG_N, aux, [2], ncols=259, table_id=T.TABLE_CPU)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing word %d" % bad[0]
+    assert oracle.verify(got, 3, [2], ncols=259, table_id=T.TABLE_CPU) == 0
+    # arbitrary (invalid) rows: every constraint is nonzero, so the quotient values check all 741 expressions at once
+    rng = np.random.default_rng(9)
+    log_n = 6
+    rnd = rng.integers(0, P, 259 << log_n, dtype=np.uint64)
+    aux = fake_ctl_aux(log_n)
+    alphas = [int(x) for x in rng.integers(1, P, 2, dtype=np.uint64)]
+    tb_o, ab_o = oracle.batch_from_values(rnd, 259, log_n), oracle.batch_from_values(aux, 3, log_n)
+    want = oracle.quotient(tb_o, ab_o, [2], alphas, table_id=T.TABLE_CPU)
+    tb, ab = zkm.PolynomialBatch.from_values(ctx, rnd, 259, log_n), zkm.PolynomialBatch.from_values(ctx, aux, 3, log_n)
+    got = ctx.quotient(tb, ab, [2], alphas, table_id=T.TABLE_CPU)
+    assert (np.asarray(got) == np.asarray(want)).all()
+    for nal in (1,):
+        want = oracle.quotient(tb_o, ab_o, [2], alphas[:nal], table_id=T.TABLE_CPU)
+        got = ctx.quotient(tb, ab, [2], alphas[:nal], table_id=T.TABLE_CPU)
+        assert (np.asarray(got) == np.asarray(want)).all()
+
+
+@pytest.mark.gpu
+def test_cpu_table_large_proof_verifies(ctx, oracle):
+    """2^14 rows (the sample program repeated): GPU proof accepted by the oracle's verifier."""
+    m = CF.Machine()
+    for _ in range(60):
+        CF.sample_program(m)
+    log_n = 14
+    trace = m.trace(log_n)
+    assert oracle.debug_constraints(T.TABLE_CPU, trace, 259, log_n)[1] is None
+    aux = fake_ctl_aux(log_n)
+    got = ctx.prove_single_table(trace, log_n, aux, [2], ncols=259, table_id=T.TABLE_CPU)
+    assert oracle.verify(got, 3, [2], ncols=259, table_id=T.TABLE_CPU) == 0

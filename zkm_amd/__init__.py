@@ -23,7 +23,7 @@ LOGIC_COLS = 69
 KECCAK_COLS = 2431
 POSEIDON_SPONGE_COLS = 110
 TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY, TABLE_POSEIDON_SPONGE = 0, 1, 2, 3, 4, 5
-TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRESS_SPONGE, TABLE_ARITHMETIC = 6, 7, 8, 9, 10
+TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRESS_SPONGE, TABLE_ARITHMETIC, TABLE_CPU = 6, 7, 8, 9, 10, 11
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [

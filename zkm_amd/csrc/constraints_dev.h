@@ -776,6 +776,442 @@ __device__ void eval_arithmetic_constraints(const gl_t* __restrict__ lv, size_t 
     }
 }
 
+// CpuStark (cpu/cpu_stark.rs:260-285).  Emission order: bootstrap_kernel.rs:308-353, decode.rs:66-100, jumps.rs (jump / jumpi /
+// jumpdirect, then branch), membus.rs:35-48, memio.rs (load :175-437, store :738-961), shift.rs:18-124, count.rs:10-75,
+// syscall.rs:12-232, bits.rs:9-64, misc.rs (rdhwr, condmov, teq, ext, ror, ins, maddu).  Columns: cpu/columns/mod.rs:62-96,
+// ops.rs:10-45, general.rs (union of the syscall / misc / io / logic views).  nv = lv + dnext.
+// Bit-string recombinations are built from byte / prefix sums instead of one 32-term sum per candidate value.
+namespace cpu {
+enum { IS_BOOT = 0, CONTEXT = 2, CODE_CONTEXT = 3, PROGRAM_COUNTER = 4, NEXT_PC = 5, KERNEL = 6, BR = 40, OPC = 50, RS = 56, RT = 61, RD = 66, SHAMT = 71,
+       FUNC = 76, GEN = 86, MEMIO = 188, CH = 205 };
+enum { BINARY = 7, BINARY_IMM, EQ_ISZERO, LOGIC, LOGIC_IMM, MOVZ, MOVN, CLZ, CLO, SHIFT, SHIFT_IMM, KECCAK_GENERAL, JUMPS, JUMPI, JUMPDIRECT,
+       BRANCH, PC_OP, GET_CONTEXT, SET_CONTEXT, EXIT_KERNEL, M_OP_LOAD, M_OP_STORE, NOP, EXT, INS, MADDU, RDHWR, SIGNEXT8, SIGNEXT16, SWAPHALF,
+       TEQ, ROR, SYSCALL };
+enum { USED = 0, IS_READ = 1, CTX = 2, SEG = 3, VIRT = 4, VAL = 5 };
+constexpr gl_t P32 = 1ULL << 32;
+constexpr gl_t INV_2_32 = 18446744065119617026ULL;  // 2^-32 (jumps.rs:15)
+constexpr gl_t INV_2 = 9223372034707292161ULL;      // (p + 1) / 2
+
+struct row {
+    const gl_t* __restrict__ p;
+    size_t cs;
+    __device__ __forceinline__ gl_t operator()(int c) const { return p[(size_t)c * cs]; }
+    __device__ __forceinline__ gl_t ch(int i, int f) const { return p[(size_t)(CH + 6 * i + f) * cs]; }
+    // sum_{i < n} col[base + i] << (i + shift)
+    __device__ __forceinline__ gl_t le(int base, int n, int shift = 0) const {
+        gl_t acc = 0;
+        for (int i = 0; i < n; i++) acc = gl_add(acc, gl_mul((*this)(base + i), (gl_t)1 << (i + shift)));
+        return acc;
+    }
+};
+__device__ __forceinline__ gl_t word(gl_t b0, gl_t b1, gl_t b2, gl_t b3) {
+    return gl_add(gl_add(b0, gl_mul(b1, 1ULL << 8)), gl_add(gl_mul(b2, 1ULL << 16), gl_mul(b3, 1ULL << 24)));
+}
+
+// memio.rs enforce_half_word :65-77 / enforce_byte :106-129
+template <int NA>
+__device__ __forceinline__ void half_word(consumer_t<NA>& k, gl_t op, gl_t rs1, gl_t mem, gl_t v1, gl_t v0) {
+    k.constraint(gl_mul(op, gl_add(gl_mul(gl_sub(rs1, 1), gl_sub(mem, v0)), gl_mul(rs1, gl_sub(mem, v1)))));
+}
+struct byte_sel_t { gl_t rs0, rs1, aux, w00, w10, w01; };
+template <int NA>
+__device__ __forceinline__ void byte_sel(consumer_t<NA>& k, const byte_sel_t& s, gl_t op, gl_t mem, gl_t v00, gl_t v10, gl_t v01, gl_t v11) {
+    k.constraint(gl_mul(op, gl_sub(gl_mul(s.rs0, s.rs1), s.aux)));
+    gl_t sum = gl_add(gl_add(gl_mul(gl_sub(mem, v00), s.w00), gl_mul(gl_sub(mem, v10), s.w10)),
+                      gl_add(gl_mul(gl_sub(mem, v01), s.w01), gl_mul(gl_sub(mem, v11), s.aux)));
+    k.constraint(gl_mul(sum, op));
+}
+}  // namespace cpu
+
+template <int NA>
+__device__ void eval_cpu_constraints(const gl_t* __restrict__ lvp, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
+    using namespace cpu;
+    const row lv{lvp, cs}, nv{lvp + dnext, cs};
+    // ---- bootstrap
+    {
+        gl_t boot = lv(IS_BOOT), d = gl_sub(nv(IS_BOOT), boot);
+        k.first_row(gl_sub(boot, 1));
+        k.last_row(boot);
+        k.transition(gl_mul(d, gl_add(d, 1)));
+#pragma unroll 1
+        for (int i = 0; i < 9; i++) {
+            gl_t f = gl_mul(boot, lv.ch(i, USED));
+            k.constraint(gl_mul(f, lv.ch(i, CTX)));
+            k.constraint(gl_mul(f, lv.ch(i, SEG)));  // Segment::Code = 0
+        }
+#pragma unroll 1
+        for (int i = 0; i < 9; i++) k.transition(gl_mul(d, lv.ch(i, USED)));
+    }
+    // ---- decode
+    {
+        gl_t km = lv(KERNEL);
+        k.constraint(gl_mul(km, gl_sub(km, 1)));
+#pragma unroll 1
+        for (int i = 0; i < 6; i++) {
+            gl_t b = lv(OPC + i);
+            k.constraint(gl_mul(b, gl_sub(b, 1)));
+        }
+        const int flags[15] = {EQ_ISZERO, KECCAK_GENERAL, JUMPS, BRANCH, PC_OP, GET_CONTEXT, SET_CONTEXT, EXIT_KERNEL,
+                               LOGIC, BINARY, BINARY_IMM, SHIFT, SHIFT_IMM, M_OP_LOAD, M_OP_STORE};
+        gl_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < 15; i++) {
+            gl_t f = lv(flags[i]);
+            k.constraint(gl_mul(f, gl_sub(f, 1)));
+            sum = gl_add(sum, f);
+        }
+        k.constraint(gl_mul(sum, gl_sub(sum, 1)));
+    }
+    // shared instruction fields
+    const gl_t rs_f = lv.le(RS, 5), rt_f = lv.le(RT, 5), rd_f = lv.le(RD, 5), sa_f = lv.le(SHAMT, 5), fn_f = lv.le(FUNC, 6);
+    const gl_t imm16 = gl_add(gl_add(fn_f, gl_mul(sa_f, 1ULL << 6)), gl_mul(rd_f, 1ULL << 11));  // insn[15:0]
+    const gl_t sign16 = lv(RD + 4);                                                               // insn[15]
+    const gl_t pc = lv(PROGRAM_COUNTER), npc_next = nv(NEXT_PC);
+    // sign_extend(imm16 << 2): 18 low bits + 14 copies of the sign
+    const gl_t off4 = gl_add(gl_mul(imm16, 4), gl_mul(sign16, 0xFFFC0000ULL));
+    // ---- jumps
+    {
+        gl_t is_jump = lv(JUMPS), is_jumpi = lv(JUMPI), is_jd = lv(JUMPDIRECT);
+        gl_t is_link = gl_mul(is_jump, lv(FUNC)), is_linki = gl_mul(is_jumpi, lv(OPC));
+        k.constraint(gl_mul(is_jump, gl_sub(npc_next, lv.ch(0, VAL))));
+        k.constraint(gl_mul(is_jump, gl_sub(rs_f, lv.ch(0, VIRT))));
+        gl_t index26 = gl_add(gl_add(imm16, gl_mul(rt_f, 1ULL << 16)), gl_mul(rs_f, 1ULL << 21));
+        gl_t aux = lv.ch(2, VAL);
+        k.constraint(gl_mul(is_jumpi, gl_sub(npc_next, gl_add(aux, gl_mul(index26, 4)))));
+        k.constraint(gl_mul(is_jd, gl_sub(aux, off4)));
+        gl_t dst = gl_add(gl_add(pc, 4), aux);
+        k.constraint(gl_mul(gl_mul(is_jd, gl_sub(npc_next, dst)), gl_sub(gl_add(npc_next, P32), dst)));
+        k.constraint(gl_mul(gl_add(gl_add(is_link, is_linki), is_jd), gl_sub(gl_add(pc, 8), lv.ch(1, VAL))));
+        gl_t link_reg = lv.ch(1, VIRT);
+        k.constraint(gl_mul(is_link, gl_sub(link_reg, rd_f)));
+        k.constraint(gl_mul(gl_add(is_linki, is_jd), gl_sub(link_reg, 31)));
+    }
+    // ---- branch
+    {
+        gl_t f = lv(BRANCH), sj = lv(BR + 0), fgt = lv(BR + 1), flt = lv(BR + 2), feq = lv(BR + 3);
+        gl_t is_gt = lv(BR + 4), is_lt = lv(BR + 5), is_eq = lv(BR + 6), is_ge = lv(BR + 7), is_le = lv(BR + 8), is_ne = lv(BR + 9);
+        gl_t norm = gl_add(gl_add(is_eq, is_ne), gl_add(is_le, is_gt)), special = gl_add(is_ge, is_lt);
+        gl_t src1 = lv.ch(0, VAL), src2 = lv.ch(1, VAL), aux1 = lv.ch(2, VAL), aux2 = lv.ch(3, VAL), aux3 = lv.ch(4, VAL), aux4 = lv.ch(5, VAL);
+        gl_t nf = gl_sub(1, f);
+        k.constraint(gl_mul(sj, gl_sub(1, sj)));
+        k.constraint(gl_mul(sj, nf));
+        k.constraint(gl_mul(f, gl_sub(1, gl_add(norm, special))));
+        k.constraint(gl_mul(f, gl_sub(1, gl_add(gl_add(flt, fgt), feq))));
+        k.constraint(gl_mul(f, gl_sub(aux4, off4)));
+        gl_t dst = gl_add(gl_add(pc, 4), aux4);
+        k.constraint(gl_mul(gl_mul(sj, gl_sub(npc_next, dst)), gl_sub(gl_add(npc_next, P32), dst)));
+        k.constraint(gl_mul(gl_mul(f, gl_sub(1, sj)), gl_sub(npc_next, gl_add(pc, 8))));
+        gl_t ca = gl_sub(gl_add(aux1, src2), src1), cb = gl_sub(gl_add(aux2, src1), src2);
+        gl_t fca = gl_mul(f, ca), fcb = gl_mul(f, cb);
+        k.constraint(gl_mul(fca, gl_sub(ca, P32)));
+        k.constraint(gl_mul(fcb, gl_sub(cb, P32)));
+        k.constraint(gl_mul(gl_mul(f, aux1), gl_sub(gl_add(aux1, aux2), P32)));
+        k.constraint(gl_mul(gl_mul(f, aux3), gl_sub(1, aux3)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(0, VIRT), rs_f)));
+        gl_t rt_reg = lv.ch(1, VIRT);
+        k.constraint(gl_mul(norm, gl_sub(rt_reg, rt_f)));
+        k.constraint(gl_mul(gl_mul(special, rt_reg), gl_sub(1, rt_reg)));
+        k.constraint(gl_mul(fca, gl_sub(P32, ca)));
+        gl_t lt = gl_mul(ca, INV_2_32);
+        k.constraint(gl_mul(flt, gl_sub(1, lt)));
+        k.constraint(gl_mul(fcb, gl_sub(P32, cb)));
+        gl_t gt = gl_mul(cb, INV_2_32);
+        k.constraint(gl_mul(fgt, gl_sub(1, gt)));
+        gl_t ne = gl_add(lt, gt);
+        k.constraint(gl_mul(feq, ne));
+        // x xor aux3 = x + aux3 - 2 x aux3
+        gl_t lt2 = gl_sub(gl_add(flt, aux3), gl_mul(gl_add(flt, flt), aux3));
+        gl_t gt2 = gl_sub(gl_add(fgt, aux3), gl_mul(gl_add(fgt, fgt), aux3));
+        k.constraint(gl_mul(is_eq, nf));
+        k.constraint(gl_mul(is_eq, gl_sub(sj, gl_sub(1, ne))));
+        k.constraint(gl_mul(is_ne, nf));
+        k.constraint(gl_mul(is_ne, gl_sub(sj, ne)));
+        k.constraint(gl_mul(is_le, nf));
+        k.constraint(gl_mul(is_le, gl_sub(sj, gl_sub(1, gt2))));
+        k.constraint(gl_mul(is_ge, nf));
+        k.constraint(gl_mul(is_ge, gl_sub(sj, gl_sub(1, lt2))));
+        k.constraint(gl_mul(is_gt, nf));
+        k.constraint(gl_mul(is_gt, gl_sub(sj, gt2)));
+        k.constraint(gl_mul(is_lt, nf));
+        k.constraint(gl_mul(is_lt, gl_sub(sj, lt2)));
+    }
+    // ---- membus
+    k.constraint(gl_sub(lv(CODE_CONTEXT), gl_mul(gl_sub(1, lv(KERNEL)), lv(CONTEXT))));
+#pragma unroll 1
+    for (int i = 0; i < 9; i++) {
+        gl_t u = lv.ch(i, USED);
+        k.constraint(gl_mul(u, gl_sub(u, 1)));
+    }
+    // ---- memio: io view = rs_le (GEN..), rt_le (GEN + 32..), mem_le (GEN + 64..), aux_rs0_mul_rs1 (GEN + 96)
+    {
+        gl_t R[4], M[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            R[j] = lv.le(GEN + 32 + 8 * j, 8);
+            M[j] = lv.le(GEN + 64 + 8 * j, 8);
+        }
+        const gl_t rs0 = lv(GEN), rs1 = lv(GEN + 1);
+        const gl_t virt = lv.le(GEN + 2, 30, 2);
+        const gl_t rs_from_bits = gl_add(virt, gl_add(rs0, gl_add(rs1, rs1)));
+        const gl_t rt_word = word(R[0], R[1], R[2], R[3]), mem_word = word(M[0], M[1], M[2], M[3]);
+        const gl_t m7 = lv(GEN + 64 + 7), m15 = lv(GEN + 64 + 15), m23 = lv(GEN + 64 + 23), m31 = lv(GEN + 64 + 31);
+        const gl_t aux_filter = lv(MEMIO + 15), rs = lv.ch(0, VAL), rt = lv.ch(1, VAL), mem = lv.ch(3, VAL);
+        const gl_t virt_raw = gl_add(rs, gl_add(imm16, gl_mul(sign16, 0xFFFF0000ULL)));
+        byte_sel_t s;
+        s.rs0 = rs0; s.rs1 = rs1; s.aux = lv(GEN + 96);
+        s.w00 = gl_add(gl_sub(gl_sub(s.aux, rs1), rs0), 1); s.w10 = gl_sub(s.aux, rs0); s.w01 = gl_sub(s.aux, rs1);
+        const gl_t addr_check = gl_mul(gl_mul(aux_filter, gl_sub(rs_from_bits, virt_raw)), gl_sub(gl_add(rs_from_bits, P32), virt_raw));
+#pragma unroll 1
+        for (int store = 0; store < 2; store++) {
+            gl_t f = gl_mul(lv(store ? M_OP_STORE : M_OP_LOAD), lv(OPC + 5));
+            k.constraint(gl_mul(f, gl_sub(1, aux_filter)));
+            k.constraint(gl_mul(f, gl_sub(lv.ch(0, SEG), 4)));  // Segment::RegisterFile
+            k.constraint(gl_mul(f, gl_sub(lv.ch(1, SEG), 4)));
+            k.constraint(addr_check);
+            k.constraint(gl_mul(f, gl_sub(rt_word, rt)));
+            k.constraint(gl_mul(f, gl_sub(virt, lv.ch(2, VIRT))));
+            if (!store) {
+                const gl_t lo16 = gl_add(M[0], gl_mul(M[1], 256)), hi16 = gl_add(M[2], gl_mul(M[3], 256));
+                half_word(k, lv(MEMIO + 0), rs1, mem, gl_add(lo16, gl_mul(m15, 0xFFFF0000ULL)), gl_add(hi16, gl_mul(m31, 0xFFFF0000ULL)));
+                byte_sel(k, s, lv(MEMIO + 1), mem, mem_word, word(R[0], M[0], M[1], M[2]), word(R[0], R[1], M[0], M[1]),
+                         word(R[0], R[1], R[2], M[0]));
+                k.constraint(gl_mul(lv(MEMIO + 2), gl_sub(mem, mem_word)));
+                byte_sel(k, s, lv(MEMIO + 3), mem, M[3], M[2], M[1], M[0]);
+                half_word(k, lv(MEMIO + 4), rs1, mem, lo16, hi16);
+                byte_sel(k, s, lv(MEMIO + 5), mem, word(M[3], R[1], R[2], R[3]), word(M[2], M[3], R[2], R[3]), word(M[1], M[2], M[3], R[3]),
+                         mem_word);
+                k.constraint(gl_mul(lv(MEMIO + 11), gl_sub(mem, mem_word)));
+                byte_sel(k, s, lv(MEMIO + 14), mem, gl_add(M[3], gl_mul(m31, 0xFFFFFF00ULL)), gl_add(M[2], gl_mul(m23, 0xFFFFFF00ULL)),
+                         gl_add(M[1], gl_mul(m15, 0xFFFFFF00ULL)), gl_add(M[0], gl_mul(m7, 0xFFFFFF00ULL)));
+            } else {
+                byte_sel(k, s, lv(MEMIO + 6), mem, word(M[0], M[1], M[2], R[0]), word(M[0], M[1], R[0], M[3]), word(M[0], R[0], M[2], M[3]),
+                         word(R[0], M[1], M[2], M[3]));
+                half_word(k, lv(MEMIO + 7), rs1, mem, word(R[0], R[1], M[2], M[3]), word(M[0], M[1], R[0], R[1]));
+                byte_sel(k, s, lv(MEMIO + 8), mem, rt_word, word(R[1], R[2], R[3], M[3]), word(R[2], R[3], M[2], M[3]),
+                         word(R[3], M[1], M[2], M[3]));
+                k.constraint(gl_mul(lv(MEMIO + 9), gl_sub(mem, rt_word)));
+                byte_sel(k, s, lv(MEMIO + 10), mem, word(M[0], M[1], M[2], R[0]), word(M[0], M[1], R[0], R[1]), word(M[0], R[0], R[1], R[2]),
+                         rt_word);
+                k.constraint(gl_mul(lv(MEMIO + 12), gl_sub(mem, rt_word)));
+                k.constraint(gl_mul(lv(MEMIO + 13), mem));
+            }
+            k.constraint(gl_mul(f, lv.ch(6, USED)));
+            k.constraint(gl_mul(f, lv.ch(7, USED)));
+        }
+    }
+    // ---- shift: variable then immediate; the power of two comes from the shift table through channel 3
+    {
+        const gl_t used3 = lv.ch(3, USED), rd1 = gl_sub(lv.ch(3, IS_READ), 1), ctx3 = lv.ch(3, CTX), seg3 = gl_sub(lv.ch(3, SEG), 3),
+                   virt3 = lv.ch(3, VIRT);
+#pragma unroll 1
+        for (int imm = 0; imm < 2; imm++) {
+            gl_t f = lv(imm ? SHIFT_IMM : SHIFT), disp = imm ? sa_f : lv.ch(0, VAL);
+            k.constraint(gl_mul(gl_mul(f, used3), rd1));
+            k.constraint(gl_mul(f, ctx3));
+            k.constraint(gl_mul(f, seg3));
+            k.constraint(gl_mul(f, gl_sub(virt3, disp)));
+        }
+    }
+    // ---- count (CLZ / CLO)
+    {
+        gl_t fz = lv(CLZ), fo = lv(CLO), f = gl_add(fo, fz);
+        k.constraint(gl_mul(f, gl_sub(lv.le(OPC, 6), 0x1c)));
+        k.constraint(gl_mul(fz, gl_sub(fn_f, 0x20)));
+        k.constraint(gl_mul(fo, gl_sub(fn_f, 0x21)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(0, VIRT), rs_f)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(1, VIRT), rd_f)));
+        gl_t sum = 0;
+#pragma unroll 1
+        for (int i = 0; i < 32; i++) {
+            gl_t b = lv(GEN + i);
+            k.constraint(gl_mul(gl_mul(f, b), gl_sub(1, b)));
+            sum = gl_add(sum, gl_mul(b, (gl_t)1 << i));
+        }
+        gl_t rs = lv.ch(0, VAL), rd = lv.ch(1, VAL);
+        k.constraint(gl_mul(fz, gl_sub(rs, sum)));
+        k.constraint(gl_mul(fo, gl_sub(gl_sub(0xffffffffULL, rs), sum)));
+        gl_t partial = lv(GEN + 31);  // bits[i..] as an integer, Horner from the top
+        k.constraint(gl_mul(gl_mul(f, partial), rd));
+#pragma unroll 1
+        for (int i = 30; i >= 0; i--) {
+            partial = gl_add(gl_add(partial, partial), lv(GEN + i));
+            const int j = 30 - i;
+            gl_t is_eq = lv(GEN + 32 + j), inv = lv(GEN + 64 + j), diff = gl_sub(partial, 1), feq = gl_mul(f, is_eq);
+            k.constraint(gl_mul(feq, diff));
+            k.constraint(gl_mul(f, gl_sub(gl_add(gl_mul(diff, inv), is_eq), 1)));
+            k.constraint(gl_mul(feq, gl_sub(rd, (gl_t)(31 - i))));
+        }
+        gl_t is_eq = lv(GEN + 32 + 31), inv = lv(GEN + 64 + 31), feq = gl_mul(f, is_eq);
+        k.constraint(gl_mul(feq, partial));
+        k.constraint(gl_mul(f, gl_sub(gl_add(gl_mul(partial, inv), is_eq), 1)));
+        k.constraint(gl_mul(feq, gl_sub(rd, 32)));
+    }
+    // ---- syscall: general = cond[12] sysnum[12] a0[3] a1
+    {
+        const gl_t f = lv(SYSCALL);
+        auto cond = [&](int i) { return lv(GEN + i); };
+        auto sysnum = [&](int i) { return lv(GEN + 12 + i); };
+        const gl_t a0_is0 = lv(GEN + 24), a0_is12 = lv(GEN + 25), a0_else = lv(GEN + 26), sz_nz = lv(GEN + 27);
+        const gl_t a0 = lv.ch(1, VAL), a1 = lv.ch(2, VAL), a2 = lv.ch(3, VAL), rv0 = lv.ch(4, VAL), rv1 = lv.ch(5, VAL);
+        const gl_t c6 = lv.ch(6, VAL), rheap = lv.ch(7, VAL);
+        const gl_t bad0 = gl_sub(0xFFFFFFFFULL, rv0), bad1 = gl_sub(9, rv1), zero1 = gl_sub(0, rv1);
+        auto fc = [&](gl_t c, gl_t x) { k.constraint(gl_mul(gl_mul(f, c), x)); };
+        auto def = [&](gl_t c, gl_t a, gl_t b) { k.constraint(gl_mul(f, gl_sub(c, gl_mul(a, b)))); };
+        const gl_t is_map = sysnum(1);
+        def(cond(0), is_map, a0_is0);
+        def(cond(1), cond(0), sz_nz);
+        fc(cond(1), gl_sub(gl_add(c6, sysnum(9)), rheap));
+        def(cond(2), cond(0), sysnum(10));
+        fc(cond(2), gl_sub(gl_add(c6, a1), rheap));
+        fc(cond(0), gl_sub(c6, rv0));
+        def(cond(3), is_map, a0_else);
+        fc(cond(3), gl_sub(a0, rv0));
+        const gl_t is_brk = sysnum(2);
+        fc(is_brk, gl_sub(1, gl_add(cond(10), cond(11))));
+        fc(cond(10), gl_sub(a0, rv0));
+        fc(cond(11), gl_sub(c6, rv0));
+        fc(is_brk, zero1);
+        const gl_t is_clone = sysnum(3);
+        fc(is_clone, gl_sub(1, rv0));
+        fc(is_clone, zero1);
+        const gl_t is_read = sysnum(5);
+        def(cond(4), is_read, a0_else);
+        fc(cond(4), bad0);
+        fc(cond(4), bad1);
+        def(cond(5), is_read, a0_is0);
+        fc(cond(5), gl_sub(0, rv0));
+        fc(cond(5), zero1);
+        const gl_t is_write = sysnum(6);
+        def(cond(6), is_write, a0_else);
+        fc(cond(6), bad0);
+        fc(cond(6), bad1);
+        def(cond(7), is_write, a0_is12);
+        fc(cond(7), gl_sub(a2, rv0));
+        fc(cond(7), zero1);
+        const gl_t is_fcntl = sysnum(7);
+        def(cond(8), is_fcntl, a0_is0);
+        fc(cond(8), gl_sub(0, rv0));
+        fc(cond(8), zero1);
+        def(cond(9), is_fcntl, a0_is12);
+        fc(cond(9), gl_sub(1, rv0));
+        fc(cond(9), zero1);
+        const gl_t rest = gl_sub(gl_sub(is_fcntl, cond(8)), cond(9));
+        def(rest, is_fcntl, a0_else);
+        fc(rest, bad0);
+        fc(rest, bad1);
+        fc(sysnum(8), gl_sub(a0, c6));
+    }
+    // ---- bits (SEB / SEH / WSBH) on io().rt_le
+    {
+        gl_t seh = lv(SIGNEXT16), seb = lv(SIGNEXT8), wsbh = lv(SWAPHALF), f = gl_add(gl_add(seh, seb), wsbh);
+        k.constraint(gl_mul(f, gl_sub(lv.ch(0, VIRT), rt_f)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(1, VIRT), rd_f)));
+        gl_t B[4] = {0, 0, 0, 0};
+#pragma unroll 1
+        for (int i = 0; i < 32; i++) {
+            gl_t b = lv(GEN + 32 + i);
+            k.constraint(gl_mul(gl_mul(f, b), gl_sub(1, b)));
+            B[i >> 3] = gl_add(B[i >> 3], gl_mul(b, (gl_t)1 << (i & 7)));
+        }
+        gl_t rd = lv.ch(1, VAL);
+        k.constraint(gl_mul(f, gl_sub(lv.ch(0, VAL), word(B[0], B[1], B[2], B[3]))));
+        k.constraint(gl_mul(seb, gl_sub(rd, gl_add(B[0], gl_mul(lv(GEN + 32 + 7), 0xFFFFFF00ULL)))));
+        k.constraint(gl_mul(seh, gl_sub(rd, gl_add(gl_add(B[0], gl_mul(B[1], 256)), gl_mul(lv(GEN + 32 + 15), 0xFFFF0000ULL)))));
+        k.constraint(gl_mul(wsbh, gl_sub(rd, word(B[1], B[0], B[3], B[2]))));
+    }
+    // ---- misc: rs_bits (GEN..), is_msb (GEN + 32..), is_lsb (GEN + 64..), auxm, auxl, auxs, rd_index, rd_index_eq_0, rd_index_eq_29
+    const gl_t auxm = lv(GEN + 96), auxl = lv(GEN + 97), auxs = lv(GEN + 98);
+    {  // rdhwr
+        gl_t f = lv(RDHWR), rd_index = lv(GEN + 99), eq0 = lv(GEN + 100), eq29 = lv(GEN + 101), rt_val = lv.ch(0, VAL);
+        k.constraint(gl_mul(f, gl_sub(lv.ch(0, VIRT), rt_f)));
+        k.constraint(gl_mul(f, gl_sub(rd_index, rd_f)));
+        gl_t f0 = gl_mul(f, eq0), f29 = gl_mul(f, eq29);
+        k.constraint(gl_mul(f0, rd_index));
+        k.constraint(gl_mul(f0, gl_sub(rt_val, 1)));
+        k.constraint(gl_mul(f29, gl_sub(rd_index, 29)));
+        k.constraint(gl_mul(f29, gl_sub(rt_val, lv.ch(1, VAL))));
+        k.constraint(gl_mul(gl_mul(f, gl_sub(gl_sub(1, eq29), eq0)), rt_val));
+    }
+    {  // condmov
+        gl_t rs = lv.ch(0, VAL), rt = lv.ch(1, VAL), rd = lv.ch(2, VAL), out = lv.ch(3, VAL), mov = lv.ch(4, VAL);
+        gl_t movn = lv(MOVN), movz = lv(MOVZ), f = gl_add(movn, movz), is_ne = gl_mul(lv(GEN), rt), no_mov = gl_sub(1, mov);
+        k.constraint(gl_mul(movn, gl_sub(mov, is_ne)));
+        k.constraint(gl_mul(movz, gl_sub(mov, gl_sub(1, is_ne))));
+        k.constraint(gl_mul(gl_mul(f, mov), no_mov));
+        k.constraint(gl_mul(f, gl_sub(out, gl_add(gl_mul(mov, rs), gl_mul(no_mov, rd)))));
+    }
+    {  // teq
+        gl_t f = lv(TEQ);
+        k.constraint(gl_mul(f, gl_sub(lv.ch(1, VIRT), rt_f)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(0, VIRT), rs_f)));
+        k.constraint(gl_mul(f, gl_sub(1, gl_mul(gl_sub(lv.ch(0, VAL), lv.ch(1, VAL)), lv(GEN)))));
+    }
+    {  // ext
+        gl_t f = lv(EXT);
+        k.constraint(gl_mul(f, gl_sub(lv.ch(1, VIRT), rt_f)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(0, VIRT), rs_f)));
+        gl_t msb = gl_add(sa_f, rd_f);
+        k.constraint(gl_mul(f, gl_sub(gl_add(gl_mul(lv.ch(1, VAL), auxs), auxl), auxm)));
+        gl_t prefix = 0;  // rs_bits[0..i)
+#pragma unroll 1
+        for (int i = 0; i < 32; i++) {
+            gl_t lpartial = prefix;
+            prefix = gl_add(prefix, gl_mul(lv(GEN + i), (gl_t)1 << i));
+            gl_t fm = gl_mul(f, lv(GEN + 32 + i)), fl = gl_mul(f, lv(GEN + 64 + i));
+            k.constraint(gl_mul(fm, gl_sub(msb, (gl_t)i)));
+            k.constraint(gl_mul(fm, gl_sub(auxm, prefix)));
+            k.constraint(gl_mul(fl, gl_sub(sa_f, (gl_t)i)));
+            k.constraint(gl_mul(fl, gl_sub(auxl, lpartial)));
+            k.constraint(gl_mul(fl, gl_sub(auxs, (gl_t)1 << i)));
+        }
+    }
+    {  // ror: rotate right by i = (x >> i) + (x mod 2^i) << (32 - i)
+        gl_t f = lv(ROR);
+        k.constraint(gl_mul(f, gl_sub(lv.ch(1, VIRT), rd_f)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(0, VIRT), rt_f)));
+        gl_t rd_val = lv.ch(1, VAL), hi = lv.le(GEN, 32), lo = 0;
+#pragma unroll 1
+        for (int i = 0; i < 32; i++) {
+            gl_t fs = gl_mul(f, lv(GEN + 64 + i));
+            k.constraint(gl_mul(fs, gl_sub(sa_f, (gl_t)i)));
+            k.constraint(gl_mul(fs, gl_sub(rd_val, gl_add(hi, gl_mul(lo, (gl_t)1 << ((32 - i) & 63))))));
+            gl_t b = lv(GEN + i);
+            lo = gl_add(lo, gl_mul(b, (gl_t)1 << i));
+            hi = gl_mul(gl_sub(hi, b), INV_2);
+        }
+    }
+    {  // ins
+        gl_t f = lv(INS);
+        k.constraint(gl_mul(f, gl_sub(lv.ch(1, VIRT), rt_f)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(2, VIRT), rt_f)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(0, VIRT), rs_f)));
+        k.constraint(gl_mul(f, gl_sub(gl_sub(lv.ch(2, VAL), auxm), gl_mul(auxl, auxs))));
+        gl_t size = gl_sub(rd_f, sa_f), prefix = 0;
+#pragma unroll 1
+        for (int i = 0; i < 32; i++) {
+            prefix = gl_add(prefix, gl_mul(lv(GEN + i), (gl_t)1 << i));
+            gl_t fm = gl_mul(f, lv(GEN + 32 + i)), fl = gl_mul(f, lv(GEN + 64 + i));
+            k.constraint(gl_mul(fl, gl_sub(sa_f, (gl_t)i)));
+            k.constraint(gl_mul(fl, gl_sub(auxs, (gl_t)1 << i)));
+            k.constraint(gl_mul(fm, gl_sub(size, (gl_t)i)));
+            k.constraint(gl_mul(fm, gl_sub(auxl, prefix)));
+        }
+    }
+    {  // maddu
+        gl_t f = lv(MADDU);
+        k.constraint(gl_mul(f, gl_sub(lv.ch(0, VIRT), rs_f)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(1, VIRT), rt_f)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(2, VIRT), 33)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(4, VIRT), 33)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(3, VIRT), 32)));
+        k.constraint(gl_mul(f, gl_sub(lv.ch(5, VIRT), 32)));
+        gl_t result = gl_add(gl_mul(lv.ch(4, VAL), P32), lv.ch(5, VAL)), addend = gl_add(gl_mul(lv.ch(2, VAL), P32), lv.ch(3, VAL));
+        gl_t mul = gl_mul(lv.ch(0, VAL), lv.ch(1, VAL));
+        k.constraint(gl_mul(gl_mul(f, auxm), gl_sub(auxm, P32)));
+        k.constraint(gl_mul(f, gl_sub(gl_sub(gl_add(mul, addend), gl_mul(auxm, P32)), result)));
+    }
+}
+
 template <int TABLE, int NA>
 __device__ __forceinline__ void eval_table_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {
     if constexpr (TABLE == ZKM_TABLE_POSEIDON) eval_poseidon_constraints<NA>(lv, cs, k);
@@ -788,6 +1224,7 @@ __device__ __forceinline__ void eval_table_constraints(const gl_t* __restrict__ 
     else if constexpr (TABLE == ZKM_TABLE_SHA_EXTEND_SPONGE) eval_sha_extend_sponge_constraints<NA>(lv, cs, dnext, k);
     else if constexpr (TABLE == ZKM_TABLE_SHA_COMPRESS) eval_sha_compress_constraints<NA>(lv, cs, dnext, k);
     else if constexpr (TABLE == ZKM_TABLE_SHA_COMPRESS_SPONGE) eval_sha_compress_sponge_constraints<NA>(lv, cs, k);
-    else eval_arithmetic_constraints<NA>(lv, cs, dnext, k);
+    else if constexpr (TABLE == ZKM_TABLE_ARITHMETIC) eval_arithmetic_constraints<NA>(lv, cs, dnext, k);
+    else eval_cpu_constraints<NA>(lv, cs, dnext, k);
 }
 

@@ -511,6 +511,7 @@ size_t zkm_table_width(int table_id) {
         case ZKM_TABLE_SHA_COMPRESS: return ZKM_SHA_COMPRESS_COLS;
         case ZKM_TABLE_SHA_COMPRESS_SPONGE: return ZKM_SHA_COMPRESS_SPONGE_COLS;
         case ZKM_TABLE_ARITHMETIC: return ZKM_ARITHMETIC_COLS;
+        case ZKM_TABLE_CPU: return ZKM_CPU_COLS;
         default: return 0;
     }
 }

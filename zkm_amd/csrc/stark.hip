@@ -178,7 +178,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
     {
         static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory", "quotient_poseidon_sponge", "quotient_sha_extend", "quotient_sha_extend_sponge", "quotient_sha_compress",
-                                            "quotient_sha_compress_sponge", "quotient_arithmetic"};
+                                            "quotient_sha_compress_sponge", "quotient_arithmetic", "quotient_cpu"};
         zkm_prof_scope ps(c, names[table_id]);
         dim3 grid((size + 255) / 256), block(256);
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
@@ -206,7 +206,9 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             case 18: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_COMPRESS_SPONGE, 1); break;
             case 19: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_SHA_COMPRESS_SPONGE, 2); break;
             case 20: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_ARITHMETIC, 1); break;
-            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_ARITHMETIC, 2); break;
+            case 21: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_ARITHMETIC, 2); break;
+            case 22: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_CPU, 1); break;
+            default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_CPU, 2); break;
         }
 #undef ZKM_LAUNCH_QUOTIENT
         ZKM_HIP_CHECK(hipGetLastError());

@@ -9,9 +9,9 @@ include/zkm_hip.h); mirrors
 from .ctl import CtlTable
 
 TABLE_POSEIDON, TABLE_LOGIC, TABLE_KECCAK_SPONGE, TABLE_KECCAK, TABLE_MEMORY, TABLE_POSEIDON_SPONGE = 0, 1, 2, 3, 4, 5
-TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRESS_SPONGE, TABLE_ARITHMETIC = 6, 7, 8, 9, 10
+TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRESS_SPONGE, TABLE_ARITHMETIC, TABLE_CPU = 6, 7, 8, 9, 10, 11
 WIDTH = {TABLE_POSEIDON: 262, TABLE_LOGIC: 69, TABLE_KECCAK_SPONGE: 470, TABLE_KECCAK: 2431, TABLE_MEMORY: 13, TABLE_POSEIDON_SPONGE: 110,
-         TABLE_SHA_EXTEND: 78, TABLE_SHA_EXTEND_SPONGE: 76, TABLE_SHA_COMPRESS: 224, TABLE_SHA_COMPRESS_SPONGE: 127, TABLE_ARITHMETIC: 54}
+         TABLE_SHA_EXTEND: 78, TABLE_SHA_EXTEND_SPONGE: 76, TABLE_SHA_COMPRESS: 224, TABLE_SHA_COMPRESS_SPONGE: 127, TABLE_ARITHMETIC: 54, TABLE_CPU: 259}
 
 # LogicStark columns (logic.rs:25-50)
 LOGIC_IS_AND, LOGIC_IS_OR, LOGIC_IS_XOR, LOGIC_IS_NOR = 0, 1, 2, 3
