@@ -577,3 +577,35 @@ def sample_program(m):
         m.syscall(kind)
     m.nop()
     return m
+
+
+def build_cpu_segment(oracle, log_cpu=8, repeat=1):
+    """CPU + Memory + Logic + Arithmetic with every cross-table lookup the reference defines among them: ctl_arithmetic (two CPU
+    lookers), the CPU looker of ctl_logic and the nine CPU channels of ctl_memory (all_stark.rs:156-164, 326-338, 480-486)."""
+    from zkm_amd import tables as T
+    from zkm_amd.ctl import CtlTable
+    from . import arith_fixtures as A
+    m = Machine()
+    for _ in range(repeat):
+        sample_program(m)
+    cpu = m.trace(log_cpu)
+    code = {"and": T.OP_AND, "or": T.OP_OR, "xor": T.OP_XOR, "nor": T.OP_NOR}
+    lops = np.array([(code[name], a, b) for name, a, b, _ in m.logic_ops], dtype=np.uint32)
+    log_logic = max(3, int(np.ceil(np.log2(len(lops)))))
+    logic = oracle.logic_trace(lops, log_logic)
+    flag = {"addu": A.IS_ADDU, "subu": A.IS_SUBU, "addiu": A.IS_ADDIU, "sll": A.IS_SLL, "srl": A.IS_SRL, "sra": A.IS_SRA,
+            "sllv": A.IS_SLLV, "srlv": A.IS_SRLV, "srav": A.IS_SRAV}
+    arith = A.generate_trace([(flag[name], a, b) for name, a, b, _, _ in m.arith_ops])
+    # (ctx, seg, virt, timestamp, is_read, value) in program order
+    mem_ops = np.array([(ctx, seg, virt, ts, is_read, value) for is_read, ctx, seg, virt, value, ts in m.mem_ops], dtype=np.uint64)
+    log_mem = int(np.ceil(np.log2(len(mem_ops)))) + 1
+    memory, natural = oracle.memory_trace(mem_ops, log_mem)
+    if natural <= (1 << (log_mem - 1)):
+        log_mem -= 1
+        memory, natural = oracle.memory_trace(mem_ops, log_mem)
+    cc, cm, cl, ca = CtlTable(), CtlTable(), CtlTable(), CtlTable()
+    tables = [(T.TABLE_CPU, cpu, 259, log_cpu, cc), (T.TABLE_MEMORY, memory, 13, log_mem, cm), (T.TABLE_LOGIC, logic, 69, log_logic, cl),
+              (T.TABLE_ARITHMETIC, arith, 54, 16, ca)]
+    ctls = [T.ctl_arithmetic(0, 3, cc, ca), (T.logic_lookers_cpu(0, cc), (2, T.logic_ctl_data(cl))),
+            (T.memory_lookers_cpu(0, cc), (1, T.memory_ctl_data(cm)))]
+    return tables, ctls, m

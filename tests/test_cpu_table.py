@@ -104,3 +104,30 @@ def test_cpu_table_large_proof_verifies(ctx, oracle):
     aux = fake_ctl_aux(log_n)
     got = ctx.prove_single_table(trace, log_n, aux, [2], ncols=259, table_id=T.TABLE_CPU)
     assert oracle.verify(got, 3, [2], ncols=259, table_id=T.TABLE_CPU) == 0
+
+
+def test_cpu_segment_cross_table_lookups(oracle):
+    """CPU + Memory + Logic + Arithmetic: ctl_arithmetic, the CPU looker of ctl_logic and the nine CPU memory channels hold on
+    the generated segment, the oracle's proofs verify, and a changed register value breaks only the cross-table check."""
+    tables, ctls, m = CF.build_cpu_segment(oracle)
+    assert oracle.check_ctls(tables, ctls) == 0
+    proofs, chal, offs = oracle.prove_with_traces(tables, ctls)
+    assert oracle.verify_all(tables, ctls, proofs, chal) == 0
+    n = 1 << tables[0][3]
+    cpu = tables[0][1].copy()
+    r = int(np.nonzero(cpu.reshape(259, n)[CF.OP["binary_op"]])[0][0])
+    cpu[CF.ch(2, 5) * n + r] += 1                     # ADDU result: unconstrained inside the CPU table, pinned by the lookups
+    assert oracle.debug_constraints(T.TABLE_CPU, cpu, 259, tables[0][3])[1] is None
+    bad = [(T.TABLE_CPU, cpu) + tables[0][2:]] + tables[1:]
+    assert oracle.check_ctls(bad, ctls) != 0
+
+
+@pytest.mark.gpu
+def test_cpu_segment_proofs_are_bit_exact(ctx, oracle):
+    tables, ctls, m = CF.build_cpu_segment(oracle)
+    want, wchal, woffs = oracle.prove_with_traces(tables, ctls)
+    got, chal, offs = ctx.prove_with_traces(tables, ctls)
+    assert offs == woffs and (chal == wchal).all()
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing word %d" % bad[0]
+    assert oracle.verify_all(tables, ctls, got, chal) == 0

@@ -415,3 +415,160 @@ def arithmetic_ctl_rows(t: CtlTable):
         t.column(local=[(reg, 1), (reg + 1, 1 << 16)])
     f = t.sum([c for c, _ in ARITH_COMBINED_OPS])
     return t.colset(range(first, first + 4), filter_constants=[f])
+
+
+# ---------------------------------------------------------------------------------------------------------------- CpuStark
+# cpu/columns/mod.rs:62-96; the CTL column builders are cpu/cpu_stark.rs:25-250.
+CPU_OP_BINARY, CPU_OP_BINARY_IMM, CPU_OP_LOGIC, CPU_OP_SHIFT, CPU_OP_SHIFT_IMM = 7, 8, 10, 16, 17
+CPU_OPCODE_BITS, CPU_FUNC_BITS = 50, 76
+CPU_IS_POSEIDON_SPONGE, CPU_IS_KECCAK_SPONGE, CPU_IS_SHA_EXTEND_SPONGE, CPU_IS_SHA_COMPRESS_SPONGE = 82, 83, 84, 85
+CPU_GENERAL, CPU_CLOCK, CPU_CHANNELS, CPU_NUM_GP_CHANNELS, CPU_NUM_CHANNELS = 86, 204, 205, 9, 10
+KS_LEN = 38
+SCS_OUT_HX = 64
+
+
+def cpu_channel(i, field):
+    """field: 0 used, 1 is_read, 2 addr_context, 3 addr_segment, 4 addr_virtual, 5 value."""
+    return CPU_CHANNELS + 6 * i + field
+
+
+def _cpu_binops(t: CtlTable):
+    for i in range(3):
+        t.single(cpu_channel(i, 5))
+
+
+def cpu_looking_logic(t: CtlTable):
+    """cpu_stark::ctl_data_logic() / ctl_filter_logic() (:131-145)."""
+    first = t.le_bits(list(range(CPU_OPCODE_BITS, CPU_OPCODE_BITS + 6)) + list(range(CPU_FUNC_BITS, CPU_FUNC_BITS + 6)))
+    _cpu_binops(t)
+    return t.colset(range(first, first + 4), filter_constants=[t.single(CPU_OP_LOGIC)])
+
+
+def cpu_looking_arithmetic(t: CtlTable):
+    """cpu_stark::ctl_arithmetic_base_rows() (:150-171): filter = binary_op + shift + shift_imm."""
+    first = t.le_bits(list(range(CPU_OPCODE_BITS, CPU_OPCODE_BITS + 6)) + list(range(CPU_FUNC_BITS, CPU_FUNC_BITS + 6)))
+    _cpu_binops(t)
+    return t.colset(range(first, first + 4), filter_constants=[t.sum([CPU_OP_BINARY, CPU_OP_SHIFT, CPU_OP_SHIFT_IMM])])
+
+
+def cpu_looking_arithmetic_imm(t: CtlTable):
+    """cpu_stark::ctl_arithmetic_imm_base_rows() (:173-186)."""
+    first = t.le_bits(range(CPU_OPCODE_BITS, CPU_OPCODE_BITS + 6))
+    _cpu_binops(t)
+    return t.colset(range(first, first + 4), filter_constants=[t.single(CPU_OP_BINARY_IMM)])
+
+
+def cpu_looking_memory(t: CtlTable, channel):
+    """cpu_stark::ctl_data_gp_memory(channel) / ctl_filter_gp_memory(channel) (:220-246): timestamp = clock * NUM_CHANNELS."""
+    first = t.single(cpu_channel(channel, 1))
+    for f in (2, 3, 4, 5):
+        t.single(cpu_channel(channel, f))
+    t.column(local=[(CPU_CLOCK, CPU_NUM_CHANNELS)])
+    return t.colset(range(first, first + 6), filter_constants=[t.single(cpu_channel(channel, 0))])
+
+
+def _cpu_looking_sponge(t: CtlTable, nchan, nvalues, flag):
+    first = t.single(cpu_channel(0, 5))
+    for i in range(1, nchan):
+        t.single(cpu_channel(i, 5))
+    t.column(local=[(CPU_CLOCK, CPU_NUM_CHANNELS)])
+    for i in range(nvalues):
+        t.single(CPU_GENERAL + i)
+    return t.colset(range(first, first + nchan + 1 + nvalues), filter_constants=[t.single(flag)])
+
+
+def cpu_looking_keccak_sponge(t: CtlTable):
+    """cpu_stark::ctl_data_keccak_sponge() (:25-43): context, segment, virt, len, timestamp, khash().value[8]."""
+    return _cpu_looking_sponge(t, 4, 8, CPU_IS_KECCAK_SPONGE)
+
+
+def cpu_looking_poseidon_sponge(t: CtlTable):
+    """cpu_stark::ctl_data_poseidon_sponge() (:94-112): ..., hash().value[4]."""
+    return _cpu_looking_sponge(t, 4, 4, CPU_IS_POSEIDON_SPONGE)
+
+
+def cpu_looking_sha_extend_sponge(t: CtlTable):
+    """cpu_stark::ctl_data_sha_extend_sponge() (:45-61): context, segment, virt, timestamp, element().value."""
+    return _cpu_looking_sponge(t, 3, 1, CPU_IS_SHA_EXTEND_SPONGE)
+
+
+def cpu_looking_sha_compress_sponge(t: CtlTable):
+    """cpu_stark::ctl_data_sha_compress_sponge() (:63-80): context, segment, virt, timestamp, shash().value[8]."""
+    return _cpu_looking_sponge(t, 3, 8, CPU_IS_SHA_COMPRESS_SPONGE)
+
+
+def keccak_sponge_looked_data(t: CtlTable):
+    """keccak_sponge_stark::ctl_looked_data() / ctl_looked_filter() (:28-50, :167-171): the digest as eight big-endian words in
+    reverse order."""
+    first = t.single(KS_CONTEXT)
+    for c in (KS_SEGMENT, KS_VIRT, KS_LEN, KS_TIMESTAMP):
+        t.single(c)
+    for i in reversed(range(8)):
+        t.column(local=[(KS_DIGEST + 4 * i + j, 1 << (24 - 8 * j)) for j in range(4)])
+    f = t.sum(range(KS_FINAL_LEN, KS_FINAL_LEN + KECCAK_RATE_BYTES))
+    return t.colset(range(first, first + 13), filter_constants=[f])
+
+
+def poseidon_sponge_looked_data(t: CtlTable):
+    """poseidon_sponge_stark::ctl_looked_data() / ctl_looked_filter() (:28-43, :102-106)."""
+    first = t.single(PS_CONTEXT)
+    for c in [PS_SEGMENT, PS_VIRT, PS_LEN, PS_TIMESTAMP] + list(range(PS_DIGEST, PS_DIGEST + 4)):
+        t.single(c)
+    f = t.sum(range(PS_FINAL_LEN, PS_FINAL_LEN + POSEIDON_RATE_BYTES))
+    return t.colset(range(first, first + 9), filter_constants=[f])
+
+
+def sha_extend_sponge_looked_data(t: CtlTable):
+    """sha_extend_sponge_stark::ctl_looked_data() / ctl_looking_sha_extend_filter() (:55-62, :97-101)."""
+    first = t.single(SES_CONTEXT)
+    for c in (SES_SEGMENT, SES_OUT_VIRT, SES_TIMESTAMP):
+        t.single(c)
+    t.le_bytes(range(SES_W_I, SES_W_I + 4))
+    return t.colset(range(first, first + 5), filter_constants=[t.sum(range(SES_ROUND, SES_ROUND + 48))])
+
+
+def sha_compress_sponge_looked_data(t: CtlTable):
+    """sha_compress_sponge_stark::ctl_looked_data() / ctl_looked_filter() (:49-61, :89-95); output_hx[i] = WrappingAdd2Op
+    {value[4], carry[2]}."""
+    first = t.single(SCS_CONTEXT)
+    for c in (SCS_SEGMENT, SCS_HX_VIRT, SCS_TIMESTAMP):
+        t.single(c)
+    for i in range(8):
+        t.le_bytes(range(SCS_OUT_HX + 6 * i, SCS_OUT_HX + 6 * i + 4))
+    return t.colset(range(first, first + 12), filter_constants=[t.single(SCS_IS_REAL)])
+
+
+def ctl_arithmetic(cpu_index, arith_index, cpu_ctl, arith_ctl):
+    """all_stark::ctl_arithmetic() (all_stark.rs:156-164)."""
+    return [(cpu_index, cpu_looking_arithmetic(cpu_ctl)), (cpu_index, cpu_looking_arithmetic_imm(cpu_ctl))], \
+        (arith_index, arithmetic_ctl_rows(arith_ctl))
+
+
+def logic_lookers_cpu(cpu_index, cpu_ctl):
+    """The CPU looker of all_stark::ctl_logic() (all_stark.rs:326-338)."""
+    return [(cpu_index, cpu_looking_logic(cpu_ctl))]
+
+
+def memory_lookers_cpu(cpu_index, cpu_ctl):
+    """The nine general-purpose channels of the CPU in all_stark::ctl_memory() (all_stark.rs:480-486)."""
+    return [(cpu_index, cpu_looking_memory(cpu_ctl, ch)) for ch in range(CPU_NUM_GP_CHANNELS)]
+
+
+def ctl_keccak_sponge(cpu_index, sponge_index, cpu_ctl, sponge_ctl):
+    """all_stark::ctl_keccak_sponge() (all_stark.rs:242-254)."""
+    return [(cpu_index, cpu_looking_keccak_sponge(cpu_ctl))], (sponge_index, keccak_sponge_looked_data(sponge_ctl))
+
+
+def ctl_poseidon_sponge(cpu_index, sponge_index, cpu_ctl, sponge_ctl):
+    """all_stark::ctl_poseidon_sponge() (all_stark.rs:197-209)."""
+    return [(cpu_index, cpu_looking_poseidon_sponge(cpu_ctl))], (sponge_index, poseidon_sponge_looked_data(sponge_ctl))
+
+
+def ctl_sha_extend_sponge(cpu_index, sponge_index, cpu_ctl, sponge_ctl):
+    """all_stark::ctl_sha_extend_sponge() (all_stark.rs:284-296)."""
+    return [(cpu_index, cpu_looking_sha_extend_sponge(cpu_ctl))], (sponge_index, sha_extend_sponge_looked_data(sponge_ctl))
+
+
+def ctl_sha_compress_sponge(cpu_index, sponge_index, cpu_ctl, sponge_ctl):
+    """all_stark::ctl_sha_compress_sponge() (all_stark.rs:326-338)."""
+    return [(cpu_index, cpu_looking_sha_compress_sponge(cpu_ctl))], (sponge_index, sha_compress_sponge_looked_data(sponge_ctl))
