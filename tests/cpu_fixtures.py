@@ -609,3 +609,104 @@ def build_cpu_segment(oracle, log_cpu=8, repeat=1):
     ctls = [T.ctl_arithmetic(0, 3, cc, ca), (T.logic_lookers_cpu(0, cc), (2, T.logic_ctl_data(cl))),
             (T.memory_lookers_cpu(0, cc), (1, T.memory_ctl_data(cm)))]
     return tables, ctls, m
+
+
+def build_full_segment(oracle):
+    """All twelve tables and all fifteen cross-table lookups of all_stark::all_cross_table_lookups() (all_stark.rs:137-155) on one
+    small segment: the sample program plus Keccak / Poseidon / SHA-extend / SHA-compress precompile rows (generate_keccak ...,
+    witness/operation.rs:1101-1458: default rows carrying the clock, the sponge flag, the operation's address / length in the channel
+    values and its result in the shared general columns)."""
+    from zkm_amd import tables as T
+    from zkm_amd.ctl import CtlTable
+    from . import arith_fixtures as A
+    from . import logic_fixtures as LF
+    m = sample_program(Machine())
+    clock = [len(m.rows) + 2]
+
+    def schedule(stride):
+        def ts(count):
+            out = np.array([10 * (clock[0] + stride * k) for k in range(count)], dtype=np.uint64)
+            clock[0] += stride * count + 2
+            return out
+        return ts
+    kt, _, (kops, kin, kts, kmem) = LF.build4(oracle, log_sponge=3, ts=schedule(2))
+    pt, _, (pdata, poff, pmeta, pin, pts, pmem) = LF.build_poseidon_path(oracle, log_sponge=4, ts=schedule(2))
+    ct, _, (chx, cw, cmeta, cops, cmem) = LF.build_sha_compress_path(oracle, ncomp=1, ts=schedule(2))
+    et, _, (ew16, emeta, ein, ets, eops, emem) = LF.build_sha_extend_path(oracle, nblocks=1, ts=schedule(96))
+
+    flag_rows = {}
+
+    def add(ts, flag, chans, values):
+        c, rem = divmod(int(ts), 10)
+        assert rem == 0 and c not in flag_rows
+        flag_rows[c] = (flag, [int(v) for v in chans], [int(v) for v in values])
+    tr = kt[0][1].reshape(470, -1)
+    for r in np.nonzero(tr[T.KS_FINAL_LEN:T.KS_FINAL_LEN + 136].sum(axis=0))[0]:
+        words = [sum(int(tr[T.KS_DIGEST + 4 * i + j, r]) << (24 - 8 * j) for j in range(4)) for i in reversed(range(8))]
+        add(tr[T.KS_TIMESTAMP, r], T.CPU_IS_KECCAK_SPONGE, [tr[T.KS_CONTEXT, r], tr[T.KS_SEGMENT, r], tr[T.KS_VIRT, r], tr[T.KS_LEN, r]], words)
+    tr = pt[0][1].reshape(110, -1)
+    for r in np.nonzero(tr[T.PS_FINAL_LEN:T.PS_FINAL_LEN + 32].sum(axis=0))[0]:
+        add(tr[T.PS_TIMESTAMP, r], T.CPU_IS_POSEIDON_SPONGE, [tr[T.PS_CONTEXT, r], tr[T.PS_SEGMENT, r], tr[T.PS_VIRT, r], tr[T.PS_LEN, r]],
+            tr[T.PS_DIGEST:T.PS_DIGEST + 4, r])
+    tr = ct[0][1].reshape(127, -1)
+    for r in np.nonzero(tr[T.SCS_IS_REAL])[0]:
+        words = [sum(int(tr[T.SCS_OUT_HX + 6 * i + j, r]) << (8 * j) for j in range(4)) for i in range(8)]
+        add(tr[T.SCS_TIMESTAMP, r], T.CPU_IS_SHA_COMPRESS_SPONGE, [tr[T.SCS_CONTEXT, r], tr[T.SCS_SEGMENT, r], tr[T.SCS_HX_VIRT, r]], words)
+    tr = et[0][1].reshape(76, -1)
+    for r in np.nonzero(tr[T.SES_ROUND:T.SES_ROUND + 48].sum(axis=0))[0]:
+        w_i = sum(int(tr[T.SES_W_I + j, r]) << (8 * j) for j in range(4))
+        add(tr[T.SES_TIMESTAMP, r], T.CPU_IS_SHA_EXTEND_SPONGE, [tr[T.SES_CONTEXT, r], tr[T.SES_SEGMENT, r], tr[T.SES_OUT_VIRT, r]], [w_i])
+    while m.clock <= max(flag_rows):
+        r = [0] * W
+        r[CLOCK] = m.clock
+        if m.clock in flag_rows:
+            flag, chans, values = flag_rows[m.clock]
+            r[flag] = 1
+            for i, v in enumerate(chans):
+                r[ch(i, 5)] = v
+            for i, v in enumerate(values):
+                r[GEN + i] = v
+        m.rows.append(r)
+    log_cpu = int(np.ceil(np.log2(len(m.rows) + 1)))
+    cpu = m.trace(log_cpu)
+
+    code = {"and": T.OP_AND, "or": T.OP_OR, "xor": T.OP_XOR, "nor": T.OP_NOR}
+    lops = np.concatenate([np.array([(code[name], a, b) for name, a, b, _ in m.logic_ops], dtype=np.uint32), kops, eops, cops])
+    np.random.default_rng(78).shuffle(lops, axis=0)
+    log_logic = int(np.ceil(np.log2(len(lops))))
+    logic = oracle.logic_trace(lops, log_logic)
+    flag = {"addu": A.IS_ADDU, "subu": A.IS_SUBU, "addiu": A.IS_ADDIU, "sll": A.IS_SLL, "srl": A.IS_SRL, "sra": A.IS_SRA,
+            "sllv": A.IS_SLLV, "srlv": A.IS_SRLV, "srav": A.IS_SRAV}
+    arith = A.generate_trace([(flag[name], a, b) for name, a, b, _, _ in m.arith_ops])
+    cpu_mem = np.array([(ctx, seg, virt, ts, is_read, value) for is_read, ctx, seg, virt, value, ts in m.mem_ops], dtype=np.uint64)
+    mem_ops = np.concatenate([cpu_mem, kmem, pmem, emem, cmem])
+    log_mem = int(np.ceil(np.log2(len(mem_ops))))
+    while True:                                   # gap-filling rows (memory_stark.rs fill_gaps) may need a larger table
+        try:
+            memory, natural = oracle.memory_trace(mem_ops, log_mem)
+            break
+        except RuntimeError:
+            log_mem += 1
+
+    c = [CtlTable() for _ in range(12)]
+    AR, CPU, PO, PS, KK, KS, SE, SES, SC, SCS, LO, ME = range(12)      # Table::all() order (all_stark.rs:117-134)
+    tables = [(T.TABLE_ARITHMETIC, arith, 54, 16, c[AR]), (T.TABLE_CPU, cpu, 259, log_cpu, c[CPU]),
+              (T.TABLE_POSEIDON, pt[1][1], 262, pt[1][3], c[PO]), (T.TABLE_POSEIDON_SPONGE, pt[0][1], 110, pt[0][3], c[PS]),
+              (T.TABLE_KECCAK, kt[1][1], 2431, kt[1][3], c[KK]), (T.TABLE_KECCAK_SPONGE, kt[0][1], 470, kt[0][3], c[KS]),
+              (T.TABLE_SHA_EXTEND, et[1][1], 78, et[1][3], c[SE]), (T.TABLE_SHA_EXTEND_SPONGE, et[0][1], 76, et[0][3], c[SES]),
+              (T.TABLE_SHA_COMPRESS, ct[1][1], 224, ct[1][3], c[SC]), (T.TABLE_SHA_COMPRESS_SPONGE, ct[0][1], 127, ct[0][3], c[SCS]),
+              (T.TABLE_LOGIC, logic, 69, log_logic, c[LO]), (T.TABLE_MEMORY, memory, 13, log_mem, c[ME])]
+    logic_lookers = T.logic_lookers_cpu(CPU, c[CPU]) + [(KS, T.keccak_sponge_looking_logic(c[KS], i)) for i in range(T.NUM_LOGIC_CTLS)] + \
+        T.logic_lookers_sha_extend(SE, c[SE]) + T.logic_lookers_sha_compress(SC, c[SC])
+    memory_lookers = T.memory_lookers_cpu(CPU, c[CPU]) + T.memory_lookers_poseidon_sponge(PS, c[PS]) + \
+        T.memory_lookers_keccak_sponge(KS, c[KS]) + T.memory_lookers_sha_extend_sponge(SES, c[SES]) + \
+        T.memory_lookers_sha_compress_sponge(SCS, c[SCS]) + T.memory_lookers_sha_compress(SC, c[SC])
+    ctls = [T.ctl_arithmetic(CPU, AR, c[CPU], c[AR]),
+            T.ctl_poseidon_sponge(CPU, PS, c[CPU], c[PS]), T.ctl_poseidon_inputs(PS, PO, c[PS], c[PO]), T.ctl_poseidon_outputs(PS, PO, c[PS], c[PO]),
+            T.ctl_keccak_sponge(CPU, KS, c[CPU], c[KS]), T.ctl_keccak_inputs(KS, KK, c[KS], c[KK]), T.ctl_keccak_outputs(KS, KK, c[KS], c[KK]),
+            T.ctl_sha_extend_sponge(CPU, SES, c[CPU], c[SES]), T.ctl_sha_extend_inputs(SES, SE, c[SES], c[SE]),
+            T.ctl_sha_extend_outputs(SES, SE, c[SES], c[SE]),
+            T.ctl_sha_compress_sponge(CPU, SCS, c[CPU], c[SCS]), T.ctl_sha_compress_inputs(SCS, SC, c[SCS], c[SC]),
+            T.ctl_sha_compress_outputs(SCS, SC, c[SCS], c[SC]),
+            (logic_lookers, (LO, T.logic_ctl_data(c[LO]))), (memory_lookers, (ME, T.memory_ctl_data(c[ME])))]
+    return tables, ctls

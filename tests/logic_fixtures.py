@@ -105,10 +105,14 @@ def poseidon_sponge_ops(seed, target_rows, max_len=200):
     return data, off, meta.reshape(-1), rows, nops
 
 
-def build_poseidon_path(oracle, log_sponge=4, seed=41):
+def build_poseidon_path(oracle, log_sponge=4, seed=41, ts=None):
     """Memory + PoseidonSponge + Poseidon with the lookups the reference defines among them
     (all_stark.rs:169-195, 487-493)."""
     data, off, meta, rows, nops = poseidon_sponge_ops(seed, (1 << log_sponge) - 1)
+    if ts is not None:
+        meta = meta.reshape(-1, 4).copy()
+        meta[:, 3] = ts(nops)
+        meta = meta.reshape(-1)
     sponge, used = oracle.poseidon_sponge_trace(data, off, meta, log_sponge)
     assert used == rows
     inputs, ts = poseidon_inputs_from_sponge(sponge, log_sponge, rows)
@@ -145,12 +149,15 @@ def memory_ops_from_sponge(sponge_trace, log_n, rows):
     return np.array(ops, dtype=np.uint64).reshape(-1, 6)
 
 
-def build4(oracle, log_sponge=3, seed=23):
+def build4(oracle, log_sponge=3, seed=23, ts=None):
     """Memory + KeccakSponge + Keccak + Logic: the Keccak precompile's data path with every cross-table lookup the
     reference defines among these tables (all_stark.rs:214-240, 340-355, 479-542)."""
     data, off, meta, rows, nops = ops_for_rows(seed, (1 << log_sponge) - 1)
     meta = meta.reshape(-1, 4).copy()
     meta[:, 2] = np.arange(nops) * 512          # disjoint word ranges: reads of one address always see one value
+    if ts is not None:
+        meta[:, 3] = ts(nops)
+        meta[:, 0], meta[:, 1] = 0, 1               # keep clear of the CPU's register file / shift table / code segments
     meta = meta.reshape(-1)
     sponge, _ = oracle.keccak_sponge_trace(data, off, meta, log_sponge)
     ops = logic_ops_from_sponge(sponge, log_sponge, rows)
@@ -173,7 +180,7 @@ def build4(oracle, log_sponge=3, seed=23):
     return tables, ctls, (ops, inputs, ts, mem_ops)
 
 
-def build_sha_extend_path(oracle, nblocks=1, seed=51):
+def build_sha_extend_path(oracle, nblocks=1, seed=51, ts=None):
     """Memory + ShaExtendSponge + ShaExtend + Logic: SHA-256 message schedules with the lookups the reference defines among
     these tables (all_stark.rs:256-282, 356-385, 503-509)."""
     rng = np.random.default_rng(seed)
@@ -181,7 +188,7 @@ def build_sha_extend_path(oracle, nblocks=1, seed=51):
     meta = np.zeros((nblocks, 4), dtype=np.uint64)
     meta[:, 1] = 1
     meta[:, 2] = (1 << 22) + np.arange(nblocks) * 1024
-    meta[:, 3] = 7 + np.arange(nblocks) * 2000
+    meta[:, 3] = 7 + np.arange(nblocks) * 2000 if ts is None else ts(nblocks)
     log_s = int(np.ceil(np.log2(48 * nblocks + 1)))
     sponge, used = oracle.sha_extend_sponge_trace(w16, meta, log_s)
     n = 1 << log_s
@@ -218,7 +225,7 @@ def build_sha_extend_path(oracle, nblocks=1, seed=51):
     return tables, ctls, (w16, meta, inputs, ts, ops, mem_ops)
 
 
-def build_sha_compress_path(oracle, ncomp=1, seed=61):
+def build_sha_compress_path(oracle, ncomp=1, seed=61, ts=None):
     """Memory + ShaCompressSponge + ShaCompress + Logic: SHA-256 compressions with the lookups the reference defines among
     these tables (all_stark.rs:298-324, 387-470, 511-525)."""
     rng = np.random.default_rng(seed)
@@ -227,7 +234,7 @@ def build_sha_compress_path(oracle, ncomp=1, seed=61):
     meta = np.zeros((ncomp, 8), dtype=np.uint64)
     meta[:, 1] = 0                                        # hx: context 0, segment Code (witness/operation.rs:1318)
     meta[:, 2] = (1 << 23) + np.arange(ncomp) * 2048      # hx address
-    meta[:, 3] = 30 + np.arange(ncomp) * 10               # timestamp
+    meta[:, 3] = 30 + np.arange(ncomp) * 10 if ts is None else ts(ncomp)   # timestamp
     meta[:, 4] = (1 << 23) + np.arange(ncomp) * 2048 + 512  # w address
     log_c = int(np.ceil(np.log2(65 * ncomp + 1)))
     log_s = max(3, int(np.ceil(np.log2(ncomp + 1))))
