@@ -40,6 +40,11 @@ def table_cases(gen):
                                     np.array([[0, 0, 64, 9, 512, 0, 0, 0]], dtype=np.uint64), 7)
 
 
+def cpu_trace(log_n):
+    from . import cpu_fixtures as CF
+    return CF.sample_program(CF.Machine()).trace(log_n)
+
+
 def test_oracle_reproduces_goldens(oracle):
     for g in GOLD["ntt"]:
         r = oracle.ntt(seeded(g["seed"], g["ncols"] << g["log_n"]), g["log_n"], inverse=g["inverse"], coset_shift=g["coset_shift"])
@@ -54,6 +59,10 @@ def test_oracle_reproduces_goldens(oracle):
     for (tid, tr), g in zip(table_cases(oracle), GOLD["tables"]):
         assert tid == g["table_id"] and h(tr) == g["trace_sha256"]
         assert h(oracle.prove(tr, g["log_n"], fake_aux(g["log_n"]), [2], ncols=g["ncols"], table_id=tid)) == g["proof_sha256"]
+    g = GOLD["cpu"]
+    tr = cpu_trace(g["log_n"])
+    assert h(tr) == g["trace_sha256"]
+    assert h(oracle.prove(tr, g["log_n"], fake_aux(g["log_n"]), [2], ncols=259, table_id=11)) == g["proof_sha256"]
 
 
 @pytest.mark.gpu
@@ -78,3 +87,7 @@ def test_hip_path_reproduces_goldens_without_the_oracle(ctx, zkm):
     for (tid, tr), g in zip(table_cases(Gen()), GOLD["tables"]):
         assert h(tr) == g["trace_sha256"]
         assert h(ctx.prove_single_table(tr, g["log_n"], fake_aux(g["log_n"]), [2], ncols=g["ncols"], table_id=tid)) == g["proof_sha256"]
+    g = GOLD["cpu"]
+    tr = cpu_trace(g["log_n"])
+    assert h(tr) == g["trace_sha256"]
+    assert h(ctx.prove_single_table(tr, g["log_n"], fake_aux(g["log_n"]), [2], ncols=259, table_id=11)) == g["proof_sha256"]
