@@ -248,7 +248,10 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values) {
     b->digests = (gl_t*)c->alloc(dwords * sizeof(gl_t));
     bool dev = zkm_is_device_ptr(src);
     hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (src_is_values) {
+    if (src_is_values && dev) {
+        // device-resident values are only read (first NTT pass); the not-yet-used LDE buffer holds the intermediate passes
+        zkm_ntt_natural_ex(c, src, n, b->lde, n, b->coeffs, n, ncols, b->log_n, /*inverse=*/true, 0);
+    } else if (src_is_values) {
         // stage the values in the (not yet used) LDE buffer, transform there, land natural-order coefficients
         ZKM_HIP_CHECK(hipMemcpyAsync(b->lde, src, ncols * n * sizeof(gl_t), kind, c->stream));
         zkm_ntt_natural(c, b->lde, b->coeffs, ncols, n, n, b->log_n, /*inverse=*/true, 0);

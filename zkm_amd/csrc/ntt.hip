@@ -598,6 +598,22 @@ void zkm_lde_bitrev(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t ncols, uns
 }
 
 void zkm_ntt_natural(zkm_ctx* c, gl_t* in_scratch, gl_t* out, size_t ncols, size_t col_stride_in, size_t col_stride_out,
+                     unsigned log_n, bool inverse, uint64_t shift);
+// natural -> natural with a read-only input: `in` is only read by the first pass, `scratch` (same column stride as `in` is not
+// required) holds the intermediate passes.  in == scratch is allowed.
+void zkm_ntt_natural_ex(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* scratch, size_t cs_s, gl_t* out, size_t cs_out, size_t ncols,
+                        unsigned log_n, bool inverse, uint64_t shift) {
+    if (log_n >= 3 && log_n <= 24 && !c->use_baseline_ntt) {
+        ntt_natural_fast(c, in, cs_in, scratch, cs_s, out, cs_out, ncols, log_n, inverse, shift);
+        return;
+    }
+    if (in != scratch)
+        ZKM_HIP_CHECK(hipMemcpy2DAsync(scratch, cs_s * sizeof(gl_t), in, cs_in * sizeof(gl_t), sizeof(gl_t) << log_n, ncols,
+                                       hipMemcpyDeviceToDevice, c->stream));
+    zkm_ntt_natural(c, scratch, out, ncols, cs_s, cs_out, log_n, inverse, shift);
+}
+
+void zkm_ntt_natural(zkm_ctx* c, gl_t* in_scratch, gl_t* out, size_t ncols, size_t col_stride_in, size_t col_stride_out,
                      unsigned log_n, bool inverse, uint64_t shift) {
     size_t n = (size_t)1 << log_n, total = ncols << log_n;
     if (log_n >= 3 && log_n <= 24 && !c->use_baseline_ntt) {

@@ -107,6 +107,8 @@ void zkm_launch_poseidon_permute(zkm_ctx*, gl_t* states, size_t k);
 void zkm_launch_keccakf(zkm_ctx*, uint64_t* states, size_t k);
 // leaf digests of a column-major matrix (row j across ncols columns of stride `col_stride` words)
 void zkm_launch_merkle_leaves(zkm_ctx*, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests);
+void zkm_ntt_natural_ex(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* scratch, size_t cs_s, gl_t* out, size_t cs_out, size_t ncols,
+                        unsigned log_n, bool inverse, uint64_t shift);
 // leaf digests of row-major leaves formed from F2 SoA arrays: leaf k = 16 consecutive (c0,c1) pairs
 void zkm_launch_merkle_leaves_ext(zkm_ctx*, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests);
 void zkm_launch_merkle_compress(zkm_ctx*, const gl_t* children, gl_t* parents, size_t nparents);
