@@ -145,6 +145,9 @@ def test_full_segment_all_fifteen_lookups(oracle):
     assert oracle.check_ctls(tables, ctls) == 0
     proofs, chal, offs = oracle.prove_with_traces(tables, ctls, public_values=[1, 2, 3])
     assert oracle.verify_all(tables, ctls, proofs, chal, public_values=[1, 2, 3]) == 0
+    # auxiliary-column counts of the real AllStark (Arithmetic 22, Cpu 26, Poseidon 4, PoseidonSponge 40, Keccak 4,
+    # KeccakSponge 180, Logic 2, Memory 6; the SHA tables follow from the same rules)
+    assert [int(proofs[offs[i] + 3]) for i in range(12)] == [22, 26, 4, 40, 4, 180, 10, 24, 24, 40, 2, 6]
     n = 1 << tables[1][3]
     cpu = tables[1][1].copy()
     for flag in (T.CPU_IS_KECCAK_SPONGE, T.CPU_IS_POSEIDON_SPONGE, T.CPU_IS_SHA_EXTEND_SPONGE, T.CPU_IS_SHA_COMPRESS_SPONGE):
