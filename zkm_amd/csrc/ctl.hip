@@ -101,6 +101,37 @@ __global__ __launch_bounds__(256) void k_ctl_terms(ctl_dev d, uint32_t zi, const
     hsum[row] = total;
 }
 
+// Tables with many looking column sets and few rows (KeccakSponge: 136 + 34 sets, a few thousand rows) are latency-bound in
+// k_ctl_terms (one thread walks every set of its row); here blockIdx.y picks the helper column, and k_ctl_rowsum adds them up.
+__global__ __launch_bounds__(256) void k_ctl_helper(ctl_dev d, uint32_t zi, const gl_t* __restrict__ trace, size_t n, gl_t* __restrict__ helpers,
+                                                    int* __restrict__ bad) {
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const zkm_ctl_z z = d.zs[zi];
+    const uint32_t* ids = d.colset_ids + z.colset_off;
+    const uint32_t j = blockIdx.y;
+    const gl_t* lv = trace + row;
+    bool next_ok = row + 1 < n;
+    gl_t h = 0;
+    for (uint32_t e = 0; e < 2 && 2 * j + e < z.ncolsets; e++) {
+        const zkm_colset cs = d.colsets[ids[2 * j + e]];
+        gl_t f = ctl_eval_filter(d, cs, lv, n, 1, next_ok);
+        if (f == 1) {
+            h = gl_add(h, gl_inv(ctl_combine(d, cs, z.beta, z.gamma, lv, n, 1, next_ok)));
+        } else if (f != 0) {
+            *bad = 1;  // "Non-binary filter?" (cross_table_lookup.rs:741)
+        }
+    }
+    helpers[(size_t)j * n + row] = h;
+}
+__global__ __launch_bounds__(256) void k_ctl_rowsum(const gl_t* __restrict__ helpers, uint32_t nh, size_t n, gl_t* __restrict__ hsum) {
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    gl_t total = 0;
+    for (uint32_t j = 0; j < nh; j++) total = gl_add(total, helpers[(size_t)j * n + row]);
+    hsum[row] = total;
+}
+
 // additive suffix scan, segments of 64:  totals[s] = sum of segment s
 __global__ void k_sum_totals(const gl_t* __restrict__ a, size_t m, gl_t* __restrict__ out) {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,8 +208,16 @@ void zkm_ctl_data_device(zkm_ctx* c, const ctl_dev_owner& own, const gl_t* d_tra
     for (uint32_t i = 0; i < own.d.nzs; i++) {
         gl_t* helpers = zs[i].num_helpers ? d_aux + hstart * n : nullptr;
         {
-            zkm_prof_scope ps(c, "ctl_terms");
-            hipLaunchKernelGGL(k_ctl_terms, dim3((n + 255) / 256), dim3(256), 0, c->stream, own.d, i, d_trace, n, helpers, d_hsum, d_bad);
+            static const char* const names[] = {"ctl_terms_2^0", "ctl_terms_2^1", "ctl_terms_2^2", "ctl_terms_2^3", "ctl_terms_2^4", "ctl_terms_2^5", "ctl_terms_2^6", "ctl_terms_2^7", "ctl_terms_2^8", "ctl_terms_2^9", "ctl_terms_2^10", "ctl_terms_2^11", "ctl_terms_2^12", "ctl_terms_2^13", "ctl_terms_2^14", "ctl_terms_2^15", "ctl_terms_2^16", "ctl_terms_2^17", "ctl_terms_2^18", "ctl_terms_2^19", "ctl_terms_2^20", "ctl_terms_2^21", "ctl_terms_2^22", "ctl_terms_2^23", "ctl_terms_2^24"};
+            unsigned lg = 0; while (((size_t)1 << lg) < n && lg < 24) lg++;
+            zkm_prof_scope ps(c, getenv("ZKM_CTL_PROF") ? names[lg] : "ctl_terms");
+            const uint32_t nh = zs[i].num_helpers;
+            if (helpers && nh >= 4 && (n >> 8) * 1 < 4096) {  // few workgroups per launch otherwise: spread the column sets over blockIdx.y
+                hipLaunchKernelGGL(k_ctl_helper, dim3((n + 255) / 256, nh), dim3(256), 0, c->stream, own.d, i, d_trace, n, helpers, d_bad);
+                hipLaunchKernelGGL(k_ctl_rowsum, dim3((n + 255) / 256), dim3(256), 0, c->stream, helpers, nh, n, d_hsum);
+            } else {
+                hipLaunchKernelGGL(k_ctl_terms, dim3((n + 255) / 256), dim3(256), 0, c->stream, own.d, i, d_trace, n, helpers, d_hsum, d_bad);
+            }
             ZKM_HIP_CHECK(hipGetLastError());
         }
         {

@@ -98,14 +98,6 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_ext(const gl_t* __restric
     *reinterpret_cast<ulonglong2*>(d + 2) = make_ulonglong2(s[2], s[3]);
 }
 
-void zkm_launch_merkle_leaves_ext(zkm_ctx* c, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests) {
-    if (arity % 4 || 2 * arity <= 4) throw std::runtime_error("merkle_leaves_ext: unsupported arity");
-    zkm_prof_scope ps(c, "merkle_leaves_ext");
-    hipLaunchKernelGGL(k_merkle_leaves_ext, dim3((nleaves + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity,
-                       digests);
-    ZKM_HIP_CHECK(hipGetLastError());
-}
-
 // ------------------------------------------------------------------ Merkle inner level
 __global__ __launch_bounds__(256) void k_merkle_compress(const gl_t* __restrict__ children, gl_t* __restrict__ parents,
                                                          size_t nparents) {
@@ -120,9 +112,87 @@ __global__ __launch_bounds__(256) void k_merkle_compress(const gl_t* __restrict_
     *reinterpret_cast<ulonglong2*>(o + 2) = make_ulonglong2(s[2], s[3]);
 }
 
+// ---- one permutation across 12 lanes (small tree levels) ----
+// The top levels of every tree hold too few nodes to fill the machine, so a launch costs one permutation's LATENCY (~35 us for
+// the one-lane-per-hash form: ~18k dependent-ish instructions).  Here a hash owns a 16-lane row of the wave (lanes 0..11 = the
+// twelve state words): every round is constant add, x^7 (lane 0 only in the partial rounds), and the circulant MDS with the
+// twelve rotated neighbours fetched by ds_bpermute -- the textbook rounds (poseidon_stark.rs:65-95, 164-169, 239-251, 310-345),
+// 30 x ~190 instructions per lane instead of ~18k, i.e. a quarter of the latency at ~5x the total work.  Used when a level has
+// at most wide_max_parents() nodes (16384; ZKM_WIDE_MAX tunes it).  Bit-exact with poseidon_permute (the fused partial rounds are an algebraic regrouping).
+__device__ __forceinline__ uint64_t poseidon_permute_wide(uint64_t x, unsigned lane) {
+    const unsigned idx = lane & 15, base = lane & ~15u;
+    const bool active = idx < 12;
+    int src[12];
+#pragma unroll
+    for (int i = 1; i < 12; i++) src[i] = (int)(base + (idx + i) % 12);
+    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const uint32_t diag = idx == 0 ? 8u : 0u;
+    const gl_t* rcp = PC::ZKM_POSEIDON_RC + (active ? idx : 0);
+    x = gl_add_loose(x, rcp[0]);
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+        const bool full = r < 4 || r >= 26;
+        const uint64_t y = poseidon_sbox7(x);
+        x = (full || idx == 0) ? y : x;
+        const uint64_t k = r + 1 < 30 ? rcp[(r + 1) * 12] : 0;
+        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+        uint64_t al = (uint64_t)(uint32_t)k + (uint64_t)lo * (C[0] + diag), ah = (k >> 32) + (uint64_t)hi * (C[0] + diag);
+#pragma unroll
+        for (int i = 1; i < 12; i++) {
+            al += (uint64_t)(uint32_t)__shfl((int)lo, src[i]) * C[i];
+            ah += (uint64_t)(uint32_t)__shfl((int)hi, src[i]) * C[i];
+        }
+        x = poseidon_fold(al, ah);
+    }
+    return gl_canon(x);
+}
+
+__global__ __launch_bounds__(256) void k_merkle_compress_wide(const gl_t* __restrict__ children, gl_t* __restrict__ parents, size_t nparents) {
+    const unsigned lane = threadIdx.x & 63, idx = lane & 15;
+    const size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = p < nparents;  // uniform over the 16-lane row; every lane of the wave takes part in the shuffles
+    uint64_t x = 0;
+    if (live && idx < 8) x = children[8 * p + idx];
+    x = poseidon_permute_wide(x, lane);
+    if (live && idx < 4) parents[4 * p + idx] = x;
+}
+
+static size_t wide_max_parents() {
+    static size_t v = [] { const char* e = getenv("ZKM_WIDE_MAX"); return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)16384; }();
+    return v;
+}
+
+// FRI layer leaves, one hash per 16-lane row (small layers): word m of leaf k is component m & 1 of value k * arity + (m >> 1).
+__global__ __launch_bounds__(256) void k_merkle_leaves_ext_wide(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nleaves,
+                                                                unsigned arity, gl_t* __restrict__ digests) {
+    const unsigned lane = threadIdx.x & 63, idx = lane & 15;
+    const size_t k = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = k < nleaves;
+    const gl_t* col = (idx & 1) ? c1 : c0;
+    uint64_t x = 0;
+    for (unsigned m = 0; m < 2 * arity; m += 8) {
+        if (live && idx < 8) x = col[k * arity + ((m + idx) >> 1)];
+        x = poseidon_permute_wide(x, lane);
+    }
+    if (live && idx < 4) digests[4 * k + idx] = x;
+}
+
+void zkm_launch_merkle_leaves_ext(zkm_ctx* c, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests) {
+    if (arity % 4 || 2 * arity <= 4) throw std::runtime_error("merkle_leaves_ext: unsupported arity");
+    zkm_prof_scope ps(c, "merkle_leaves_ext");
+    if (nleaves <= wide_max_parents() / 4)
+        hipLaunchKernelGGL(k_merkle_leaves_ext_wide, dim3((nleaves * 16 + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
+    else
+        hipLaunchKernelGGL(k_merkle_leaves_ext, dim3((nleaves + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
 void zkm_launch_merkle_compress(zkm_ctx* c, const gl_t* children, gl_t* parents, size_t nparents) {
     zkm_prof_scope ps(c, "merkle_compress");
-    hipLaunchKernelGGL(k_merkle_compress, dim3((nparents + 255) / 256), dim3(256), 0, c->stream, children, parents, nparents);
+    if (nparents <= wide_max_parents())
+        hipLaunchKernelGGL(k_merkle_compress_wide, dim3((nparents * 16 + 255) / 256), dim3(256), 0, c->stream, children, parents, nparents);
+    else
+        hipLaunchKernelGGL(k_merkle_compress, dim3((nparents + 255) / 256), dim3(256), 0, c->stream, children, parents, nparents);
     ZKM_HIP_CHECK(hipGetLastError());
 }
 

@@ -756,8 +756,10 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             unsigned long long* d_best = (unsigned long long*)c->alloc(8);
             scratch.push_back(d_best);
             unsigned long long best = ~0ULL;
-            const uint64_t span = (uint64_t)1 << 20;
-            for (uint64_t base = 0; best == ~0ULL; base += span) {
+            // candidates per launch: 4 x the expected number of trials (a hit in the first launch with probability 1 - e^-4), then 2^20
+            const unsigned first_bits = cfg->pow_bits + 2 < 8 ? 8 : (cfg->pow_bits + 2 > 20 ? 20 : cfg->pow_bits + 2);
+            uint64_t span = (uint64_t)1 << first_bits;
+            for (uint64_t base = 0; best == ~0ULL; base += span, span = (uint64_t)1 << 20) {
                 if (base > ((uint64_t)1 << 40)) throw std::runtime_error("Proof of work failed. This is highly unlikely!");
                 ZKM_HIP_CHECK(hipMemsetAsync(d_best, 0xff, 8, c->stream));
                 {
