@@ -174,7 +174,7 @@ static void suffix_sum(zkm_ctx* c, const gl_t* a, size_t n, gl_t* out) {
         hipLaunchKernelGGL(k_sum_scan, dim3((nseg + 63) / 64), dim3(64), 0, c->stream, lv[l].t, lv[l].m, upper, nupper, S[l]);
     }
     ZKM_HIP_CHECK(hipGetLastError());
-    c->sync();
+    // no host sync: the temporaries go back to the caching allocator, whose blocks are only ever reused by later work on this stream
     for (size_t l = 1; l < lv.size(); l++) { c->release(lv[l].t); c->release(S[l]); }
 }
 

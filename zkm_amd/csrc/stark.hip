@@ -215,8 +215,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     }
     // coset_ifft(g) of each challenge's evaluations (prover.rs:784-788)
     zkm_ntt_natural(c, d_vals, d_out, nalphas, size, size, log_q, true, GL_GENERATOR);
-    c->sync();  // d_alphas / d_vals are recycled below
-    c->release(d_vals);
+    c->release(d_vals);  // stream-ordered reuse: no host sync needed
     c->release(d_alphas);
 }
 
@@ -443,7 +442,7 @@ static void divide_accumulate(zkm_ctx* c, const gl_t* a0, const gl_t* a1, size_t
         }
     }
     ZKM_HIP_CHECK(hipGetLastError());
-    c->sync();
+    // no host sync: released blocks are only reused by later work on this stream
     for (size_t l = 1; l < lv.size(); l++) {
         c->release(lv[l].t0); c->release(lv[l].t1);
         c->release(S[l].first); c->release(S[l].second);
