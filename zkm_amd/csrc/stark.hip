@@ -97,7 +97,7 @@ __device__ void eval_ctl_constraints(const ctl_dev& d, const gl_t* __restrict__ 
 // of the 4n-row LDE is natural quotient index i = bitrev_{L-1}(j) (every `step` = 2nd natural LDE row,
 // prover.rs:668-675); "next" is natural +2 in the 2n domain (prover.rs:704) = +4 in the 4n domain.
 template <int TABLE, int NA>
-__global__ __launch_bounds__(256) void k_quotient(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux,
+__global__ __launch_bounds__(256, (TABLE == ZKM_TABLE_CPU || TABLE == ZKM_TABLE_POSEIDON || TABLE == ZKM_TABLE_ARITHMETIC ? 4 : 1)) void k_quotient(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux,
                                                            unsigned log_n, unsigned lde_bits, ctl_dev ctl, lookup_dev lookups,
                                                            uint32_t num_lookup_cols, const gl_t* alphas,
                                                            const gl_t* __restrict__ wpow /* w_{4n}^t two-level table */,
