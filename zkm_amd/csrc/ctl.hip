@@ -51,6 +51,7 @@ void ctl_dev_owner::upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z
     if (t->nfilter_idx) memcpy(&h[o_fi], t->filter_idx, t->nfilter_idx * 4);
     if (nids) memcpy(&h[o_ids], colset_ids, nids * 4);
     blob = c->alloc(total);
+    h_zs.assign(zs, zs + nzs);
     ZKM_HIP_CHECK(hipMemcpyAsync(blob, h.data(), total, hipMemcpyHostToDevice, c->stream));
     c->sync();
     char* b = (char*)blob;

@@ -5,6 +5,8 @@
 // (CTL data generation) or one lane = one quotient-domain point (constraint checks).  The descriptor arrays are
 // wave-uniform, so they come through the scalar cache; the per-lane work is the column gathers.
 #pragma once
+#include <vector>
+
 #include "zkm_internal.h"
 
 struct ctl_dev {
@@ -53,6 +55,7 @@ __device__ __forceinline__ gl_t ctl_combine(const ctl_dev& d, const zkm_colset& 
 struct ctl_dev_owner {
     zkm_ctx* c = nullptr;
     void* blob = nullptr;
+    std::vector<zkm_ctl_z> h_zs;  // host copy of the CtlZData list (launch planning)
     ctl_dev d{};
     size_t naux = 0;
     // lookup_mode: logUp lookups keep a helper column even for a single looking column (lookup.rs:34-38)

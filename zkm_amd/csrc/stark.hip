@@ -51,44 +51,55 @@ static void make_layout(proof_layout& y, const zkm_stark_config* c, unsigned log
 // CTL checks driven by the column-set description (eval_helper_columns cross_table_lookup.rs:1006-1058,
 // eval_cross_table_lookup_checks :1067-1150).  The benchmark's fake CTL data (helper columns, no column sets)
 // is the ncolsets == 0 case: only the last-row / transition checks on Z are emitted.
+// Constraints of CtlZData `i`: helper-column checks q0 <= q < q1, then (if `closing`) the last-row / transition checks on Z.
+// `start` = index of the z's first helper column among the auxiliary columns.
+template <int NA>
+__device__ void eval_ctl_z(const ctl_dev& d, uint32_t i, uint32_t start, uint32_t q0, uint32_t q1, bool closing, const gl_t* __restrict__ tl,
+                           size_t N, ptrdiff_t dnext, const gl_t* __restrict__ aux, size_t j, size_t jn, consumer_t<NA>& k) {
+    const zkm_ctl_z z = d.zs[i];
+    const uint32_t* ids = d.colset_ids + z.colset_off;
+    if (z.num_helpers) {
+        for (uint32_t q = q0; q < q1; q++) {
+            gl_t h = aux[(size_t)(start + q) * N + j];
+            const zkm_colset c0 = d.colsets[ids[2 * q]];
+            gl_t combin0 = ctl_combine(d, c0, z.beta, z.gamma, tl, N, dnext, true), f0 = ctl_eval_filter(d, c0, tl, N, dnext, true);
+            if (2 * q + 1 < z.ncolsets) {
+                const zkm_colset c1 = d.colsets[ids[2 * q + 1]];
+                gl_t combin1 = ctl_combine(d, c1, z.beta, z.gamma, tl, N, dnext, true), f1 = ctl_eval_filter(d, c1, tl, N, dnext, true);
+                k.constraint(gl_sub(gl_sub(gl_mul(gl_mul(combin1, combin0), h), gl_mul(f0, combin1)), gl_mul(f1, combin0)));
+            } else {
+                k.constraint(gl_sub(gl_mul(combin0, h), f0));
+            }
+        }
+    }
+    if (!closing) return;
+    gl_t local_z = aux[(size_t)(d.total_helpers + i) * N + j], next_z = aux[(size_t)(d.total_helpers + i) * N + jn];
+    if (z.num_helpers) {
+        gl_t h_sum = 0;
+        for (uint32_t q = 0; q < z.num_helpers; q++) h_sum = gl_add(h_sum, aux[(size_t)(start + q) * N + j]);
+        k.last_row(gl_sub(local_z, h_sum));
+        k.transition(gl_sub(gl_sub(local_z, next_z), h_sum));
+    } else if (z.ncolsets > 1) {
+        const zkm_colset c0 = d.colsets[ids[0]], c1 = d.colsets[ids[1]];
+        gl_t combin0 = ctl_combine(d, c0, z.beta, z.gamma, tl, N, dnext, true), combin1 = ctl_combine(d, c1, z.beta, z.gamma, tl, N, dnext, true);
+        gl_t f0 = ctl_eval_filter(d, c0, tl, N, dnext, true), f1 = ctl_eval_filter(d, c1, tl, N, dnext, true);
+        gl_t cc = gl_mul(combin0, combin1), rhs = gl_add(gl_mul(f0, combin1), gl_mul(f1, combin0));
+        k.last_row(gl_sub(gl_mul(cc, local_z), rhs));
+        k.transition(gl_sub(gl_mul(cc, gl_sub(local_z, next_z)), rhs));
+    } else {
+        const zkm_colset c0 = d.colsets[ids[0]];
+        gl_t combin0 = ctl_combine(d, c0, z.beta, z.gamma, tl, N, dnext, true), f0 = ctl_eval_filter(d, c0, tl, N, dnext, true);
+        k.last_row(gl_sub(gl_mul(combin0, local_z), f0));
+        k.transition(gl_sub(gl_mul(combin0, gl_sub(local_z, next_z)), f0));
+    }
+}
 template <int NA>
 __device__ void eval_ctl_constraints(const ctl_dev& d, const gl_t* __restrict__ tl, size_t N, ptrdiff_t dnext,
                                      const gl_t* __restrict__ aux, size_t j, size_t jn, consumer_t<NA>& k) {
     uint32_t start = 0;
     for (uint32_t i = 0; i < d.nzs; i++) {
         const zkm_ctl_z z = d.zs[i];
-        const uint32_t* ids = d.colset_ids + z.colset_off;
-        gl_t local_z = aux[(size_t)(d.total_helpers + i) * N + j], next_z = aux[(size_t)(d.total_helpers + i) * N + jn];
-        if (z.num_helpers) {
-            for (uint32_t q = 0; 2 * q < z.ncolsets; q++) {
-                gl_t h = aux[(size_t)(start + q) * N + j];
-                const zkm_colset c0 = d.colsets[ids[2 * q]];
-                gl_t combin0 = ctl_combine(d, c0, z.beta, z.gamma, tl, N, dnext, true), f0 = ctl_eval_filter(d, c0, tl, N, dnext, true);
-                if (2 * q + 1 < z.ncolsets) {
-                    const zkm_colset c1 = d.colsets[ids[2 * q + 1]];
-                    gl_t combin1 = ctl_combine(d, c1, z.beta, z.gamma, tl, N, dnext, true), f1 = ctl_eval_filter(d, c1, tl, N, dnext, true);
-                    k.constraint(gl_sub(gl_sub(gl_mul(gl_mul(combin1, combin0), h), gl_mul(f0, combin1)), gl_mul(f1, combin0)));
-                } else {
-                    k.constraint(gl_sub(gl_mul(combin0, h), f0));
-                }
-            }
-            gl_t h_sum = 0;
-            for (uint32_t q = 0; q < z.num_helpers; q++) h_sum = gl_add(h_sum, aux[(size_t)(start + q) * N + j]);
-            k.last_row(gl_sub(local_z, h_sum));
-            k.transition(gl_sub(gl_sub(local_z, next_z), h_sum));
-        } else if (z.ncolsets > 1) {
-            const zkm_colset c0 = d.colsets[ids[0]], c1 = d.colsets[ids[1]];
-            gl_t combin0 = ctl_combine(d, c0, z.beta, z.gamma, tl, N, dnext, true), combin1 = ctl_combine(d, c1, z.beta, z.gamma, tl, N, dnext, true);
-            gl_t f0 = ctl_eval_filter(d, c0, tl, N, dnext, true), f1 = ctl_eval_filter(d, c1, tl, N, dnext, true);
-            gl_t cc = gl_mul(combin0, combin1), rhs = gl_add(gl_mul(f0, combin1), gl_mul(f1, combin0));
-            k.last_row(gl_sub(gl_mul(cc, local_z), rhs));
-            k.transition(gl_sub(gl_mul(cc, gl_sub(local_z, next_z)), rhs));
-        } else {
-            const zkm_colset c0 = d.colsets[ids[0]];
-            gl_t combin0 = ctl_combine(d, c0, z.beta, z.gamma, tl, N, dnext, true), f0 = ctl_eval_filter(d, c0, tl, N, dnext, true);
-            k.last_row(gl_sub(gl_mul(combin0, local_z), f0));
-            k.transition(gl_sub(gl_mul(combin0, gl_sub(local_z, next_z)), f0));
-        }
+        eval_ctl_z<NA>(d, i, start, 0, z.num_helpers ? (z.ncolsets + 1) / 2 : 0, true, tl, N, dnext, aux, j, jn, k);
         start += z.num_helpers;
     }
 }
@@ -96,26 +107,21 @@ __device__ void eval_ctl_constraints(const ctl_dev& d, const gl_t* __restrict__ 
 // One thread per point of the quotient domain g<w_2n>, visited in LDE storage order: storage row j < 2n
 // of the 4n-row LDE is natural quotient index i = bitrev_{L-1}(j) (every `step` = 2nd natural LDE row,
 // prover.rs:668-675); "next" is natural +2 in the 2n domain (prover.rs:704) = +4 in the 4n domain.
-template <int TABLE, int NA>
-__global__ __launch_bounds__(256, (TABLE == ZKM_TABLE_CPU || TABLE == ZKM_TABLE_POSEIDON || TABLE == ZKM_TABLE_ARITHMETIC ? 4 : 1)) void k_quotient(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux,
-                                                           unsigned log_n, unsigned lde_bits, ctl_dev ctl, lookup_dev lookups,
-                                                           uint32_t num_lookup_cols, const gl_t* alphas,
-                                                           const gl_t* __restrict__ wpow /* w_{4n}^t two-level table */,
-                                                           gl_t gn, gl_t zh_inv0, gl_t zh_inv1, gl_t last, gl_t w_n, gl_t n_inv,
-                                                           gl_t* __restrict__ out) {
-    size_t N = (size_t)1 << lde_bits;
-    size_t size = N >> 1;
-    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= size) return;
+// Per-point setup shared by the quotient kernels.
+struct quotient_point {
+    size_t j, jn;
+    uint32_t i;
+};
+template <int NA>
+__device__ __forceinline__ quotient_point quotient_setup(size_t j, unsigned lde_bits, const gl_t* __restrict__ alphas, const gl_t* __restrict__ wpow,
+                                                         gl_t gn, gl_t last, gl_t w_n, gl_t n_inv, consumer_t<NA>& k) {
+    const size_t N = (size_t)1 << lde_bits;
     uint32_t t = bitrev32((uint32_t)j, lde_bits);  // natural index in the 4n domain (even)
     uint32_t i = t >> 1;                           // natural index in the 2n quotient domain
     uint32_t tn = (t + 4) & (uint32_t)(N - 1);
-    size_t jn = bitrev32(tn, lde_bits);
-
     // x = g * w_{4n}^t
     unsigned h = (lde_bits + 1) / 2;
     gl_t x = gl_mul(GL_GENERATOR, gl_mul_loose(wpow[t & ((1u << h) - 1)], wpow[((size_t)1 << h) + (t >> h)]));
-    consumer_t<NA> k;
 #pragma unroll
     for (int a = 0; a < NA; a++) { k.alpha[a] = alphas[a]; k.acc[a] = 0; }
     k.z_last = gl_sub(x, last);
@@ -126,14 +132,88 @@ __global__ __launch_bounds__(256, (TABLE == ZKM_TABLE_CPU || TABLE == ZKM_TABLE_
     gl_t zn = gl_mul(zh, n_inv);
     k.l_first = gl_mul(zn, gl_mul(dinv, d1));
     k.l_last = gl_mul(zn, gl_mul(dinv, d0));
+    return quotient_point{j, (size_t)bitrev32(tn, lde_bits), i};
+}
 
-    eval_table_constraints<TABLE, NA>(trace + j, N, (ptrdiff_t)jn - (ptrdiff_t)j, k);
+// The vanishing polynomial is accumulated by separate launches (vanishing_poly.rs:30-45 order: table constraints, the table's
+// lookups, then the cross-table lookup checks): k_quotient<TABLE> stores the running accumulators after the table's own
+// constraints; the table-independent CTL kernels continue the same Horner recurrence acc = acc * alpha + c through the CTL checks
+// and multiply by Z_H^-1.  The descriptor interpreter stays out of the per-table kernels' register budgets, and a table with few
+// rows and hundreds of looking column sets (KeccakSponge) can spread its CTL checks over many workgroups:
+//   k_quotient_ctl          all CTL constraints of a point in one thread (large tables: already enough parallelism)
+//   k_quotient_ctl_chunk    blockIdx.y = a chunk of consecutive constraints [k_begin, k_end); Horner from 0 within the chunk,
+//                           scaled by alpha^(K - k_end) (K = number of CTL constraints) into tmp[chunk]
+//   k_quotient_ctl_sum      acc * alpha^K + sum of the chunks, times Z_H^-1
+// -- the same polynomial in alpha, so the values are identical.
+template <int TABLE, int NA>
+__global__ __launch_bounds__(256, (TABLE == ZKM_TABLE_CPU || TABLE == ZKM_TABLE_POSEIDON || TABLE == ZKM_TABLE_ARITHMETIC ? 4 : 1)) void k_quotient(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux,
+                                                           unsigned log_n, unsigned lde_bits, lookup_dev lookups, const gl_t* alphas,
+                                                           const gl_t* __restrict__ wpow /* w_{4n}^t two-level table */,
+                                                           gl_t gn, gl_t last, gl_t w_n, gl_t n_inv, gl_t* __restrict__ out) {
+    size_t N = (size_t)1 << lde_bits;
+    size_t size = N >> 1;
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= size) return;
+    consumer_t<NA> k;
+    const quotient_point q = quotient_setup<NA>(j, lde_bits, alphas, wpow, gn, last, w_n, n_inv, k);
+    eval_table_constraints<TABLE, NA>(trace + j, N, (ptrdiff_t)q.jn - (ptrdiff_t)j, k);
     // auxiliary columns: the table's lookup helper columns first, then the CTL helper columns and Zs (prover.rs:495-508)
-    if constexpr (TABLE == ZKM_TABLE_MEMORY || TABLE == ZKM_TABLE_ARITHMETIC) eval_lookup_constraints<NA>(lookups, trace + j, N, aux, j, jn, k);
-    eval_ctl_constraints<NA>(ctl, trace + j, N, (ptrdiff_t)jn - (ptrdiff_t)j, aux + (size_t)num_lookup_cols * N, j, jn, k);
+    if constexpr (TABLE == ZKM_TABLE_MEMORY || TABLE == ZKM_TABLE_ARITHMETIC) eval_lookup_constraints<NA>(lookups, trace + j, N, aux, j, q.jn, k);
+#pragma unroll
+    for (int a = 0; a < NA; a++) out[(size_t)a * size + q.i] = k.acc[a];
+}
+
+template <int NA>
+__global__ __launch_bounds__(256) void k_quotient_ctl(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux, unsigned lde_bits, ctl_dev ctl,
+                                                      uint32_t num_lookup_cols, const gl_t* alphas, const gl_t* __restrict__ wpow, gl_t gn,
+                                                      gl_t zh_inv0, gl_t zh_inv1, gl_t last, gl_t w_n, gl_t n_inv, gl_t* __restrict__ out) {
+    size_t N = (size_t)1 << lde_bits;
+    size_t size = N >> 1;
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= size) return;
+    consumer_t<NA> k;
+    const quotient_point q = quotient_setup<NA>(j, lde_bits, alphas, wpow, gn, last, w_n, n_inv, k);
+#pragma unroll
+    for (int a = 0; a < NA; a++) k.acc[a] = out[(size_t)a * size + q.i];
+    eval_ctl_constraints<NA>(ctl, trace + j, N, (ptrdiff_t)q.jn - (ptrdiff_t)j, aux + (size_t)num_lookup_cols * N, j, q.jn, k);
+    gl_t zi = (q.i & 1) ? zh_inv1 : zh_inv0;
+#pragma unroll
+    for (int a = 0; a < NA; a++) out[(size_t)a * size + q.i] = gl_mul(k.acc[a], zi);
+}
+
+struct ctl_chunk {
+    uint32_t z, helper_start, q0, q1, closing, tail;  // tail = K - k_end: constraints that follow the chunk
+};
+template <int NA>
+__global__ __launch_bounds__(256) void k_quotient_ctl_chunk(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux, unsigned lde_bits, ctl_dev ctl,
+                                                            const ctl_chunk* __restrict__ chunks, uint32_t num_lookup_cols, const gl_t* alphas,
+                                                            const gl_t* __restrict__ wpow, gl_t gn, gl_t last, gl_t w_n, gl_t n_inv,
+                                                            gl_t* __restrict__ tmp /* [chunk][NA][size] */) {
+    size_t N = (size_t)1 << lde_bits;
+    size_t size = N >> 1;
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= size) return;
+    const ctl_chunk ch = chunks[blockIdx.y];
+    consumer_t<NA> k;
+    const quotient_point q = quotient_setup<NA>(j, lde_bits, alphas, wpow, gn, last, w_n, n_inv, k);
+    eval_ctl_z<NA>(ctl, ch.z, ch.helper_start, ch.q0, ch.q1, ch.closing != 0, trace + j, N, (ptrdiff_t)q.jn - (ptrdiff_t)j,
+                   aux + (size_t)num_lookup_cols * N, j, q.jn, k);
+#pragma unroll
+    for (int a = 0; a < NA; a++)
+        tmp[((size_t)blockIdx.y * NA + a) * size + q.i] = gl_mul(k.acc[a], gl_pow(k.alpha[a], ch.tail));
+}
+template <int NA>
+__global__ __launch_bounds__(256) void k_quotient_ctl_sum(const gl_t* __restrict__ tmp, uint32_t nchunks, uint32_t nconstraints, const gl_t* alphas,
+                                                          gl_t zh_inv0, gl_t zh_inv1, size_t size, gl_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
     gl_t zi = (i & 1) ? zh_inv1 : zh_inv0;
 #pragma unroll
-    for (int a = 0; a < NA; a++) out[(size_t)a * size + i] = gl_mul(k.acc[a], zi);
+    for (int a = 0; a < NA; a++) {
+        gl_t acc = gl_mul(out[(size_t)a * size + i], gl_pow(alphas[a], nconstraints));
+        for (uint32_t c = 0; c < nchunks; c++) acc = gl_add(acc, tmp[((size_t)c * NA + a) * size + i]);
+        out[(size_t)a * size + i] = gl_mul(acc, zi);
+    }
 }
 
 // quotient polys: d_out = nalphas x 2n natural-order coefficients (device)
@@ -182,8 +262,8 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
         zkm_prof_scope ps(c, names[table_id]);
         dim3 grid((size + 255) / 256), block(256);
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
-    hipLaunchKernelGGL((k_quotient<T, NA>), grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, ctl, lookups, NL, d_alphas, \
-                       wpow, gn, zh0, zh1, last, w_n, n_inv, d_vals)
+    hipLaunchKernelGGL((k_quotient<T, NA>), grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, lookups, d_alphas, wpow, gn, \
+                       last, w_n, n_inv, d_vals)
         switch (table_id * 2 + (int)nalphas - 1) {
             case 0: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON, 1); break;
             case 1: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON, 2); break;
@@ -211,6 +291,58 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             default: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_CPU, 2); break;
         }
 #undef ZKM_LAUNCH_QUOTIENT
+        ZKM_HIP_CHECK(hipGetLastError());
+    }
+    {
+        zkm_prof_scope ps(c, "quotient_ctl");
+        dim3 grid((size + 255) / 256), block(256);
+        // chunk plan: at most CHUNK helper checks per chunk, the closing checks with the last chunk of their Z
+        const uint32_t CHUNK = 4;
+        std::vector<ctl_chunk> plan;
+        uint32_t K = 0, hstart = 0;
+        std::vector<uint32_t> kend;
+        for (uint32_t zi = 0; zi < own.h_zs.size(); zi++) {
+            // helper checks exist only for real column sets (the benchmark's fake CTL data has helper columns but no sets)
+            const uint32_t np = own.h_zs[zi].num_helpers ? (own.h_zs[zi].ncolsets + 1) / 2 : 0;
+            uint32_t q = 0;
+            do {
+                const uint32_t q1 = np - q > CHUNK ? q + CHUNK : np;
+                const bool closing = q1 == np;
+                K += (q1 - q) + (closing ? 2 : 0);
+                plan.push_back(ctl_chunk{zi, hstart, q, q1, closing ? 1u : 0u, 0});
+                kend.push_back(K);
+                q = q1;
+            } while (q < np);
+            hstart += own.h_zs[zi].num_helpers;
+        }
+        for (size_t i = 0; i < plan.size(); i++) plan[i].tail = K - kend[i];
+        const bool chunked = plan.size() >= 8 && size <= ((size_t)1 << 18);
+        if (!chunked) {
+            if (nalphas == 1)
+                hipLaunchKernelGGL((k_quotient_ctl<1>), grid, block, 0, c->stream, trace->lde, aux->lde, lde_bits, ctl, NL, d_alphas, wpow, gn, zh0, zh1,
+                                   last, w_n, n_inv, d_vals);
+            else
+                hipLaunchKernelGGL((k_quotient_ctl<2>), grid, block, 0, c->stream, trace->lde, aux->lde, lde_bits, ctl, NL, d_alphas, wpow, gn, zh0, zh1,
+                                   last, w_n, n_inv, d_vals);
+        } else {
+            ctl_chunk* d_plan = (ctl_chunk*)c->alloc(plan.size() * sizeof(ctl_chunk));
+            gl_t* d_tmp = (gl_t*)c->alloc(plan.size() * nalphas * size * sizeof(gl_t));
+            ZKM_HIP_CHECK(hipMemcpyAsync(d_plan, plan.data(), plan.size() * sizeof(ctl_chunk), hipMemcpyHostToDevice, c->stream));
+            dim3 grid2((unsigned)((size + 255) / 256), (unsigned)plan.size());
+            if (nalphas == 1) {
+                hipLaunchKernelGGL((k_quotient_ctl_chunk<1>), grid2, block, 0, c->stream, trace->lde, aux->lde, lde_bits, ctl, d_plan, NL, d_alphas, wpow,
+                                   gn, last, w_n, n_inv, d_tmp);
+                hipLaunchKernelGGL((k_quotient_ctl_sum<1>), grid, block, 0, c->stream, d_tmp, (uint32_t)plan.size(), K, d_alphas, zh0, zh1, size, d_vals);
+            } else {
+                hipLaunchKernelGGL((k_quotient_ctl_chunk<2>), grid2, block, 0, c->stream, trace->lde, aux->lde, lde_bits, ctl, d_plan, NL, d_alphas, wpow,
+                                   gn, last, w_n, n_inv, d_tmp);
+                hipLaunchKernelGGL((k_quotient_ctl_sum<2>), grid, block, 0, c->stream, d_tmp, (uint32_t)plan.size(), K, d_alphas, zh0, zh1, size, d_vals);
+            }
+            ZKM_HIP_CHECK(hipGetLastError());
+            c->sync();  // `plan` (pageable host memory) must outlive the copy
+            c->release(d_plan);
+            c->release(d_tmp);
+        }
         ZKM_HIP_CHECK(hipGetLastError());
     }
     // coset_ifft(g) of each challenge's evaluations (prover.rs:784-788)
