@@ -45,9 +45,20 @@ __device__ __forceinline__ uint64_t red6(uint64_t lo, uint64_t hi) {
     r += (r < t0) ? GL_EPS : 0;
     return r;
 }
+// red6 with the wrap of h0 * EPS + t0 taken from the multiply-add's own carry-out (inline asm: mad, select, add)
+__device__ __forceinline__ uint64_t red7(uint64_t lo, uint64_t hi) {
+    uint32_t h1 = (uint32_t)(hi >> 32), h0 = (uint32_t)hi;
+    uint64_t t0 = lo - h1;
+    uint32_t m = (uint32_t)((int32_t)((uint32_t)(t0 >> 32) & ~(uint32_t)(lo >> 32)) >> 31);
+    t0 -= m;
+    uint64_t r, carry;
+    uint32_t add;
+    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, -1, %1" : "=&v"(r), "=&s"(carry), "=v"(add) : "v"(h0), "v"(t0));
+    return r + add;
+}
 template <int R> __device__ __forceinline__ uint64_t mul_r(uint64_t a, uint64_t b) {
     uint64_t lo, hi; gl_mul_wide(a, b, lo, hi);
-    return R == 4 ? red4(lo, hi) : R == 5 ? red5(lo, hi) : red6(lo, hi);
+    return R == 4 ? red4(lo, hi) : R == 5 ? red5(lo, hi) : R == 6 ? red6(lo, hi) : red7(lo, hi);
 }
 template <int V>
 __device__ __forceinline__ uint64_t sbox(uint64_t x) {
@@ -95,5 +106,6 @@ int main() {
     run<2, true>("new + squarings fence", d); run<2, false>("new + squarings nofence", d);
     run<3, true>("chained zext addends fence", d); run<3, false>("chained nofence", d);
     run<4, true>("chained + mad-fused reduce", d); run<5, true>("chained + select-EPS reduce", d); run<6, true>("chained + sign-mask borrow", d);
+    run<7, true>("sign-mask + mad carry-out asm", d); run<7, false>("mad carry-out asm nofence", d);
     return 0;
 }

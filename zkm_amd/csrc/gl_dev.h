@@ -73,9 +73,18 @@ GL_HD uint64_t gl_reduce128(uint64_t lo, uint64_t hi) {
     uint64_t t0 = lo - h1;
     uint32_t m = (uint32_t)((int32_t)((uint32_t)(t0 >> 32) & ~(uint32_t)(lo >> 32)) >> 31);
     t0 -= m;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The wrap of h0 * EPS + t0 is the multiply-add's own carry-out (an SGPR pair): mad, select, add -- no 64-bit compare.
+    // The compiler does not form this (it adds separately and compares); tools/ubench3.hip: +14 % x^7 s-boxes/s.
+    uint64_t r, carry;
+    uint32_t wrap;
+    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, -1, %1" : "=&v"(r), "=&s"(carry), "=v"(wrap) : "v"(h0), "v"(t0));
+    return r + wrap;
+#else
     uint64_t r = (uint64_t)h0 * 0xFFFFFFFFu + t0;
     r += (r < t0) ? GL_EPS : 0;
     return r;
+#endif
 }
 
 // 64 x 64 -> 128.  Device: four chained 32x32+64 multiply-adds sharing their partial products; every addend fits (no
