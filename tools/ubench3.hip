@@ -56,12 +56,25 @@ __device__ __forceinline__ uint64_t red7(uint64_t lo, uint64_t hi) {
     asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, -1, %1" : "=&v"(r), "=&s"(carry), "=v"(add) : "v"(h0), "v"(t0));
     return r + add;
 }
+// product with the middle terms summed in one 64-bit accumulator, its overflow taken from the carry-out
+__device__ __forceinline__ uint64_t mul_c(uint64_t a, uint64_t b) {
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint64_t p00 = (uint64_t)al * bl;
+    uint64_t m1 = (uint64_t)al * bh + (p00 >> 32);
+    uint64_t m2, c;
+    uint32_t cw;
+    asm("v_mad_u64_u32 %0, %1, %3, %4, %5\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, 1, %1" : "=&v"(m2), "=&s"(c), "=v"(cw) : "v"(ah), "v"(bl), "v"(m1));
+    uint64_t hi = (uint64_t)ah * bh + ((m2 >> 32) | ((uint64_t)cw << 32));
+    uint64_t lo = (m2 << 32) | (uint32_t)p00;
+    return red7(lo, hi);
+}
 template <int R> __device__ __forceinline__ uint64_t mul_r(uint64_t a, uint64_t b) {
     uint64_t lo, hi; gl_mul_wide(a, b, lo, hi);
     return R == 4 ? red4(lo, hi) : R == 5 ? red5(lo, hi) : R == 6 ? red6(lo, hi) : red7(lo, hi);
 }
 template <int V>
 __device__ __forceinline__ uint64_t sbox(uint64_t x) {
+    if (V == 8) { uint64_t x2 = mul_c(x, x), x4 = mul_c(x2, x2), x3 = mul_c(x, x2); return mul_c(x3, x4); }
     if (V >= 4) { uint64_t x2 = mul_r<V>(x, x), x4 = mul_r<V>(x2, x2), x3 = mul_r<V>(x, x2); return mul_r<V>(x3, x4); }
     if (V == 0) { uint64_t x2 = mul_old(x, x), x4 = mul_old(x2, x2), x3 = mul_old(x, x2); return mul_old(x3, x4); }
     if (V == 1) { uint64_t x2 = mul_new(x, x), x4 = mul_new(x2, x2), x3 = mul_new(x, x2); return mul_new(x3, x4); }
@@ -107,5 +120,6 @@ int main() {
     run<3, true>("chained zext addends fence", d); run<3, false>("chained nofence", d);
     run<4, true>("chained + mad-fused reduce", d); run<5, true>("chained + select-EPS reduce", d); run<6, true>("chained + sign-mask borrow", d);
     run<7, true>("sign-mask + mad carry-out asm", d); run<7, false>("mad carry-out asm nofence", d);
+    run<8, true>("carry-out product + reduce", d); run<8, false>("carry-out product nofence", d);
     return 0;
 }
