@@ -56,6 +56,15 @@ namespace pc_dev {
 #define POSEIDON_SCHED_FENCE() ((void)0)
 #endif
 
+// Hide a small multiplier from the optimiser (it stays in an SGPR).  Left to itself the compiler turns the MDS entries that are
+// powers of two (2, 8, 16) into v_lshl_add_u64, which needs the 32-bit word zero-extended into a register pair first (a v_mov per
+// term) and issues no faster than the v_mad_u64_u32 that takes the word directly.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define POSEIDON_OPAQUE(c) asm("" : "+s"(c))
+#else
+#define POSEIDON_OPAQUE(c) ((void)0)
+#endif
+
 // x^7 on a loose value -> loose
 GL_HD uint64_t poseidon_sbox7(uint64_t x) {
     uint64_t x2 = gl_mul_loose(x, x);
@@ -70,6 +79,17 @@ GL_HD uint64_t poseidon_sbox7(uint64_t x) {
 //   which cannot wrap (c = 1 implies hs_lo32 < 2^28).
 // Additive constants are folded in by starting the accumulators at (const_lo, const_hi).
 GL_HD uint64_t poseidon_fold(uint64_t al, uint64_t ah) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // t = al + EPS ah_hi < 2^60; adding 2^32 ah_lo only touches the high word, and its carry-out (an SGPR pair) selects the EPS
+    // correction: multiply-add, add, select, add.  t < 2^60 means the corrected sum cannot wrap again.
+    const uint64_t t = (uint64_t)(uint32_t)(ah >> 32) * 0xFFFFFFFFu + al;
+    uint32_t rhi, wrap;
+    uint64_t carry;
+    asm("v_add_co_u32_e64 %0, %1, %3, %4\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, -1, %1"
+        : "=&v"(rhi), "=&s"(carry), "=v"(wrap)
+        : "v"((uint32_t)(t >> 32)), "v"((uint32_t)ah));
+    return (((uint64_t)rhi << 32) | (uint32_t)t) + wrap;
+#endif
     uint64_t s1 = (uint64_t)(uint32_t)(ah >> 32) * 0xFFFFFFFFu + al;
     uint64_t hs = (uint64_t)(uint32_t)ah + (s1 >> 32);
     uint64_t base = (hs << 32) | (uint32_t)s1;
@@ -89,7 +109,10 @@ GL_HD void poseidon_mds_add(uint64_t s[12], const uint64_t* add) {
         lo[i] = (uint32_t)s[i];
         hi[i] = (uint32_t)(s[i] >> 32);
     }
-    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20}, diag = 8;
+#pragma unroll
+    for (int i = 0; i < 12; i++) POSEIDON_OPAQUE(C[i]);
+    POSEIDON_OPAQUE(diag);
 #pragma unroll
     for (int r = 0; r < 12; r++) {
         uint64_t al = ADD ? (uint64_t)(uint32_t)add[r] : 0, ah = ADD ? add[r] >> 32 : 0;
@@ -99,8 +122,8 @@ GL_HD void poseidon_mds_add(uint64_t s[12], const uint64_t* add) {
             ah += (uint64_t)hi[(i + r) % 12] * C[i];
         }
         if (r == 0) {
-            al += (uint64_t)lo[0] * 8u;
-            ah += (uint64_t)hi[0] * 8u;
+            al += (uint64_t)lo[0] * diag;
+            ah += (uint64_t)hi[0] * diag;
         }
         s[r] = poseidon_fold(al, ah);
         if ((r & 3) == 3) POSEIDON_SCHED_FENCE();
