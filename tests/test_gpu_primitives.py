@@ -79,7 +79,7 @@ def test_ntt_roundtrip_large(ctx):
     assert (ctx.ntt(y, ncols, log_n, inverse=True, coset_shift=G) == x).all()
 
 
-@pytest.mark.parametrize("log_n,ncols", [(3, 1), (5, 4), (5, 5), (6, 13), (8, 262), (10, 9), (12, 20)])
+@pytest.mark.parametrize("log_n,ncols", [(3, 1), (5, 4), (5, 5), (6, 13), (8, 262), (10, 9), (12, 20), (14, 5)])
 def test_commit_matches_oracle(ctx, zkm, oracle, log_n, ncols):
     rng = np.random.default_rng(100 + log_n + ncols)
     vals = rand_field(rng, ncols << log_n)
