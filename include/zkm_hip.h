@@ -36,6 +36,9 @@ void* zkm_ctx_stream(zkm_ctx* ctx);
 /* Device memory held by the context's caching allocator: bytes in live allocations (DeviceBuffers, batches, scratch of a call in
  * flight) and bytes cached for reuse (freed on zkm_ctx_destroy, or when an allocation would otherwise fail). */
 void zkm_ctx_memory(const zkm_ctx* ctx, size_t* live_bytes, size_t* cached_bytes);
+/* Return every cached (not live) block to the device (the free lists are exact-size: a segment of many table shapes leaves one
+ * cached block per distinct size behind). */
+void zkm_ctx_trim(zkm_ctx* ctx);
 int zkm_dev_alloc(zkm_ctx* ctx, size_t bytes, void** out, char** err);
 int zkm_dev_free(zkm_ctx* ctx, void* p);
 int zkm_dev_upload(zkm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, char** err);
@@ -205,6 +208,13 @@ void zkm_standard_config(zkm_stark_config* cfg);
 #define ZKM_TABLE_SHA_COMPRESS_SPONGE 9
 #define ZKM_TABLE_ARITHMETIC 10
 #define ZKM_TABLE_CPU 11
+/* Position of a table in the reference's Table enum (all_stark.rs:96-110: Arithmetic = 0, Cpu, Poseidon, PoseidonSponge, Keccak,
+ * KeccakSponge, ShaExtend, ShaExtendSponge, ShaCompress, ShaCompressSponge, Logic, Memory = 11), or -1 for an unknown id.  The
+ * ZKM_TABLE_* ids above are NOT in that order.  prove_with_traces (prover.rs:144-200, 234-438) commits, observes and proves the
+ * tables in Table::all() order on one transcript: zkm_prove_with_traces / zkm_prove_segment_image use the caller's array order and
+ * reject an array that holds all twelve tables in any other order (sub-segments of fewer tables, as the tests prove them, are the
+ * caller's responsibility). */
+int zkm_table_enum_index(int table_id);
 #define ZKM_ARITHMETIC_COLS 54
 #define ZKM_CPU_COLS 259
 #define ZKM_MEMORY_COLS 13

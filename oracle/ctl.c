@@ -15,6 +15,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include "zkm_oracle.h"
+#include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "gl.h"
 
 static gl_t col_eval_table(const zko_ctl_table* t, uint32_t ci, const uint64_t* trace, size_t n, size_t row) {
@@ -353,9 +356,13 @@ int zko_prove_with_traces(const zko_stark_config* cfg, const zko_table_input* ta
     for (size_t t = 0; t < ntables && !rc; t++) {
         size_t n = (size_t)1 << tables[t].log_n;
         uint64_t* aux = (uint64_t*)calloc(tz[t].naux * n + 1, sizeof(uint64_t));
+        double t0 = omp_get_wtime();
         zko_ctl_data(tables[t].ctl, tz[t].zs, tz[t].ids, tz[t].nzs, tables[t].trace, tables[t].ncols, tables[t].log_n, aux);
+        double t1 = omp_get_wtime();
+        if (getenv("ZKO_TIMING")) fprintf(stderr, "[oracle] table %zu id %d: ctl_data %.2f s\n", t, tables[t].table_id, t1 - t0);
         rc = zko_prove_single_table_ctl(tables[t].table_id, cfg, tables[t].trace, tables[t].ncols, tables[t].log_n, aux, tz[t].naux,
                                         tables[t].ctl, tz[t].zs, tz[t].ids, tz[t].nzs, lookup_ch, &ch, proofs + offs[t]);
+        if (getenv("ZKO_TIMING")) fprintf(stderr, "[oracle] table %zu id %d: prove %.2f s\n", t, tables[t].table_id, omp_get_wtime() - t1);
         free(aux);
     }
     free_zs(tz, ntables);

@@ -35,13 +35,16 @@ static inline gl_t gl_sub(gl_t a, gl_t b) { return a >= b ? a - b : a - b + GL_P
 static inline gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
 
 static inline gl_t gl_reduce128(u128_t x) {
+    /* 2^64 == 2^32 - 1 and 2^96 == -1 (mod p).  Branch-free: the two corrections are data dependent with probability ~1/2
+     * (mispredicted branches cost more than the arithmetic), so they are applied through masks. */
     uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
     uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
-    uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS;
+    uint64_t t0, r;
+    uint64_t borrow = __builtin_sub_overflow(lo, hi_hi, &t0);
+    t0 -= (0 - borrow) & GL_EPS;                 /* lo - hi_hi + 2^64 == ... - EPS (mod p); cannot borrow again: t0 >= 2^64 - 2^32 */
     uint64_t t1 = hi_lo * GL_EPS;
-    uint64_t r = t0 + t1;
-    if (r < t1) r += GL_EPS;
+    uint64_t carry = __builtin_add_overflow(t0, t1, &r);
+    r += (0 - carry) & GL_EPS;                   /* cannot carry again: after a wrap r < 2^64 - 2^32 */
     return gl_canon(r);
 }
 static inline gl_t gl_mul(gl_t a, gl_t b) { return gl_reduce128((u128_t)a * b); }

@@ -721,6 +721,9 @@ static int prove_generic_ex(int table_id, const zko_stark_config* cfg, const uin
         zko_batch_free(qb);
     }
     if (stage_s) memcpy(stage_s, ts, sizeof ts);
+    if (getenv("ZKO_TIMING"))
+        fprintf(stderr, "[oracle] table %d 2^%u: trace %.2f aux %.2f quotient %.2f qcommit %.2f open %.2f combine %.2f fri+pow %.2f queries %.2f s\n",
+                table_id, log_n, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], ts[7]);
     return 0;
 }
 

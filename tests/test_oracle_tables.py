@@ -295,3 +295,52 @@ def test_arithmetic_table_all_operations(oracle):
     bad = trace.copy()
     bad[30 * n + 40000] = 1 << 16
     assert not _arith_proof_ok(oracle, bad)
+
+
+# ---- known-answer vectors held by the reference's own SHA table tests
+REF_SHA_W = [
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 34013193, 67559435, 1711661200, 3020350282, 1447362251, 3118632270,
+    4004188394, 690615167, 6070360, 1105370215, 2385558114, 2348232513, 507799627, 2098764358, 5845374, 823657968, 2969863067,
+    3903496557, 4274682881, 2059629362, 1849247231, 2656047431, 835162919, 2096647516, 2259195856, 1779072524, 3152121987,
+    4210324067, 1557957044, 376930560, 982142628, 3926566666, 4164334963, 789545383, 1028256580, 2867933222, 3843938318,
+    1135234440, 390334875, 2025924737, 3318322046, 3436065867, 652746999, 4261492214, 2543173532, 3334668051, 3166416553,
+    634956631]
+REF_SHA_H = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+REF_SHA_OUTPUT_HX = [3592665057, 2164530888, 1223339564, 3041196771, 2006723467, 2963045520, 3851824201, 3453903005]
+
+
+def _le4(tr, col, row):
+    return sum(int(tr[col + j][row]) << (8 * j) for j in range(4))
+
+
+def test_sha_compress_reference_vector(oracle):
+    """sha_compress/sha_compress_stark.rs:933-965 test_generation: round 0 on the SHA-256 IV with w_0 = 0, K_0:
+    temp1_add_temp2.value == 4228417613 and d_add_temp1.value == 2563236514 (columns 140.. and 134.. of columns.rs:41-43)."""
+    tr = oracle.sha_compress_trace([REF_SHA_H], [REF_SHA_W], np.zeros((1, 8), dtype=np.uint64), 7).reshape(224, 128)
+    assert _le4(tr, 140, 0) == 4228417613
+    assert _le4(tr, 134, 0) == 2563236514
+    assert _le4(tr, 36, 0) == 0 and _le4(tr, 40, 0) == 0x428a2f98  # w_0, K_0 (constants.rs SHA_COMPRESS_K[0])
+
+
+def test_sha_compress_sponge_reference_vector(oracle):
+    """sha_compress_sponge/sha_compress_sponge_stark.rs:380-448 test_generation: the eight output_hx words of one
+    compression of W on the IV (output_hx[q].value = columns 64 + 6 q .. + 3, columns.rs:6-12)."""
+    tr = oracle.sha_compress_sponge_trace([REF_SHA_H], [REF_SHA_W], np.zeros((1, 8), dtype=np.uint64), 3).reshape(127, 8)
+    assert [_le4(tr, 64 + 6 * q, 0) for q in range(8)] == REF_SHA_OUTPUT_HX
+    # the reference's W is itself a message schedule: w[16..] extend w[0..15] (sha_extend) -- ties the two tables together
+    sp, used = oracle.sha_extend_sponge_trace([REF_SHA_W[:16]], np.zeros((1, 4), dtype=np.uint64), 6)
+    sp = sp.reshape(76, 64)
+    assert used == 48 and [_le4(sp, 64, r) for r in range(48)] == REF_SHA_W[16:]
+
+
+def test_sha_extend_reference_vector(oracle):
+    """sha_extend/sha_extend_stark.rs:443-476 test_correction: inputs w[i-15], w[i-2], w[i-16], w[i-7] = 0, 1, 2, 3."""
+    inp = np.array([0, 1, 2, 3], dtype="<u4").view(np.uint8)
+    tr = oracle.sha_extend_trace(inp, [0], 2).reshape(78, 4)
+    rotr = lambda x, r: ((x >> r) | (x << (32 - r))) & 0xFFFFFFFF
+    s0 = rotr(0, 7) ^ rotr(0, 18) ^ (0 >> 3)
+    s1 = rotr(1, 17) ^ rotr(1, 19) ^ (1 >> 10)
+    assert _le4(tr, 0, 0) == (s1 + 2 + s0 + 3) & 0xFFFFFFFF == 40965
+    # and against the reference's W: w[16] = extend(w[1], w[14], w[0], w[9])
+    inp = np.array([REF_SHA_W[1], REF_SHA_W[14], REF_SHA_W[0], REF_SHA_W[9]], dtype="<u4").view(np.uint8)
+    assert _le4(oracle.sha_extend_trace(inp, [0], 2).reshape(78, 4), 0, 0) == REF_SHA_W[16] == 34013193

@@ -90,6 +90,59 @@ def test_segment_image_round_trip_and_sizing(zkm, oracle):
         assert b"zkm_prove_segment_image" in err.value
 
 
+def test_segment_image_hostile_headers_are_rejected(zkm, oracle):
+    """every size in the image header is untrusted.  Values chosen so that the sums the old checks formed
+    (o + npub + 8 ntables, 3 ncolumns + nterms + ..., ncols << log_n, looking_off + nlooking) wrap around 2^64."""
+    import ctypes as C
+    tables, ctls = build(oracle)
+    img = zkm.segment_image(tables, ctls, public_values=[1, 2])
+    lib = zkm.load()
+    cfg = zkm.StarkConfig()
+    lib.zkm_standard_config(C.byref(cfg))
+    u64p = C.POINTER(C.c_uint64)
+    nt, npub, nctls = int(img[2]), int(img[3]), int(img[4])
+    th = 8 + npub                       # first table record
+    M = (1 << 64) - 1
+
+    def rejected(edit):
+        bad = img.copy()
+        edit(bad)
+        offs = (C.c_size_t * (nt + 1))()
+        total = C.c_size_t()
+        err = C.c_char_p()
+        rc = lib.zkm_prove_segment_image(None, C.byref(cfg), bad.ctypes.data_as(u64p), bad.size, None, C.byref(total), offs, None, C.byref(err))
+        return rc != 0 and b"zkm_prove_segment_image" in (err.value or b"")
+
+    def setw(i, v):
+        def f(a):
+            a[i] = np.uint64(v)
+        return f
+    assert rejected(setw(3, M - 15))                    # npub: o + npub + 8 ntables wraps to a small number
+    assert rejected(setw(3, 1 << 63))
+    assert rejected(setw(2, 4097))                      # ntables over the limit
+    assert rejected(setw(4, M))                         # nctls
+    assert rejected(setw(5, M - 3))                     # nsides: o + 2 nctls + nsides wraps
+    for f, v in ((4, (M // 3) + 2), (4, M), (5, M), (5, M - 1), (6, (1 << 62) + 1), (7, M), (7, M - 1)):
+        assert rejected(setw(th + f, v)), (f, v)        # ncolumns / nterms / ncolsets / nfilter_idx: the `need` sum wraps
+    assert rejected(setw(th + 1, 1 << 60))              # ncols so large that ncols << log_n wraps
+    assert rejected(setw(th + 1, 0))
+    assert rejected(setw(th + 2, 41))                   # log_n
+    assert rejected(setw(th + 2, 64))
+    assert rejected(setw(th + 3, M))                    # trace offset
+    assert rejected(setw(th + 3, img.size))
+    # looking_off + nlooking wrapping in 32 bits / pointing past the sides array
+    ctl0 = None
+    o = 8 + npub + 8 * nt
+    for t in range(nt):
+        h = img[th + 8 * t: th + 8 * t + 8]
+        o += 3 * int(h[4]) + (int(h[5]) + 1) // 2 + int(h[5]) + 4 * int(h[6]) + (int(h[7]) + 1) // 2
+    ctl0 = o
+    assert nctls > 0
+    assert rejected(setw(ctl0, (0xFFFFFFFF << 32) | 2))          # looking_off = 2^32 - 1, nlooking = 2
+    assert rejected(setw(ctl0, (1 << 32) | 0xFFFFFFFF))          # nlooking = 2^32 - 1
+    assert not rejected(lambda a: None)                          # the untouched image still parses
+
+
 @pytest.mark.gpu
 def test_prove_from_image_equals_in_memory_path(ctx, zkm, oracle):
     tables, ctls = build(oracle)

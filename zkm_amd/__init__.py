@@ -27,7 +27,7 @@ TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRES
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
-    "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_memory", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
+    "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_memory", "zkm_ctx_trim", "zkm_table_enum_index", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
     "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_free",
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_keccak_trace", "zkm_logic_trace",
@@ -127,6 +127,8 @@ def load():
         "zkm_sha_compress_sponge_trace": (C.c_int, [cp, cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_keccak_trace": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_ctx_memory": (None, [cp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+        "zkm_ctx_trim": (None, [cp]),
+        "zkm_table_enum_index": (C.c_int, [C.c_int]),
         "zkm_logic_trace": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_table_width": (C.c_size_t, [C.c_int]),
         "zkm_challenger_init": (None, [C.POINTER(Challenger)]),
@@ -250,6 +252,10 @@ class Context:
         live, cached = C.c_size_t(), C.c_size_t()
         self.L.zkm_ctx_memory(self.h, C.byref(live), C.byref(cached))
         return live.value, cached.value
+
+    def trim(self):
+        """Return the allocator's cached blocks to the device."""
+        self.L.zkm_ctx_trim(self.h)
 
     def synchronize(self):
         err = C.c_char_p()

@@ -32,14 +32,19 @@ void* zkm_ctx::alloc(size_t bytes) {
     } else {
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
-            // drop the cache and retry once
-            for (auto& kv : free_blocks) (void)hipFree(kv.second);
-            free_blocks.clear();
+            // drop the cache and retry once; the failed call's error must not stay behind as the "last error" of the next launch check
+            (void)hipGetLastError();
+            trim();
             ZKM_HIP_CHECK(hipMalloc(&p, bytes));
         }
     }
     live_blocks[p] = bytes;
     return p;
+}
+void zkm_ctx::trim() {
+    (void)hipStreamSynchronize(stream);  // cached blocks may still be in use by queued kernels
+    for (auto& kv : free_blocks) (void)hipFree(kv.second);
+    free_blocks.clear();
 }
 void zkm_ctx::release(void* p) {
     if (!p) return;
@@ -136,6 +141,12 @@ void zkm_ctx_memory(const zkm_ctx* c, size_t* live_bytes, size_t* cached_bytes) 
     for (auto& kv : c->free_blocks) cached += kv.first;
     if (live_bytes) *live_bytes = live;
     if (cached_bytes) *cached_bytes = cached;
+}
+
+void zkm_ctx_trim(zkm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    c->trim();
 }
 
 int zkm_dev_alloc(zkm_ctx* c, size_t bytes, void** out, char** err) {

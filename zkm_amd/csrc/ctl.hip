@@ -8,7 +8,8 @@
 #include "ctl_dev.h"
 
 // ------------------------------------------------------------------ descriptor upload + validation
-void ctl_dev_owner::upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, bool lookup_mode) {
+void ctl_dev_owner::upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, bool lookup_mode,
+                           size_t trace_ncols) {
     c = ctx;
     static const zkm_ctl_table empty{};
     if (!t) t = &empty;
@@ -36,8 +37,13 @@ void ctl_dev_owner::upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z
     for (size_t i = 0; i < t->ncolumns; i++)
         if ((size_t)t->columns[i].term_off + t->columns[i].n_local + t->columns[i].n_next > t->nterms)
             throw std::runtime_error("CTL description: term range out of bounds");
-    for (size_t i = 0; i < t->nterms; i++)
+    for (size_t i = 0; i < t->ncolumns; i++)
+        if (t->columns[i].constant >= GL_P) throw std::runtime_error("CTL description: non-canonical constant");
+    for (size_t i = 0; i < t->nterms; i++) {
         if (t->term_coeff[i] >= GL_P) throw std::runtime_error("CTL description: non-canonical coefficient");
+        // every kernel that evaluates the description indexes trace columns with term_col: checked before anything is launched
+        if (trace_ncols && t->term_col[i] >= trace_ncols) throw std::runtime_error("CTL description: trace column index out of range");
+    }
     // one blob: [columns | term_coeff | colsets | zs | term_col | filter_idx | colset_ids]
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t o_cols = 0, o_coeff = al(o_cols + t->ncolumns * sizeof(zkm_column)), o_sets = al(o_coeff + t->nterms * 8);
@@ -296,7 +302,7 @@ int zkm_ctl_data(zkm_ctx* c, const zkm_ctl_table* table, const zkm_ctl_z* zs, co
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         size_t n = (size_t)1 << log_n;
         ctl_dev_owner own;
-        own.upload(c, table, zs, colset_ids, nzs);
+        own.upload(c, table, zs, colset_ids, nzs, false, ncols);
         for (size_t i = 0; i < (table ? table->nterms : 0); i++)
             if (table->term_col[i] >= ncols) throw std::runtime_error("CTL description: trace column index out of range");
         bool tdev = zkm_is_device_ptr(trace), adev = zkm_is_device_ptr(aux_out);
@@ -325,12 +331,13 @@ int zkm_ctl_data(zkm_ctx* c, const zkm_ctl_table* table, const zkm_ctl_z* zs, co
 
 // (ceil(nlookup / 2) + 1) columns of n into d_out (device): helper columns then Z (lookup.rs:46-124)
 static void lookup_helper_columns_device(zkm_ctx* c, const zkm_ctl_table* table, const uint32_t* colset_ids, size_t nlookup, uint32_t table_col,
-                                         uint32_t freq_col, uint64_t challenge, const gl_t* d_trace, size_t n, gl_t* d_out) {
+                                         uint32_t freq_col, uint64_t challenge, const gl_t* d_trace, size_t n, gl_t* d_out,
+                                         size_t trace_ncols = 0) {
     std::vector<void*> tmp;
     size_t nh = (nlookup + 1) / 2;
     zkm_ctl_z z{(uint32_t)nlookup, 0, (uint32_t)nh, 0, 1, challenge};  // GrandProductChallenge{beta: 1, gamma: challenge}
     ctl_dev_owner own;
-    own.upload(c, table, &z, colset_ids, 1, /*lookup_mode=*/true);
+    own.upload(c, table, &z, colset_ids, 1, /*lookup_mode=*/true, trace_ncols);
     try {
         gl_t* d_hsum = (gl_t*)c->alloc(n * 8);
         tmp.push_back(d_hsum);
@@ -412,7 +419,7 @@ int zkm_lookup_helper_columns(zkm_ctx* c, const zkm_ctl_table* table, const uint
         if (!tdev) { tmp.push_back(d_trace); ZKM_HIP_CHECK(hipMemcpyAsync(d_trace, trace, ncols * n * 8, hipMemcpyHostToDevice, c->stream)); }
         gl_t* d_out = odev ? out : (gl_t*)c->alloc((nh + 1) * n * 8);
         if (!odev) tmp.push_back(d_out);
-        lookup_helper_columns_device(c, table, colset_ids, nlookup, table_col, freq_col, challenge, d_trace, n, d_out);
+        lookup_helper_columns_device(c, table, colset_ids, nlookup, table_col, freq_col, challenge, d_trace, n, d_out, ncols);
         if (!odev) ZKM_HIP_CHECK(hipMemcpyAsync(out, d_out, (nh + 1) * n * 8, hipMemcpyDeviceToHost, c->stream));
         c->sync();
         for (void* p : tmp) c->release(p);
@@ -423,6 +430,15 @@ int zkm_lookup_helper_columns(zkm_ctx* c, const zkm_ctl_table* table, const uint
         return fail(err, e.what());
     }
     return 0;
+}
+
+int zkm_table_enum_index(int table_id) {
+    static const int order[12] = {ZKM_TABLE_ARITHMETIC, ZKM_TABLE_CPU, ZKM_TABLE_POSEIDON, ZKM_TABLE_POSEIDON_SPONGE, ZKM_TABLE_KECCAK,
+                                  ZKM_TABLE_KECCAK_SPONGE, ZKM_TABLE_SHA_EXTEND, ZKM_TABLE_SHA_EXTEND_SPONGE, ZKM_TABLE_SHA_COMPRESS,
+                                  ZKM_TABLE_SHA_COMPRESS_SPONGE, ZKM_TABLE_LOGIC, ZKM_TABLE_MEMORY};
+    for (int i = 0; i < 12; i++)
+        if (order[i] == table_id) return i;
+    return -1;
 }
 
 size_t zkm_all_proof_words(const zkm_stark_config* cfg, const zkm_table_input* tables, size_t ntables,
@@ -448,7 +464,21 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
     std::vector<zkm_batch*> commits(ntables, nullptr);
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
-        if (cfg->num_challenges > 4) throw std::runtime_error("too many challenges");
+        if (ntables == 12) {  // a whole AllStark segment: the transcript only matches the reference's in Table::all() order
+            bool all = true, ordered = true;
+            for (size_t t = 0; t < 12; t++) {
+                int e = zkm_table_enum_index(tables[t].table_id);
+                all = all && e >= 0;
+                ordered = ordered && e == (int)t;
+            }
+            bool distinct = all;
+            for (size_t a = 0; a < 12 && distinct; a++)
+                for (size_t b = a + 1; b < 12; b++)
+                    if (tables[a].table_id == tables[b].table_id) distinct = false;
+            if (distinct && !ordered)
+                throw std::runtime_error("zkm_prove_with_traces: the twelve tables must be given in the reference's Table enum order "
+                                         "(all_stark.rs:96-110; see zkm_table_enum_index)");
+        }
         std::vector<size_t> offs(ntables + 1);
         if (!zkm_all_proof_words(cfg, tables, ntables, ctls, sides, nctls, offs.data()) && ntables)
             throw std::runtime_error("zkm_prove_with_traces: malformed cross-table lookups");
@@ -476,7 +506,7 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
         for (size_t t = 0; t < ntables; t++) {
             size_t n = (size_t)1 << tables[t].log_n;
             ctl_dev_owner own;
-            own.upload(c, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size());
+            own.upload(c, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), false, tables[t].ncols);
             bool tdev = zkm_is_device_ptr(tables[t].trace);
             gl_t* d_trace = tdev ? const_cast<gl_t*>(tables[t].trace) : (gl_t*)c->alloc(tables[t].ncols * n * 8);
             if (!tdev) ZKM_HIP_CHECK(hipMemcpyAsync(d_trace, tables[t].trace, tables[t].ncols * n * 8, hipMemcpyHostToDevice, c->stream));

@@ -208,16 +208,35 @@ __global__ __launch_bounds__(512) void k_ntt_pass(ntt_pass_args p) {
 
     const uint32_t col0 = blockIdx.y * p.cpb;
     const uint32_t col1 = col0 + p.cpb < p.ncols ? col0 + p.cpb : p.ncols;
-    for (uint32_t col = col0; col < col1; col++) {
+    // Software pipeline over the workgroup's columns: the 8 words of column c + 1 are requested before column c is
+    // transformed (16 VGPRs), so the HBM latency of the next loads is covered by ~800 VALU instructions instead of
+    // being exposed at the top of every iteration.  nx[] holds raw words; the coset pre-scale is applied when they are consumed.
+    gl_t nx[8];
+    auto fetch = [&](uint32_t col) {
         const gl_t* __restrict__ src = p.in + (size_t)col * p.cs_in;
-        gl_t* __restrict__ dst = p.out + (size_t)col * p.cs_out;
-        gl_t x[8];
         if (!IN_A) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 uint32_t off = in0 + (uint32_t)j * in_step;
-                x[j] = off < p.n_in ? src[off] : 0;
+                nx[j] = off < p.n_in ? src[off] : 0;
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                int idx = tid + e * nthreads;
+                int a = idx & (R - 1), bb = idx >> S;
+                size_t off = base_in + (size_t)a * p.sa_in + (size_t)bb * p.sb_in;
+                nx[e] = off < p.n_in ? src[off] : 0;
+            }
+        }
+    };
+    if (col0 < col1) fetch(col0);
+    for (uint32_t col = col0; col < col1; col++) {
+        gl_t* __restrict__ dst = p.out + (size_t)col * p.cs_out;
+        gl_t x[8];
+        if (!IN_A) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = nx[j];
             __builtin_amdgcn_sched_barrier(0);
             if (do_pre) {
 #pragma unroll
@@ -234,13 +253,15 @@ __global__ __launch_bounds__(512) void k_ntt_pass(ntt_pass_args p) {
                 int idx = tid + e * nthreads;
                 int a = idx & (R - 1), bb = idx >> S;
                 size_t off = base_in + (size_t)a * p.sa_in + (size_t)bb * p.sb_in;
-                gl_t v = off < p.n_in ? src[off] : 0;
+                gl_t v = nx[e];
                 if (do_pre && off < p.n_in) v = gl_mul_loose(v, pow_lookup(p.pre_tab, p.pre_log, off));
                 lds[a * tp + bb] = v;
             }
             __syncthreads();
             R0::lds_read(lds, tp, b, rg, x);
         }
+        if (col + 1 < col1) fetch(col + 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (!IN_A && S >= 3 && p.zero_padded) R0::compute_zero_padded(x, w0);
         else R0::compute(x, w0);
         if (NR > 1) {

@@ -136,37 +136,53 @@ int zkm_prove_segment_image(zkm_ctx* c, const zkm_stark_config* cfg, const uint6
                             size_t* proof_words_out, size_t* offsets_out, uint64_t* challenges, char** err) {
     if (!img || image_words < HEADER_WORDS || img[0] != SEGMENT_MAGIC) return fail_msg(err, "zkm_prove_segment_image: not a ZKMTRACE image");
     if (img[1] != SEGMENT_VERSION) return fail_msg(err, "zkm_prove_segment_image: unsupported image version");
-    const size_t ntables = img[2], npub = img[3], nctls = img[4], nsides = img[5];
+    // Every size below comes from the image: all checks are subtractions against the words that remain (no sums of untrusted
+    // 64-bit fields, which could wrap), and every field is bounded before it is multiplied or used as a shift count.
+    const uint64_t ntables = img[2], npub = img[3], nctls = img[4], nsides = img[5];
     size_t o = HEADER_WORDS;
-    if (ntables > 4096 || nctls > 65536 || o + npub + TABLE_WORDS * ntables > image_words) return fail_msg(err, "zkm_prove_segment_image: truncated header");
+    auto take = [&](uint64_t words, size_t per) -> bool {  // reserve words * per image words at o; false if they do not fit
+        if (per && words > (image_words - o) / per) return false;
+        o += (size_t)words * per;
+        return true;
+    };
+    if (ntables > 4096 || nctls > 65536) return fail_msg(err, "zkm_prove_segment_image: truncated header");
     const uint64_t* pub = img + o;
-    o += npub;
+    if (!take(npub, 1)) return fail_msg(err, "zkm_prove_segment_image: truncated header");
     const uint64_t* th = img + o;
-    o += TABLE_WORDS * ntables;
+    if (!take(ntables, TABLE_WORDS)) return fail_msg(err, "zkm_prove_segment_image: truncated header");
     std::vector<zkm_ctl_table> descs(ntables);
     std::vector<zkm_table_input> tables(ntables);
     for (size_t t = 0; t < ntables; t++) {
         const uint64_t* h = th + TABLE_WORDS * t;
         zkm_ctl_table& d = descs[t];
+        const char* trunc = "zkm_prove_segment_image: truncated table description";
+        // (u32 arrays are stored two per word: counts are bounded by twice the remaining words before u32_words() rounds them)
+        if (h[1] == 0 || h[1] > (1u << 20) || h[2] > 40) return fail_msg(err, "zkm_prove_segment_image: table width / height out of range");
+        if (h[5] > 2 * (uint64_t)(image_words - o) || h[7] > 2 * (uint64_t)(image_words - o)) return fail_msg(err, trunc);
         d.ncolumns = h[4]; d.nterms = h[5]; d.ncolsets = h[6]; d.nfilter_idx = h[7];
-        size_t need = 3 * d.ncolumns + u32_words(d.nterms) + d.nterms + 4 * d.ncolsets + u32_words(d.nfilter_idx);
-        if (h[2] > 40 || o + need > image_words) return fail_msg(err, "zkm_prove_segment_image: truncated table description");
-        d.columns = (const zkm_column*)(img + o); o += 3 * d.ncolumns;
-        d.term_col = (const uint32_t*)(img + o); o += u32_words(d.nterms);
-        d.term_coeff = img + o; o += d.nterms;
-        d.colsets = (const zkm_colset*)(img + o); o += 4 * d.ncolsets;
-        d.filter_idx = (const uint32_t*)(img + o); o += u32_words(d.nfilter_idx);
+        d.columns = (const zkm_column*)(img + o);
+        if (!take(h[4], 3)) return fail_msg(err, trunc);
+        d.term_col = (const uint32_t*)(img + o);
+        if (!take(u32_words(d.nterms), 1)) return fail_msg(err, trunc);
+        d.term_coeff = img + o;
+        if (!take(h[5], 1)) return fail_msg(err, trunc);
+        d.colsets = (const zkm_colset*)(img + o);
+        if (!take(h[6], 4)) return fail_msg(err, trunc);
+        d.filter_idx = (const uint32_t*)(img + o);
+        if (!take(u32_words(d.nfilter_idx), 1)) return fail_msg(err, trunc);
         tables[t].table_id = (int)h[0]; tables[t].ncols = h[1]; tables[t].log_n = (unsigned)h[2]; tables[t].ctl = &d;
-        size_t words = (size_t)h[1] << h[2];
+        // ncols <= 2^20 and log_n <= 40: the product cannot wrap
+        const uint64_t words = h[1] << h[2];
         if (h[3] > image_words || words > image_words - h[3]) return fail_msg(err, "zkm_prove_segment_image: trace data out of bounds");
         tables[t].trace = img + h[3];
     }
-    if (o + 2 * nctls + nsides > image_words) return fail_msg(err, "zkm_prove_segment_image: truncated lookup description");
     const zkm_cross_table_lookup* ctls = (const zkm_cross_table_lookup*)(img + o);
-    o += 2 * nctls;
+    if (!take(nctls, 2)) return fail_msg(err, "zkm_prove_segment_image: truncated lookup description");
     const zkm_ctl_side* sides = (const zkm_ctl_side*)(img + o);
+    if (!take(nsides, 1)) return fail_msg(err, "zkm_prove_segment_image: truncated lookup description");
     for (size_t i = 0; i < nctls; i++)
-        if ((size_t)ctls[i].looking_off + ctls[i].nlooking > nsides) return fail_msg(err, "zkm_prove_segment_image: looking sides out of range");
+        if (ctls[i].looking_off > nsides || ctls[i].nlooking > nsides - ctls[i].looking_off)
+            return fail_msg(err, "zkm_prove_segment_image: looking sides out of range");
     std::vector<size_t> offs(ntables + 1, 0);
     size_t total = zkm_all_proof_words(cfg, tables.data(), ntables, ctls, sides, nctls, offs.data());
     if (!total && ntables) return fail_msg(err, "zkm_prove_segment_image: malformed cross-table lookups");

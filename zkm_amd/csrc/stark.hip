@@ -18,11 +18,28 @@ struct proof_layout {
 // FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) (config.rs:25)
 static unsigned fri_num_layers(const zkm_stark_config* c, unsigned degree_bits) {
     unsigned l = 0, d = degree_bits;
-    while (d > c->final_poly_bits && d + c->rate_bits - c->arity_bits >= c->cap_height) { d -= c->arity_bits; l++; }
+    // (d >= arity_bits keeps the subtraction from wrapping when final_poly_bits < arity_bits)
+    while (d > c->final_poly_bits && d >= c->arity_bits && d + c->rate_bits - c->arity_bits >= c->cap_height) { d -= c->arity_bits; l++; }
     return l;
 }
 
+// Every field of the caller's config is checked once, here, before any allocation or transcript mutation (make_layout is the first
+// thing every prove entry point and zkm_proof_words call).  The quotient kernels carry at most two alpha accumulators
+// (StarkConfig::num_challenges = 2 in standard_fast_config, config.rs:17-30).
+static void validate_config(const zkm_stark_config* c, unsigned log_n) {
+    if (!c) throw std::runtime_error("stark config: null");
+    if (log_n == 0 || log_n > 32) throw std::runtime_error("stark config: degree_bits out of range");
+    if (c->rate_bits != 2) throw std::runtime_error("stark config: only rate_bits = 2 is supported");
+    if (c->arity_bits < 2 || c->arity_bits > 6) throw std::runtime_error("stark config: arity_bits must be in 2..6");
+    if (c->pow_bits == 0 || c->pow_bits > 32) throw std::runtime_error("stark config: proof_of_work_bits must be in 1..32");
+    if (c->num_challenges < 1 || c->num_challenges > 2) throw std::runtime_error("stark config: num_challenges must be 1 or 2");
+    if (c->num_queries == 0 || c->num_queries > 4096) throw std::runtime_error("stark config: num_query_rounds must be in 1..4096");
+    if (c->cap_height > log_n + c->rate_bits) throw std::runtime_error("stark config: cap_height exceeds the height of the Merkle tree");
+    if (c->final_poly_bits > 32) throw std::runtime_error("stark config: final_poly_bits out of range");
+}
+
 static void make_layout(proof_layout& y, const zkm_stark_config* c, unsigned log_n, size_t W, size_t A, size_t Z) {
+    validate_config(c, log_n);
     y.log_n = log_n; y.lde_bits = log_n + c->rate_bits; y.cap = c->cap_height;
     y.W = W; y.A = A; y.Q = (size_t)c->num_challenges * 2; y.Z = Z;
     y.L = fri_num_layers(c, log_n);
@@ -666,8 +683,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
     // openings-only mode (zkm_prove_openings, BASELINE config 4): the three commitments exist already; the transcript
     // is compact -> zeta -> openings -> prove_openings
     const bool openings_only = aux_batch_in != nullptr;
-    if (cfg->rate_bits != 2 || cfg->arity_bits < 2 || cfg->arity_bits > 6 || cfg->pow_bits == 0 || cfg->pow_bits > 32)
-        throw std::runtime_error("zkm_prove_single_table: unsupported FRI configuration");
+    validate_config(cfg, log_n);  // before zkm_num_lookup_columns reads it; make_layout checks again
     // the table's own lookup helper columns come first among the auxiliary polynomials (prover.rs:467-508)
     const size_t NL = openings_only ? 0 : zkm_num_lookup_columns(table_id, cfg);
     if (NL && !lookup_challenges) throw std::runtime_error("this table has lookups: lookup challenges are required");
@@ -688,7 +704,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
     if (A_ctl == 0) throw std::runtime_error("No CTL? aux column count does not match the CTL description");  // prover.rs:509
     const size_t total_helpers = A - Z;  // index of the first CTL Z among the auxiliary polynomials
     ctl_dev_owner own;
-    if (!openings_only) own.upload(c, ctl_table, zs, colset_ids, Z);
+    if (!openings_only) own.upload(c, ctl_table, zs, colset_ids, Z, false, W);
     if (ctl_table && !openings_only)
         for (size_t i = 0; i < ctl_table->nterms; i++)
             if (ctl_table->term_col[i] >= W) throw std::runtime_error("CTL description: trace column index out of range");
@@ -957,9 +973,13 @@ static int fail(char** err, const std::string& msg) {
 extern "C" {
 
 size_t zkm_proof_words(const zkm_stark_config* cfg, unsigned log_n, size_t ncols, size_t naux, size_t nctl_zs) {
-    proof_layout y;
-    make_layout(y, cfg, log_n, ncols, naux, nctl_zs);
-    return y.total;
+    try {  // 0 = unsupported configuration (the prove entry points report which field)
+        proof_layout y;
+        make_layout(y, cfg, log_n, ncols, naux, nctl_zs);
+        return y.total;
+    } catch (...) {
+        return 0;
+    }
 }
 
 // CtlZData of the benchmark's fake CTL shape: helper columns, no column sets (poseidon_stark.rs:786-799)

@@ -57,6 +57,7 @@ struct zkm_ctx {
 
     void* alloc(size_t bytes);
     void release(void* p);
+    void trim();  // hipFree every cached (not live) block
     void ensure_twiddles(unsigned log_n);
     const gl_t* pow_table(uint64_t shift, unsigned log_n);  // lo: 2^ceil(log_n/2) entries, then hi
     uint64_t* staging(size_t words);
@@ -64,6 +65,17 @@ struct zkm_ctx {
     void prof_begin(const char* name);
     void prof_end();
     void sync() { ZKM_HIP_CHECK(hipStreamSynchronize(stream)); }
+};
+
+// RAII owner of one scratch block from the context's allocator (released on every exit path)
+struct zkm_scratch {
+    zkm_ctx* c;
+    void* p;
+    zkm_scratch(zkm_ctx* ctx, size_t bytes) : c(ctx), p(ctx->alloc(bytes)) {}
+    zkm_scratch(const zkm_scratch&) = delete;
+    zkm_scratch& operator=(const zkm_scratch&) = delete;
+    ~zkm_scratch() { c->release(p); }
+    template <class T> T* as() const { return (T*)p; }
 };
 
 // RAII profiling scope around one kernel launch (or a small group)
