@@ -39,6 +39,14 @@ void zkm_ctx_memory(const zkm_ctx* ctx, size_t* live_bytes, size_t* cached_bytes
 /* Return every cached (not live) block to the device (the free lists are exact-size: a segment of many table shapes leaves one
  * cached block per distinct size behind). */
 void zkm_ctx_trim(zkm_ctx* ctx);
+/* Pinned host memory (N3, trace ingest): host-resident traces (the reference's Vec<PolynomialValues>, prover.rs:144-167) are
+ * uploaded in column chunks on a copy stream while earlier chunks are transformed and hashed; that overlap needs page-locked
+ * source memory.  Either let the witness generator write into zkm_host_alloc memory, or zkm_host_register its own buffers once.
+ * Pageable host pointers are accepted everywhere too (the upload then blocks the calling thread chunk by chunk). */
+int zkm_host_alloc(zkm_ctx* ctx, size_t bytes, void** out, char** err);
+int zkm_host_free(zkm_ctx* ctx, void* p);
+int zkm_host_register(zkm_ctx* ctx, void* p, size_t bytes, char** err);
+int zkm_host_unregister(zkm_ctx* ctx, void* p);
 int zkm_dev_alloc(zkm_ctx* ctx, size_t bytes, void** out, char** err);
 int zkm_dev_free(zkm_ctx* ctx, void* p);
 int zkm_dev_upload(zkm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, char** err);
@@ -68,6 +76,9 @@ int zkm_batch_cap(const zkm_batch* b, uint64_t* out);
 int zkm_batch_coeffs(const zkm_batch* b, uint64_t* out);
 /* get_lde_values(natural_index, 1) (prover.rs:687): one LDE row, ncols words, host out */
 int zkm_batch_lde_row(const zkm_batch* b, size_t natural_index, uint64_t* out);
+/* get_lde_values_packed(index_start, step) generalised to `count` consecutive indices (prover.rs:687, 723-748: the quotient
+ * loop reads rows i_start .. i_start + P::WIDTH): out[i * ncols + c] = get_lde_values(index_start + i, step)[c], host or device */
+int zkm_batch_lde_rows(const zkm_batch* b, size_t index_start, size_t step, size_t count, uint64_t* out);
 /* merkle_tree.leaves[leaf_index] and merkle_tree.prove(leaf_index): (lde_bits - cap_height) x 4 words */
 int zkm_batch_leaf(const zkm_batch* b, size_t leaf_index, uint64_t* out);
 int zkm_batch_merkle_path(const zkm_batch* b, size_t leaf_index, uint64_t* siblings_out);
@@ -353,6 +364,18 @@ int zkm_prove_with_traces(zkm_ctx* ctx, const zkm_stark_config* cfg, const zkm_t
                           const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls,
                           const uint64_t* public_values, size_t npublic, uint64_t* proofs_out, uint64_t* ctl_challenges_out,
                           char** err);
+
+/* The AllStark of the reference (all_stark.rs:96-155, 136-542) ships with the library, so a caller proves a whole segment from
+ * the twelve traces alone: zkm_all_stark_ctls returns the fifteen cross-table lookups (sides name tables by their position in
+ * the Table enum, all_stark.rs:96-110), zkm_all_stark_ctl_table the column sets of one table, and zkm_prove_segment ==
+ * prove_with_traces (prover.rs:130-232) on traces[t] / log_n[t] of Table::all()[t] (widths: zkm_table_width).  Pass
+ * proofs_out = NULL to size the output first: proof_offsets_out[13] (offsets of the twelve blobs + the total).
+ * (csrc/all_stark_ctl.inc is generated from zkm_amd/tables.py by tools/gen_all_stark_ctl.py.) */
+int zkm_all_stark_ctls(const zkm_cross_table_lookup** ctls_out, size_t* nctls_out, const zkm_ctl_side** sides_out, size_t* nsides_out);
+const zkm_ctl_table* zkm_all_stark_ctl_table(int table_id);
+int zkm_prove_segment(zkm_ctx* ctx, const zkm_stark_config* cfg, const uint64_t* const* traces, const unsigned* log_n,
+                      const uint64_t* public_values, size_t npublic, uint64_t* proofs_out, size_t* proof_offsets_out,
+                      uint64_t* ctl_challenges_out, char** err);
 
 /* a10 alone (BASELINE config 4): PolynomialBatch::prove_openings (call site prover.rs:618-628) for the STARK FRI
  * instance (stark.rs:91-148: batches at zeta, g*zeta and 1 over the trace / auxiliary / quotient oracles) on three

@@ -40,9 +40,21 @@ def _ptr(a):
     return a.ctypes.data_as(u64p)
 
 
+def _default_threads():
+    """OpenMP threads for the oracle.  The parallel regions are short (per column / per row loops of small tables); on a 256-core
+    host the fork/join cost of 256 threads per region dominates (a 12-table test segment: 157 s with 256 threads, 25 s with 8),
+    so the default is capped.  OMP_NUM_THREADS in the environment wins; Oracle.set_threads() changes it at run time."""
+    return min(os.cpu_count() or 1, 32)
+
+
 class Oracle:
-    def __init__(self):
+    def __init__(self, threads=None):
+        if "OMP_NUM_THREADS" not in os.environ and threads is None:
+            threads = _default_threads()
         self.lib = C.CDLL(build())
+        self._gomp = None
+        if threads is not None:
+            self.set_threads(threads)
         L = self.lib
         L.zko_gl_mul.restype = C.c_uint64
         L.zko_gl_mul.argtypes = [C.c_uint64, C.c_uint64]
@@ -76,6 +88,18 @@ class Oracle:
         L.zko_quotient_poseidon.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t, u64p, C.c_size_t, u64p]
         L.zko_poseidon_eval_row.argtypes = [u64p, u64p, C.c_size_t, u64p]
         L.zko_challenger_get.restype = C.c_uint64
+
+    def set_threads(self, n):
+        """omp_set_num_threads for the oracle's parallel regions (libgomp is already loaded by the oracle library)."""
+        if self._gomp is None:
+            self._gomp = C.CDLL("libgomp.so.1")
+        self._gomp.omp_set_num_threads(int(n))
+        self.threads = int(n)
+
+    def get_threads(self):
+        if self._gomp is None:
+            self._gomp = C.CDLL("libgomp.so.1")
+        return int(self._gomp.omp_get_max_threads())
 
     # ---- primitives
     def gl_mul(self, a, b):

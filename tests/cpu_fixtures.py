@@ -688,7 +688,9 @@ def build_full_segment(oracle):
         except RuntimeError:
             log_mem += 1
 
-    c = [CtlTable() for _ in range(12)]
+    # the column sets and the fifteen lookups come from the product-side description (zkm_amd/tables.py all_cross_table_lookups,
+    # the same data csrc/all_stark_ctl.inc is generated from)
+    c, ctls = T.all_cross_table_lookups()
     AR, CPU, PO, PS, KK, KS, SE, SES, SC, SCS, LO, ME = range(12)      # Table::all() order (all_stark.rs:117-134)
     tables = [(T.TABLE_ARITHMETIC, arith, 54, 16, c[AR]), (T.TABLE_CPU, cpu, 259, log_cpu, c[CPU]),
               (T.TABLE_POSEIDON, pt[1][1], 262, pt[1][3], c[PO]), (T.TABLE_POSEIDON_SPONGE, pt[0][1], 110, pt[0][3], c[PS]),
@@ -696,17 +698,4 @@ def build_full_segment(oracle):
               (T.TABLE_SHA_EXTEND, et[1][1], 78, et[1][3], c[SE]), (T.TABLE_SHA_EXTEND_SPONGE, et[0][1], 76, et[0][3], c[SES]),
               (T.TABLE_SHA_COMPRESS, ct[1][1], 224, ct[1][3], c[SC]), (T.TABLE_SHA_COMPRESS_SPONGE, ct[0][1], 127, ct[0][3], c[SCS]),
               (T.TABLE_LOGIC, logic, 69, log_logic, c[LO]), (T.TABLE_MEMORY, memory, 13, log_mem, c[ME])]
-    logic_lookers = T.logic_lookers_cpu(CPU, c[CPU]) + [(KS, T.keccak_sponge_looking_logic(c[KS], i)) for i in range(T.NUM_LOGIC_CTLS)] + \
-        T.logic_lookers_sha_extend(SE, c[SE]) + T.logic_lookers_sha_compress(SC, c[SC])
-    memory_lookers = T.memory_lookers_cpu(CPU, c[CPU]) + T.memory_lookers_poseidon_sponge(PS, c[PS]) + \
-        T.memory_lookers_keccak_sponge(KS, c[KS]) + T.memory_lookers_sha_extend_sponge(SES, c[SES]) + \
-        T.memory_lookers_sha_compress_sponge(SCS, c[SCS]) + T.memory_lookers_sha_compress(SC, c[SC])
-    ctls = [T.ctl_arithmetic(CPU, AR, c[CPU], c[AR]),
-            T.ctl_poseidon_sponge(CPU, PS, c[CPU], c[PS]), T.ctl_poseidon_inputs(PS, PO, c[PS], c[PO]), T.ctl_poseidon_outputs(PS, PO, c[PS], c[PO]),
-            T.ctl_keccak_sponge(CPU, KS, c[CPU], c[KS]), T.ctl_keccak_inputs(KS, KK, c[KS], c[KK]), T.ctl_keccak_outputs(KS, KK, c[KS], c[KK]),
-            T.ctl_sha_extend_sponge(CPU, SES, c[CPU], c[SES]), T.ctl_sha_extend_inputs(SES, SE, c[SES], c[SE]),
-            T.ctl_sha_extend_outputs(SES, SE, c[SES], c[SE]),
-            T.ctl_sha_compress_sponge(CPU, SCS, c[CPU], c[SCS]), T.ctl_sha_compress_inputs(SCS, SC, c[SCS], c[SC]),
-            T.ctl_sha_compress_outputs(SCS, SC, c[SCS], c[SC]),
-            (logic_lookers, (LO, T.logic_ctl_data(c[LO]))), (memory_lookers, (ME, T.memory_ctl_data(c[ME])))]
     return tables, ctls

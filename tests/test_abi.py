@@ -59,3 +59,48 @@ def test_proof_layout_sizes_agree(zkm, oracle):
     lib = zkm.load()
     for log_n in (5, 7, 12, 16, 20, 22):
         assert lib.zkm_proof_words(C.byref(cfg), log_n, 262, 4, 2) == oracle.proof_words(cfg_o, log_n, 262, 4, 2)
+
+
+def test_all_stark_ctl_inc_is_current():
+    """csrc/all_stark_ctl.inc (the AllStark lookups compiled into the library) is generated from zkm_amd/tables.py."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_all_stark_ctl", os.path.join(ROOT, "tools", "gen_all_stark_ctl.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.render() == open(os.path.join(ROOT, "zkm_amd", "csrc", "all_stark_ctl.inc")).read(), "run tools/gen_all_stark_ctl.py"
+
+
+def test_prove_segment_sizing_and_descriptors(zkm, oracle):
+    """zkm_prove_segment sizes a whole AllStark segment without a GPU, from the description inside the library; it agrees with the
+    oracle's sizing of the same tables + lookups built through zkm_amd/tables.py, and the exported lookups are the fifteen of
+    all_cross_table_lookups() (all_stark.rs:136-155)."""
+    from zkm_amd import tables as T
+    lib = zkm.load()
+    seg = np.load(os.path.join(ROOT, "tests", "golden", "segment12.npz"))
+    log_n = [int(x) for x in seg["log_n"]]
+    ctl_tables, ctls = T.all_cross_table_lookups()
+    tables = [(T.TABLE_ENUM_ORDER[i], seg["t%d" % i], T.WIDTH[T.TABLE_ENUM_ORDER[i]], log_n[i], ctl_tables[i]) for i in range(12)]
+    want_total, want_offs = oracle.all_proof_words(tables, ctls)
+    cfg = zkm.StarkConfig()
+    lib.zkm_standard_config(C.byref(cfg))
+    ptrs = (C.c_void_p * 12)(*[t[1].ctypes.data for t in tables])
+    lg = (C.c_uint * 12)(*log_n)
+    offs = (C.c_size_t * 13)()
+    err = C.c_char_p()
+    assert lib.zkm_prove_segment(None, C.byref(cfg), ptrs, lg, None, 0, None, offs, None, C.byref(err)) == 0
+    assert list(offs) == list(want_offs) and offs[12] == want_total
+    n, ns = C.c_size_t(), C.c_size_t()
+    assert lib.zkm_all_stark_ctls(None, C.byref(n), None, C.byref(ns)) == 0
+    assert n.value == 15 and ns.value == sum(len(looking) for looking, _ in ctls)
+    assert [lib.zkm_table_enum_index(t) for t in T.TABLE_ENUM_ORDER] == list(range(12)) and lib.zkm_table_enum_index(99) == -1
+    assert lib.zkm_all_stark_ctl_table(99) is None and lib.zkm_all_stark_ctl_table(T.TABLE_CPU) is not None
+    lg[1] = 99  # a table height the library cannot size
+    assert lib.zkm_prove_segment(None, C.byref(cfg), ptrs, lg, None, 0, None, offs, None, C.byref(err)) != 0
+
+
+def test_rust_sys_block_names_every_export(zkm):
+    """integration/rust/zkm_hip_sys.rs (the extern "C" block a maintainer adds to the plonky2 fork) declares exactly the exported
+    functions of include/zkm_hip.h."""
+    text = open(os.path.join(ROOT, "integration", "rust", "zkm_hip_sys.rs")).read()
+    rust = set(re.findall(r"pub fn (zkm_[a-z0-9_]+)\s*\(", text))
+    assert rust == set(header_functions()), rust ^ set(header_functions())

@@ -50,3 +50,61 @@ def test_two_rank_gloo(tmp_path):
                         "127.0.0.1", "--master-port", "29513", str(script)], capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK [0, 2, 4, 6]" in r.stdout
+
+
+BENCH_WORKER = textwrap.dedent("""
+    # bench.py itself under torchrun with world_size 2 on gloo: a stub Context stands in for the GPU (none in this suite), so the
+    # sharding (--segments 7: seeds 100..106 round-robin), the barrier / max-over-ranks timing, the per-rank trace slots and the JSON
+    # line on rank 0 are the code the first multi-GPU run executes.
+    import json, sys, time, types
+    sys.path.insert(0, %r)
+    import numpy as np, torch
+    import zkm_amd
+    from zkm_amd import dist as zd
+    proved = []
+    class Buf:
+        def __init__(self, seed): self.seed = seed
+        def upload(self, a): return self
+        def download(self): return np.zeros(8, dtype=np.uint64)
+        def free(self): pass
+    class StubContext:
+        def __init__(self, device): self.on = False
+        def poseidon_trace(self, seed, n, log_n): return Buf(seed)
+        def alloc(self, words): return Buf(None)
+        def prove_single_table(self, trace, log_n, aux, nh):
+            proved.append(trace.seed); time.sleep(0.01); return np.full(5, trace.seed, dtype=np.uint64)
+        def profile(self, on): pass
+        def profile_reset(self): pass
+        def profile_records(self): return {"merkle_leaves": (len(proved), 1.0 * len(proved)), "ntt_pass_strided": (3, 0.5)}
+        def close(self): pass
+    zkm_amd.Context = StubContext
+    torch.cuda.is_available = lambda: True
+    torch.cuda.set_device = lambda d: None
+    torch.cuda.synchronize = lambda: None
+    torch.cuda.get_device_properties = lambda d: types.SimpleNamespace(multi_processor_count=256)
+    real_init = zd.init
+    zd.init = lambda backend=None: real_init("gloo")
+    sys.argv = ["bench.py", "--gpus", "2", "--segments", "7", "--warmup", "1", "--log-n", "10", "--no-cpu-baseline", "--no-extras"]
+    import runpy
+    runpy.run_path(%r, run_name="__main__")
+    rank = int(__import__("os").environ["RANK"])
+    want = [100 + s for s in range(rank, 7, 2)]
+    assert proved[1:len(want) + 1] == want, (rank, proved)          # proved[0] is the warm-up
+    print("RANK%%d OK %%s" %% (rank, proved))
+""") % (ROOT, os.path.join(ROOT, "bench.py"))
+
+
+def test_bench_sharding_path_two_rank_gloo(tmp_path):
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29517", str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RANK0 OK" in r.stdout and "RANK1 OK" in r.stdout
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout            # exactly one JSON line, from rank 0
+    import json
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["segments_total"] == 7 and j["config"]["segments_per_gpu"] == 4
+    assert j["value"] > 0 and abs(j["value"] * j["ms_per_step"] * 4 / 7 / 1e3 - 1) < 1e-6   # value = total / elapsed, ms_per_step = elapsed / 4

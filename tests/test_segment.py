@@ -157,3 +157,65 @@ def test_prove_from_image_equals_in_memory_path(ctx, zkm, oracle):
     for k in range(len(tables)):
         lay, _ = zkm.proof_layout(got[offs[k]:offs[k + 1]])
         assert lay.total_words == offs[k + 1] - offs[k] and lay.degree_bits == tables[k][3]
+
+
+@pytest.mark.gpu
+def test_prove_segment_uses_the_shipped_all_stark(ctx, zkm, oracle):
+    """zkm_prove_segment proves the twelve tables from their traces alone (the AllStark lookups are compiled into the library,
+    csrc/all_stark_ctl.inc): same bytes as zkm_prove_with_traces driven by the Python description, and as the oracle."""
+    import os
+    from zkm_amd import tables as T
+    seg = np.load(os.path.join(os.path.dirname(__file__), "golden", "segment12.npz"))
+    log_n = [int(x) for x in seg["log_n"]]
+    traces = [seg["t%d" % i] for i in range(12)]
+    got, chal, offs = ctx.prove_segment(traces, log_n, public_values=[1, 2, 3])
+    ctl_tables, ctls = T.all_cross_table_lookups()
+    tables = [(T.TABLE_ENUM_ORDER[i], traces[i], T.WIDTH[T.TABLE_ENUM_ORDER[i]], log_n[i], ctl_tables[i]) for i in range(12)]
+    want, wchal, woffs = ctx.prove_with_traces(tables, ctls, public_values=[1, 2, 3])
+    assert offs == woffs and (chal == wchal).all() and (got == want).all()
+    ref, rchal, _ = oracle.prove_with_traces(tables, ctls, public_values=[1, 2, 3])
+    assert (got == ref).all() and (chal == rchal).all()
+    # a full segment in any other table order is refused (the transcript would not match the reference's)
+    swapped = [tables[1], tables[0]] + tables[2:]
+    with pytest.raises(zkm.ZkmError, match="Table enum order"):
+        ctx.prove_with_traces(swapped, ctls, public_values=[1, 2, 3])
+
+
+@pytest.mark.gpu
+def test_gpu_proof_blob_walks_through_the_layout(ctx, zkm, oracle):
+    """N4 on a GPU-made proof: every field zkm_proof_get_layout / _query_layout report is where the batches say it is -- caps equal
+    the commitments' caps, every query round's leaves and Merkle paths authenticate against them, FRI layer evals chain."""
+    log_n = 8
+    n = 1 << log_n
+    trace = oracle.poseidon_trace(21, n - 9, log_n)
+    aux = np.zeros(3 * n, dtype=np.uint64)          # the benchmark's fake CTL shape: two helper columns and a Z, all zero (valid)
+    tb = zkm.PolynomialBatch.from_values(ctx, trace, 262, log_n)
+    ab = zkm.PolynomialBatch.from_values(ctx, aux, 3, log_n)
+    proof = ctx.prove_single_table(None, log_n, aux, [2], trace_batch=tb)
+    assert oracle.verify(proof, 3, [2]) == 0
+    lay, q = zkm.proof_layout(proof)
+    assert lay.total_words == proof.size and (lay.degree_bits, lay.trace_cols, lay.aux_cols, lay.ctl_zs) == (log_n, 262, 3, 1)
+    C4 = 4 << int(lay.cap_height)
+    assert (proof[lay.trace_cap:lay.trace_cap + C4] == tb.cap().reshape(-1)).all()
+    assert (proof[lay.aux_cap:lay.aux_cap + C4] == ab.cap().reshape(-1)).all()
+    lde_bits = log_n + int(lay.rate_bits)
+    N = 1 << lde_bits
+    rows_t = {tuple(int(x) for x in tb.leaf(i)[:4]): i for i in range(N)}
+    for r in range(int(lay.num_queries)):
+        base = lay.query_round_proofs + r * lay.query_round_words
+        leaf = proof[base + q.oracle_evals[0]: base + q.oracle_evals[0] + 262]
+        x = rows_t[tuple(int(v) for v in leaf[:4])]                      # the queried leaf index, recovered from the data
+        assert (tb.leaf(x) == leaf).all()
+        sib = proof[base + q.oracle_siblings[0]: base + q.oracle_siblings[0] + 4 * q.initial_siblings]
+        assert (tb.merkle_path(x).reshape(-1) == sib).all()
+        aleaf = proof[base + q.oracle_evals[1]: base + q.oracle_evals[1] + 3]
+        assert (ab.leaf(x) == aleaf).all()
+        asib = proof[base + q.oracle_siblings[1]: base + q.oracle_siblings[1] + 4 * q.initial_siblings]
+        assert (ab.merkle_path(x).reshape(-1) == asib).all()
+        assert q.oracle_cols[2] == lay.quotient_polys and q.layer_siblings_count[0] == lde_bits - int(lay.arity_bits) - int(lay.cap_height)
+    # bulk LDE accessor == row-at-a-time accessor (get_lde_values_packed, prover.rs:687)
+    rows = tb.lde_rows(5, 2, 7)
+    for i in range(7):
+        assert (rows[i] == tb.lde_row((5 + i) * 2)).all()
+    tb.free()
+    ab.free()

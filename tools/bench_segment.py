@@ -1,55 +1,74 @@
 #!/usr/bin/env python3
-"""Development aid: wall time and per-kernel HIP-event profile of zkm_prove_with_traces on the twelve-table test segment
-(tests/cpu_fixtures.build_full_segment) and of a 2^LOG-row CPU-table proof.  Uses the oracle only to build the fixture."""
-import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-import zkm_amd as z
-import zkm_amd.tables
-from oracle.oracle_py import Oracle
-from tests import cpu_fixtures as CF
-from tests.test_gpu_tables import fake_ctl_aux
+"""Whole-segment timing: zkm_prove_segment (prove_with_traces, prover.rs:130-232, on all twelve tables with the fifteen
+cross-table lookups) with wall time next to the per-kernel HIP-event profile.
 
-ctx = z.Context(0)
-o = Oracle()
-out = {}
-tables, ctls = CF.build_full_segment(o)
-ctx.prove_with_traces(tables, ctls)
-ctx.profile(True); ctx.profile_reset()
-t = time.time()
-ctx.prove_with_traces(tables, ctls)
-out["segment12_wall_s"] = time.time() - t
-out["segment12_kernels"] = {k: {"n": v[0], "ms": round(v[1], 3)} for k, v in sorted(ctx.profile_records().items(), key=lambda kv: -kv[1][1])[:14]}
-# the same twelve tables tiled to the sizes of a 2^20-cycle segment (no longer a valid witness -- timing only)
-SIZES = {z.tables.TABLE_CPU: 20, z.tables.TABLE_MEMORY: 21, z.tables.TABLE_ARITHMETIC: 19, z.tables.TABLE_LOGIC: 17, z.tables.TABLE_KECCAK: 15,
-         z.tables.TABLE_KECCAK_SPONGE: 12, z.tables.TABLE_POSEIDON: 14, z.tables.TABLE_POSEIDON_SPONGE: 14, z.tables.TABLE_SHA_EXTEND: 16,
-         z.tables.TABLE_SHA_EXTEND_SPONGE: 16, z.tables.TABLE_SHA_COMPRESS: 16, z.tables.TABLE_SHA_COMPRESS_SPONGE: 10}
-big = []
-for tid, tr, w, ln, ct in tables:
-    L = max(SIZES[tid], ln)
-    t2 = np.ascontiguousarray(np.tile(np.asarray(tr).reshape(w, -1), (1, 1 << (L - ln)))).reshape(-1)
-    big.append((tid, ctx.alloc(t2.size).upload(t2), w, L, ct))
-ctx.prove_with_traces(big, ctls)
-ctx.profile_reset()
-t = time.time()
-ctx.prove_with_traces(big, ctls)
-out["segment12_2^20_wall_s"] = time.time() - t
-out["segment12_2^20_kernels"] = {k: {"n": v[0], "ms": round(v[1], 3)} for k, v in sorted(ctx.profile_records().items(), key=lambda kv: -kv[1][1])[:24]}
-out["segment12_2^20_memory"] = ctx.memory()
-for b in big:
-    b[1].free()
-log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 18
-m = CF.Machine()
-while len(m.rows) + 260 < (1 << 14):
-    CF.sample_program(m)
-small = m.trace(14).reshape(259, -1)
-trace = np.ascontiguousarray(np.tile(small, (1, 1 << (log_n - 14)))).reshape(-1)   # not a valid witness across the seams; timing only
-aux = fake_ctl_aux(log_n)
-d = ctx.alloc(trace.size).upload(trace)
-ctx.prove_single_table(d, log_n, aux, [2], ncols=259, table_id=11)
-ctx.profile_reset()
-t = time.time()
-ctx.prove_single_table(d, log_n, aux, [2], ncols=259, table_id=11)
-out["cpu_table_2^%d_wall_s" % log_n] = time.time() - t
-out["cpu_table_kernels"] = {k: {"n": v[0], "ms": round(v[1], 3)} for k, v in sorted(ctx.profile_records().items(), key=lambda kv: -kv[1][1])[:10]}
-print(json.dumps(out, indent=1))
+The traces are the committed test segment (tests/golden/segment12.npz) tiled to the table heights of a 2^16-cycle segment
+(the reference's default segment size, emulator/src/utils.rs:6) or of a 2^20-cycle one -- rows repeat, so the witness is not
+valid across the seams; the prover does not care, the numbers are timings only.  No oracle, no fixture builders.
+
+  python tools/bench_segment.py [16|20]        prints one JSON object
+  from tools.bench_segment import small_segment_rate   (bench.py's `segment_2_16` key)
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+# table heights (log2 rows) in Table::all() order: Arithmetic, Cpu, Poseidon, PoseidonSponge, Keccak, KeccakSponge, ShaExtend,
+# ShaExtendSponge, ShaCompress, ShaCompressSponge, Logic, Memory -- a CPU table of 2^k cycles with the precompile mix of the test segment
+HEIGHTS = {16: [16, 16, 10, 10, 11, 8, 12, 12, 12, 6, 13, 17],
+           20: [19, 20, 14, 14, 15, 12, 16, 16, 16, 10, 17, 21]}
+
+
+def tiled_segment(ctx, log_cycles):
+    from zkm_amd import tables as T
+    seg = np.load(os.path.join(ROOT, "tests", "golden", "segment12.npz"))
+    base = [int(x) for x in seg["log_n"]]
+    bufs, logs = [], []
+    for i in range(12):
+        w = T.WIDTH[T.TABLE_ENUM_ORDER[i]]
+        L = max(HEIGHTS[log_cycles][i], base[i])
+        t = np.ascontiguousarray(np.tile(seg["t%d" % i].reshape(w, -1), (1, 1 << (L - base[i])))).reshape(-1)
+        bufs.append(ctx.alloc(t.size).upload(t))
+        logs.append(L)
+    return bufs, logs
+
+
+def segment_rate(ctx, log_cycles, reps=3):
+    import torch
+    bufs, logs = tiled_segment(ctx, log_cycles)
+    ctx.prove_segment(bufs, logs, public_values=[1, 2, 3])       # warm-up: allocator, twiddles, power tables
+    ctx.profile(True)
+    ctx.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        proofs, _, offs = ctx.prove_segment(bufs, logs, public_values=[1, 2, 3])
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    rec = ctx.profile_records()
+    ctx.profile(False)
+    for b in bufs:
+        b.free()
+    kernel_ms = sum(v[1] for v in rec.values()) / reps
+    return {"cpu_cycles_log2": log_cycles, "table_heights_log2": logs, "segments_per_s": 1.0 / wall, "ms_per_segment": wall * 1e3,
+            "kernel_ms_per_segment": kernel_ms, "wall_over_kernel_sum": wall * 1e3 / kernel_ms,
+            "launches_per_segment": sum(v[0] for v in rec.values()) / reps, "proof_words": int(offs[12]),
+            "kernel_ms": {k: round(v[1] / reps, 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])[:12]},
+            "note": "twelve tables, fifteen lookups, one zkm_prove_segment call; traces device-resident, tiled test segment (timing only)"}
+
+
+def small_segment_rate(ctx):
+    return segment_rate(ctx, 16)
+
+
+if __name__ == "__main__":
+    import zkm_amd
+    c = zkm_amd.Context(0)
+    out = segment_rate(c, int(sys.argv[1]) if len(sys.argv) > 1 else 16)
+    out["memory_live_cached"] = c.memory()
+    print(json.dumps(out, indent=1))

@@ -27,9 +27,10 @@ TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRES
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
-    "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_memory", "zkm_ctx_trim", "zkm_table_enum_index", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
+    "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_memory", "zkm_ctx_trim", "zkm_table_enum_index", "zkm_host_alloc", "zkm_host_free",
+    "zkm_host_register", "zkm_host_unregister", "zkm_all_stark_ctls", "zkm_all_stark_ctl_table", "zkm_prove_segment", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
     "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_free",
-    "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_leaf", "zkm_batch_merkle_path",
+    "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_lde_rows", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_keccak_trace", "zkm_logic_trace",
     "zkm_poseidon_sponge_trace", "zkm_poseidon_trace_inputs", "zkm_sha_extend_trace", "zkm_sha_extend_sponge_trace",
     "zkm_sha_compress_trace", "zkm_sha_compress_sponge_trace",
@@ -112,6 +113,7 @@ def load():
         "zkm_batch_cap": (C.c_int, [cp, u64p]),
         "zkm_batch_coeffs": (C.c_int, [cp, cp]),
         "zkm_batch_lde_row": (C.c_int, [cp, C.c_size_t, u64p]),
+        "zkm_batch_lde_rows": (C.c_int, [cp, C.c_size_t, C.c_size_t, C.c_size_t, cp]),
         "zkm_batch_leaf": (C.c_int, [cp, C.c_size_t, u64p]),
         "zkm_batch_merkle_path": (C.c_int, [cp, C.c_size_t, u64p]),
         "zkm_batch_digest_layer": (C.c_int, [cp, C.c_uint, u64p]),
@@ -128,6 +130,14 @@ def load():
         "zkm_keccak_trace": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_ctx_memory": (None, [cp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "zkm_ctx_trim": (None, [cp]),
+        "zkm_all_stark_ctls": (C.c_int, [cpp, C.POINTER(C.c_size_t), cpp, C.POINTER(C.c_size_t)]),
+        "zkm_all_stark_ctl_table": (cp, [C.c_int]),
+        "zkm_prove_segment": (C.c_int, [cp, C.POINTER(StarkConfig), C.POINTER(C.c_void_p), C.POINTER(C.c_uint), u64p, C.c_size_t, u64p,
+                                        C.POINTER(C.c_size_t), u64p, err]),
+        "zkm_host_alloc": (C.c_int, [cp, C.c_size_t, cpp, err]),
+        "zkm_host_free": (C.c_int, [cp, cp]),
+        "zkm_host_register": (C.c_int, [cp, cp, C.c_size_t, err]),
+        "zkm_host_unregister": (C.c_int, [cp, cp]),
         "zkm_table_enum_index": (C.c_int, [C.c_int]),
         "zkm_logic_trace": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_table_width": (C.c_size_t, [C.c_int]),
@@ -238,6 +248,9 @@ class Context:
 
     def close(self):
         if self.h:
+            for p in list(getattr(self, "_pinned", {}).values()):
+                self.L.zkm_host_free(self.h, p)
+            self._pinned = {}
             self.L.zkm_ctx_destroy(self.h)
             self.h = None
 
@@ -252,6 +265,21 @@ class Context:
         live, cached = C.c_size_t(), C.c_size_t()
         self.L.zkm_ctx_memory(self.h, C.byref(live), C.byref(cached))
         return live.value, cached.value
+
+    def pinned_array(self, words):
+        """A uint64 ndarray in page-locked host memory (zkm_host_alloc): uploads from it overlap with compute.  Freed with the
+        context (or explicitly with free_pinned)."""
+        p, err = C.c_void_p(), C.c_char_p()
+        _check(self.L.zkm_host_alloc(self.h, words * 8, C.byref(p), C.byref(err)), err)
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(words,))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def free_pinned(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self.L.zkm_host_free(self.h, p)
 
     def trim(self):
         """Return the allocator's cached blocks to the device."""
@@ -497,6 +525,25 @@ class Context:
                                             C.byref(err)), err)
         return proofs, chal, list(offs)
 
+    def prove_segment(self, traces, log_ns, public_values=(), cfg=None):
+        """prove_with_traces (prover.rs:130-232) on the twelve tables of Table::all() (all_stark.rs:117-134) with the AllStark
+        description that ships inside the library: traces[t] = ndarray or DeviceBuffer of table t in enum order, log_ns[t] its
+        height.  Returns (proofs, ctl_challenges, offsets)."""
+        cfg = cfg or self.standard_config()
+        assert len(traces) == 12 and len(log_ns) == 12
+        keep = [t if isinstance(t, DeviceBuffer) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
+        ptrs = (C.c_void_p * 12)(*[_data_ptr(t).value for t in keep])
+        lg = (C.c_uint * 12)(*[int(x) for x in log_ns])
+        pub = np.ascontiguousarray(public_values, dtype=np.uint64)
+        offs = (C.c_size_t * 13)()
+        err = C.c_char_p()
+        _check(self.L.zkm_prove_segment(None, C.byref(cfg), ptrs, lg, pub.ctypes.data_as(u64p), pub.size, None, offs, None, C.byref(err)), err)
+        proofs = np.zeros(offs[12], dtype=np.uint64)
+        chal = np.zeros(2 * cfg.num_challenges, dtype=np.uint64)
+        _check(self.L.zkm_prove_segment(self.h, C.byref(cfg), ptrs, lg, pub.ctypes.data_as(u64p), pub.size, proofs.ctypes.data_as(u64p), offs,
+                                        chal.ctypes.data_as(u64p), C.byref(err)), err)
+        return proofs, chal, list(offs)
+
     def prove_segment_image(self, image, cfg=None):
         """Prove every table of a ZKMTRACE segment image (see segment_image()).  Returns (proofs, ctl_challenges, offsets)."""
         cfg = cfg or self.standard_config()
@@ -592,6 +639,13 @@ class PolynomialBatch:
         out = np.zeros(self.ncols, dtype=np.uint64)
         assert self.ctx.L.zkm_batch_lde_row(self.h, natural_index, out.ctypes.data_as(u64p)) == 0
         return out
+
+    def lde_rows(self, index_start, step, count):
+        """get_lde_values_packed(index_start, step) for `count` consecutive indices: count x ncols."""
+        out = np.zeros(count * self.ncols, dtype=np.uint64)
+        if self.ctx.L.zkm_batch_lde_rows(self.h, index_start, step, count, _np_ptr(out)) != 0:
+            raise ZkmError("zkm_batch_lde_rows failed")
+        return out.reshape(count, self.ncols)
 
     def leaf(self, i):
         out = np.zeros(self.ncols, dtype=np.uint64)

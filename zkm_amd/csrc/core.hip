@@ -1,4 +1,6 @@
 // core.hip -- context, memory, profiling, Fiat-Shamir transcript and the PolynomialBatch part of the C ABI.
+#include <algorithm>
+
 #include "poseidon_dev.h"
 #include "zkm_internal.h"
 
@@ -111,6 +113,7 @@ int zkm_ctx_create(int device, zkm_ctx** out, char** err) {
     c->num_cus = prop.multiProcessorCount;
     c->use_baseline_ntt = getenv("ZKM_BASELINE_NTT") != nullptr;  // A/B switch for profiling
     ZKM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (const char* e = getenv("ZKM_INGEST_CHUNK")) c->ingest_chunk_cols = (size_t)strtoul(e, nullptr, 10);  // tuning / A-B switch
     *out = c;
     ZKM_API_END(err)
 }
@@ -119,6 +122,7 @@ void zkm_ctx_destroy(zkm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
     for (auto& kv : c->live_blocks) (void)hipFree(kv.first);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
@@ -147,6 +151,29 @@ void zkm_ctx_trim(zkm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     c->trim();
+}
+
+// Pinned host memory for the witness generator's buffers: hipMemcpyAsync from pageable memory is staged by the runtime and
+// blocks the host; from pinned memory the chunked upload of zkm_batch_build overlaps with compute.
+int zkm_host_alloc(zkm_ctx* c, size_t bytes, void** out, char** err) {
+    ZKM_API_BEGIN
+    ZKM_HIP_CHECK(hipSetDevice(c->device));
+    ZKM_HIP_CHECK(hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault));
+    ZKM_API_END(err)
+}
+int zkm_host_free(zkm_ctx* c, void* p) {
+    (void)hipSetDevice(c->device);
+    return hipHostFree(p) == hipSuccess ? 0 : 1;
+}
+int zkm_host_register(zkm_ctx* c, void* p, size_t bytes, char** err) {
+    ZKM_API_BEGIN
+    ZKM_HIP_CHECK(hipSetDevice(c->device));
+    ZKM_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    ZKM_API_END(err)
+}
+int zkm_host_unregister(zkm_ctx* c, void* p) {
+    (void)hipSetDevice(c->device);
+    return hipHostUnregister(p) == hipSuccess ? 0 : 1;
 }
 
 int zkm_dev_alloc(zkm_ctx* c, size_t bytes, void** out, char** err) {
@@ -249,7 +276,7 @@ void zkm_standard_config(zkm_stark_config* c) {
 // ------------------------------------------------------------------ PolynomialBatch
 // from_values: iNTT each column (coefficients kept), then from_coeffs: coset LDE (x 2^rate_bits, shift g),
 // rows in bit-reversed order, Poseidon Merkle tree, cap.  src may be a host or device pointer.
-void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values) {
+void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t* dev_values) {
     zkm_ctx* c = b->ctx;
     size_t n = b->n(), N = b->N(), ncols = b->ncols;
     if (b->log_n + b->rate_bits > 30) throw std::runtime_error("polynomial batch too large");
@@ -259,18 +286,54 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values) {
     b->digests = (gl_t*)c->alloc(dwords * sizeof(gl_t));
     bool dev = zkm_is_device_ptr(src);
     hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (src_is_values && dev) {
+    const size_t CH = c->ingest_chunk_cols;
+    bool leaves_done = false;
+    if (src_is_values && !dev && CH && CH % 8 == 0 && ncols >= 2 * CH) {
+        // Host-resident values (prover.rs:144-167: the traces arrive as Vec<PolynomialValues>): pipelined ingest.  The upload is
+        // split into chunks of CH columns on the copy stream; the compute stream transforms (iNTT, LDE) and ABSORBS chunk k
+        // (leaf sponge, hash.hip k_merkle_leaves_chunk) while chunk k + 1 .. are in flight, so PCIe time hides behind hashing.
+        // Each chunk is staged in the LDE region of its own columns (or lands in dev_values), so there is no buffer to recycle.
+        if (!c->copy_stream) ZKM_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        const size_t nchunks = (ncols + CH - 1) / CH;
+        std::vector<hipEvent_t> ev(nchunks);
+        zkm_scratch state(c, 12 * N * sizeof(gl_t));
+        hipEvent_t start = c->get_event();
+        ZKM_HIP_CHECK(hipEventRecord(start, c->stream));            // the LDE buffer may still be in use by queued work of a freed batch
+        ZKM_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, start, 0));
+        for (size_t k = 0; k < nchunks; k++) {
+            size_t c0 = k * CH, nc = std::min(CH, ncols - c0);
+            gl_t* dst = dev_values ? dev_values + c0 * n : b->lde + c0 * N;
+            ZKM_HIP_CHECK(hipMemcpyAsync(dst, src + c0 * n, nc * n * sizeof(gl_t), hipMemcpyHostToDevice, c->copy_stream));
+            ev[k] = c->get_event();
+            ZKM_HIP_CHECK(hipEventRecord(ev[k], c->copy_stream));
+        }
+        for (size_t k = 0; k < nchunks; k++) {
+            size_t c0 = k * CH, nc = std::min(CH, ncols - c0);
+            gl_t* vals = dev_values ? dev_values + c0 * n : b->lde + c0 * N;
+            ZKM_HIP_CHECK(hipStreamWaitEvent(c->stream, ev[k], 0));
+            zkm_ntt_natural_ex(c, vals, n, b->lde + c0 * N, n, b->coeffs + c0 * n, n, nc, b->log_n, /*inverse=*/true, 0);
+            zkm_lde_bitrev(c, b->coeffs + c0 * n, b->lde + c0 * N, nc, b->log_n, b->rate_bits, GL_GENERATOR);
+            zkm_launch_merkle_leaves_chunk(c, b->lde + c0 * N, N, nc, N, state.as<gl_t>(), k == 0, k + 1 == nchunks, b->digests);
+        }
+        c->sync();  // (events and the sponge state are recycled below)
+        for (auto e : ev) c->event_pool.push_back(e);
+        c->event_pool.push_back(start);
+        leaves_done = true;
+    } else if (src_is_values && dev) {
         // device-resident values are only read (first NTT pass); the not-yet-used LDE buffer holds the intermediate passes
         zkm_ntt_natural_ex(c, src, n, b->lde, n, b->coeffs, n, ncols, b->log_n, /*inverse=*/true, 0);
     } else if (src_is_values) {
-        // stage the values in the (not yet used) LDE buffer, transform there, land natural-order coefficients
-        ZKM_HIP_CHECK(hipMemcpyAsync(b->lde, src, ncols * n * sizeof(gl_t), kind, c->stream));
-        zkm_ntt_natural(c, b->lde, b->coeffs, ncols, n, n, b->log_n, /*inverse=*/true, 0);
+        // stage the values in the (not yet used) LDE buffer (or the caller's device copy), transform, land natural-order coefficients
+        gl_t* vals = dev_values ? dev_values : b->lde;
+        ZKM_HIP_CHECK(hipMemcpyAsync(vals, src, ncols * n * sizeof(gl_t), kind, c->stream));
+        zkm_ntt_natural_ex(c, vals, n, b->lde, n, b->coeffs, n, ncols, b->log_n, /*inverse=*/true, 0);
     } else {
         ZKM_HIP_CHECK(hipMemcpyAsync(b->coeffs, src, ncols * n * sizeof(gl_t), kind, c->stream));
     }
-    zkm_lde_bitrev(c, b->coeffs, b->lde, ncols, b->log_n, b->rate_bits, GL_GENERATOR);
-    zkm_launch_merkle_leaves(c, b->lde, N, ncols, N, b->digests);
+    if (!leaves_done) {
+        zkm_lde_bitrev(c, b->coeffs, b->lde, ncols, b->log_n, b->rate_bits, GL_GENERATOR);
+        zkm_launch_merkle_leaves(c, b->lde, N, ncols, N, b->digests);
+    }
     zkm_merkle_build_inner(c, b->digests, b->level_off, b->lde_bits(), b->cap_height);
     size_t capw = (size_t)4 << b->cap_height;
     uint64_t* st = c->staging(capw);
@@ -279,11 +342,35 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values) {
     b->cap.assign(st, st + capw);
 }
 
+// out[i * ncols + col] = lde[col][bitrev((index_start + i) * step)]: lanes run along i, so reads of one column are scattered
+// (bit-reversed rows) but writes are dense; the accessor is off the proving path
+__global__ __launch_bounds__(256) void k_gather_lde_rows(const gl_t* __restrict__ lde, size_t N, unsigned lde_bits, size_t ncols,
+                                                         size_t index_start, size_t step, size_t count, gl_t* __restrict__ out) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * ncols) return;
+    size_t i = idx / ncols, col = idx % ncols;
+    size_t row = bitrev32((uint32_t)((index_start + i) * step), lde_bits);
+    out[idx] = lde[col * N + row];
+}
+
 static zkm_batch* batch_new(zkm_ctx* c, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height) {
     if (ncols == 0) throw std::runtime_error("empty polynomial batch");
     if (cap_height > log_n + rate_bits) throw std::runtime_error("cap_height exceeds LDE size");
     zkm_batch* b = new zkm_batch();
     b->ctx = c; b->ncols = ncols; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
+    return b;
+}
+
+// from_values keeping the uploaded values in dev_values (see zkm_batch_build); throws
+zkm_batch* zkm_batch_commit_values_keep(zkm_ctx* c, const uint64_t* values, size_t ncols, unsigned log_n, unsigned rate_bits,
+                                        unsigned cap_height, gl_t* dev_values) {
+    zkm_batch* b = batch_new(c, ncols, log_n, rate_bits, cap_height);
+    try {
+        zkm_batch_build(b, values, true, dev_values);
+    } catch (...) {
+        zkm_batch_free(b);
+        throw;
+    }
     return b;
 }
 
@@ -345,6 +432,27 @@ int zkm_batch_leaf(const zkm_batch* b, size_t leaf, uint64_t* out) {
 int zkm_batch_lde_row(const zkm_batch* b, size_t natural_index, uint64_t* out) {
     if (natural_index >= b->N()) return 1;
     return zkm_batch_leaf(b, bitrev32((uint32_t)natural_index, b->lde_bits()), out);
+}
+int zkm_batch_lde_rows(const zkm_batch* b, size_t index_start, size_t step, size_t count, uint64_t* out) {
+    // get_lde_values_packed(index_start, step) for `count` consecutive indices (prover.rs:687, 723-748): row i of the output is
+    // get_lde_values(index_start + i, step) = leaves[reverse_bits((index_start + i) * step)], ncols words; out host or device
+    if (!count) return 0;
+    if (step == 0 || (index_start + count - 1) > (b->N() - 1) / step) return 1;
+    zkm_ctx* c = b->ctx;
+    try {
+        bool dev = zkm_is_device_ptr(out);
+        zkm_scratch tmp(c, dev ? 8 : count * b->ncols * sizeof(gl_t));
+        gl_t* d = dev ? out : tmp.as<gl_t>();
+        size_t total = count * b->ncols;
+        hipLaunchKernelGGL(k_gather_lde_rows, dim3((total + 255) / 256), dim3(256), 0, c->stream, b->lde, b->N(), b->lde_bits(), b->ncols,
+                           index_start, step, count, d);
+        ZKM_HIP_CHECK(hipGetLastError());
+        if (!dev) ZKM_HIP_CHECK(hipMemcpyAsync(out, d, total * sizeof(gl_t), hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+    } catch (...) {
+        return 1;
+    }
+    return 0;
 }
 int zkm_batch_merkle_path(const zkm_batch* b, size_t leaf, uint64_t* sib) {
     if (leaf >= b->N()) return 1;

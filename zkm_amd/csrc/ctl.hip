@@ -6,6 +6,7 @@
 // reference batch-inverts, the inverse is unique so the bytes agree), accumulate helper columns, then an
 // additive suffix scan produces the upside-down running sum Z.
 #include "ctl_dev.h"
+#include "all_stark_ctl.inc"
 
 // ------------------------------------------------------------------ descriptor upload + validation
 void ctl_dev_owner::upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, bool lookup_mode,
@@ -432,6 +433,32 @@ int zkm_lookup_helper_columns(zkm_ctx* c, const zkm_ctl_table* table, const uint
     return 0;
 }
 
+// ---- the AllStark description shipped with the library (all_stark_ctl.inc, generated from zkm_amd/tables.py)
+int zkm_all_stark_ctls(const zkm_cross_table_lookup** ctls_out, size_t* nctls_out, const zkm_ctl_side** sides_out, size_t* nsides_out) {
+    if (ctls_out) *ctls_out = AS_CTLS;
+    if (nctls_out) *nctls_out = AS_NCTLS;
+    if (sides_out) *sides_out = AS_SIDES;
+    if (nsides_out) *nsides_out = AS_NSIDES;
+    return 0;
+}
+const zkm_ctl_table* zkm_all_stark_ctl_table(int table_id) {
+    int e = zkm_table_enum_index(table_id);
+    return e < 0 ? nullptr : &AS_CTL_TABLES[e];
+}
+int zkm_prove_segment(zkm_ctx* c, const zkm_stark_config* cfg, const uint64_t* const* traces, const unsigned* log_n,
+                      const uint64_t* pub, size_t npub, uint64_t* proofs, size_t* offsets_out, uint64_t* challenges, char** err) {
+    if (!traces || !log_n) return fail(err, "zkm_prove_segment: null argument");
+    zkm_table_input tables[12];
+    for (int t = 0; t < 12; t++) tables[t] = zkm_table_input{AS_TABLE_IDS[t], traces[t], AS_TABLE_WIDTH[t], log_n[t], &AS_CTL_TABLES[t]};
+    size_t offs[13];
+    size_t total = zkm_all_proof_words(cfg, tables, 12, AS_CTLS, AS_SIDES, AS_NCTLS, offs);
+    if (!total) return fail(err, "zkm_prove_segment: unsupported configuration or table size");
+    if (offsets_out) memcpy(offsets_out, offs, sizeof offs);
+    if (!proofs) return 0;  // sizing pass
+    if (!c || !challenges) return fail(err, "zkm_prove_segment: null argument");
+    return zkm_prove_with_traces(c, cfg, tables, 12, AS_CTLS, AS_SIDES, AS_NCTLS, pub, npub, proofs, challenges, err);
+}
+
 int zkm_table_enum_index(int table_id) {
     static const int order[12] = {ZKM_TABLE_ARITHMETIC, ZKM_TABLE_CPU, ZKM_TABLE_POSEIDON, ZKM_TABLE_POSEIDON_SPONGE, ZKM_TABLE_KECCAK,
                                   ZKM_TABLE_KECCAK_SPONGE, ZKM_TABLE_SHA_EXTEND, ZKM_TABLE_SHA_EXTEND_SPONGE, ZKM_TABLE_SHA_COMPRESS,
@@ -448,8 +475,10 @@ size_t zkm_all_proof_words(const zkm_stark_config* cfg, const zkm_table_input* t
         size_t total = 0;
         for (size_t t = 0; t < ntables; t++) {
             if (offs) offs[t] = total;
-            total += zkm_proof_words(cfg, tables[t].log_n, tables[t].ncols, zkm_num_lookup_columns(tables[t].table_id, cfg) + tz[t].naux,
-                                     tz[t].zs.size());
+            size_t w = zkm_proof_words(cfg, tables[t].log_n, tables[t].ncols, zkm_num_lookup_columns(tables[t].table_id, cfg) + tz[t].naux,
+                                       tz[t].zs.size());
+            if (!w) return 0;  // unsupported configuration / table height
+            total += w;
         }
         if (offs) offs[ntables] = total;
         return total;
@@ -462,6 +491,11 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
                           const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls, const uint64_t* pub,
                           size_t npub, uint64_t* proofs, uint64_t* challenges, char** err) {
     std::vector<zkm_batch*> commits(ntables, nullptr);
+    std::vector<gl_t*> d_traces(ntables, nullptr);  // device copies of host-resident traces: uploaded ONCE (with the commitment), reused below
+    auto drop_traces = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        for (auto& p : d_traces) { c->release(p); p = nullptr; }
+    };
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         if (ntables == 12) {  // a whole AllStark segment: the transcript only matches the reference's in Table::all() order
@@ -486,12 +520,10 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
         zkm_challenger ch;
         zkm_challenger_init(&ch);
         for (size_t t = 0; t < ntables; t++) {
-            char* e = nullptr;
-            if (zkm_batch_commit_values(c, tables[t].trace, tables[t].ncols, tables[t].log_n, cfg->rate_bits, cfg->cap_height, &commits[t], &e)) {
-                std::string msg = e ? e : "commit failed";
-                free(e);
-                throw std::runtime_error(msg);
-            }
+            if (tables[t].ncols == 0 || tables[t].log_n > 30) throw std::runtime_error("zkm_prove_with_traces: bad table shape");
+            if (!zkm_is_device_ptr(tables[t].trace)) d_traces[t] = (gl_t*)c->alloc((tables[t].ncols << tables[t].log_n) * sizeof(gl_t));
+            commits[t] = zkm_batch_commit_values_keep(c, tables[t].trace, tables[t].ncols, tables[t].log_n, cfg->rate_bits, cfg->cap_height,
+                                                      d_traces[t]);
             zkm_challenger_observe(&ch, commits[t]->cap.data(), commits[t]->cap.size());  // :182-185
         }
         zkm_challenger_observe(&ch, pub, npub);  // :187 observe_public_values
@@ -507,9 +539,7 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
             size_t n = (size_t)1 << tables[t].log_n;
             ctl_dev_owner own;
             own.upload(c, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), false, tables[t].ncols);
-            bool tdev = zkm_is_device_ptr(tables[t].trace);
-            gl_t* d_trace = tdev ? const_cast<gl_t*>(tables[t].trace) : (gl_t*)c->alloc(tables[t].ncols * n * 8);
-            if (!tdev) ZKM_HIP_CHECK(hipMemcpyAsync(d_trace, tables[t].trace, tables[t].ncols * n * 8, hipMemcpyHostToDevice, c->stream));
+            gl_t* d_trace = d_traces[t] ? d_traces[t] : const_cast<gl_t*>(tables[t].trace);
             gl_t* d_aux = (gl_t*)c->alloc((tz[t].naux ? tz[t].naux : 1) * n * 8);
             int rc = 0;
             char* e = nullptr;
@@ -520,12 +550,12 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
                                                 &ch, proofs + offs[t], &e);
             } catch (...) {
                 (void)hipStreamSynchronize(c->stream);
-                if (!tdev) c->release(d_trace);
                 c->release(d_aux);
                 throw;
             }
-            if (!tdev) c->release(d_trace);
             c->release(d_aux);
+            c->release(d_traces[t]);  // (stream-ordered reuse; the table's proof has been downloaded, i.e. the stream is drained)
+            d_traces[t] = nullptr;
             if (rc) {
                 std::string msg = e ? e : "prove_single_table failed";
                 free(e);
@@ -534,9 +564,11 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
         }
     } catch (const std::exception& e) {
         for (auto b : commits) zkm_batch_free(b);
+        drop_traces();
         return fail(err, e.what());
     }
     for (auto b : commits) zkm_batch_free(b);
+    drop_traces();
     return 0;
 }
 

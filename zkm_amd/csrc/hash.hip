@@ -74,6 +74,54 @@ void zkm_launch_merkle_leaves(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t 
     ZKM_HIP_CHECK(hipGetLastError());
 }
 
+// Leaf hashing in column chunks (pipelined host ingest, core.hip zkm_batch_build): the sponge absorbs eight columns per
+// permutation in column order, so a chunk of columns [c0, c0 + nc) -- c0 a multiple of 8 -- can be absorbed as soon as its LDE
+// exists, with the 12-word sponge state of every row parked in HBM between chunks (state[i * nrows + j], lane-contiguous).
+// first: the state starts at zero; last: the digest is written instead of the state.  Same permutation sequence as
+// k_merkle_leaves, so digests are identical.
+__global__ __launch_bounds__(256) void k_merkle_leaves_chunk(const gl_t* __restrict__ lde, size_t nrows, size_t nc, size_t col_stride,
+                                                             gl_t* __restrict__ state, int first, int last, gl_t* __restrict__ digests) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nrows) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = first ? 0 : state[(size_t)i * nrows + j];
+    const gl_t* p = lde + j;
+    size_t c = 0;
+    for (; c + 8 <= nc; c += 8) {
+        uint64_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = p[(c + i) * col_stride];
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[i] = v[i];
+        poseidon_permute(s);
+    }
+    if (c < nc) {  // ragged tail: only legal in the last chunk
+        size_t rem = nc - c;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if ((size_t)i < rem) s[i] = p[(c + i) * col_stride];
+        poseidon_permute(s);
+    }
+    if (last) {
+        uint64_t* d = digests + 4 * j;
+        *reinterpret_cast<ulonglong2*>(d) = make_ulonglong2(s[0], s[1]);
+        *reinterpret_cast<ulonglong2*>(d + 2) = make_ulonglong2(s[2], s[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; i++) state[(size_t)i * nrows + j] = s[i];
+    }
+}
+
+void zkm_launch_merkle_leaves_chunk(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t nc, size_t col_stride, gl_t* state, bool first,
+                                    bool last, gl_t* digests) {
+    if (!last && nc % 8) throw std::runtime_error("merkle_leaves_chunk: only the last chunk may hold a ragged group of columns");
+    zkm_prof_scope ps(c, "merkle_leaves");
+    hipLaunchKernelGGL(k_merkle_leaves_chunk, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, lde, nrows, nc, col_stride, state,
+                       first ? 1 : 0, last ? 1 : 0, digests);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
 // leaves of a FRI layer: leaf k = arity consecutive F2 values (bit-reversed order), flattened c0,c1,c0,c1..
 __global__ __launch_bounds__(256) void k_merkle_leaves_ext(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1,
                                                            size_t nleaves, unsigned arity, gl_t* __restrict__ digests) {

@@ -35,6 +35,8 @@ struct zkm_twiddles {
 struct zkm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // host -> device ingest, overlapped with the compute stream (created on first use)
+    size_t ingest_chunk_cols = 32;      // columns per ingest chunk (ZKM_INGEST_CHUNK; 0 = monolithic upload)
     int num_cus = 256;
     bool use_baseline_ntt = false;  // A/B switch: radix-2 one-stage-per-launch kernels
     // profiling
@@ -119,6 +121,9 @@ void zkm_launch_poseidon_permute(zkm_ctx*, gl_t* states, size_t k);
 void zkm_launch_keccakf(zkm_ctx*, uint64_t* states, size_t k);
 // leaf digests of a column-major matrix (row j across ncols columns of stride `col_stride` words)
 void zkm_launch_merkle_leaves(zkm_ctx*, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests);
+// the same digests from column chunks: state = 12 x nrows words kept between the chunks of one matrix (see hash.hip)
+void zkm_launch_merkle_leaves_chunk(zkm_ctx*, const gl_t* lde, size_t nrows, size_t nc, size_t col_stride, gl_t* state, bool first,
+                                    bool last, gl_t* digests);
 void zkm_ntt_natural_ex(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* scratch, size_t cs_s, gl_t* out, size_t cs_out, size_t ncols,
                         unsigned log_n, bool inverse, uint64_t shift);
 // leaf digests of row-major leaves formed from F2 SoA arrays: leaf k = 16 consecutive (c0,c1) pairs
@@ -148,7 +153,11 @@ void zkm_launch_scale_pad(zkm_ctx*, const gl_t* in, size_t col_stride_in, gl_t* 
 void zkm_lde_bitrev(zkm_ctx*, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, unsigned rate_bits, uint64_t shift);
 
 // ---- core.hip
-void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values);
+// dev_values (optional, ncols x n words of device memory): host values are uploaded THERE and stay (the caller reuses them, e.g. for
+// the CTL columns of prove_with_traces) instead of being staged inside the batch's LDE buffer.
+void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t* dev_values = nullptr);
+zkm_batch* zkm_batch_commit_values_keep(zkm_ctx* c, const uint64_t* values, size_t ncols, unsigned log_n, unsigned rate_bits,
+                                        unsigned cap_height, gl_t* dev_values);
 void zkm_host_poseidon_permute(uint64_t st[12]);
 // ---- hash.hip (LogicStark witness)
 // ---- tables' own logUp lookups (core.hip: definitions; ctl.hip: helper columns)

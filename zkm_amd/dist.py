@@ -67,10 +67,17 @@ def gather_proofs(local):
     return merged
 
 
-def prove_segments(prove_fn, num_segments, sync_fn=None):
-    """Prove `num_segments` independent segments across all ranks.
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
-    prove_fn(segment_index) -> proof; sync_fn() drains the local GPU (torch.cuda.synchronize).
+
+def prove_segments(prove_fn, num_segments, sync_fn=None, gather=True):
+    """Prove `num_segments` independent segments across all ranks (this is bench.py's timed region).
+
+    prove_fn(segment_index) -> proof; sync_fn() drains the local GPU (torch.cuda.synchronize).  The clock runs from a
+    barrier + sync to a sync + barrier and the slowest rank defines the job time.  gather=False skips collecting the proofs on
+    rank 0 (bench.py only needs the time).
     Returns (proofs_on_rank0_or_None, whole_job_seconds)."""
     world, rank, _ = env_world()
     mine = assign_segments(num_segments, world, rank)
@@ -83,4 +90,4 @@ def prove_segments(prove_fn, num_segments, sync_fn=None):
         sync_fn()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
-    return gather_proofs(local), elapsed
+    return (gather_proofs(local) if gather else None), elapsed

@@ -572,3 +572,32 @@ def ctl_sha_extend_sponge(cpu_index, sponge_index, cpu_ctl, sponge_ctl):
 def ctl_sha_compress_sponge(cpu_index, sponge_index, cpu_ctl, sponge_ctl):
     """all_stark::ctl_sha_compress_sponge() (all_stark.rs:326-338)."""
     return [(cpu_index, cpu_looking_sha_compress_sponge(cpu_ctl))], (sponge_index, sha_compress_sponge_looked_data(sponge_ctl))
+
+
+# ---- the whole AllStark (all_stark.rs:96-155): table order of Table::all() and all_cross_table_lookups()
+TABLE_ENUM_ORDER = [TABLE_ARITHMETIC, TABLE_CPU, TABLE_POSEIDON, TABLE_POSEIDON_SPONGE, TABLE_KECCAK, TABLE_KECCAK_SPONGE, TABLE_SHA_EXTEND,
+                    TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRESS_SPONGE, TABLE_LOGIC, TABLE_MEMORY]
+
+
+def all_cross_table_lookups():
+    """all_cross_table_lookups() (all_stark.rs:136-155) on the twelve tables in Table::all() order.
+    Returns (ctl_tables, ctls): ctl_tables[i] = the CtlTable (column sets) of table TABLE_ENUM_ORDER[i]; ctls = the fifteen
+    lookups as (looking sides, looked side), sides = (table index in enum order, column-set index).  The construction order of
+    the column sets is part of the contract: it fixes the column-set indices the C tables of csrc/all_stark_ctl.inc are
+    generated from (tools/gen_all_stark_ctl.py)."""
+    c = [CtlTable() for _ in range(12)]
+    AR, CPU, PO, PS, KK, KS, SE, SES, SC, SCS, LO, ME = range(12)
+    logic_lookers = logic_lookers_cpu(CPU, c[CPU]) + [(KS, keccak_sponge_looking_logic(c[KS], i)) for i in range(NUM_LOGIC_CTLS)] + \
+        logic_lookers_sha_extend(SE, c[SE]) + logic_lookers_sha_compress(SC, c[SC])
+    memory_lookers = memory_lookers_cpu(CPU, c[CPU]) + memory_lookers_poseidon_sponge(PS, c[PS]) + \
+        memory_lookers_keccak_sponge(KS, c[KS]) + memory_lookers_sha_extend_sponge(SES, c[SES]) + \
+        memory_lookers_sha_compress_sponge(SCS, c[SCS]) + memory_lookers_sha_compress(SC, c[SC])
+    ctls = [ctl_arithmetic(CPU, AR, c[CPU], c[AR]),
+            ctl_poseidon_sponge(CPU, PS, c[CPU], c[PS]), ctl_poseidon_inputs(PS, PO, c[PS], c[PO]), ctl_poseidon_outputs(PS, PO, c[PS], c[PO]),
+            ctl_keccak_sponge(CPU, KS, c[CPU], c[KS]), ctl_keccak_inputs(KS, KK, c[KS], c[KK]), ctl_keccak_outputs(KS, KK, c[KS], c[KK]),
+            ctl_sha_extend_sponge(CPU, SES, c[CPU], c[SES]), ctl_sha_extend_inputs(SES, SE, c[SES], c[SE]),
+            ctl_sha_extend_outputs(SES, SE, c[SES], c[SE]),
+            ctl_sha_compress_sponge(CPU, SCS, c[CPU], c[SCS]), ctl_sha_compress_inputs(SCS, SC, c[SCS], c[SC]),
+            ctl_sha_compress_outputs(SCS, SC, c[SCS], c[SC]),
+            (logic_lookers, (LO, logic_ctl_data(c[LO]))), (memory_lookers, (ME, memory_ctl_data(c[ME])))]
+    return c, ctls
