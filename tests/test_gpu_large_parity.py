@@ -107,12 +107,12 @@ def test_pipelined_host_ingest_equals_monolithic(zkm, oracle, monkeypatch):
     stream and absorbed chunk by chunk (k_merkle_leaves_chunk); the commitment must not depend on the chunking, the source
     memory kind (pageable / pinned) or the ragged last chunk."""
     rng = np.random.default_rng(77)
-    log_n = 10
+    log_n = 13
     for ncols in (64, 77, 262):
         vals = rand_field(rng, ncols << log_n)
         want = oracle.batch_from_values(vals, ncols, log_n)
         caps = []
-        for chunk in ("0", "8", "32"):
+        for chunk in ("0", "8", "32"):  # (log_n 13: the smallest height the pipelined path takes)
             monkeypatch.setenv("ZKM_INGEST_CHUNK", chunk)
             c = zkm.Context(0)
             b = zkm.PolynomialBatch.from_values(c, vals, ncols, log_n)

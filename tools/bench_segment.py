@@ -39,16 +39,15 @@ def tiled_segment(ctx, log_cycles):
 
 
 def segment_rate(ctx, log_cycles, reps=3):
-    import torch
     bufs, logs = tiled_segment(ctx, log_cycles)
     ctx.prove_segment(bufs, logs, public_values=[1, 2, 3])       # warm-up: allocator, twiddles, power tables
     ctx.profile(True)
     ctx.profile_reset()
-    torch.cuda.synchronize()
+    ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         proofs, _, offs = ctx.prove_segment(bufs, logs, public_values=[1, 2, 3])
-    torch.cuda.synchronize()
+    ctx.synchronize()
     wall = (time.perf_counter() - t0) / reps
     rec = ctx.profile_records()
     ctx.profile(False)
@@ -62,13 +61,55 @@ def segment_rate(ctx, log_cycles, reps=3):
             "note": "twelve tables, fifteen lookups, one zkm_prove_segment call; traces device-resident, tiled test segment (timing only)"}
 
 
-def small_segment_rate(ctx):
-    return segment_rate(ctx, 16)
+def concurrent_segment_rate(device, log_cycles, nctx, reps=3):
+    """`nctx` host threads, each with its OWN context (own stream, allocator, transcript) on the same GPU, proving independent
+    segments at the same time: in the launch-bound regime of small segments the GPU interleaves their kernels, so the per-level
+    Merkle / per-layer FRI latencies of one segment are filled with the work of the others.  Segments are independent proofs
+    (prover/examples/utils/src/utils.rs:57-68), so this is the same sharding as across GPUs, applied within one."""
+    import threading
+    import zkm_amd
+    ctxs = [zkm_amd.Context(device) for _ in range(nctx)]
+    data = [tiled_segment(c, log_cycles) for c in ctxs]
+    for c, (bufs, logs) in zip(ctxs, data):
+        c.prove_segment(bufs, logs, public_values=[1, 2, 3])
+        c.synchronize()
+    start = threading.Barrier(nctx + 1)
+
+    def work(c, bufs, logs):
+        start.wait()
+        for _ in range(reps):
+            c.prove_segment(bufs, logs, public_values=[1, 2, 3])
+        c.synchronize()
+    th = [threading.Thread(target=work, args=(c, b, l)) for c, (b, l) in zip(ctxs, data)]
+    for t in th:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    for c, (bufs, _) in zip(ctxs, data):
+        for b in bufs:
+            b.free()
+        c.close()
+    return {"contexts": nctx, "segments_per_s": nctx * reps / wall, "ms_per_segment_amortised": wall * 1e3 / (nctx * reps)}
+
+
+def small_segment_rate(ctx, device=0):
+    out = segment_rate(ctx, 16)
+    try:
+        out["concurrent"] = [concurrent_segment_rate(device, 16, k) for k in (2, 4)]
+    except Exception as e:  # the single-context figure stands on its own
+        out["concurrent_error"] = str(e)
+    return out
 
 
 if __name__ == "__main__":
     import zkm_amd
     c = zkm_amd.Context(0)
-    out = segment_rate(c, int(sys.argv[1]) if len(sys.argv) > 1 else 16)
+    lc = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    out = segment_rate(c, lc)
     out["memory_live_cached"] = c.memory()
+    if lc == 16:
+        out["concurrent"] = [concurrent_segment_rate(0, 16, k) for k in (2, 4, 8)]
     print(json.dumps(out, indent=1))

@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_LIB_PATH = os.path.join(_CSRC, "libzkmhip.so")
+_LIB_PATH = os.environ.get("ZKM_HIP_LIB") or os.path.join(_CSRC, "libzkmhip.so")   # (ZKM_HIP_LIB: A/B builds of the same in-tree sources)
 
 P = 0xFFFFFFFF00000001
 POSEIDON_COLS = 262

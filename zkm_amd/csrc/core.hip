@@ -288,7 +288,7 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
     hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const size_t CH = c->ingest_chunk_cols;
     bool leaves_done = false;
-    if (src_is_values && !dev && CH && CH % 8 == 0 && ncols >= 2 * CH) {
+    if (src_is_values && !dev && CH && CH % 8 == 0 && ncols >= 2 * CH && b->log_n >= 13) {  // (short tables: one upload, wide leaf hashing)
         // Host-resident values (prover.rs:144-167: the traces arrive as Vec<PolynomialValues>): pipelined ingest.  The upload is
         // split into chunks of CH columns on the copy stream; the compute stream transforms (iNTT, LDE) and ABSORBS chunk k
         // (leaf sponge, hash.hip k_merkle_leaves_chunk) while chunk k + 1 .. are in flight, so PCIe time hides behind hashing.

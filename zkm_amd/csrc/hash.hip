@@ -66,11 +66,18 @@ __global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ 
     *reinterpret_cast<ulonglong2*>(d + 2) = make_ulonglong2(s[2], s[3]);
 }
 
+__global__ void k_merkle_leaves_wide(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests);
+static size_t wide_max_leaves();
+
 void zkm_launch_merkle_leaves(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests) {
     // rows of <= 4 elements are copied, not hashed (hash_or_noop): profile them under their own name
     zkm_prof_scope ps(c, ncols <= 4 ? "merkle_leaves_copy" : "merkle_leaves");
-    hipLaunchKernelGGL(k_merkle_leaves, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride,
-                       digests);
+    if (ncols > 4 && nrows <= wide_max_leaves())
+        // short, wide matrices (Keccak: 2431 columns x a few thousand rows): one lane per leaf leaves the machine empty and pays one
+        // permutation's full latency per 8 columns; 16 lanes per leaf cut that latency to a third and fill 16x the lanes
+        hipLaunchKernelGGL(k_merkle_leaves_wide, dim3((nrows * 16 + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
+    else
+        hipLaunchKernelGGL(k_merkle_leaves, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
     ZKM_HIP_CHECK(hipGetLastError());
 }
 
@@ -203,6 +210,26 @@ __global__ __launch_bounds__(256) void k_merkle_compress_wide(const gl_t* __rest
     if (live && idx < 8) x = children[8 * p + idx];
     x = poseidon_permute_wide(x, lane);
     if (live && idx < 4) parents[4 * p + idx] = x;
+}
+
+// Column-major leaves, one leaf per 16-lane row (see poseidon_permute_wide): lanes 0..7 of the row fetch the next eight columns of
+// their leaf (overwrite-mode absorb: a ragged tail overwrites only the words that exist), all 12 lanes permute.  Bit-exact with
+// k_merkle_leaves.  Used when the matrix has at most wide_max_leaves() rows.
+__global__ __launch_bounds__(256) void k_merkle_leaves_wide(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride,
+                                                            gl_t* __restrict__ digests) {
+    const unsigned lane = threadIdx.x & 63, idx = lane & 15;
+    const size_t leaf = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = leaf < nrows;  // uniform over the 16-lane row; every lane of the wave takes part in the shuffles
+    uint64_t x = 0;
+    for (size_t c = 0; c < ncols; c += 8) {
+        if (live && idx < 8 && c + idx < ncols) x = lde[(c + idx) * col_stride + leaf];
+        x = poseidon_permute_wide(x, lane);
+    }
+    if (live && idx < 4) digests[4 * leaf + idx] = x;
+}
+static size_t wide_max_leaves() {
+    static size_t v = [] { const char* e = getenv("ZKM_WIDE_MAX_LEAVES"); return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)16384; }();
+    return v;
 }
 
 static size_t wide_max_parents() {

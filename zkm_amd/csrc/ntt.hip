@@ -94,6 +94,14 @@ struct ntt_pass_args {
     gl_t post_scale;
     const gl_t* post_tab;
     uint32_t post_log;
+    // coset fusion (first pass of the coset-split LDE): ncoset independent transforms of the SAME input, coset k pre-scaled with
+    // pre_tab_k[k] and written at out + out_off_k[k]; workgroups of one tile's cosets are dispatched next to each other on one XCD
+    uint32_t ncoset;
+    const gl_t* pre_tab_k[4];
+    size_t out_off_k[4];
+    // PRE == 3: the pre-scale s_k^t of element t = t0 + j * row_step is B * D_k^j with B = s_k^t0 looked up once per thread and
+    // pre_dj[k][j] = (s_k^row_step)^j wave-uniform: no table access inside the column loop
+    gl_t pre_dj[4][8];
 };
 
 template <int S, int K>
@@ -174,21 +182,37 @@ struct ntt_round {
 // that side; LDS is then only the exchange buffer between rounds.
 // PRE / POST: 0 = never, 1 = always, 2 = decided at run time (keeps the scale paths out of the register
 // allocation of the hot variants)
-template <int S, bool IN_A, bool OUT_A, int PRE, int POST>
-__global__ __launch_bounds__(512) void k_ntt_pass(ntt_pass_args p) {
+// ZP: the input is shorter than the transform (rows beyond n_in read as zero): only then are loads bounds-checked.
+// PF: software-prefetch the next column (16 VGPRs); off where the kernel must stay within 128 VGPRs for two workgroups per CU.
+template <int S, bool IN_A, bool OUT_A, int PRE, int POST, bool ZP = false, bool PF = true>
+#ifndef ZKM_NTT_OCC
+#define ZKM_NTT_OCC 2
+#endif
+__global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(ntt_pass_args p) {
     extern __shared__ __attribute__((aligned(16))) gl_t lds[];
     constexpr int R = 1 << S, NR = (S + 2) / 3;
     using R0 = ntt_round<S, 0>;
     using R1 = ntt_round<S, (NR > 1 ? 1 : 0)>;
     using R2 = ntt_round<S, (NR > 2 ? 2 : 0)>;
     using RL = ntt_round<S, NR - 1>;  // last round: q == 0, rows (rg << 3) | j
-    const bool do_pre = PRE == 1 || (PRE == 2 && p.pre_tab != nullptr);
+    const bool do_pre = PRE == 1 || (PRE == 2 && (p.pre_tab != nullptr || p.ncoset > 1));
+    static_assert(PRE != 3 || (!IN_A && !ZP), "factored pre-scale: strided input only");
     const bool do_post = POST == 1 || (POST == 2 && (p.post_scale != 1 || p.post_tab != nullptr));
     const int logT = p.log_T, T = 1 << logT, tp = p.tp;
     const int nthreads = (R >> 3) << logT;
     const int tid = threadIdx.x;
     const int b = tid & (T - 1), rg = tid >> logT;
-    const uint32_t tile = blockIdx.x, t_hi = tile / p.n_lo, t_lo = tile % p.n_lo;
+    // coset-fused launches: consecutive workgroup ids go round-robin over the 8 XCDs, so the ncoset workgroups of one tile get ids
+    // 8 apart -- same XCD, same L2: the input tile comes from HBM once and from L2 ncoset - 1 times
+    uint32_t tile = blockIdx.x, coset = 0;
+    if (p.ncoset > 1) {
+        const uint32_t g = blockIdx.x >> 3;
+        coset = g % p.ncoset;
+        tile = (g / p.ncoset) * 8 + (blockIdx.x & 7);
+    }
+    const gl_t* const pre_tab = p.ncoset > 1 ? p.pre_tab_k[coset] : p.pre_tab;
+    const size_t out_off = p.ncoset > 1 ? p.out_off_k[coset] : 0;
+    const uint32_t t_hi = tile / p.n_lo, t_lo = tile % p.n_lo;
     const size_t base_in = (size_t)t_hi * p.bi_hi + (size_t)t_lo * p.bi_lo;
     const size_t base_out = (size_t)t_hi * p.bo_hi + (size_t)t_lo * p.bo_lo;
     const size_t i_low = p.m ? (((size_t)t_lo << logT) + b) : 0;
@@ -198,51 +222,67 @@ __global__ __launch_bounds__(512) void k_ntt_pass(ntt_pass_args p) {
     if (NR > 1) R1::load_tw(w1, p.tw, rg, p.m, i_low);
     if (NR > 2) R2::load_tw(w2, p.tw, rg, p.m, i_low);
 
-    // column-independent offsets
+    // column-independent offsets.  Every global access is (wave-uniform base) + (one 32-bit lane offset): the 8 row bases of a
+    // thread differ by uniform multiples of the row step, so the addresses cost scalar adds, not a VGPR pair per row.
     // direct input: rows rg + j*(R/8) (== R0::row(rg, j)), column b
-    // (32-bit element offsets: a column holds < 2^29 elements, so the wave-uniform column base stays scalar)
-    const uint32_t in0 = (uint32_t)(base_in + (size_t)rg * p.sa_in + (size_t)b * p.sb_in), in_step = (uint32_t)((size_t)(R >> 3) * p.sa_in);
+    const uint32_t lane_in = (uint32_t)((size_t)rg * p.sa_in + (size_t)b * p.sb_in);
+    const size_t in_step = (size_t)(R >> 3) * p.sa_in;
     // direct output: rows of the last round, optionally bit-reversed: bitrev((rg<<3)|j) = brev3(j)*(R/8) + bitrev(rg, S-3)
-    const uint32_t out0 = (uint32_t)(base_out + (size_t)(p.rev_rows ? bitrev32((uint32_t)rg, S - 3) : (uint32_t)(rg << 3)) * p.sa_out + (size_t)b * p.sb_out);
-    const uint32_t out_step = (uint32_t)(p.rev_rows ? (size_t)(R >> 3) * p.sa_out : p.sa_out);
+    const uint32_t lane_out = (uint32_t)((size_t)(p.rev_rows ? bitrev32((uint32_t)rg, S - 3) : (uint32_t)(rg << 3)) * p.sa_out + (size_t)b * p.sb_out);
+    const size_t out_step = p.rev_rows ? (size_t)(R >> 3) * p.sa_out : p.sa_out;
+    // (the coset pre-scale table and the bounds check index by element: 32-bit element offsets, a column holds < 2^29 elements)
+    const uint32_t in0 = (uint32_t)base_in + lane_in, in_step32 = (uint32_t)in_step;
 
     const uint32_t col0 = blockIdx.y * p.cpb;
     const uint32_t col1 = col0 + p.cpb < p.ncols ? col0 + p.cpb : p.ncols;
     // Software pipeline over the workgroup's columns: the 8 words of column c + 1 are requested before column c is
     // transformed (16 VGPRs), so the HBM latency of the next loads is covered by ~800 VALU instructions instead of
     // being exposed at the top of every iteration.  nx[] holds raw words; the coset pre-scale is applied when they are consumed.
+    gl_t gpre[8];
+    if (PRE == 3) {
+        const gl_t B = pow_lookup(pre_tab, p.pre_log, in0);
+#pragma unroll
+        for (int j = 0; j < 8; j++) gpre[j] = j ? gl_mul(B, p.pre_dj[coset][j]) : gl_canon(B);
+    }
     gl_t nx[8];
     auto fetch = [&](uint32_t col) {
-        const gl_t* __restrict__ src = p.in + (size_t)col * p.cs_in;
+        const gl_t* __restrict__ src = p.in + (size_t)col * p.cs_in + base_in;   // wave-uniform
         if (!IN_A) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                uint32_t off = in0 + (uint32_t)j * in_step;
-                nx[j] = off < p.n_in ? src[off] : 0;
+                const gl_t* row = src + (size_t)j * in_step;                       // still uniform
+                nx[j] = (!ZP || in0 + (uint32_t)j * in_step32 < p.n_in) ? row[lane_in] : 0;
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 int idx = tid + e * nthreads;
                 int a = idx & (R - 1), bb = idx >> S;
-                size_t off = base_in + (size_t)a * p.sa_in + (size_t)bb * p.sb_in;
-                nx[e] = off < p.n_in ? src[off] : 0;
+                size_t off = (size_t)a * p.sa_in + (size_t)bb * p.sb_in;
+                nx[e] = (!ZP || base_in + off < p.n_in) ? src[off] : 0;
             }
         }
     };
-    if (col0 < col1) fetch(col0);
+    if (PF && col0 < col1) fetch(col0);
     for (uint32_t col = col0; col < col1; col++) {
-        gl_t* __restrict__ dst = p.out + (size_t)col * p.cs_out;
+        if (!PF) fetch(col);
+        gl_t* __restrict__ dst = p.out + (size_t)col * p.cs_out + out_off + (OUT_A ? 0 : base_out);   // wave-uniform
         gl_t x[8];
         if (!IN_A) {
 #pragma unroll
             for (int j = 0; j < 8; j++) x[j] = nx[j];
             __builtin_amdgcn_sched_barrier(0);
-            if (do_pre) {
+            if (PRE == 3) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const uint32_t off = in0 + (uint32_t)j * in_step;
-                    if (off < p.n_in) x[j] = gl_mul_loose(x[j], pow_lookup(p.pre_tab, p.pre_log, off));  // (the table only covers the unpadded input)
+                    x[j] = gl_mul_loose(x[j], gpre[j]);
+                    if (j & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (do_pre) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t off = in0 + (uint32_t)j * in_step32;
+                    if (!ZP || off < p.n_in) x[j] = gl_mul_loose(x[j], pow_lookup(pre_tab, p.pre_log, off));  // (the table only covers the unpadded input)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -254,13 +294,13 @@ __global__ __launch_bounds__(512) void k_ntt_pass(ntt_pass_args p) {
                 int a = idx & (R - 1), bb = idx >> S;
                 size_t off = base_in + (size_t)a * p.sa_in + (size_t)bb * p.sb_in;
                 gl_t v = nx[e];
-                if (do_pre && off < p.n_in) v = gl_mul_loose(v, pow_lookup(p.pre_tab, p.pre_log, off));
+                if (do_pre && (!ZP || off < p.n_in)) v = gl_mul_loose(v, pow_lookup(pre_tab, p.pre_log, off));
                 lds[a * tp + bb] = v;
             }
             __syncthreads();
             R0::lds_read(lds, tp, b, rg, x);
         }
-        if (col + 1 < col1) fetch(col + 1);
+        if (PF && col + 1 < col1) fetch(col + 1);
         __builtin_amdgcn_sched_barrier(0);
         if (!IN_A && S >= 3 && p.zero_padded) R0::compute_zero_padded(x, w0);
         else R0::compute(x, w0);
@@ -282,7 +322,7 @@ __global__ __launch_bounds__(512) void k_ntt_pass(ntt_pass_args p) {
                 for (int j = 0; j < 8; j++) {
                     const int jj = p.rev_rows ? (int)(((j & 1) << 2) | (j & 2) | ((j >> 2) & 1)) : j;
                     if (p.post_scale != 1) x[j] = gl_mul(x[j], p.post_scale);
-                    if (p.post_tab) x[j] = gl_mul(x[j], pow_lookup(p.post_tab, p.post_log, out0 + (uint32_t)jj * out_step));
+                    if (p.post_tab) x[j] = gl_mul(x[j], pow_lookup(p.post_tab, p.post_log, (uint32_t)base_out + lane_out + (uint32_t)((size_t)jj * out_step)));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -293,7 +333,7 @@ __global__ __launch_bounds__(512) void k_ntt_pass(ntt_pass_args p) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int jj = p.rev_rows ? (int)(((j & 1) << 2) | (j & 2) | ((j >> 2) & 1)) : j;
-                dst[out0 + (uint32_t)jj * out_step] = x[j];
+                (dst + (size_t)jj * out_step)[lane_out] = x[j];
             }
         } else {
             RL::lds_write(lds, tp, b, rg, x);
@@ -331,28 +371,33 @@ static ntt_plan make_plan(unsigned L) {
     return pl;
 }
 
-template <int S, bool IN_A, bool OUT_A, int PRE, int POST>
+template <int S, bool IN_A, bool OUT_A, int PRE, int POST, bool ZP = false, bool PF = true>
 static void launch_pass_t(zkm_ctx* c, const ntt_pass_args& a, size_t ntiles) {
     static bool attr_done = false;
     if (!attr_done) {
-        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass<S, IN_A, OUT_A, PRE, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass<S, IN_A, OUT_A, PRE, POST, ZP, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     int T = 1 << a.log_T;
     size_t shmem = ((size_t)1 << S) * a.tp * sizeof(gl_t);
-    dim3 grid((unsigned)ntiles, (a.ncols + a.cpb - 1) / a.cpb), block((unsigned)(((1 << S) >> 3) * T));
-    hipLaunchKernelGGL((k_ntt_pass<S, IN_A, OUT_A, PRE, POST>), grid, block, shmem, c->stream, a);
+    dim3 grid((unsigned)(ntiles * (a.ncoset > 1 ? a.ncoset : 1)), (a.ncols + a.cpb - 1) / a.cpb), block((unsigned)(((1 << S) >> 3) * T));
+    hipLaunchKernelGGL((k_ntt_pass<S, IN_A, OUT_A, PRE, POST, ZP, PF>), grid, block, shmem, c->stream, a);
 }
 
 template <int S>
 static void launch_pass_s(zkm_ctx* c, const ntt_pass_args& a, size_t ntiles) {
-    const bool pre = a.pre_tab != nullptr, post = a.post_scale != 1 || a.post_tab != nullptr;
+    const bool pre = a.pre_tab != nullptr || a.ncoset > 1, post = a.post_scale != 1 || a.post_tab != nullptr;
+    const bool zp = a.n_in != ~(size_t)0;  // the input is shorter than the transform (zero-padded LDE): bounds-checked loads
     if (!a.in_contig_a && !a.out_contig_a) {
         if (post) throw std::runtime_error("ntt pass: strided pass cannot post-scale");
-        if (pre) launch_pass_t<S, false, false, 1, 0>(c, a, ntiles);
+        if (a.ncoset > 1) launch_pass_t<S, false, false, 3, 0, false, false>(c, a, ntiles);
+        else if (pre && zp) launch_pass_t<S, false, false, 1, 0, true>(c, a, ntiles);
+        else if (pre) launch_pass_t<S, false, false, 1, 0>(c, a, ntiles);
+        else if (zp) launch_pass_t<S, false, false, 0, 0, true>(c, a, ntiles);
         else launch_pass_t<S, false, false, 0, 0>(c, a, ntiles);
     } else if (a.in_contig_a && a.out_contig_a) {
-        launch_pass_t<S, true, true, 2, 2>(c, a, ntiles);
+        if (zp) launch_pass_t<S, true, true, 2, 2, true>(c, a, ntiles);
+        else launch_pass_t<S, true, true, 2, 2>(c, a, ntiles);
     } else if (a.in_contig_a && !a.out_contig_a) {
         if (pre) throw std::runtime_error("ntt pass: transposing pass cannot pre-scale");
         if (post) launch_pass_t<S, true, false, 0, 1>(c, a, ntiles);
@@ -496,6 +541,191 @@ static void ntt_natural_fast(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* scr
     }
 }
 
+// ------------------------------------------------------------------ large contiguous pass
+// The LAST pass of a bit-reversed-output transform: SA + 6 radix-2 DIF stages on blocks of E = 2^(SA+6) CONTIGUOUS elements (64 KB
+// for SA = 7), one block per workgroup iteration, 8 elements per thread.  Phase 1 treats the block as [2^SA rows][64 columns] and
+// runs the SA upper stages like a strided pass (lanes along the 64 contiguous elements, rows at stride 64); phase 2 runs the six
+// lower stages on the 64-element rows themselves with the lanes along the 2^SA rows (the LDS image [a * 65 + b] is conflict-free
+// in both directions: 65 words = 130 banks == 2 mod 64).  Global accesses are word tid + NT * j on the way in and, after a last
+// pass through LDS, on the way out: 512 B per wave instruction.  Phase-2 twiddles only depend on the row group (tid >> SA), which
+// is wave-uniform for SA >= 6: they live in SGPRs.  The next block is prefetched while the current one is transformed.
+struct ntt_big_args {
+    gl_t* data;
+    size_t cs;            // column stride (elements)
+    uint32_t ncols;
+    uint32_t blocks_per_col;
+    uint32_t canon_out;
+    const gl_t* tw;
+};
+
+template <int S, int K>
+struct ntt_round_t : ntt_round<S, K> {  // the same row / twiddle scheme with explicit LDS strides
+    using B = ntt_round<S, K>;
+    __device__ static __forceinline__ void lds_read(const gl_t* lds, int sr, int sb, int b, int rg, gl_t (&x)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = lds[B::row(rg, j) * sr + b * sb];
+    }
+    __device__ static __forceinline__ void lds_write(gl_t* lds, int sr, int sb, int b, int rg, const gl_t (&x)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) lds[B::row(rg, j) * sr + b * sb] = x[j];
+    }
+};
+
+template <int SA>
+__global__ __launch_bounds__((1 << SA) * 8) void k_ntt_big(ntt_big_args p) {
+    extern __shared__ __attribute__((aligned(16))) gl_t lds[];
+    constexpr int RA = 1 << SA, NT = RA * 8, LP = 65, NR1 = (SA + 2) / 3;
+    constexpr bool UNI = SA >= 6;  // tid >> SA is uniform over a wave
+    using A0 = ntt_round_t<SA, 0>;
+    using A1 = ntt_round_t<SA, (NR1 > 1 ? 1 : 0)>;
+    using A2 = ntt_round_t<SA, (NR1 > 2 ? 2 : 0)>;
+    using B0 = ntt_round_t<6, 0>;
+    using B1 = ntt_round_t<6, 1>;
+    const int tid = threadIdx.x;
+    const int b = tid & 63, rg = tid >> 6;                  // phase 1: column b, row group rg
+    const int a2 = tid & (RA - 1);                          // phase 2: row a2 of the phase-1 output ...
+    const int rg2 = UNI ? __builtin_amdgcn_readfirstlane(tid >> SA) : (tid >> SA);  // ... group rg2 of its 64 elements
+
+    gl_t wa0[7], wa1[7], wa2[7], wb0[7], wb1[7];
+    A0::load_tw(wa0, p.tw, rg, 6, (size_t)b);
+    if (NR1 > 1) A1::load_tw(wa1, p.tw, rg, 6, (size_t)b);
+    if (NR1 > 2) A2::load_tw(wa2, p.tw, rg, 6, (size_t)b);
+    B0::load_tw(wb0, p.tw, rg2, 0, 0);
+    B1::load_tw(wb1, p.tw, rg2, 0, 0);
+
+    const uint32_t total = p.ncols * p.blocks_per_col;
+    auto block_ptr = [&](uint32_t blk) { return p.data + (size_t)(blk / p.blocks_per_col) * p.cs + ((size_t)(blk % p.blocks_per_col) << (SA + 6)); };
+    gl_t nx[8];
+    uint32_t blk = blockIdx.x;
+    if (blk < total) {
+        const gl_t* src = block_ptr(blk);
+#pragma unroll
+        for (int j = 0; j < 8; j++) nx[j] = src[tid + NT * j];
+    }
+    for (; blk < total; blk += gridDim.x) {
+        gl_t* const dst = block_ptr(blk);
+        gl_t x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = nx[j];          // rows rg + (RA / 8) j == A0::row(rg, j), column b
+        if (blk + gridDim.x < total) {
+            const gl_t* src = block_ptr(blk + gridDim.x);
+#pragma unroll
+            for (int j = 0; j < 8; j++) nx[j] = src[tid + NT * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 1: SA stages along the rows, lanes along b
+        A0::compute(x, wa0);
+        if (NR1 > 1) {
+            A0::lds_write(lds, LP, 1, b, rg, x);
+            __syncthreads();
+            A1::lds_read(lds, LP, 1, b, rg, x);
+            A1::compute(x, wa1);
+        }
+        if (NR1 > 2) {
+            __syncthreads();
+            A1::lds_write(lds, LP, 1, b, rg, x);
+            __syncthreads();
+            A2::lds_read(lds, LP, 1, b, rg, x);
+            A2::compute(x, wa2);
+        }
+        using AL = ntt_round_t<SA, NR1 - 1>;
+        if (NR1 > 1) __syncthreads();
+        AL::lds_write(lds, LP, 1, b, rg, x);
+        __syncthreads();
+        // ---- phase 2: the six stages inside each 64-element row, lanes along the rows
+        B0::lds_read(lds, 1, LP, a2, rg2, x);
+        B0::compute(x, wb0);
+        __syncthreads();
+        B0::lds_write(lds, 1, LP, a2, rg2, x);
+        __syncthreads();
+        B1::lds_read(lds, 1, LP, a2, rg2, x);
+        B1::compute(x, wb1);
+        __syncthreads();
+        B1::lds_write(lds, 1, LP, a2, rg2, x);
+        __syncthreads();
+        // ---- out: word p of the block sits at lds[p + (p >> 6)]
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int pidx = tid + NT * j;
+            gl_t v = lds[pidx + (pidx >> 6)];
+            if (p.canon_out) v = gl_canon(v);
+            dst[pidx] = v;
+        }
+        __syncthreads();  // LDS is reused by the next block
+    }
+}
+
+template <int SA>
+static void launch_big_t(zkm_ctx* c, const ntt_big_args& a) {
+    static bool attr_done = false;
+    size_t shmem = ((size_t)1 << SA) * 65 * sizeof(gl_t);
+    if (!attr_done) {
+        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_big<SA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    uint32_t total = a.ncols * a.blocks_per_col;
+    uint32_t grid = total < (uint32_t)c->num_cus * 8 ? total : (uint32_t)c->num_cus * 8;
+    hipLaunchKernelGGL((k_ntt_big<SA>), dim3(grid), dim3((1u << SA) * 8), shmem, c->stream, a);
+}
+
+// S2 = 11, 12, 13 lower stages of every contiguous 2^S2 block of `ncols` columns of length 2^L, in place
+static void ntt_big_pass(zkm_ctx* c, gl_t* data, size_t cs, size_t ncols, unsigned L, int S2, const gl_t* tw) {
+    ntt_big_args a{data, cs, (uint32_t)ncols, (uint32_t)(((size_t)1 << L) >> S2), 1u, tw};
+    zkm_prof_scope ps(c, "ntt_pass_big");
+    switch (S2) {
+        case 11: launch_big_t<5>(c, a); break;
+        case 12: launch_big_t<6>(c, a); break;
+        case 13: launch_big_t<7>(c, a); break;
+        default: throw std::runtime_error("ntt big pass: unsupported stage count");
+    }
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
+// Coset-split LDE (rate 4): the evaluations on g<w_4n> in bit-reversed order are four blocks of n -- block bitrev2(k) holds the
+// size-n DIF transform of c_t (g w_4n^k)^t (position bitrev(k + 4 i) = bitrev2(k) n + bitrev(i)).  Two launches: (A) the upper
+// log_n - S2 stages of all four transforms, strided, coset-fused (the coefficients are read once from HBM, three more times from
+// L2; 4n words written); (B) the lower S2 stages on contiguous 2^S2 blocks, in place.  HBM traffic per column 8n + 32n + 64n =
+// 104n bytes against 168n of the three-pass zero-padded transform.
+static bool lde_coset_split(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, uint64_t shift) {
+    static const bool off = getenv("ZKM_NTT_LDE_3PASS") != nullptr;  // A/B switch
+    if (off || log_n < 14 || log_n > 21 || shift <= 1) return false;
+    const size_t n = (size_t)1 << log_n, N = n << 2;
+    static const int s2_env = getenv("ZKM_NTT_S2") ? atoi(getenv("ZKM_NTT_S2")) : 0;  // tuning knob (11..13)
+    // S2 = 12 wherever the strided pass can take the other log_n - 12 stages (3..8): the 2^12-element block kernel runs two
+    // workgroups per CU (512 threads, 100 VGPRs, 33 KB LDS), the 2^13 one only one -- measured at 262 x 2^20: 6.8 ms / 12 stages
+    // against 8.4 ms / 13 stages (profiles/r02_ntt_split_ab.txt)
+    int S2 = (log_n >= 15 && log_n <= 20) ? 12 : (log_n - 13 >= 3 ? 13 : (int)log_n - 3);
+    if (s2_env >= 11 && s2_env <= 13 && (int)log_n - s2_env >= 3 && (int)log_n - s2_env <= 8) S2 = s2_env;
+    const int S1 = (int)log_n - S2;   // S1 in 3..8
+    c->ensure_twiddles(log_n + 2);
+    ntt_pass_args a{};
+    a.in = coeffs; a.out = out; a.cs_in = n; a.cs_out = N; a.ncols = (uint32_t)ncols;
+    a.tw = c->tw.fwd; a.m = (uint32_t)S2; a.post_scale = 1; a.n_in = ~(size_t)0; a.pre_log = log_n;  // (every offset of the tile is < n)
+    a.log_T = pick_log_T(S1, (size_t)1 << S2);
+    a.tp = 1u << a.log_T;
+    a.n_lo = (uint32_t)(((size_t)1 << S2) >> a.log_T);
+    a.bi_hi = a.bo_hi = n; a.bi_lo = a.bo_lo = (size_t)1 << a.log_T;  // (one tile row of blocks: t_hi is always 0)
+    a.sa_in = a.sa_out = (size_t)1 << S2; a.sb_in = a.sb_out = 1;
+    const size_t ntiles = a.n_lo;
+    if (ntiles % 8) return false;
+    a.ncoset = 4;
+    const gl_t w4n = gl_root_of_unity(log_n + 2);
+    gl_t sk = shift;
+    const uint64_t row_step = (((uint64_t)1 << S1) >> 3) << S2;   // elements between the 8 rows a thread holds
+    for (unsigned k = 0; k < 4; k++) {
+        a.pre_tab_k[k] = c->pow_table(sk, log_n);
+        a.out_off_k[k] = (size_t)bitrev32(k, 2) * n;
+        const gl_t D = gl_pow(sk, row_step);
+        gl_t dj = 1;
+        for (int j = 0; j < 8; j++) { a.pre_dj[k][j] = dj; dj = gl_mul(dj, D); }
+        sk = gl_mul(sk, w4n);
+    }
+    a.canon_out = 0;
+    launch_pass(c, S1, a, ntiles, "ntt_pass_strided");
+    ntt_big_pass(c, out, N, ncols, log_n + 2, S2, c->tw.fwd);
+    return true;
+}
+
 // ------------------------------------------------------------------ baseline radix-2 kernels
 // One global-memory DIF stage (span h = 2^s): used for the strides that do not fit one workgroup.
 __global__ __launch_bounds__(256) void k_dif_stage(gl_t* __restrict__ data, size_t col_stride, unsigned log_n, unsigned s,
@@ -612,6 +842,7 @@ void zkm_launch_scale_pad(zkm_ctx* c, const gl_t* in, size_t col_stride_in, gl_t
 
 void zkm_lde_bitrev(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, unsigned rate_bits, uint64_t shift) {
     size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    if (rate_bits == 2 && !c->use_baseline_ntt && lde_coset_split(c, coeffs, out, ncols, log_n, shift)) return;
     if (log_n + rate_bits >= 3 && !c->use_baseline_ntt) {
         ntt_dif_bitrev_fast(c, coeffs, n, out, N, ncols, log_n + rate_bits, false, n, log_n, shift);
         return;
