@@ -62,7 +62,7 @@ def parse(lines):
     innermost loop header the block belongs to (from the asm printer's own loop annotations, which survive loop rotation and
     out-of-line blocks), and parent[header] = enclosing loop's header or None."""
     blocks, parent = [], {}
-    cur = {"label": None, "ops": [], "loop": None}
+    cur = {"label": None, "ops": [], "loop": None, "name": None}
 
     def annotate(block, note, own_label):
         m = re.search(r"in Loop: Header=(BB\w+)", note)
@@ -84,7 +84,8 @@ def parse(lines):
             while k < len(lines) and lines[k].lstrip().startswith(";") and not re.match(r"^\s*;\s*%bb\.\d+:", lines[k]):
                 note += lines[k]
                 k += 1
-            cur = {"label": lab.group(1) if lab else None, "ops": [], "loop": None}
+            cur = {"label": lab.group(1) if lab else None, "ops": [], "loop": None,
+                   "name": lab.group(1) if lab else re.search(r"%bb\.\d+", l).group(0)}
             annotate(cur, note, cur["label"])
             continue
         if not s or s.startswith("."):
@@ -94,7 +95,7 @@ def parse(lines):
         if op.startswith("s_cbranch") or op == "s_branch":
             blocks.append(cur)
             # a fall-through block without its own annotation stays in the loop of the block it follows
-            cur = {"label": None, "ops": [], "loop": cur["loop"]}
+            cur = {"label": None, "ops": [], "loop": cur["loop"], "name": cur.get("name")}
     if cur["ops"] or cur["label"]:
         blocks.append(cur)
     return blocks, parent
@@ -132,6 +133,8 @@ def main():
     ap.add_argument("kernel")
     ap.add_argument("--trips", default="", help="comma-separated trip counts, one per loop in header order")
     ap.add_argument("--only-loop", type=int, default=None, help="restrict to the body of the K-th loop (header order)")
+    ap.add_argument("--exec", default="", help="NAME=count,...: executions of a block (label or %%bb.N; a branch-split block keeps its name) "
+                    "per iteration of the --only-loop loop, for code under a condition the trip counts cannot express")
     ap.add_argument("--cost", default=os.path.join(ROOT, "profiles", "r02_ubench_issue_cost.json"))
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -162,6 +165,10 @@ def main():
         root = loops[args.only_loop]
         keep = [root in chain(b["loop"]) for b in blocks]
         weight = [w // trip[root] if k else w for w, k in zip(weight, keep)]   # per iteration of the selected loop
+    overrides = dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in args.exec.split(",") if kv)
+    for i, b in enumerate(blocks):
+        if b.get("name") in overrides:
+            weight[i] = overrides[b["name"]]
     hist = {}
     for i in range(len(blocks)):
         if not keep[i]:
@@ -173,7 +180,7 @@ def main():
         classes[classify(op)] = classes.get(classify(op), 0) + n
     out = {"source": args.source, "kernel": sym, "loops": [{"header": h, "parent": parent.get(h), "trip": trip[h]} for h in loops],
            "region": "one iteration of loop %s" % loops[args.only_loop] if args.only_loop is not None else "whole kernel",
-           "class_totals": classes, "histogram": dict(sorted(hist.items(), key=lambda kv: -kv[1]))}
+           "block_executions_override": overrides, "class_totals": classes, "histogram": dict(sorted(hist.items(), key=lambda kv: -kv[1]))}
     if os.path.exists(args.cost):
         cost = json.load(open(args.cost))["cycles_per_wave_instr"]
         default = cost.get("_default_vop3", 4.4)

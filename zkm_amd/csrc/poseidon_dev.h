@@ -37,12 +37,14 @@ namespace pc_host {
 #undef ZKM_CONST
 #define ZKM_CONST static const
 #include "poseidon_constants.inc"
+ZKM_CONST uint64_t ZKM_POSEIDON_ZERO12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // "constants" after the last round
 }  // namespace pc_host
 #if defined(__HIPCC__)
 namespace pc_dev {
 #undef ZKM_CONST
 #define ZKM_CONST static __device__ __constant__ const
 #include "poseidon_constants.inc"
+ZKM_CONST uint64_t ZKM_POSEIDON_ZERO12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 }  // namespace pc_dev
 #endif
 #undef ZKM_CONST
@@ -198,44 +200,34 @@ GL_HD void poseidon_partial_group(uint64_t s[12], uint64_t c1, uint64_t c2, cons
 }
 
 // In: any uint64 words (loose).  Out: canonical.
+// One loop over the eight full rounds with the partial-round section hanging off round 3: every piece of round code exists
+// once, so the hot loop of the leaf kernel (33 absorb steps per row) is ~30 KB of instructions instead of ~57 KB (the second
+// block of full rounds, two inline s-box layers and the last MDS used to be separate copies) and stays inside the 64 KB
+// instruction cache two CUs share.
 GL_HD void poseidon_permute(uint64_t s[12]) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_add_loose(s[i], PC::ZKM_POSEIDON_RC[i]);
 #pragma unroll 1
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < 8; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             s[i] = poseidon_sbox7(s[i]);
             if ((i & 1) == 1) POSEIDON_SCHED_FENCE();
         }
-        poseidon_mds_add<true>(s, &PC::ZKM_POSEIDON_RC[(r + 1) * 12]);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; i++) {  // round 3's s-boxes; its MDS opens the first fused group
-        s[i] = poseidon_sbox7(s[i]);
-        if ((i & 1) == 1) POSEIDON_SCHED_FENCE();
-    }
+        if (r == 3) {
+            // round 3's MDS opens the first fused group; the groups cover the MDS of rounds 3 .. 25 and the s-boxes of rounds 4 .. 25
 #pragma unroll 1
-    for (int g = 0; g < 7; g++) {  // MDS of rounds 3g+3 .. 3g+5 and the s-boxes of rounds 3g+4, 3g+5; then round 3g+6's
-        poseidon_partial_group<3>(s, PC::ZKM_POSEIDON_FUSED_C1[g], PC::ZKM_POSEIDON_FUSED_C2[g], PC::ZKM_POSEIDON_FUSED_C3[g]);
-        s[0] = poseidon_sbox7(s[0]);
-    }
-    poseidon_partial_group<2>(s, PC::ZKM_POSEIDON_FUSED_C1[7], 0, PC::ZKM_POSEIDON_FUSED_C3[7]);  // MDS of rounds 24, 25
-#pragma unroll 1
-    for (int r = 26; r < 29; r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            s[i] = poseidon_sbox7(s[i]);
-            if ((i & 1) == 1) POSEIDON_SCHED_FENCE();
+            for (int g = 0; g < 7; g++) {  // MDS of rounds 3g+3 .. 3g+5 and the s-boxes of rounds 3g+4, 3g+5; then round 3g+6's
+                poseidon_partial_group<3>(s, PC::ZKM_POSEIDON_FUSED_C1[g], PC::ZKM_POSEIDON_FUSED_C2[g], PC::ZKM_POSEIDON_FUSED_C3[g]);
+                s[0] = poseidon_sbox7(s[0]);
+            }
+            poseidon_partial_group<2>(s, PC::ZKM_POSEIDON_FUSED_C1[7], 0, PC::ZKM_POSEIDON_FUSED_C3[7]);  // MDS of rounds 24, 25
+        } else {
+            // full round r < 3 is round r, r > 3 is round 22 + r; the constants added are those of the NEXT round (none after the last)
+            const int next = (r < 3 ? r : 22 + r) + 1;
+            poseidon_mds_add<true>(s, next < 30 ? &PC::ZKM_POSEIDON_RC[next * 12] : PC::ZKM_POSEIDON_ZERO12);
         }
-        poseidon_mds_add<true>(s, &PC::ZKM_POSEIDON_RC[(r + 1) * 12]);
     }
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        s[i] = poseidon_sbox7(s[i]);
-        if ((i & 1) == 1) POSEIDON_SCHED_FENCE();
-    }
-    poseidon_mds(s);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
