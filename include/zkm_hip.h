@@ -384,6 +384,24 @@ int zkm_prove_segment(zkm_ctx* ctx, const zkm_stark_config* cfg, const uint64_t*
 int zkm_prove_openings(zkm_ctx* ctx, const zkm_stark_config* cfg, const zkm_batch* trace_batch, const zkm_batch* aux_batch,
                        const zkm_batch* quot_batch, size_t nctl_zs, zkm_challenger* challenger, uint64_t* proof_out, char** err);
 
+/* PolynomialBatch::prove_openings (plonky2 fri/oracle.rs) for an ARBITRARY FriInstanceInfo: `noracles` (<= 8) commitments of equal
+ * degree, `nbatches` FriBatchInfo { point, polynomials: (oracle_index, polynomial_index)... } in instance order.  Transcript as in
+ * plonky2: alpha <- challenger; per batch the alpha-reduced polynomial divided by (X - point), batches chained with
+ * ReducingFactor::shift_poly; commit phase with one cap + beta per reduction arity; final polynomial; proof of work; query rounds.
+ * (The openings themselves are the caller's: observe them before the call, as StarkOpeningSet / OpeningSet do.)  With the three
+ * STARK oracles and the three batches of stark.rs:91-148 the output equals the FRI part of zkm_prove_openings' blob.
+ * FRI proof blob: [0] magic "ZKMFRIPF" [1] degree_bits [2] noracles [3] cap_height [4] L fri layers [5] F final_poly_len
+ *   [6] num_queries [7] rate_bits [8] arity_bits [9..15] 0 [16..23] columns of each oracle
+ *   commit_phase_merkle_caps[L][C*4]  final_poly[2F]  pow_witness[1]
+ *   query_round_proofs[num_queries]: per oracle evals[cols] + siblings[(lde_bits - cap_height)*4]; per layer evals[2*2^arity_bits] +
+ *   siblings[(lde_bits - arity_bits*(i+1) - cap_height)*4] */
+#define ZKM_FRI_PROOF_MAGIC 0x46504952464d4b5aULL
+typedef struct { uint32_t oracle, poly; } zkm_fri_poly;
+typedef struct { uint64_t point[2]; const zkm_fri_poly* polys; size_t npolys; } zkm_fri_batch;
+size_t zkm_fri_proof_words(const zkm_stark_config* cfg, unsigned log_n, const size_t* oracle_cols, size_t noracles);
+int zkm_fri_prove(zkm_ctx* ctx, const zkm_stark_config* cfg, const zkm_batch* const* oracles, size_t noracles, const zkm_fri_batch* batches,
+                  size_t nbatches, zkm_challenger* challenger, uint64_t* proof_out, char** err);
+
 /* ------------------------------------------------------------------ stage entry points (parity / reuse)
  * a6: compute_quotient_polys (prover.rs:645-789): nalphas polys of 2n coefficients, natural order;
  * out host or device. */

@@ -152,6 +152,10 @@ extern "C" {
     pub fn zkm_prove_segment(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, traces: *const *const u64, log_n: *const c_uint,
                              public_values: *const u64, npublic: usize, proofs_out: *mut u64, proof_offsets_out: *mut usize,
                              ctl_challenges_out: *mut u64, err: *mut *mut c_char) -> c_int;
+    pub fn zkm_fri_proof_words(cfg: *const zkm_stark_config, log_n: c_uint, oracle_cols: *const usize, noracles: usize) -> usize;
+    pub fn zkm_fri_prove(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, oracles: *const *const zkm_batch, noracles: usize,
+                         batches: *const zkm_fri_batch, nbatches: usize, challenger: *mut zkm_challenger, proof_out: *mut u64,
+                         err: *mut *mut c_char) -> c_int;
     pub fn zkm_prove_openings(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, trace_batch: *const zkm_batch, aux_batch: *const zkm_batch,
                               quot_batch: *const zkm_batch, nctl_zs: usize, challenger: *mut zkm_challenger, proof_out: *mut u64,
                               err: *mut *mut c_char) -> c_int;

@@ -202,3 +202,54 @@ def test_no_device_memory_is_leaked(zkm, oracle):
     # the only growth between the first baseline and now is resident tables (twiddles / powers for the new sizes)
     assert base2 - base < 64 << 20
     c.close()
+
+
+def test_generic_fri_instance_equals_the_stark_instance(ctx, zkm, oracle):
+    """zkm_fri_prove takes the FriInstanceInfo as data (oracles + batches of (oracle, polynomial) at a point).  Fed the three oracles
+    and three batches of the STARK instance (stark.rs:91-148) and the transcript state prove_single_table has after observing the
+    openings, it must reproduce the FRI part of zkm_prove_openings' blob word for word; a second, different instance (two oracles,
+    one batch, other point) must at least be self-consistent with the oracle-checked STARK path on its shared pieces."""
+    import ctypes as C
+    log_n, (W, A, Q, Z) = 9, (13, 4, 4, 2)
+    rng = np.random.default_rng(91)
+    n = 1 << log_n
+    tv, av, qc = (rng.integers(0, P, k * n, dtype=np.uint64) for k in (W, A, Q))
+    tb, ab = zkm.PolynomialBatch.from_values(ctx, tv, W, log_n), zkm.PolynomialBatch.from_values(ctx, av, A, log_n)
+    qb = zkm.PolynomialBatch.from_coeffs(ctx, qc, Q, log_n)
+    ch1 = zkm.challenger_new()
+    zkm.challenger_observe(ch1, [7, 8, 9])
+    blob = ctx.prove_openings(tb, ab, qb, Z, challenger=ch1)
+    lay, q = zkm.proof_layout(blob)
+    # replay the transcript up to the point where prove_openings draws alpha: compact, zeta, observe_openings (proof.rs:336-367)
+    ch2 = zkm.challenger_new()
+    zkm.challenger_observe(ch2, [7, 8, 9])
+    st = np.zeros(12, dtype=np.uint64)
+    zkm.load().zkm_challenger_compact(C.byref(ch2), st.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert (st == blob[lay.init_challenger_state:lay.init_challenger_state + 12]).all()
+    zeta = (int(zkm.challenger_get(ch2)), int(zkm.challenger_get(ch2)))
+    g = oracle.root_of_unity(log_n)
+    zeta_next = (zeta[0] * g % P, zeta[1] * g % P)
+    sec = lambda off, words: blob[off:off + words]
+    for off, words in ((lay.local_values, 2 * W), (lay.aux_polys, 2 * A), (lay.quotient_polys_open, 2 * Q), (lay.next_values, 2 * W),
+                       (lay.aux_polys_next, 2 * A)):
+        zkm.challenger_observe(ch2, sec(off, words))
+    for i in range(Z):
+        zkm.challenger_observe(ch2, [int(blob[lay.ctl_zs_first + i]), 0])
+    polys0 = [(0, c) for c in range(W)] + [(1, c) for c in range(A)] + [(2, c) for c in range(Q)]
+    polys1 = [(0, c) for c in range(W)] + [(1, c) for c in range(A)]
+    polys2 = [(1, c) for c in range(A - Z, A)]
+    fri = ctx.fri_prove([tb, ab, qb], [(zeta, polys0), (zeta_next, polys1), ((1, 0), polys2)], ch2)
+    assert int(fri[0]) == int.from_bytes(b"ZKMFRIPF", "little") and [int(x) for x in fri[1:9]] == [log_n, 3, 4, int(lay.fri_layers),
+                                                                                              int(lay.final_poly_len), 37, 2, 4]
+    assert [int(x) for x in fri[16:19]] == [W, A, Q]
+    assert (fri[24:] == blob[lay.commit_phase_merkle_caps:]).all()       # caps, final polynomial, PoW witness, all 37 query rounds
+    assert list(ch2.state) == list(ch1.state) and ch2.n_in == ch1.n_in and ch2.n_out == ch1.n_out
+    # another instance: two oracles, one batch at another point -- accepted shapes and error paths
+    fri2 = ctx.fri_prove([ab, qb], [((5, 6), [(1, 3), (0, 0), (1, 0)])], zkm.challenger_new())
+    assert int(fri2[2]) == 2 and [int(x) for x in fri2[16:18]] == [A, Q]
+    with pytest.raises(zkm.ZkmError):
+        ctx.fri_prove([ab, qb], [((5, 6), [(2, 0)])], zkm.challenger_new())          # oracle index out of range
+    with pytest.raises(zkm.ZkmError):
+        ctx.fri_prove([ab, qb], [((P, 0), [(0, 0)])], zkm.challenger_new())          # non-canonical point
+    for b in (tb, ab, qb):
+        b.free()

@@ -36,7 +36,7 @@ EXPORTS = [
     "zkm_sha_compress_trace", "zkm_sha_compress_sponge_trace",
     "zkm_table_width", "zkm_num_lookup_columns", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
-    "zkm_prove_single_table", "zkm_prove_openings", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
+    "zkm_prove_single_table", "zkm_prove_openings", "zkm_fri_prove", "zkm_fri_proof_words", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
     "zkm_proof_get_layout", "zkm_proof_get_query_layout", "zkm_segment_image_words", "zkm_segment_image_write", "zkm_prove_segment_image",
     "zkm_quotient", "zkm_eval_openings", "zkm_profile_enable", "zkm_profile_reset",
     "zkm_profile_count", "zkm_profile_get", "zkm_version",
@@ -149,6 +149,8 @@ def load():
         "zkm_proof_words": (C.c_size_t, [C.POINTER(StarkConfig), C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t]),
         "zkm_prove_single_table": (C.c_int, [cp, C.c_int, C.POINTER(StarkConfig), cp, C.c_size_t, C.c_uint, cp, cp, C.c_size_t,
                                              C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Challenger), u64p, err]),
+        "zkm_fri_proof_words": (C.c_size_t, [C.POINTER(StarkConfig), C.c_uint, C.POINTER(C.c_size_t), C.c_size_t]),
+        "zkm_fri_prove": (C.c_int, [cp, C.POINTER(StarkConfig), cpp, C.c_size_t, cp, C.c_size_t, C.POINTER(Challenger), u64p, err]),
         "zkm_prove_openings": (C.c_int, [cp, C.POINTER(StarkConfig), cp, cp, cp, C.c_size_t, C.POINTER(Challenger), u64p, err]),
         "zkm_prove_single_table_ctl": (C.c_int, [cp, C.c_int, C.POINTER(StarkConfig), cp, C.c_size_t, C.c_uint, cp, cp, C.c_size_t,
                                                  cp, cp, cp, C.c_size_t, u64p, C.POINTER(Challenger), u64p, err]),
@@ -559,6 +561,29 @@ class Context:
         _check(self.L.zkm_prove_segment_image(self.h, C.byref(cfg), image.ctypes.data_as(u64p), image.size, proofs.ctypes.data_as(u64p),
                                               C.byref(total), offs, chal.ctypes.data_as(u64p), C.byref(err)), err)
         return proofs, chal, list(offs)
+
+    def fri_prove(self, oracles, batches, challenger, cfg=None):
+        """PolynomialBatch::prove_openings for an arbitrary FriInstanceInfo: oracles = list of PolynomialBatch, batches = list of
+        ((point_c0, point_c1), [(oracle_index, polynomial_index), ...]).  Returns the FRI proof blob (layout in zkm_hip.h)."""
+        cfg = cfg or self.standard_config()
+        orc = (C.c_void_p * len(oracles))(*[o.h.value for o in oracles])
+        cols = (C.c_size_t * len(oracles))(*[o.ncols for o in oracles])
+        words = self.L.zkm_fri_proof_words(C.byref(cfg), oracles[0].log_n, cols, len(oracles))
+        if not words:
+            raise ZkmError("zkm_fri_proof_words: unsupported configuration")
+
+        class FriBatch(C.Structure):
+            _fields_ = [("point", C.c_uint64 * 2), ("polys", C.c_void_p), ("npolys", C.c_size_t)]
+        keep, arr = [], (FriBatch * len(batches))()
+        for i, (pt, polys) in enumerate(batches):
+            a = np.array(polys, dtype=np.uint32).reshape(-1, 2)
+            keep.append(a)
+            arr[i] = FriBatch((C.c_uint64 * 2)(int(pt[0]), int(pt[1])), a.ctypes.data, len(a))
+        out = np.zeros(words, dtype=np.uint64)
+        err = C.c_char_p()
+        _check(self.L.zkm_fri_prove(self.h, C.byref(cfg), C.cast(orc, C.POINTER(C.c_void_p)), len(oracles), C.cast(arr, C.c_void_p), len(batches),
+                                    C.byref(challenger), out.ctypes.data_as(u64p), C.byref(err)), err)
+        return out
 
     def prove_openings(self, trace_batch, aux_batch, quot_batch, nctl_zs, challenger=None, cfg=None):
         """PolynomialBatch::prove_openings for the STARK FRI instance on three existing commitments (BASELINE config 4)."""

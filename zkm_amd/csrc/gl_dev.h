@@ -111,6 +111,20 @@ GL_HD void gl_mul_wide(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
 #endif
 }
 
+// loose * 2^K -> loose for the small roots of unity of this field: w_8 = 2^24, w_4 = 2^48 (and w_16 = 2^12, w_32 = 2^6, w_64 = 2^3),
+// i.e. the twiddles of the last transform stages are shifts: x * 2^K = (x << K) reduced, one multiply-add (K < 32) or the plain
+// 128-bit reduction (K < 64) instead of the four multiply-adds of a general product, and no twiddle register.
+template <int K>
+GL_HD uint64_t gl_mul_pow2(uint64_t x) {
+    static_assert(K > 0 && K < 96, "gl_mul_pow2: 0 < K < 96");
+    if constexpr (K < 64) {
+        // x * 2^K = lo + 2^64 hi with hi = x >> (64 - K); for K < 32 the high word h1 of hi is zero and the compiler drops its terms
+        return gl_reduce128(x << K, x >> (64 - K));
+    } else {
+        return gl_mul_pow2<K - 48>(gl_mul_pow2<48>(x));
+    }
+}
+
 // loose * loose -> loose
 GL_HD uint64_t gl_mul_loose(uint64_t a, uint64_t b) {
     uint64_t lo, hi;

@@ -87,6 +87,7 @@ struct ntt_pass_args {
     uint32_t in_contig_a, out_contig_a, rev_rows, m;
     uint32_t zero_padded;  // first pass of a x4 zero-padded transform: rows >= 2^S / 4 of every tile are zero
     uint32_t canon_out;  // last pass of a transform: outputs must be canonical (intermediate passes may store loose words)
+    uint32_t pow2_last;  // last pass (m == 0) with S % 3 == 0: the last round's twiddles are powers of two (1 forward, 2 inverse roots)
     const gl_t* tw;
     const gl_t* pre_tab;
     uint32_t pre_log;
@@ -152,6 +153,51 @@ struct ntt_round {
         bfly(x[4], x[5], w[6]); bfly(x[6], x[7], w[6]);
         __builtin_amdgcn_sched_barrier(0);
     }
+    // The LAST round of the LAST pass (q == 0, m == 0): its twiddles are the 8th / 4th roots of unity w_8^j = 2^(24 j), w_4 = 2^48 (and
+    // 1 for the final stage), so 7 of the 12 butterflies need no product at all and the other 5 a shift (gl_mul_pow2).  Inverse
+    // roots are the negated powers w_8^-j = -2^(96 - 24 j): the sign goes into the subtraction (v - u instead of u - v, with u
+    // the canonicalised operand).  Same field elements as compute() with the table twiddles, hence bit-exact.
+    template <int E, bool NEG>
+    __device__ static __forceinline__ void bfly_pow2(gl_t& u, gl_t& v) {
+        if (!NEG) {
+            const gl_t vc = gl_canon(v);
+            const uint64_t t = gl_add_lc(u, vc), d = gl_sub_lc(u, vc);
+            v = E ? gl_mul_pow2<(E ? E : 1)>(d) : d;
+            u = t;
+        } else {
+            const gl_t uc = gl_canon(u);
+            const uint64_t t = gl_add_lc(v, uc), d = gl_sub_lc(v, uc);   // v - u
+            v = gl_mul_pow2<(E ? E : 1)>(d);
+            u = t;
+        }
+    }
+    template <bool INV>
+    __device__ static __forceinline__ void compute_pow2(gl_t (&x)[8]) {
+        static_assert(q == 0 && top == 2, "compute_pow2: the three lowest stages");
+        if (!INV) {
+            bfly_pow2<0, false>(x[0], x[4]); bfly_pow2<24, false>(x[1], x[5]);
+            __builtin_amdgcn_sched_barrier(0);
+            bfly_pow2<48, false>(x[2], x[6]); bfly_pow2<72, false>(x[3], x[7]);
+            __builtin_amdgcn_sched_barrier(0);
+            bfly_pow2<0, false>(x[0], x[2]); bfly_pow2<48, false>(x[1], x[3]);
+            __builtin_amdgcn_sched_barrier(0);
+            bfly_pow2<0, false>(x[4], x[6]); bfly_pow2<48, false>(x[5], x[7]);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            bfly_pow2<0, false>(x[0], x[4]); bfly_pow2<72, true>(x[1], x[5]);     // w_8^-1 = -2^72
+            __builtin_amdgcn_sched_barrier(0);
+            bfly_pow2<48, true>(x[2], x[6]); bfly_pow2<24, true>(x[3], x[7]);     // w_8^-2 = -2^48, w_8^-3 = -2^24
+            __builtin_amdgcn_sched_barrier(0);
+            bfly_pow2<0, false>(x[0], x[2]); bfly_pow2<48, true>(x[1], x[3]);     // w_4^-1 = -2^48
+            __builtin_amdgcn_sched_barrier(0);
+            bfly_pow2<0, false>(x[4], x[6]); bfly_pow2<48, true>(x[5], x[7]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bfly_pow2<0, false>(x[0], x[1]); bfly_pow2<0, false>(x[2], x[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        bfly_pow2<0, false>(x[4], x[5]); bfly_pow2<0, false>(x[6], x[7]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // First round of a x4 zero-padded transform (coset LDE): only x[0], x[1] are non-zero, so the first two stages are
     // plain twiddle multiplications -- bfly(u, 0) = (u, u w) -- 6 products instead of 8 butterflies.
     __device__ static __forceinline__ void compute_zero_padded(gl_t (&x)[8], const gl_t (&w)[7]) {
@@ -175,6 +221,17 @@ struct ntt_round {
         for (int j = 0; j < 8; j++) lds[row(rg, j) * tp + b] = x[j];
     }
 };
+
+// the last round of a pass: with the shift twiddles where the pass allows them (pow2_last != 0 implies m == 0)
+template <int S, int K>
+__device__ __forceinline__ void ntt_last_round(gl_t (&x)[8], const gl_t (&w)[7], uint32_t pow2_last) {
+    using R = ntt_round<S, K>;
+    if constexpr (S % 3 == 0 && K == (S + 2) / 3 - 1) {
+        if (pow2_last == 1) { R::template compute_pow2<false>(x); return; }
+        if (pow2_last == 2) { R::template compute_pow2<true>(x); return; }
+    }
+    R::compute(x, w);
+}
 
 // IN_A / OUT_A: the butterfly (row) dimension is the contiguous one in HBM on the input / output side.
 // When it is not, the thread's 8 register-resident rows of the first (last) round are exactly what it
@@ -303,18 +360,21 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
         if (PF && col + 1 < col1) fetch(col + 1);
         __builtin_amdgcn_sched_barrier(0);
         if (!IN_A && S >= 3 && p.zero_padded) R0::compute_zero_padded(x, w0);
+        else if (NR == 1) ntt_last_round<S, 0>(x, w0, p.pow2_last);
         else R0::compute(x, w0);
         if (NR > 1) {
             R0::lds_write(lds, tp, b, rg, x);
             __syncthreads();
             R1::lds_read(lds, tp, b, rg, x);
-            R1::compute(x, w1);
+            if (NR == 2) ntt_last_round<S, (NR > 1 ? 1 : 0)>(x, w1, p.pow2_last);
+            else R1::compute(x, w1);
         }
         if (NR > 2) {
             R1::lds_write(lds, tp, b, rg, x);
             __syncthreads();
             R2::lds_read(lds, tp, b, rg, x);
-            R2::compute(x, w2);
+            if (NR == 3) ntt_last_round<S, (NR > 2 ? 2 : 0)>(x, w2, p.pow2_last);
+            else R2::compute(x, w2);
         }
         if (!OUT_A) {
             if (do_post) {
@@ -368,6 +428,16 @@ static ntt_plan make_plan(unsigned L) {
     // the larger radices go to the LAST passes: a strided pass of 2^S rows only has 4096 / 2^S contiguous columns per row, and
     // 128 B row segments (S = 8) reach about half the HBM rate of 256 B ones (S = 7); the last pass is contiguous along rows
     for (int i = 0; i < pl.np; i++) pl.S[i] = base + (i >= pl.np - extra ? 1 : 0);
+    // A last pass of exactly 6 stages ends on a full three-stage round whose twiddles are powers of two (compute_pow2): take it
+    // whenever the other passes can absorb the remaining stages (3..8 each).
+    if (pl.np >= 2) {
+        int rest = (int)L - 6, k = pl.np - 1;
+        if (rest >= 3 * k && rest <= 8 * k) {
+            int b2 = rest / k, e2 = rest % k;
+            for (int i = 0; i < k; i++) pl.S[i] = b2 + (i >= k - e2 ? 1 : 0);
+            pl.S[k] = 6;
+        }
+    }
     return pl;
 }
 
@@ -482,6 +552,7 @@ static void ntt_dif_bitrev_fast(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* 
             ntiles = a.n_lo;
         }
         a.canon_out = m == 0;
+        a.pow2_last = m == 0 ? (inverse ? 2u : 1u) : 0u;
         launch_pass(c, S, a, ntiles, m > 0 ? "ntt_pass_strided" : "ntt_pass_contig");
     }
 }
@@ -537,6 +608,7 @@ static void ntt_natural_fast(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* scr
             ntiles = Nmid * a.n_lo;
         }
         a.canon_out = last;
+        a.pow2_last = last ? (inverse ? 2u : 1u) : 0u;
         launch_pass(c, S, a, ntiles, last ? "ntt_pass_transpose" : "ntt_pass_strided");
     }
 }
@@ -586,12 +658,11 @@ __global__ __launch_bounds__((1 << SA) * 8) void k_ntt_big(ntt_big_args p) {
     const int a2 = tid & (RA - 1);                          // phase 2: row a2 of the phase-1 output ...
     const int rg2 = UNI ? __builtin_amdgcn_readfirstlane(tid >> SA) : (tid >> SA);  // ... group rg2 of its 64 elements
 
-    gl_t wa0[7], wa1[7], wa2[7], wb0[7], wb1[7];
+    gl_t wa0[7], wa1[7], wa2[7], wb0[7];
     A0::load_tw(wa0, p.tw, rg, 6, (size_t)b);
     if (NR1 > 1) A1::load_tw(wa1, p.tw, rg, 6, (size_t)b);
     if (NR1 > 2) A2::load_tw(wa2, p.tw, rg, 6, (size_t)b);
-    B0::load_tw(wb0, p.tw, rg2, 0, 0);
-    B1::load_tw(wb1, p.tw, rg2, 0, 0);
+    B0::load_tw(wb0, p.tw, rg2, 0, 0);   // (the last round's twiddles are powers of two: B1::compute_pow2)
 
     const uint32_t total = p.ncols * p.blocks_per_col;
     auto block_ptr = [&](uint32_t blk) { return p.data + (size_t)(blk / p.blocks_per_col) * p.cs + ((size_t)(blk % p.blocks_per_col) << (SA + 6)); };
@@ -639,7 +710,7 @@ __global__ __launch_bounds__((1 << SA) * 8) void k_ntt_big(ntt_big_args p) {
         B0::lds_write(lds, 1, LP, a2, rg2, x);
         __syncthreads();
         B1::lds_read(lds, 1, LP, a2, rg2, x);
-        B1::compute(x, wb1);
+        B1::template compute_pow2<false>(x);
         __syncthreads();
         B1::lds_write(lds, 1, LP, a2, rg2, x);
         __syncthreads();

@@ -628,16 +628,18 @@ __global__ __launch_bounds__(256) void k_pow_search(pow_state st, unsigned pos, 
 // ------------------------------------------------------------------ query gather
 struct gather_oracle { const gl_t* lde; const gl_t* digests; uint32_t ncols, nsib; uint64_t N; uint64_t level_off[32]; };
 struct gather_layer { const gl_t *c0, *c1, *digests; uint32_t nsib; uint64_t level_off[32]; };
-struct gather_args {
-    gather_oracle o[3];
+#define ZKM_FRI_MAX_ORACLES 8
+struct gather_args {  // (lives in device memory: larger than the kernel-argument segment)
+    gather_oracle o[ZKM_FRI_MAX_ORACLES];
     gather_layer l[8];
-    uint32_t nlayers, arity_bits;
+    uint32_t noracles, nlayers, arity_bits, _pad;
     uint64_t query_words;
 };
-__global__ void k_gather_queries(gather_args g, const uint64_t* __restrict__ xs, gl_t* __restrict__ out) {
+__global__ void k_gather_queries(const gather_args* __restrict__ gp, const uint64_t* __restrict__ xs, gl_t* __restrict__ out) {
+    const gather_args& g = *gp;
     uint64_t x = xs[blockIdx.x];
     gl_t* o = out + (size_t)blockIdx.x * g.query_words;
-    for (int k = 0; k < 3; k++) {
+    for (uint32_t k = 0; k < g.noracles; k++) {
         const gather_oracle& r = g.o[k];
         for (uint32_t c = threadIdx.x; c < r.ncols; c += blockDim.x) o[c] = r.lde[(size_t)c * r.N + x];
         o += r.ncols;
@@ -674,6 +676,159 @@ struct fri_layer {
     size_t len = 0;
     unsigned log_leaves = 0;
 };
+
+// ------------------------------------------------------------------ FRI: everything after the alpha-combination
+// One composite polynomial per FriBatchInfo (coefficients, F2 as two arrays), its opening point and the factor alpha^(#polys of
+// the batch) of ReducingFactor::shift_poly.  fri_finish divides each by (X - point), accumulates the final
+// polynomial, runs the commit phase (LDE, Merkle tree, cap -> transcript, beta, fold), the proof of work and the query rounds over
+// `noracles` initial oracles.  Shared by prove_single_table (the STARK instance of stark.rs:91-148) and zkm_fri_prove (any instance).
+struct fri_composite {
+    const gl_t *c0, *c1;
+    gl2_t point, shift;
+};
+
+static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, const std::vector<fri_composite>& comps,
+                       const zkm_batch* const* orc, size_t noracles, zkm_challenger* ch, unsigned L, size_t F, size_t nq, size_t query_words,
+                       uint64_t* caps_out, uint64_t* final_out, uint64_t* pow_out, uint64_t* queries_out) {
+    if (noracles == 0 || noracles > ZKM_FRI_MAX_ORACLES) throw std::runtime_error("FRI: 1..8 initial oracles");
+    if (L > 8) throw std::runtime_error("too many FRI layers");
+    const size_t n = (size_t)1 << log_n, C4 = (size_t)4 << cfg->cap_height;
+    const unsigned lde_bits = log_n + cfg->rate_bits;
+    const size_t N = (size_t)1 << lde_bits;
+    std::vector<fri_layer> layers(L);
+    std::vector<void*> scratch;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        for (auto& l : layers) { c->release(l.values); c->release(l.digests); }
+        for (void* p : scratch) c->release(p);
+    };
+    try {
+        gl_t* d_fin = (gl_t*)c->alloc(2 * n * sizeof(gl_t));  // final poly coefficients [2][n]
+        scratch.push_back(d_fin);
+        ZKM_HIP_CHECK(hipMemsetAsync(d_fin, 0, 2 * n * sizeof(gl_t), c->stream));
+        for (const fri_composite& k : comps) divide_accumulate(c, k.c0, k.c1, n, k.point, k.shift, d_fin, d_fin + n);
+
+        // commit phase: coefficients stay in d_fin (length clen, implicitly zero-padded x4)
+        size_t clen = n;
+        unsigned clog = log_n;
+        gl_t shift = GL_GENERATOR;
+        unsigned arity = 1u << cfg->arity_bits;
+        gl_t* d_coef0 = d_fin;      // c0 array (clen)
+        gl_t* d_coef1 = d_fin + n;  // c1 array
+        for (unsigned l = 0; l < L; l++) {
+            fri_layer& fl = layers[l];
+            fl.len = clen << cfg->rate_bits;
+            fl.values = (gl_t*)c->alloc(2 * fl.len * sizeof(gl_t));
+            // values = coset_fft(shift) of the zero-padded coefficients, bit-reversed: two base-field columns
+            // (the two coefficient arrays are contiguous: [c0 | c1], column stride clen)
+            if (d_coef1 != d_coef0 + clen) throw std::runtime_error("internal: FRI coefficient arrays not contiguous");
+            zkm_lde_bitrev(c, d_coef0, fl.values, 2, clog, cfg->rate_bits, shift);
+            fl.log_leaves = clog + cfg->rate_bits - cfg->arity_bits;
+            size_t dwords = zkm_merkle_layout(fl.log_leaves, cfg->cap_height, fl.level_off);
+            fl.digests = (gl_t*)c->alloc(dwords * sizeof(gl_t));
+            zkm_launch_merkle_leaves_ext(c, fl.values, fl.values + fl.len, (size_t)1 << fl.log_leaves, arity, fl.digests);
+            zkm_merkle_build_inner(c, fl.digests, fl.level_off, fl.log_leaves, cfg->cap_height);
+            uint64_t* capo = caps_out + l * C4;
+            ZKM_HIP_CHECK(hipMemcpyAsync(capo, fl.digests + fl.level_off[fl.log_leaves - cfg->cap_height], C4 * 8, hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+            zkm_challenger_observe(ch, capo, C4);
+            gl2_t beta = challenger_get_ext(ch);
+            size_t nout = clen >> cfg->arity_bits;
+            gl_t* d_new = (gl_t*)c->alloc(2 * nout * sizeof(gl_t));
+            scratch.push_back(d_new);
+            {
+                zkm_prof_scope ps(c, "fri_fold");
+                hipLaunchKernelGGL(k_fri_fold, dim3((nout + 255) / 256), dim3(256), 0, c->stream, d_coef0, d_coef1, nout, arity, beta, d_new, d_new + nout);
+                ZKM_HIP_CHECK(hipGetLastError());
+            }
+            d_coef0 = d_new;
+            d_coef1 = d_new + nout;
+            clen = nout;
+            clog -= cfg->arity_bits;
+            shift = gl_pow(shift, arity);
+        }
+        if (clen != F) throw std::runtime_error("internal: final polynomial length mismatch");
+        {
+            std::vector<gl_t> f(2 * clen);
+            ZKM_HIP_CHECK(hipMemcpyAsync(f.data(), d_coef0, clen * 8, hipMemcpyDeviceToHost, c->stream));
+            ZKM_HIP_CHECK(hipMemcpyAsync(f.data() + clen, d_coef1, clen * 8, hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+            uint64_t* fp = final_out;
+            for (size_t i = 0; i < clen; i++) { fp[2 * i] = f[i]; fp[2 * i + 1] = f[clen + i]; }
+            zkm_challenger_observe(ch, fp, 2 * clen);
+        }
+
+        // proof of work (App. A.9), smallest witness
+        {
+            pow_state st;
+            memcpy(st.s, ch->state, sizeof st.s);
+            for (uint32_t i = 0; i < ch->n_in; i++) st.s[i] = ch->in_buf[i];
+            unsigned long long* d_best = (unsigned long long*)c->alloc(8);
+            scratch.push_back(d_best);
+            unsigned long long best = ~0ULL;
+            // candidates per launch: 4 x the expected number of trials (a hit in the first launch with probability 1 - e^-4), then 2^20
+            const unsigned first_bits = cfg->pow_bits + 2 < 8 ? 8 : (cfg->pow_bits + 2 > 20 ? 20 : cfg->pow_bits + 2);
+            uint64_t span = (uint64_t)1 << first_bits;
+            for (uint64_t base = 0; best == ~0ULL; base += span, span = (uint64_t)1 << 20) {
+                if (base > ((uint64_t)1 << 40)) throw std::runtime_error("Proof of work failed. This is highly unlikely!");
+                ZKM_HIP_CHECK(hipMemsetAsync(d_best, 0xff, 8, c->stream));
+                {
+                    zkm_prof_scope ps(c, "fri_pow_search");
+                    hipLaunchKernelGGL(k_pow_search, dim3(span / 256), dim3(256), 0, c->stream, st, ch->n_in, cfg->pow_bits, base, d_best);
+                    ZKM_HIP_CHECK(hipGetLastError());
+                }
+                ZKM_HIP_CHECK(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c->stream));
+                c->sync();
+            }
+            uint64_t w = best;
+            *pow_out = w;
+            zkm_challenger_observe(ch, &w, 1);
+            uint64_t resp = zkm_challenger_get(ch);
+            if ((resp >> (64 - cfg->pow_bits)) != 0) throw std::runtime_error("internal: proof-of-work response check failed");
+        }
+
+        // query rounds
+        {
+            std::vector<uint64_t> xs(nq);
+            for (size_t q = 0; q < nq; q++) xs[q] = zkm_challenger_get(ch) % N;
+            uint64_t* d_xs = (uint64_t*)c->alloc(nq * 8);
+            scratch.push_back(d_xs);
+            ZKM_HIP_CHECK(hipMemcpyAsync(d_xs, xs.data(), nq * 8, hipMemcpyHostToDevice, c->stream));
+            std::vector<gather_args> gav(1);
+            gather_args& ga = gav[0];
+            memset(&ga, 0, sizeof ga);
+            ga.noracles = (uint32_t)noracles;
+                    for (size_t k = 0; k < noracles; k++) {
+                ga.o[k].lde = orc[k]->lde; ga.o[k].digests = orc[k]->digests; ga.o[k].ncols = (uint32_t)orc[k]->ncols;
+                ga.o[k].nsib = lde_bits - cfg->cap_height; ga.o[k].N = N;
+                for (size_t i = 0; i < orc[k]->level_off.size() && i < 32; i++) ga.o[k].level_off[i] = orc[k]->level_off[i];
+            }
+            for (unsigned l = 0; l < L; l++) {
+                ga.l[l].c0 = layers[l].values; ga.l[l].c1 = layers[l].values + layers[l].len; ga.l[l].digests = layers[l].digests;
+                ga.l[l].nsib = layers[l].log_leaves - cfg->cap_height;
+                for (size_t i = 0; i < layers[l].level_off.size() && i < 32; i++) ga.l[l].level_off[i] = layers[l].level_off[i];
+            }
+            ga.nlayers = L; ga.arity_bits = cfg->arity_bits; ga.query_words = query_words;
+            gather_args* d_ga = (gather_args*)c->alloc(sizeof(gather_args));
+            scratch.push_back(d_ga);
+            ZKM_HIP_CHECK(hipMemcpyAsync(d_ga, &ga, sizeof ga, hipMemcpyHostToDevice, c->stream));
+            gl_t* d_q = (gl_t*)c->alloc(nq * query_words * 8);
+            scratch.push_back(d_q);
+            {
+                zkm_prof_scope ps(c, "fri_gather_queries");
+                hipLaunchKernelGGL(k_gather_queries, dim3(nq), dim3(256), 0, c->stream, d_ga, d_xs, d_q);
+                ZKM_HIP_CHECK(hipGetLastError());
+            }
+            ZKM_HIP_CHECK(hipMemcpyAsync(queries_out, d_q, nq * query_words * 8, hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+        }
+
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+    cleanup();
+}
 
 static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
                                const zkm_batch* trace_batch, const uint64_t* aux, size_t A_ctl, const zkm_ctl_table* ctl_table,
@@ -837,122 +992,14 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
                                total_helpers, d_apow, n, d_comp);
             ZKM_HIP_CHECK(hipGetLastError());
         }
-        gl_t* d_fin = (gl_t*)c->alloc(2 * n * sizeof(gl_t));  // final poly coefficients [2][n]
-        scratch.push_back(d_fin);
-        ZKM_HIP_CHECK(hipMemsetAsync(d_fin, 0, 2 * n * sizeof(gl_t), c->stream));
-        auto apow_at = [&](size_t j) { return gl2_t{apow[2 * j], apow[2 * j + 1]}; };
-        divide_accumulate(c, d_comp, d_comp + n, n, zeta, apow_at(np0), d_fin, d_fin + n);
-        divide_accumulate(c, d_comp + 2 * n, d_comp + 3 * n, n, zeta_next, apow_at(np1), d_fin, d_fin + n);
-        divide_accumulate(c, d_comp + 4 * n, d_comp + 5 * n, n, gl2_t{1, 0}, apow_at(np2), d_fin, d_fin + n);
-
-        // commit phase: coefficients stay in d_fin (length clen, implicitly zero-padded x4)
-        size_t clen = n;
-        unsigned clog = log_n;
-        gl_t shift = GL_GENERATOR;
-        unsigned arity = 1u << cfg->arity_bits;
-        gl_t* d_coef0 = d_fin;      // c0 array (clen)
-        gl_t* d_coef1 = d_fin + n;  // c1 array
-        for (unsigned l = 0; l < y.L; l++) {
-            fri_layer& fl = layers[l];
-            fl.len = clen << cfg->rate_bits;
-            fl.values = (gl_t*)c->alloc(2 * fl.len * sizeof(gl_t));
-            // values = coset_fft(shift) of the zero-padded coefficients, bit-reversed: two base-field columns
-            // (the two coefficient arrays are contiguous: [c0 | c1], column stride clen)
-            if (d_coef1 != d_coef0 + clen) throw std::runtime_error("internal: FRI coefficient arrays not contiguous");
-            zkm_lde_bitrev(c, d_coef0, fl.values, 2, clog, cfg->rate_bits, shift);
-            fl.log_leaves = clog + cfg->rate_bits - cfg->arity_bits;
-            size_t dwords = zkm_merkle_layout(fl.log_leaves, cfg->cap_height, fl.level_off);
-            fl.digests = (gl_t*)c->alloc(dwords * sizeof(gl_t));
-            zkm_launch_merkle_leaves_ext(c, fl.values, fl.values + fl.len, (size_t)1 << fl.log_leaves, arity, fl.digests);
-            zkm_merkle_build_inner(c, fl.digests, fl.level_off, fl.log_leaves, cfg->cap_height);
-            uint64_t* capo = proof + y.o_fri_caps + l * y.C * 4;
-            ZKM_HIP_CHECK(hipMemcpyAsync(capo, fl.digests + fl.level_off[fl.log_leaves - cfg->cap_height], y.C * 4 * 8, hipMemcpyDeviceToHost, c->stream));
-            c->sync();
-            zkm_challenger_observe(ch, capo, y.C * 4);
-            gl2_t beta = challenger_get_ext(ch);
-            size_t nout = clen >> cfg->arity_bits;
-            gl_t* d_new = (gl_t*)c->alloc(2 * nout * sizeof(gl_t));
-            scratch.push_back(d_new);
-            {
-                zkm_prof_scope ps(c, "fri_fold");
-                hipLaunchKernelGGL(k_fri_fold, dim3((nout + 255) / 256), dim3(256), 0, c->stream, d_coef0, d_coef1, nout, arity, beta, d_new, d_new + nout);
-                ZKM_HIP_CHECK(hipGetLastError());
-            }
-            d_coef0 = d_new;
-            d_coef1 = d_new + nout;
-            clen = nout;
-            clog -= cfg->arity_bits;
-            shift = gl_pow(shift, arity);
-        }
-        if (clen != y.F) throw std::runtime_error("internal: final polynomial length mismatch");
+        // divide by (X - point), accumulate, commit phase, proof of work, query rounds: shared with zkm_fri_prove
         {
-            std::vector<gl_t> f(2 * clen);
-            ZKM_HIP_CHECK(hipMemcpyAsync(f.data(), d_coef0, clen * 8, hipMemcpyDeviceToHost, c->stream));
-            ZKM_HIP_CHECK(hipMemcpyAsync(f.data() + clen, d_coef1, clen * 8, hipMemcpyDeviceToHost, c->stream));
-            c->sync();
-            uint64_t* fp = proof + y.o_final;
-            for (size_t i = 0; i < clen; i++) { fp[2 * i] = f[i]; fp[2 * i + 1] = f[clen + i]; }
-            zkm_challenger_observe(ch, fp, 2 * clen);
-        }
-
-        // proof of work (App. A.9), smallest witness
-        {
-            pow_state st;
-            memcpy(st.s, ch->state, sizeof st.s);
-            for (uint32_t i = 0; i < ch->n_in; i++) st.s[i] = ch->in_buf[i];
-            unsigned long long* d_best = (unsigned long long*)c->alloc(8);
-            scratch.push_back(d_best);
-            unsigned long long best = ~0ULL;
-            // candidates per launch: 4 x the expected number of trials (a hit in the first launch with probability 1 - e^-4), then 2^20
-            const unsigned first_bits = cfg->pow_bits + 2 < 8 ? 8 : (cfg->pow_bits + 2 > 20 ? 20 : cfg->pow_bits + 2);
-            uint64_t span = (uint64_t)1 << first_bits;
-            for (uint64_t base = 0; best == ~0ULL; base += span, span = (uint64_t)1 << 20) {
-                if (base > ((uint64_t)1 << 40)) throw std::runtime_error("Proof of work failed. This is highly unlikely!");
-                ZKM_HIP_CHECK(hipMemsetAsync(d_best, 0xff, 8, c->stream));
-                {
-                    zkm_prof_scope ps(c, "fri_pow_search");
-                    hipLaunchKernelGGL(k_pow_search, dim3(span / 256), dim3(256), 0, c->stream, st, ch->n_in, cfg->pow_bits, base, d_best);
-                    ZKM_HIP_CHECK(hipGetLastError());
-                }
-                ZKM_HIP_CHECK(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c->stream));
-                c->sync();
-            }
-            uint64_t w = best;
-            proof[y.o_pow] = w;
-            zkm_challenger_observe(ch, &w, 1);
-            uint64_t resp = zkm_challenger_get(ch);
-            if ((resp >> (64 - cfg->pow_bits)) != 0) throw std::runtime_error("internal: proof-of-work response check failed");
-        }
-
-        // query rounds
-        {
-            std::vector<uint64_t> xs(y.nq);
-            for (size_t q = 0; q < y.nq; q++) xs[q] = zkm_challenger_get(ch) % N;
-            uint64_t* d_xs = (uint64_t*)c->alloc(y.nq * 8);
-            scratch.push_back(d_xs);
-            ZKM_HIP_CHECK(hipMemcpyAsync(d_xs, xs.data(), y.nq * 8, hipMemcpyHostToDevice, c->stream));
-            gather_args ga{};
+            std::vector<fri_composite> comps = {{d_comp, d_comp + n, zeta, gl2_t{apow[2 * np0], apow[2 * np0 + 1]}},
+                                                {d_comp + 2 * n, d_comp + 3 * n, zeta_next, gl2_t{apow[2 * np1], apow[2 * np1 + 1]}},
+                                                {d_comp + 4 * n, d_comp + 5 * n, gl2_t{1, 0}, gl2_t{apow[2 * np2], apow[2 * np2 + 1]}}};
             const zkm_batch* orc[3] = {tb, abp, qbp};
-            for (int k = 0; k < 3; k++) {
-                ga.o[k].lde = orc[k]->lde; ga.o[k].digests = orc[k]->digests; ga.o[k].ncols = (uint32_t)orc[k]->ncols;
-                ga.o[k].nsib = y.lde_bits - y.cap; ga.o[k].N = N;
-                for (size_t i = 0; i < orc[k]->level_off.size() && i < 32; i++) ga.o[k].level_off[i] = orc[k]->level_off[i];
-            }
-            for (unsigned l = 0; l < y.L; l++) {
-                ga.l[l].c0 = layers[l].values; ga.l[l].c1 = layers[l].values + layers[l].len; ga.l[l].digests = layers[l].digests;
-                ga.l[l].nsib = layers[l].log_leaves - y.cap;
-                for (size_t i = 0; i < layers[l].level_off.size() && i < 32; i++) ga.l[l].level_off[i] = layers[l].level_off[i];
-            }
-            ga.nlayers = y.L; ga.arity_bits = cfg->arity_bits; ga.query_words = y.query_words;
-            gl_t* d_q = (gl_t*)c->alloc(y.nq * y.query_words * 8);
-            scratch.push_back(d_q);
-            {
-                zkm_prof_scope ps(c, "fri_gather_queries");
-                hipLaunchKernelGGL(k_gather_queries, dim3(y.nq), dim3(256), 0, c->stream, ga, d_xs, d_q);
-                ZKM_HIP_CHECK(hipGetLastError());
-            }
-            ZKM_HIP_CHECK(hipMemcpyAsync(proof + y.o_queries, d_q, y.nq * y.query_words * 8, hipMemcpyDeviceToHost, c->stream));
-            c->sync();
+            fri_finish(c, cfg, log_n, comps, orc, 3, ch, y.L, y.F, y.nq, y.query_words, proof + y.o_fri_caps, proof + y.o_final, proof + y.o_pow,
+                       proof + y.o_queries);
         }
     } catch (...) {
         cleanup();
@@ -969,6 +1016,132 @@ static int fail(char** err, const std::string& msg) {
     }
     return 1;
 }
+
+// ---- PolynomialBatch::prove_openings for an arbitrary FriInstanceInfo (plonky2 fri/oracle.rs; instance of the STARKs: stark.rs:91-148)
+// composite of one batch: sum_j alpha^j p_j, polynomials named by pointer (any oracle, any column)
+__global__ __launch_bounds__(256) void k_fri_combine_generic(const gl_t* const* __restrict__ polys, size_t npolys, const gl_t* __restrict__ apow,
+                                                             size_t n, gl_t* __restrict__ c0, gl_t* __restrict__ c1) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gl_t a0 = 0, a1 = 0;
+    for (size_t j = 0; j < npolys; j++) {
+        gl_t v = polys[j][i];
+        a0 = gl_add(a0, gl_mul(v, apow[2 * j]));
+        a1 = gl_add(a1, gl_mul(v, apow[2 * j + 1]));
+    }
+    c0[i] = a0;
+    c1[i] = a1;
+}
+
+struct fri_blob_layout {
+    unsigned L;
+    size_t F, C4, o_caps, o_final, o_pow, o_queries, query_words, total;
+};
+static void fri_blob_make(fri_blob_layout& y, const zkm_stark_config* cfg, unsigned log_n, const size_t* cols, size_t noracles) {
+    validate_config(cfg, log_n);
+    if (noracles == 0 || noracles > ZKM_FRI_MAX_ORACLES) throw std::runtime_error("zkm_fri_prove: 1..8 oracles");
+    y.L = fri_num_layers(cfg, log_n);
+    y.F = (size_t)1 << (log_n - y.L * cfg->arity_bits);
+    y.C4 = (size_t)4 << cfg->cap_height;
+    const unsigned lde_bits = log_n + cfg->rate_bits;
+    size_t o = 24;
+    y.o_caps = o; o += y.L * y.C4;
+    y.o_final = o; o += 2 * y.F;
+    y.o_pow = o; o += 1;
+    y.o_queries = o;
+    size_t q = 0;
+    for (size_t k = 0; k < noracles; k++) q += cols[k] + (size_t)(lde_bits - cfg->cap_height) * 4;
+    for (unsigned i = 0; i < y.L; i++) q += 2 * ((size_t)1 << cfg->arity_bits) + (size_t)(lde_bits - cfg->arity_bits * (i + 1) - cfg->cap_height) * 4;
+    y.query_words = q;
+    y.total = o + q * cfg->num_queries;
+}
+
+extern "C" {
+
+size_t zkm_fri_proof_words(const zkm_stark_config* cfg, unsigned log_n, const size_t* oracle_cols, size_t noracles) {
+    try {
+        fri_blob_layout y;
+        fri_blob_make(y, cfg, log_n, oracle_cols, noracles);
+        return y.total;
+    } catch (...) {
+        return 0;
+    }
+}
+
+int zkm_fri_prove(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch* const* oracles, size_t noracles, const zkm_fri_batch* batches,
+                  size_t nbatches, zkm_challenger* ch, uint64_t* proof, char** err) {
+    std::vector<void*> scratch;
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!oracles || !batches || !nbatches || !ch || !proof) throw std::runtime_error("zkm_fri_prove: null argument");
+        if (noracles == 0 || noracles > ZKM_FRI_MAX_ORACLES) throw std::runtime_error("zkm_fri_prove: 1..8 oracles");
+        const unsigned log_n = oracles[0]->log_n;
+        size_t cols[ZKM_FRI_MAX_ORACLES];
+        for (size_t k = 0; k < noracles; k++) {
+            if (!oracles[k] || oracles[k]->log_n != log_n || oracles[k]->rate_bits != cfg->rate_bits || oracles[k]->cap_height != cfg->cap_height)
+                throw std::runtime_error("zkm_fri_prove: oracles must share degree, rate and cap height with the config");
+            cols[k] = oracles[k]->ncols;
+        }
+        fri_blob_layout y;
+        fri_blob_make(y, cfg, log_n, cols, noracles);
+        const size_t n = (size_t)1 << log_n;
+        size_t maxp = 0;
+        for (size_t b = 0; b < nbatches; b++) {
+            if (batches[b].npolys == 0 || !batches[b].polys) throw std::runtime_error("zkm_fri_prove: empty batch");
+            if (batches[b].point[0] >= GL_P || batches[b].point[1] >= GL_P) throw std::runtime_error("zkm_fri_prove: non-canonical opening point");
+            for (size_t j = 0; j < batches[b].npolys; j++)
+                if (batches[b].polys[j].oracle >= noracles || batches[b].polys[j].poly >= cols[batches[b].polys[j].oracle])
+                    throw std::runtime_error("zkm_fri_prove: polynomial index out of range");
+            maxp = std::max(maxp, batches[b].npolys);
+        }
+        memset(proof, 0, y.total * sizeof(uint64_t));
+        proof[0] = ZKM_FRI_PROOF_MAGIC; proof[1] = log_n; proof[2] = noracles; proof[3] = cfg->cap_height; proof[4] = y.L; proof[5] = y.F;
+        proof[6] = cfg->num_queries; proof[7] = cfg->rate_bits; proof[8] = cfg->arity_bits;
+        for (size_t k = 0; k < noracles; k++) proof[16 + k] = cols[k];
+
+        gl2_t alpha = challenger_get_ext(ch);
+        std::vector<gl_t> apow(2 * (maxp + 1));
+        {
+            gl2_t pw{1, 0};
+            for (size_t j = 0; j <= maxp; j++) { apow[2 * j] = pw.c0; apow[2 * j + 1] = pw.c1; pw = gl2_mul(pw, alpha); }
+        }
+        gl_t* d_apow = (gl_t*)c->alloc(apow.size() * sizeof(gl_t));
+        scratch.push_back(d_apow);
+        ZKM_HIP_CHECK(hipMemcpyAsync(d_apow, apow.data(), apow.size() * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+        gl_t* d_comp = (gl_t*)c->alloc(2 * nbatches * n * sizeof(gl_t));
+        scratch.push_back(d_comp);
+        std::vector<const gl_t*> ptrs;
+        std::vector<size_t> first(nbatches);
+        for (size_t b = 0; b < nbatches; b++) {
+            first[b] = ptrs.size();
+            for (size_t j = 0; j < batches[b].npolys; j++) ptrs.push_back(oracles[batches[b].polys[j].oracle]->coeffs + (size_t)batches[b].polys[j].poly * n);
+        }
+        const gl_t** d_ptrs = (const gl_t**)c->alloc(ptrs.size() * sizeof(gl_t*));
+        scratch.push_back((void*)d_ptrs);
+        ZKM_HIP_CHECK(hipMemcpyAsync((void*)d_ptrs, ptrs.data(), ptrs.size() * sizeof(gl_t*), hipMemcpyHostToDevice, c->stream));
+        std::vector<fri_composite> comps;
+        for (size_t b = 0; b < nbatches; b++) {
+            zkm_prof_scope ps(c, "fri_combine");
+            hipLaunchKernelGGL(k_fri_combine_generic, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_ptrs + first[b], batches[b].npolys, d_apow, n,
+                               d_comp + 2 * b * n, d_comp + (2 * b + 1) * n);
+            ZKM_HIP_CHECK(hipGetLastError());
+            const size_t np = batches[b].npolys;
+            comps.push_back({d_comp + 2 * b * n, d_comp + (2 * b + 1) * n, gl2_t{batches[b].point[0], batches[b].point[1]},
+                             gl2_t{apow[2 * np], apow[2 * np + 1]}});
+        }
+        ZKM_HIP_CHECK(hipStreamSynchronize(c->stream));  // host vectors (ptrs, apow) are consumed
+        fri_finish(c, cfg, log_n, comps, oracles, noracles, ch, y.L, y.F, cfg->num_queries, y.query_words, proof + y.o_caps, proof + y.o_final,
+                   proof + y.o_pow, proof + y.o_queries);
+    } catch (const std::exception& e) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* q : scratch) c->release(q);
+        return fail(err, e.what());
+    }
+    for (void* q : scratch) c->release(q);
+    return 0;
+}
+
+}  // extern "C"
 
 extern "C" {
 
