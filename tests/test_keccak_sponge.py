@@ -109,3 +109,42 @@ def test_config5_sponge_table_2_20_rows_witness_and_commit(ctx, zkm, oracle):
     coeffs = None
     b.free()
     buf.free()
+
+
+@pytest.mark.gpu
+def test_config5_stretch_keccak_stark_2_20_rows_proof_verifies(ctx, zkm, oracle):
+    """BASELINE config 5 at its stretch size: KeccakStark, 2431 columns x 2^20 rows (43,690 permutations; 20 GB of trace, 81 GB of
+    LDE, 1.3 G leaf permutations) -- witness kernel, commitment, 797-constraint quotient, openings and FRI on the device; the oracle
+    verifies (constraint identity at zeta, Merkle paths of all 37 queries against the caps, FRI), and sampled LDE columns are
+    compared word for word with the oracle's transform of the downloaded coefficients."""
+    from zkm_amd import tables as T
+    log_n = 20
+    n = 1 << log_n
+    k = n // 24
+    rng = np.random.default_rng(520)
+    trace = ctx.keccak_trace(rng.integers(0, 1 << 64, (k, 25), dtype=np.uint64), rng.integers(0, 1 << 30, k), log_n)
+    aux = np.zeros(3 * n, dtype=np.uint64)
+    tb = zkm.PolynomialBatch.from_values(ctx, trace, 2431, log_n)            # 20 GB coefficients + 81 GB LDE + digests
+    proof = ctx.prove_single_table(None, log_n, aux, [2], ncols=2431, table_id=T.TABLE_KECCAK, trace_batch=tb)
+    assert oracle.verify(proof, 3, [2], ncols=2431, table_id=T.TABLE_KECCAK) == 0
+    bad = proof.copy()
+    bad[len(bad) // 3] ^= 1
+    assert oracle.verify(bad, 3, [2], ncols=2431, table_id=T.TABLE_KECCAK) != 0
+    # three columns (first, a bit-decomposition column in the middle, last) of the big commitment against the oracle's transform,
+    # and sampled leaves authenticated against the cap with the oracle's hash functions
+    sel = (0, 1200, 2430)
+    ob = oracle.batch_from_values(np.concatenate([trace.download(n, c * n) for c in sel]), 3, log_n)
+    cap = tb.cap().reshape(-1, 4)
+    N = 4 * n
+    for i in (0, 1, N // 2 + 12345, N - 1, int(rng.integers(0, N))):
+        row = tb.lde_row(i)
+        assert [int(row[c]) for c in sel] == [int(x) for x in ob.lde_row(i)], i
+    for leaf_index in (0, 77, N - 1, int(rng.integers(0, N))):
+        cur, idx = oracle.hash_or_noop(tb.leaf(leaf_index)), leaf_index
+        for sib in tb.merkle_path(leaf_index).reshape(-1, 4):
+            cur = oracle.two_to_one(sib, cur) if idx & 1 else oracle.two_to_one(cur, sib)
+            idx >>= 1
+        assert (cur == cap[idx]).all(), leaf_index
+    tb.free()
+    trace.free()
+    ctx.trim()

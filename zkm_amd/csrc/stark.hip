@@ -1214,12 +1214,12 @@ int zkm_quotient(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_bat
         own.upload(c, nullptr, zs.data(), nullptr, nctl_zs);
         size_t words = nalphas * 2 * trace->n();
         bool dev = zkm_is_device_ptr(out_coeffs);
-        gl_t* d = dev ? out_coeffs : (gl_t*)c->alloc(words * 8);
+        zkm_scratch tmp(c, dev ? 8 : words * 8);   // released on every exit path
+        gl_t* d = dev ? out_coeffs : tmp.as<gl_t>();
         quotient_device(c, table_id, trace, aux, own, nullptr, alphas, nalphas, d);
         if (!dev) {
             ZKM_HIP_CHECK(hipMemcpyAsync(out_coeffs, d, words * 8, hipMemcpyDeviceToHost, c->stream));
             c->sync();
-            c->release(d);
         }
     } catch (const std::exception& e) {
         return fail(err, e.what());
