@@ -59,6 +59,11 @@ int zkm_dev_download(zkm_ctx* ctx, void* dst_host, const void* src_dev, size_t b
  * shift^i then NTT, inverse = iNTT then scale coeff i by shift^-i (plonky2 conventions). */
 int zkm_ntt(zkm_ctx* ctx, uint64_t* cols, size_t ncols, unsigned log_n, int inverse, uint64_t coset_shift, char** err);
 
+/* Parity / debug: the loose-arithmetic field primitives of the butterflies on arbitrary 64-bit words (also >= p), n pairs from host
+ * memory: out = 6 x n canonical words: a + b, a - b, a 2^24, a 2^48, a 2^72, a b (mod p).  Exercises the second-correction
+ * branches of the device add / subtract that field data reaches with probability ~2^-64. */
+int zkm_field_selftest(zkm_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, char** err);
+
 /* ------------------------------------------------------------------ K1-K5: PolynomialBatch
  * zkm_batch_commit_values == PolynomialBatch::from_values(values, rate_bits, false, cap_height, ..)
  *   (prover.rs:154-163, 514-521); zkm_batch_commit_coeffs == from_coeffs (prover.rs:579-586).

@@ -95,6 +95,7 @@ extern "C" {
     pub fn zkm_batch_leaf(b: *const zkm_batch, leaf_index: usize, out: *mut u64) -> c_int;
     pub fn zkm_batch_merkle_path(b: *const zkm_batch, leaf_index: usize, siblings_out: *mut u64) -> c_int;
     pub fn zkm_batch_digest_layer(b: *const zkm_batch, level: c_uint, out: *mut u64) -> c_int;
+    pub fn zkm_field_selftest(ctx: *mut zkm_ctx, a: *const u64, b: *const u64, n: usize, out: *mut u64, err: *mut *mut c_char) -> c_int;
     // hash primitives, witness kernels
     pub fn zkm_poseidon_permute_batch(ctx: *mut zkm_ctx, states: *mut u64, k: usize, err: *mut *mut c_char) -> c_int;
     pub fn zkm_keccakf_batch(ctx: *mut zkm_ctx, states: *mut u64, k: usize, err: *mut *mut c_char) -> c_int;

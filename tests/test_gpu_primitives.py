@@ -135,3 +135,30 @@ def test_errors_are_reported(ctx, zkm):
         zkm.PolynomialBatch.from_values(ctx, np.zeros(8, dtype=np.uint64), 1, 3, rate_bits=2, cap_height=9)
     with pytest.raises(zkm.ZkmError):
         ctx.ntt(np.zeros(8, dtype=np.uint64), 1, 3, coset_shift=P)
+
+
+def test_loose_field_primitives_on_edge_words(ctx):
+    """The butterflies work on "loose" words (any uint64 stands for its residue).  Their add / subtract take the probable
+    correction from the carry-out and the improbable second one (both operands >= p, or a borrow below 2^32) on a wave-uniform
+    branch that field data never takes: here every combination of edge words takes it, next to random words, for all lanes of a
+    wave and for single lanes of a wave (the branch is per wave, the fix per lane)."""
+    M = (1 << 64) - 1
+    edge = [0, 1, 2, 0xFFFFFFFF, 0x100000000, P - 2, P - 1, P, P + 1, P + 0xFFFFFFFE, M - 1, M, 0xFFFFFFFF00000000, 0x7FFFFFFFFFFFFFFF, 1 << 63]
+    pairs = [(x, y) for x in edge for y in edge]
+    rng = np.random.default_rng(5)
+    # a wave whose only double-wrapping lane is lane 37, then whole waves of edge pairs, then random words
+    a = [int(v) for v in rng.integers(0, P, 64, dtype=np.uint64)] + [x for x, _ in pairs] + [int(v) for v in rng.integers(0, 1 << 64, 500, dtype=np.uint64)]
+    b = [int(v) for v in rng.integers(0, P, 64, dtype=np.uint64)] + [y for _, y in pairs] + [int(v) for v in rng.integers(0, 1 << 64, 500, dtype=np.uint64)]
+    a[37], b[37] = M, M
+    a[5], b[5] = 3, M          # second borrow: 3 - (2^64 - 1)
+    # products whose low 64 bits are smaller than their top 32 bits (a b = X 2^96 + small): the borrow of lo - h1 in the reduction,
+    # which field data meets with probability < 2^-32 per product and which sits behind a never-taken branch
+    for i, (x, y) in enumerate([(1 << 63, 0x7FFFFFFF << 33), (1 << 48, 0xFFFF << 48), (1 << 48, 1 << 48), ((1 << 48) + 1, 0xABCD << 48),
+                                (0xFFFFFFFF << 32, 0xFFFFFFFF << 32), (M, M), (P - 1, P - 1), (1 << 32, 1 << 32), (0x1234 << 48, 1)]):
+        a[10 + i], b[10 + i] = x, y
+    got = ctx.field_selftest(a, b)
+    want = [[(x + y) % P for x, y in zip(a, b)], [(x - y) % P for x, y in zip(a, b)], [x * (1 << 24) % P for x in a],
+            [x * (1 << 48) % P for x in a], [x * (1 << 72) % P for x in a], [x * y % P for x, y in zip(a, b)]]
+    for row, w, name in zip(got, want, ("add", "sub", "2^24", "2^48", "2^72", "mul")):
+        bad = [i for i in range(len(a)) if int(row[i]) != w[i]]
+        assert not bad, (name, bad[:5], hex(a[bad[0]]), hex(b[bad[0]]))

@@ -88,6 +88,15 @@ def parse(lines):
                    "name": lab.group(1) if lab else re.search(r"%bb\.\d+", l).group(0)}
             annotate(cur, note, cur["label"])
             continue
+        mreg = re.search(r"ZKM_REGION (\w+)", l)
+        if mreg:
+            # a region marker splits the block: what follows (in layout order) belongs to the named region
+            if cur["ops"]:
+                blocks.append(cur)
+                cur = {"label": None, "ops": [], "loop": cur["loop"], "name": cur.get("name"), "cold": cur.get("cold", False)}
+            cur["region"] = mreg.group(1)
+        if "ZKM_COLD" in l:
+            cur["cold"] = True   # source-level marker (gl_dev.h): a block behind a never-taken branch
         if not s or s.startswith("."):
             continue
         op = s.split()[0]
@@ -135,6 +144,8 @@ def main():
     ap.add_argument("--only-loop", type=int, default=None, help="restrict to the body of the K-th loop (header order)")
     ap.add_argument("--exec", default="", help="NAME=count,...: executions of a block (label or %%bb.N; a branch-split block keeps its name) "
                     "per iteration of the --only-loop loop, for code under a condition the trip counts cannot express")
+    ap.add_argument("--region-exec", default="", help="REGION=count,...: executions per iteration of the --only-loop loop of the code that "
+                    "follows a `; ZKM_REGION name` marker (source-level markers, e.g. poseidon_dev.h) up to the next marker, in layout order")
     ap.add_argument("--cost", default=os.path.join(ROOT, "profiles", "r02_ubench_issue_cost.json"))
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -165,6 +176,16 @@ def main():
         root = loops[args.only_loop]
         keep = [root in chain(b["loop"]) for b in blocks]
         weight = [w // trip[root] if k else w for w, k in zip(weight, keep)]   # per iteration of the selected loop
+    for i, b in enumerate(blocks):   # cold blocks, and the fall-through pieces a branch splits them into, do not execute
+        if b.get("cold"):
+            weight[i] = 0
+    rexec = dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in args.region_exec.split(",") if kv)
+    region = None
+    for i, b in enumerate(blocks):
+        region = b.get("region", region)
+        if rexec and keep[i] and not b.get("cold"):
+            if region in rexec:
+                weight[i] = rexec[region]
     overrides = dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in args.exec.split(",") if kv)
     for i, b in enumerate(blocks):
         if b.get("name") in overrides:

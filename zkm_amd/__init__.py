@@ -29,7 +29,7 @@ u64p = C.POINTER(C.c_uint64)
 EXPORTS = [
     "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_memory", "zkm_ctx_trim", "zkm_table_enum_index", "zkm_host_alloc", "zkm_host_free",
     "zkm_host_register", "zkm_host_unregister", "zkm_all_stark_ctls", "zkm_all_stark_ctl_table", "zkm_prove_segment", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
-    "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_free",
+    "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_field_selftest", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_free",
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_lde_rows", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_keccak_trace", "zkm_logic_trace",
     "zkm_poseidon_sponge_trace", "zkm_poseidon_trace_inputs", "zkm_sha_extend_trace", "zkm_sha_extend_sponge_trace",
@@ -106,6 +106,7 @@ def load():
         "zkm_dev_free": (C.c_int, [cp, cp]),
         "zkm_dev_upload": (C.c_int, [cp, cp, cp, C.c_size_t, err]),
         "zkm_dev_download": (C.c_int, [cp, cp, cp, C.c_size_t, err]),
+        "zkm_field_selftest": (C.c_int, [cp, u64p, u64p, C.c_size_t, u64p, err]),
         "zkm_ntt": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, C.c_int, C.c_uint64, err]),
         "zkm_batch_commit_values": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, cpp, err]),
         "zkm_batch_commit_coeffs": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, cpp, err]),
@@ -304,6 +305,14 @@ class Context:
         err = C.c_char_p()
         _check(self.L.zkm_ntt(self.h, _data_ptr(cols), ncols, log_n, int(inverse), coset_shift, C.byref(err)), err)
         return cols
+
+    def field_selftest(self, a, b):
+        """(a + b, a - b, a 2^24, a 2^48, a 2^72, a b) mod p through the device's loose-arithmetic primitives, for arbitrary 64-bit words."""
+        a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros(6 * a.size, dtype=np.uint64)
+        err = C.c_char_p()
+        _check(self.L.zkm_field_selftest(self.h, a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), a.size, out.ctypes.data_as(u64p), C.byref(err)), err)
+        return out.reshape(6, -1)
 
     def poseidon_permute_batch(self, states):
         k = (states.size if isinstance(states, np.ndarray) else states.words) // 12

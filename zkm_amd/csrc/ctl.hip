@@ -5,6 +5,7 @@
 // One lane per trace row: evaluate the filter and the challenge-combined column set, invert (Fermat; the
 // reference batch-inverts, the inverse is unique so the bytes agree), accumulate helper columns, then an
 // additive suffix scan produces the upside-down running sum Z.
+#define GL_REDUCE_BRANCHFREE 1   // (gl_dev.h: these kernels interleave independent products at low occupancy)
 #include "ctl_dev.h"
 #include "all_stark_ctl.inc"
 

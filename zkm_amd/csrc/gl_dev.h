@@ -63,6 +63,65 @@ GL_HD uint64_t gl_sub_lc(uint64_t a, gl_t b) {
     return d;
 }
 
+// loose +/- loose -> loose for the NTT butterflies.  a + b wraps once with probability ~1/2 (corrected branch-free from the add's own
+// carry-out) and a SECOND time only when both operands are non-canonical (a, b >= p: probability ~2^-64 on field data); likewise a
+// second borrow of a - b needs b >= p and a < 2^32.  The second correction is therefore a wave-uniform branch on the carry mask
+// that is never taken in practice instead of a canonicalisation of one operand on every butterfly (4 VALU instructions, ~17 issue
+// cycles): correctness does not depend on it being rare.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint64_t gl_add_rr(uint64_t a, uint64_t b) {
+    uint32_t rl, rh, e;
+    uint64_t c2;
+    asm("v_add_co_u32 %0, vcc, %4, %5\n\t"
+        "v_addc_co_u32 %1, vcc, %6, %7, vcc\n\t"
+        "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %2\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "s_mov_b64 %3, vcc"
+        : "=&v"(rl), "=&v"(rh), "=&v"(e), "=s"(c2)
+        : "v"((uint32_t)a), "v"((uint32_t)b), "v"((uint32_t)(a >> 32)), "v"((uint32_t)(b >> 32))
+        : "vcc");
+    uint64_t r = ((uint64_t)rh << 32) | rl;
+    if (__builtin_expect(c2 != 0, 0)) {              // c2 is the wave's carry mask: a scalar branch
+        asm volatile("; ZKM_COLD (tools/isa_histogram.py: never-taken block)");
+        const bool mine = (c2 >> (__lane_id() & 63)) & 1;
+        if (mine) r += GL_EPS;                       // after a second wrap r < 2^32: cannot wrap again
+    }
+    return r;
+}
+__device__ __forceinline__ uint64_t gl_sub_rr(uint64_t a, uint64_t b) {
+    uint32_t rl, rh, e;
+    uint64_t c2;
+    asm("v_sub_co_u32 %0, vcc, %4, %5\n\t"
+        "v_subb_co_u32 %1, vcc, %6, %7, vcc\n\t"
+        "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+        "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "s_mov_b64 %3, vcc"
+        : "=&v"(rl), "=&v"(rh), "=&v"(e), "=s"(c2)
+        : "v"((uint32_t)a), "v"((uint32_t)b), "v"((uint32_t)(a >> 32)), "v"((uint32_t)(b >> 32))
+        : "vcc");
+    uint64_t r = ((uint64_t)rh << 32) | rl;
+    if (__builtin_expect(c2 != 0, 0)) {
+        asm volatile("; ZKM_COLD");
+        const bool mine = (c2 >> (__lane_id() & 63)) & 1;
+        if (mine) r -= GL_EPS;                       // after a second borrow r > 2^64 - 2^32: cannot borrow again
+    }
+    return r;
+}
+#else
+GL_HD uint64_t gl_add_rr(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    if (s < a) { uint64_t t = s + GL_EPS; s = t < s ? t + GL_EPS : t; }
+    return s;
+}
+GL_HD uint64_t gl_sub_rr(uint64_t a, uint64_t b) {
+    uint64_t d = a - b;
+    if (a < b) { uint64_t t = d - GL_EPS; d = t > d ? t - GL_EPS : t; }
+    return d;
+}
+#endif
+
 // 128-bit (hi:lo) -> loose.  Standard Goldilocks reduction: 2^64 == 2^32 - 1, 2^96 == -1, written for gfx950 issue costs
 // (tools/ubench3.hip: compare + select chains are the expensive part of a modmul, moves and plain 32-bit ops are cheap):
 //   t0 = lo - h1           borrow <=> lo < h1 < 2^32 <=> the high word went from 0 to 0xFFFFFFFF; the borrow mask
@@ -70,9 +129,30 @@ GL_HD uint64_t gl_sub_lc(uint64_t a, gl_t b) {
 //   r  = h0 * EPS + t0     one multiply-add; if it wrapped, r < 2^64 - 2^33 + 1 and adding EPS cannot wrap again
 GL_HD uint64_t gl_reduce128(uint64_t lo, uint64_t hi) {
     uint32_t h1 = (uint32_t)(hi >> 32), h0 = (uint32_t)hi;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_REDUCE_BRANCHFREE)
+    // t0 = lo - h1 borrows only if lo < h1 < 2^32, i.e. with probability < 2^-32 on products of field data: the borrow mask comes out
+    // of the subtract itself and the correction (t0 -= EPS: the wrapped value is > 2^64 - 2^32, it cannot borrow again) sits behind a
+    // wave-uniform branch that is practically never taken -- 2 VALU instructions instead of 6 (the r01 form builds the mask from
+    // the sign of t0_hi & ~lo_hi and subtracts it unconditionally: kept below for GL_REDUCE_BRANCHFREE).  A modular multiply is
+    // 12 VALU instructions (was 17): Poseidon 14.6k -> 13.3k per permutation, leaf hashing 48.8 -> 44.5 ms.  The branch is a
+    // scheduling barrier, so kernels that live on interleaving independent products at low occupancy (quotient, openings:
+    // +30 % / +70 % with it) define GL_REDUCE_BRANCHFREE.  tests: zkm_field_selftest feeds the borrowing products.
+    uint32_t tl, th;
+    uint64_t bm;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\tv_subbrev_co_u32 %1, vcc, 0, %4, vcc\n\ts_mov_b64 %2, vcc"
+        : "=&v"(tl), "=&v"(th), "=s"(bm)
+        : "v"((uint32_t)lo), "v"((uint32_t)(lo >> 32)), "v"(h1)
+        : "vcc");
+    uint64_t t0 = ((uint64_t)th << 32) | tl;
+    if (__builtin_expect(bm != 0, 0)) {
+        asm volatile("; ZKM_COLD");
+        if ((bm >> (__lane_id() & 63)) & 1) t0 -= GL_EPS;
+    }
+#else
     uint64_t t0 = lo - h1;
     uint32_t m = (uint32_t)((int32_t)((uint32_t)(t0 >> 32) & ~(uint32_t)(lo >> 32)) >> 31);
     t0 -= m;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     // The wrap of h0 * EPS + t0 is the multiply-add's own carry-out (an SGPR pair): mad, select, add -- no 64-bit compare.
     // The compiler does not form this (it adds separately and compares); tools/ubench3.hip: +14 % x^7 s-boxes/s.

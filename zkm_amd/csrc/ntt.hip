@@ -63,6 +63,38 @@ __device__ __forceinline__ gl_t pow_lookup(const gl_t* __restrict__ tab, unsigne
     return gl_mul_loose(tab[i & (((size_t)1 << h) - 1)], tab[((size_t)1 << h) + (i >> h)]);
 }
 
+// ------------------------------------------------------------------ field-primitive self test (parity / debug)
+// out[0][i] = a + b, out[1][i] = a - b, out[2][i] = a * 2^24, out[3][i] = a * 2^48, out[4][i] = a * 2^72, out[5][i] = a * b, all mod p and
+// canonical, for ANY 64-bit words a, b (also >= p): the loose-arithmetic primitives of the butterflies (gl_add_rr / gl_sub_rr with their
+// never-taken second-correction branches, gl_mul_pow2, gl_mul_loose) on exactly the inputs random data does not produce.
+__global__ void k_field_selftest(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, size_t n, uint64_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t x = a[i], y = b[i];
+    out[i] = gl_canon(gl_add_rr(x, y));
+    out[n + i] = gl_canon(gl_sub_rr(x, y));
+    out[2 * n + i] = gl_canon(gl_mul_pow2<24>(x));
+    out[3 * n + i] = gl_canon(gl_mul_pow2<48>(x));
+    out[4 * n + i] = gl_canon(gl_mul_pow2<72>(x));
+    out[5 * n + i] = gl_mul(x, y);
+}
+extern "C" int zkm_field_selftest(zkm_ctx* c, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, char** err) {
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        zkm_scratch da(c, n * 8), db(c, n * 8), dout(c, 6 * n * 8);
+        ZKM_HIP_CHECK(hipMemcpyAsync(da.p, a, n * 8, hipMemcpyHostToDevice, c->stream));
+        ZKM_HIP_CHECK(hipMemcpyAsync(db.p, b, n * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_field_selftest, dim3((n + 255) / 256), dim3(256), 0, c->stream, da.as<uint64_t>(), db.as<uint64_t>(), n, dout.as<uint64_t>());
+        ZKM_HIP_CHECK(hipGetLastError());
+        ZKM_HIP_CHECK(hipMemcpyAsync(out, dout.p, 6 * n * 8, hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+    } catch (const std::exception& e) {
+        if (err) *err = strdup(e.what());
+        return 1;
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------ multi-stage LDS pass kernel
 // One launch performs S (3..8) consecutive radix-2 DIF stages of many length-2^S sub-transforms.
 // A workgroup owns a tile of R = 2^S "rows" (the butterfly dimension, element stride sa) x T "columns"
@@ -126,11 +158,11 @@ struct ntt_round {
         }
     }
     __device__ static __forceinline__ void bfly(gl_t& u, gl_t& v, gl_t w) {
-        // loose arithmetic inside a pass: only v is canonicalised (one compare), the sum / difference take one correction
-        // each and the product is not canonicalised at all; the last pass canonicalises on the way out (canon_out)
-        const gl_t vc = gl_canon(v);
-        const uint64_t t = gl_add_lc(u, vc);
-        v = gl_mul_loose(gl_sub_lc(u, vc), w);
+        // all-loose arithmetic inside a pass: the sum and the difference take their one probable correction from the add's / subtract's
+        // own carry-out and the improbable second one on a never-taken uniform branch (gl_add_rr / gl_sub_rr); the product is not
+        // canonicalised at all; the last pass canonicalises on the way out (canon_out)
+        const uint64_t t = gl_add_rr(u, v);
+        v = gl_mul_loose(gl_sub_rr(u, v), w);
         u = t;
     }
     // up to three DIF stages on the 8 register-resident rows; sched_barrier keeps the compiler from
@@ -155,21 +187,12 @@ struct ntt_round {
     }
     // The LAST round of the LAST pass (q == 0, m == 0): its twiddles are the 8th / 4th roots of unity w_8^j = 2^(24 j), w_4 = 2^48 (and
     // 1 for the final stage), so 7 of the 12 butterflies need no product at all and the other 5 a shift (gl_mul_pow2).  Inverse
-    // roots are the negated powers w_8^-j = -2^(96 - 24 j): the sign goes into the subtraction (v - u instead of u - v, with u
-    // the canonicalised operand).  Same field elements as compute() with the table twiddles, hence bit-exact.
+    // roots are the negated powers w_8^-j = -2^(96 - 24 j): the sign goes into the subtraction (v - u instead of u - v).  Same field elements as compute() with the table twiddles, hence bit-exact.
     template <int E, bool NEG>
     __device__ static __forceinline__ void bfly_pow2(gl_t& u, gl_t& v) {
-        if (!NEG) {
-            const gl_t vc = gl_canon(v);
-            const uint64_t t = gl_add_lc(u, vc), d = gl_sub_lc(u, vc);
-            v = E ? gl_mul_pow2<(E ? E : 1)>(d) : d;
-            u = t;
-        } else {
-            const gl_t uc = gl_canon(u);
-            const uint64_t t = gl_add_lc(v, uc), d = gl_sub_lc(v, uc);   // v - u
-            v = gl_mul_pow2<(E ? E : 1)>(d);
-            u = t;
-        }
+        const uint64_t t = gl_add_rr(u, v), d = NEG ? gl_sub_rr(v, u) : gl_sub_rr(u, v);
+        v = E ? gl_mul_pow2<(E ? E : 1)>(d) : d;
+        u = t;
     }
     template <bool INV>
     __device__ static __forceinline__ void compute_pow2(gl_t (&x)[8]) {
@@ -295,12 +318,20 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
     // Software pipeline over the workgroup's columns: the 8 words of column c + 1 are requested before column c is
     // transformed (16 VGPRs), so the HBM latency of the next loads is covered by ~800 VALU instructions instead of
     // being exposed at the top of every iteration.  nx[] holds raw words; the coset pre-scale is applied when they are consumed.
+#ifndef ZKM_NTT_PRE_SGPR
+#define ZKM_NTT_PRE_SGPR 0   // 1: apply D_k^j from SGPRs and B separately (15 products per column instead of 8, 14 VGPRs less)
+#endif
+#if ZKM_NTT_PRE_SGPR
+    gl_t preB = 0;
+    if (PRE == 3) preB = gl_canon(pow_lookup(pre_tab, p.pre_log, in0));
+#else
     gl_t gpre[8];
     if (PRE == 3) {
         const gl_t B = pow_lookup(pre_tab, p.pre_log, in0);
 #pragma unroll
         for (int j = 0; j < 8; j++) gpre[j] = j ? gl_mul(B, p.pre_dj[coset][j]) : gl_canon(B);
     }
+#endif
     gl_t nx[8];
     auto fetch = [&](uint32_t col) {
         const gl_t* __restrict__ src = p.in + (size_t)col * p.cs_in + base_in;   // wave-uniform
@@ -332,8 +363,14 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
             if (PRE == 3) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
+#if ZKM_NTT_PRE_SGPR
+                    if (j) x[j] = gl_mul_loose(x[j], p.pre_dj[coset][j]);
+                    x[j] = gl_mul_loose(x[j], preB);
+                    __builtin_amdgcn_sched_barrier(0);
+#else
                     x[j] = gl_mul_loose(x[j], gpre[j]);
                     if (j & 1) __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
             } else if (do_pre) {
 #pragma unroll

@@ -53,9 +53,13 @@ ZKM_CONST uint64_t ZKM_POSEIDON_ZERO12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PC pc_dev
 #define POSEIDON_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// region markers for tools/isa_histogram.py (comments in the assembly; no instructions): the permutation's control flow has parts
+// that run 8, 7 and 1 times per permutation, which loop trip counts alone cannot express
+#define POSEIDON_REGION(name) asm volatile("; ZKM_REGION " name)
 #else
 #define PC pc_host
 #define POSEIDON_SCHED_FENCE() ((void)0)
+#define POSEIDON_REGION(name) ((void)0)
 #endif
 
 // Hide a small multiplier from the optimiser (it stays in an SGPR).  Left to itself the compiler turns the MDS entries that are
@@ -205,29 +209,36 @@ GL_HD void poseidon_partial_group(uint64_t s[12], uint64_t c1, uint64_t c2, cons
 // block of full rounds, two inline s-box layers and the last MDS used to be separate copies) and stays inside the 64 KB
 // instruction cache two CUs share.
 GL_HD void poseidon_permute(uint64_t s[12]) {
+    POSEIDON_REGION("entry");
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_add_loose(s[i], PC::ZKM_POSEIDON_RC[i]);
 #pragma unroll 1
     for (int r = 0; r < 8; r++) {
+        POSEIDON_REGION("full_sbox");
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             s[i] = poseidon_sbox7(s[i]);
             if ((i & 1) == 1) POSEIDON_SCHED_FENCE();
         }
         if (r == 3) {
+            POSEIDON_REGION("partial_head");
             // round 3's MDS opens the first fused group; the groups cover the MDS of rounds 3 .. 25 and the s-boxes of rounds 4 .. 25
 #pragma unroll 1
             for (int g = 0; g < 7; g++) {  // MDS of rounds 3g+3 .. 3g+5 and the s-boxes of rounds 3g+4, 3g+5; then round 3g+6's
+                POSEIDON_REGION("partial_group");
                 poseidon_partial_group<3>(s, PC::ZKM_POSEIDON_FUSED_C1[g], PC::ZKM_POSEIDON_FUSED_C2[g], PC::ZKM_POSEIDON_FUSED_C3[g]);
                 s[0] = poseidon_sbox7(s[0]);
             }
+            POSEIDON_REGION("partial_tail");
             poseidon_partial_group<2>(s, PC::ZKM_POSEIDON_FUSED_C1[7], 0, PC::ZKM_POSEIDON_FUSED_C3[7]);  // MDS of rounds 24, 25
         } else {
+            POSEIDON_REGION("full_mds");
             // full round r < 3 is round r, r > 3 is round 22 + r; the constants added are those of the NEXT round (none after the last)
             const int next = (r < 3 ? r : 22 + r) + 1;
             poseidon_mds_add<true>(s, next < 30 ? &PC::ZKM_POSEIDON_RC[next * 12] : PC::ZKM_POSEIDON_ZERO12);
         }
     }
+    POSEIDON_REGION("exit");
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }

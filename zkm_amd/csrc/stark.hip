@@ -5,6 +5,7 @@
 // (proof.rs:299-334) and plonky2's PolynomialBatch::prove_openings / fri_proof.
 // The Challenger stays on the host (a few hundred field elements per table); only caps, openings,
 // the final polynomial and the query openings cross PCIe.
+#define GL_REDUCE_BRANCHFREE 1   // (gl_dev.h: these kernels interleave independent products at low occupancy)
 #include "constraints_dev.h"
 #include "ctl_dev.h"
 
