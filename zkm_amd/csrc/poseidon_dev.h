@@ -138,10 +138,7 @@ GL_HD void poseidon_mds_add(uint64_t s[12], const uint64_t* add) {
 GL_HD void poseidon_mds(uint64_t s[12]) { poseidon_mds_add<false>(s, nullptr); }
 
 // sbox(a) - a mod p, loose -> loose
-GL_HD uint64_t poseidon_sbox_delta(uint64_t a) {
-    uint64_t neg = GL_P - gl_canon(a);  // in (0, p]
-    return gl_add_loose(poseidon_sbox7(a), neg);
-}
+GL_HD uint64_t poseidon_sbox_delta(uint64_t a) { return gl_sub_rr(poseidon_sbox7(a), a); }
 GL_HD constexpr uint32_t poseidon_m1(int i, int j) {
     constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     return C[(j - i + 12) % 12] + ((i == 0 && j == 0) ? 8u : 0u);
