@@ -73,6 +73,7 @@ BENCH_WORKER = textwrap.dedent("""
         def alloc(self, words): return Buf(None)
         def prove_single_table(self, trace, log_n, aux, nh):
             proved.append(trace.seed); time.sleep(0.01); return np.full(5, trace.seed, dtype=np.uint64)
+        def synchronize(self): pass
         def profile(self, on): pass
         def profile_reset(self): pass
         def profile_records(self): return {"merkle_leaves": (len(proved), 1.0 * len(proved)), "ntt_pass_strided": (3, 0.5)}
@@ -84,22 +85,32 @@ BENCH_WORKER = textwrap.dedent("""
     torch.cuda.get_device_properties = lambda d: types.SimpleNamespace(multi_processor_count=256)
     real_init = zd.init
     zd.init = lambda backend=None: real_init("gloo")
-    sys.argv = ["bench.py", "--gpus", "2", "--segments", "7", "--warmup", "1", "--log-n", "10", "--no-cpu-baseline", "--no-extras"]
+    NCTX = %d
+    sys.argv = ["bench.py", "--gpus", "2", "--segments", "7", "--warmup", "1", "--log-n", "10", "--no-cpu-baseline", "--no-extras",
+                "--contexts", str(NCTX)]
     import runpy
     runpy.run_path(%r, run_name="__main__")
     rank = int(__import__("os").environ["RANK"])
     want = [100 + s for s in range(rank, 7, 2)]
-    assert proved[1:len(want) + 1] == want, (rank, proved)          # proved[0] is the warm-up
+    timed = proved[NCTX:NCTX + len(want)]                           # the first NCTX calls are the warm-ups, one per context
+    if NCTX == 1:
+        assert timed == want, (rank, proved)                        # one context: in segment order
+    else:
+        assert sorted(timed) == want, (rank, proved)                # a queue: every segment of this rank exactly once
     print("RANK%%d OK %%s" %% (rank, proved))
-""") % (ROOT, os.path.join(ROOT, "bench.py"))
+""")
 
 
-def test_bench_sharding_path_two_rank_gloo(tmp_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("nctx", [1, 2])
+def test_bench_sharding_path_two_rank_gloo(tmp_path, nctx):
     script = tmp_path / "bench_worker.py"
-    script.write_text(BENCH_WORKER)
+    script.write_text(BENCH_WORKER % (ROOT, nctx, os.path.join(ROOT, "bench.py")))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29517", str(script)], capture_output=True, text=True, timeout=300, env=env)
+                        "127.0.0.1", "--master-port", str(29517 + nctx), str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "RANK0 OK" in r.stdout and "RANK1 OK" in r.stdout
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -107,4 +118,30 @@ def test_bench_sharding_path_two_rank_gloo(tmp_path):
     import json
     j = json.loads(line[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["segments_total"] == 7 and j["config"]["segments_per_gpu"] == 4
+    assert j["config"]["contexts_per_gpu"] == nctx and j["single_context"]["ms_per_step"] > 0
     assert j["value"] > 0 and abs(j["value"] * j["ms_per_step"] * 4 / 7 / 1e3 - 1) < 1e-6   # value = total / elapsed, ms_per_step = elapsed / 4
+
+
+def test_run_workers_queue_and_errors():
+    """The per-GPU worker queue: every segment exactly once, worker indices in range, first exception re-raised on the caller."""
+    sys.path.insert(0, ROOT)
+    import threading
+    import time
+    from zkm_amd.dist import run_workers
+    seen, lock = [], threading.Lock()
+
+    def fn(s, w):
+        time.sleep(0.002 * (s % 3))
+        with lock:
+            seen.append((s, w))
+        return s * s
+    out = run_workers(fn, range(23), 4)
+    assert out == {s: s * s for s in range(23)}
+    assert sorted(s for s, _ in seen) == list(range(23)) and {w for _, w in seen} <= {0, 1, 2, 3} and len({w for _, w in seen}) > 1
+
+    def bad(s, w):
+        if s == 5:
+            raise ValueError("segment 5")
+        return s
+    with pytest.raises(ValueError, match="segment 5"):
+        run_workers(bad, range(50), 3)

@@ -95,6 +95,12 @@ extern "C" int zkm_field_selftest(zkm_ctx* c, const uint64_t* a, const uint64_t*
     return 0;
 }
 
+// development hooks for timing experiments (never defined in the product build): where does a pass spend its time?
+#if defined(ZKM_EXP_NOBAR)
+#define NTT_SYNC() ((void)0)
+#else
+#define NTT_SYNC() __syncthreads()
+#endif
 // ------------------------------------------------------------------ multi-stage LDS pass kernel
 // One launch performs S (3..8) consecutive radix-2 DIF stages of many length-2^S sub-transforms.
 // A workgroup owns a tile of R = 2^S "rows" (the butterfly dimension, element stride sa) x T "columns"
@@ -161,6 +167,9 @@ struct ntt_round {
         // all-loose arithmetic inside a pass: the sum and the difference take their one probable correction from the add's / subtract's
         // own carry-out and the improbable second one on a never-taken uniform branch (gl_add_rr / gl_sub_rr); the product is not
         // canonicalised at all; the last pass canonicalises on the way out (canon_out)
+#if defined(ZKM_EXP_NOCOMPUTE)
+        u += v; v ^= w; return;
+#endif
         const uint64_t t = gl_add_rr(u, v);
         v = gl_mul_loose(gl_sub_rr(u, v), w);
         u = t;
@@ -190,6 +199,9 @@ struct ntt_round {
     // roots are the negated powers w_8^-j = -2^(96 - 24 j): the sign goes into the subtraction (v - u instead of u - v).  Same field elements as compute() with the table twiddles, hence bit-exact.
     template <int E, bool NEG>
     __device__ static __forceinline__ void bfly_pow2(gl_t& u, gl_t& v) {
+#if defined(ZKM_EXP_NOCOMPUTE)
+        u += v; v ^= (uint64_t)E; return;
+#endif
         const uint64_t t = gl_add_rr(u, v), d = NEG ? gl_sub_rr(v, u) : gl_sub_rr(u, v);
         v = E ? gl_mul_pow2<(E ? E : 1)>(d) : d;
         u = t;
@@ -391,24 +403,26 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
                 if (do_pre && (!ZP || off < p.n_in)) v = gl_mul_loose(v, pow_lookup(pre_tab, p.pre_log, off));
                 lds[a * tp + bb] = v;
             }
-            __syncthreads();
+            NTT_SYNC();
             R0::lds_read(lds, tp, b, rg, x);
         }
+#if !defined(ZKM_EXP_NOMEM)
         if (PF && col + 1 < col1) fetch(col + 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (!IN_A && S >= 3 && p.zero_padded) R0::compute_zero_padded(x, w0);
         else if (NR == 1) ntt_last_round<S, 0>(x, w0, p.pow2_last);
         else R0::compute(x, w0);
         if (NR > 1) {
             R0::lds_write(lds, tp, b, rg, x);
-            __syncthreads();
+            NTT_SYNC();
             R1::lds_read(lds, tp, b, rg, x);
             if (NR == 2) ntt_last_round<S, (NR > 1 ? 1 : 0)>(x, w1, p.pow2_last);
             else R1::compute(x, w1);
         }
         if (NR > 2) {
             R1::lds_write(lds, tp, b, rg, x);
-            __syncthreads();
+            NTT_SYNC();
             R2::lds_read(lds, tp, b, rg, x);
             if (NR == 3) ntt_last_round<S, (NR > 2 ? 2 : 0)>(x, w2, p.pow2_last);
             else R2::compute(x, w2);
@@ -430,11 +444,14 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int jj = p.rev_rows ? (int)(((j & 1) << 2) | (j & 2) | ((j >> 2) & 1)) : j;
+#if defined(ZKM_EXP_NOMEM)
+                if (x[j] == 0x0123456789abcdefull)
+#endif
                 (dst + (size_t)jj * out_step)[lane_out] = x[j];
             }
         } else {
             RL::lds_write(lds, tp, b, rg, x);
-            __syncthreads();
+            NTT_SYNC();
 #pragma unroll 2
             for (int e = 0; e < 8; e++) {
                 int idx = tid + e * nthreads;
@@ -450,7 +467,7 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
                 dst[off] = v;
             }
         }
-        if (IN_A || OUT_A || NR > 1) __syncthreads();  // LDS is reused by the next column
+        if (IN_A || OUT_A || NR > 1) NTT_SYNC();  // LDS is reused by the next column
     }
 }
 
@@ -715,51 +732,56 @@ __global__ __launch_bounds__((1 << SA) * 8) void k_ntt_big(ntt_big_args p) {
         gl_t x[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = nx[j];          // rows rg + (RA / 8) j == A0::row(rg, j), column b
+#if !defined(ZKM_EXP_NOMEM)
         if (blk + gridDim.x < total) {
             const gl_t* src = block_ptr(blk + gridDim.x);
 #pragma unroll
             for (int j = 0; j < 8; j++) nx[j] = src[tid + NT * j];
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 1: SA stages along the rows, lanes along b
         A0::compute(x, wa0);
         if (NR1 > 1) {
             A0::lds_write(lds, LP, 1, b, rg, x);
-            __syncthreads();
+            NTT_SYNC();
             A1::lds_read(lds, LP, 1, b, rg, x);
             A1::compute(x, wa1);
         }
         if (NR1 > 2) {
-            __syncthreads();
+            NTT_SYNC();
             A1::lds_write(lds, LP, 1, b, rg, x);
-            __syncthreads();
+            NTT_SYNC();
             A2::lds_read(lds, LP, 1, b, rg, x);
             A2::compute(x, wa2);
         }
         using AL = ntt_round_t<SA, NR1 - 1>;
-        if (NR1 > 1) __syncthreads();
+        if (NR1 > 1) NTT_SYNC();
         AL::lds_write(lds, LP, 1, b, rg, x);
-        __syncthreads();
+        NTT_SYNC();
         // ---- phase 2: the six stages inside each 64-element row, lanes along the rows
         B0::lds_read(lds, 1, LP, a2, rg2, x);
         B0::compute(x, wb0);
-        __syncthreads();
+        NTT_SYNC();
         B0::lds_write(lds, 1, LP, a2, rg2, x);
-        __syncthreads();
+        NTT_SYNC();
         B1::lds_read(lds, 1, LP, a2, rg2, x);
         B1::template compute_pow2<false>(x);
-        __syncthreads();
+        NTT_SYNC();
         B1::lds_write(lds, 1, LP, a2, rg2, x);
-        __syncthreads();
+        NTT_SYNC();
         // ---- out: word p of the block sits at lds[p + (p >> 6)]
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int pidx = tid + NT * j;
             gl_t v = lds[pidx + (pidx >> 6)];
             if (p.canon_out) v = gl_canon(v);
+#if defined(ZKM_EXP_NOMEM)
+            if (v == 0x0123456789abcdefull)
+#endif
             dst[pidx] = v;
         }
-        __syncthreads();  // LDS is reused by the next block
+        NTT_SYNC();  // LDS is reused by the next block
     }
 }
 

@@ -72,12 +72,45 @@ def shutdown():
         dist.destroy_process_group()
 
 
-def prove_segments(prove_fn, num_segments, sync_fn=None, gather=True):
+def run_workers(prove_fn, segments, workers):
+    """`workers` host threads pull `segments` from one queue; thread w calls prove_fn(s, w) -- w selects the worker's own context
+    (own stream, allocator and transcript; a context is single-owner).  Independent segments proven side by side on
+    one GPU fill each other's transcript round trips and overlap HBM-bound NTT passes with VALU-bound hashing.  The first
+    exception stops the queue and is re-raised here."""
+    import threading
+    it = iter(list(segments))
+    lock = threading.Lock()
+    out, errs = {}, []
+
+    def loop(w):
+        while not errs:
+            with lock:
+                s = next(it, None)
+            if s is None:
+                return
+            try:
+                r = prove_fn(s, w)
+                with lock:
+                    out[s] = r
+            except BaseException as e:  # noqa: B902 -- re-raised on the calling thread
+                errs.append(e)
+    th = [threading.Thread(target=loop, args=(w,), name="zkm-worker-%d" % w) for w in range(workers)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    return out
+
+
+def prove_segments(prove_fn, num_segments, sync_fn=None, gather=True, workers=1):
     """Prove `num_segments` independent segments across all ranks (this is bench.py's timed region).
 
     prove_fn(segment_index) -> proof; sync_fn() drains the local GPU (torch.cuda.synchronize).  The clock runs from a
     barrier + sync to a sync + barrier and the slowest rank defines the job time.  gather=False skips collecting the proofs on
-    rank 0 (bench.py only needs the time).
+    rank 0 (bench.py only needs the time).  workers = k > 1: this rank's segments go through run_workers and prove_fn is
+    called as prove_fn(segment_index, worker_index).
     Returns (proofs_on_rank0_or_None, whole_job_seconds)."""
     world, rank, _ = env_world()
     mine = assign_segments(num_segments, world, rank)
@@ -85,7 +118,7 @@ def prove_segments(prove_fn, num_segments, sync_fn=None, gather=True):
     if sync_fn:
         sync_fn()
     t0 = time.perf_counter()
-    local = {s: prove_fn(s) for s in mine}
+    local = {s: prove_fn(s) for s in mine} if workers <= 1 else run_workers(prove_fn, mine, workers)
     if sync_fn:
         sync_fn()
     barrier()
