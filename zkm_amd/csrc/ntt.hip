@@ -309,10 +309,17 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
     const size_t base_out = (size_t)t_hi * p.bo_hi + (size_t)t_lo * p.bo_lo;
     const size_t i_low = p.m ? (((size_t)t_lo << logT) + b) : 0;
 
+#if defined(ZKM_EXP_FAKETW)   // timing experiment: one twiddle set for all rounds (wrong results, 28 VGPRs less)
+    gl_t w0[7];
+    R0::load_tw(w0, p.tw, rg, p.m, i_low);
+    gl_t (&w1)[7] = w0;
+    gl_t (&w2)[7] = w0;
+#else
     gl_t w0[7], w1[7], w2[7];
     R0::load_tw(w0, p.tw, rg, p.m, i_low);
     if (NR > 1) R1::load_tw(w1, p.tw, rg, p.m, i_low);
     if (NR > 2) R2::load_tw(w2, p.tw, rg, p.m, i_low);
+#endif
 
     // column-independent offsets.  Every global access is (wave-uniform base) + (one 32-bit lane offset): the 8 row bases of a
     // thread differ by uniform multiples of the row step, so the addresses cost scalar adds, not a VGPR pair per row.
@@ -785,6 +792,144 @@ __global__ __launch_bounds__((1 << SA) * 8) void k_ntt_big(ntt_big_args p) {
     }
 }
 
+// ---- the 2^12-element block with ONE workgroup barrier: 3 + 9 stages.
+// Round 1 (stages 11, 10, 9) works on the words a thread loads anyway (tid + 512 j: 512 B per wave instruction); what is left
+// are eight independent 2^9-point problems, and 2^9 words are exactly what ONE wave holds (64 lanes x 8 registers): after the
+// single cross-wave exchange every wave owns a sub-block and runs stages 8 .. 0 on its own -- rounds of three stages with the
+// register-resident bits (8,7,6), (5,4,3), (2,1,0), exchanged through the wave's own LDS region, which needs no workgroup
+// barrier (a wave's LDS instructions execute in order); the last round's twiddles are powers of two.  Word t of a sub-block
+// lives at A(t) = (t + 8 (t >> 6)) ^ ((t >> 3) & 7): conflict-free for all four access patterns, reads (32-lane groups, 64-bit
+// banks mod 32) and writes (16-lane groups, mod 16) alike.  Two LDS images alternate between blocks, so the next block's round-1
+// stores never wait for this block's readers: four LDS round trips and one barrier per block (k_ntt_big<6>: five and nine).
+#define ZKM_WAVE_SYNC()                                      \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+#ifndef ZKM_BLK12_WAVES
+#define ZKM_BLK12_WAVES 4
+#endif
+#ifndef ZKM_BLK12_IMAGES
+#define ZKM_BLK12_IMAGES 2
+#endif
+__global__ __launch_bounds__(512, ZKM_BLK12_WAVES) void k_ntt_blk12(ntt_big_args p) {
+    extern __shared__ __attribute__((aligned(16))) gl_t lds[];
+    constexpr int NT = 512, SB = 576;
+    using R = ntt_round<3, 0>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto A = [](int t) { return (t + ((t >> 6) << 3)) ^ ((t >> 3) & 7); };
+    const int a1 = A(tid);                                        // round-1 store: word tid of sub-block j
+
+    // round-1 twiddles (one set per thread) stay in registers; those of rounds 2 and 3 only depend on the lane (64 x 7 and 8 x 7
+    // words) and are re-read from LDS when needed -- 28 VGPRs that decide between one and two workgroups per CU
+    gl_t w1[7];
+    R::load_tw(w1, p.tw, 0, 9, (size_t)tid);
+    gl_t* const twl = lds + ZKM_BLK12_IMAGES * 8 * SB;
+    if (tid < 64) {
+        gl_t w[7];
+        R::load_tw(w, p.tw, 0, 6, (size_t)tid);
+#pragma unroll
+        for (int k = 0; k < 7; k++) twl[k * 64 + tid] = w[k];
+    } else if (tid < 72) {
+        gl_t w[7];
+        R::load_tw(w, p.tw, 0, 3, (size_t)(tid - 64));
+#pragma unroll
+        for (int k = 0; k < 7; k++) twl[448 + k * 8 + (tid - 64)] = w[k];
+    }
+    __syncthreads();
+
+    const uint32_t total = p.ncols * p.blocks_per_col;
+    auto block_ptr = [&](uint32_t blk) { return p.data + (size_t)(blk / p.blocks_per_col) * p.cs + ((size_t)(blk % p.blocks_per_col) << 12); };
+    gl_t nx[8];
+    uint32_t blk = blockIdx.x;
+    if (blk < total) {
+        const gl_t* src = block_ptr(blk);
+#pragma unroll
+        for (int j = 0; j < 8; j++) nx[j] = src[tid + NT * j];
+    }
+    int buf = 0;
+    for (; blk < total; blk += gridDim.x, buf ^= (ZKM_BLK12_IMAGES - 1)) {
+        gl_t* const dst = block_ptr(blk);
+        gl_t* const img = lds + buf * (8 * SB);
+        gl_t x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = nx[j];
+#if !defined(ZKM_EXP_NOMEM)
+        if (blk + gridDim.x < total) {
+            const gl_t* src = block_ptr(blk + gridDim.x);
+#pragma unroll
+            for (int j = 0; j < 8; j++) nx[j] = src[tid + NT * j];
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        R::compute(x, w1);                                        // stages 11, 10, 9
+        if (ZKM_BLK12_IMAGES == 1) NTT_SYNC();                    // (single image: the previous block's readers must be done)
+#pragma unroll
+        for (int j = 0; j < 8; j++) img[j * SB + a1] = x[j];
+        NTT_SYNC();                                               // the only workgroup barrier of the block
+        // per-lane LDS offsets of the wave-local rounds, recomputed per block from an opaque copy of the lane id: kept live across the
+        // loop they would cost ~20 VGPRs and push the kernel over the 128 that two workgroups per CU allow
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int l7 = l & 7, h3 = l >> 3;
+        const int a2 = A(l);                                      // rounds 2 / out: words l + 64 j at a2 + 72 j
+        const int a3 = 72 * h3;                                   // round 3: words 64 h3 + 8 j + l7 at a3 + 8 j + (l7 ^ j)
+        const int a4 = 8 * l + 8 * h3;                            // round 4: words 8 l + j at a4 + (j ^ l7)
+        gl_t* const sub = img + wv * SB;
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = sub[a2 + 72 * j];
+        gl_t w[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) w[k] = twl[k * 64 + l];
+        R::compute(x, w);                                         // stages 8, 7, 6
+#pragma unroll
+        for (int j = 0; j < 8; j++) sub[a2 + 72 * j] = x[j];
+        ZKM_WAVE_SYNC();
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = sub[a3 + 8 * j + (l7 ^ j)];
+#pragma unroll
+        for (int k = 0; k < 7; k++) w[k] = twl[448 + k * 8 + l7];
+        R::compute(x, w);                                         // stages 5, 4, 3
+#pragma unroll
+        for (int j = 0; j < 8; j++) sub[a3 + 8 * j + (l7 ^ j)] = x[j];
+        ZKM_WAVE_SYNC();
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = sub[a4 + (l7 ^ j)];
+        R::template compute_pow2<false>(x);                       // stages 2, 1, 0
+        if (p.canon_out) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = gl_canon(x[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) sub[a4 + (l7 ^ j)] = x[j];
+        ZKM_WAVE_SYNC();
+        gl_t* const out = dst + (wv << 9);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const gl_t v = sub[a2 + 72 * j];
+#if defined(ZKM_EXP_NOMEM)
+            if (v == 0x0123456789abcdefull)
+#endif
+            out[l + 64 * j] = v;
+        }
+    }
+}
+
+static void launch_blk12(zkm_ctx* c, const ntt_big_args& a) {
+    static bool attr_done = false;
+    const size_t shmem = (ZKM_BLK12_IMAGES * 8 * 576 + 7 * 64 + 7 * 8) * sizeof(gl_t);
+    if (!attr_done) {
+        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_blk12, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    uint32_t total = a.ncols * a.blocks_per_col;
+    uint32_t grid = total < (uint32_t)c->num_cus * 8 ? total : (uint32_t)c->num_cus * 8;
+    hipLaunchKernelGGL(k_ntt_blk12, dim3(grid), dim3(512), shmem, c->stream, a);
+}
+
 template <int SA>
 static void launch_big_t(zkm_ctx* c, const ntt_big_args& a) {
     static bool attr_done = false;
@@ -804,11 +949,212 @@ static void ntt_big_pass(zkm_ctx* c, gl_t* data, size_t cs, size_t ncols, unsign
     zkm_prof_scope ps(c, "ntt_pass_big");
     switch (S2) {
         case 11: launch_big_t<5>(c, a); break;
-        case 12: launch_big_t<6>(c, a); break;
+        case 12: {
+            static const bool old = getenv("ZKM_NTT_BIG_OLD") != nullptr;  // A/B switch: the 6 + 6 kernel
+            if (old) launch_big_t<6>(c, a);
+            else launch_blk12(c, a);
+            break;
+        }
         case 13: launch_big_t<7>(c, a); break;
         default: throw std::runtime_error("ntt big pass: unsupported stage count");
     }
     ZKM_HIP_CHECK(hipGetLastError());
+}
+
+// ---- Pass A of the coset-split LDE with BLOCK twiddles (stages S = 6, 7, 8 of a 2^12-column tile).
+// The decimation-in-frequency recursion with a geometric weight r^t carried implicitly instead of multiplied in:
+//   D(f, N, r)[i] = sum_t f(t) r^t w_N^(i t);   split t = t' + (N/2) e, i = 2 i' + eps, W = r^(N/2):
+//   D[2 i']     = D(f(t') + W f(t' + N/2), N/2, r)[i'],      D[2 i' + 1] = D(f(t') - W f(t' + N/2), N/2, r w_N)[i'].
+// Every butterfly is (u, v) -> (u + W v, u - W v) with ONE W per block of the stage: block q of stage k (2^k blocks) has
+//   W(k, q) = shift^(n / 2^(k+1)) * w_(2^(k+1))^bitrev_k(q),
+// which only depends on the ROW bits above the stage -- uniform over a tile's columns, so the twiddles of the first two rounds
+// are wave-uniform and live in SGPRs (the plain DIF form keeps 21 lane-dependent twiddles = 42 VGPRs and the factored pre-scale
+// 16 more, which held the kernel to one workgroup per CU).  The coset shift is inside W, so there is no pre-scale; what the
+// plain form multiplies in stage by stage is applied once at the end: row p (holding output residue i_lo = bitrev_S(p)) and
+// column t_lo get  (shift w_n^i_lo)^t_lo = shift^t_lo * w_n^(i_lo t_lo)  -- 8 factors per thread, fixed for the tile, kept in
+// registers across the polynomial columns.  Same number of products as before (32 butterflies + 8 per column and thread), the
+// same field elements on the way out (pass B is unchanged), twice the occupancy.
+struct lde_upper_args {
+    const gl_t* in;
+    gl_t* out;
+    size_t cs_in, cs_out;
+    uint32_t ncols, cpb, log_n, S2;
+    const gl_t* tw;            // forward table: w_n^e = tw[n/2 + e] for e < n/2
+    const gl_t* ct;            // [4 cosets][2^S]: W(k, q) at 2^k + q
+    const gl_t* pre_tab_k[4];  // shift_k^t (two-level power table over n)
+    size_t out_off_k[4];
+};
+
+template <int S, int K>
+struct ct_round : ntt_round<S, K> {
+    using B = ntt_round<S, K>;
+    // W of local stage q + jb for register index j: heap index 2^(S-1-q-jb) + ((rg >> q) << (2 - jb)) + (j >> (jb + 1))
+    template <bool UNI>
+    __device__ static __forceinline__ void load(gl_t (&w)[7], const gl_t* __restrict__ tab, int rg) {
+        int rgq = rg >> B::q;
+        if (UNI) rgq = __builtin_amdgcn_readfirstlane(rgq);
+#pragma unroll
+        for (int jb = 2; jb >= 0; jb--) {
+            if (jb > B::top) continue;
+            const int base = jb == 2 ? 0 : (jb == 1 ? 1 : 3);
+#pragma unroll
+            for (int jh = 0; jh < (4 >> jb); jh++) w[base + jh] = tab[(1 << (S - 1 - B::q - jb)) + (rgq << (2 - jb)) + jh];
+        }
+    }
+    __device__ static __forceinline__ void bfly(gl_t& u, gl_t& v, gl_t w) {
+#if defined(ZKM_EXP_NOCOMPUTE)
+        u += v; v ^= w; return;
+#endif
+        const uint64_t t = gl_mul_loose(v, w);
+        v = gl_sub_rr(u, t);
+        u = gl_add_rr(u, t);
+    }
+    __device__ static __forceinline__ void compute(gl_t (&x)[8], const gl_t (&w)[7]) {
+        if (B::top >= 2) {
+            bfly(x[0], x[4], w[0]); bfly(x[1], x[5], w[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            bfly(x[2], x[6], w[0]); bfly(x[3], x[7], w[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (B::top >= 1) {
+            bfly(x[0], x[2], w[1]); bfly(x[1], x[3], w[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            bfly(x[4], x[6], w[2]); bfly(x[5], x[7], w[2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bfly(x[0], x[1], w[3]); bfly(x[2], x[3], w[4]);
+        __builtin_amdgcn_sched_barrier(0);
+        bfly(x[4], x[5], w[5]); bfly(x[6], x[7], w[6]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+template <int S>
+__global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
+    extern __shared__ __attribute__((aligned(16))) gl_t lds[];
+    constexpr int R = 1 << S, NR = (S + 2) / 3, LT = 12 - S, T = 1 << LT;
+    using R0 = ct_round<S, 0>;
+    using R1 = ct_round<S, (NR > 1 ? 1 : 0)>;
+    using R2 = ct_round<S, (NR > 2 ? 2 : 0)>;
+    using RL = ct_round<S, NR - 1>;  // last round: q == 0, rows (rg << 3) | j
+    const int tid = threadIdx.x, b = tid & (T - 1), rg = tid >> LT;
+    // the four cosets of a tile on one XCD (ids 8 apart), as in k_ntt_pass
+    const uint32_t g = blockIdx.x >> 3, coset = g & 3, tile = (g >> 2) * 8 + (blockIdx.x & 7);
+    const uint32_t t_lo = (tile << LT) + b;                      // column of the 2^S2-wide row this lane works on
+    const gl_t* const ct = p.ct + ((size_t)coset << S);
+
+    gl_t w0[7], w1[7], w2[7];
+    R0::template load<(LT + R0::q >= 6)>(w0, ct, rg);
+    if (NR > 1) R1::template load<(LT + R1::q >= 6)>(w1, ct, rg);
+    if (NR > 2) R2::template load<(LT + R2::q >= 6)>(w2, ct, rg);
+
+    // (shift w_n^i_lo)^t_lo for the 8 rows this thread stores
+    gl_t post[8];
+    {
+        const gl_t Bv = pow_lookup(p.pre_tab_k[coset], p.log_n, t_lo);
+        const uint64_t half = (uint64_t)1 << (p.log_n - 1);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint64_t e = (uint64_t)bitrev32((uint32_t)RL::row(rg, j), S) * t_lo;   // < 2^S * 2^S2 = n
+            gl_t wv = p.tw[half + (e & (half - 1))];
+            if (e >= half) wv = GL_P - wv;                        // w_n^(n/2) = -1
+            post[j] = gl_mul(Bv, wv);
+        }
+    }
+
+    const size_t sa = (size_t)1 << p.S2;
+    const uint32_t lane_in = (uint32_t)((size_t)rg * sa) + t_lo;             // rows rg + j R/8 (== R0::row(rg, j))
+    const size_t in_step = (size_t)(R >> 3) * sa;
+    const uint32_t lane_out = (uint32_t)((size_t)(rg << 3) * sa) + t_lo;     // rows (rg << 3) | j
+    const size_t out_off = p.out_off_k[coset];
+
+    const uint32_t col0 = blockIdx.y * p.cpb;
+    const uint32_t col1 = col0 + p.cpb < p.ncols ? col0 + p.cpb : p.ncols;
+    gl_t nx[8];
+    auto fetch = [&](uint32_t col) {
+        const gl_t* __restrict__ src = p.in + (size_t)col * p.cs_in;         // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 8; j++) nx[j] = (src + (size_t)j * in_step)[lane_in];
+    };
+    if (col0 < col1) fetch(col0);
+    int ex = 0;                                                               // exchanges done so far: alternates the two LDS images
+    for (uint32_t col = col0; col < col1; col++) {
+        gl_t* __restrict__ dst = p.out + (size_t)col * p.cs_out + out_off;   // wave-uniform
+        gl_t x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = nx[j];
+#if !defined(ZKM_EXP_NOMEM)
+        if (col + 1 < col1) fetch(col + 1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        R0::compute(x, w0);
+        if (NR > 1) {
+            gl_t* const img = lds + (ex & 1) * (R * T);
+            ex++;
+            R0::lds_write(img, T, b, rg, x);
+            NTT_SYNC();
+            R1::lds_read(img, T, b, rg, x);
+            R1::compute(x, w1);
+        }
+        if (NR > 2) {
+            gl_t* const img = lds + (ex & 1) * (R * T);
+            ex++;
+            R1::lds_write(img, T, b, rg, x);
+            NTT_SYNC();
+            R2::lds_read(img, T, b, rg, x);
+            R2::compute(x, w2);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            x[j] = gl_mul_loose(x[j], post[j]);
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+#if defined(ZKM_EXP_NOMEM)
+            if (x[j] == 0x0123456789abcdefull)
+#endif
+            (dst + (size_t)j * sa)[lane_out] = x[j];
+        }
+    }
+}
+
+template <int S>
+static void launch_lde_upper_t(zkm_ctx* c, const lde_upper_args& a) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_lde_upper<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const size_t shmem = 2 * 4096 * sizeof(gl_t);                             // two images of the 2^S x 2^(12-S) tile
+    const uint32_t ntiles = (1u << a.S2) >> (12 - S);
+    dim3 grid(ntiles * 4, (a.ncols + a.cpb - 1) / a.cpb);
+    hipLaunchKernelGGL((k_lde_upper<S>), grid, dim3(512), shmem, c->stream, a);
+}
+
+// W(k, q) = shift_c^(n / 2^(k+1)) * w_(2^(k+1))^bitrev_k(q) at [c][2^k + q], c = 0..3, shift_c = shift * w_4n^c
+static const gl_t* lde_ct_table(zkm_ctx* c, uint64_t shift, unsigned log_n, unsigned S) {
+    auto key = std::make_tuple(shift, log_n, S);
+    auto it = c->lde_ct_tables.find(key);
+    if (it != c->lde_ct_tables.end()) return it->second;
+    const size_t R = (size_t)1 << S;
+    std::vector<gl_t> host(4 * R, 0);
+    const gl_t w4n = gl_root_of_unity(log_n + 2);
+    gl_t sk = shift;
+    for (unsigned cs = 0; cs < 4; cs++) {
+        for (unsigned k = 0; k < S; k++) {
+            const gl_t base = gl_pow(sk, (uint64_t)1 << (log_n - k - 1));
+            const gl_t wk = gl_root_of_unity(k + 1);
+            for (uint32_t q = 0; q < (1u << k); q++)
+                host[cs * R + ((size_t)1 << k) + q] = gl_mul(base, gl_pow(wk, k ? bitrev32(q, k) : 0));
+        }
+        sk = gl_mul(sk, w4n);
+    }
+    gl_t* d = (gl_t*)c->alloc(host.size() * sizeof(gl_t));
+    ZKM_HIP_CHECK(hipMemcpyAsync(d, host.data(), host.size() * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+    ZKM_HIP_CHECK(hipStreamSynchronize(c->stream));  // host vector goes out of scope
+    c->lde_ct_tables[key] = d;
+    return d;
 }
 
 // Coset-split LDE (rate 4): the evaluations on g<w_4n> in bit-reversed order are four blocks of n -- block bitrev2(k) holds the
@@ -851,7 +1197,25 @@ static bool lde_coset_split(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t nc
         sk = gl_mul(sk, w4n);
     }
     a.canon_out = 0;
-    launch_pass(c, S1, a, ntiles, "ntt_pass_strided");
+    static const bool dif_a = getenv("ZKM_NTT_LDE_DIF") != nullptr;  // A/B switch: pass A in the plain DIF form with the factored pre-scale
+    if (!dif_a && S2 == 12 && S1 >= 6) {
+        lde_upper_args u{};
+        u.in = coeffs; u.out = out; u.cs_in = n; u.cs_out = N; u.ncols = (uint32_t)ncols; u.log_n = log_n; u.S2 = (uint32_t)S2;
+        u.tw = c->tw.fwd; u.ct = lde_ct_table(c, shift, log_n, (unsigned)S1);
+        for (unsigned k = 0; k < 4; k++) { u.pre_tab_k[k] = a.pre_tab_k[k]; u.out_off_k[k] = a.out_off_k[k]; }
+        size_t want = (ncols * ntiles) / 2048;                        // columns per workgroup (as launch_pass)
+        u.cpb = (uint32_t)(want < 1 ? 1 : (want > 16 ? 16 : want));
+        if (u.cpb > u.ncols) u.cpb = u.ncols;
+        zkm_prof_scope ps(c, "ntt_pass_strided");
+        switch (S1) {
+            case 6: launch_lde_upper_t<6>(c, u); break;
+            case 7: launch_lde_upper_t<7>(c, u); break;
+            default: launch_lde_upper_t<8>(c, u); break;
+        }
+        ZKM_HIP_CHECK(hipGetLastError());
+    } else {
+        launch_pass(c, S1, a, ntiles, "ntt_pass_strided");
+    }
     ntt_big_pass(c, out, N, ncols, log_n + 2, S2, c->tw.fwd);
     return true;
 }

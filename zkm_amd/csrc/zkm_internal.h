@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <map>
+#include <tuple>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -53,6 +54,8 @@ struct zkm_ctx {
     zkm_twiddles tw;
     // power tables for coset scaling: key (shift, log_n) -> device ptr [lo table 2^h | hi table 2^(log_n-h)]
     std::map<std::pair<uint64_t, unsigned>, gl_t*> pow_tables;
+    // block twiddles of the coset-split LDE's upper stages: key (shift, log_n, stages) -> device ptr [4 cosets][2^stages]
+    std::map<std::tuple<uint64_t, unsigned, unsigned>, gl_t*> lde_ct_tables;
     // pinned host staging
     uint64_t* h_staging = nullptr;
     size_t h_staging_words = 0;
