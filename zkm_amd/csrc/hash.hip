@@ -51,14 +51,16 @@ __global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ 
             for (int i = 0; i < 8; i++) v[i] = p[(c + i) * col_stride];
 #pragma unroll
             for (int i = 0; i < 8; i++) s[i] = v[i];
-            poseidon_permute(s);
+            // another whole chunk follows: it replaces words 0..7, only the capacity words are carried over.  Before a ragged chunk
+            // (it keeps words rem..7) and at the end (digest) the whole state is needed.
+            poseidon_permute_out(s, c + 16 <= ncols ? POSEIDON_OUT_CAPACITY : (c + 8 == ncols ? POSEIDON_OUT_DIGEST : POSEIDON_OUT_ALL));
         }
         if (c < ncols) {
             size_t rem = ncols - c;
 #pragma unroll
             for (int i = 0; i < 8; i++)
                 if ((size_t)i < rem) s[i] = p[(c + i) * col_stride];
-            poseidon_permute(s);
+            poseidon_permute_out(s, POSEIDON_OUT_DIGEST);
         }
     }
     uint64_t* d = digests + 4 * j;
@@ -101,14 +103,15 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_chunk(const gl_t* __restr
         for (int i = 0; i < 8; i++) v[i] = p[(c + i) * col_stride];
 #pragma unroll
         for (int i = 0; i < 8; i++) s[i] = v[i];
-        poseidon_permute(s);
+        // (the state parked between chunks is the whole, canonical state: the last permutation of a launch keeps all twelve words)
+        poseidon_permute_out(s, c + 16 <= nc ? POSEIDON_OUT_CAPACITY : POSEIDON_OUT_ALL);
     }
     if (c < nc) {  // ragged tail: only legal in the last chunk
         size_t rem = nc - c;
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if ((size_t)i < rem) s[i] = p[(c + i) * col_stride];
-        poseidon_permute(s);
+        poseidon_permute_out(s, POSEIDON_OUT_ALL);
     }
     if (last) {
         uint64_t* d = digests + 4 * j;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_ext(const gl_t* __restric
             s[2 * i] = a[e + i];
             s[2 * i + 1] = b[e + i];
         }
-        poseidon_permute(s);
+        poseidon_permute_out(s, e + 4 < arity ? POSEIDON_OUT_CAPACITY : POSEIDON_OUT_DIGEST);
     }
     uint64_t* d = digests + 4 * k;
     *reinterpret_cast<ulonglong2*>(d) = make_ulonglong2(s[0], s[1]);
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void k_merkle_compress(const gl_t* __restrict_
     const ulonglong2* ch = reinterpret_cast<const ulonglong2*>(children + 8 * i);
     ulonglong2 a = ch[0], b = ch[1], cc = ch[2], d = ch[3];
     uint64_t s[12] = {a.x, a.y, b.x, b.y, cc.x, cc.y, d.x, d.y, 0, 0, 0, 0};
-    poseidon_permute(s);
+    poseidon_permute_out(s, POSEIDON_OUT_DIGEST);
     uint64_t* o = parents + 4 * i;
     *reinterpret_cast<ulonglong2*>(o) = make_ulonglong2(s[0], s[1]);
     *reinterpret_cast<ulonglong2*>(o + 2) = make_ulonglong2(s[2], s[3]);

@@ -107,7 +107,7 @@ GL_HD uint64_t poseidon_fold(uint64_t al, uint64_t ah) {
 // Each state word is split into 32-bit halves, the halves are accumulated in two 64-bit sums that start at the halves of
 // the additive constant (next round's constant) and stay < 2^32 * 265 < 2^41, and the pair is folded once (poseidon_fold).
 // Inputs loose, outputs loose.
-template <bool ADD>
+template <bool ADD, int ROW0 = 0, int ROW1 = 12>
 GL_HD void poseidon_mds_add(uint64_t s[12], const uint64_t* add) {
     uint32_t lo[12], hi[12];
 #pragma unroll
@@ -120,7 +120,7 @@ GL_HD void poseidon_mds_add(uint64_t s[12], const uint64_t* add) {
     for (int i = 0; i < 12; i++) POSEIDON_OPAQUE(C[i]);
     POSEIDON_OPAQUE(diag);
 #pragma unroll
-    for (int r = 0; r < 12; r++) {
+    for (int r = ROW0; r < ROW1; r++) {   // (rows outside [ROW0, ROW1) keep their input word: callers treat them as dead)
         uint64_t al = ADD ? (uint64_t)(uint32_t)add[r] : 0, ah = ADD ? add[r] >> 32 : 0;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
@@ -200,12 +200,20 @@ GL_HD void poseidon_partial_group(uint64_t s[12], uint64_t c1, uint64_t c2, cons
     }
 }
 
-// In: any uint64 words (loose).  Out: canonical.
 // One loop over the eight full rounds with the partial-round section hanging off round 3: every piece of round code exists
 // once, so the hot loop of the leaf kernel (33 absorb steps per row) is ~30 KB of instructions instead of ~57 KB (the second
 // block of full rounds, two inline s-box layers and the last MDS used to be separate copies) and stays inside the 64 KB
 // instruction cache two CUs share.
-GL_HD void poseidon_permute(uint64_t s[12]) {
+//
+// What the caller reads of the result.  A sponge in overwrite mode (plonky2 hash_n_to_m_no_pad: the next input chunk REPLACES the rate
+// words) only carries the four capacity words from one permutation to the next, and a digest is the first four words: the last MDS
+// layer then needs 4 of its 12 rows (8 x (24 multiply-adds + fold) less) and only what leaves the sponge is canonicalised.
+//   ALL: twelve canonical words.   CAPACITY: words 8..11, loose (they go straight into the next permutation); words 0..7 are garbage.
+//   DIGEST: words 0..3, canonical; words 4..11 are garbage.
+enum { POSEIDON_OUT_ALL = 0, POSEIDON_OUT_CAPACITY = 1, POSEIDON_OUT_DIGEST = 2 };
+
+// In: any uint64 words (loose).  `out` must be wave-uniform on the device (it selects code, not lanes).
+GL_HD void poseidon_permute_out(uint64_t s[12], int out) {
     POSEIDON_REGION("entry");
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_add_loose(s[i], PC::ZKM_POSEIDON_RC[i]);
@@ -228,6 +236,10 @@ GL_HD void poseidon_permute(uint64_t s[12]) {
             }
             POSEIDON_REGION("partial_tail");
             poseidon_partial_group<2>(s, PC::ZKM_POSEIDON_FUSED_C1[7], 0, PC::ZKM_POSEIDON_FUSED_C3[7]);  // MDS of rounds 24, 25
+        } else if (r == 7 && out != POSEIDON_OUT_ALL) {
+            POSEIDON_REGION("last_mds_rows");
+            if (out == POSEIDON_OUT_CAPACITY) poseidon_mds_add<false, 8, 12>(s, nullptr);
+            else poseidon_mds_add<false, 0, 4>(s, nullptr);
         } else {
             POSEIDON_REGION("full_mds");
             // full round r < 3 is round r, r > 3 is round 22 + r; the constants added are those of the NEXT round (none after the last)
@@ -236,6 +248,14 @@ GL_HD void poseidon_permute(uint64_t s[12]) {
         }
     }
     POSEIDON_REGION("exit");
+    if (out == POSEIDON_OUT_ALL) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+        for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+    } else if (out == POSEIDON_OUT_DIGEST) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) s[i] = gl_canon(s[i]);
+    }
 }
+
+// In: any uint64 words (loose).  Out: canonical.
+GL_HD void poseidon_permute(uint64_t s[12]) { poseidon_permute_out(s, POSEIDON_OUT_ALL); }
