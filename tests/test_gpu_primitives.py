@@ -156,6 +156,23 @@ def test_loose_field_primitives_on_edge_words(ctx):
     for i, (x, y) in enumerate([(1 << 63, 0x7FFFFFFF << 33), (1 << 48, 0xFFFF << 48), (1 << 48, 1 << 48), ((1 << 48) + 1, 0xABCD << 48),
                                 (0xFFFFFFFF << 32, 0xFFFFFFFF << 32), (M, M), (P - 1, P - 1), (1 << 32, 1 << 32), (0x1234 << 48, 1)]):
         a[10 + i], b[10 + i] = x, y
+    # products with the middle carry c (2^96 c == -c, fed into the reduction as the borrow-in of lo - h1' - c) AND a low word
+    # below h1' + c: pick bl odd and al with al bl = small (mod 2^32), bh large, and ah so that the middle word of lo is zero
+    slot, tries = 30, 0
+    while slot < 62:
+        tries += 1
+        bl = int(rng.integers(0, 1 << 31)) * 2 + 1
+        small = 1 if slot % 2 else int(rng.integers(0, 1 << 16))
+        al = small * pow(bl, -1, 1 << 32) % (1 << 32)
+        bh = int(rng.integers(1 << 31, 1 << 32))
+        m1 = al * bh + ((al * bl) >> 32)
+        ah = (-m1 * pow(bl, -1, 1 << 32)) % (1 << 32)
+        m2 = ah * bl + m1
+        x, y = (ah << 32) | al, (bh << 32) | bl
+        if (m2 >> 64) == 1 and (x * y) & M == small:
+            a[slot], b[slot] = x, y
+            slot += 1
+        assert tries < 10000
     got = ctx.field_selftest(a, b)
     want = [[(x + y) % P for x, y in zip(a, b)], [(x - y) % P for x, y in zip(a, b)], [x * (1 << 24) % P for x in a],
             [x * (1 << 48) % P for x in a], [x * (1 << 72) % P for x in a], [x * y % P for x, y in zip(a, b)]]

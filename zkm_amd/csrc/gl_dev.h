@@ -207,9 +207,38 @@ GL_HD uint64_t gl_mul_pow2(uint64_t x) {
 
 // loose * loose -> loose
 GL_HD uint64_t gl_mul_loose(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_REDUCE_BRANCHFREE)
+    // gl_mul_wide + gl_reduce128 fused around the ONE carry of the product: m2 = ah bl + m1 may exceed 64 bits, and that bit
+    // weighs 2^96 == -1.  Instead of materialising it (v_cndmask) and adding it into the high word, it stays in the SGPR pair the
+    // multiply-add wrote it to and enters the reduction's first subtract as its borrow-in:
+    //   a b = lo + 2^64 hi' + 2^96 c,  hi' = ah bh + (m2 >> 32) < 2^64   ==>   t0 = lo - h1' - c,  r = h0' EPS + t0
+    // t0 borrows only if lo < h1' + c <= 2^32 (probability ~2^-32): same never-taken branch as in gl_reduce128.  11 VALU instructions.
+    const uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    const uint64_t p00 = (uint64_t)al * bl;
+    const uint64_t m1 = (uint64_t)al * bh + (p00 >> 32);
+    uint64_t m2, c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(m2), "=&s"(c) : "v"(ah), "v"(bl), "v"(m1));
+    const uint64_t hi = (uint64_t)ah * bh + (m2 >> 32);
+    uint32_t tl, th;
+    uint64_t bm;
+    asm("v_subb_co_u32 %0, vcc, %3, %5, %6\n\tv_subbrev_co_u32 %1, vcc, 0, %4, vcc\n\ts_mov_b64 %2, vcc"
+        : "=&v"(tl), "=&v"(th), "=s"(bm)
+        : "v"((uint32_t)p00), "v"((uint32_t)m2), "v"((uint32_t)(hi >> 32)), "s"(c)
+        : "vcc");
+    uint64_t t0 = ((uint64_t)th << 32) | tl;
+    if (__builtin_expect(bm != 0, 0)) {
+        asm volatile("; ZKM_COLD");
+        if ((bm >> (__lane_id() & 63)) & 1) t0 -= GL_EPS;
+    }
+    uint64_t r, carry;
+    uint32_t wrap;
+    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, -1, %1" : "=&v"(r), "=&s"(carry), "=v"(wrap) : "v"((uint32_t)hi), "v"(t0));
+    return r + wrap;
+#else
     uint64_t lo, hi;
     gl_mul_wide(a, b, lo, hi);
     return gl_reduce128(lo, hi);
+#endif
 }
 // loose * loose -> canonical
 GL_HD gl_t gl_mul(uint64_t a, uint64_t b) { return gl_canon(gl_mul_loose(a, b)); }
