@@ -49,12 +49,13 @@ if "FETCH_SIZE" in ml and "WRITE_SIZE" in ml:
         latest["k_merkle_leaves"]["valu_insts_per_wave"] = ml["SQ_INSTS_VALU"]["max"] / ml["SQ_WAVES"]["max"]
     if "GRBM_GUI_ACTIVE" in ml:
         latest["k_merkle_leaves"]["grbm_gui_active_max"] = ml["GRBM_GUI_ACTIVE"]["max"]
-fetch = sum(v["pmc"]["FETCH_SIZE"]["sum"] for k, v in res.items() if "k_ntt_" in k and "FETCH_SIZE" in v.get("pmc", {}))
-write = sum(v["pmc"]["WRITE_SIZE"]["sum"] for k, v in res.items() if "k_ntt_" in k and "WRITE_SIZE" in v.get("pmc", {}))
+is_ntt = lambda k: "k_ntt_" in k or "k_lde_upper" in k   # every NTT / LDE kernel of ntt.hip
+fetch = sum(v["pmc"]["FETCH_SIZE"]["sum"] for k, v in res.items() if is_ntt(k) and "FETCH_SIZE" in v.get("pmc", {}))
+write = sum(v["pmc"]["WRITE_SIZE"]["sum"] for k, v in res.items() if is_ntt(k) and "WRITE_SIZE" in v.get("pmc", {}))
 if fetch and write:
     latest["ntt"] = {"fetch_bytes_per_proof": 2 * 1024 * fetch / proofs, "write_bytes_per_proof": 1024 * write / proofs,
                      "traffic_bytes_per_proof": (2 * 1024 * fetch + 1024 * write) / proofs,
-                     "kernel_ms_per_proof": sum(v["stats"]["total_ns"] for k, v in res.items() if "k_ntt_" in k and "stats" in v) / proofs / 1e6}
+                     "kernel_ms_per_proof": sum(v["stats"]["total_ns"] for k, v in res.items() if is_ntt(k) and "stats" in v) / proofs / 1e6}
 json.dump(latest, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(latest, indent=1))
 for k, v in sorted(res.items(), key=lambda kv: -kv[1].get("stats", {}).get("total_ns", 0))[:14]:
