@@ -60,8 +60,9 @@ int zkm_dev_download(zkm_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 int zkm_ntt(zkm_ctx* ctx, uint64_t* cols, size_t ncols, unsigned log_n, int inverse, uint64_t coset_shift, char** err);
 
 /* Parity / debug: the loose-arithmetic field primitives of the butterflies on arbitrary 64-bit words (also >= p), n pairs from host
- * memory: out = 6 x n canonical words: a + b, a - b, a 2^24, a 2^48, a 2^72, a b (mod p).  Exercises the second-correction
- * branches of the device add / subtract that field data reaches with probability ~2^-64. */
+ * memory: out = 7 x n canonical words: a + b, a - b, a 2^24, a 2^48, a 2^72, a b, and a b again through the branch-free product the
+ * quotient / opening kernels use (mod p).  Exercises the corrections of the device arithmetic that field data reaches with probability
+ * 2^-32 .. 2^-64 (second wrap of add / subtract, borrow of the Goldilocks reduction with and without the product's middle carry). */
 int zkm_field_selftest(zkm_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, char** err);
 
 /* ------------------------------------------------------------------ K1-K5: PolynomialBatch

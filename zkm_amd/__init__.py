@@ -307,12 +307,13 @@ class Context:
         return cols
 
     def field_selftest(self, a, b):
-        """(a + b, a - b, a 2^24, a 2^48, a 2^72, a b) mod p through the device's loose-arithmetic primitives, for arbitrary 64-bit words."""
+        """(a + b, a - b, a 2^24, a 2^48, a 2^72, a b, a b [branch-free product]) mod p through the device's loose-arithmetic primitives,
+        for arbitrary 64-bit words."""
         a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
-        out = np.zeros(6 * a.size, dtype=np.uint64)
+        out = np.zeros(7 * a.size, dtype=np.uint64)
         err = C.c_char_p()
         _check(self.L.zkm_field_selftest(self.h, a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), a.size, out.ctypes.data_as(u64p), C.byref(err)), err)
-        return out.reshape(6, -1)
+        return out.reshape(7, -1)
 
     def poseidon_permute_batch(self, states):
         k = (states.size if isinstance(states, np.ndarray) else states.words) // 12

@@ -207,7 +207,27 @@ GL_HD uint64_t gl_mul_pow2(uint64_t x) {
 
 // loose * loose -> loose
 GL_HD uint64_t gl_mul_loose(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_REDUCE_BRANCHFREE)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_REDUCE_BRANCHFREE)
+    // the branch-free form of the fused product below (kernels that interleave independent products at low occupancy): the same
+    // borrow-in, then the r01 borrow mask -- lo < h1' + c <= 2^32 still means "high word went from 0 to 0xFFFFFFFF"
+    const uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    const uint64_t p00 = (uint64_t)al * bl;
+    const uint64_t m1 = (uint64_t)al * bh + (p00 >> 32);
+    uint64_t m2, c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(m2), "=&s"(c) : "v"(ah), "v"(bl), "v"(m1));
+    const uint64_t hi = (uint64_t)ah * bh + (m2 >> 32);
+    uint32_t tl, th;
+    asm("v_subb_co_u32 %0, vcc, %2, %4, %5\n\tv_subbrev_co_u32 %1, vcc, 0, %3, vcc"
+        : "=&v"(tl), "=&v"(th)
+        : "v"((uint32_t)p00), "v"((uint32_t)m2), "v"((uint32_t)(hi >> 32)), "s"(c)
+        : "vcc");
+    uint64_t t0 = ((uint64_t)th << 32) | tl;
+    t0 -= (uint32_t)((int32_t)(th & ~(uint32_t)m2) >> 31);
+    uint64_t r, carry;
+    uint32_t wrap;
+    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, -1, %1" : "=&v"(r), "=&s"(carry), "=v"(wrap) : "v"((uint32_t)hi), "v"(t0));
+    return r + wrap;
+#elif defined(__HIP_DEVICE_COMPILE__)
     // gl_mul_wide + gl_reduce128 fused around the ONE carry of the product: m2 = ah bl + m1 may exceed 64 bits, and that bit
     // weighs 2^96 == -1.  Instead of materialising it (v_cndmask) and adding it into the high word, it stays in the SGPR pair the
     // multiply-add wrote it to and enters the reduction's first subtract as its borrow-in:

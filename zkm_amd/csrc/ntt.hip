@@ -64,7 +64,8 @@ __device__ __forceinline__ gl_t pow_lookup(const gl_t* __restrict__ tab, unsigne
 }
 
 // ------------------------------------------------------------------ field-primitive self test (parity / debug)
-// out[0][i] = a + b, out[1][i] = a - b, out[2][i] = a * 2^24, out[3][i] = a * 2^48, out[4][i] = a * 2^72, out[5][i] = a * b, all mod p and
+// out[0][i] = a + b, out[1][i] = a - b, out[2][i] = a * 2^24, out[3][i] = a * 2^48, out[4][i] = a * 2^72, out[5][i] = a * b (out[6]: the same
+// product from stark.hip's branch-free build of gl_mul_loose), all mod p and
 // canonical, for ANY 64-bit words a, b (also >= p): the loose-arithmetic primitives of the butterflies (gl_add_rr / gl_sub_rr with their
 // never-taken second-correction branches, gl_mul_pow2, gl_mul_loose) on exactly the inputs random data does not produce.
 __global__ void k_field_selftest(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, size_t n, uint64_t* __restrict__ out) {
@@ -81,12 +82,13 @@ __global__ void k_field_selftest(const uint64_t* __restrict__ a, const uint64_t*
 extern "C" int zkm_field_selftest(zkm_ctx* c, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, char** err) {
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
-        zkm_scratch da(c, n * 8), db(c, n * 8), dout(c, 6 * n * 8);
+        zkm_scratch da(c, n * 8), db(c, n * 8), dout(c, 7 * n * 8);
         ZKM_HIP_CHECK(hipMemcpyAsync(da.p, a, n * 8, hipMemcpyHostToDevice, c->stream));
         ZKM_HIP_CHECK(hipMemcpyAsync(db.p, b, n * 8, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_field_selftest, dim3((n + 255) / 256), dim3(256), 0, c->stream, da.as<uint64_t>(), db.as<uint64_t>(), n, dout.as<uint64_t>());
         ZKM_HIP_CHECK(hipGetLastError());
-        ZKM_HIP_CHECK(hipMemcpyAsync(out, dout.p, 6 * n * 8, hipMemcpyDeviceToHost, c->stream));
+        zkm_launch_mul_selftest_branchfree(c, da.as<uint64_t>(), db.as<uint64_t>(), n, dout.as<uint64_t>() + 6 * n);
+        ZKM_HIP_CHECK(hipMemcpyAsync(out, dout.p, 7 * n * 8, hipMemcpyDeviceToHost, c->stream));
         c->sync();
     } catch (const std::exception& e) {
         if (err) *err = strdup(e.what());

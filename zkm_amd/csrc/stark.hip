@@ -1057,6 +1057,16 @@ static void fri_blob_make(fri_blob_layout& y, const zkm_stark_config* cfg, unsig
     y.total = o + q * cfg->num_queries;
 }
 
+// parity / debug: a b mod p through THIS translation unit's gl_mul_loose (GL_REDUCE_BRANCHFREE), for zkm_field_selftest
+__global__ void k_mul_selftest_branchfree(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, size_t n, uint64_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gl_canon(gl_mul_loose(a[i], b[i]));
+}
+void zkm_launch_mul_selftest_branchfree(zkm_ctx* c, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    hipLaunchKernelGGL(k_mul_selftest_branchfree, dim3((n + 255) / 256), dim3(256), 0, c->stream, a, b, n, out);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
 extern "C" {
 
 size_t zkm_fri_proof_words(const zkm_stark_config* cfg, unsigned log_n, const size_t* oracle_cols, size_t noracles) {

@@ -121,6 +121,7 @@ inline bool zkm_is_device_ptr(const void* p) {
 
 // ---- hash.hip
 void zkm_launch_poseidon_permute(zkm_ctx*, gl_t* states, size_t k);
+void zkm_launch_mul_selftest_branchfree(zkm_ctx*, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);  // stark.hip
 void zkm_launch_keccakf(zkm_ctx*, uint64_t* states, size_t k);
 // leaf digests of a column-major matrix (row j across ncols columns of stride `col_stride` words)
 void zkm_launch_merkle_leaves(zkm_ctx*, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests);
