@@ -32,12 +32,13 @@ def test_large_ntt_matches_oracle(ctx, oracle, log_n):
         assert bad.size == 0, (log_n, inverse, shift, int(bad[0]), bad.size)
 
 
-@pytest.mark.parametrize("log_n,ncols", [(17, 262), (18, 5), (19, 2), (20, 3), (22, 1)])
+@pytest.mark.parametrize("log_n,ncols", [(15, 7), (17, 262), (18, 5), (19, 2), (20, 3), (21, 1), (22, 1)])
 def test_large_commit_matches_oracle(ctx, zkm, oracle, log_n, ncols):
     """from_values at bench-sized transforms: coefficients (all of them), cap, digest layers, sampled LDE rows /
     leaves / Merkle paths.  (17, 262) is the bench's column count on the 3-pass iNTT + 3-pass LDE plan;
     (20, 3) and (22, 1) are the bench's / config 4's row counts (LDE lengths 2^22 / 2^24); 18, 19, 20 are the three stage
-    counts (6, 7, 8) of the block-twiddle first LDE pass (k_lde_upper), 17 the plain DIF first pass (5 stages)."""
+    counts (6, 7, 8) of the block-twiddle first LDE pass (k_lde_upper), 15 and 17 the plain DIF first pass (3 and 5 stages), 21 the
+    2^13-element block kernel."""
     rng = np.random.default_rng(2000 + log_n)
     vals = rand_field(rng, ncols << log_n)
     b = zkm.PolynomialBatch.from_values(ctx, vals, ncols, log_n)

@@ -188,12 +188,14 @@ int zkm_dev_free(zkm_ctx* c, void* p) {
 }
 int zkm_dev_upload(zkm_ctx* c, void* dst, const void* src, size_t bytes, char** err) {
     ZKM_API_BEGIN
+    ZKM_HIP_CHECK(hipSetDevice(c->device));   // (the current device is per host thread; contexts are driven from worker threads)
     ZKM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     c->sync();
     ZKM_API_END(err)
 }
 int zkm_dev_download(zkm_ctx* c, void* dst, const void* src, size_t bytes, char** err) {
     ZKM_API_BEGIN
+    ZKM_HIP_CHECK(hipSetDevice(c->device));
     ZKM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     c->sync();
     ZKM_API_END(err)
