@@ -10,6 +10,7 @@
 //
 // Twiddles: per-stage tables tw[(1<<s) + j] = w_{2^(s+1)}^j, so the butterflies of one stage read
 // consecutive entries with consecutive lanes.
+#include <atomic>
 #include "zkm_internal.h"
 
 // ------------------------------------------------------------------ twiddle / power tables
@@ -504,13 +505,20 @@ static ntt_plan make_plan(unsigned L) {
     return pl;
 }
 
+// hipFuncSetAttribute is per device: remember which devices have the dynamic-LDS limit of a kernel raised (one bit per device; a
+// process may hold contexts on several GPUs, and several host threads may get here at once -- setting it twice is harmless)
+template <typename K>
+static void ntt_allow_big_lds(zkm_ctx* c, K kernel, std::atomic<uint64_t>& done) {
+    const uint64_t bit = (uint64_t)1 << (c->device & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.fetch_or(bit, std::memory_order_release);
+}
+
 template <int S, bool IN_A, bool OUT_A, int PRE, int POST, bool ZP = false, bool PF = true>
 static void launch_pass_t(zkm_ctx* c, const ntt_pass_args& a, size_t ntiles) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_pass<S, IN_A, OUT_A, PRE, POST, ZP, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    ntt_allow_big_lds(c, k_ntt_pass<S, IN_A, OUT_A, PRE, POST, ZP, PF>, lds_ok);
     int T = 1 << a.log_T;
     size_t shmem = ((size_t)1 << S) * a.tp * sizeof(gl_t);
     dim3 grid((unsigned)(ntiles * (a.ncoset > 1 ? a.ncoset : 1)), (a.ncols + a.cpb - 1) / a.cpb), block((unsigned)(((1 << S) >> 3) * T));
@@ -559,12 +567,12 @@ static void launch_pass(zkm_ctx* c, int S, ntt_pass_args a, size_t ntiles, const
 }
 
 static size_t ntt_max_tile_elems() {
-    static size_t v = 0;
-    if (!v) {
+    static const size_t v = [] {
         const char* e = getenv("ZKM_NTT_TILE");  // tuning knob: elements per workgroup tile (threads = tile / 8)
-        v = e ? (size_t)atol(e) : 2048;
-        if (v < 512 || v > 4096) v = 4096;  // threads = tile / 8 <= 512 (the kernel's launch bound)
-    }
+        size_t t = e ? (size_t)atol(e) : 2048;
+        if (t < 512 || t > 4096) t = 4096;      // threads = tile / 8 <= 512 (the kernel's launch bound)
+        return t;
+    }();
     return v;
 }
 static uint32_t pick_log_T(int S, size_t bdim) {
@@ -921,12 +929,9 @@ __global__ __launch_bounds__(512, ZKM_BLK12_WAVES) void k_ntt_blk12(ntt_big_args
 }
 
 static void launch_blk12(zkm_ctx* c, const ntt_big_args& a) {
-    static bool attr_done = false;
+    static std::atomic<uint64_t> lds_ok{0};
     const size_t shmem = (ZKM_BLK12_IMAGES * 8 * 576 + 7 * 64 + 7 * 8) * sizeof(gl_t);
-    if (!attr_done) {
-        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_blk12, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    ntt_allow_big_lds(c, k_ntt_blk12, lds_ok);
     uint32_t total = a.ncols * a.blocks_per_col;
     uint32_t grid = total < (uint32_t)c->num_cus * 8 ? total : (uint32_t)c->num_cus * 8;
     hipLaunchKernelGGL(k_ntt_blk12, dim3(grid), dim3(512), shmem, c->stream, a);
@@ -934,12 +939,9 @@ static void launch_blk12(zkm_ctx* c, const ntt_big_args& a) {
 
 template <int SA>
 static void launch_big_t(zkm_ctx* c, const ntt_big_args& a) {
-    static bool attr_done = false;
+    static std::atomic<uint64_t> lds_ok{0};
     size_t shmem = ((size_t)1 << SA) * 65 * sizeof(gl_t);
-    if (!attr_done) {
-        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_big<SA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    ntt_allow_big_lds(c, k_ntt_big<SA>, lds_ok);
     uint32_t total = a.ncols * a.blocks_per_col;
     uint32_t grid = total < (uint32_t)c->num_cus * 8 ? total : (uint32_t)c->num_cus * 8;
     hipLaunchKernelGGL((k_ntt_big<SA>), dim3(grid), dim3((1u << SA) * 8), shmem, c->stream, a);
@@ -1123,11 +1125,8 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
 
 template <int S>
 static void launch_lde_upper_t(zkm_ctx* c, const lde_upper_args& a) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_lde_upper<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    ntt_allow_big_lds(c, k_lde_upper<S>, lds_ok);
     const size_t shmem = 2 * 4096 * sizeof(gl_t);                             // two images of the 2^S x 2^(12-S) tile
     const uint32_t ntiles = (1u << a.S2) >> (12 - S);
     dim3 grid(ntiles * 4, (a.ncols + a.cpb - 1) / a.cpb);
