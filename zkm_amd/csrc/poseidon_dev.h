@@ -67,8 +67,14 @@ ZKM_CONST uint64_t ZKM_POSEIDON_ZERO12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0
 // term) and issues no faster than the v_mad_u64_u32 that takes the word directly.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define POSEIDON_OPAQUE(c) asm("" : "+s"(c))
+// A table pointer the optimiser cannot see through and cannot move: the constants behind it are (re)loaded with scalar loads where
+// they are used.  Without it the loop-invariant ones (first-round constants, the last fused group's) are hoisted out of the sponge
+// loop as ~100 SGPRs, spilled to VGPR lanes and read back with v_readlane -- 150 vector instructions per permutation for values the
+// scalar cache delivers for free.
+#define POSEIDON_OPAQUE_PTR(p) asm volatile("" : "+s"(p))
 #else
 #define POSEIDON_OPAQUE(c) ((void)0)
+#define POSEIDON_OPAQUE_PTR(p) ((void)0)
 #endif
 
 // x^7 on a loose value -> loose
@@ -215,8 +221,10 @@ enum { POSEIDON_OUT_ALL = 0, POSEIDON_OUT_CAPACITY = 1, POSEIDON_OUT_DIGEST = 2 
 // In: any uint64 words (loose).  `out` must be wave-uniform on the device (it selects code, not lanes).
 GL_HD void poseidon_permute_out(uint64_t s[12], int out) {
     POSEIDON_REGION("entry");
+    const uint64_t* rc0 = PC::ZKM_POSEIDON_RC;
+    POSEIDON_OPAQUE_PTR(rc0);
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add_loose(s[i], PC::ZKM_POSEIDON_RC[i]);
+    for (int i = 0; i < 12; i++) s[i] = gl_add_loose(s[i], rc0[i]);
 #pragma unroll 1
     for (int r = 0; r < 8; r++) {
         POSEIDON_REGION("full_sbox");
@@ -235,7 +243,11 @@ GL_HD void poseidon_permute_out(uint64_t s[12], int out) {
                 s[0] = poseidon_sbox7(s[0]);
             }
             POSEIDON_REGION("partial_tail");
-            poseidon_partial_group<2>(s, PC::ZKM_POSEIDON_FUSED_C1[7], 0, PC::ZKM_POSEIDON_FUSED_C3[7]);  // MDS of rounds 24, 25
+            const uint64_t* fc1 = PC::ZKM_POSEIDON_FUSED_C1;
+            const uint64_t* fc3 = PC::ZKM_POSEIDON_FUSED_C3[7];
+            POSEIDON_OPAQUE_PTR(fc1);
+            POSEIDON_OPAQUE_PTR(fc3);
+            poseidon_partial_group<2>(s, fc1[7], 0, fc3);  // MDS of rounds 24, 25
         } else if (r == 7 && out != POSEIDON_OUT_ALL) {
             POSEIDON_REGION("last_mds_rows");
             if (out == POSEIDON_OUT_CAPACITY) poseidon_mds_add<false, 8, 12>(s, nullptr);
