@@ -802,15 +802,17 @@ __global__ __launch_bounds__((1 << SA) * 8) void k_ntt_big(ntt_big_args p) {
     }
 }
 
-// ---- the 2^12-element block with ONE workgroup barrier: 3 + 9 stages.
+// ---- the 2^12-element block with ONE exchange across waves: 3 + 9 stages.
 // Round 1 (stages 11, 10, 9) works on the words a thread loads anyway (tid + 512 j: 512 B per wave instruction); what is left
 // are eight independent 2^9-point problems, and 2^9 words are exactly what ONE wave holds (64 lanes x 8 registers): after the
 // single cross-wave exchange every wave owns a sub-block and runs stages 8 .. 0 on its own -- rounds of three stages with the
 // register-resident bits (8,7,6), (5,4,3), (2,1,0), exchanged through the wave's own LDS region, which needs no workgroup
 // barrier (a wave's LDS instructions execute in order); the last round's twiddles are powers of two.  Word t of a sub-block
 // lives at A(t) = (t + 8 (t >> 6)) ^ ((t >> 3) & 7): conflict-free for all four access patterns, reads (32-lane groups, 64-bit
-// banks mod 32) and writes (16-lane groups, mod 16) alike.  Two LDS images alternate between blocks, so the next block's round-1
-// stores never wait for this block's readers: four LDS round trips and one barrier per block (k_ntt_big<6>: five and nine).
+// banks mod 32) and writes (16-lane groups, mod 16) alike.  Four LDS round trips and two workgroup barriers per block (one
+// before the round-1 stores: the previous block's readers must be done; one after them) against five and nine in k_ntt_big<6>.
+// 78 VGPRs and 41 KB of LDS: three workgroups per CU, whose waves cover each other's memory latency -- measured better than two
+// workgroups with a register prefetch of the next block and two alternating LDS images (5.17 vs 5.49 ms for 262 x 2^22).
 #define ZKM_WAVE_SYNC()                                      \
     do {                                                     \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -818,13 +820,7 @@ __global__ __launch_bounds__((1 << SA) * 8) void k_ntt_big(ntt_big_args p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
-#ifndef ZKM_BLK12_WAVES
-#define ZKM_BLK12_WAVES 4
-#endif
-#ifndef ZKM_BLK12_IMAGES
-#define ZKM_BLK12_IMAGES 2
-#endif
-__global__ __launch_bounds__(512, ZKM_BLK12_WAVES) void k_ntt_blk12(ntt_big_args p) {
+__global__ __launch_bounds__(512, 6) void k_ntt_blk12(ntt_big_args p) {
     extern __shared__ __attribute__((aligned(16))) gl_t lds[];
     constexpr int NT = 512, SB = 576;
     using R = ntt_round<3, 0>;
@@ -834,10 +830,10 @@ __global__ __launch_bounds__(512, ZKM_BLK12_WAVES) void k_ntt_blk12(ntt_big_args
     const int a1 = A(tid);                                        // round-1 store: word tid of sub-block j
 
     // round-1 twiddles (one set per thread) stay in registers; those of rounds 2 and 3 only depend on the lane (64 x 7 and 8 x 7
-    // words) and are re-read from LDS when needed -- 28 VGPRs that decide between one and two workgroups per CU
+    // words) and are re-read from LDS when needed -- 28 VGPRs
     gl_t w1[7];
     R::load_tw(w1, p.tw, 0, 9, (size_t)tid);
-    gl_t* const twl = lds + ZKM_BLK12_IMAGES * 8 * SB;
+    gl_t* const twl = lds + 8 * SB;
     if (tid < 64) {
         gl_t w[7];
         R::load_tw(w, p.tw, 0, 6, (size_t)tid);
@@ -853,42 +849,25 @@ __global__ __launch_bounds__(512, ZKM_BLK12_WAVES) void k_ntt_blk12(ntt_big_args
 
     const uint32_t total = p.ncols * p.blocks_per_col;
     auto block_ptr = [&](uint32_t blk) { return p.data + (size_t)(blk / p.blocks_per_col) * p.cs + ((size_t)(blk % p.blocks_per_col) << 12); };
-    gl_t nx[8];
-    uint32_t blk = blockIdx.x;
-    if (blk < total) {
-        const gl_t* src = block_ptr(blk);
-#pragma unroll
-        for (int j = 0; j < 8; j++) nx[j] = src[tid + NT * j];
-    }
-    int buf = 0;
-    for (; blk < total; blk += gridDim.x, buf ^= (ZKM_BLK12_IMAGES - 1)) {
+    for (uint32_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
         gl_t* const dst = block_ptr(blk);
-        gl_t* const img = lds + buf * (8 * SB);
         gl_t x[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = nx[j];
-#if !defined(ZKM_EXP_NOMEM)
-        if (blk + gridDim.x < total) {
-            const gl_t* src = block_ptr(blk + gridDim.x);
-#pragma unroll
-            for (int j = 0; j < 8; j++) nx[j] = src[tid + NT * j];
-        }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 8; j++) x[j] = dst[tid + NT * j];
         R::compute(x, w1);                                        // stages 11, 10, 9
-        if (ZKM_BLK12_IMAGES == 1) NTT_SYNC();                    // (single image: the previous block's readers must be done)
+        NTT_SYNC();                                               // the previous block's readers are done with the image
 #pragma unroll
-        for (int j = 0; j < 8; j++) img[j * SB + a1] = x[j];
-        NTT_SYNC();                                               // the only workgroup barrier of the block
-        // per-lane LDS offsets of the wave-local rounds, recomputed per block from an opaque copy of the lane id: kept live across the
-        // loop they would cost ~20 VGPRs and push the kernel over the 128 that two workgroups per CU allow
+        for (int j = 0; j < 8; j++) lds[j * SB + a1] = x[j];
+        NTT_SYNC();
+        // per-lane LDS offsets of the wave-local rounds, recomputed per block from an opaque copy of the lane id (kept live across
+        // the loop they would cost ~20 VGPRs)
         int l = lane;
         asm volatile("" : "+v"(l));
         const int l7 = l & 7, h3 = l >> 3;
         const int a2 = A(l);                                      // rounds 2 / out: words l + 64 j at a2 + 72 j
         const int a3 = 72 * h3;                                   // round 3: words 64 h3 + 8 j + l7 at a3 + 8 j + (l7 ^ j)
         const int a4 = 8 * l + 8 * h3;                            // round 4: words 8 l + j at a4 + (j ^ l7)
-        gl_t* const sub = img + wv * SB;
+        gl_t* const sub = lds + wv * SB;
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = sub[a2 + 72 * j];
         gl_t w[7];
@@ -930,10 +909,10 @@ __global__ __launch_bounds__(512, ZKM_BLK12_WAVES) void k_ntt_blk12(ntt_big_args
 
 static void launch_blk12(zkm_ctx* c, const ntt_big_args& a) {
     static std::atomic<uint64_t> lds_ok{0};
-    const size_t shmem = (ZKM_BLK12_IMAGES * 8 * 576 + 7 * 64 + 7 * 8) * sizeof(gl_t);
+    const size_t shmem = (8 * 576 + 7 * 64 + 7 * 8) * sizeof(gl_t);
     ntt_allow_big_lds(c, k_ntt_blk12, lds_ok);
     uint32_t total = a.ncols * a.blocks_per_col;
-    uint32_t grid = total < (uint32_t)c->num_cus * 8 ? total : (uint32_t)c->num_cus * 8;
+    uint32_t grid = total < (uint32_t)c->num_cus * 12 ? total : (uint32_t)c->num_cus * 12;
     hipLaunchKernelGGL(k_ntt_blk12, dim3(grid), dim3(512), shmem, c->stream, a);
 }
 
