@@ -253,3 +253,31 @@ def test_generic_fri_instance_equals_the_stark_instance(ctx, zkm, oracle):
         ctx.fri_prove([ab, qb], [((P, 0), [(0, 0)])], zkm.challenger_new())          # non-canonical point
     for b in (tb, ab, qb):
         b.free()
+
+
+def test_concurrent_contexts_are_bit_exact(ctx, zkm):
+    """bench.py's throughput mode: k contexts on one GPU, one host thread each, proving independent segments side by side
+    (zkm_amd.dist.run_workers).  Every proof made that way must equal the proof the same segment gets from one context working
+    alone -- shared traces are read-only, twiddle / power tables, allocator, stream and transcript are per context."""
+    from zkm_amd.dist import run_workers
+    log_n = 14
+    n = 1 << log_n
+    seeds = list(range(300, 310))
+    traces = {s: ctx.poseidon_trace(s, n - 7, log_n) for s in seeds}
+    aux_host, nh = fake_ctl_aux(n)
+    aux = ctx.alloc(aux_host.size).upload(aux_host)
+    alone = {s: ctx.prove_single_table(traces[s], log_n, aux, nh) for s in seeds}
+    ctx.synchronize()
+    workers = [zkm.Context(0) for _ in range(3)]
+    try:
+        for rep in range(2):       # second round: warm allocators, different interleaving
+            got = run_workers(lambda s, w: workers[w].prove_single_table(traces[s], log_n, aux, nh), seeds, len(workers))
+            assert sorted(got) == seeds
+            for s in seeds:
+                assert (got[s] == alone[s]).all(), (rep, s)
+    finally:
+        for w in workers:
+            w.close()
+    for t in traces.values():
+        t.free()
+    aux.free()
