@@ -182,6 +182,27 @@ def test_prove_segment_uses_the_shipped_all_stark(ctx, zkm, oracle):
 
 
 @pytest.mark.gpu
+def test_segments_proven_side_by_side_are_bit_exact(ctx, zkm):
+    """Twelve-table segments from three contexts working at the same time (host traces: each call uploads, commits and proves)
+    equal the segment proof of one context working alone."""
+    import os
+    from zkm_amd.dist import run_workers
+    seg = np.load(os.path.join(os.path.dirname(__file__), "golden", "segment12.npz"))
+    log_n = [int(x) for x in seg["log_n"]]
+    traces = [seg["t%d" % i] for i in range(12)]
+    want, wchal, woffs = ctx.prove_segment(traces, log_n, public_values=[1, 2, 3])
+    workers = [zkm.Context(0) for _ in range(3)]
+    try:
+        got = run_workers(lambda s, w: workers[w].prove_segment(traces, log_n, public_values=[1, 2, 3]), range(6), len(workers))
+    finally:
+        for w in workers:
+            w.close()
+    for s in range(6):
+        proofs, chal, offs = got[s]
+        assert offs == woffs and (chal == wchal).all() and (proofs == want).all(), s
+
+
+@pytest.mark.gpu
 def test_gpu_proof_blob_walks_through_the_layout(ctx, zkm, oracle):
     """N4 on a GPU-made proof: every field zkm_proof_get_layout / _query_layout report is where the batches say it is -- caps equal
     the commitments' caps, every query round's leaves and Merkle paths authenticate against them, FRI layer evals chain."""
