@@ -238,5 +238,10 @@ def test_gpu_proof_blob_walks_through_the_layout(ctx, zkm, oracle):
     rows = tb.lde_rows(5, 2, 7)
     for i in range(7):
         assert (rows[i] == tb.lde_row((5 + i) * 2)).all()
+    # out-of-range and wrapping arguments are refused, not wrapped around
+    N = 1 << lde_bits
+    assert (tb.lde_rows(N // 2 - 3, 2, 3)[2] == tb.lde_row(N - 2)).all()
+    for start, step, count in ((N // 2 - 2, 2, 3), (N, 1, 1), (0, 0, 1), ((1 << 64) - 1, 1, 2), (1, 1, (1 << 64) - 1)):
+        assert tb.ctx.L.zkm_batch_lde_rows(tb.h, start, step, count, None) != 0, (start, step, count)
     tb.free()
     ab.free()

@@ -439,9 +439,12 @@ int zkm_batch_lde_rows(const zkm_batch* b, size_t index_start, size_t step, size
     // get_lde_values_packed(index_start, step) for `count` consecutive indices (prover.rs:687, 723-748): row i of the output is
     // get_lde_values(index_start + i, step) = leaves[reverse_bits((index_start + i) * step)], ncols words; out host or device
     if (!count) return 0;
-    if (step == 0 || (index_start + count - 1) > (b->N() - 1) / step) return 1;
+    if (step == 0) return 1;
+    const size_t last_ok = (b->N() - 1) / step;                     // largest index whose (index * step) is a row of the LDE
+    if (index_start > last_ok || count - 1 > last_ok - index_start) return 1;   // (no wrap-around for hostile arguments)
     zkm_ctx* c = b->ctx;
     try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
         bool dev = zkm_is_device_ptr(out);
         zkm_scratch tmp(c, dev ? 8 : count * b->ncols * sizeof(gl_t));
         gl_t* d = dev ? out : tmp.as<gl_t>();
