@@ -61,7 +61,7 @@ def segment_rate(ctx, log_cycles, reps=3):
             "note": "twelve tables, fifteen lookups, one zkm_prove_segment call; traces device-resident, tiled test segment (timing only)"}
 
 
-def concurrent_segment_rate(device, log_cycles, nctx, reps=3):
+def concurrent_segment_rate(device, log_cycles, nctx, reps=6):
     """`nctx` host threads, each with its OWN context (own stream, allocator, transcript) on the same GPU, proving independent
     segments at the same time: in the launch-bound regime of small segments the GPU interleaves their kernels, so the per-level
     Merkle / per-layer FRI latencies of one segment are filled with the work of the others.  Segments are independent proofs
@@ -92,7 +92,7 @@ def concurrent_segment_rate(device, log_cycles, nctx, reps=3):
         for b in bufs:
             b.free()
         c.close()
-    return {"contexts": nctx, "segments_per_s": nctx * reps / wall, "ms_per_segment_amortised": wall * 1e3 / (nctx * reps)}
+    return {"contexts": nctx, "segments_per_context": reps, "segments_per_s": nctx * reps / wall, "ms_per_segment_amortised": wall * 1e3 / (nctx * reps)}
 
 
 def small_segment_rate(ctx, device=0):
