@@ -98,7 +98,7 @@ def concurrent_segment_rate(device, log_cycles, nctx, reps=6):
 def small_segment_rate(ctx, device=0):
     out = segment_rate(ctx, 16)
     try:
-        out["concurrent"] = [concurrent_segment_rate(device, 16, k) for k in (2, 4)]
+        out["concurrent"] = [concurrent_segment_rate(device, 16, k) for k in (2, 4, 8)]
     except Exception as e:  # the single-context figure stands on its own
         out["concurrent_error"] = str(e)
     return out
