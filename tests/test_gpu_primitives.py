@@ -101,6 +101,21 @@ def test_commit_matches_oracle(ctx, zkm, oracle, log_n, ncols):
     b2.free()
 
 
+@pytest.mark.parametrize("ncols", [5, 8, 9, 15, 16, 17, 24, 31])
+def test_leaf_sponge_modes_at_chunk_boundaries(ctx, zkm, oracle, ncols):
+    """The one-leaf-per-lane kernel (more than 2^14 LDE rows) only computes what the sponge carries on: capacity rows after a whole
+    chunk that is followed by another, all twelve before a ragged chunk, digest rows at the end.  Column counts on either side of
+    the multiples of 8 take every combination (8 and 16: the last whole chunk is the end; 9, 17: a ragged chunk of one follows)."""
+    log_n = 13
+    rng = np.random.default_rng(4000 + ncols)
+    vals = rand_field(rng, ncols << log_n)
+    b = zkm.PolynomialBatch.from_values(ctx, vals, ncols, log_n)
+    ob = oracle.batch_from_values(vals, ncols, log_n)
+    assert (b.digest_layer(0) == ob.digest_layer(0)).all()
+    assert (b.cap() == ob.cap()).all()
+    b.free()
+
+
 def test_commit_other_rate_and_cap(ctx, zkm, oracle):
     rng = np.random.default_rng(77)
     log_n, ncols = 6, 11
