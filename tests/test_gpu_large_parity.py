@@ -5,6 +5,8 @@ full 2^16-row proof (BASELINE config 1 size) were only round-tripped / verifier-
 with the oracle element by element.  The oracle NTT is O(n log n) (oracle/commit.c), a 2^22 transform takes
 well under a second per column on the host.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -72,6 +74,31 @@ def test_proof_is_bit_exact_2_16(ctx, zkm, oracle):
     assert bad.size == 0, "first differing proof word: %d" % bad[0]
     assert oracle.verify(got, 4, [1, 1]) == 0
     trace_dev.free()
+
+
+def test_proof_is_bit_exact_2_20(ctx, zkm, oracle):
+    """The bench workload itself (BASELINE config 2: PoseidonStark 262 x 2^20, the proof bench.py times): GPU proof bytes == oracle
+    proof bytes, every word.  The oracle needs about a minute on the host cores (64 OpenMP threads) and ~30 GB of host memory; the
+    trace is compared through a checksum only (the oracle regenerates it from the seed)."""
+    log_n = 20
+    n = 1 << log_n
+    old = oracle.get_threads()
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    try:
+        trace_dev = ctx.poseidon_trace(100, n, log_n)             # bench.py's segment 0 (seed 100)
+        trace = trace_dev.download()
+        want_trace = oracle.poseidon_trace(100, n, log_n)
+        assert int(np.bitwise_xor.reduce(trace)) == int(np.bitwise_xor.reduce(want_trace)) and (trace[::4099] == want_trace[::4099]).all()
+        del want_trace
+        aux = np.zeros(4 * n, dtype=np.uint64)
+        got = ctx.prove_single_table(trace_dev, log_n, aux, [1, 1])
+        want = oracle.prove(trace, log_n, aux, [1, 1])
+        assert got.size == want.size
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "first differing proof word: %d of %d" % (bad[0], got.size)
+        trace_dev.free()
+    finally:
+        oracle.set_threads(old)
 
 
 def test_prove_openings_bit_exact_2_17(ctx, zkm, oracle):
