@@ -182,6 +182,37 @@ def test_prove_segment_uses_the_shipped_all_stark(ctx, zkm, oracle):
 
 
 @pytest.mark.gpu
+def test_segment_at_2_16_cycle_heights_is_bit_exact(ctx, zkm, oracle):
+    """The reference's default segment size (2^16 cycles, emulator/src/utils.rs:6): the committed twelve-table test segment tiled to the
+    table heights tools/bench_segment.py times (CPU and Arithmetic 2^16, Memory 2^17, precompile tables 2^6 .. 2^13), proven by
+    zkm_prove_segment and by the oracle's prove_with_traces -- all twelve proof blobs and the CTL challenges word for word.  (Tiled
+    rows are not a valid witness across the seams; neither prover looks at validity.)"""
+    import os
+    from zkm_amd import tables as T
+    from tools.bench_segment import HEIGHTS
+    seg = np.load(os.path.join(os.path.dirname(__file__), "golden", "segment12.npz"))
+    base = [int(x) for x in seg["log_n"]]
+    traces, log_n = [], []
+    for i in range(12):
+        w = T.WIDTH[T.TABLE_ENUM_ORDER[i]]
+        L = max(HEIGHTS[16][i], base[i])
+        traces.append(np.ascontiguousarray(np.tile(seg["t%d" % i].reshape(w, -1), (1, 1 << (L - base[i])))).reshape(-1))
+        log_n.append(L)
+    got, chal, offs = ctx.prove_segment(traces, log_n, public_values=[1, 2, 3])
+    ctl_tables, ctls = T.all_cross_table_lookups()
+    tables = [(T.TABLE_ENUM_ORDER[i], traces[i], T.WIDTH[T.TABLE_ENUM_ORDER[i]], log_n[i], ctl_tables[i]) for i in range(12)]
+    old = oracle.get_threads()
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    try:
+        ref, rchal, roffs = oracle.prove_with_traces(tables, ctls, public_values=[1, 2, 3])
+    finally:
+        oracle.set_threads(old)
+    assert list(offs) == list(roffs) and (chal == rchal).all()
+    bad = np.nonzero(got != ref)[0]
+    assert bad.size == 0, "first differing word %d (table %d)" % (bad[0], int(np.searchsorted(offs, bad[0], side="right")) - 1)
+
+
+@pytest.mark.gpu
 def test_segments_proven_side_by_side_are_bit_exact(ctx, zkm):
     """Twelve-table segments from three contexts working at the same time (host traces: each call uploads, commits and proves)
     equal the segment proof of one context working alone."""
