@@ -101,18 +101,27 @@ def test_proof_is_bit_exact_2_20(ctx, zkm, oracle):
         oracle.set_threads(old)
 
 
-def test_prove_openings_bit_exact_2_17(ctx, zkm, oracle):
-    """FRI on the 3-pass plans (final polynomial 2^17 coefficients, LDE 2^19): GPU bytes == oracle bytes."""
-    log_n = 17
-    rng = np.random.default_rng(4017)
+@pytest.mark.parametrize("log_n", [17, 22])
+def test_prove_openings_bit_exact(ctx, zkm, oracle, log_n):
+    """FRI on the 3-pass plans (final polynomial 2^17 coefficients, LDE 2^19) and BASELINE config 4 literally (13 + 4 + 4 polynomials of
+    2^22 coefficients, LDE 2^24, folds [4,4,4,4,4], 4 final coefficients): GPU bytes == oracle bytes."""
+    rng = np.random.default_rng(4000 + log_n)
     n = 1 << log_n
     tv, av, qc = (rng.integers(0, P, k * n, dtype=np.uint64) for k in (13, 4, 4))
-    otb, oab, oqb = oracle.batch_from_values(tv, 13, log_n), oracle.batch_from_values(av, 4, log_n), oracle.batch_from_coeffs(qc, 4, log_n)
+    old = oracle.get_threads()
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    try:
+        otb, oab, oqb = oracle.batch_from_values(tv, 13, log_n), oracle.batch_from_values(av, 4, log_n), oracle.batch_from_coeffs(qc, 4, log_n)
+        want = oracle.prove_openings(otb, oab, oqb, 2)
+    finally:
+        oracle.set_threads(old)
     tb, ab = zkm.PolynomialBatch.from_values(ctx, tv, 13, log_n), zkm.PolynomialBatch.from_values(ctx, av, 4, log_n)
     qb = zkm.PolynomialBatch.from_coeffs(ctx, qc, 4, log_n)
-    want = oracle.prove_openings(otb, oab, oqb, 2)
+    assert (tb.cap() == otb.cap()).all() and (qb.cap() == oqb.cap()).all()
     got = ctx.prove_openings(tb, ab, qb, 2)
-    assert (got == want).all()
+    assert got.size == want.size
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing word %d of %d" % (bad[0], got.size)
     for b in (tb, ab, qb):
         b.free()
 
