@@ -105,8 +105,20 @@ def test_config5_sponge_table_2_20_rows_witness_and_commit(ctx, zkm, oracle):
             d = oracle.two_to_one(s, d) if idx & 1 else oracle.two_to_one(d, s)
             idx >>= 1
         assert (cap[idx] == d).all()
-    # natural LDE row 0 is the evaluation at the coset shift g: sum_k c_k g^k for one column
-    coeffs = None
+    # the whole table and the whole commitment against the oracle: every trace word, then the cap (which covers every LDE word
+    # and every hash of the tree) and a sample of coefficient columns
+    import os
+    old = oracle.get_threads()
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    try:
+        trace = buf.download()
+        want, wused = oracle.keccak_sponge_trace(data, off, meta, log_n)
+        assert wused == used and (trace == want).all()
+        del want
+        ob = oracle.batch_from_values(trace, W, log_n)
+        assert (b.cap() == ob.cap()).all()
+    finally:
+        oracle.set_threads(old)
     b.free()
     buf.free()
 
