@@ -49,6 +49,11 @@ if "FETCH_SIZE" in ml and "WRITE_SIZE" in ml:
         latest["k_merkle_leaves"]["valu_insts_per_wave"] = ml["SQ_INSTS_VALU"]["max"] / ml["SQ_WAVES"]["max"]
     if "GRBM_GUI_ACTIVE" in ml:
         latest["k_merkle_leaves"]["grbm_gui_active_max"] = ml["GRBM_GUI_ACTIVE"]["max"]
+        st = res.get("k_merkle_leaves", {}).get("stats", {})
+        if st.get("max_ns"):
+            # GPU cycles of the launch (the counter is summed over the 8 XCDs) over its duration in the kernel-trace pass: the clock the
+            # kernel really ran at, which is what its issue fractions should be taken against (nominal: 2.4 GHz)
+            latest["k_merkle_leaves"]["clock_ghz_measured"] = ml["GRBM_GUI_ACTIVE"]["max"] / 8 / st["max_ns"]
 is_ntt = lambda k: "k_ntt_" in k or "k_lde_upper" in k   # every NTT / LDE kernel of ntt.hip
 fetch = sum(v["pmc"]["FETCH_SIZE"]["sum"] for k, v in res.items() if is_ntt(k) and "FETCH_SIZE" in v.get("pmc", {}))
 write = sum(v["pmc"]["WRITE_SIZE"]["sum"] for k, v in res.items() if is_ntt(k) and "WRITE_SIZE" in v.get("pmc", {}))
