@@ -32,3 +32,28 @@ def ctx(zkm):
     c = zkm.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(scope="session")
+def oracle_proof_2_20(oracle):
+    """The CPU oracle's proof of the bench workload (PoseidonStark 262 x 2^20, witness seed 100 = segment 0 of bench.py / BASELINE
+    configs 2 and 3), computed ONCE per session (about a minute on 64 host threads, ~30 GB of host memory) and shared by the tests
+    that compare GPU proofs with it.  A dict: trace xor-checksum and sampled words, the proof words, the oracle's wall and stage seconds."""
+    import time
+    import numpy as np
+    log_n = 20
+    n = 1 << log_n
+    old = oracle.get_threads()
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    try:
+        trace = oracle.poseidon_trace(100, n, log_n)
+        aux = np.zeros(4 * n, dtype=np.uint64)
+        t0 = time.time()
+        proof, stages = oracle.prove(trace, log_n, aux, [1, 1], want_stages=True)
+        secs = time.time() - t0
+    finally:
+        oracle.set_threads(old)
+    out = {"xor": int(np.bitwise_xor.reduce(trace)), "sample": trace[::4099].copy(), "proof": proof, "seconds": secs, "stage_s": stages,
+           "threads": min(64, os.cpu_count() or 1)}
+    del trace
+    return out

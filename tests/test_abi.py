@@ -70,6 +70,35 @@ def test_all_stark_ctl_inc_is_current():
     assert m.render() == open(os.path.join(ROOT, "zkm_amd", "csrc", "all_stark_ctl.inc")).read(), "run tools/gen_all_stark_ctl.py"
 
 
+def test_all_stark_looking_side_order_is_the_references():
+    """The looking sides of every lookup come in the order the reference chains them (all_stark.rs): a consumer that indexes them
+    positionally (verify_cross_table_lookups, the recursion circuits) must see the same sequence.  ctl_memory (:479-542): the CPU's
+    NUM_GP_CHANNELS memory channels, then KeccakSponge (136 rate bytes), PoseidonSponge (32), ShaExtendSponge, ShaCompressSponge,
+    ShaCompress (4); ctl_logic (:340-477): CPU, KeccakSponge, ShaExtend, ShaCompress."""
+    from zkm_amd import tables as T
+    AR, CPU, PO, PS, KK, KS, SE, SES, SC, SCS, LO, ME = range(12)
+    _, ctls = T.all_cross_table_lookups()
+    assert len(ctls) == 15
+
+    def runs(sides):
+        out = []
+        for t, _ in sides:
+            if out and out[-1][0] == t:
+                out[-1][1] += 1
+            else:
+                out.append([t, 1])
+        return [tuple(r) for r in out]
+    mem_looking, mem_looked = ctls[14]
+    assert mem_looked[0] == ME
+    r = runs(mem_looking)
+    assert [t for t, _ in r] == [CPU, KS, PS, SES, SCS, SC], r
+    assert dict(r)[KS] == 136 and dict(r)[PS] == 32 and dict(r)[SC] == 4
+    logic_looking, logic_looked = ctls[13]
+    assert logic_looked[0] == LO and [t for t, _ in runs(logic_looking)] == [CPU, KS, SE, SC]
+    # the looked tables of the fifteen lookups, in all_cross_table_lookups() order (all_stark.rs:137-155)
+    assert [looked[0] for _, looked in ctls] == [AR, PS, PO, PO, KS, KK, KK, SES, SE, SE, SCS, SC, SC, LO, ME]
+
+
 def test_prove_segment_sizing_and_descriptors(zkm, oracle):
     """zkm_prove_segment sizes a whole AllStark segment without a GPU, from the description inside the library; it agrees with the
     oracle's sizing of the same tables + lookups built through zkm_amd/tables.py, and the exported lookups are the fifteen of

@@ -82,6 +82,9 @@ BENCH_WORKER = textwrap.dedent("""
     torch.cuda.is_available = lambda: True
     torch.cuda.set_device = lambda d: None
     torch.cuda.synchronize = lambda: None
+    torch.cuda.device_count = lambda: 2
+    torch.cuda.current_device = lambda: 0
+    torch.cuda.mem_get_info = lambda d=None: (200 << 30, 288 << 30)
     torch.cuda.get_device_properties = lambda d: types.SimpleNamespace(multi_processor_count=256)
     real_init = zd.init
     zd.init = lambda backend=None: real_init("gloo")
@@ -119,6 +122,8 @@ def test_bench_sharding_path_two_rank_gloo(tmp_path, nctx):
     j = json.loads(line[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["segments_total"] == 7 and j["config"]["segments_per_gpu"] == 4
     assert j["config"]["contexts_per_gpu"] == nctx and j["single_context"]["ms_per_step"] > 0
+    assert j["timed_segments"] == 7 and j["timed_segments_per_gpu"] == 4 and j["config"]["distinct_traces_per_gpu"] == 4
+    assert j["config"]["proofs_gathered_on_rank0"] == 7            # gathered over the process group after the clock stopped
     assert j["value"] > 0 and abs(j["value"] * j["ms_per_step"] * 4 / 7 / 1e3 - 1) < 1e-6   # value = total / elapsed, ms_per_step = elapsed / 4
 
 
@@ -145,3 +150,46 @@ def test_run_workers_queue_and_errors():
         return s
     with pytest.raises(ValueError, match="segment 5"):
         run_workers(bad, range(50), 3)
+
+
+def test_one_rank_per_gpu_is_enforced(monkeypatch):
+    """bench.py refuses a world that does not fit the visible GPUs (two ranks sharing a device would fake a scaling curve)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    from zkm_amd import dist as zd
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert zd.check_gpus(2, 1) == 1
+    with pytest.raises(SystemExit, match="ranks on this node but 2 GPUs"):
+        zd.check_gpus(8, 3)
+    assert zd.check_gpus(8, 3, share_gpu=True) == 0               # the single-GPU rehearsal puts every rank on device 0
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    with pytest.raises(SystemExit, match="no GPU visible"):
+        zd.check_gpus(1, 0)
+
+
+def test_cpu_pinning_splits_the_allowed_cpus(monkeypatch):
+    """Without a readable GPU topology every local rank gets its own even slice of the allowed CPUs (and with one, the GPU's NUMA
+    node); worker threads started afterwards inherit the mask."""
+    sys.path.insert(0, ROOT)
+    import torch
+    from zkm_amd import dist as zd
+    allowed = sorted(os.sched_getaffinity(0))
+    set_to = {}
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: set_to.__setitem__("cpus", list(cpus)))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    seen = []
+    for r in range(2):
+        info = zd.pin_to_gpu(r, 2)
+        assert info["pinned"] and info["how"] == "even-split"
+        seen.append(set(set_to["cpus"]))
+        assert seen[-1] <= set(allowed) and seen[-1]
+    if len(allowed) >= 2:
+        assert not (seen[0] & seen[1])
+    # a GPU on NUMA node with known CPUs: that node's CPUs (intersected with the allowed set)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(zd, "gpu_numa_cpus", lambda d: allowed[:max(1, len(allowed) // 2)])
+    info = zd.pin_to_gpu(0, 1)
+    assert info["pinned"] and info["how"] == "numa" and set_to["cpus"] == allowed[:max(1, len(allowed) // 2)]
+    assert zd._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]

@@ -45,6 +45,7 @@ void* zkm_ctx::alloc(size_t bytes) {
 }
 void zkm_ctx::trim() {
     (void)hipStreamSynchronize(stream);  // cached blocks may still be in use by queued kernels
+    if (copy_stream) (void)hipStreamSynchronize(copy_stream);  // ... or be the target of an upload still in flight
     for (auto& kv : free_blocks) (void)hipFree(kv.second);
     free_blocks.clear();
 }
@@ -74,13 +75,17 @@ hipEvent_t zkm_ctx::get_event() {
     ZKM_HIP_CHECK(hipEventCreate(&e));
     return e;
 }
-void zkm_ctx::prof_begin(const char* name) {
+size_t zkm_ctx::prof_begin(const char* name) {
     zkm_prof_rec r{name, get_event(), get_event()};
     ZKM_HIP_CHECK(hipEventRecord(r.start, stream));
     prof.push_back(r);
     prof_agg_valid = false;
+    return prof.size() - 1;
 }
-void zkm_ctx::prof_end() { ZKM_HIP_CHECK(hipEventRecord(prof.back().stop, stream)); }
+void zkm_ctx::prof_end(size_t idx) {
+    // (a destructor must not throw: a failed record leaves the pair unmeasured, prof_aggregate reports 0 ms for it)
+    if (idx < prof.size()) (void)hipEventRecord(prof[idx].stop, stream);
+}
 
 // Stark::lookups() of the tables with constraint kernels.  Memory: RANGE_CHECK (10) looked up in COUNTER (11) with
 // FREQUENCIES (12), memory_stark.rs:476-483.
@@ -297,29 +302,42 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
         // Each chunk is staged in the LDE region of its own columns (or lands in dev_values), so there is no buffer to recycle.
         if (!c->copy_stream) ZKM_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         const size_t nchunks = (ncols + CH - 1) / CH;
-        std::vector<hipEvent_t> ev(nchunks);
+        std::vector<hipEvent_t> ev;
+        ev.reserve(nchunks + 1);
         zkm_scratch state(c, 12 * N * sizeof(gl_t));
-        hipEvent_t start = c->get_event();
-        ZKM_HIP_CHECK(hipEventRecord(start, c->stream));            // the LDE buffer may still be in use by queued work of a freed batch
-        ZKM_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, start, 0));
-        for (size_t k = 0; k < nchunks; k++) {
-            size_t c0 = k * CH, nc = std::min(CH, ncols - c0);
-            gl_t* dst = dev_values ? dev_values + c0 * n : b->lde + c0 * N;
-            ZKM_HIP_CHECK(hipMemcpyAsync(dst, src + c0 * n, nc * n * sizeof(gl_t), hipMemcpyHostToDevice, c->copy_stream));
-            ev[k] = c->get_event();
-            ZKM_HIP_CHECK(hipEventRecord(ev[k], c->copy_stream));
+        // Every exit path -- also a HIP error in the middle of the loop -- drains BOTH streams before the sponge state, the events
+        // and (in the callers' unwinding) the batch's buffers go back to the allocator: uploads may still be in flight into them, and
+        // the caller may free the host source as soon as this returns.
+        auto drain = [&]() {
+            (void)hipStreamSynchronize(c->copy_stream);
+            (void)hipStreamSynchronize(c->stream);
+            for (auto e : ev) c->event_pool.push_back(e);
+            ev.clear();
+        };
+        try {
+            ev.push_back(c->get_event());
+            ZKM_HIP_CHECK(hipEventRecord(ev[0], c->stream));           // the LDE buffer may still be in use by queued work of a freed batch
+            ZKM_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, ev[0], 0));
+            for (size_t k = 0; k < nchunks; k++) {
+                size_t c0 = k * CH, nc = std::min(CH, ncols - c0);
+                gl_t* dst = dev_values ? dev_values + c0 * n : b->lde + c0 * N;
+                ZKM_HIP_CHECK(hipMemcpyAsync(dst, src + c0 * n, nc * n * sizeof(gl_t), hipMemcpyHostToDevice, c->copy_stream));
+                ev.push_back(c->get_event());
+                ZKM_HIP_CHECK(hipEventRecord(ev.back(), c->copy_stream));
+            }
+            for (size_t k = 0; k < nchunks; k++) {
+                size_t c0 = k * CH, nc = std::min(CH, ncols - c0);
+                gl_t* vals = dev_values ? dev_values + c0 * n : b->lde + c0 * N;
+                ZKM_HIP_CHECK(hipStreamWaitEvent(c->stream, ev[k + 1], 0));
+                zkm_ntt_natural_ex(c, vals, n, b->lde + c0 * N, n, b->coeffs + c0 * n, n, nc, b->log_n, /*inverse=*/true, 0);
+                zkm_lde_bitrev(c, b->coeffs + c0 * n, b->lde + c0 * N, nc, b->log_n, b->rate_bits, GL_GENERATOR);
+                zkm_launch_merkle_leaves_chunk(c, b->lde + c0 * N, N, nc, N, state.as<gl_t>(), k == 0, k + 1 == nchunks, b->digests);
+            }
+        } catch (...) {
+            drain();
+            throw;
         }
-        for (size_t k = 0; k < nchunks; k++) {
-            size_t c0 = k * CH, nc = std::min(CH, ncols - c0);
-            gl_t* vals = dev_values ? dev_values + c0 * n : b->lde + c0 * N;
-            ZKM_HIP_CHECK(hipStreamWaitEvent(c->stream, ev[k], 0));
-            zkm_ntt_natural_ex(c, vals, n, b->lde + c0 * N, n, b->coeffs + c0 * n, n, nc, b->log_n, /*inverse=*/true, 0);
-            zkm_lde_bitrev(c, b->coeffs + c0 * n, b->lde + c0 * N, nc, b->log_n, b->rate_bits, GL_GENERATOR);
-            zkm_launch_merkle_leaves_chunk(c, b->lde + c0 * N, N, nc, N, state.as<gl_t>(), k == 0, k + 1 == nchunks, b->digests);
-        }
-        c->sync();  // (events and the sponge state are recycled below)
-        for (auto e : ev) c->event_pool.push_back(e);
-        c->event_pool.push_back(start);
+        drain();
         leaves_done = true;
     } else if (src_is_values && dev) {
         // device-resident values are only read (first NTT pass); the not-yet-used LDE buffer holds the intermediate passes
@@ -409,6 +427,7 @@ int zkm_batch_commit_coeffs(zkm_ctx* c, const uint64_t* coeffs, size_t ncols, un
 void zkm_batch_free(zkm_batch* b) {
     if (!b) return;
     (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->ctx->copy_stream) (void)hipStreamSynchronize(b->ctx->copy_stream);
     b->ctx->release(b->coeffs);
     b->ctx->release(b->lde);
     b->ctx->release(b->digests);

@@ -520,12 +520,25 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
         // "compute all trace commitments" prover.rs:144-167
         zkm_challenger ch;
         zkm_challenger_init(&ch);
-        for (size_t t = 0; t < ntables; t++) {
-            if (tables[t].ncols == 0 || tables[t].log_n > 30) throw std::runtime_error("zkm_prove_with_traces: bad table shape");
-            if (!zkm_is_device_ptr(tables[t].trace)) d_traces[t] = (gl_t*)c->alloc((tables[t].ncols << tables[t].log_n) * sizeof(gl_t));
-            commits[t] = zkm_batch_commit_values_keep(c, tables[t].trace, tables[t].ncols, tables[t].log_n, cfg->rate_bits, cfg->cap_height,
-                                                      d_traces[t]);
-            zkm_challenger_observe(&ch, commits[t]->cap.data(), commits[t]->cap.size());  // :182-185
+        // Host-resident traces are uploaded once, with their commitment, and the device copy is reused for the table's CTL / lookup
+        // columns -- as long as the copies kept this way stay within a quarter of the memory that is free now (all twelve commitments
+        // -- coefficients + 4x LDE + digests -- are alive at the same time, and a full-size Keccak table alone is 20 GB of values).
+        // A trace beyond that budget is dropped after its commitment and uploaded again when its table is proven.
+        size_t free_b = 0, total_b = 0, kept = 0;
+        ZKM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        const size_t keep_limit = free_b / 4;
+        {
+            zkm_prof_scope st(c, "stage/compute all trace commitments");
+            for (size_t t = 0; t < ntables; t++) {
+                if (tables[t].ncols == 0 || tables[t].log_n > 30) throw std::runtime_error("zkm_prove_with_traces: bad table shape");
+                const size_t bytes = (tables[t].ncols << tables[t].log_n) * sizeof(gl_t);
+                const bool host = !zkm_is_device_ptr(tables[t].trace);
+                const bool keep = host && kept + bytes <= keep_limit;
+                if (keep) { d_traces[t] = (gl_t*)c->alloc(bytes); kept += bytes; }
+                commits[t] = zkm_batch_commit_values_keep(c, tables[t].trace, tables[t].ncols, tables[t].log_n, cfg->rate_bits, cfg->cap_height,
+                                                          d_traces[t]);
+                zkm_challenger_observe(&ch, commits[t]->cap.data(), commits[t]->cap.size());  // :182-185
+            }
         }
         zkm_challenger_observe(&ch, pub, npub);  // :187 observe_public_values
         for (unsigned k = 0; k < cfg->num_challenges; k++) {  // :190, beta then gamma (cross_table_lookup.rs:560-566)
@@ -540,12 +553,19 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
             size_t n = (size_t)1 << tables[t].log_n;
             ctl_dev_owner own;
             own.upload(c, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), false, tables[t].ncols);
+            if (!d_traces[t] && !zkm_is_device_ptr(tables[t].trace)) {  // (over the keep budget: second upload)
+                d_traces[t] = (gl_t*)c->alloc(tables[t].ncols * n * sizeof(gl_t));
+                ZKM_HIP_CHECK(hipMemcpyAsync(d_traces[t], tables[t].trace, tables[t].ncols * n * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+            }
             gl_t* d_trace = d_traces[t] ? d_traces[t] : const_cast<gl_t*>(tables[t].trace);
             gl_t* d_aux = (gl_t*)c->alloc((tz[t].naux ? tz[t].naux : 1) * n * 8);
             int rc = 0;
             char* e = nullptr;
             try {
-                zkm_ctl_data_device(c, own, d_trace, tables[t].log_n, d_aux);
+                {
+                    zkm_prof_scope st(c, "stage/compute CTL data");  // :191-200 (per table here: the data of table t is built right before its proof)
+                    zkm_ctl_data_device(c, own, d_trace, tables[t].log_n, d_aux);
+                }
                 rc = zkm_prove_single_table_ctl(c, tables[t].table_id, cfg, d_trace, tables[t].ncols, tables[t].log_n, commits[t], d_aux,
                                                 tz[t].naux, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), lookup_ch,
                                                 &ch, proofs + offs[t], &e);

@@ -6,6 +6,8 @@
 // The Challenger stays on the host (a few hundred field elements per table); only caps, openings,
 // the final polynomial and the query openings cross PCIe.
 #define GL_REDUCE_BRANCHFREE 1   // (gl_dev.h: these kernels interleave independent products at low occupancy)
+#include <memory>
+
 #include "constraints_dev.h"
 #include "ctl_dev.h"
 
@@ -887,6 +889,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             own_trace = new zkm_batch();
             own_trace->ctx = c; own_trace->ncols = W; own_trace->log_n = log_n; own_trace->rate_bits = cfg->rate_bits;
             own_trace->cap_height = cfg->cap_height;
+            zkm_prof_scope st(c, "stage/compute trace commitment");  // prover.rs:146-163 (done by the caller in the reference)
             zkm_batch_build(own_trace, trace, true);
             tb = own_trace;
         }
@@ -903,6 +906,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             ab->ctx = c; ab->ncols = A; ab->log_n = log_n; ab->rate_bits = cfg->rate_bits; ab->cap_height = cfg->cap_height;
             if (NL) {
                 // "compute lookup helper columns" :475-493, then the CTL columns behind them
+                auto st = std::make_unique<zkm_prof_scope>(c, "stage/compute lookup helper columns");
                 gl_t* d_all = (gl_t*)c->alloc(A * n * sizeof(gl_t));
                 scratch.push_back(d_all);
                 const gl_t* d_trace = trace;
@@ -914,8 +918,11 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
                 }
                 zkm_table_lookup_columns_device(c, table_id, lookup_challenges, cfg->num_challenges, d_trace, n, d_all);
                 ZKM_HIP_CHECK(hipMemcpyAsync(d_all + NL * n, aux, A_ctl * n * sizeof(gl_t), hipMemcpyDefault, c->stream));
+                st.reset();
+                zkm_prof_scope st2(c, "stage/compute auxiliary polynomials commitment");  // :511-522
                 zkm_batch_build(ab, d_all, true);
             } else {
+                zkm_prof_scope st2(c, "stage/compute auxiliary polynomials commitment");
                 zkm_batch_build(ab, aux, true);
             }
             memcpy(caps + y.C * 4, ab->cap.data(), y.C * 4 * 8);
@@ -926,10 +933,16 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             // quotient :543-587
             gl_t* d_quot = (gl_t*)c->alloc(cfg->num_challenges * 2 * n * sizeof(gl_t));
             scratch.push_back(d_quot);
-            quotient_device(c, table_id, tb, ab, own, lookup_challenges, alphas, cfg->num_challenges, d_quot);
+            {
+                zkm_prof_scope st(c, "stage/compute quotient polys");  // :543-559
+                quotient_device(c, table_id, tb, ab, own, lookup_challenges, alphas, cfg->num_challenges, d_quot);
+            }
             qb = new zkm_batch();
             qb->ctx = c; qb->ncols = y.Q; qb->log_n = log_n; qb->rate_bits = cfg->rate_bits; qb->cap_height = cfg->cap_height;
-            zkm_batch_build(qb, d_quot, false);  // chunks [q0_lo, q0_hi, q1_lo, q1_hi] == d_quot viewed as Q columns of n
+            {
+                zkm_prof_scope st(c, "stage/compute quotient commitment");  // :576-587
+                zkm_batch_build(qb, d_quot, false);  // chunks [q0_lo, q0_hi, q1_lo, q1_hi] == d_quot viewed as Q columns of n
+            }
             memcpy(caps + 2 * y.C * 4, qb->cap.data(), y.C * 4 * 8);
             zkm_challenger_observe(ch, caps + 2 * y.C * 4, y.C * 4);  // :589
             abp = ab;
@@ -952,6 +965,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
         uint64_t* op = proof + y.o_open;
         uint64_t *o_local = op, *o_next = op + 2 * W, *o_aux = op + 4 * W, *o_auxn = o_aux + 2 * A, *o_ctl = o_auxn + 2 * A, *o_quot = o_ctl + Z;
         {
+            zkm_prof_scope st(c, "stage/openings (StarkOpeningSet::new)");  // proof.rs:299-334, between two timed! scopes in the reference
             auto tv = eval_batch(c, tb, zeta, zeta_next);
             for (size_t i = 0; i < W; i++) {
                 o_local[2 * i] = tv[i].at_z0.c0; o_local[2 * i + 1] = tv[i].at_z0.c1;
@@ -975,6 +989,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
         for (size_t i = 0; i < Z; i++) { uint64_t e[2] = {o_ctl[i], 0}; zkm_challenger_observe(ch, e, 2); }
 
         // ---- prove_openings (App. A.8)
+        zkm_prof_scope st_fri(c, "stage/compute openings proof");  // prover.rs:618-628
         gl2_t alpha = challenger_get_ext(ch);
         size_t np0 = W + A + y.Q, np1 = W + A, np2 = Z;
         std::vector<gl_t> apow(2 * (np0 + 1));
@@ -1080,11 +1095,15 @@ size_t zkm_fri_proof_words(const zkm_stark_config* cfg, unsigned log_n, const si
 }
 
 int zkm_fri_prove(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch* const* oracles, size_t noracles, const zkm_fri_batch* batches,
-                  size_t nbatches, zkm_challenger* ch, uint64_t* proof, char** err) {
+                  size_t nbatches, zkm_challenger* ch_io, uint64_t* proof, char** err) {
     std::vector<void*> scratch;
+    if (!c || !cfg || !oracles || !batches || !nbatches || !ch_io || !proof) return fail(err, "zkm_fri_prove: null argument");
+    // The transcript is advanced on a copy and handed back only when the whole proof exists: a failed call leaves the caller's
+    // challenger where it was (the reference's prove_openings cannot fail half way; a C ABI call can).
+    zkm_challenger local = *ch_io;
+    zkm_challenger* const ch = &local;
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
-        if (!oracles || !batches || !nbatches || !ch || !proof) throw std::runtime_error("zkm_fri_prove: null argument");
         if (noracles == 0 || noracles > ZKM_FRI_MAX_ORACLES) throw std::runtime_error("zkm_fri_prove: 1..8 oracles");
         const unsigned log_n = oracles[0]->log_n;
         size_t cols[ZKM_FRI_MAX_ORACLES];
@@ -1147,8 +1166,13 @@ int zkm_fri_prove(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch* cons
         (void)hipStreamSynchronize(c->stream);
         for (void* q : scratch) c->release(q);
         return fail(err, e.what());
+    } catch (...) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* q : scratch) c->release(q);
+        return fail(err, "zkm_fri_prove: unknown error");
     }
     for (void* q : scratch) c->release(q);
+    *ch_io = local;
     return 0;
 }
 
@@ -1180,27 +1204,37 @@ int zkm_prove_single_table_ctl(zkm_ctx* c, int table_id, const zkm_stark_config*
                                const zkm_batch* trace_batch, const uint64_t* aux, size_t naux, const zkm_ctl_table* table,
                                const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, const uint64_t* lookup_challenges,
                                zkm_challenger* challenger, uint64_t* proof_out, char** err) {
+    if (!c || !cfg || !challenger || !proof_out) return fail(err, "zkm_prove_single_table: null argument");
+    zkm_challenger local = *challenger;   // (handed back on success only: a failed call leaves the caller's transcript untouched)
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         if (!trace && !trace_batch) throw std::runtime_error("zkm_prove_single_table: need trace values or a trace commitment");
         prove_single_table(c, table_id, cfg, trace, ncols, log_n, trace_batch, aux, naux, table, zs, colset_ids, nzs, lookup_challenges,
-                           challenger, proof_out);
+                           &local, proof_out);
     } catch (const std::exception& e) {
         return fail(err, e.what());
+    } catch (...) {
+        return fail(err, "zkm_prove_single_table: unknown error");
     }
+    *challenger = local;
     return 0;
 }
 
 int zkm_prove_openings(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch* trace_batch, const zkm_batch* aux_batch,
                        const zkm_batch* quot_batch, size_t nctl_zs, zkm_challenger* challenger, uint64_t* proof_out, char** err) {
+    if (!c || !cfg || !challenger || !proof_out) return fail(err, "zkm_prove_openings: null argument");
+    zkm_challenger local = *challenger;
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         if (!trace_batch || !aux_batch || !quot_batch) throw std::runtime_error("zkm_prove_openings: three commitments are required");
         prove_single_table(c, -1, cfg, nullptr, trace_batch->ncols, trace_batch->log_n, trace_batch, nullptr, aux_batch->ncols, nullptr,
-                           nullptr, nullptr, nctl_zs, nullptr, challenger, proof_out, aux_batch, quot_batch);
+                           nullptr, nullptr, nctl_zs, nullptr, &local, proof_out, aux_batch, quot_batch);
     } catch (const std::exception& e) {
         return fail(err, e.what());
+    } catch (...) {
+        return fail(err, "zkm_prove_openings: unknown error");
     }
+    *challenger = local;
     return 0;
 }
 
@@ -1213,6 +1247,8 @@ int zkm_prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg
                                           nctl_zs, nullptr, challenger, proof_out, err);
     } catch (const std::exception& e) {
         return fail(err, e.what());
+    } catch (...) {
+        return fail(err, "zkm_prove_single_table: unknown error");
     }
 }
 

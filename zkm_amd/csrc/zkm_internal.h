@@ -67,8 +67,8 @@ struct zkm_ctx {
     const gl_t* pow_table(uint64_t shift, unsigned log_n);  // lo: 2^ceil(log_n/2) entries, then hi
     uint64_t* staging(size_t words);
     hipEvent_t get_event();
-    void prof_begin(const char* name);
-    void prof_end();
+    size_t prof_begin(const char* name);   // returns the record's index (scopes nest: a stage scope holds kernel scopes)
+    void prof_end(size_t idx);
     void sync() { ZKM_HIP_CHECK(hipStreamSynchronize(stream)); }
 };
 
@@ -83,14 +83,20 @@ struct zkm_scratch {
     template <class T> T* as() const { return (T*)p; }
 };
 
-// RAII profiling scope around one kernel launch (or a small group)
+// RAII profiling scope around one kernel launch (or a small group).  Names starting with "stage/" are the reference's timed!
+// scopes (prover.rs:146-153, 193, 204, 479, 513, 545, 578, 620): event pairs at the stage boundaries, reported beside the kernel
+// records (consumers separate the two by the prefix; a stage's time includes its transcript round trips and launch gaps).
 struct zkm_prof_scope {
     zkm_ctx* c;
-    zkm_prof_scope(zkm_ctx* ctx, const char* name) : c(ctx) {
-        if (c->profiling) c->prof_begin(name);
+    size_t idx = 0;
+    bool on;
+    zkm_prof_scope(zkm_ctx* ctx, const char* name) : c(ctx), on(ctx->profiling) {
+        if (on) idx = c->prof_begin(name);
     }
+    zkm_prof_scope(const zkm_prof_scope&) = delete;
+    zkm_prof_scope& operator=(const zkm_prof_scope&) = delete;
     ~zkm_prof_scope() {
-        if (c->profiling) c->prof_end();
+        if (on) c->prof_end(idx);
     }
 };
 

@@ -589,8 +589,10 @@ def all_cross_table_lookups():
     AR, CPU, PO, PS, KK, KS, SE, SES, SC, SCS, LO, ME = range(12)
     logic_lookers = logic_lookers_cpu(CPU, c[CPU]) + [(KS, keccak_sponge_looking_logic(c[KS], i)) for i in range(NUM_LOGIC_CTLS)] + \
         logic_lookers_sha_extend(SE, c[SE]) + logic_lookers_sha_compress(SC, c[SC])
-    memory_lookers = memory_lookers_cpu(CPU, c[CPU]) + memory_lookers_poseidon_sponge(PS, c[PS]) + \
-        memory_lookers_keccak_sponge(KS, c[KS]) + memory_lookers_sha_extend_sponge(SES, c[SES]) + \
+    # ctl_memory() chains cpu, keccak_sponge, poseidon_sponge, sha_extend_sponge, sha_compress_sponge, sha_compress (all_stark.rs:527-534):
+    # a consumer that indexes the looking sides positionally (verifier, recursion) sees the reference's order
+    memory_lookers = memory_lookers_cpu(CPU, c[CPU]) + memory_lookers_keccak_sponge(KS, c[KS]) + \
+        memory_lookers_poseidon_sponge(PS, c[PS]) + memory_lookers_sha_extend_sponge(SES, c[SES]) + \
         memory_lookers_sha_compress_sponge(SCS, c[SCS]) + memory_lookers_sha_compress(SC, c[SC])
     ctls = [ctl_arithmetic(CPU, AR, c[CPU], c[AR]),
             ctl_poseidon_sponge(CPU, PS, c[CPU], c[PS]), ctl_poseidon_inputs(PS, PO, c[PS], c[PO]), ctl_poseidon_outputs(PS, PO, c[PS], c[PO]),
