@@ -75,6 +75,13 @@ int zkm_batch_commit_values(zkm_ctx* ctx, const uint64_t* values, size_t ncols, 
                             unsigned cap_height, zkm_batch** out, char** err);
 int zkm_batch_commit_coeffs(zkm_ctx* ctx, const uint64_t* coeffs, size_t ncols, unsigned log_n, unsigned rate_bits,
                             unsigned cap_height, zkm_batch** out, char** err);
+/* The same two constructors from ONE POINTER PER COLUMN: the reference's argument is a Vec<PolynomialValues<F>> /
+ * Vec<PolynomialCoeffs<F>> -- a separate heap allocation per column (prover.rs:154-163 trace_poly_values, :576-587 chunks) -- so the
+ * Rust side passes `values.iter().map(|p| p.values.as_ptr())` and nothing is flattened on the host.  columns[i] -> 2^log_n words,
+ * host (pageable, pinned or registered) or device; columns_are_values != 0: from_values, 0: from_coeffs.  Wide host-resident
+ * matrices take the same pipelined ingest as zkm_batch_commit_values (column chunks on a copy stream). */
+int zkm_batch_commit_columns(zkm_ctx* ctx, const uint64_t* const* columns, size_t ncols, unsigned log_n, int columns_are_values,
+                             unsigned rate_bits, unsigned cap_height, zkm_batch** out, char** err);
 void zkm_batch_free(zkm_batch* b);
 /* .merkle_tree.cap (prover.rs:180, 524, 588): 2^cap_height digests x 4 words, host out */
 int zkm_batch_cap(const zkm_batch* b, uint64_t* out);
@@ -359,10 +366,12 @@ int zkm_prove_single_table_ctl(zkm_ctx* ctx, int table_id, const zkm_stark_confi
  * num_challenges (beta, gamma) pairs. */
 typedef struct {
     int table_id;
-    const uint64_t* trace;      /* ncols x 2^log_n, host or device */
+    const uint64_t* trace;      /* ncols x 2^log_n in one block, host or device; NULL when `columns` is given */
     size_t ncols;
     unsigned log_n;
     const zkm_ctl_table* ctl;   /* column sets referenced by the cross-table lookups */
+    const uint64_t* const* columns;  /* or: one pointer per column (2^log_n words each, host or device) -- the reference's
+                                        Vec<PolynomialValues<F>> (prover.rs:130-142) without a host-side flatten; NULL = use `trace` */
 } zkm_table_input;
 size_t zkm_all_proof_words(const zkm_stark_config* cfg, const zkm_table_input* tables, size_t ntables,
                            const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls, size_t* proof_offsets_out);
@@ -382,6 +391,10 @@ const zkm_ctl_table* zkm_all_stark_ctl_table(int table_id);
 int zkm_prove_segment(zkm_ctx* ctx, const zkm_stark_config* cfg, const uint64_t* const* traces, const unsigned* log_n,
                       const uint64_t* public_values, size_t npublic, uint64_t* proofs_out, size_t* proof_offsets_out,
                       uint64_t* ctl_challenges_out, char** err);
+/* zkm_prove_segment with one pointer per column: columns[t][i] -> column i of table t (Table::all() order), 2^log_n[t] words. */
+int zkm_prove_segment_columns(zkm_ctx* ctx, const zkm_stark_config* cfg, const uint64_t* const* const* columns, const unsigned* log_n,
+                              const uint64_t* public_values, size_t npublic, uint64_t* proofs_out, size_t* proof_offsets_out,
+                              uint64_t* ctl_challenges_out, char** err);
 
 /* a10 alone (BASELINE config 4): PolynomialBatch::prove_openings (call site prover.rs:618-628) for the STARK FRI
  * instance (stark.rs:91-148: batches at zeta, g*zeta and 1 over the trace / auxiliary / quotient oracles) on three

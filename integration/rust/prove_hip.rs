@@ -55,27 +55,43 @@ pub fn zkm_config(c: &StarkConfig) -> zkm_stark_config {
     }
 }
 
-/// Vec<PolynomialValues<F>> -> column-major canonical words (the layout prover/src/util.rs:37-46 produces).
-/// Traces are BORROWED by the library: the `trace_poly_values.clone()` of prover.rs:155-157 disappears.
-pub fn flatten<F: PrimeField64>(cols: &[PolynomialValues<F>]) -> Vec<u64> {
+/// One pointer per column of a `Vec<PolynomialValues<F>>` -- each column is its own heap allocation (prover.rs:154-163 hands the
+/// vector to `PolynomialBatch::from_values`), and `GoldilocksField` is `#[repr(transparent)]` over a u64, so the library reads the
+/// columns where they lie: no 2 GiB `flatten` copy on the host, and the `trace_poly_values.clone()` of prover.rs:155-157 disappears
+/// (inputs are BORROWED for the call).  A `GoldilocksField` may hold any u64 representing its residue (products are reduced below
+/// 2^64, not below p -- e.g. the s-box values of poseidon_stark.rs:133-160); the library's transforms accept any representative and
+/// it canonicalises the device copy it keeps for the CTL / lookup columns, so no `to_canonical_u64()` pass is needed here.
+pub fn column_ptrs<F: PrimeField64>(cols: &[PolynomialValues<F>]) -> Vec<*const u64> {
+    const { assert!(core::mem::size_of::<F>() == 8) };
     let n = cols.first().map_or(0, |c| c.len());
-    let mut out = Vec::with_capacity(cols.len() * n);
-    for c in cols {
-        debug_assert_eq!(c.len(), n);
-        out.extend(c.values.iter().map(|x| x.to_canonical_u64()));
-    }
-    out
+    cols.iter()
+        .map(|c| {
+            debug_assert_eq!(c.len(), n);
+            c.values.as_ptr() as *const u64
+        })
+        .collect()
+}
+
+/// What `observe_public_values` (get_challenges.rs:91-105) feeds the transcript, in its order: the eight u32 limbs of
+/// `roots_before.root`, the eight of `roots_after.root` (observe_root :13-20, `from_canonical_u32`), then every byte of `userdata`
+/// as one field element (`from_canonical_u8`, :101-103).  This is the `public_values` argument of zkm_prove_segment /
+/// zkm_prove_with_traces (observed right after the trace caps, prover.rs:182-187).
+pub fn public_values_words(pv: &PublicValues) -> Vec<u64> {
+    let mut w = Vec::with_capacity(16 + pv.userdata.len());
+    w.extend(pv.roots_before.root.iter().map(|&limb| limb as u64));
+    w.extend(pv.roots_after.root.iter().map(|&limb| limb as u64));
+    w.extend(pv.userdata.iter().map(|&b| b as u64));
+    w
 }
 
 /// Body of `prove_with_traces` (prover.rs:130-232 + prove_with_commitments :234-438): one library call for the whole segment.
-/// The AllStark cross-table-lookup description (all_stark.rs:136-542) ships inside the library (zkm_prove_segment), so
-/// nothing but the twelve traces, the public values and the config crosses the boundary.
+/// The AllStark cross-table-lookup description (all_stark.rs:136-542) ships inside the library (zkm_prove_segment_columns), so
+/// nothing but the column pointers of the twelve traces, the public values and the config crosses the boundary.
 pub fn prove_with_traces_hip<F, C, const D: usize>(
     ctx: *mut zkm_ctx,
     config: &StarkConfig,
     trace_poly_values: &[Vec<PolynomialValues<F>>; NUM_TABLES],
     public_values: PublicValues,
-    public_value_words: &[u64], // what observe_public_values (get_challenges.rs:13-60) feeds the transcript, in order
 ) -> Result<AllProof<F, C, D>>
 where
     F: RichField + Extendable<D>,
@@ -83,17 +99,18 @@ where
     C::Hasher: Hasher<F, Hash = HashOut<F>>,
 {
     let cfg = zkm_config(config);
-    let flat: Vec<Vec<u64>> = trace_poly_values.iter().map(|t| flatten(t)).collect();
-    let ptrs: Vec<*const u64> = flat.iter().map(|v| v.as_ptr()).collect();
+    let public_value_words = public_values_words(&public_values);
+    let cols: Vec<Vec<*const u64>> = trace_poly_values.iter().map(|t| column_ptrs(t)).collect();
+    let ptrs: Vec<*const *const u64> = cols.iter().map(|v| v.as_ptr()).collect();
     let log_n: Vec<u32> = trace_poly_values.iter().map(|t| t[0].len().trailing_zeros()).collect();
     let mut offs = vec![0usize; NUM_TABLES + 1];
     let mut err = std::ptr::null_mut();
     // sizing pass (proofs_out = NULL), then the proving pass
-    check(unsafe { zkm_prove_segment(std::ptr::null_mut(), &cfg, ptrs.as_ptr(), log_n.as_ptr(), public_value_words.as_ptr(),
+    check(unsafe { zkm_prove_segment_columns(std::ptr::null_mut(), &cfg, ptrs.as_ptr(), log_n.as_ptr(), public_value_words.as_ptr(),
                                      public_value_words.len(), std::ptr::null_mut(), offs.as_mut_ptr(), std::ptr::null_mut(), &mut err) }, err)?;
     let mut blob = vec![0u64; offs[NUM_TABLES]];
     let mut chal = vec![0u64; 2 * config.num_challenges];
-    check(unsafe { zkm_prove_segment(ctx, &cfg, ptrs.as_ptr(), log_n.as_ptr(), public_value_words.as_ptr(), public_value_words.len(),
+    check(unsafe { zkm_prove_segment_columns(ctx, &cfg, ptrs.as_ptr(), log_n.as_ptr(), public_value_words.as_ptr(), public_value_words.len(),
                                      blob.as_mut_ptr(), offs.as_mut_ptr(), chal.as_mut_ptr(), &mut err) }, err)?;
     let stark_proofs: [StarkProofWithMetadata<F, C, D>; NUM_TABLES] =
         core::array::from_fn(|t| stark_proof_from_blob::<F, C, D>(&blob[offs[t]..offs[t + 1]]));
@@ -121,17 +138,24 @@ where
     C: GenericConfig<D, F = F, Hasher = plonky2::hash::poseidon::PoseidonHash>,
 {
     let cfg = zkm_config(config);
-    let (trace, aux) = (flatten(trace_poly_values), flatten(aux_columns));
     let log_n = trace_poly_values[0].len().trailing_zeros();
     let helpers: Vec<u32> = num_ctl_helper_polys.iter().map(|&x| x as u32).collect();
     let words = unsafe { zkm_proof_words(&cfg, log_n, trace_poly_values.len(), aux_columns.len(), helpers.len()) };
     anyhow::ensure!(words != 0, "libzkmhip: unsupported StarkConfig");
+    let mut err = std::ptr::null_mut();
+    // the trace commitment of prover.rs:154-163 from the column pointers (no flatten); the few auxiliary columns go over as one block
+    let tcols = column_ptrs(trace_poly_values);
+    let mut trace_batch: *mut zkm_batch = std::ptr::null_mut();
+    check(unsafe { zkm_batch_commit_columns(ctx, tcols.as_ptr(), tcols.len(), log_n, 1, cfg.rate_bits, cfg.cap_height, &mut trace_batch,
+                                            &mut err) }, err)?;
+    let aux: Vec<u64> = aux_columns.iter().flat_map(|c| c.values.iter().map(|x| x.to_canonical_u64())).collect();
     let mut blob = vec![0u64; words];
     let mut ch = challenger.to_zkm();
-    let mut err = std::ptr::null_mut();
-    check(unsafe { zkm_prove_single_table(ctx, zkm_table_id(table), &cfg, trace.as_ptr(), trace_poly_values.len(), log_n, std::ptr::null(),
-                                          aux.as_ptr(), aux_columns.len(), helpers.as_ptr(), helpers.len(), &mut ch, blob.as_mut_ptr(),
-                                          &mut err) }, err)?;
-    challenger.set_from_zkm(&ch);
+    let rc = unsafe { zkm_prove_single_table(ctx, zkm_table_id(table), &cfg, std::ptr::null(), trace_poly_values.len(), log_n, trace_batch,
+                                             aux.as_ptr(), aux_columns.len(), helpers.as_ptr(), helpers.len(), &mut ch, blob.as_mut_ptr(),
+                                             &mut err) };
+    unsafe { zkm_batch_free(trace_batch) };
+    check(rc, err)?;
+    challenger.set_from_zkm(&ch);   // (the library hands the transcript back only when the proof exists)
     Ok(stark_proof_from_blob::<F, C, D>(&blob))
 }

@@ -51,7 +51,8 @@ pub struct zkm_ctl_side { pub table: u32, pub colset: u32 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct zkm_cross_table_lookup { pub nlooking: u32, pub looking_off: u32, pub looked: zkm_ctl_side }
 #[repr(C)] #[derive(Clone, Copy, Debug)]
-pub struct zkm_table_input { pub table_id: c_int, pub trace: *const u64, pub ncols: usize, pub log_n: c_uint, pub ctl: *const zkm_ctl_table }
+pub struct zkm_table_input { pub table_id: c_int, pub trace: *const u64, pub ncols: usize, pub log_n: c_uint, pub ctl: *const zkm_ctl_table,
+                             pub columns: *const *const u64 }
 /// descriptor of one FRI oracle / batch for zkm_prove_openings_fri (FriInstanceInfo, stark.rs:91-148)
 #[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct zkm_fri_poly { pub oracle: u32, pub poly: u32 }
@@ -87,6 +88,8 @@ extern "C" {
                                    out: *mut *mut zkm_batch, err: *mut *mut c_char) -> c_int;
     pub fn zkm_batch_commit_coeffs(ctx: *mut zkm_ctx, coeffs: *const u64, ncols: usize, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint,
                                    out: *mut *mut zkm_batch, err: *mut *mut c_char) -> c_int;
+    pub fn zkm_batch_commit_columns(ctx: *mut zkm_ctx, columns: *const *const u64, ncols: usize, log_n: c_uint, columns_are_values: c_int,
+                                    rate_bits: c_uint, cap_height: c_uint, out: *mut *mut zkm_batch, err: *mut *mut c_char) -> c_int;
     pub fn zkm_batch_free(b: *mut zkm_batch);
     pub fn zkm_batch_cap(b: *const zkm_batch, out: *mut u64) -> c_int;
     pub fn zkm_batch_coeffs(b: *const zkm_batch, out: *mut u64) -> c_int;
@@ -153,6 +156,9 @@ extern "C" {
     pub fn zkm_prove_segment(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, traces: *const *const u64, log_n: *const c_uint,
                              public_values: *const u64, npublic: usize, proofs_out: *mut u64, proof_offsets_out: *mut usize,
                              ctl_challenges_out: *mut u64, err: *mut *mut c_char) -> c_int;
+    pub fn zkm_prove_segment_columns(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, columns: *const *const *const u64, log_n: *const c_uint,
+                                     public_values: *const u64, npublic: usize, proofs_out: *mut u64, proof_offsets_out: *mut usize,
+                                     ctl_challenges_out: *mut u64, err: *mut *mut c_char) -> c_int;
     pub fn zkm_fri_proof_words(cfg: *const zkm_stark_config, log_n: c_uint, oracle_cols: *const usize, noracles: usize) -> usize;
     pub fn zkm_fri_prove(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, oracles: *const *const zkm_batch, noracles: usize,
                          batches: *const zkm_fri_batch, nbatches: usize, challenger: *mut zkm_challenger, proof_out: *mut u64,

@@ -137,7 +137,8 @@ typedef struct {
 typedef struct { uint32_t ncolsets, colset_off, num_helpers, _pad; uint64_t beta, gamma; } zko_ctl_z;
 typedef struct { uint32_t table, colset; } zko_ctl_side;
 typedef struct { uint32_t nlooking, looking_off; zko_ctl_side looked; } zko_cross_table_lookup;
-typedef struct { int table_id; const uint64_t* trace; size_t ncols; unsigned log_n; const zko_ctl_table* ctl; } zko_table_input;
+/* (same layout as zkm_table_input of include/zkm_hip.h, so the tests pack one array for both; the oracle only reads `trace`) */
+typedef struct { int table_id; const uint64_t* trace; size_t ncols; unsigned log_n; const zko_ctl_table* ctl; const uint64_t* const* columns; } zko_table_input;
 
 void zko_ctl_data(const zko_ctl_table* t, const zko_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, const uint64_t* trace,
                   size_t ncols, unsigned log_n, uint64_t* aux_out);

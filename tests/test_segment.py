@@ -276,3 +276,92 @@ def test_gpu_proof_blob_walks_through_the_layout(ctx, zkm, oracle):
         assert tb.ctx.L.zkm_batch_lde_rows(tb.h, start, step, count, None) != 0, (start, step, count)
     tb.free()
     ab.free()
+
+
+P = 0xFFFFFFFF00000001
+
+
+def _split_columns(flat, ncols, rng=None):
+    """One separately allocated array per column (the reference's Vec<PolynomialValues<F>>); with rng, words below 2^32 - 1 are
+    replaced by their non-canonical representative v + p here and there (a plonky2 GoldilocksField may hold either)."""
+    cols = [np.array(c, dtype=np.uint64) for c in np.asarray(flat, dtype=np.uint64).reshape(ncols, -1)]
+    if rng is not None:
+        for c in cols:
+            pick = (c < np.uint64(0xFFFFFFFF)) & (rng.integers(0, 3, c.size) == 0)
+            c[pick] += np.uint64(P)
+    return cols
+
+
+def test_segment_image_from_column_pointers(zkm, oracle):
+    """zkm_table_input.columns: the image written from one pointer per column equals the image written from the flat block."""
+    from zkm_amd import ctl as zc
+    import ctypes as C
+    tables, ctls = build(oracle)
+    img = zkm.segment_image(tables, ctls, public_values=[4, 5])
+    lib = zkm.load()
+    keep = [_split_columns(tr, ncols) for (_, tr, ncols, _, _) in tables]
+    packed = [(tid, [c.ctypes.data for c in cols], ncols, log_n, ct) for (tid, _, ncols, log_n, ct), cols in zip(tables, keep)]
+    tarr, keep2 = zc.pack_tables(packed)
+    carr, sides = zc.pack_ctls(ctls)
+    pub = np.array([4, 5], dtype=np.uint64)
+    words = lib.zkm_segment_image_words(tarr, len(tables), carr.ctypes.data, sides.ctypes.data, len(carr), pub.size)
+    assert words == img.size
+    out = np.zeros(words, dtype=np.uint64)
+    err = C.c_char_p()
+    u64p = C.POINTER(C.c_uint64)
+    assert lib.zkm_segment_image_write(tarr, len(tables), carr.ctypes.data, sides.ctypes.data, len(carr), pub.ctypes.data_as(u64p), pub.size,
+                                       out.ctypes.data_as(u64p), C.byref(err)) == 0, err.value
+    assert (out == img).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncols,log_n", [(5, 9), (77, 13), (262, 13)])
+def test_commit_columns_equals_commit_values(ctx, zkm, oracle, ncols, log_n):
+    """zkm_batch_commit_columns (one pointer per column): same coefficients, cap, leaves and paths as the flat
+    from_values / from_coeffs -- through the monolithic upload (5 x 2^9) and the pipelined column-chunk ingest (>= 64 columns x 2^13)
+    -- also when some words are the non-canonical representative v + p of their field element."""
+    rng = np.random.default_rng(600 + ncols)
+    vals = rng.integers(0, P, ncols << log_n, dtype=np.uint64)
+    vals[::7] = rng.integers(0, 1 << 32, vals[::7].size, dtype=np.uint64)
+    want = oracle.batch_from_values(vals, ncols, log_n)
+    for noncanon in (None, rng):
+        cols = _split_columns(vals, ncols, noncanon)
+        b = zkm.PolynomialBatch.from_columns(ctx, cols, log_n)
+        assert (b.cap() == want.cap()).all() and (b.coeffs() == want.coeffs()).all()
+        for i in (0, 3, (4 << log_n) - 1):
+            assert (b.leaf(i) == want.leaf(i)).all() and (b.merkle_path(i) == want.merkle_path(i)).all()
+        b.free()
+    wc = oracle.batch_from_coeffs(vals, ncols, log_n)
+    b = zkm.PolynomialBatch.from_columns(ctx, _split_columns(vals, ncols), log_n, values=False)
+    assert (b.cap() == wc.cap()).all() and (b.coeffs() == vals).all()
+    b.free()
+    with pytest.raises(zkm.ZkmError, match="null"):
+        import ctypes as C
+        h, err = C.c_void_p(), C.c_char_p()
+        ptrs = (C.c_void_p * 2)(None, None)
+        rc = ctx.L.zkm_batch_commit_columns(ctx.h, ptrs, 2, 4, 1, 2, 4, C.byref(h), C.byref(err))
+        assert rc != 0
+        raise zkm.ZkmError(err.value.decode())
+
+
+@pytest.mark.gpu
+def test_prove_segment_from_column_pointers(ctx, zkm):
+    """zkm_prove_segment_columns: the twelve traces as one pointer per column (some words non-canonical) give the proof of the flat,
+    canonical traces word for word -- commitment, CTL data and lookup columns all read the same field elements."""
+    import os
+    from zkm_amd import tables as T
+    seg = np.load(os.path.join(os.path.dirname(__file__), "golden", "segment12.npz"))
+    log_n = [int(x) for x in seg["log_n"]]
+    traces = [seg["t%d" % i] for i in range(12)]
+    want, wchal, woffs = ctx.prove_segment(traces, log_n, public_values=[1, 2, 3])
+    rng = np.random.default_rng(12)
+    cols = [_split_columns(traces[i], T.WIDTH[T.TABLE_ENUM_ORDER[i]], rng) for i in range(12)]
+    got, chal, offs = ctx.prove_segment(cols, log_n, public_values=[1, 2, 3])
+    assert offs == woffs and (chal == wchal).all()
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first differing word %d" % bad[0]
+    # the generic entry point with zkm_table_input.columns
+    ctl_tables, ctls = T.all_cross_table_lookups()
+    tables = [(T.TABLE_ENUM_ORDER[i], cols[i], T.WIDTH[T.TABLE_ENUM_ORDER[i]], log_n[i], ctl_tables[i]) for i in range(12)]
+    got2, chal2, offs2 = ctx.prove_with_traces(tables, ctls, public_values=[1, 2, 3])
+    assert offs2 == woffs and (got2 == want).all()

@@ -53,12 +53,17 @@ def segment_rate(ctx, log_cycles, reps=3):
     ctx.profile(False)
     for b in bufs:
         b.free()
-    kernel_ms = sum(v[1] for v in rec.values()) / reps
+    krec = {k: v for k, v in rec.items() if not k.startswith("stage/")}      # kernel records; "stage/..." = the reference's timed! scopes
+    kernel_ms = sum(v[1] for v in krec.values()) / reps
     return {"cpu_cycles_log2": log_cycles, "table_heights_log2": logs, "segments_per_s": 1.0 / wall, "ms_per_segment": wall * 1e3,
             "kernel_ms_per_segment": kernel_ms, "wall_over_kernel_sum": wall * 1e3 / kernel_ms,
-            "launches_per_segment": sum(v[0] for v in rec.values()) / reps, "proof_words": int(offs[12]),
-            "kernel_ms": {k: round(v[1] / reps, 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])[:12]},
-            "note": "twelve tables, fifteen lookups, one zkm_prove_segment call; traces device-resident, tiled test segment (timing only)"}
+            "launches_per_segment": sum(v[0] for v in krec.values()) / reps, "proof_words": int(offs[12]),
+            "kernel_ms": {k: round(v[1] / reps, 3) for k, v in sorted(krec.items(), key=lambda kv: -kv[1][1])[:12]},
+            "stage_ms": {k[6:]: round(v[1] / reps, 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1]) if k.startswith("stage/")},
+            "note": "twelve tables, fifteen lookups, one zkm_prove_segment call; traces device-resident, tiled test segment (timing only). The trace "
+                    "commitments, and after the CTL challenges the CTL data + auxiliary commitments, of the twelve tables run side by side on the "
+                    "context's commit lanes: kernel_ms sums launches that overlapped (each counts its own duration), and the per-table stage "
+                    "scopes of those two phases overlap too -- wall_over_kernel_sum below 1 means concurrency, not a faster clock"}
 
 
 def concurrent_segment_rate(device, log_cycles, nctx, reps=6):

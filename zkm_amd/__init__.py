@@ -28,8 +28,8 @@ u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
     "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_memory", "zkm_ctx_trim", "zkm_table_enum_index", "zkm_host_alloc", "zkm_host_free",
-    "zkm_host_register", "zkm_host_unregister", "zkm_all_stark_ctls", "zkm_all_stark_ctl_table", "zkm_prove_segment", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
-    "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_field_selftest", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_free",
+    "zkm_host_register", "zkm_host_unregister", "zkm_all_stark_ctls", "zkm_all_stark_ctl_table", "zkm_prove_segment", "zkm_prove_segment_columns", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
+    "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_field_selftest", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_commit_columns", "zkm_batch_free",
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_lde_rows", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_keccak_trace", "zkm_logic_trace",
     "zkm_poseidon_sponge_trace", "zkm_poseidon_trace_inputs", "zkm_sha_extend_trace", "zkm_sha_extend_sponge_trace",
@@ -110,6 +110,7 @@ def load():
         "zkm_ntt": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, C.c_int, C.c_uint64, err]),
         "zkm_batch_commit_values": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, cpp, err]),
         "zkm_batch_commit_coeffs": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, cpp, err]),
+        "zkm_batch_commit_columns": (C.c_int, [cp, C.POINTER(C.c_void_p), C.c_size_t, C.c_uint, C.c_int, C.c_uint, C.c_uint, cpp, err]),
         "zkm_batch_free": (None, [cp]),
         "zkm_batch_cap": (C.c_int, [cp, u64p]),
         "zkm_batch_coeffs": (C.c_int, [cp, cp]),
@@ -135,6 +136,8 @@ def load():
         "zkm_all_stark_ctl_table": (cp, [C.c_int]),
         "zkm_prove_segment": (C.c_int, [cp, C.POINTER(StarkConfig), C.POINTER(C.c_void_p), C.POINTER(C.c_uint), u64p, C.c_size_t, u64p,
                                         C.POINTER(C.c_size_t), u64p, err]),
+        "zkm_prove_segment_columns": (C.c_int, [cp, C.POINTER(StarkConfig), C.POINTER(C.c_void_p), C.POINTER(C.c_uint), u64p, C.c_size_t, u64p,
+                                                C.POINTER(C.c_size_t), u64p, err]),
         "zkm_host_alloc": (C.c_int, [cp, C.c_size_t, cpp, err]),
         "zkm_host_free": (C.c_int, [cp, cp]),
         "zkm_host_register": (C.c_int, [cp, cp, C.c_size_t, err]),
@@ -521,7 +524,9 @@ class Context:
         ctls: list of (looking=[(table, colset)..], looked=(table, colset)).  Returns (proofs, ctl_challenges, offsets)."""
         from . import ctl as zc
         cfg = cfg or self.standard_config()
-        packed = [(tid, _data_ptr(tr).value, ncols, log_n, ct) for (tid, tr, ncols, log_n, ct) in tables]
+        # (a trace given as a LIST of per-column arrays goes through zkm_table_input.columns: one pointer per column)
+        packed = [(tid, [_data_ptr(col).value for col in tr] if isinstance(tr, (list, tuple)) else _data_ptr(tr).value, ncols, log_n, ct)
+                  for (tid, tr, ncols, log_n, ct) in tables]
         tarr, keep = zc.pack_tables(packed)
         carr, sides = zc.pack_ctls(ctls)
         offs = (C.c_size_t * (len(tables) + 1))()
@@ -543,6 +548,8 @@ class Context:
         height.  Returns (proofs, ctl_challenges, offsets)."""
         cfg = cfg or self.standard_config()
         assert len(traces) == 12 and len(log_ns) == 12
+        if all(isinstance(t, (list, tuple)) for t in traces):
+            return self._prove_segment_columns(traces, log_ns, public_values, cfg)
         keep = [t if isinstance(t, DeviceBuffer) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
         ptrs = (C.c_void_p * 12)(*[_data_ptr(t).value for t in keep])
         lg = (C.c_uint * 12)(*[int(x) for x in log_ns])
@@ -554,6 +561,22 @@ class Context:
         chal = np.zeros(2 * cfg.num_challenges, dtype=np.uint64)
         _check(self.L.zkm_prove_segment(self.h, C.byref(cfg), ptrs, lg, pub.ctypes.data_as(u64p), pub.size, proofs.ctypes.data_as(u64p), offs,
                                         chal.ctypes.data_as(u64p), C.byref(err)), err)
+        return proofs, chal, list(offs)
+
+    def _prove_segment_columns(self, traces, log_ns, public_values, cfg):
+        """zkm_prove_segment_columns: traces[t] = list of per-column arrays (each its own allocation, like Vec<PolynomialValues<F>>)."""
+        keep = [[c if isinstance(c, DeviceBuffer) else np.ascontiguousarray(c, dtype=np.uint64) for c in t] for t in traces]
+        cols = [(C.c_void_p * len(t))(*[_data_ptr(c).value for c in t]) for t in keep]
+        tabs = (C.c_void_p * 12)(*[C.addressof(c) for c in cols])
+        lg = (C.c_uint * 12)(*[int(x) for x in log_ns])
+        pub = np.ascontiguousarray(public_values, dtype=np.uint64)
+        offs = (C.c_size_t * 13)()
+        err = C.c_char_p()
+        _check(self.L.zkm_prove_segment_columns(None, C.byref(cfg), tabs, lg, pub.ctypes.data_as(u64p), pub.size, None, offs, None, C.byref(err)), err)
+        proofs = np.zeros(offs[12], dtype=np.uint64)
+        chal = np.zeros(2 * cfg.num_challenges, dtype=np.uint64)
+        _check(self.L.zkm_prove_segment_columns(self.h, C.byref(cfg), tabs, lg, pub.ctypes.data_as(u64p), pub.size, proofs.ctypes.data_as(u64p),
+                                                offs, chal.ctypes.data_as(u64p), C.byref(err)), err)
         return proofs, chal, list(offs)
 
     def prove_segment_image(self, image, cfg=None):
@@ -635,6 +658,18 @@ class PolynomialBatch:
         _check(ctx.L.zkm_batch_commit_values(ctx.h, _data_ptr(values), ncols, log_n, rate_bits, cap_height, C.byref(h),
                                              C.byref(err)), err)
         return cls(ctx, h, ncols, log_n, rate_bits, cap_height)
+
+    @classmethod
+    def from_columns(cls, ctx, columns, log_n, values=True, rate_bits=2, cap_height=4):
+        """from_values / from_coeffs from one array per column (zkm_batch_commit_columns): the shape of the reference's
+        Vec<PolynomialValues<F>> -- nothing is flattened on the host."""
+        keep = [c if isinstance(c, DeviceBuffer) else np.ascontiguousarray(c, dtype=np.uint64) for c in columns]
+        ptrs = (C.c_void_p * len(keep))(*[_data_ptr(c).value for c in keep])
+        h = C.c_void_p()
+        err = C.c_char_p()
+        _check(ctx.L.zkm_batch_commit_columns(ctx.h, ptrs, len(keep), log_n, int(bool(values)), rate_bits, cap_height, C.byref(h),
+                                              C.byref(err)), err)
+        return cls(ctx, h, len(keep), log_n, rate_bits, cap_height)
 
     @classmethod
     def from_coeffs(cls, ctx, coeffs, ncols, log_n, rate_bits=2, cap_height=4):

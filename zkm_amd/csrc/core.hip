@@ -48,6 +48,22 @@ void zkm_ctx::trim() {
     if (copy_stream) (void)hipStreamSynchronize(copy_stream);  // ... or be the target of an upload still in flight
     for (auto& kv : free_blocks) (void)hipFree(kv.second);
     free_blocks.clear();
+    for (zkm_ctx* l : lanes) l->trim();
+}
+void zkm_ctx::ensure_lanes(size_t k) {
+    while (lanes.size() < k) {
+        zkm_ctx* l = new zkm_ctx();
+        l->device = device;
+        l->num_cus = num_cus;
+        l->ingest_chunk_cols = ingest_chunk_cols;
+        hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete l;
+            ZKM_HIP_CHECK(e);
+        }
+        lanes.push_back(l);
+    }
+    for (zkm_ctx* l : lanes) l->profiling = profiling;
 }
 void zkm_ctx::release(void* p) {
     if (!p) return;
@@ -116,7 +132,6 @@ int zkm_ctx_create(int device, zkm_ctx** out, char** err) {
     hipDeviceProp_t prop;
     ZKM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
-    c->use_baseline_ntt = getenv("ZKM_BASELINE_NTT") != nullptr;  // A/B switch for profiling
     ZKM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char* e = getenv("ZKM_INGEST_CHUNK")) c->ingest_chunk_cols = (size_t)strtoul(e, nullptr, 10);  // tuning / A-B switch
     *out = c;
@@ -126,6 +141,8 @@ int zkm_ctx_create(int device, zkm_ctx** out, char** err) {
 void zkm_ctx_destroy(zkm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (zkm_ctx* l : c->lanes) zkm_ctx_destroy(l);
+    c->lanes.clear();
     (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
@@ -148,6 +165,12 @@ void zkm_ctx_memory(const zkm_ctx* c, size_t* live_bytes, size_t* cached_bytes) 
     size_t live = 0, cached = 0;
     for (auto& kv : c->live_blocks) live += kv.second;
     for (auto& kv : c->free_blocks) cached += kv.first;
+    for (const zkm_ctx* l : c->lanes) {
+        size_t a = 0, b = 0;
+        zkm_ctx_memory(l, &a, &b);
+        live += a;
+        cached += b;
+    }
     if (live_bytes) *live_bytes = live;
     if (cached_bytes) *cached_bytes = cached;
 }
@@ -207,27 +230,39 @@ int zkm_dev_download(zkm_ctx* c, void* dst, const void* src, size_t bytes, char*
 }
 
 // ------------------------------------------------------------------ profiling
-void zkm_profile_enable(zkm_ctx* c, int on) { c->profiling = on != 0; }
+void zkm_profile_enable(zkm_ctx* c, int on) {
+    c->profiling = on != 0;
+    for (zkm_ctx* l : c->lanes) l->profiling = c->profiling;
+}
 void zkm_profile_reset(zkm_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& r : c->prof) { c->event_pool.push_back(r.start); c->event_pool.push_back(r.stop); }
     c->prof.clear();
     c->prof_agg.clear();
     c->prof_agg_valid = false;
+    for (zkm_ctx* l : c->lanes) zkm_profile_reset(l);
 }
-static void prof_aggregate(zkm_ctx* c) {
-    if (c->prof_agg_valid) return;
-    (void)hipStreamSynchronize(c->stream);
-    c->prof_agg.clear();
-    for (auto& r : c->prof) {
+// (records of the commit lanes are reported with the context's: launches that ran side by side on different lanes each count
+// their own duration, so a sum over kernels can exceed the wall time of a segment)
+static void prof_collect(zkm_ctx* from, std::vector<zkm_ctx::agg>& agg) {
+    (void)hipStreamSynchronize(from->stream);
+    for (auto& r : from->prof) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) ms = 0;
         bool found = false;
-        for (auto& a : c->prof_agg)
+        for (auto& a : agg)
             if (a.name == r.name || !strcmp(a.name, r.name)) { a.launches++; a.ms += ms; found = true; break; }
-        if (!found) c->prof_agg.push_back({r.name, 1, (double)ms});
+        if (!found) agg.push_back({r.name, 1, (double)ms});
     }
-    c->prof_agg_valid = true;
+}
+static void prof_aggregate(zkm_ctx* c) {
+    bool lane_records = false;
+    for (zkm_ctx* l : c->lanes) lane_records = lane_records || !l->prof.empty();
+    if (c->prof_agg_valid && !lane_records) return;
+    c->prof_agg.clear();
+    prof_collect(c, c->prof_agg);
+    for (zkm_ctx* l : c->lanes) prof_collect(l, c->prof_agg);
+    c->prof_agg_valid = !lane_records;   // (lane records may still grow without invalidating this context's flag)
 }
 size_t zkm_profile_count(zkm_ctx* c) {
     prof_aggregate(c);
@@ -283,15 +318,44 @@ void zkm_standard_config(zkm_stark_config* c) {
 // ------------------------------------------------------------------ PolynomialBatch
 // from_values: iNTT each column (coefficients kept), then from_coeffs: coset LDE (x 2^rate_bits, shift g),
 // rows in bit-reversed order, Poseidon Merkle tree, cap.  src may be a host or device pointer.
-void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t* dev_values) {
+// Values that arrive from the host and STAY on the device for other readers (dev_values: the CTL / lookup column kernels of
+// prove_with_traces read them with canonical arithmetic) are canonicalised once after the upload: a plonky2 GoldilocksField may hold
+// any u64 representing its residue (products are reduced to < 2^64, not < p), and the Rust side hands its columns over as they lie.
+// The transforms themselves accept any representative (loose arithmetic), so the commitment is that of the same polynomial.
+__global__ __launch_bounds__(256) void k_canon(gl_t* __restrict__ v, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) v[i] = gl_canon(v[i]);
+}
+void zkm_launch_canon(zkm_ctx* c, gl_t* v, size_t total) {
+    zkm_prof_scope ps(c, "ingest_canonicalise");
+    hipLaunchKernelGGL(k_canon, dim3((total + 255) / 256), dim3(256), 0, c->stream, v, total);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
+// src_cols (optional, instead of src): one pointer per column, each to n words -- the reference's Vec<PolynomialValues<F>> is one heap
+// allocation per column (prover.rs:154-163), so the Rust side hands the column pointers over instead of flattening 2 GiB on the host.
+void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t* dev_values, const uint64_t* const* src_cols) {
     zkm_ctx* c = b->ctx;
     size_t n = b->n(), N = b->N(), ncols = b->ncols;
     if (b->log_n + b->rate_bits > 30) throw std::runtime_error("polynomial batch too large");
+    if (!src && !src_cols) throw std::runtime_error("polynomial batch: no source");
+    if (src_cols)
+        for (size_t i = 0; i < ncols; i++)
+            if (!src_cols[i]) throw std::runtime_error("polynomial batch: null column pointer");
+    // columns [c0, c0 + nc) of the source to dst (column stride n) on stream st
+    auto copy_cols = [&](gl_t* dst, size_t c0, size_t nc, hipMemcpyKind kind, hipStream_t st) {
+        if (!src_cols) {
+            ZKM_HIP_CHECK(hipMemcpyAsync(dst, src + c0 * n, nc * n * sizeof(gl_t), kind, st));
+            return;
+        }
+        for (size_t i = 0; i < nc; i++)
+            ZKM_HIP_CHECK(hipMemcpyAsync(dst + i * n, src_cols[c0 + i], n * sizeof(gl_t), hipMemcpyDefault, st));
+    };
     b->coeffs = (gl_t*)c->alloc(ncols * n * sizeof(gl_t));
     b->lde = (gl_t*)c->alloc(ncols * N * sizeof(gl_t));
     size_t dwords = zkm_merkle_layout(b->lde_bits(), b->cap_height, b->level_off);
     b->digests = (gl_t*)c->alloc(dwords * sizeof(gl_t));
-    bool dev = zkm_is_device_ptr(src);
+    bool dev = !src_cols && zkm_is_device_ptr(src);   // (column pointers are staged like host values, wherever each one lives)
     hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const size_t CH = c->ingest_chunk_cols;
     bool leaves_done = false;
@@ -321,7 +385,7 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
             for (size_t k = 0; k < nchunks; k++) {
                 size_t c0 = k * CH, nc = std::min(CH, ncols - c0);
                 gl_t* dst = dev_values ? dev_values + c0 * n : b->lde + c0 * N;
-                ZKM_HIP_CHECK(hipMemcpyAsync(dst, src + c0 * n, nc * n * sizeof(gl_t), hipMemcpyHostToDevice, c->copy_stream));
+                copy_cols(dst, c0, nc, hipMemcpyHostToDevice, c->copy_stream);
                 ev.push_back(c->get_event());
                 ZKM_HIP_CHECK(hipEventRecord(ev.back(), c->copy_stream));
             }
@@ -329,6 +393,7 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
                 size_t c0 = k * CH, nc = std::min(CH, ncols - c0);
                 gl_t* vals = dev_values ? dev_values + c0 * n : b->lde + c0 * N;
                 ZKM_HIP_CHECK(hipStreamWaitEvent(c->stream, ev[k + 1], 0));
+                if (dev_values) zkm_launch_canon(c, vals, nc * n);
                 zkm_ntt_natural_ex(c, vals, n, b->lde + c0 * N, n, b->coeffs + c0 * n, n, nc, b->log_n, /*inverse=*/true, 0);
                 zkm_lde_bitrev(c, b->coeffs + c0 * n, b->lde + c0 * N, nc, b->log_n, b->rate_bits, GL_GENERATOR);
                 zkm_launch_merkle_leaves_chunk(c, b->lde + c0 * N, N, nc, N, state.as<gl_t>(), k == 0, k + 1 == nchunks, b->digests);
@@ -345,10 +410,11 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
     } else if (src_is_values) {
         // stage the values in the (not yet used) LDE buffer (or the caller's device copy), transform, land natural-order coefficients
         gl_t* vals = dev_values ? dev_values : b->lde;
-        ZKM_HIP_CHECK(hipMemcpyAsync(vals, src, ncols * n * sizeof(gl_t), kind, c->stream));
+        copy_cols(vals, 0, ncols, kind, c->stream);
+        if (dev_values) zkm_launch_canon(c, vals, ncols * n);
         zkm_ntt_natural_ex(c, vals, n, b->lde, n, b->coeffs, n, ncols, b->log_n, /*inverse=*/true, 0);
     } else {
-        ZKM_HIP_CHECK(hipMemcpyAsync(b->coeffs, src, ncols * n * sizeof(gl_t), kind, c->stream));
+        copy_cols(b->coeffs, 0, ncols, kind, c->stream);
     }
     if (!leaves_done) {
         zkm_lde_bitrev(c, b->coeffs, b->lde, ncols, b->log_n, b->rate_bits, GL_GENERATOR);
@@ -383,10 +449,10 @@ static zkm_batch* batch_new(zkm_ctx* c, size_t ncols, unsigned log_n, unsigned r
 
 // from_values keeping the uploaded values in dev_values (see zkm_batch_build); throws
 zkm_batch* zkm_batch_commit_values_keep(zkm_ctx* c, const uint64_t* values, size_t ncols, unsigned log_n, unsigned rate_bits,
-                                        unsigned cap_height, gl_t* dev_values) {
+                                        unsigned cap_height, gl_t* dev_values, const uint64_t* const* columns) {
     zkm_batch* b = batch_new(c, ncols, log_n, rate_bits, cap_height);
     try {
-        zkm_batch_build(b, values, true, dev_values);
+        zkm_batch_build(b, values, true, dev_values, columns);
     } catch (...) {
         zkm_batch_free(b);
         throw;
@@ -407,6 +473,24 @@ int zkm_batch_commit_values(zkm_ctx* c, const uint64_t* values, size_t ncols, un
     } catch (const std::exception& e) {
         zkm_batch_free(b);
         return fail(err, e.what());
+    }
+    return 0;
+}
+int zkm_batch_commit_columns(zkm_ctx* c, const uint64_t* const* columns, size_t ncols, unsigned log_n, int columns_are_values,
+                             unsigned rate_bits, unsigned cap_height, zkm_batch** out, char** err) {
+    zkm_batch* b = nullptr;
+    try {
+        if (!c || !columns || !out) throw std::runtime_error("zkm_batch_commit_columns: null argument");
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        b = batch_new(c, ncols, log_n, rate_bits, cap_height);
+        zkm_batch_build(b, nullptr, columns_are_values != 0, nullptr, columns);
+        *out = b;
+    } catch (const std::exception& e) {
+        zkm_batch_free(b);
+        return fail(err, e.what());
+    } catch (...) {
+        zkm_batch_free(b);
+        return fail(err, "zkm_batch_commit_columns: unknown error");
     }
     return 0;
 }
@@ -587,7 +671,7 @@ static int sponge_trace(zkm_ctx* c, const char* what, size_t rate, bool poseidon
         if (nops) ZKM_HIP_CHECK(hipMemcpyAsync(d_meta, meta, nops * 32, hipMemcpyHostToDevice, c->stream));
         ZKM_HIP_CHECK(hipMemcpyAsync(d_row, row_off.data(), (nops + 1) * 8, hipMemcpyHostToDevice, c->stream));
         if (poseidon) zkm_launch_poseidon_sponge_trace(c, d_in, d_off, d_meta, d_row, nops, log_n, out_dev);
-        else zkm_launch_keccak_sponge_trace(c, d_in, d_off, d_meta, d_row, nops, log_n, out_dev);
+        else zkm_launch_keccak_sponge_trace(c, d_in, d_off, d_meta, d_row, nops, (size_t)row_off[nops], log_n, out_dev);
         c->sync();
         if (rows_used_out) *rows_used_out = row_off[nops];
         for (void* p : tmp) c->release(p);

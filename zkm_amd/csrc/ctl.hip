@@ -6,6 +6,11 @@
 // reference batch-inverts, the inverse is unique so the bytes agree), accumulate helper columns, then an
 // additive suffix scan produces the upside-down running sum Z.
 #define GL_REDUCE_BRANCHFREE 1   // (gl_dev.h: these kernels interleave independent products at low occupancy)
+#include <algorithm>
+#include <atomic>
+#include <exception>
+#include <thread>
+
 #include "ctl_dev.h"
 #include "all_stark_ctl.inc"
 
@@ -450,13 +455,30 @@ int zkm_prove_segment(zkm_ctx* c, const zkm_stark_config* cfg, const uint64_t* c
                       const uint64_t* pub, size_t npub, uint64_t* proofs, size_t* offsets_out, uint64_t* challenges, char** err) {
     if (!traces || !log_n) return fail(err, "zkm_prove_segment: null argument");
     zkm_table_input tables[12];
-    for (int t = 0; t < 12; t++) tables[t] = zkm_table_input{AS_TABLE_IDS[t], traces[t], AS_TABLE_WIDTH[t], log_n[t], &AS_CTL_TABLES[t]};
+    for (int t = 0; t < 12; t++) tables[t] = zkm_table_input{AS_TABLE_IDS[t], traces[t], AS_TABLE_WIDTH[t], log_n[t], &AS_CTL_TABLES[t], nullptr};
     size_t offs[13];
     size_t total = zkm_all_proof_words(cfg, tables, 12, AS_CTLS, AS_SIDES, AS_NCTLS, offs);
     if (!total) return fail(err, "zkm_prove_segment: unsupported configuration or table size");
     if (offsets_out) memcpy(offsets_out, offs, sizeof offs);
     if (!proofs) return 0;  // sizing pass
     if (!c || !challenges) return fail(err, "zkm_prove_segment: null argument");
+    return zkm_prove_with_traces(c, cfg, tables, 12, AS_CTLS, AS_SIDES, AS_NCTLS, pub, npub, proofs, challenges, err);
+}
+
+int zkm_prove_segment_columns(zkm_ctx* c, const zkm_stark_config* cfg, const uint64_t* const* const* columns, const unsigned* log_n,
+                              const uint64_t* pub, size_t npub, uint64_t* proofs, size_t* offsets_out, uint64_t* challenges, char** err) {
+    if (!columns || !log_n) return fail(err, "zkm_prove_segment_columns: null argument");
+    zkm_table_input tables[12];
+    for (int t = 0; t < 12; t++) {
+        if (!columns[t]) return fail(err, "zkm_prove_segment_columns: null table");
+        tables[t] = zkm_table_input{AS_TABLE_IDS[t], nullptr, AS_TABLE_WIDTH[t], log_n[t], &AS_CTL_TABLES[t], columns[t]};
+    }
+    size_t offs[13];
+    size_t total = zkm_all_proof_words(cfg, tables, 12, AS_CTLS, AS_SIDES, AS_NCTLS, offs);
+    if (!total) return fail(err, "zkm_prove_segment_columns: unsupported configuration or table size");
+    if (offsets_out) memcpy(offsets_out, offs, sizeof offs);
+    if (!proofs) return 0;  // sizing pass
+    if (!c || !challenges) return fail(err, "zkm_prove_segment_columns: null argument");
     return zkm_prove_with_traces(c, cfg, tables, 12, AS_CTLS, AS_SIDES, AS_NCTLS, pub, npub, proofs, challenges, err);
 }
 
@@ -488,14 +510,60 @@ size_t zkm_all_proof_words(const zkm_stark_config* cfg, const zkm_table_input* t
     }
 }
 
+}  // extern "C"
+
+// Work that is independent per table -- the trace commitments, and after the CTL challenges the CTL data + auxiliary commitments --
+// runs side by side on the context's COMMIT LANES (sub-contexts with their own stream, allocator and tables, one host thread
+// each; the calling thread works on the context itself).  A segment of the reference's default size has nine tables of 2^6 .. 2^13
+// rows whose launches cannot fill the GPU and are chains of latency-bound steps (small Merkle levels, cap downloads): `small`
+// tables are pulled from one queue, largest first; `big` ones (LDE over 1 GiB: they fill the machine on their own) stay on the
+// context.  fn(worker context, table index); the first exception stops the queue and is rethrown on the caller.
+template <class F>
+static void run_on_lanes(zkm_ctx* c, const std::vector<size_t>& big, const std::vector<size_t>& small, F&& fn) {
+    const size_t nlanes = small.size() >= 2 ? std::min<size_t>(ZKM_COMMIT_LANES, small.size()) - 1 : 0;
+    c->ensure_lanes(nlanes);
+    std::atomic<size_t> next{0};
+    std::vector<std::exception_ptr> errs(nlanes + 1);
+    auto work = [&](zkm_ctx* w, size_t slot, bool take_big) {
+        try {
+            ZKM_HIP_CHECK(hipSetDevice(c->device));
+            if (take_big)
+                for (size_t t : big) fn(w, t);
+            for (size_t i = next.fetch_add(1); i < small.size(); i = next.fetch_add(1)) fn(w, small[i]);
+        } catch (...) {
+            errs[slot] = std::current_exception();
+            next.store(small.size());                    // stop handing out work
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t k = 0; k < nlanes; k++) threads.emplace_back(work, c->lanes[k], k + 1, false);
+    work(c, 0, true);
+    for (auto& th : threads) th.join();
+    for (auto& e : errs)
+        if (e) std::rethrow_exception(e);
+}
+
+extern "C" {
+
 int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_table_input* tables, size_t ntables,
                           const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls, const uint64_t* pub,
                           size_t npub, uint64_t* proofs, uint64_t* challenges, char** err) {
-    std::vector<zkm_batch*> commits(ntables, nullptr);
+    std::vector<zkm_batch*> commits(ntables, nullptr), aux_commits(ntables, nullptr);
     std::vector<gl_t*> d_traces(ntables, nullptr);  // device copies of host-resident traces: uploaded ONCE (with the commitment), reused below
+    std::vector<zkm_ctx*> d_owner(ntables, nullptr);  // ... each from the allocator of the context (commit lane) that uploaded it
     auto drop_traces = [&]() {
         (void)hipStreamSynchronize(c->stream);
-        for (auto& p : d_traces) { c->release(p); p = nullptr; }
+        for (size_t t = 0; t < d_traces.size(); t++) {
+            if (d_traces[t]) (d_owner[t] ? d_owner[t] : c)->release(d_traces[t]);
+            d_traces[t] = nullptr;
+        }
+    };
+    auto drop_all = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        for (zkm_ctx* l : c->lanes) (void)hipStreamSynchronize(l->stream);
+        for (auto b : commits) zkm_batch_free(b);
+        for (auto b : aux_commits) zkm_batch_free(b);
+        drop_traces();
     };
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
@@ -527,18 +595,32 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
         size_t free_b = 0, total_b = 0, kept = 0;
         ZKM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         const size_t keep_limit = free_b / 4;
+        std::vector<char> keep(ntables, 0), host(ntables, 0);
+        std::vector<size_t> big, small;
         {
             zkm_prof_scope st(c, "stage/compute all trace commitments");
+            // The commitments do not depend on each other -- only the transcript does, and it starts after them (prover.rs:144-167 is a
+            // plain loop; :182-185 observes the caps in table order): run_on_lanes.
             for (size_t t = 0; t < ntables; t++) {
                 if (tables[t].ncols == 0 || tables[t].log_n > 30) throw std::runtime_error("zkm_prove_with_traces: bad table shape");
+                if (!tables[t].trace && !tables[t].columns) throw std::runtime_error("zkm_prove_with_traces: table without a trace");
                 const size_t bytes = (tables[t].ncols << tables[t].log_n) * sizeof(gl_t);
-                const bool host = !zkm_is_device_ptr(tables[t].trace);
-                const bool keep = host && kept + bytes <= keep_limit;
-                if (keep) { d_traces[t] = (gl_t*)c->alloc(bytes); kept += bytes; }
-                commits[t] = zkm_batch_commit_values_keep(c, tables[t].trace, tables[t].ncols, tables[t].log_n, cfg->rate_bits, cfg->cap_height,
-                                                          d_traces[t]);
-                zkm_challenger_observe(&ch, commits[t]->cap.data(), commits[t]->cap.size());  // :182-185
+                host[t] = tables[t].columns || !zkm_is_device_ptr(tables[t].trace);   // (column pointers are gathered into one device block)
+                keep[t] = host[t] && kept + bytes <= keep_limit;
+                if (keep[t]) kept += bytes;
+                ((bytes << cfg->rate_bits) > ((size_t)1 << 30) ? big : small).push_back(t);
             }
+            std::sort(small.begin(), small.end(),
+                      [&](size_t a, size_t b) { return (tables[a].ncols << tables[a].log_n) > (tables[b].ncols << tables[b].log_n); });
+            run_on_lanes(c, big, small, [&](zkm_ctx* w, size_t t) {
+                if (keep[t]) {
+                    d_traces[t] = (gl_t*)w->alloc((tables[t].ncols << tables[t].log_n) * sizeof(gl_t));
+                    d_owner[t] = w;
+                }
+                commits[t] = zkm_batch_commit_values_keep(w, tables[t].trace, tables[t].ncols, tables[t].log_n, cfg->rate_bits, cfg->cap_height,
+                                                          d_traces[t], tables[t].columns);
+            });
+            for (size_t t = 0; t < ntables; t++) zkm_challenger_observe(&ch, commits[t]->cap.data(), commits[t]->cap.size());  // :182-185
         }
         zkm_challenger_observe(&ch, pub, npub);  // :187 observe_public_values
         for (unsigned k = 0; k < cfg->num_challenges; k++) {  // :190, beta then gamma (cross_table_lookup.rs:560-566)
@@ -548,48 +630,63 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
         auto tz = derive_zs(ntables, ctls, sides, nctls, cfg->num_challenges, challenges);
         uint64_t lookup_ch[4];  // the betas of the CTL challenges (prover.rs:468-474)
         for (unsigned k = 0; k < cfg->num_challenges; k++) lookup_ch[k] = challenges[2 * k];
-        // "compute CTL data" :191-200 + "compute all proofs given commitments" :234-438: tables in order, one transcript
-        for (size_t t = 0; t < ntables; t++) {
-            size_t n = (size_t)1 << tables[t].log_n;
+        // "compute CTL data" :191-200 and each table's "compute auxiliary polynomials commitment" :511-522 (with its "compute lookup helper
+        // columns" :475-493) depend on the CTL challenges only, not on the transcript of the table proofs: all tables' auxiliary
+        // commitments are built now, side by side (run_on_lanes).  The transcript then observes them in table order, below.
+        run_on_lanes(c, big, small, [&](zkm_ctx* w, size_t t) {
+            if (tz[t].naux == 0) return;   // ("No CTL?" -- reported by prove_single_table in table order, prover.rs:509)
+            const size_t n = (size_t)1 << tables[t].log_n, W = tables[t].ncols;
+            const size_t NL = zkm_num_lookup_columns(tables[t].table_id, cfg), A = NL + tz[t].naux;
             ctl_dev_owner own;
-            own.upload(c, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), false, tables[t].ncols);
-            if (!d_traces[t] && !zkm_is_device_ptr(tables[t].trace)) {  // (over the keep budget: second upload)
-                d_traces[t] = (gl_t*)c->alloc(tables[t].ncols * n * sizeof(gl_t));
-                ZKM_HIP_CHECK(hipMemcpyAsync(d_traces[t], tables[t].trace, tables[t].ncols * n * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+            own.upload(w, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), false, W);
+            const gl_t* d_trace = d_traces[t] ? d_traces[t] : tables[t].trace;
+            zkm_scratch again(w, (!d_traces[t] && host[t]) ? W * n * sizeof(gl_t) : 8);
+            if (!d_traces[t] && host[t]) {   // (over the keep budget: second upload)
+                gl_t* d = again.as<gl_t>();
+                if (tables[t].columns)
+                    for (size_t i = 0; i < W; i++) ZKM_HIP_CHECK(hipMemcpyAsync(d + i * n, tables[t].columns[i], n * sizeof(gl_t), hipMemcpyDefault, w->stream));
+                else
+                    ZKM_HIP_CHECK(hipMemcpyAsync(d, tables[t].trace, W * n * sizeof(gl_t), hipMemcpyHostToDevice, w->stream));
+                zkm_launch_canon(w, d, W * n);   // (as zkm_batch_build does for the copies it keeps)
+                d_trace = d;
             }
-            gl_t* d_trace = d_traces[t] ? d_traces[t] : const_cast<gl_t*>(tables[t].trace);
-            gl_t* d_aux = (gl_t*)c->alloc((tz[t].naux ? tz[t].naux : 1) * n * 8);
-            int rc = 0;
-            char* e = nullptr;
+            zkm_scratch d_all(w, A * n * sizeof(gl_t));   // [lookup helper columns | CTL helper columns and Zs], prover.rs:497-508
+            {
+                zkm_prof_scope st(w, "stage/compute CTL data");
+                zkm_ctl_data_device(w, own, d_trace, tables[t].log_n, d_all.as<gl_t>() + NL * n);
+            }
+            if (NL) {
+                zkm_prof_scope st(w, "stage/compute lookup helper columns");
+                zkm_table_lookup_columns_device(w, tables[t].table_id, lookup_ch, cfg->num_challenges, d_trace, n, d_all.as<gl_t>());
+            }
+            zkm_prof_scope st(w, "stage/compute auxiliary polynomials commitment");
+            zkm_batch* ab = new zkm_batch();
+            ab->ctx = w; ab->ncols = A; ab->log_n = tables[t].log_n; ab->rate_bits = cfg->rate_bits; ab->cap_height = cfg->cap_height;
+            aux_commits[t] = ab;   // (owned from here on: freed with the others on every exit path)
+            zkm_batch_build(ab, d_all.as<uint64_t>(), true);
+            w->sync();             // d_all / `again` go back to the lane's allocator when this returns
+        });
+        drop_traces();             // the device copies of the traces have served their purpose (commitment, CTL data, lookup columns)
+        // "compute all proofs given commitments" :234-438: tables in order, one transcript
+        for (size_t t = 0; t < ntables; t++) {
             try {
-                {
-                    zkm_prof_scope st(c, "stage/compute CTL data");  // :191-200 (per table here: the data of table t is built right before its proof)
-                    zkm_ctl_data_device(c, own, d_trace, tables[t].log_n, d_aux);
-                }
-                rc = zkm_prove_single_table_ctl(c, tables[t].table_id, cfg, d_trace, tables[t].ncols, tables[t].log_n, commits[t], d_aux,
-                                                tz[t].naux, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), lookup_ch,
-                                                &ch, proofs + offs[t], &e);
-            } catch (...) {
-                (void)hipStreamSynchronize(c->stream);
-                c->release(d_aux);
-                throw;
-            }
-            c->release(d_aux);
-            c->release(d_traces[t]);  // (stream-ordered reuse; the table's proof has been downloaded, i.e. the stream is drained)
-            d_traces[t] = nullptr;
-            if (rc) {
-                std::string msg = e ? e : "prove_single_table failed";
-                free(e);
-                throw std::runtime_error("table " + std::to_string(t) + ": " + msg);
+                if (!aux_commits[t]) throw std::runtime_error("No CTL? aux column count does not match the CTL description");  // prover.rs:509
+                zkm_challenger local = ch;
+                zkm_prove_single_table_aux(c, tables[t].table_id, cfg, tables[t].ncols, tables[t].log_n, commits[t], aux_commits[t], tz[t].naux,
+                                           tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), lookup_ch, &local, proofs + offs[t]);
+                ch = local;
+            } catch (const std::exception& e) {
+                throw std::runtime_error("table " + std::to_string(t) + ": " + e.what());
             }
         }
     } catch (const std::exception& e) {
-        for (auto b : commits) zkm_batch_free(b);
-        drop_traces();
+        drop_all();
         return fail(err, e.what());
+    } catch (...) {
+        drop_all();
+        return fail(err, "zkm_prove_with_traces: unknown error");
     }
-    for (auto b : commits) zkm_batch_free(b);
-    drop_traces();
+    drop_all();
     return 0;
 }
 

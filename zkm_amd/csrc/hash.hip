@@ -156,18 +156,54 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_ext(const gl_t* __restric
     *reinterpret_cast<ulonglong2*>(d + 2) = make_ulonglong2(s[2], s[3]);
 }
 
-// ------------------------------------------------------------------ Merkle inner level
-__global__ __launch_bounds__(256) void k_merkle_compress(const gl_t* __restrict__ children, gl_t* __restrict__ parents,
-                                                         size_t nparents) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nparents) return;
-    const ulonglong2* ch = reinterpret_cast<const ulonglong2*>(children + 8 * i);
-    ulonglong2 a = ch[0], b = ch[1], cc = ch[2], d = ch[3];
-    uint64_t s[12] = {a.x, a.y, b.x, b.y, cc.x, cc.y, d.x, d.y, 0, 0, 0, 0};
-    poseidon_permute_out(s, POSEIDON_OUT_DIGEST);
-    uint64_t* o = parents + 4 * i;
-    *reinterpret_cast<ulonglong2*>(o) = make_ulonglong2(s[0], s[1]);
-    *reinterpret_cast<ulonglong2*>(o + 2) = make_ulonglong2(s[2], s[3]);
+// ------------------------------------------------------------------ Merkle inner levels, fused (K5)
+// plonky2 builds a tree in one call (MerkleTree::new, call sites prover.rs:154-163); here a launch takes up to THREE levels.
+// Large levels (first level of the launch >= 2^17 parents): one hash per lane.  A workgroup of 256 threads owns 512 children of
+// level l and produces their 256 parents, then -- from LDS, no trip through HBM -- the 128 and the 64 nodes above (whole waves
+// stay active: 4, 2, 1, and the waves that are done leave at once).  Every level is also stored (Merkle paths read all of them).  The permutation code exists once (the level
+// loop is not unrolled), so the kernel stays within the instruction cache like k_merkle_leaves.
+struct merkle_fused_args {
+    const gl_t* children;   // level l: 2 * nparents digests
+    gl_t* parents[3];       // levels l + 1 .. l + 3
+    uint32_t levels;        // 1 .. 3
+};
+
+__global__ __launch_bounds__(256) void k_merkle_fused(merkle_fused_args p) {
+    __shared__ uint64_t sh[2][4][256];                    // [buffer][word][node]: parents of the level just made, word-major
+    const unsigned tid = threadIdx.x;
+    uint64_t s[12];
+    {
+        const ulonglong2* ch = reinterpret_cast<const ulonglong2*>(p.children + 8 * ((size_t)blockIdx.x * 256 + tid));
+        ulonglong2 a = ch[0], b = ch[1], cc = ch[2], d = ch[3];
+        s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = cc.x; s[5] = cc.y; s[6] = d.x; s[7] = d.y;
+    }
+#pragma unroll 1
+    for (unsigned lvl = 0; lvl < p.levels; lvl++) {
+        const unsigned width = 256u >> lvl;               // nodes of this level in the workgroup: 256, 128, 64 == the surviving threads
+        if (lvl) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                s[w] = sh[(lvl - 1) & 1][w][2 * tid];
+                s[4 + w] = sh[(lvl - 1) & 1][w][2 * tid + 1];
+            }
+        }
+#pragma unroll
+        for (int w = 8; w < 12; w++) s[w] = 0;
+        poseidon_permute_out(s, POSEIDON_OUT_DIGEST);
+        uint64_t* o = p.parents[lvl] + 4 * ((size_t)blockIdx.x * width + tid);
+        *reinterpret_cast<ulonglong2*>(o) = make_ulonglong2(s[0], s[1]);
+        *reinterpret_cast<ulonglong2*>(o + 2) = make_ulonglong2(s[2], s[3]);
+        if (lvl + 1 < p.levels) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) sh[lvl & 1][w][tid] = s[w];
+        }
+        if (lvl + 1 == p.levels) return;
+        __syncthreads();
+        // Waves without a node in the next level leave NOW and free their slots for the next workgroup (s_barrier only waits for the
+        // surviving waves of a workgroup): parked at the barriers they would hold a third of the CU's wave slots idle, and this
+        // kernel needs every slot it can get (one permutation per lane is ~12k dependent-ish instructions).
+        if (tid >= (width >> 1)) return;
+    }
 }
 
 // ---- one permutation across 12 lanes (small tree levels) ----
@@ -176,7 +212,7 @@ __global__ __launch_bounds__(256) void k_merkle_compress(const gl_t* __restrict_
 // twelve state words): every round is constant add, x^7 (lane 0 only in the partial rounds), and the circulant MDS with the
 // twelve rotated neighbours fetched by ds_bpermute -- the textbook rounds (poseidon_stark.rs:65-95, 164-169, 239-251, 310-345),
 // 30 x ~190 instructions per lane instead of ~18k, i.e. a quarter of the latency at ~5x the total work.  Used when a level has
-// at most wide_max_parents() nodes (16384; ZKM_WIDE_MAX tunes it).  Bit-exact with poseidon_permute (the fused partial rounds are an algebraic regrouping).
+// fewer than 2^17 nodes (k_merkle_fused_wide).  Bit-exact with poseidon_permute (the fused partial rounds are an algebraic regrouping).
 __device__ __forceinline__ uint64_t poseidon_permute_wide(uint64_t x, unsigned lane) {
     const unsigned idx = lane & 15, base = lane & ~15u;
     const bool active = idx < 12;
@@ -205,14 +241,44 @@ __device__ __forceinline__ uint64_t poseidon_permute_wide(uint64_t x, unsigned l
     return gl_canon(x);
 }
 
-__global__ __launch_bounds__(256) void k_merkle_compress_wide(const gl_t* __restrict__ children, gl_t* __restrict__ parents, size_t nparents) {
-    const unsigned lane = threadIdx.x & 63, idx = lane & 15;
-    const size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const bool live = p < nparents;  // uniform over the 16-lane row; every lane of the wave takes part in the shuffles
-    uint64_t x = 0;
-    if (live && idx < 8) x = children[8 * p + idx];
-    x = poseidon_permute_wide(x, lane);
-    if (live && idx < 4) parents[4 * p + idx] = x;
+// Small levels, fused: a workgroup (256 threads = 16 hash slots of 16 lanes) owns a subtree with 2^J children (J <= 6) and climbs
+// its J levels through LDS -- ceil(2^(J-k) / 16) rounds of wide permutations at level k -- instead of one launch per level: the top
+// of a tree is a chain of dependent permutations (one wide permutation ~10 us), and every launch boundary added its gap to it.
+struct merkle_fused_wide_args {
+    const gl_t* children;   // level l: nsub * 2^J digests
+    gl_t* parents[6];       // levels l + 1 .. l + J
+    uint32_t J;             // levels in this launch (1 .. 6)
+};
+
+__global__ __launch_bounds__(256) void k_merkle_fused_wide(merkle_fused_wide_args p) {
+    __shared__ uint64_t sh[2][64 * 4];                    // digests of the current level of this subtree (AoS, as in HBM)
+    const unsigned tid = threadIdx.x, lane = tid & 63, idx = lane & 15, slot = tid >> 4;
+    const unsigned C = 1u << p.J;
+    {
+        const gl_t* src = p.children + (size_t)blockIdx.x * C * 4;
+        for (unsigned w = tid; w < C * 4; w += 256) sh[0][w] = src[w];
+    }
+    __syncthreads();
+    for (unsigned lvl = 0; lvl < p.J; lvl++) {
+        const unsigned np = C >> (lvl + 1);               // parents of this level in the subtree
+        const uint64_t* in = sh[lvl & 1];
+        uint64_t* out = sh[(lvl + 1) & 1];
+        gl_t* g = p.parents[lvl] + (size_t)blockIdx.x * np * 4;
+        if ((slot & ~3u) >= np) return;                  // this wave has no node here or above: leave (the barrier only counts survivors)
+        for (unsigned h0 = 0; h0 < np; h0 += 16) {
+            // (a wave holds four slots; one with no live slot in this round skips it -- uniform over the wave)
+            if (h0 + (slot & ~3u) >= np) continue;
+            const unsigned h = h0 + slot;
+            const bool live = h < np;                     // uniform over the 16-lane row; every lane of the wave shuffles
+            uint64_t x = (live && idx < 8) ? in[8 * h + idx] : 0;
+            x = poseidon_permute_wide(x, lane);
+            if (live && idx < 4) {
+                out[4 * h + idx] = x;
+                g[4 * h + idx] = x;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // Column-major leaves, one leaf per 16-lane row (see poseidon_permute_wide): lanes 0..7 of the row fetch the next eight columns of
@@ -230,15 +296,8 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_wide(const gl_t* __restri
     }
     if (live && idx < 4) digests[4 * leaf + idx] = x;
 }
-static size_t wide_max_leaves() {
-    static size_t v = [] { const char* e = getenv("ZKM_WIDE_MAX_LEAVES"); return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)16384; }();
-    return v;
-}
+static size_t wide_max_leaves() { return 16384; }
 
-static size_t wide_max_parents() {
-    static size_t v = [] { const char* e = getenv("ZKM_WIDE_MAX"); return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)16384; }();
-    return v;
-}
 
 // FRI layer leaves, one hash per 16-lane row (small layers): word m of leaf k is component m & 1 of value k * arity + (m >> 1).
 __global__ __launch_bounds__(256) void k_merkle_leaves_ext_wide(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nleaves,
@@ -258,19 +317,10 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_ext_wide(const gl_t* __re
 void zkm_launch_merkle_leaves_ext(zkm_ctx* c, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests) {
     if (arity % 4 || 2 * arity <= 4) throw std::runtime_error("merkle_leaves_ext: unsupported arity");
     zkm_prof_scope ps(c, "merkle_leaves_ext");
-    if (nleaves <= wide_max_parents() / 4)
+    if (nleaves <= 4096)   // small layers: one hash per 16-lane row
         hipLaunchKernelGGL(k_merkle_leaves_ext_wide, dim3((nleaves * 16 + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
     else
         hipLaunchKernelGGL(k_merkle_leaves_ext, dim3((nleaves + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
-    ZKM_HIP_CHECK(hipGetLastError());
-}
-
-void zkm_launch_merkle_compress(zkm_ctx* c, const gl_t* children, gl_t* parents, size_t nparents) {
-    zkm_prof_scope ps(c, "merkle_compress");
-    if (nparents <= wide_max_parents())
-        hipLaunchKernelGGL(k_merkle_compress_wide, dim3((nparents * 16 + 255) / 256), dim3(256), 0, c->stream, children, parents, nparents);
-    else
-        hipLaunchKernelGGL(k_merkle_compress, dim3((nparents + 255) / 256), dim3(256), 0, c->stream, children, parents, nparents);
     ZKM_HIP_CHECK(hipGetLastError());
 }
 
@@ -285,24 +335,77 @@ size_t zkm_merkle_layout(unsigned log_leaves, unsigned cap_height, std::vector<s
     return total;
 }
 
+// All digest levels above the leaves, up to the cap: fused launches (k_merkle_fused: <= 3 levels, one hash per lane, while the first
+// level of the launch has >= 2^17 nodes; k_merkle_fused_wide: <= 6 levels, 16 lanes per hash, below that).  A 2^22-leaf tree with a
+// 16-digest cap (18 levels) is 2 + 2 launches instead of 18.
 void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves,
                             unsigned cap_height) {
-    unsigned top = log_leaves - cap_height;
-    for (unsigned l = 1; l <= top; l++)
-        zkm_launch_merkle_compress(c, digests + level_off[l - 1], digests + level_off[l], (size_t)1 << (log_leaves - l));
+    const unsigned top = log_leaves - cap_height;
+    unsigned l = 0;                                        // level of the children of the next launch
+    while (l < top) {
+        zkm_prof_scope ps(c, "merkle_compress");
+        const unsigned log_p1 = log_leaves - l - 1;       // log2(#parents) of the first level made
+        const unsigned rem = top - l;
+        if (log_p1 >= 17) {
+            merkle_fused_args a{};
+            a.children = digests + level_off[l];
+            a.levels = rem < 3 ? rem : 3;
+            for (unsigned k = 0; k < a.levels; k++) a.parents[k] = digests + level_off[l + 1 + k];
+            hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(((size_t)1 << log_p1) / 256)), dim3(256), 0, c->stream, a);
+            l += a.levels;
+        } else {
+            merkle_fused_wide_args a{};
+            a.children = digests + level_off[l];
+            unsigned J = rem < 6 ? rem : 6;
+            if (J > log_p1 + 1) J = log_p1 + 1;           // (a subtree cannot have more children than the level)
+            a.J = J;
+            for (unsigned k = 0; k < J; k++) a.parents[k] = digests + level_off[l + 1 + k];
+            hipLaunchKernelGGL(k_merkle_fused_wide, dim3((unsigned)(((size_t)2 << log_p1) >> J)), dim3(256), 0, c->stream, a);
+            l += J;
+        }
+        ZKM_HIP_CHECK(hipGetLastError());
+    }
 }
 
-// ------------------------------------------------------------------ Keccak-f[1600]
-__global__ __launch_bounds__(256) void k_keccakf(uint64_t* states, size_t k) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= k) return;
-    uint64_t a[25];
-    uint64_t* st = states + idx * 25;
+// ------------------------------------------------------------------ Keccak-f[1600] batch (K15)
+// States are 25-word records (AoS: the layout of the reference's [u64; 25], cpu/kernel/keccak_util.rs:6-31).  One state per lane; a
+// wave's 64 states are 12.8 KB of CONTIGUOUS memory, moved as 25 coalesced 512 B accesses each way and transposed through the wave's
+// own LDS region (word j of lane t at t * 25 + j: the stride 25 is odd, so the 64-bit accesses of a half-wave hit 32 different
+// banks).  The direct form -- every lane loading its record at a 200 B stride -- touched 64 cache lines per instruction and ran at
+// 1.7 TB/s (profiles/r03_a_configs_4_5.json).  No workgroup barrier: a wave only touches its own region.
+#define ZKM_HASH_WAVE_SYNC()                                  \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+__global__ __launch_bounds__(256) void k_keccakf(uint64_t* __restrict__ states, size_t k) {
+    __shared__ uint64_t sh[4][64 * 25];
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t first = ((size_t)blockIdx.x * 4 + wv) * 64;            // first state of this wave
+    if (first >= k) return;                                               // (uniform over the wave)
+    const size_t nwords = (k - first < 64 ? k - first : 64) * 25;         // words this wave owns
+    uint64_t* const g = states + first * 25;
+    uint64_t* const w = sh[wv];
 #pragma unroll
-    for (int i = 0; i < 25; i++) a[i] = st[i];
+    for (int i = 0; i < 25; i++) {
+        const unsigned e = i * 64 + lane;
+        if (e < nwords) w[e] = g[e];
+    }
+    ZKM_HASH_WAVE_SYNC();
+    uint64_t a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = w[lane * 25 + i];                 // (lanes past the tail permute garbage that is never stored)
     keccakf_dev(a);
 #pragma unroll
-    for (int i = 0; i < 25; i++) st[i] = a[i];
+    for (int i = 0; i < 25; i++) w[lane * 25 + i] = a[i];
+    ZKM_HASH_WAVE_SYNC();
+#pragma unroll
+    for (int i = 0; i < 25; i++) {
+        const unsigned e = i * 64 + lane;
+        if (e < nwords) g[e] = w[e];
+    }
 }
 
 void zkm_launch_keccakf(zkm_ctx* c, uint64_t* states, size_t k) {

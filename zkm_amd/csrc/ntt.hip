@@ -98,12 +98,6 @@ extern "C" int zkm_field_selftest(zkm_ctx* c, const uint64_t* a, const uint64_t*
     return 0;
 }
 
-// development hooks for timing experiments (never defined in the product build): where does a pass spend its time?
-#if defined(ZKM_EXP_NOBAR)
-#define NTT_SYNC() ((void)0)
-#else
-#define NTT_SYNC() __syncthreads()
-#endif
 // ------------------------------------------------------------------ multi-stage LDS pass kernel
 // One launch performs S (3..8) consecutive radix-2 DIF stages of many length-2^S sub-transforms.
 // A workgroup owns a tile of R = 2^S "rows" (the butterfly dimension, element stride sa) x T "columns"
@@ -170,9 +164,6 @@ struct ntt_round {
         // all-loose arithmetic inside a pass: the sum and the difference take their one probable correction from the add's / subtract's
         // own carry-out and the improbable second one on a never-taken uniform branch (gl_add_rr / gl_sub_rr); the product is not
         // canonicalised at all; the last pass canonicalises on the way out (canon_out)
-#if defined(ZKM_EXP_NOCOMPUTE)
-        u += v; v ^= w; return;
-#endif
         const uint64_t t = gl_add_rr(u, v);
         v = gl_mul_loose(gl_sub_rr(u, v), w);
         u = t;
@@ -202,9 +193,6 @@ struct ntt_round {
     // roots are the negated powers w_8^-j = -2^(96 - 24 j): the sign goes into the subtraction (v - u instead of u - v).  Same field elements as compute() with the table twiddles, hence bit-exact.
     template <int E, bool NEG>
     __device__ static __forceinline__ void bfly_pow2(gl_t& u, gl_t& v) {
-#if defined(ZKM_EXP_NOCOMPUTE)
-        u += v; v ^= (uint64_t)E; return;
-#endif
         const uint64_t t = gl_add_rr(u, v), d = NEG ? gl_sub_rr(v, u) : gl_sub_rr(u, v);
         v = E ? gl_mul_pow2<(E ? E : 1)>(d) : d;
         u = t;
@@ -280,10 +268,7 @@ __device__ __forceinline__ void ntt_last_round(gl_t (&x)[8], const gl_t (&w)[7],
 // ZP: the input is shorter than the transform (rows beyond n_in read as zero): only then are loads bounds-checked.
 // PF: software-prefetch the next column (16 VGPRs); off where the kernel must stay within 128 VGPRs for two workgroups per CU.
 template <int S, bool IN_A, bool OUT_A, int PRE, int POST, bool ZP = false, bool PF = true>
-#ifndef ZKM_NTT_OCC
-#define ZKM_NTT_OCC 2
-#endif
-__global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(ntt_pass_args p) {
+__global__ __launch_bounds__(512, 2) void k_ntt_pass(ntt_pass_args p) {
     extern __shared__ __attribute__((aligned(16))) gl_t lds[];
     constexpr int R = 1 << S, NR = (S + 2) / 3;
     using R0 = ntt_round<S, 0>;
@@ -312,17 +297,10 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
     const size_t base_out = (size_t)t_hi * p.bo_hi + (size_t)t_lo * p.bo_lo;
     const size_t i_low = p.m ? (((size_t)t_lo << logT) + b) : 0;
 
-#if defined(ZKM_EXP_FAKETW)   // timing experiment: one twiddle set for all rounds (wrong results, 28 VGPRs less)
-    gl_t w0[7];
-    R0::load_tw(w0, p.tw, rg, p.m, i_low);
-    gl_t (&w1)[7] = w0;
-    gl_t (&w2)[7] = w0;
-#else
     gl_t w0[7], w1[7], w2[7];
     R0::load_tw(w0, p.tw, rg, p.m, i_low);
     if (NR > 1) R1::load_tw(w1, p.tw, rg, p.m, i_low);
     if (NR > 2) R2::load_tw(w2, p.tw, rg, p.m, i_low);
-#endif
 
     // column-independent offsets.  Every global access is (wave-uniform base) + (one 32-bit lane offset): the 8 row bases of a
     // thread differ by uniform multiples of the row step, so the addresses cost scalar adds, not a VGPR pair per row.
@@ -340,20 +318,12 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
     // Software pipeline over the workgroup's columns: the 8 words of column c + 1 are requested before column c is
     // transformed (16 VGPRs), so the HBM latency of the next loads is covered by ~800 VALU instructions instead of
     // being exposed at the top of every iteration.  nx[] holds raw words; the coset pre-scale is applied when they are consumed.
-#ifndef ZKM_NTT_PRE_SGPR
-#define ZKM_NTT_PRE_SGPR 0   // 1: apply D_k^j from SGPRs and B separately (15 products per column instead of 8, 14 VGPRs less)
-#endif
-#if ZKM_NTT_PRE_SGPR
-    gl_t preB = 0;
-    if (PRE == 3) preB = gl_canon(pow_lookup(pre_tab, p.pre_log, in0));
-#else
     gl_t gpre[8];
     if (PRE == 3) {
         const gl_t B = pow_lookup(pre_tab, p.pre_log, in0);
 #pragma unroll
         for (int j = 0; j < 8; j++) gpre[j] = j ? gl_mul(B, p.pre_dj[coset][j]) : gl_canon(B);
     }
-#endif
     gl_t nx[8];
     auto fetch = [&](uint32_t col) {
         const gl_t* __restrict__ src = p.in + (size_t)col * p.cs_in + base_in;   // wave-uniform
@@ -385,14 +355,8 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
             if (PRE == 3) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-#if ZKM_NTT_PRE_SGPR
-                    if (j) x[j] = gl_mul_loose(x[j], p.pre_dj[coset][j]);
-                    x[j] = gl_mul_loose(x[j], preB);
-                    __builtin_amdgcn_sched_barrier(0);
-#else
                     x[j] = gl_mul_loose(x[j], gpre[j]);
                     if (j & 1) __builtin_amdgcn_sched_barrier(0);
-#endif
                 }
             } else if (do_pre) {
 #pragma unroll
@@ -413,26 +377,24 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
                 if (do_pre && (!ZP || off < p.n_in)) v = gl_mul_loose(v, pow_lookup(pre_tab, p.pre_log, off));
                 lds[a * tp + bb] = v;
             }
-            NTT_SYNC();
+            __syncthreads();
             R0::lds_read(lds, tp, b, rg, x);
         }
-#if !defined(ZKM_EXP_NOMEM)
         if (PF && col + 1 < col1) fetch(col + 1);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if (!IN_A && S >= 3 && p.zero_padded) R0::compute_zero_padded(x, w0);
         else if (NR == 1) ntt_last_round<S, 0>(x, w0, p.pow2_last);
         else R0::compute(x, w0);
         if (NR > 1) {
             R0::lds_write(lds, tp, b, rg, x);
-            NTT_SYNC();
+            __syncthreads();
             R1::lds_read(lds, tp, b, rg, x);
             if (NR == 2) ntt_last_round<S, (NR > 1 ? 1 : 0)>(x, w1, p.pow2_last);
             else R1::compute(x, w1);
         }
         if (NR > 2) {
             R1::lds_write(lds, tp, b, rg, x);
-            NTT_SYNC();
+            __syncthreads();
             R2::lds_read(lds, tp, b, rg, x);
             if (NR == 3) ntt_last_round<S, (NR > 2 ? 2 : 0)>(x, w2, p.pow2_last);
             else R2::compute(x, w2);
@@ -454,14 +416,11 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int jj = p.rev_rows ? (int)(((j & 1) << 2) | (j & 2) | ((j >> 2) & 1)) : j;
-#if defined(ZKM_EXP_NOMEM)
-                if (x[j] == 0x0123456789abcdefull)
-#endif
                 (dst + (size_t)jj * out_step)[lane_out] = x[j];
             }
         } else {
             RL::lds_write(lds, tp, b, rg, x);
-            NTT_SYNC();
+            __syncthreads();
 #pragma unroll 2
             for (int e = 0; e < 8; e++) {
                 int idx = tid + e * nthreads;
@@ -477,7 +436,7 @@ __global__ __launch_bounds__(512, (PRE == 3 ? ZKM_NTT_OCC : 2)) void k_ntt_pass(
                 dst[off] = v;
             }
         }
-        if (IN_A || OUT_A || NR > 1) NTT_SYNC();  // LDS is reused by the next column
+        if (IN_A || OUT_A || NR > 1) __syncthreads();  // LDS is reused by the next column
     }
 }
 
@@ -566,18 +525,10 @@ static void launch_pass(zkm_ctx* c, int S, ntt_pass_args a, size_t ntiles, const
     ZKM_HIP_CHECK(hipGetLastError());
 }
 
-static size_t ntt_max_tile_elems() {
-    static const size_t v = [] {
-        const char* e = getenv("ZKM_NTT_TILE");  // tuning knob: elements per workgroup tile (threads = tile / 8)
-        size_t t = e ? (size_t)atol(e) : 2048;
-        if (t < 512 || t > 4096) t = 4096;      // threads = tile / 8 <= 512 (the kernel's launch bound)
-        return t;
-    }();
-    return v;
-}
 static uint32_t pick_log_T(int S, size_t bdim) {
+    constexpr size_t TILE = 2048;  // elements per workgroup tile (threads = tile / 8): measured best of 512 .. 4096 (profiles/r02_ubench_strided_tiles.txt)
     uint32_t lt = 6;  // 64 lanes along the tile's column dimension
-    while (lt > 0 && (((size_t)1 << S) << lt) > ntt_max_tile_elems()) lt--;
+    while (lt > 0 && (((size_t)1 << S) << lt) > TILE) lt--;
     while (lt > 0 && ((size_t)1 << lt) > bdim) lt--;
     return lt;
 }
@@ -749,56 +700,51 @@ __global__ __launch_bounds__((1 << SA) * 8) void k_ntt_big(ntt_big_args p) {
         gl_t x[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = nx[j];          // rows rg + (RA / 8) j == A0::row(rg, j), column b
-#if !defined(ZKM_EXP_NOMEM)
         if (blk + gridDim.x < total) {
             const gl_t* src = block_ptr(blk + gridDim.x);
 #pragma unroll
             for (int j = 0; j < 8; j++) nx[j] = src[tid + NT * j];
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 1: SA stages along the rows, lanes along b
         A0::compute(x, wa0);
         if (NR1 > 1) {
             A0::lds_write(lds, LP, 1, b, rg, x);
-            NTT_SYNC();
+            __syncthreads();
             A1::lds_read(lds, LP, 1, b, rg, x);
             A1::compute(x, wa1);
         }
         if (NR1 > 2) {
-            NTT_SYNC();
+            __syncthreads();
             A1::lds_write(lds, LP, 1, b, rg, x);
-            NTT_SYNC();
+            __syncthreads();
             A2::lds_read(lds, LP, 1, b, rg, x);
             A2::compute(x, wa2);
         }
         using AL = ntt_round_t<SA, NR1 - 1>;
-        if (NR1 > 1) NTT_SYNC();
+        if (NR1 > 1) __syncthreads();
         AL::lds_write(lds, LP, 1, b, rg, x);
-        NTT_SYNC();
+        __syncthreads();
         // ---- phase 2: the six stages inside each 64-element row, lanes along the rows
         B0::lds_read(lds, 1, LP, a2, rg2, x);
         B0::compute(x, wb0);
-        NTT_SYNC();
+        __syncthreads();
         B0::lds_write(lds, 1, LP, a2, rg2, x);
-        NTT_SYNC();
+        __syncthreads();
         B1::lds_read(lds, 1, LP, a2, rg2, x);
         B1::template compute_pow2<false>(x);
-        NTT_SYNC();
+        __syncthreads();
         B1::lds_write(lds, 1, LP, a2, rg2, x);
-        NTT_SYNC();
+        __syncthreads();
         // ---- out: word p of the block sits at lds[p + (p >> 6)]
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int pidx = tid + NT * j;
             gl_t v = lds[pidx + (pidx >> 6)];
             if (p.canon_out) v = gl_canon(v);
-#if defined(ZKM_EXP_NOMEM)
-            if (v == 0x0123456789abcdefull)
-#endif
             dst[pidx] = v;
         }
-        NTT_SYNC();  // LDS is reused by the next block
+        __syncthreads();  // LDS is reused by the next block
     }
 }
 
@@ -855,10 +801,10 @@ __global__ __launch_bounds__(512, 6) void k_ntt_blk12(ntt_big_args p) {
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = dst[tid + NT * j];
         R::compute(x, w1);                                        // stages 11, 10, 9
-        NTT_SYNC();                                               // the previous block's readers are done with the image
+        __syncthreads();                                               // the previous block's readers are done with the image
 #pragma unroll
         for (int j = 0; j < 8; j++) lds[j * SB + a1] = x[j];
-        NTT_SYNC();
+        __syncthreads();
         // per-lane LDS offsets of the wave-local rounds, recomputed per block from an opaque copy of the lane id (kept live across
         // the loop they would cost ~20 VGPRs)
         int l = lane;
@@ -899,9 +845,6 @@ __global__ __launch_bounds__(512, 6) void k_ntt_blk12(ntt_big_args p) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const gl_t v = sub[a2 + 72 * j];
-#if defined(ZKM_EXP_NOMEM)
-            if (v == 0x0123456789abcdefull)
-#endif
             out[l + 64 * j] = v;
         }
     }
@@ -932,12 +875,7 @@ static void ntt_big_pass(zkm_ctx* c, gl_t* data, size_t cs, size_t ncols, unsign
     zkm_prof_scope ps(c, "ntt_pass_big");
     switch (S2) {
         case 11: launch_big_t<5>(c, a); break;
-        case 12: {
-            static const bool old = getenv("ZKM_NTT_BIG_OLD") != nullptr;  // A/B switch: the 6 + 6 kernel
-            if (old) launch_big_t<6>(c, a);
-            else launch_blk12(c, a);
-            break;
-        }
+        case 12: launch_blk12(c, a); break;
         case 13: launch_big_t<7>(c, a); break;
         default: throw std::runtime_error("ntt big pass: unsupported stage count");
     }
@@ -985,9 +923,6 @@ struct ct_round : ntt_round<S, K> {
         }
     }
     __device__ static __forceinline__ void bfly(gl_t& u, gl_t& v, gl_t w) {
-#if defined(ZKM_EXP_NOCOMPUTE)
-        u += v; v ^= w; return;
-#endif
         const uint64_t t = gl_mul_loose(v, w);
         v = gl_sub_rr(u, t);
         u = gl_add_rr(u, t);
@@ -1066,16 +1001,14 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
         gl_t x[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = nx[j];
-#if !defined(ZKM_EXP_NOMEM)
         if (col + 1 < col1) fetch(col + 1);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         R0::compute(x, w0);
         if (NR > 1) {
             gl_t* const img = lds + (ex & 1) * (R * T);
             ex++;
             R0::lds_write(img, T, b, rg, x);
-            NTT_SYNC();
+            __syncthreads();
             R1::lds_read(img, T, b, rg, x);
             R1::compute(x, w1);
         }
@@ -1083,7 +1016,7 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
             gl_t* const img = lds + (ex & 1) * (R * T);
             ex++;
             R1::lds_write(img, T, b, rg, x);
-            NTT_SYNC();
+            __syncthreads();
             R2::lds_read(img, T, b, rg, x);
             R2::compute(x, w2);
         }
@@ -1094,9 +1027,6 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-#if defined(ZKM_EXP_NOMEM)
-            if (x[j] == 0x0123456789abcdefull)
-#endif
             (dst + (size_t)j * sa)[lane_out] = x[j];
         }
     }
@@ -1139,50 +1069,36 @@ static const gl_t* lde_ct_table(zkm_ctx* c, uint64_t shift, unsigned log_n, unsi
 
 // Coset-split LDE (rate 4): the evaluations on g<w_4n> in bit-reversed order are four blocks of n -- block bitrev2(k) holds the
 // size-n DIF transform of c_t (g w_4n^k)^t (position bitrev(k + 4 i) = bitrev2(k) n + bitrev(i)).  Two launches: (A) the upper
-// log_n - S2 stages of all four transforms, strided, coset-fused (the coefficients are read once from HBM, three more times from
+// S1 = log_n - S2 stages of all four transforms, strided, coset-fused (the coefficients are read once from HBM, three more times from
 // L2; 4n words written); (B) the lower S2 stages on contiguous 2^S2 blocks, in place.  HBM traffic per column 8n + 32n + 64n =
 // 104n bytes against 168n of the three-pass zero-padded transform.
+//   log_n      14   15..17   18..20    21    22
+//   S1 / S2   3/11  3..5/12  6..8/12  8/13  9/13      S1 >= 6: block-twiddle kernel k_lde_upper<S1>; below: plain DIF pass, factored pre-scale
+// S2 = 12 wherever pass A can take the other log_n - 12 stages: the 2^12-element block kernel runs three workgroups per CU, the 2^13
+// one a single one (measured at 262 x 2^20: 6.8 ms / 12 stages against 8.4 ms / 13 stages, profiles/r02_ntt_split_ab.txt).  2^22-row
+// polynomials (BASELINE config 4) need nine upper stages: a 512-row x 8-column tile, i.e. 64 B row segments -- slower per byte than
+// the 128 B segments of S1 = 8, still 104n instead of 168n bytes.
 static bool lde_coset_split(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, uint64_t shift) {
-    static const bool off = getenv("ZKM_NTT_LDE_3PASS") != nullptr;  // A/B switch
-    if (off || log_n < 14 || log_n > 21 || shift <= 1) return false;
+    if (log_n < 14 || log_n > 22 || shift <= 1) return false;
     const size_t n = (size_t)1 << log_n, N = n << 2;
-    static const int s2_env = getenv("ZKM_NTT_S2") ? atoi(getenv("ZKM_NTT_S2")) : 0;  // tuning knob (11..13)
-    // S2 = 12 wherever the strided pass can take the other log_n - 12 stages (3..8): the 2^12-element block kernel runs two
-    // workgroups per CU (512 threads, 100 VGPRs, 33 KB LDS), the 2^13 one only one -- measured at 262 x 2^20: 6.8 ms / 12 stages
-    // against 8.4 ms / 13 stages (profiles/r02_ntt_split_ab.txt)
-    int S2 = (log_n >= 15 && log_n <= 20) ? 12 : (log_n - 13 >= 3 ? 13 : (int)log_n - 3);
-    if (s2_env >= 11 && s2_env <= 13 && (int)log_n - s2_env >= 3 && (int)log_n - s2_env <= 8) S2 = s2_env;
-    const int S1 = (int)log_n - S2;   // S1 in 3..8
+    const int S2 = log_n == 14 ? 11 : (log_n <= 20 ? 12 : 13);
+    const int S1 = (int)log_n - S2;   // 3..9
     c->ensure_twiddles(log_n + 2);
-    ntt_pass_args a{};
-    a.in = coeffs; a.out = out; a.cs_in = n; a.cs_out = N; a.ncols = (uint32_t)ncols;
-    a.tw = c->tw.fwd; a.m = (uint32_t)S2; a.post_scale = 1; a.n_in = ~(size_t)0; a.pre_log = log_n;  // (every offset of the tile is < n)
-    a.log_T = pick_log_T(S1, (size_t)1 << S2);
-    a.tp = 1u << a.log_T;
-    a.n_lo = (uint32_t)(((size_t)1 << S2) >> a.log_T);
-    a.bi_hi = a.bo_hi = n; a.bi_lo = a.bo_lo = (size_t)1 << a.log_T;  // (one tile row of blocks: t_hi is always 0)
-    a.sa_in = a.sa_out = (size_t)1 << S2; a.sb_in = a.sb_out = 1;
-    const size_t ntiles = a.n_lo;
-    if (ntiles % 8) return false;
-    a.ncoset = 4;
     const gl_t w4n = gl_root_of_unity(log_n + 2);
+    const gl_t* pre_tab_k[4];
+    size_t out_off_k[4];
     gl_t sk = shift;
-    const uint64_t row_step = (((uint64_t)1 << S1) >> 3) << S2;   // elements between the 8 rows a thread holds
     for (unsigned k = 0; k < 4; k++) {
-        a.pre_tab_k[k] = c->pow_table(sk, log_n);
-        a.out_off_k[k] = (size_t)bitrev32(k, 2) * n;
-        const gl_t D = gl_pow(sk, row_step);
-        gl_t dj = 1;
-        for (int j = 0; j < 8; j++) { a.pre_dj[k][j] = dj; dj = gl_mul(dj, D); }
+        pre_tab_k[k] = c->pow_table(sk, log_n);
+        out_off_k[k] = (size_t)bitrev32(k, 2) * n;
         sk = gl_mul(sk, w4n);
     }
-    a.canon_out = 0;
-    static const bool dif_a = getenv("ZKM_NTT_LDE_DIF") != nullptr;  // A/B switch: pass A in the plain DIF form with the factored pre-scale
-    if (!dif_a && S2 == 12 && S1 >= 6) {
+    if (S1 >= 6) {
         lde_upper_args u{};
         u.in = coeffs; u.out = out; u.cs_in = n; u.cs_out = N; u.ncols = (uint32_t)ncols; u.log_n = log_n; u.S2 = (uint32_t)S2;
         u.tw = c->tw.fwd; u.ct = lde_ct_table(c, shift, log_n, (unsigned)S1);
-        for (unsigned k = 0; k < 4; k++) { u.pre_tab_k[k] = a.pre_tab_k[k]; u.out_off_k[k] = a.out_off_k[k]; }
+        for (unsigned k = 0; k < 4; k++) { u.pre_tab_k[k] = pre_tab_k[k]; u.out_off_k[k] = out_off_k[k]; }
+        const size_t ntiles = ((size_t)1 << S2) >> (12 - S1);
         size_t want = (ncols * ntiles) / 2048;                        // columns per workgroup (as launch_pass)
         u.cpb = (uint32_t)(want < 1 ? 1 : (want > 16 ? 16 : want));
         if (u.cpb > u.ncols) u.cpb = u.ncols;
@@ -1190,18 +1106,40 @@ static bool lde_coset_split(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t nc
         switch (S1) {
             case 6: launch_lde_upper_t<6>(c, u); break;
             case 7: launch_lde_upper_t<7>(c, u); break;
-            default: launch_lde_upper_t<8>(c, u); break;
+            case 8: launch_lde_upper_t<8>(c, u); break;
+            default: launch_lde_upper_t<9>(c, u); break;
         }
         ZKM_HIP_CHECK(hipGetLastError());
     } else {
+        ntt_pass_args a{};
+        a.in = coeffs; a.out = out; a.cs_in = n; a.cs_out = N; a.ncols = (uint32_t)ncols;
+        a.tw = c->tw.fwd; a.m = (uint32_t)S2; a.post_scale = 1; a.n_in = ~(size_t)0; a.pre_log = log_n;  // (every offset of the tile is < n)
+        a.log_T = pick_log_T(S1, (size_t)1 << S2);
+        a.tp = 1u << a.log_T;
+        a.n_lo = (uint32_t)(((size_t)1 << S2) >> a.log_T);
+        a.bi_hi = a.bo_hi = n; a.bi_lo = a.bo_lo = (size_t)1 << a.log_T;  // (one tile row of blocks: t_hi is always 0)
+        a.sa_in = a.sa_out = (size_t)1 << S2; a.sb_in = a.sb_out = 1;
+        const size_t ntiles = a.n_lo;                                    // 2^S2 / 64 tiles of 64 columns: a multiple of 8
+        a.ncoset = 4;
+        const uint64_t row_step = (((uint64_t)1 << S1) >> 3) << S2;       // elements between the 8 rows a thread holds
+        sk = shift;
+        for (unsigned k = 0; k < 4; k++) {
+            a.pre_tab_k[k] = pre_tab_k[k];
+            a.out_off_k[k] = out_off_k[k];
+            const gl_t D = gl_pow(sk, row_step);
+            gl_t dj = 1;
+            for (int j = 0; j < 8; j++) { a.pre_dj[k][j] = dj; dj = gl_mul(dj, D); }
+            sk = gl_mul(sk, w4n);
+        }
+        a.canon_out = 0;
         launch_pass(c, S1, a, ntiles, "ntt_pass_strided");
     }
     ntt_big_pass(c, out, N, ncols, log_n + 2, S2, c->tw.fwd);
     return true;
 }
 
-// ------------------------------------------------------------------ baseline radix-2 kernels
-// One global-memory DIF stage (span h = 2^s): used for the strides that do not fit one workgroup.
+// ------------------------------------------------------------------ radix-2 kernels for the sizes the pass kernels do not take
+// (transforms of fewer than 8 points, natural-order transforms beyond 2^24): one global-memory DIF stage per launch (span h = 2^s) ...
 __global__ __launch_bounds__(256) void k_dif_stage(gl_t* __restrict__ data, size_t col_stride, unsigned log_n, unsigned s,
                                                    const gl_t* __restrict__ tw, size_t total) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1216,7 +1154,7 @@ __global__ __launch_bounds__(256) void k_dif_stage(gl_t* __restrict__ data, size
     p[i + h] = gl_mul(gl_sub(u, v), tw[h + j]);
 }
 
-// The lowest `lows` stages of every contiguous 2^lows chunk, staged through LDS.
+// ... and the lowest `lows` stages of every contiguous 2^lows chunk, staged through LDS.
 template <int LOWS>
 __global__ __launch_bounds__(256) void k_dif_low(gl_t* __restrict__ data, size_t col_stride, unsigned log_n,
                                                  const gl_t* __restrict__ tw) {
@@ -1316,8 +1254,8 @@ void zkm_launch_scale_pad(zkm_ctx* c, const gl_t* in, size_t col_stride_in, gl_t
 
 void zkm_lde_bitrev(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, unsigned rate_bits, uint64_t shift) {
     size_t n = (size_t)1 << log_n, N = n << rate_bits;
-    if (rate_bits == 2 && !c->use_baseline_ntt && lde_coset_split(c, coeffs, out, ncols, log_n, shift)) return;
-    if (log_n + rate_bits >= 3 && !c->use_baseline_ntt) {
+    if (rate_bits == 2 && lde_coset_split(c, coeffs, out, ncols, log_n, shift)) return;
+    if (log_n + rate_bits >= 3) {
         ntt_dif_bitrev_fast(c, coeffs, n, out, N, ncols, log_n + rate_bits, false, n, log_n, shift);
         return;
     }
@@ -1331,7 +1269,7 @@ void zkm_ntt_natural(zkm_ctx* c, gl_t* in_scratch, gl_t* out, size_t ncols, size
 // required) holds the intermediate passes.  in == scratch is allowed.
 void zkm_ntt_natural_ex(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* scratch, size_t cs_s, gl_t* out, size_t cs_out, size_t ncols,
                         unsigned log_n, bool inverse, uint64_t shift) {
-    if (log_n >= 3 && log_n <= 24 && !c->use_baseline_ntt) {
+    if (log_n >= 3 && log_n <= 24) {
         ntt_natural_fast(c, in, cs_in, scratch, cs_s, out, cs_out, ncols, log_n, inverse, shift);
         return;
     }
@@ -1344,7 +1282,7 @@ void zkm_ntt_natural_ex(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* scratch,
 void zkm_ntt_natural(zkm_ctx* c, gl_t* in_scratch, gl_t* out, size_t ncols, size_t col_stride_in, size_t col_stride_out,
                      unsigned log_n, bool inverse, uint64_t shift) {
     size_t n = (size_t)1 << log_n, total = ncols << log_n;
-    if (log_n >= 3 && log_n <= 24 && !c->use_baseline_ntt) {
+    if (log_n >= 3 && log_n <= 24) {
         ntt_natural_fast(c, in_scratch, col_stride_in, in_scratch, col_stride_in, out, col_stride_out, ncols, log_n, inverse, shift);
         return;
     }

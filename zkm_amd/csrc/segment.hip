@@ -99,8 +99,13 @@ int zkm_segment_image_write(const zkm_table_input* tables, size_t ntables, const
         if (ctls[i].looking_off != nsides) return fail_msg(err, "zkm_segment_image_write: looking sides must be stored in lookup order");
         nsides += ctls[i].nlooking;
     }
-    for (size_t t = 0; t < ntables; t++)
-        if (zkm_is_device_ptr(tables[t].trace)) return fail_msg(err, "zkm_segment_image_write: traces must be host pointers");
+    for (size_t t = 0; t < ntables; t++) {
+        if (!tables[t].trace && !tables[t].columns) return fail_msg(err, "zkm_segment_image_write: table without a trace");
+        if (!tables[t].columns && zkm_is_device_ptr(tables[t].trace)) return fail_msg(err, "zkm_segment_image_write: traces must be host pointers");
+        for (size_t i = 0; tables[t].columns && i < tables[t].ncols; i++)
+            if (!tables[t].columns[i] || zkm_is_device_ptr(tables[t].columns[i]))
+                return fail_msg(err, "zkm_segment_image_write: columns must be host pointers");
+    }
     img[0] = SEGMENT_MAGIC; img[1] = SEGMENT_VERSION; img[2] = ntables; img[3] = npub; img[4] = nctls; img[5] = nsides; img[6] = img[7] = 0;
     size_t o = HEADER_WORDS;
     if (npub) memcpy(img + o, pub, npub * 8);
@@ -126,7 +131,10 @@ int zkm_segment_image_write(const zkm_table_input* tables, size_t ntables, const
     for (size_t t = 0; t < ntables; t++) {
         size_t words = tables[t].ncols << tables[t].log_n;
         th[TABLE_WORDS * t + 3] = o;
-        memcpy(img + o, tables[t].trace, words * 8);
+        if (tables[t].columns)
+            for (size_t i = 0; i < tables[t].ncols; i++) memcpy(img + o + (i << tables[t].log_n), tables[t].columns[i], (size_t)8 << tables[t].log_n);
+        else
+            memcpy(img + o, tables[t].trace, words * 8);
         o += words;
     }
     return 0;
@@ -175,6 +183,7 @@ int zkm_prove_segment_image(zkm_ctx* c, const zkm_stark_config* cfg, const uint6
         const uint64_t words = h[1] << h[2];
         if (h[3] > image_words || words > image_words - h[3]) return fail_msg(err, "zkm_prove_segment_image: trace data out of bounds");
         tables[t].trace = img + h[3];
+        tables[t].columns = nullptr;
     }
     const zkm_cross_table_lookup* ctls = (const zkm_cross_table_lookup*)(img + o);
     if (!take(nctls, 2)) return fail_msg(err, "zkm_prove_segment_image: truncated lookup description");

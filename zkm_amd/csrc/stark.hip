@@ -839,19 +839,21 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
                                zkm_challenger* ch, uint64_t* proof, const zkm_batch* aux_batch_in = nullptr,
                                const zkm_batch* quot_batch_in = nullptr) {
     // openings-only mode (zkm_prove_openings, BASELINE config 4): the three commitments exist already; the transcript
-    // is compact -> zeta -> openings -> prove_openings
-    const bool openings_only = aux_batch_in != nullptr;
+    // is compact -> zeta -> openings -> prove_openings.  aux_given (zkm_prove_with_traces): the auxiliary commitment was built ahead of
+    // the transcript (it only depends on the CTL challenges); everything from observing its cap on runs here.
+    const bool openings_only = quot_batch_in != nullptr;
+    const bool aux_given = aux_batch_in != nullptr && !openings_only;
     validate_config(cfg, log_n);  // before zkm_num_lookup_columns reads it; make_layout checks again
     // the table's own lookup helper columns come first among the auxiliary polynomials (prover.rs:467-508)
     const size_t NL = openings_only ? 0 : zkm_num_lookup_columns(table_id, cfg);
     if (NL && !lookup_challenges) throw std::runtime_error("this table has lookups: lookup challenges are required");
-    if (NL && !trace) throw std::runtime_error("this table has lookups: the trace values are required to build their helper columns");
+    if (NL && !trace && !aux_given) throw std::runtime_error("this table has lookups: the trace values are required to build their helper columns");
     if (!NL) lookup_challenges = nullptr;
     const size_t A = NL + A_ctl;
     proof_layout y;
     make_layout(y, cfg, log_n, W, A, Z);
     if (y.L > 8) throw std::runtime_error("too many FRI layers");
-    size_t n = (size_t)1 << log_n, N = (size_t)1 << y.lde_bits;
+    size_t n = (size_t)1 << log_n;
     if (openings_only) {
         if (Z > A) throw std::runtime_error("zkm_prove_openings: more CTL Zs than auxiliary polynomials");
     } else {
@@ -900,7 +902,10 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
         uint64_t* caps = proof + y.o_caps;
         memcpy(caps, tb->cap.data(), y.C * 4 * 8);
         const zkm_batch *abp = aux_batch_in, *qbp = quot_batch_in;
-        if (!openings_only) {
+        if (aux_given) {
+            if (abp->ncols != A || abp->log_n != log_n || abp->rate_bits != cfg->rate_bits || abp->cap_height != cfg->cap_height)
+                throw std::runtime_error("auxiliary commitment does not match the table shape / config");
+        } else if (!openings_only) {
             // auxiliary commitment :511-522
             ab = new zkm_batch();
             ab->ctx = c; ab->ncols = A; ab->log_n = log_n; ab->rate_bits = cfg->rate_bits; ab->cap_height = cfg->cap_height;
@@ -914,6 +919,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
                     gl_t* d = (gl_t*)c->alloc(W * n * sizeof(gl_t));
                     scratch.push_back(d);
                     ZKM_HIP_CHECK(hipMemcpyAsync(d, trace, W * n * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+                    zkm_launch_canon(c, d, W * n);   // (host words may be any representative; the lookup kernels want canonical ones)
                     d_trace = d;
                 }
                 zkm_table_lookup_columns_device(c, table_id, lookup_challenges, cfg->num_challenges, d_trace, n, d_all);
@@ -925,7 +931,10 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
                 zkm_prof_scope st2(c, "stage/compute auxiliary polynomials commitment");
                 zkm_batch_build(ab, aux, true);
             }
-            memcpy(caps + y.C * 4, ab->cap.data(), y.C * 4 * 8);
+            abp = ab;
+        }
+        if (!openings_only) {
+            memcpy(caps + y.C * 4, abp->cap.data(), y.C * 4 * 8);
             zkm_challenger_observe(ch, caps + y.C * 4, y.C * 4);  // :525
             gl_t alphas[4];
             for (unsigned i = 0; i < cfg->num_challenges; i++) alphas[i] = zkm_challenger_get(ch);  // :527
@@ -935,7 +944,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             scratch.push_back(d_quot);
             {
                 zkm_prof_scope st(c, "stage/compute quotient polys");  // :543-559
-                quotient_device(c, table_id, tb, ab, own, lookup_challenges, alphas, cfg->num_challenges, d_quot);
+                quotient_device(c, table_id, tb, abp, own, lookup_challenges, alphas, cfg->num_challenges, d_quot);
             }
             qb = new zkm_batch();
             qb->ctx = c; qb->ncols = y.Q; qb->log_n = log_n; qb->rate_bits = cfg->rate_bits; qb->cap_height = cfg->cap_height;
@@ -945,7 +954,6 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             }
             memcpy(caps + 2 * y.C * 4, qb->cap.data(), y.C * 4 * 8);
             zkm_challenger_observe(ch, caps + 2 * y.C * 4, y.C * 4);  // :589
-            abp = ab;
             qbp = qb;
         } else {
             for (const zkm_batch* b : {abp, qbp})
@@ -1022,6 +1030,16 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
         throw;
     }
     cleanup();
+}
+
+// prove_single_table on an existing trace AND auxiliary commitment (zkm_prove_with_traces builds the auxiliary commitments of all
+// tables ahead of the transcript, side by side); throws
+void zkm_prove_single_table_aux(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, size_t ncols, unsigned log_n, const zkm_batch* trace_batch,
+                                const zkm_batch* aux_batch, size_t naux_ctl, const zkm_ctl_table* table, const zkm_ctl_z* zs,
+                                const uint32_t* colset_ids, size_t nzs, const uint64_t* lookup_challenges, zkm_challenger* ch, uint64_t* proof) {
+    if (!trace_batch || !aux_batch) throw std::runtime_error("prove_single_table: commitments are required");
+    prove_single_table(c, table_id, cfg, nullptr, ncols, log_n, trace_batch, nullptr, naux_ctl, table, zs, colset_ids, nzs, lookup_challenges, ch,
+                       proof, aux_batch, nullptr);
 }
 
 // ------------------------------------------------------------------ C ABI

@@ -8,16 +8,37 @@
 #include "zkm_internal.h"
 
 // ------------------------------------------------------------------ KeccakSpongeStark witness (a12)
-// One lane per sponge operation (rows of one operation chain through the permutation, keccak_sponge_stark.rs:253-299);
-// column map keccak_sponge/columns.rs:19-70.  The output buffer is zero-filled first; only non-zero cells are stored.
-__global__ __launch_bounds__(128) void k_keccak_sponge_trace(const uint8_t* __restrict__ inputs, const uint64_t* __restrict__ off,
-                                                             const uint64_t* __restrict__ meta, const uint64_t* __restrict__ row_off,
-                                                             size_t nops, size_t n, gl_t* __restrict__ out) {
-    size_t op = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Rows of one operation chain through the permutation (keccak_sponge_stark.rs:253-299: the state after row k is the input of row
+// k + 1), rows of different operations are independent; column map keccak_sponge/columns.rs:19-70.  Two launches:
+//   (1) k_keccak_sponge_states: one lane per OPERATION walks its chain and parks the sponge state BEFORE each of its rows (25 words)
+//       plus the row's operation index -- 204 B per row, the only data that depends on the chain;
+//   (2) k_keccak_sponge_rows: one lane per ROW rebuilds the row from that state (one more permutation: 1 M extra Keccak-f cost
+//       0.25 ms) and stores all 470 cells, zeros included -- lane = row, so every column store is one contiguous 512 B wave access
+//       and the table needs no zero-fill.  (The one-lane-per-operation form stored only the non-zero cells of a zero-filled table,
+//       4.6 rows apart per lane: 8-byte partial-line writes, 14 GB of HBM traffic for a 3.9 GB table -- profiles/r03_a_*.)
+// word i of the padded 136-byte block of a row (pad10*1 on the final row, :334-341)
+__device__ __forceinline__ uint64_t sponge_block_word(const uint8_t* __restrict__ msg, size_t rem, bool full, int i) {
+    uint64_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const size_t pos = (size_t)8 * i + j;
+        uint32_t b = pos < rem ? msg[pos] : 0;
+        if (!full) {
+            if (pos == rem) b = (rem == 135) ? 0x81 : 0x01;
+            else if (pos == 135) b = 0x80;
+        }
+        w |= (uint64_t)b << (8 * j);
+    }
+    return w;
+}
+
+__global__ __launch_bounds__(128) void k_keccak_sponge_states(const uint8_t* __restrict__ inputs, const uint64_t* __restrict__ off,
+                                                              const uint64_t* __restrict__ row_off, size_t nops,
+                                                              uint64_t* __restrict__ row_state, uint32_t* __restrict__ row_op) {
+    const size_t op = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (op >= nops) return;
     const uint8_t* msg = inputs + off[op];
-    const size_t len = off[op + 1] - off[op], nwords = (len + 3) / 4;
-    const uint64_t ctxv = meta[4 * op], seg = meta[4 * op + 1], vbase = meta[4 * op + 2], ts = meta[4 * op + 3];
+    const size_t len = off[op + 1] - off[op];
     uint64_t st[25];
 #pragma unroll
     for (int i = 0; i < 25; i++) st[i] = 0;
@@ -25,62 +46,87 @@ __global__ __launch_bounds__(128) void k_keccak_sponge_trace(const uint8_t* __re
     for (;;) {
         const size_t rem = len - absorbed;
         const bool full = rem >= 136;
-        gl_t* o = out + row;
-        if (full) o[0] = 1;
-        else o[(size_t)(40 + rem) * n] = 1;
-        o[1 * n] = ctxv;
-        o[2 * n] = seg;
-        for (size_t i = 0; i < 34; i++) {
-            size_t w = absorbed / 4 + i;
-            if (w < nwords) o[(3 + i) * n] = vbase + w;
-        }
-        o[37 * n] = ts;
-        o[38 * n] = len;
-        o[39 * n] = absorbed;
+        uint64_t* rs = row_state + row * 25;
 #pragma unroll
-        for (int i = 0; i < 34; i++) o[(size_t)(176 + i) * n] = (uint32_t)(st[i / 2] >> (32 * (i & 1)));
+        for (int i = 0; i < 25; i++) rs[i] = st[i];
+        row_op[row] = (uint32_t)op;
+        if (!full) break;                                   // (the state after the final row is not needed by anyone)
 #pragma unroll
-        for (int i = 0; i < 16; i++) o[(size_t)(210 + i) * n] = (uint32_t)(st[(34 + i) / 2] >> (32 * ((34 + i) & 1)));
-        // block bytes with pad10*1 on the final row (:334-341), absorbed 8 bytes at a time
-#pragma unroll 1
-        for (int i = 0; i < 17; i++) {
-            uint64_t w = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                size_t pos = (size_t)8 * i + j;
-                uint32_t b = pos < rem && (full || pos < rem) ? msg[absorbed + pos] : 0;
-                if (!full) {
-                    if (pos == rem) b = (rem == 135) ? 0x81 : 0x01;
-                    else if (pos == 135) b = 0x80;
-                }
-                if (b) o[(size_t)(226 + pos) * n] = b;
-                w |= (uint64_t)b << (8 * j);
-            }
-            // st[i] ^= w  (static index via a switch-free select chain is costly; use the unrolled xor below)
-#pragma unroll
-            for (int q = 0; q < 17; q++)
-                if (q == i) st[q] ^= w;
-        }
-#pragma unroll
-        for (int i = 0; i < 34; i++) o[(size_t)(362 + i) * n] = (uint32_t)(st[i / 2] >> (32 * (i & 1)));
+        for (int i = 0; i < 17; i++) st[i] ^= sponge_block_word(msg + absorbed, rem, full, i);
         keccakf_dev(st);
-#pragma unroll
-        for (int i = 0; i < 42; i++) o[(size_t)(396 + i) * n] = (uint32_t)(st[(8 + i) / 2] >> (32 * ((8 + i) & 1)));
-#pragma unroll
-        for (int i = 0; i < 32; i++) o[(size_t)(438 + i) * n] = (uint8_t)(st[i / 8] >> (8 * (i & 7)));
         row++;
-        if (!full) break;
         absorbed += 136;
     }
 }
 
+__global__ __launch_bounds__(256) void k_keccak_sponge_rows(const uint8_t* __restrict__ inputs, const uint64_t* __restrict__ off,
+                                                            const uint64_t* __restrict__ meta, const uint64_t* __restrict__ row_off,
+                                                            const uint64_t* __restrict__ row_state, const uint32_t* __restrict__ row_op,
+                                                            size_t rows_used, size_t n, gl_t* __restrict__ out) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    gl_t* o = out + r;
+    if (r >= rows_used) {                                   // padding rows are all zero (keccak_sponge_stark.rs:243-247)
+#pragma unroll 10
+        for (int cidx = 0; cidx < ZKM_KECCAK_SPONGE_COLS; cidx++) o[(size_t)cidx * n] = 0;
+        return;
+    }
+    const size_t op = row_op[r];
+    const size_t absorbed = (r - row_off[op]) * 136;
+    const uint8_t* msg = inputs + off[op] + absorbed;
+    const size_t len = off[op + 1] - off[op], nwords = (len + 3) / 4, rem = len - absorbed;
+    const bool full = rem >= 136;
+    o[0] = full ? 1 : 0;
+    o[1 * n] = meta[4 * op];
+    o[2 * n] = meta[4 * op + 1];
+    {
+        const uint64_t vbase = meta[4 * op + 2];
+#pragma unroll 2
+        for (size_t i = 0; i < 34; i++) {
+            const size_t w = absorbed / 4 + i;
+            o[(3 + i) * n] = w < nwords ? vbase + w : 0;
+        }
+    }
+    o[37 * n] = meta[4 * op + 3];
+    o[38 * n] = len;
+    o[39 * n] = absorbed;
+#pragma unroll 8
+    for (size_t k = 0; k < 136; k++) o[(40 + k) * n] = (!full && k == rem) ? 1 : 0;
+    uint64_t st[25];
+    {
+        const uint64_t* rs = row_state + r * 25;
+#pragma unroll
+        for (int i = 0; i < 25; i++) st[i] = rs[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 34; i++) o[(size_t)(176 + i) * n] = (uint32_t)(st[i / 2] >> (32 * (i & 1)));
+#pragma unroll
+    for (int i = 0; i < 16; i++) o[(size_t)(210 + i) * n] = (uint32_t)(st[(34 + i) / 2] >> (32 * ((34 + i) & 1)));
+#pragma unroll
+    for (int i = 0; i < 17; i++) {
+        const uint64_t w = sponge_block_word(msg, rem, full, i);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[(size_t)(226 + 8 * i + j) * n] = (uint8_t)(w >> (8 * j));
+        st[i] ^= w;
+    }
+#pragma unroll
+    for (int i = 0; i < 34; i++) o[(size_t)(362 + i) * n] = (uint32_t)(st[i / 2] >> (32 * (i & 1)));
+    keccakf_dev(st);
+#pragma unroll
+    for (int i = 0; i < 42; i++) o[(size_t)(396 + i) * n] = (uint32_t)(st[(8 + i) / 2] >> (32 * ((8 + i) & 1)));
+#pragma unroll
+    for (int i = 0; i < 32; i++) o[(size_t)(438 + i) * n] = (uint8_t)(st[i / 8] >> (8 * (i & 7)));
+}
+
 void zkm_launch_keccak_sponge_trace(zkm_ctx* c, const uint8_t* d_inputs, const uint64_t* d_off, const uint64_t* d_meta,
-                                    const uint64_t* d_row_off, size_t nops, unsigned log_n, gl_t* out) {
-    size_t n = (size_t)1 << log_n;
-    ZKM_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)ZKM_KECCAK_SPONGE_COLS * n * sizeof(gl_t), c->stream));
-    if (!nops) return;
+                                    const uint64_t* d_row_off, size_t nops, size_t rows_used, unsigned log_n, gl_t* out) {
+    const size_t n = (size_t)1 << log_n;
+    zkm_scratch row_state(c, (rows_used ? rows_used : 1) * 25 * sizeof(uint64_t)), row_op(c, (rows_used ? rows_used : 1) * sizeof(uint32_t));
     zkm_prof_scope ps(c, "keccak_sponge_trace");
-    hipLaunchKernelGGL(k_keccak_sponge_trace, dim3((nops + 127) / 128), dim3(128), 0, c->stream, d_inputs, d_off, d_meta, d_row_off, nops, n, out);
+    if (nops) hipLaunchKernelGGL(k_keccak_sponge_states, dim3((nops + 127) / 128), dim3(128), 0, c->stream, d_inputs, d_off, d_row_off, nops,
+                                 row_state.as<uint64_t>(), row_op.as<uint32_t>());
+    hipLaunchKernelGGL(k_keccak_sponge_rows, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_inputs, d_off, d_meta, d_row_off,
+                       row_state.as<uint64_t>(), row_op.as<uint32_t>(), rows_used, n, out);
     ZKM_HIP_CHECK(hipGetLastError());
 }
 

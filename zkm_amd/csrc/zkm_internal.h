@@ -39,7 +39,6 @@ struct zkm_ctx {
     hipStream_t copy_stream = nullptr;  // host -> device ingest, overlapped with the compute stream (created on first use)
     size_t ingest_chunk_cols = 32;      // columns per ingest chunk (ZKM_INGEST_CHUNK; 0 = monolithic upload)
     int num_cus = 256;
-    bool use_baseline_ntt = false;  // A/B switch: radix-2 one-stage-per-launch kernels
     // profiling
     bool profiling = false;
     std::vector<zkm_prof_rec> prof;
@@ -59,6 +58,12 @@ struct zkm_ctx {
     // pinned host staging
     uint64_t* h_staging = nullptr;
     size_t h_staging_words = 0;
+    // commit lanes (ctl.hip zkm_prove_with_traces): sub-contexts -- own stream, allocator, twiddle / power tables, profiler records --
+    // on which the independent trace commitments of one segment are built side by side, one host thread each.  Owned by this
+    // context (created on first use, destroyed with it); a lane has no lanes of its own.  A batch remembers the (sub-)context
+    // that built it and returns its memory there.
+    std::vector<zkm_ctx*> lanes;
+    void ensure_lanes(size_t k);
 
     void* alloc(size_t bytes);
     void release(void* p);
@@ -71,6 +76,8 @@ struct zkm_ctx {
     void prof_end(size_t idx);
     void sync() { ZKM_HIP_CHECK(hipStreamSynchronize(stream)); }
 };
+
+#define ZKM_COMMIT_LANES 4   // trace commitments in flight per context (the context itself + 3 lanes)
 
 // RAII owner of one scratch block from the context's allocator (released on every exit path)
 struct zkm_scratch {
@@ -138,13 +145,12 @@ void zkm_ntt_natural_ex(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* scratch,
                         unsigned log_n, bool inverse, uint64_t shift);
 // leaf digests of row-major leaves formed from F2 SoA arrays: leaf k = 16 consecutive (c0,c1) pairs
 void zkm_launch_merkle_leaves_ext(zkm_ctx*, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests);
-void zkm_launch_merkle_compress(zkm_ctx*, const gl_t* children, gl_t* parents, size_t nparents);
 void zkm_launch_poseidon_trace(zkm_ctx*, uint64_t seed, const uint64_t* d_inputs, const uint64_t* d_ts, size_t num_perms, unsigned log_n,
                                gl_t* out);
 void zkm_launch_poseidon_sponge_trace(zkm_ctx*, const uint8_t* d_inputs, const uint64_t* d_off, const uint64_t* d_meta,
                                       const uint64_t* d_row_off, size_t nops, unsigned log_n, gl_t* out);
 void zkm_launch_keccak_sponge_trace(zkm_ctx*, const uint8_t* d_inputs, const uint64_t* d_off, const uint64_t* d_meta,
-                                    const uint64_t* d_row_off, size_t nops, unsigned log_n, gl_t* out);
+                                    const uint64_t* d_row_off, size_t nops, size_t rows_used, unsigned log_n, gl_t* out);
 // build all digest layers above level 0; fills level_off and returns total words needed (call with digests==nullptr to size)
 size_t zkm_merkle_layout(unsigned log_leaves, unsigned cap_height, std::vector<size_t>& level_off);
 void zkm_merkle_build_inner(zkm_ctx*, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height);
@@ -165,9 +171,16 @@ void zkm_lde_bitrev(zkm_ctx*, const gl_t* coeffs, gl_t* out, size_t ncols, unsig
 // ---- core.hip
 // dev_values (optional, ncols x n words of device memory): host values are uploaded THERE and stay (the caller reuses them, e.g. for
 // the CTL columns of prove_with_traces) instead of being staged inside the batch's LDE buffer.
-void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t* dev_values = nullptr);
+// src_cols (optional, instead of src): one pointer per column (each n words, host or device).
+void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t* dev_values = nullptr,
+                     const uint64_t* const* src_cols = nullptr);
 zkm_batch* zkm_batch_commit_values_keep(zkm_ctx* c, const uint64_t* values, size_t ncols, unsigned log_n, unsigned rate_bits,
-                                        unsigned cap_height, gl_t* dev_values);
+                                        unsigned cap_height, gl_t* dev_values, const uint64_t* const* columns = nullptr);
+// stark.hip: prove_single_table on an existing trace and auxiliary commitment (throws)
+void zkm_prove_single_table_aux(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, size_t ncols, unsigned log_n, const zkm_batch* trace_batch,
+                                const zkm_batch* aux_batch, size_t naux_ctl, const zkm_ctl_table* table, const zkm_ctl_z* zs,
+                                const uint32_t* colset_ids, size_t nzs, const uint64_t* lookup_challenges, zkm_challenger* ch, uint64_t* proof);
+void zkm_launch_canon(zkm_ctx* c, gl_t* v, size_t total);   // v[i] = canonical representative of v[i], in place
 void zkm_host_poseidon_permute(uint64_t st[12]);
 // ---- hash.hip (LogicStark witness)
 // ---- tables' own logUp lookups (core.hip: definitions; ctl.hip: helper columns)

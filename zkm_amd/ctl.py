@@ -22,7 +22,8 @@ class CtlTableStruct(C.Structure):
 
 
 class TableInputStruct(C.Structure):
-    _fields_ = [("table_id", C.c_int), ("trace", C.c_void_p), ("ncols", C.c_size_t), ("log_n", C.c_uint), ("ctl", C.c_void_p)]
+    _fields_ = [("table_id", C.c_int), ("trace", C.c_void_p), ("ncols", C.c_size_t), ("log_n", C.c_uint), ("ctl", C.c_void_p),
+                ("columns", C.c_void_p)]
 
 
 class CtlTable:
@@ -116,11 +117,18 @@ def pack_ctls(ctls):
 
 
 def pack_tables(tables):
-    """tables: list of (table_id, trace_ptr_int, ncols, log_n, CtlTable).  Returns (ctypes array, keepalive)."""
+    """tables: list of (table_id, trace_ptr_int, ncols, log_n, CtlTable); trace_ptr_int may be a LIST of ncols column pointers
+    (zkm_table_input.columns: the reference's Vec<PolynomialValues>).  Returns (ctypes array, keepalive)."""
     arr = (TableInputStruct * len(tables))()
     keep = []
     for i, (tid, ptr, ncols, log_n, ctl) in enumerate(tables):
         st = ctl.pack()
         keep.append(st)
-        arr[i] = TableInputStruct(tid, ptr, ncols, log_n, C.addressof(st))
+        if isinstance(ptr, (list, tuple)):
+            assert len(ptr) == ncols
+            cols = (C.c_void_p * ncols)(*ptr)
+            keep.append(cols)
+            arr[i] = TableInputStruct(tid, None, ncols, log_n, C.addressof(st), C.addressof(cols))
+        else:
+            arr[i] = TableInputStruct(tid, ptr, ncols, log_n, C.addressof(st), None)
     return arr, keep
