@@ -36,6 +36,9 @@ void* zkm_ctx_stream(zkm_ctx* ctx);
 /* Device memory held by the context's caching allocator: bytes in live allocations (DeviceBuffers, batches, scratch of a call in
  * flight) and bytes cached for reuse (freed on zkm_ctx_destroy, or when an allocation would otherwise fail). */
 void zkm_ctx_memory(const zkm_ctx* ctx, size_t* live_bytes, size_t* cached_bytes);
+/* Of the live bytes: tables the context keeps for reuse (twiddles, coset power tables, block twiddles -- also those of its commit
+ * lanes, which build their own on first use).  live - resident == 0 between calls when the caller holds no buffers or batches. */
+size_t zkm_ctx_resident_bytes(const zkm_ctx* ctx);
 /* Return every cached (not live) block to the device (the free lists are exact-size: a segment of many table shapes leaves one
  * cached block per distinct size behind). */
 void zkm_ctx_trim(zkm_ctx* ctx);

@@ -73,6 +73,7 @@ extern "C" {
     pub fn zkm_ctx_synchronize(ctx: *mut zkm_ctx, err: *mut *mut c_char) -> c_int;
     pub fn zkm_ctx_stream(ctx: *mut zkm_ctx) -> *mut c_void;
     pub fn zkm_ctx_memory(ctx: *const zkm_ctx, live_bytes: *mut usize, cached_bytes: *mut usize);
+    pub fn zkm_ctx_resident_bytes(ctx: *const zkm_ctx) -> usize;
     pub fn zkm_ctx_trim(ctx: *mut zkm_ctx);
     pub fn zkm_dev_alloc(ctx: *mut zkm_ctx, bytes: usize, out: *mut *mut c_void, err: *mut *mut c_char) -> c_int;
     pub fn zkm_dev_free(ctx: *mut zkm_ctx, p: *mut c_void) -> c_int;

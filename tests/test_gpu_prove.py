@@ -185,22 +185,34 @@ def test_no_device_memory_is_leaked(zkm, oracle):
     c = zkm.Context(0)
     trace = oracle.poseidon_trace(3, 100, 7)
     aux = np.zeros(4 << 7, dtype=np.uint64)
-    c.prove_single_table(trace, 7, aux, [1, 1])          # warm up: twiddles / power tables stay resident by design
+    def transient():   # live bytes that are not resident tables (twiddles / power tables stay by design; the commit lanes of
+        live, _ = c.memory()   # prove_with_traces build their own on first use, whichever lane a table lands on)
+        return live - c.resident_bytes()
+    c.prove_single_table(trace, 7, aux, [1, 1])
     base, _ = c.memory()
+    assert transient() == 0
     for _ in range(3):
         c.prove_single_table(trace, 7, aux, [1, 1])
+    assert c.memory()[0] == base and transient() == 0
     with pytest.raises(zkm.ZkmError):
         c.prove_single_table(trace, 7, aux, [1, 1], table_id=99)
     with pytest.raises(zkm.ZkmError):
         c.prove_single_table(trace, 7, np.zeros(3 << 7, dtype=np.uint64), [1, 1])        # aux does not match the CTL description
+    assert transient() == 0
     t4, c4, _ = logic_fixtures.build4(oracle, log_sponge=3)
-    c.prove_with_traces(t4, c4)
-    base2, _ = c.memory()
-    c.prove_with_traces(t4, c4)
-    live, cached = c.memory()
-    assert live == base2, (base, base2, live)
-    # the only growth between the first baseline and now is resident tables (twiddles / powers for the new sizes)
-    assert base2 - base < 64 << 20
+    for _ in range(3):
+        c.prove_with_traces(t4, c4)
+        assert transient() == 0
+    # a multi-table call that fails late -- all trace and auxiliary commitments exist, the last table has no constraint kernel --
+    # releases everything as well (commitments built on the lanes included)
+    bad = list(t4)
+    bad[-1] = (99,) + tuple(bad[-1][1:])
+    with pytest.raises(zkm.ZkmError):
+        c.prove_with_traces(bad, c4)
+    assert transient() == 0
+    live, _ = c.memory()
+    # the only growth since the first baseline is resident tables (for the new sizes, on the context and its lanes)
+    assert live - base < 64 << 20 and live - base <= c.resident_bytes()
     c.close()
 
 

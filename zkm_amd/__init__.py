@@ -27,7 +27,7 @@ TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRES
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
-    "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_memory", "zkm_ctx_trim", "zkm_table_enum_index", "zkm_host_alloc", "zkm_host_free",
+    "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_memory", "zkm_ctx_resident_bytes", "zkm_ctx_trim", "zkm_table_enum_index", "zkm_host_alloc", "zkm_host_free",
     "zkm_host_register", "zkm_host_unregister", "zkm_all_stark_ctls", "zkm_all_stark_ctl_table", "zkm_prove_segment", "zkm_prove_segment_columns", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
     "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_field_selftest", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_commit_columns", "zkm_batch_free",
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_lde_rows", "zkm_batch_leaf", "zkm_batch_merkle_path",
@@ -131,6 +131,7 @@ def load():
         "zkm_sha_compress_sponge_trace": (C.c_int, [cp, cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_keccak_trace": (C.c_int, [cp, cp, cp, C.c_size_t, C.c_uint, cp, err]),
         "zkm_ctx_memory": (None, [cp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+        "zkm_ctx_resident_bytes": (C.c_size_t, [cp]),
         "zkm_ctx_trim": (None, [cp]),
         "zkm_all_stark_ctls": (C.c_int, [cpp, C.POINTER(C.c_size_t), cpp, C.POINTER(C.c_size_t)]),
         "zkm_all_stark_ctl_table": (cp, [C.c_int]),
@@ -271,6 +272,10 @@ class Context:
         live, cached = C.c_size_t(), C.c_size_t()
         self.L.zkm_ctx_memory(self.h, C.byref(live), C.byref(cached))
         return live.value, cached.value
+
+    def resident_bytes(self):
+        """Of the live bytes: tables kept for reuse (twiddles, power tables; the commit lanes' included)."""
+        return self.L.zkm_ctx_resident_bytes(self.h)
 
     def pinned_array(self, words):
         """A uint64 ndarray in page-locked host memory (zkm_host_alloc): uploads from it overlap with compute.  Freed with the

@@ -175,6 +175,12 @@ void zkm_ctx_memory(const zkm_ctx* c, size_t* live_bytes, size_t* cached_bytes) 
     if (cached_bytes) *cached_bytes = cached;
 }
 
+size_t zkm_ctx_resident_bytes(const zkm_ctx* c) {
+    size_t r = c->resident_bytes;
+    for (const zkm_ctx* l : c->lanes) r += zkm_ctx_resident_bytes(l);
+    return r;
+}
+
 void zkm_ctx_trim(zkm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

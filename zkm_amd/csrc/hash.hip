@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_ext(const gl_t* __restric
 
 // ------------------------------------------------------------------ Merkle inner levels, fused (K5)
 // plonky2 builds a tree in one call (MerkleTree::new, call sites prover.rs:154-163); here a launch takes up to THREE levels.
-// Large levels (first level of the launch >= 2^17 parents): one hash per lane.  A workgroup of 256 threads owns 512 children of
+// Large levels (first level of the launch >= 2^15 parents): one hash per lane.  A workgroup of 256 threads owns 512 children of
 // level l and produces their 256 parents, then -- from LDS, no trip through HBM -- the 128 and the 64 nodes above (whole waves
 // stay active: 4, 2, 1, and the waves that are done leave at once).  Every level is also stored (Merkle paths read all of them).  The permutation code exists once (the level
 // loop is not unrolled), so the kernel stays within the instruction cache like k_merkle_leaves.
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_merkle_fused(merkle_fused_args p) {
 // twelve state words): every round is constant add, x^7 (lane 0 only in the partial rounds), and the circulant MDS with the
 // twelve rotated neighbours fetched by ds_bpermute -- the textbook rounds (poseidon_stark.rs:65-95, 164-169, 239-251, 310-345),
 // 30 x ~190 instructions per lane instead of ~18k, i.e. a quarter of the latency at ~5x the total work.  Used when a level has
-// fewer than 2^17 nodes (k_merkle_fused_wide).  Bit-exact with poseidon_permute (the fused partial rounds are an algebraic regrouping).
+// fewer than 2^15 nodes (k_merkle_fused_wide).  Bit-exact with poseidon_permute (the fused partial rounds are an algebraic regrouping).
 __device__ __forceinline__ uint64_t poseidon_permute_wide(uint64_t x, unsigned lane) {
     const unsigned idx = lane & 15, base = lane & ~15u;
     const bool active = idx < 12;
@@ -336,8 +336,12 @@ size_t zkm_merkle_layout(unsigned log_leaves, unsigned cap_height, std::vector<s
 }
 
 // All digest levels above the leaves, up to the cap: fused launches (k_merkle_fused: <= 3 levels, one hash per lane, while the first
-// level of the launch has >= 2^17 nodes; k_merkle_fused_wide: <= 6 levels, 16 lanes per hash, below that).  A 2^22-leaf tree with a
-// 16-digest cap (18 levels) is 2 + 2 launches instead of 18.
+// level of the launch has >= 2^15 nodes; k_merkle_fused_wide: <= 6 levels, 16 lanes per hash, below that).  A 2^22-leaf tree with a
+// 16-digest cap (18 levels) is 3 + 2 launches instead of 18.  (Measured and dropped, profiles/r03_merkle_inner_levels.txt: a lane
+// reducing a 16-node subtree by itself -- no barrier, 15 back-to-back permutations -- leaves 4096 waves for a 2^22-leaf tree, four per
+// SIMD, and the permutation needs five to saturate the issue port: 2.65 G permutations/s against 2.7 here and 3.33 in the leaf kernel.)  The 16-lane form takes a quarter of the latency of a permutation but
+// 7.5x its issue slots (1.4k instead of 190 wave instructions per hash), so it is kept to the levels where a launch is nothing but
+// latency: with several contexts proving side by side the slots it would waste on 2^13 .. 2^16-node levels belong to the others.
 void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves,
                             unsigned cap_height) {
     const unsigned top = log_leaves - cap_height;
@@ -346,7 +350,7 @@ void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>
         zkm_prof_scope ps(c, "merkle_compress");
         const unsigned log_p1 = log_leaves - l - 1;       // log2(#parents) of the first level made
         const unsigned rem = top - l;
-        if (log_p1 >= 17) {
+        if (log_p1 >= 15) {
             merkle_fused_args a{};
             a.children = digests + level_off[l];
             a.levels = rem < 3 ? rem : 3;
@@ -368,44 +372,32 @@ void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>
 }
 
 // ------------------------------------------------------------------ Keccak-f[1600] batch (K15)
-// States are 25-word records (AoS: the layout of the reference's [u64; 25], cpu/kernel/keccak_util.rs:6-31).  One state per lane; a
-// wave's 64 states are 12.8 KB of CONTIGUOUS memory, moved as 25 coalesced 512 B accesses each way and transposed through the wave's
-// own LDS region (word j of lane t at t * 25 + j: the stride 25 is odd, so the 64-bit accesses of a half-wave hit 32 different
-// banks).  The direct form -- every lane loading its record at a 200 B stride -- touched 64 cache lines per instruction and ran at
-// 1.7 TB/s (profiles/r03_a_configs_4_5.json).  No workgroup barrier: a wave only touches its own region.
-#define ZKM_HASH_WAVE_SYNC()                                  \
-    do {                                                      \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                      \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
+// States are 25-word records (AoS: the layout of the reference's [u64; 25], cpu/kernel/keccak_util.rs:6-31), one state per lane:
+// ~6.3k VALU instructions per permutation (xor, v_alignbit_b32 rotations, v_bfi chi) for 400 B moved.  Each lane moves its own record
+// with 16-byte accesses (records are 8-byte aligned: 200 = 8 * 25); a wave's 64 records are 12.8 KB of contiguous memory, so every
+// cache line comes from HBM once and the partial-line accesses are served by L1 / L2.  Measured on 2^22 states
+// (profiles/r03_keccakf_variants.txt): 8 B accesses + generic 64-bit rotates 0.96 ms (r02); this form 0.82 ms = 5.1 G permutations/s;
+// the records staged and transposed through LDS with fully coalesced 512 B accesses 0.91 ms (one 12.8 KB image per wave: three
+// waves per SIMD) and 1.01 ms (two 6.4 KB halves: four waves, twice the LDS instructions) -- the transposition costs more than
+// the uncoalesced 16 B accesses do.
+struct __attribute__((aligned(8))) keccak_pair { uint64_t x, y; };
 
 __global__ __launch_bounds__(256) void k_keccakf(uint64_t* __restrict__ states, size_t k) {
-    __shared__ uint64_t sh[4][64 * 25];
-    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const size_t first = ((size_t)blockIdx.x * 4 + wv) * 64;            // first state of this wave
-    if (first >= k) return;                                               // (uniform over the wave)
-    const size_t nwords = (k - first < 64 ? k - first : 64) * 25;         // words this wave owns
-    uint64_t* const g = states + first * 25;
-    uint64_t* const w = sh[wv];
-#pragma unroll
-    for (int i = 0; i < 25; i++) {
-        const unsigned e = i * 64 + lane;
-        if (e < nwords) w[e] = g[e];
-    }
-    ZKM_HASH_WAVE_SYNC();
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= k) return;
     uint64_t a[25];
+    uint64_t* st = states + idx * 25;
 #pragma unroll
-    for (int i = 0; i < 25; i++) a[i] = w[lane * 25 + i];                 // (lanes past the tail permute garbage that is never stored)
+    for (int i = 0; i < 12; i++) {
+        const keccak_pair v = *reinterpret_cast<const keccak_pair*>(st + 2 * i);
+        a[2 * i] = v.x;
+        a[2 * i + 1] = v.y;
+    }
+    a[24] = st[24];
     keccakf_dev(a);
 #pragma unroll
-    for (int i = 0; i < 25; i++) w[lane * 25 + i] = a[i];
-    ZKM_HASH_WAVE_SYNC();
-#pragma unroll
-    for (int i = 0; i < 25; i++) {
-        const unsigned e = i * 64 + lane;
-        if (e < nwords) g[e] = w[e];
-    }
+    for (int i = 0; i < 12; i++) *reinterpret_cast<keccak_pair*>(st + 2 * i) = keccak_pair{a[2 * i], a[2 * i + 1]};
+    st[24] = a[24];
 }
 
 void zkm_launch_keccakf(zkm_ctx* c, uint64_t* states, size_t k) {

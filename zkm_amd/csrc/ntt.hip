@@ -29,8 +29,9 @@ __global__ void k_build_twiddles(gl_t* tw, unsigned log_max, bool inverse) {
 void zkm_ctx::ensure_twiddles(unsigned log_n) {
     if (log_n <= tw.log_max && tw.fwd) return;
     unsigned lm = log_n < 12 ? 12 : log_n;
-    if (tw.fwd) { release(tw.fwd); release(tw.inv); }
+    if (tw.fwd) { release(tw.fwd); release(tw.inv); resident_bytes -= 2 * (sizeof(gl_t) << tw.log_max); }
     size_t total = (size_t)1 << lm;
+    resident_bytes += 2 * total * sizeof(gl_t);
     tw.fwd = (gl_t*)alloc(total * sizeof(gl_t));
     tw.inv = (gl_t*)alloc(total * sizeof(gl_t));
     hipLaunchKernelGGL(k_build_twiddles, dim3((total + 255) / 256), dim3(256), 0, stream, tw.fwd, lm, false);
@@ -56,6 +57,7 @@ const gl_t* zkm_ctx::pow_table(uint64_t shift, unsigned log_n) {
     ZKM_HIP_CHECK(hipMemcpyAsync(d, host.data(), host.size() * sizeof(gl_t), hipMemcpyHostToDevice, stream));
     ZKM_HIP_CHECK(hipStreamSynchronize(stream));  // host vector goes out of scope
     pow_tables[key] = d;
+    resident_bytes += host.size() * sizeof(gl_t);
     return d;
 }
 
@@ -1064,6 +1066,7 @@ static const gl_t* lde_ct_table(zkm_ctx* c, uint64_t shift, unsigned log_n, unsi
     ZKM_HIP_CHECK(hipMemcpyAsync(d, host.data(), host.size() * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
     ZKM_HIP_CHECK(hipStreamSynchronize(c->stream));  // host vector goes out of scope
     c->lde_ct_tables[key] = d;
+    c->resident_bytes += host.size() * sizeof(gl_t);
     return d;
 }
 

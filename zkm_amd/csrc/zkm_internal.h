@@ -55,6 +55,7 @@ struct zkm_ctx {
     std::map<std::pair<uint64_t, unsigned>, gl_t*> pow_tables;
     // block twiddles of the coset-split LDE's upper stages: key (shift, log_n, stages) -> device ptr [4 cosets][2^stages]
     std::map<std::tuple<uint64_t, unsigned, unsigned>, gl_t*> lde_ct_tables;
+    size_t resident_bytes = 0;  // of the live blocks: tables kept for reuse (twiddles, power tables, block twiddles)
     // pinned host staging
     uint64_t* h_staging = nullptr;
     size_t h_staging_words = 0;
