@@ -359,6 +359,16 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
     };
     b->coeffs = (gl_t*)c->alloc(ncols * n * sizeof(gl_t));
     b->lde = (gl_t*)c->alloc(ncols * N * sizeof(gl_t));
+    // Coefficient layout (zkm_internal.h): 2^18 .. 2^20 rows at rate 4 take the two-pass inverse transform, which leaves the coefficients
+    // in the digit order the first LDE pass reads as contiguous runs; every batch of such a height has that layout (from_coeffs
+    // converts its natural-order input after the LDE), so kernels that walk several batches position by position agree.
+    b->coeff_s1 = b->rate_bits == 2 ? zkm_coeff_layout_s1(b->log_n) : 0;
+    const unsigned s1 = b->coeff_s1;
+    // values (nc columns, stride n, device) -> coefficients of columns [c0, c0 + nc)
+    auto inverse_transform = [&](const gl_t* vals, size_t c0, size_t nc) {
+        if (s1) zkm_intt_digit(c, vals, n, b->coeffs + c0 * n, n, nc, b->log_n);
+        else zkm_ntt_natural_ex(c, vals, n, b->lde + c0 * N, n, b->coeffs + c0 * n, n, nc, b->log_n, /*inverse=*/true, 0);
+    };
     size_t dwords = zkm_merkle_layout(b->lde_bits(), b->cap_height, b->level_off);
     b->digests = (gl_t*)c->alloc(dwords * sizeof(gl_t));
     bool dev = !src_cols && zkm_is_device_ptr(src);   // (column pointers are staged like host values, wherever each one lives)
@@ -400,8 +410,8 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
                 gl_t* vals = dev_values ? dev_values + c0 * n : b->lde + c0 * N;
                 ZKM_HIP_CHECK(hipStreamWaitEvent(c->stream, ev[k + 1], 0));
                 if (dev_values) zkm_launch_canon(c, vals, nc * n);
-                zkm_ntt_natural_ex(c, vals, n, b->lde + c0 * N, n, b->coeffs + c0 * n, n, nc, b->log_n, /*inverse=*/true, 0);
-                zkm_lde_bitrev(c, b->coeffs + c0 * n, b->lde + c0 * N, nc, b->log_n, b->rate_bits, GL_GENERATOR);
+                inverse_transform(vals, c0, nc);
+                zkm_lde_bitrev(c, b->coeffs + c0 * n, b->lde + c0 * N, nc, b->log_n, b->rate_bits, GL_GENERATOR, s1);
                 zkm_launch_merkle_leaves_chunk(c, b->lde + c0 * N, N, nc, N, state.as<gl_t>(), k == 0, k + 1 == nchunks, b->digests);
             }
         } catch (...) {
@@ -412,19 +422,25 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
         leaves_done = true;
     } else if (src_is_values && dev) {
         // device-resident values are only read (first NTT pass); the not-yet-used LDE buffer holds the intermediate passes
-        zkm_ntt_natural_ex(c, src, n, b->lde, n, b->coeffs, n, ncols, b->log_n, /*inverse=*/true, 0);
+        inverse_transform(src, 0, ncols);
     } else if (src_is_values) {
         // stage the values in the (not yet used) LDE buffer (or the caller's device copy), transform, land natural-order coefficients
         gl_t* vals = dev_values ? dev_values : b->lde;
         copy_cols(vals, 0, ncols, kind, c->stream);
         if (dev_values) zkm_launch_canon(c, vals, ncols * n);
-        zkm_ntt_natural_ex(c, vals, n, b->lde, n, b->coeffs, n, ncols, b->log_n, /*inverse=*/true, 0);
+        inverse_transform(vals, 0, ncols);
     } else {
         copy_cols(b->coeffs, 0, ncols, kind, c->stream);
     }
     if (!leaves_done) {
-        zkm_lde_bitrev(c, b->coeffs, b->lde, ncols, b->log_n, b->rate_bits, GL_GENERATOR);
+        zkm_lde_bitrev(c, b->coeffs, b->lde, ncols, b->log_n, b->rate_bits, GL_GENERATOR, src_is_values ? s1 : 0);
         zkm_launch_merkle_leaves(c, b->lde, N, ncols, N, b->digests);
+    }
+    if (!src_is_values && s1) {
+        // from_coeffs: the LDE above read the caller's natural order; the batch keeps the coefficients in the common layout
+        zkm_scratch nat(c, ncols * n * sizeof(gl_t));
+        ZKM_HIP_CHECK(hipMemcpyAsync(nat.p, b->coeffs, ncols * n * sizeof(gl_t), hipMemcpyDeviceToDevice, c->stream));
+        zkm_coeff_layout_convert(c, nat.as<gl_t>(), n, b->coeffs, n, ncols, b->log_n, /*to_natural=*/false);
     }
     zkm_merkle_build_inner(c, b->digests, b->level_off, b->lde_bits(), b->cap_height);
     size_t capw = (size_t)4 << b->cap_height;
@@ -528,9 +544,26 @@ int zkm_batch_cap(const zkm_batch* b, uint64_t* out) {
     return 0;
 }
 int zkm_batch_coeffs(const zkm_batch* b, uint64_t* out) {
-    hipMemcpyKind kind = zkm_is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (hipMemcpyAsync(out, b->coeffs, b->ncols * b->n() * sizeof(gl_t), kind, b->ctx->stream) != hipSuccess) return 1;
-    return hipStreamSynchronize(b->ctx->stream) == hipSuccess ? 0 : 1;
+    // .polynomials in NATURAL order, whatever layout the batch keeps them in
+    zkm_ctx* c = b->ctx;
+    const size_t bytes = b->ncols * b->n() * sizeof(gl_t);
+    const bool dev = zkm_is_device_ptr(out);
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (!b->coeff_s1) {
+            ZKM_HIP_CHECK(hipMemcpyAsync(out, b->coeffs, bytes, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+        } else {
+            zkm_scratch nat(c, dev ? 8 : bytes);
+            gl_t* d = dev ? out : nat.as<gl_t>();
+            zkm_coeff_layout_convert(c, b->coeffs, b->n(), d, b->n(), b->ncols, b->log_n, /*to_natural=*/true);
+            if (!dev) ZKM_HIP_CHECK(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream));
+            c->sync();   // (the scratch goes back to the allocator on return)
+        }
+        c->sync();
+    } catch (...) {
+        return 1;
+    }
+    return 0;
 }
 int zkm_batch_leaf(const zkm_batch* b, size_t leaf, uint64_t* out) {
     if (leaf >= b->N()) return 1;

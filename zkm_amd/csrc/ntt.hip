@@ -652,6 +652,8 @@ struct ntt_big_args {
     uint32_t blocks_per_col;
     uint32_t canon_out;
     const gl_t* tw;
+    gl_t scale;           // k_ntt_blk12<INV = true>: n^-1, applied on the way out
+    uint32_t s1;          // k_ntt_blk12<.., PERM = true>: stages of the strided pass before this one (the digit layout, zkm_internal.h)
 };
 
 template <int S, int K>
@@ -768,6 +770,13 @@ __global__ __launch_bounds__((1 << SA) * 8) void k_ntt_big(ntt_big_args p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
+// INV: inverse roots (the table passed in p.tw, the negated powers of two of the last round) and the scale n^-1 on the way out.
+// PERM: the block is stored in the DIGIT order of the coefficient layout (zkm_coeff_exponent, zkm_internal.h) instead of in place:
+// word q of the block (holding the output whose index has the high twelve bits rev12(q)) goes to position
+// rev_(12-s1)(q >> s1) * 2^s1 + rev_s1(q mod 2^s1), so that the 2^s1 coefficients t_lo + 2^12 t_hi of one t_lo are CONTIGUOUS in t_hi
+// -- the runs k_lde_upper reads its tile from.  Lanes store consecutive positions (512 B per wave instruction) and fetch the word
+// that belongs there from the LDS image (any wave's sub-block: one more workgroup barrier).
+template <bool INV, bool PERM>
 __global__ __launch_bounds__(512, 6) void k_ntt_blk12(ntt_big_args p) {
     extern __shared__ __attribute__((aligned(16))) gl_t lds[];
     constexpr int NT = 512, SB = 576;
@@ -835,30 +844,45 @@ __global__ __launch_bounds__(512, 6) void k_ntt_blk12(ntt_big_args p) {
         ZKM_WAVE_SYNC();
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = sub[a4 + (l7 ^ j)];
-        R::template compute_pow2<false>(x);                       // stages 2, 1, 0
-        if (p.canon_out) {
+        R::template compute_pow2<INV>(x);                         // stages 2, 1, 0
+        if (INV) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = gl_mul(x[j], p.scale);   // (canonical)
+        } else if (p.canon_out) {
 #pragma unroll
             for (int j = 0; j < 8; j++) x[j] = gl_canon(x[j]);
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) sub[a4 + (l7 ^ j)] = x[j];
-        ZKM_WAVE_SYNC();
-        gl_t* const out = dst + (wv << 9);
+        if (PERM) {
+            __syncthreads();                                      // every sub-block of the image is final
+            const unsigned s1 = p.s1, cb = 12 - s1;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const gl_t v = sub[a2 + 72 * j];
-            out[l + 64 * j] = v;
+            for (int j = 0; j < 8; j++) {
+                const unsigned pos = tid + NT * j;
+                const unsigned q = (bitrev32(pos >> s1, cb) << s1) | bitrev32(pos & ((1u << s1) - 1), s1);
+                dst[pos] = lds[(q >> 9) * SB + A(q & 511)];
+            }
+        } else {
+            ZKM_WAVE_SYNC();
+            gl_t* const out = dst + (wv << 9);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const gl_t v = sub[a2 + 72 * j];
+                out[l + 64 * j] = v;
+            }
         }
     }
 }
 
+template <bool INV, bool PERM>
 static void launch_blk12(zkm_ctx* c, const ntt_big_args& a) {
     static std::atomic<uint64_t> lds_ok{0};
     const size_t shmem = (8 * 576 + 7 * 64 + 7 * 8) * sizeof(gl_t);
-    ntt_allow_big_lds(c, k_ntt_blk12, lds_ok);
+    ntt_allow_big_lds(c, k_ntt_blk12<INV, PERM>, lds_ok);
     uint32_t total = a.ncols * a.blocks_per_col;
     uint32_t grid = total < (uint32_t)c->num_cus * 12 ? total : (uint32_t)c->num_cus * 12;
-    hipLaunchKernelGGL(k_ntt_blk12, dim3(grid), dim3(512), shmem, c->stream, a);
+    hipLaunchKernelGGL((k_ntt_blk12<INV, PERM>), dim3(grid), dim3(512), shmem, c->stream, a);
 }
 
 template <int SA>
@@ -873,11 +897,11 @@ static void launch_big_t(zkm_ctx* c, const ntt_big_args& a) {
 
 // S2 = 11, 12, 13 lower stages of every contiguous 2^S2 block of `ncols` columns of length 2^L, in place
 static void ntt_big_pass(zkm_ctx* c, gl_t* data, size_t cs, size_t ncols, unsigned L, int S2, const gl_t* tw) {
-    ntt_big_args a{data, cs, (uint32_t)ncols, (uint32_t)(((size_t)1 << L) >> S2), 1u, tw};
+    ntt_big_args a{data, cs, (uint32_t)ncols, (uint32_t)(((size_t)1 << L) >> S2), 1u, tw, 1, 0};
     zkm_prof_scope ps(c, "ntt_pass_big");
     switch (S2) {
         case 11: launch_big_t<5>(c, a); break;
-        case 12: launch_blk12(c, a); break;
+        case 12: launch_blk12<false, false>(c, a); break;
         case 13: launch_big_t<7>(c, a); break;
         default: throw std::runtime_error("ntt big pass: unsupported stage count");
     }
@@ -949,7 +973,13 @@ struct ct_round : ntt_round<S, K> {
     }
 };
 
-template <int S>
+// RUNS: the coefficients come in the digit layout of the two-pass inverse transform (zkm_coeff_exponent): the 2^S coefficients
+// t_lo + 2^S2 t_hi of column t_lo are a contiguous run, in t_hi order, at rev_S(t_lo mod 2^S) * 2^12 + (t_lo >> S) * 2^S -- the tile is
+// 2^(12-S) runs instead of 2^S row segments.  The first round then has its lanes along the ROWS of a run (thread = (row group rgA,
+// column bA), rgA fastest): each load instruction reads 2^(S-3) consecutive words of a run, and the block twiddles of the first round
+// depend on no row bit a thread holds, so they stay uniform.  The first exchange goes through a column-major image ([column][row],
+// stride 2^S + 1) that the row-fastest lanes write and the column-fastest lanes of the later rounds read without bank conflicts.
+template <int S, bool RUNS>
 __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
     extern __shared__ __attribute__((aligned(16))) gl_t lds[];
     constexpr int R = 1 << S, NR = (S + 2) / 3, LT = 12 - S, T = 1 << LT;
@@ -963,8 +993,10 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
     const uint32_t t_lo = (tile << LT) + b;                      // column of the 2^S2-wide row this lane works on
     const gl_t* const ct = p.ct + ((size_t)coset << S);
 
+    constexpr int RG = R >> 3, IMG = R * T + T;                  // row groups; words per LDS image (the column-major one is padded)
+    const int rgA = RUNS ? tid & (RG - 1) : rg, bA = RUNS ? tid / RG : b;   // first-round thread mapping
     gl_t w0[7], w1[7], w2[7];
-    R0::template load<(LT + R0::q >= 6)>(w0, ct, rg);
+    R0::template load<(RUNS || LT + R0::q >= 6)>(w0, ct, rgA);
     if (NR > 1) R1::template load<(LT + R1::q >= 6)>(w1, ct, rg);
     if (NR > 2) R2::template load<(LT + R2::q >= 6)>(w2, ct, rg);
 
@@ -983,8 +1015,10 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
     }
 
     const size_t sa = (size_t)1 << p.S2;
-    const uint32_t lane_in = (uint32_t)((size_t)rg * sa) + t_lo;             // rows rg + j R/8 (== R0::row(rg, j))
-    const size_t in_step = (size_t)(R >> 3) * sa;
+    // rows rg + j R/8 (== R0::row(rg, j)) of column t_lo
+    const uint32_t t_loA = (tile << LT) + bA;
+    const uint32_t lane_in = RUNS ? ((bitrev32(t_loA & (R - 1), S) << 12) | ((t_loA >> S) << S)) + (uint32_t)rgA : (uint32_t)((size_t)rg * sa) + t_lo;
+    const size_t in_step = RUNS ? (size_t)(R >> 3) : (size_t)(R >> 3) * sa;
     const uint32_t lane_out = (uint32_t)((size_t)(rg << 3) * sa) + t_lo;     // rows (rg << 3) | j
     const size_t out_off = p.out_off_k[coset];
 
@@ -1007,15 +1041,23 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
         __builtin_amdgcn_sched_barrier(0);
         R0::compute(x, w0);
         if (NR > 1) {
-            gl_t* const img = lds + (ex & 1) * (R * T);
+            gl_t* const img = lds + (ex & 1) * IMG;
             ex++;
-            R0::lds_write(img, T, b, rg, x);
-            __syncthreads();
-            R1::lds_read(img, T, b, rg, x);
+            if (RUNS) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) img[bA * (R + 1) + R0::row(rgA, j)] = x[j];
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 8; j++) x[j] = img[b * (R + 1) + R1::row(rg, j)];
+            } else {
+                R0::lds_write(img, T, b, rg, x);
+                __syncthreads();
+                R1::lds_read(img, T, b, rg, x);
+            }
             R1::compute(x, w1);
         }
         if (NR > 2) {
-            gl_t* const img = lds + (ex & 1) * (R * T);
+            gl_t* const img = lds + (ex & 1) * IMG;
             ex++;
             R1::lds_write(img, T, b, rg, x);
             __syncthreads();
@@ -1034,14 +1076,14 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
     }
 }
 
-template <int S>
+template <int S, bool RUNS = false>
 static void launch_lde_upper_t(zkm_ctx* c, const lde_upper_args& a) {
     static std::atomic<uint64_t> lds_ok{0};
-    ntt_allow_big_lds(c, k_lde_upper<S>, lds_ok);
-    const size_t shmem = 2 * 4096 * sizeof(gl_t);                             // two images of the 2^S x 2^(12-S) tile
+    ntt_allow_big_lds(c, k_lde_upper<S, RUNS>, lds_ok);
+    const size_t shmem = 2 * (4096 + (4096 >> S)) * sizeof(gl_t);             // two images of the 2^S x 2^(12-S) tile (+ one pad word per column)
     const uint32_t ntiles = (1u << a.S2) >> (12 - S);
     dim3 grid(ntiles * 4, (a.ncols + a.cpb - 1) / a.cpb);
-    hipLaunchKernelGGL((k_lde_upper<S>), grid, dim3(512), shmem, c->stream, a);
+    hipLaunchKernelGGL((k_lde_upper<S, RUNS>), grid, dim3(512), shmem, c->stream, a);
 }
 
 // W(k, q) = shift_c^(n / 2^(k+1)) * w_(2^(k+1))^bitrev_k(q) at [c][2^k + q], c = 0..3, shift_c = shift * w_4n^c
@@ -1081,8 +1123,9 @@ static const gl_t* lde_ct_table(zkm_ctx* c, uint64_t shift, unsigned log_n, unsi
 // one a single one (measured at 262 x 2^20: 6.8 ms / 12 stages against 8.4 ms / 13 stages, profiles/r02_ntt_split_ab.txt).  2^22-row
 // polynomials (BASELINE config 4) need nine upper stages: a 512-row x 8-column tile, i.e. 64 B row segments -- slower per byte than
 // the 128 B segments of S1 = 8, still 104n instead of 168n bytes.
-static bool lde_coset_split(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, uint64_t shift) {
+static bool lde_coset_split(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, uint64_t shift, unsigned coeff_s1) {
     if (log_n < 14 || log_n > 22 || shift <= 1) return false;
+    if (coeff_s1 && (coeff_s1 != log_n - 12 || coeff_s1 < 6 || coeff_s1 > 8)) throw std::runtime_error("internal: LDE of an unexpected coefficient layout");
     const size_t n = (size_t)1 << log_n, N = n << 2;
     const int S2 = log_n == 14 ? 11 : (log_n <= 20 ? 12 : 13);
     const int S1 = (int)log_n - S2;   // 3..9
@@ -1106,11 +1149,19 @@ static bool lde_coset_split(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t nc
         u.cpb = (uint32_t)(want < 1 ? 1 : (want > 16 ? 16 : want));
         if (u.cpb > u.ncols) u.cpb = u.ncols;
         zkm_prof_scope ps(c, "ntt_pass_strided");
-        switch (S1) {
-            case 6: launch_lde_upper_t<6>(c, u); break;
-            case 7: launch_lde_upper_t<7>(c, u); break;
-            case 8: launch_lde_upper_t<8>(c, u); break;
-            default: launch_lde_upper_t<9>(c, u); break;
+        if (coeff_s1) {
+            switch (S1) {
+                case 6: launch_lde_upper_t<6, true>(c, u); break;
+                case 7: launch_lde_upper_t<7, true>(c, u); break;
+                default: launch_lde_upper_t<8, true>(c, u); break;
+            }
+        } else {
+            switch (S1) {
+                case 6: launch_lde_upper_t<6>(c, u); break;
+                case 7: launch_lde_upper_t<7>(c, u); break;
+                case 8: launch_lde_upper_t<8>(c, u); break;
+                default: launch_lde_upper_t<9>(c, u); break;
+            }
         }
         ZKM_HIP_CHECK(hipGetLastError());
     } else {
@@ -1255,9 +1306,79 @@ void zkm_launch_scale_pad(zkm_ctx* c, const gl_t* in, size_t col_stride_in, gl_t
     ZKM_HIP_CHECK(hipGetLastError());
 }
 
-void zkm_lde_bitrev(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, unsigned rate_bits, uint64_t shift) {
+// ------------------------------------------------------------------ values -> coefficients in the digit layout: TWO passes
+// from_values needs an inverse transform natural -> natural, and a self-sorting transform of 2^20 points takes three passes of <= 8
+// stages (the last one transposing).  Nothing forces the coefficients to be stored in natural order, though: their consumers are this
+// library's own kernels.  A plain decimation-in-frequency transform is the strided pass of S1 = log_n - 12 stages followed by the
+// 2^12-element block kernel (twelve stages per pass), 32n instead of 48n bytes per column; what it leaves in place is bit-reversed,
+// and the block kernel stores its block in the order the first LDE pass reads best (k_ntt_blk12<.., PERM>): position
+//     P = rev_S1(e mod 2^S1) * 2^12 + ((e >> S1) mod 2^(12-S1)) * 2^S1 + (e >> 12)          holds the coefficient of X^e
+// (zkm_coeff_exponent is the inverse map).  Used for 2^18 .. 2^20 rows (S1 = 6, 7, 8: where k_lde_upper takes the first LDE pass);
+// other heights keep natural order.  Consumers: k_lde_upper<S, RUNS>, the openings (exponent-indexed power table), the FRI
+// combination (position-wise, then zkm_coeffs_to_natural on the composite polynomials), zkm_batch_coeffs (converts on the way out).
+void zkm_intt_digit(zkm_ctx* c, const gl_t* values, size_t cs_in, gl_t* coeffs, size_t cs_out, size_t ncols, unsigned log_n) {
+    const unsigned s1 = zkm_coeff_layout_s1(log_n);
+    if (!s1) throw std::runtime_error("internal: no digit layout for this height");
+    const size_t n = (size_t)1 << log_n;
+    c->ensure_twiddles(log_n);
+    ntt_pass_args a{};
+    a.in = values; a.out = coeffs; a.cs_in = cs_in; a.cs_out = cs_out; a.ncols = (uint32_t)ncols;
+    a.tw = c->tw.inv; a.m = 12; a.post_scale = 1; a.n_in = ~(size_t)0;
+    a.log_T = pick_log_T((int)s1, (size_t)1 << 12);
+    a.tp = 1u << a.log_T;
+    a.n_lo = (uint32_t)(((size_t)1 << 12) >> a.log_T);
+    a.bi_hi = a.bo_hi = n; a.bi_lo = a.bo_lo = (size_t)1 << a.log_T;
+    a.sa_in = a.sa_out = (size_t)1 << 12; a.sb_in = a.sb_out = 1;
+    a.canon_out = 0;
+    launch_pass(c, (int)s1, a, a.n_lo, "ntt_pass_strided");
+    ntt_big_args b{coeffs, cs_out, (uint32_t)ncols, (uint32_t)(n >> 12), 1u, c->tw.inv, gl_inv((gl_t)(n % GL_P)), s1};
+    zkm_prof_scope ps(c, "ntt_pass_big");
+    launch_blk12<true, true>(c, b);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
+// Layout conversion of whole columns, both directions (to_natural: out[e(P)] = in[P]; else out[P] = in[e(P)]).  A workgroup moves the
+// tile k_lde_upper would read: 2^(12-s1) runs of 2^s1 coefficients on the digit side == 2^s1 rows of 2^(12-s1) consecutive exponents
+// on the natural side, through LDS, so both sides move contiguous segments (>= 128 B).  in != out.
+__global__ __launch_bounds__(256) void k_coeff_layout(const gl_t* __restrict__ in, size_t cs_in, gl_t* __restrict__ out, size_t cs_out,
+                                                      unsigned log_n, unsigned s1, int to_natural) {
+    __shared__ gl_t tile[4096 + 64];
+    const unsigned lt = 12 - s1, T = 1u << lt, R = 1u << s1;
+    const uint32_t t0 = blockIdx.x << lt;                         // first exponent-column (t_lo) of the tile
+    const gl_t* src = in + (size_t)blockIdx.y * cs_in;
+    gl_t* dst = out + (size_t)blockIdx.y * cs_out;
+    // tile[(b * R + t_hi) with a pad of one word per 64]: element of column t_lo = t0 + b, row t_hi
+    auto slot = [](unsigned i) { return i + (i >> 6); };
+    for (unsigned i = threadIdx.x; i < 4096; i += 256) {
+        const unsigned b = to_natural ? i >> s1 : i & (T - 1), t_hi = to_natural ? i & (R - 1) : i >> lt;
+        const uint32_t t_lo = t0 + b;
+        const uint32_t P = (bitrev32(t_lo & (R - 1), s1) << 12) | ((t_lo >> s1) << s1) | t_hi, e = (t_hi << 12) | t_lo;
+        tile[slot(b * R + t_hi)] = src[to_natural ? P : e];
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < 4096; i += 256) {
+        const unsigned b = to_natural ? i & (T - 1) : i >> s1, t_hi = to_natural ? i >> lt : i & (R - 1);
+        const uint32_t t_lo = t0 + b;
+        const uint32_t P = (bitrev32(t_lo & (R - 1), s1) << 12) | ((t_lo >> s1) << s1) | t_hi, e = (t_hi << 12) | t_lo;
+        dst[to_natural ? e : P] = tile[slot(b * R + t_hi)];
+    }
+}
+
+void zkm_coeff_layout_convert(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* out, size_t cs_out, size_t ncols, unsigned log_n, bool to_natural) {
+    const unsigned s1 = zkm_coeff_layout_s1(log_n);
+    if (!s1) throw std::runtime_error("internal: no digit layout for this height");
+    if (!ncols) return;
+    zkm_prof_scope ps(c, "coeff_layout");
+    hipLaunchKernelGGL(k_coeff_layout, dim3(((size_t)1 << log_n) >> 12, (unsigned)ncols), dim3(256), 0, c->stream, in, cs_in, out, cs_out, log_n, s1,
+                       to_natural ? 1 : 0);
+    ZKM_HIP_CHECK(hipGetLastError());
+}
+
+void zkm_lde_bitrev(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, unsigned rate_bits, uint64_t shift,
+                    unsigned coeff_s1) {
     size_t n = (size_t)1 << log_n, N = n << rate_bits;
-    if (rate_bits == 2 && lde_coset_split(c, coeffs, out, ncols, log_n, shift)) return;
+    if (rate_bits == 2 && lde_coset_split(c, coeffs, out, ncols, log_n, shift, coeff_s1)) return;
+    if (coeff_s1) throw std::runtime_error("internal: the digit coefficient layout is only produced where the coset-split LDE reads it");
     if (log_n + rate_bits >= 3) {
         ntt_dif_bitrev_fast(c, coeffs, n, out, N, ncols, log_n + rate_bits, false, n, log_n, shift);
         return;

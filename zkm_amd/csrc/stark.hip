@@ -380,10 +380,13 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
 // of one chunk so a power is loaded once per OPEN_CPB coefficients; all loads are coalesced.
 #define OPEN_CHUNK_LOG 14
 #define OPEN_CPB 4
-__global__ __launch_bounds__(256) void k_open_powers(gl2_t z0, gl2_t z1, unsigned chunk_len, gl_t* __restrict__ pw /* [4][chunk_len] */) {
+// pw[.][k] = z^(exponent of position k of a column): the batch's coefficient layout (zkm_coeff_exponent) is a permutation of the BITS
+// of the position, so the exponent of position chunk * chunk_len + k is e(k) + e(chunk * chunk_len) and the table of one chunk serves all.
+__global__ __launch_bounds__(256) void k_open_powers(gl2_t z0, gl2_t z1, unsigned chunk_len, unsigned coeff_s1, gl_t* __restrict__ pw /* [4][chunk_len] */) {
     unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= chunk_len) return;
-    gl2_t p0 = gl2_pow(z0, k), p1 = gl2_pow(z1, k);
+    const uint64_t e = zkm_coeff_exponent(k, coeff_s1);
+    gl2_t p0 = gl2_pow(z0, e), p1 = gl2_pow(z1, e);
     pw[k] = p0.c0; pw[chunk_len + k] = p0.c1; pw[2 * chunk_len + k] = p1.c0; pw[3 * chunk_len + k] = p1.c1;
 }
 struct lazy_sum {
@@ -452,7 +455,7 @@ static std::vector<open_vals> eval_batch(zkm_ctx* c, const zkm_batch* b, gl2_t z
     gl_t* d_pw = (gl_t*)c->alloc((size_t)4 * chunk_len * sizeof(gl_t));
     {
         zkm_prof_scope ps(c, "open_partials");
-        hipLaunchKernelGGL(k_open_powers, dim3((chunk_len + 255) / 256), dim3(256), 0, c->stream, z0, z1, chunk_len, d_pw);
+        hipLaunchKernelGGL(k_open_powers, dim3((chunk_len + 255) / 256), dim3(256), 0, c->stream, z0, z1, chunk_len, b->coeff_s1, d_pw);
         hipLaunchKernelGGL(k_open_partials, dim3(nchunks, (b->ncols + OPEN_CPB - 1) / OPEN_CPB), dim3(256), 0, c->stream, b->coeffs, log_n,
                            b->ncols, d_pw, d_part);
         ZKM_HIP_CHECK(hipGetLastError());
@@ -462,15 +465,21 @@ static std::vector<open_vals> eval_batch(zkm_ctx* c, const zkm_batch* b, gl2_t z
     c->sync();
     c->release(d_part);
     c->release(d_pw);
-    gl2_t s0 = gl2_pow(z0, (uint64_t)1 << chunk_log), s1 = gl2_pow(z1, (uint64_t)1 << chunk_log);
+    // chunk ch contributes z^(exponent of its first position) * partial (natural order: z^(ch * chunk_len), i.e. Horner over the chunks)
+    std::vector<gl2_t> f0(nchunks), f1(nchunks);
+    for (size_t ch = 0; ch < nchunks; ch++) {
+        const uint64_t e = zkm_coeff_exponent((uint32_t)(ch << chunk_log), b->coeff_s1);
+        f0[ch] = gl2_pow(z0, e);
+        f1[ch] = gl2_pow(z1, e);
+    }
     std::vector<open_vals> out(b->ncols);
     for (size_t col = 0; col < b->ncols; col++) {
         gl2_t a0{0, 0}, a1{0, 0};
         gl_t sum = 0;
-        for (size_t ch = nchunks; ch-- > 0;) {
+        for (size_t ch = 0; ch < nchunks; ch++) {
             const gl_t* q = &part[(col * nchunks + ch) * 5];
-            a0 = gl2_add(gl2_mul(a0, s0), gl2_t{q[0], q[1]});
-            a1 = gl2_add(gl2_mul(a1, s1), gl2_t{q[2], q[3]});
+            a0 = gl2_add(a0, gl2_mul(f0[ch], gl2_t{q[0], q[1]}));
+            a1 = gl2_add(a1, gl2_mul(f1[ch], gl2_t{q[2], q[3]}));
             sum = gl_add(sum, q[4]);
         }
         out[col] = open_vals{a0, a1, sum};
@@ -1010,11 +1019,20 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
         ZKM_HIP_CHECK(hipMemcpyAsync(d_apow, apow.data(), apow.size() * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
         gl_t* d_comp = (gl_t*)c->alloc(6 * n * sizeof(gl_t));
         scratch.push_back(d_comp);
+        if (tb->coeff_s1 != abp->coeff_s1 || tb->coeff_s1 != qbp->coeff_s1) throw std::runtime_error("internal: coefficient layouts of the three oracles differ");
         {
             zkm_prof_scope ps(c, "fri_combine");
             hipLaunchKernelGGL(k_fri_combine, dim3((n + 255) / 256), dim3(256), 0, c->stream, tb->coeffs, W, abp->coeffs, A, qbp->coeffs, y.Q,
                                total_helpers, d_apow, n, d_comp);
             ZKM_HIP_CHECK(hipGetLastError());
+        }
+        if (tb->coeff_s1) {
+            // the combination is position-wise, so the six composite arrays come out in the batches' coefficient layout; the division by
+            // (X - point) walks exponents in order
+            gl_t* d_nat = (gl_t*)c->alloc(6 * n * sizeof(gl_t));
+            scratch.push_back(d_nat);
+            zkm_coeff_layout_convert(c, d_comp, n, d_nat, n, 6, log_n, /*to_natural=*/true);
+            d_comp = d_nat;
         }
         // divide by (X - point), accumulate, commit phase, proof of work, query rounds: shared with zkm_fri_prove
         {
@@ -1126,7 +1144,8 @@ int zkm_fri_prove(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch* cons
         const unsigned log_n = oracles[0]->log_n;
         size_t cols[ZKM_FRI_MAX_ORACLES];
         for (size_t k = 0; k < noracles; k++) {
-            if (!oracles[k] || oracles[k]->log_n != log_n || oracles[k]->rate_bits != cfg->rate_bits || oracles[k]->cap_height != cfg->cap_height)
+            if (!oracles[k] || oracles[k]->log_n != log_n || oracles[k]->rate_bits != cfg->rate_bits || oracles[k]->cap_height != cfg->cap_height ||
+                oracles[k]->coeff_s1 != oracles[0]->coeff_s1)
                 throw std::runtime_error("zkm_fri_prove: oracles must share degree, rate and cap height with the config");
             cols[k] = oracles[k]->ncols;
         }
@@ -1176,6 +1195,12 @@ int zkm_fri_prove(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch* cons
             const size_t np = batches[b].npolys;
             comps.push_back({d_comp + 2 * b * n, d_comp + (2 * b + 1) * n, gl2_t{batches[b].point[0], batches[b].point[1]},
                              gl2_t{apow[2 * np], apow[2 * np + 1]}});
+        }
+        if (oracles[0]->coeff_s1) {   // (the layout is a function of the height: the same for every oracle; see prove_single_table)
+            gl_t* d_nat = (gl_t*)c->alloc(2 * nbatches * n * sizeof(gl_t));
+            scratch.push_back(d_nat);
+            zkm_coeff_layout_convert(c, d_comp, n, d_nat, n, 2 * nbatches, log_n, /*to_natural=*/true);
+            for (auto& k : comps) { k.c0 = d_nat + (k.c0 - d_comp); k.c1 = d_nat + (k.c1 - d_comp); }
         }
         ZKM_HIP_CHECK(hipStreamSynchronize(c->stream));  // host vectors (ptrs, apow) are consumed
         fri_finish(c, cfg, log_n, comps, oracles, noracles, ch, y.L, y.F, cfg->num_queries, y.query_words, proof + y.o_caps, proof + y.o_final,

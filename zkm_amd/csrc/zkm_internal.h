@@ -112,7 +112,8 @@ struct zkm_batch {
     zkm_ctx* ctx = nullptr;
     size_t ncols = 0;
     unsigned log_n = 0, rate_bits = 0, cap_height = 0;
-    gl_t* coeffs = nullptr;   // ncols x n, natural order
+    gl_t* coeffs = nullptr;   // ncols x n; position P of a column = coefficient of X^zkm_coeff_exponent(P, coeff_s1)
+    unsigned coeff_s1 = 0;    // 0: natural order; else the digit layout of the two-pass inverse transform (2^18 .. 2^20 rows)
     gl_t* lde = nullptr;      // ncols x N, rows bit-reversed
     gl_t* digests = nullptr;  // levels 0..top concatenated, 4 words per node
     std::vector<size_t> level_off;  // word offsets
@@ -166,8 +167,20 @@ void zkm_ntt_natural(zkm_ctx*, gl_t* in_scratch, gl_t* out, size_t ncols, size_t
 // out[c][i] = in[c][i] * shift^i for i < n_in, 0 for n_in <= i < n_out  (columns strided)
 void zkm_launch_scale_pad(zkm_ctx*, const gl_t* in, size_t col_stride_in, gl_t* out, size_t col_stride_out, size_t ncols,
                           unsigned log_n_in, unsigned log_n_out, uint64_t shift);
-// coset LDE of natural-order coefficients into bit-reversed evaluations: out (ncols x 2^(log_n+rate_bits))
-void zkm_lde_bitrev(zkm_ctx*, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, unsigned rate_bits, uint64_t shift);
+// coset LDE of coefficients (natural order, or the digit layout when coeff_s1 != 0) into bit-reversed evaluations: out (ncols x 2^(log_n+rate_bits))
+void zkm_lde_bitrev(zkm_ctx*, const gl_t* coeffs, gl_t* out, size_t ncols, unsigned log_n, unsigned rate_bits, uint64_t shift,
+                    unsigned coeff_s1 = 0);
+// ---- coefficient layout of a batch (ntt.hip zkm_intt_digit): position P of a column holds the coefficient of X^zkm_coeff_exponent(P).
+// s1 = 0: natural order.  s1 = log_n - 12 for 2^18 .. 2^20 rows: what the two-pass inverse transform leaves (see ntt.hip).
+inline unsigned zkm_coeff_layout_s1(unsigned log_n) { return (log_n >= 18 && log_n <= 20) ? log_n - 12 : 0; }
+GL_HD uint32_t zkm_coeff_exponent(uint32_t P, unsigned s1) {
+    if (!s1) return P;
+    const uint32_t t_hi = P & ((1u << s1) - 1), cc = (P >> s1) & ((1u << (12 - s1)) - 1), blk = P >> 12;
+    return (t_hi << 12) | (cc << s1) | bitrev32(blk, s1);
+}
+// values (natural, read-only) -> coefficients in the digit layout, two passes; coefficient columns to / from natural order (in != out)
+void zkm_intt_digit(zkm_ctx*, const gl_t* values, size_t cs_in, gl_t* coeffs, size_t cs_out, size_t ncols, unsigned log_n);
+void zkm_coeff_layout_convert(zkm_ctx*, const gl_t* in, size_t cs_in, gl_t* out, size_t cs_out, size_t ncols, unsigned log_n, bool to_natural);
 
 // ---- core.hip
 // dev_values (optional, ncols x n words of device memory): host values are uploaded THERE and stay (the caller reuses them, e.g. for
