@@ -1145,7 +1145,9 @@ static bool lde_coset_split(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t nc
         u.tw = c->tw.fwd; u.ct = lde_ct_table(c, shift, log_n, (unsigned)S1);
         for (unsigned k = 0; k < 4; k++) { u.pre_tab_k[k] = pre_tab_k[k]; u.out_off_k[k] = out_off_k[k]; }
         const size_t ntiles = ((size_t)1 << S2) >> (12 - S1);
-        size_t want = (ncols * ntiles) / 2048;                        // columns per workgroup (as launch_pass)
+        // columns per workgroup (as launch_pass).  (8 instead of 16, to keep the four coset workgroups of a tile closer together in time:
+        // measured worse -- 43.0 instead of 41.9 GB per proof and +7 % time, profiles/r03_e vs r03_d.)
+        size_t want = (ncols * ntiles) / 2048;
         u.cpb = (uint32_t)(want < 1 ? 1 : (want > 16 ? 16 : want));
         if (u.cpb > u.ncols) u.cpb = u.ncols;
         zkm_prof_scope ps(c, "ntt_pass_strided");
@@ -1324,7 +1326,8 @@ void zkm_intt_digit(zkm_ctx* c, const gl_t* values, size_t cs_in, gl_t* coeffs, 
     ntt_pass_args a{};
     a.in = values; a.out = coeffs; a.cs_in = cs_in; a.cs_out = cs_out; a.ncols = (uint32_t)ncols;
     a.tw = c->tw.inv; a.m = 12; a.post_scale = 1; a.n_in = ~(size_t)0;
-    a.log_T = pick_log_T((int)s1, (size_t)1 << 12);
+    a.log_T = 12 - s1;   // a 4096-element tile (512 threads): 2^(12 - s1) contiguous columns per row, >= 128 B segments (the 2048-element
+                         // tile of pick_log_T gives an eight-stage pass 64 B rows: every cache line fetched by two workgroups)
     a.tp = 1u << a.log_T;
     a.n_lo = (uint32_t)(((size_t)1 << 12) >> a.log_T);
     a.bi_hi = a.bo_hi = n; a.bi_lo = a.bo_lo = (size_t)1 << a.log_T;
