@@ -1145,8 +1145,9 @@ static bool lde_coset_split(zkm_ctx* c, const gl_t* coeffs, gl_t* out, size_t nc
         u.tw = c->tw.fwd; u.ct = lde_ct_table(c, shift, log_n, (unsigned)S1);
         for (unsigned k = 0; k < 4; k++) { u.pre_tab_k[k] = pre_tab_k[k]; u.out_off_k[k] = out_off_k[k]; }
         const size_t ntiles = ((size_t)1 << S2) >> (12 - S1);
-        // columns per workgroup (as launch_pass).  (8 instead of 16, to keep the four coset workgroups of a tile closer together in time:
-        // measured worse -- 43.0 instead of 41.9 GB per proof and +7 % time, profiles/r03_e vs r03_d.)
+        // columns per workgroup (as launch_pass).  Two things were measured against the L2 misses of the four cosets' re-reads (1.4 GB per
+        // proof) and lost, profiles/r03_ntt_variants.txt: 8 columns per workgroup (43.0 GB, +7 % time), two cosets per 1024-thread
+        // workgroup (41.7 GB, +12 % time).
         size_t want = (ncols * ntiles) / 2048;
         u.cpb = (uint32_t)(want < 1 ? 1 : (want > 16 ? 16 : want));
         if (u.cpb > u.ncols) u.cpb = u.ncols;
