@@ -35,13 +35,15 @@ def test_large_ntt_matches_oracle(ctx, oracle, log_n):
         assert bad.size == 0, (log_n, inverse, shift, int(bad[0]), bad.size)
 
 
-@pytest.mark.parametrize("log_n,ncols", [(15, 7), (17, 262), (18, 5), (19, 2), (20, 3), (21, 1), (22, 1)])
+@pytest.mark.parametrize("log_n,ncols", [(15, 7), (17, 262), (18, 5), (18, 70), (19, 2), (20, 3), (21, 1), (22, 1)])
 def test_large_commit_matches_oracle(ctx, zkm, oracle, log_n, ncols):
     """from_values at bench-sized transforms: coefficients (all of them), cap, digest layers, sampled LDE rows /
     leaves / Merkle paths.  (17, 262) is the bench's column count on the 3-pass iNTT + 3-pass LDE plan;
     (20, 3) and (22, 1) are the bench's / config 4's row counts (LDE lengths 2^22 / 2^24); 18, 19, 20 are the three stage
-    counts (6, 7, 8) of the block-twiddle first LDE pass (k_lde_upper), 15 and 17 the plain DIF first pass (3 and 5 stages), 21 the
-    2^13-element block kernel."""
+    counts (6, 7, 8) of the block-twiddle first LDE pass (k_lde_upper) AND of the two-pass inverse transform with its digit coefficient
+    layout (round 3: the coefficients are compared in natural order through zkm_batch_coeffs); (18, 70) takes that path through the
+    pipelined column-chunk ingest (host values, >= 64 columns); 15 and 17 are the plain DIF first pass (3 and 5 stages), 21 and 22 the
+    2^13-element block kernel with 8 and 9 upper stages."""
     rng = np.random.default_rng(2000 + log_n)
     vals = rand_field(rng, ncols << log_n)
     b = zkm.PolynomialBatch.from_values(ctx, vals, ncols, log_n)
@@ -106,10 +108,12 @@ def test_proof_is_bit_exact_2_20(ctx, zkm, oracle_proof_2_20):
                   open(os.path.join(out, "cpu_oracle_full_size.json"), "w"), indent=1)
 
 
-@pytest.mark.parametrize("log_n", [17, 22])
+@pytest.mark.parametrize("log_n", [17, 18, 19, 22])
 def test_prove_openings_bit_exact(ctx, zkm, oracle, log_n):
-    """FRI on the 3-pass plans (final polynomial 2^17 coefficients, LDE 2^19) and BASELINE config 4 literally (13 + 4 + 4 polynomials of
-    2^22 coefficients, LDE 2^24, folds [4,4,4,4,4], 4 final coefficients): GPU bytes == oracle bytes."""
+    """FRI on the 3-pass plans (final polynomial 2^17 coefficients, LDE 2^19), on the digit coefficient layouts of 2^18 and 2^19 rows
+    (openings from the exponent-indexed power table, combination converted to natural order; 2^20 is the bench proof's test) and
+    BASELINE config 4 literally (13 + 4 + 4 polynomials of 2^22 coefficients, LDE 2^24, folds [4,4,4,4,4], 4 final coefficients):
+    GPU bytes == oracle bytes."""
     rng = np.random.default_rng(4000 + log_n)
     n = 1 << log_n
     tv, av, qc = (rng.integers(0, P, k * n, dtype=np.uint64) for k in (13, 4, 4))

@@ -216,13 +216,14 @@ def test_no_device_memory_is_leaked(zkm, oracle):
     c.close()
 
 
-def test_generic_fri_instance_equals_the_stark_instance(ctx, zkm, oracle):
+@pytest.mark.parametrize("log_n", [9, 18])
+def test_generic_fri_instance_equals_the_stark_instance(ctx, zkm, oracle, log_n):
     """zkm_fri_prove takes the FriInstanceInfo as data (oracles + batches of (oracle, polynomial) at a point).  Fed the three oracles
     and three batches of the STARK instance (stark.rs:91-148) and the transcript state prove_single_table has after observing the
     openings, it must reproduce the FRI part of zkm_prove_openings' blob word for word; a second, different instance (two oracles,
     one batch, other point) must at least be self-consistent with the oracle-checked STARK path on its shared pieces."""
     import ctypes as C
-    log_n, (W, A, Q, Z) = 9, (13, 4, 4, 2)
+    W, A, Q, Z = 13, 4, 4, 2            # (log_n 18: the batches keep their coefficients in the digit layout of the two-pass inverse transform)
     rng = np.random.default_rng(91)
     n = 1 << log_n
     tv, av, qc = (rng.integers(0, P, k * n, dtype=np.uint64) for k in (W, A, Q))
