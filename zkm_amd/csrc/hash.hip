@@ -296,7 +296,12 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_wide(const gl_t* __restri
     }
     if (live && idx < 4) digests[4 * leaf + idx] = x;
 }
-static size_t wide_max_leaves() { return 16384; }
+// Rows up to which a leaf gets a 16-lane row (k_merkle_leaves_wide).  One absorb step takes ~10 us in the 16-lane form while every SIMD
+// holds at most one such wave (4096 rows), ~21 us with two (8192), ~41 us with four (16384) -- against ~27 us for the one-lane form
+// on a wave that has its SIMD to itself, which it has for these heights (4096 rows = 64 waves).  Beyond 4096 rows the wide form
+// is at best a little faster alone and occupies the whole machine for it (7.5x the instructions): the other tables of the segment,
+// committed side by side on the lanes, and other contexts want those slots.
+static size_t wide_max_leaves() { return 4096; }
 
 
 // FRI layer leaves, one hash per 16-lane row (small layers): word m of leaf k is component m & 1 of value k * arity + (m >> 1).
