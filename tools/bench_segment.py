@@ -59,6 +59,7 @@ def segment_rate(ctx, log_cycles, reps=3):
             "kernel_ms_per_segment": kernel_ms, "wall_over_kernel_sum": wall * 1e3 / kernel_ms,
             "launches_per_segment": sum(v[0] for v in krec.values()) / reps, "proof_words": int(offs[12]),
             "kernel_ms": {k: round(v[1] / reps, 3) for k, v in sorted(krec.items(), key=lambda kv: -kv[1][1])[:12]},
+            "launches": {k: round(v[0] / reps, 1) for k, v in sorted(krec.items(), key=lambda kv: -kv[1][0])[:12]},
             "stage_ms": {k[6:]: round(v[1] / reps, 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1]) if k.startswith("stage/")},
             "note": "twelve tables, fifteen lookups, one zkm_prove_segment call; traces device-resident, tiled test segment (timing only). The trace "
                     "commitments, and after the CTL challenges the CTL data + auxiliary commitments, of the twelve tables run side by side on the "

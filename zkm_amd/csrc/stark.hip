@@ -445,44 +445,57 @@ __global__ __launch_bounds__(256) void k_open_partials(const gl_t* __restrict__ 
 
 struct open_vals { gl2_t at_z0, at_z1; gl_t at_one; };
 
-// evaluate every polynomial of the batch at z0, z1 (F2) and 1
-static std::vector<open_vals> eval_batch(zkm_ctx* c, const zkm_batch* b, gl2_t z0, gl2_t z1) {
-    unsigned log_n = b->log_n;
-    unsigned chunk_log = log_n < OPEN_CHUNK_LOG ? log_n : OPEN_CHUNK_LOG;
-    size_t nchunks = (size_t)1 << (log_n - chunk_log), words = b->ncols * nchunks * 5;
-    gl_t* d_part = (gl_t*)c->alloc(words * sizeof(gl_t));
-    const unsigned chunk_len = 1u << chunk_log;
-    gl_t* d_pw = (gl_t*)c->alloc((size_t)4 * chunk_len * sizeof(gl_t));
+// evaluate every polynomial of the batches (same height, same coefficient layout) at z0, z1 (F2) and 1: one power table, one launch
+// per batch, one download
+static std::vector<std::vector<open_vals>> eval_batches(zkm_ctx* c, const std::vector<const zkm_batch*>& bs, gl2_t z0, gl2_t z1) {
+    const zkm_batch* b0 = bs.at(0);
+    const unsigned log_n = b0->log_n, chunk_log = log_n < OPEN_CHUNK_LOG ? log_n : OPEN_CHUNK_LOG, chunk_len = 1u << chunk_log;
+    const size_t nchunks = (size_t)1 << (log_n - chunk_log);
+    size_t total_cols = 0;
+    for (const zkm_batch* b : bs) {
+        if (b->log_n != log_n || b->coeff_s1 != b0->coeff_s1) throw std::runtime_error("internal: openings of batches with different shapes");
+        total_cols += b->ncols;
+    }
+    const size_t words = total_cols * nchunks * 5;
+    zkm_scratch d_part(c, words * sizeof(gl_t)), d_pw(c, (size_t)4 * chunk_len * sizeof(gl_t));
     {
         zkm_prof_scope ps(c, "open_partials");
-        hipLaunchKernelGGL(k_open_powers, dim3((chunk_len + 255) / 256), dim3(256), 0, c->stream, z0, z1, chunk_len, b->coeff_s1, d_pw);
-        hipLaunchKernelGGL(k_open_partials, dim3(nchunks, (b->ncols + OPEN_CPB - 1) / OPEN_CPB), dim3(256), 0, c->stream, b->coeffs, log_n,
-                           b->ncols, d_pw, d_part);
+        hipLaunchKernelGGL(k_open_powers, dim3((chunk_len + 255) / 256), dim3(256), 0, c->stream, z0, z1, chunk_len, b0->coeff_s1, d_pw.as<gl_t>());
+        size_t col0 = 0;
+        for (const zkm_batch* b : bs) {
+            hipLaunchKernelGGL(k_open_partials, dim3(nchunks, (b->ncols + OPEN_CPB - 1) / OPEN_CPB), dim3(256), 0, c->stream, b->coeffs, log_n,
+                               b->ncols, d_pw.as<gl_t>(), d_part.as<gl_t>() + col0 * nchunks * 5);
+            col0 += b->ncols;
+        }
         ZKM_HIP_CHECK(hipGetLastError());
     }
     std::vector<gl_t> part(words);
-    ZKM_HIP_CHECK(hipMemcpyAsync(part.data(), d_part, words * sizeof(gl_t), hipMemcpyDeviceToHost, c->stream));
+    ZKM_HIP_CHECK(hipMemcpyAsync(part.data(), d_part.p, words * sizeof(gl_t), hipMemcpyDeviceToHost, c->stream));
     c->sync();
-    c->release(d_part);
-    c->release(d_pw);
     // chunk ch contributes z^(exponent of its first position) * partial (natural order: z^(ch * chunk_len), i.e. Horner over the chunks)
     std::vector<gl2_t> f0(nchunks), f1(nchunks);
     for (size_t ch = 0; ch < nchunks; ch++) {
-        const uint64_t e = zkm_coeff_exponent((uint32_t)(ch << chunk_log), b->coeff_s1);
+        const uint64_t e = zkm_coeff_exponent((uint32_t)(ch << chunk_log), b0->coeff_s1);
         f0[ch] = gl2_pow(z0, e);
         f1[ch] = gl2_pow(z1, e);
     }
-    std::vector<open_vals> out(b->ncols);
-    for (size_t col = 0; col < b->ncols; col++) {
-        gl2_t a0{0, 0}, a1{0, 0};
-        gl_t sum = 0;
-        for (size_t ch = 0; ch < nchunks; ch++) {
-            const gl_t* q = &part[(col * nchunks + ch) * 5];
-            a0 = gl2_add(a0, gl2_mul(f0[ch], gl2_t{q[0], q[1]}));
-            a1 = gl2_add(a1, gl2_mul(f1[ch], gl2_t{q[2], q[3]}));
-            sum = gl_add(sum, q[4]);
+    std::vector<std::vector<open_vals>> out;
+    size_t col0 = 0;
+    for (const zkm_batch* b : bs) {
+        std::vector<open_vals> o(b->ncols);
+        for (size_t col = 0; col < b->ncols; col++) {
+            gl2_t a0{0, 0}, a1{0, 0};
+            gl_t sum = 0;
+            for (size_t ch = 0; ch < nchunks; ch++) {
+                const gl_t* q = &part[((col0 + col) * nchunks + ch) * 5];
+                a0 = gl2_add(a0, gl2_mul(f0[ch], gl2_t{q[0], q[1]}));
+                a1 = gl2_add(a1, gl2_mul(f1[ch], gl2_t{q[2], q[3]}));
+                sum = gl_add(sum, q[4]);
+            }
+            o[col] = open_vals{a0, a1, sum};
         }
-        out[col] = open_vals{a0, a1, sum};
+        out.push_back(std::move(o));
+        col0 += b->ncols;
     }
     return out;
 }
@@ -527,88 +540,78 @@ __global__ __launch_bounds__(256) void k_fri_combine(const gl_t* __restrict__ tc
     comp[5 * n + i] = z1;
 }
 
-// divide_by_linear as a hierarchical suffix scan with segments of 64:
-// totals:  out[s] = sum_{k<64} a[64 s + k] z^k
-__global__ void k_seg_totals(const gl_t* __restrict__ a0, const gl_t* __restrict__ a1, size_t m, gl2_t z, gl_t* __restrict__ o0,
-                             gl_t* __restrict__ o1) {
-    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t nseg = (m + 63) / 64;
+// divide_by_linear as a hierarchical suffix scan with segments of 64, for ALL batches of the instance in one set of
+// launches (blockIdx.y = batch; the STARK instance has three: zeta, g zeta, 1).  Per batch b: q_b = (comp_b(X) - comp_b(z_b)) / (X - z_b),
+// q_b[k - 1] = S_b[k] with S_b[k] = a_b[k] + z_b S_b[k + 1]; the final polynomial is sum_b w_b q_b, w_b = prod_{b' > b} shift_b'
+// (plonky2 accumulates final = final * alpha^(#polys of the batch) + quotient, batch by batch: the same sum, regrouped).
+#define FRI_MAX_BATCHES 8
+struct seg_batches {
+    uint32_t nb;
+    const gl_t* a0[FRI_MAX_BATCHES];   // this level's arrays of every batch (level 0: the composite polynomials)
+    const gl_t* a1[FRI_MAX_BATCHES];
+    gl2_t z[FRI_MAX_BATCHES];          // z_b^(64^level)
+    gl2_t w[FRI_MAX_BATCHES];          // weight of the batch in the final sum (bottom level)
+};
+// totals:  out_b[s] = sum_{k<64} a_b[64 s + k] z_b^k          (out: [batch][2][nseg])
+__global__ void k_seg_totals(seg_batches p, size_t m, gl_t* __restrict__ out) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + 63) / 64;
+    const unsigned b = blockIdx.y;
     if (s >= nseg) return;
+    const gl_t *a0 = p.a0[b], *a1 = p.a1[b];
+    const gl2_t z = p.z[b];
     gl2_t acc{0, 0};
-    size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
+    const size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
     for (size_t k = end; k-- > s * 64;) acc = gl2_add(gl2_mul(acc, z), gl2_t{a0[k], a1[k]});
-    o0[s] = acc.c0;
-    o1[s] = acc.c1;
+    out[(2 * b) * nseg + s] = acc.c0;
+    out[(2 * b + 1) * nseg + s] = acc.c1;
 }
-// scan:  S[k] = a[k] + z S[k+1] inside each segment, carry-in = upper[s+1] (0 past the end)
-// mode 0: store S;  mode 1 (bottom level): fin[k-1] = fin[k-1] * shift + S[k]  (the dropped remainder is S[0]),
-//         fin[m-1] = fin[m-1] * shift
-__global__ void k_seg_scan(const gl_t* __restrict__ a0, const gl_t* __restrict__ a1, size_t m, gl2_t z, const gl_t* __restrict__ u0,
-                           const gl_t* __restrict__ u1, size_t nupper, gl_t* __restrict__ s0, gl_t* __restrict__ s1, int mode,
-                           gl2_t shift) {
-    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t nseg = (m + 63) / 64;
+// scan of an upper level:  S_b[k] = a_b[k] + z_b S_b[k+1] inside each segment, carry-in = upper_b[s+1] (0 past the end)
+// (upper: [batch][2][nupper] suffix values of the level above, or null at the top; out: [batch][2][m])
+__global__ void k_seg_scan(seg_batches p, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ out) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + 63) / 64;
+    const unsigned b = blockIdx.y;
     if (s >= nseg) return;
+    const gl_t *a0 = p.a0[b], *a1 = p.a1[b];
+    const gl2_t z = p.z[b];
     gl2_t acc{0, 0};
-    if (u0 && s + 1 < nupper) acc = gl2_t{u0[s + 1], u1[s + 1]};
-    size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
-    if (mode == 1 && end == m) {
-        gl2_t f = gl2_mul(gl2_t{s0[m - 1], s1[m - 1]}, shift);
-        s0[m - 1] = f.c0;
-        s1[m - 1] = f.c1;
-    }
+    if (upper && s + 1 < nupper) acc = gl2_t{upper[(2 * b) * nupper + s + 1], upper[(2 * b + 1) * nupper + s + 1]};
+    const size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
     for (size_t k = end; k-- > s * 64;) {
         acc = gl2_add(gl2_mul(acc, z), gl2_t{a0[k], a1[k]});
-        if (mode == 0) {
-            s0[k] = acc.c0;
-            s1[k] = acc.c1;
-        } else if (k > 0) {
-            gl2_t f = gl2_add(gl2_mul(gl2_t{s0[k - 1], s1[k - 1]}, shift), acc);
-            s0[k - 1] = f.c0;
-            s1[k - 1] = f.c1;
+        out[(2 * b) * m + k] = acc.c0;
+        out[(2 * b + 1) * m + k] = acc.c1;
+    }
+}
+// bottom level: fin[k - 1] = sum_b w_b S_b[k] (the dropped remainders are the S_b[0]), fin[m - 1] = 0
+__global__ void k_seg_scan_final(seg_batches p, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ f0,
+                                 gl_t* __restrict__ f1) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + 63) / 64;
+    if (s >= nseg) return;
+    gl2_t acc[FRI_MAX_BATCHES];                              // (fixed trip counts + a uniform guard: the accumulators stay in registers)
+#pragma unroll
+    for (unsigned b = 0; b < FRI_MAX_BATCHES; b++) {
+        acc[b] = gl2_t{0, 0};
+        if (b < p.nb && upper && s + 1 < nupper) acc[b] = gl2_t{upper[(2 * b) * nupper + s + 1], upper[(2 * b + 1) * nupper + s + 1]};
+    }
+    const size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
+    if (end == m) { f0[m - 1] = 0; f1[m - 1] = 0; }
+    for (size_t k = end; k-- > s * 64;) {
+        gl2_t f{0, 0};
+#pragma unroll
+        for (unsigned b = 0; b < FRI_MAX_BATCHES; b++) {
+            if (b < p.nb) {
+                acc[b] = gl2_add(gl2_mul(acc[b], p.z[b]), gl2_t{p.a0[b][k], p.a1[b][k]});
+                f = gl2_add(f, gl2_mul(acc[b], p.w[b]));
+            }
         }
+        if (k > 0) { f0[k - 1] = f.c0; f1[k - 1] = f.c1; }
     }
 }
 
-// fin = fin * shift + (comp(X) - comp(z)) / (X - z), re-padded to n coefficients
-static void divide_accumulate(zkm_ctx* c, const gl_t* a0, const gl_t* a1, size_t n, gl2_t z, gl2_t shift, gl_t* f0, gl_t* f1) {
-    // build the pyramid of totals
-    struct level { gl_t *t0, *t1; size_t m; gl2_t z; };
-    std::vector<level> lv;
-    lv.push_back(level{const_cast<gl_t*>(a0), const_cast<gl_t*>(a1), n, z});
-    zkm_prof_scope ps(c, "fri_divide_linear");
-    while (lv.back().m > 64) {
-        level& b = lv.back();
-        size_t nseg = (b.m + 63) / 64;
-        gl_t* t0 = (gl_t*)c->alloc(nseg * sizeof(gl_t));
-        gl_t* t1 = (gl_t*)c->alloc(nseg * sizeof(gl_t));
-        hipLaunchKernelGGL(k_seg_totals, dim3((nseg + 63) / 64), dim3(64), 0, c->stream, b.t0, b.t1, b.m, b.z, t0, t1);
-        lv.push_back(level{t0, t1, nseg, gl2_pow(b.z, 64)});
-    }
-    // top-down: suffix values of each level
-    std::vector<std::pair<gl_t*, gl_t*>> S(lv.size(), {nullptr, nullptr});
-    for (size_t l = lv.size(); l-- > 0;) {
-        level& b = lv[l];
-        size_t nseg = (b.m + 63) / 64;
-        const gl_t *u0 = nullptr, *u1 = nullptr;
-        size_t nupper = 0;
-        if (l + 1 < lv.size()) { u0 = S[l + 1].first; u1 = S[l + 1].second; nupper = lv[l + 1].m; }
-        if (l == 0) {
-            hipLaunchKernelGGL(k_seg_scan, dim3((nseg + 63) / 64), dim3(64), 0, c->stream, b.t0, b.t1, b.m, b.z, u0, u1, nupper, f0, f1, 1, shift);
-        } else {
-            S[l].first = (gl_t*)c->alloc(b.m * sizeof(gl_t));
-            S[l].second = (gl_t*)c->alloc(b.m * sizeof(gl_t));
-            hipLaunchKernelGGL(k_seg_scan, dim3((nseg + 63) / 64), dim3(64), 0, c->stream, b.t0, b.t1, b.m, b.z, u0, u1, nupper, S[l].first,
-                               S[l].second, 0, shift);
-        }
-    }
-    ZKM_HIP_CHECK(hipGetLastError());
-    // no host sync: released blocks are only reused by later work on this stream
-    for (size_t l = 1; l < lv.size(); l++) {
-        c->release(lv[l].t0); c->release(lv[l].t1);
-        c->release(S[l].first); c->release(S[l].second);
-    }
-}
+struct fri_composite;
+// fin = sum over the batches (in order) of: fin * shift_b + (comp_b(X) - comp_b(z_b)) / (X - z_b), re-padded to n coefficients.
+// fin is written completely (no zero-fill needed).
+static void divide_accumulate_all(zkm_ctx* c, const std::vector<fri_composite>& comps, size_t n, gl_t* f0, gl_t* f1);
 
 // ------------------------------------------------------------------ K13: FRI fold
 // c'_j = sum_{i < arity} beta^i c_{arity j + i}   (reduce_with_powers per chunk)
@@ -699,6 +702,53 @@ struct fri_composite {
     gl2_t point, shift;
 };
 
+static void divide_accumulate_all(zkm_ctx* c, const std::vector<fri_composite>& comps, size_t n, gl_t* f0, gl_t* f1) {
+    const unsigned nb = (unsigned)comps.size();
+    if (nb == 0 || nb > FRI_MAX_BATCHES) throw std::runtime_error("FRI: 1..8 opening batches");
+    zkm_prof_scope ps(c, "fri_divide_linear");
+    // level sizes: n, ceil(n / 64), ... down to <= 64
+    std::vector<size_t> m{n};
+    while (m.back() > 64) m.push_back((m.back() + 63) / 64);
+    const size_t L = m.size();
+    std::vector<seg_batches> lv(L);
+    std::vector<gl_t*> tot(L, nullptr), suf(L, nullptr);   // tot[l]: [nb][2][m[l]] totals feeding level l (l >= 1); suf[l]: suffix values of level l
+    std::vector<void*> tmp;
+    gl2_t wacc{1, 0};
+    for (unsigned b = nb; b-- > 0;) {                      // w_b = product of the shifts of the batches after b
+        lv[0].w[b] = wacc;
+        wacc = gl2_mul(wacc, comps[b].shift);
+    }
+    for (unsigned b = 0; b < nb; b++) { lv[0].a0[b] = comps[b].c0; lv[0].a1[b] = comps[b].c1; lv[0].z[b] = comps[b].point; }
+    lv[0].nb = nb;
+    for (size_t l = 1; l < L; l++) {
+        tot[l] = (gl_t*)c->alloc(2 * nb * m[l] * sizeof(gl_t));
+        tmp.push_back(tot[l]);
+        hipLaunchKernelGGL(k_seg_totals, dim3((unsigned)((m[l] + 63) / 64), nb), dim3(64), 0, c->stream, lv[l - 1], m[l - 1], tot[l]);
+        lv[l] = lv[0];
+        for (unsigned b = 0; b < nb; b++) {
+            lv[l].a0[b] = tot[l] + (2 * b) * m[l];
+            lv[l].a1[b] = tot[l] + (2 * b + 1) * m[l];
+            lv[l].z[b] = gl2_pow(lv[l - 1].z[b], 64);
+        }
+    }
+    // top-down: suffix values of each level
+    for (size_t l = L; l-- > 0;) {
+        const size_t nseg = (m[l] + 63) / 64;
+        const gl_t* upper = l + 1 < L ? suf[l + 1] : nullptr;
+        const size_t nupper = l + 1 < L ? m[l + 1] : 0;
+        if (l == 0) {
+            hipLaunchKernelGGL(k_seg_scan_final, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, c->stream, lv[0], m[0], upper, nupper, f0, f1);
+        } else {
+            suf[l] = (gl_t*)c->alloc(2 * nb * m[l] * sizeof(gl_t));
+            tmp.push_back(suf[l]);
+            hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)((nseg + 63) / 64), nb), dim3(64), 0, c->stream, lv[l], m[l], upper, nupper, suf[l]);
+        }
+    }
+    ZKM_HIP_CHECK(hipGetLastError());
+    // no host sync: released blocks are only reused by later work on this stream
+    for (void* q : tmp) c->release(q);
+}
+
 static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, const std::vector<fri_composite>& comps,
                        const zkm_batch* const* orc, size_t noracles, zkm_challenger* ch, unsigned L, size_t F, size_t nq, size_t query_words,
                        uint64_t* caps_out, uint64_t* final_out, uint64_t* pow_out, uint64_t* queries_out) {
@@ -717,8 +767,7 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
     try {
         gl_t* d_fin = (gl_t*)c->alloc(2 * n * sizeof(gl_t));  // final poly coefficients [2][n]
         scratch.push_back(d_fin);
-        ZKM_HIP_CHECK(hipMemsetAsync(d_fin, 0, 2 * n * sizeof(gl_t), c->stream));
-        for (const fri_composite& k : comps) divide_accumulate(c, k.c0, k.c1, n, k.point, k.shift, d_fin, d_fin + n);
+        divide_accumulate_all(c, comps, n, d_fin, d_fin + n);
 
         // commit phase: coefficients stay in d_fin (length clen, implicitly zero-padded x4)
         size_t clen = n;
@@ -983,18 +1032,17 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
         uint64_t *o_local = op, *o_next = op + 2 * W, *o_aux = op + 4 * W, *o_auxn = o_aux + 2 * A, *o_ctl = o_auxn + 2 * A, *o_quot = o_ctl + Z;
         {
             zkm_prof_scope st(c, "stage/openings (StarkOpeningSet::new)");  // proof.rs:299-334, between two timed! scopes in the reference
-            auto tv = eval_batch(c, tb, zeta, zeta_next);
+            auto ev = eval_batches(c, {tb, abp, qbp}, zeta, zeta_next);
+            const auto &tv = ev[0], &av = ev[1], &qv = ev[2];
             for (size_t i = 0; i < W; i++) {
                 o_local[2 * i] = tv[i].at_z0.c0; o_local[2 * i + 1] = tv[i].at_z0.c1;
                 o_next[2 * i] = tv[i].at_z1.c0; o_next[2 * i + 1] = tv[i].at_z1.c1;
             }
-            auto av = eval_batch(c, abp, zeta, zeta_next);
             for (size_t i = 0; i < A; i++) {
                 o_aux[2 * i] = av[i].at_z0.c0; o_aux[2 * i + 1] = av[i].at_z0.c1;
                 o_auxn[2 * i] = av[i].at_z1.c0; o_auxn[2 * i + 1] = av[i].at_z1.c1;
                 if (i >= total_helpers) o_ctl[i - total_helpers] = av[i].at_one;
             }
-            auto qv = eval_batch(c, qbp, zeta, zeta_next);
             for (size_t i = 0; i < y.Q; i++) { o_quot[2 * i] = qv[i].at_z0.c0; o_quot[2 * i + 1] = qv[i].at_z0.c1; }
         }
         // observe_openings(to_fri_openings) proof.rs:336-367
@@ -1321,7 +1369,7 @@ int zkm_eval_openings(zkm_ctx* c, const zkm_batch* b, const uint64_t zeta[2], ui
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         gl2_t z{zeta[0], zeta[1]};
-        auto v = eval_batch(c, b, z, z);
+        auto v = eval_batches(c, {b}, z, z)[0];
         for (size_t i = 0; i < b->ncols; i++) { out[2 * i] = v[i].at_z0.c0; out[2 * i + 1] = v[i].at_z0.c1; }
     } catch (const std::exception& e) {
         return fail(err, e.what());
