@@ -41,6 +41,10 @@ def oracle_proof_2_20(oracle):
     that compare GPU proofs with it.  A dict: trace xor-checksum and sampled words, the proof words, the oracle's wall and stage seconds."""
     import time
     import numpy as np
+    if (os.cpu_count() or 1) < 32:
+        # ~70 s on 64 threads; on a small host it would eat the GPU suite's time limit and every later test with it.  The tests that use
+        # this fixture keep their size-independent checks (oracle verifier, single-context equality) and skip the word-for-word part.
+        return None
     log_n = 20
     n = 1 << log_n
     old = oracle.get_threads()

@@ -38,8 +38,9 @@ def test_config3_64_segments_four_contexts(zkm, oracle, oracle_proof_2_20):
             alone = solo.prove_single_table(traces[s], LOG_N, aux, [1, 1])
             assert alone.size == proofs[s].size and (alone == proofs[s]).all(), "segment %d differs from its single-context proof" % s
         solo.close()
-        want = oracle_proof_2_20["proof"]
-        assert proofs[0].size == want.size and (proofs[0] == want).all(), "segment 0 (seed 100) differs from the CPU oracle's proof"
+        if oracle_proof_2_20 is not None:                           # (None on hosts too small to run the oracle at 2^20 rows in time)
+            want = oracle_proof_2_20["proof"]
+            assert proofs[0].size == want.size and (proofs[0] == want).all(), "segment 0 (seed 100) differs from the CPU oracle's proof"
         rate = NSEG / elapsed
         print("config 3 on one MI355X: %d segments in %.2f s = %.2f proofs/s (%d contexts)" % (NSEG, elapsed, rate, NCTX))
         assert rate > 5.0                                           # sanity only (r02: 16 proofs/s); the number of record is bench.py's
