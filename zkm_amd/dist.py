@@ -91,7 +91,6 @@ def pin_to_gpu(local_rank, local_world, device=None):
 
 def init(backend=None):
     """Initialise the process group from torchrun's environment (no-op for a single process)."""
-    global _HOST_GROUP
     world, rank, local_rank = env_world()
     if world > 1 and not dist.is_initialized():
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -102,7 +101,6 @@ def init(backend=None):
             dev = torch.cuda.current_device()   # the caller has set the rank's device (bench.py: check_gpus -> set_device)
             kw["device_id"] = torch.device("cuda", dev)
         dist.init_process_group(backend, **kw)
-        _HOST_GROUP = dist.new_group(backend="gloo") if backend == "nccl" else None
     return world, rank, local_rank
 
 
@@ -129,8 +127,13 @@ def max_over_ranks(seconds):
 def gather_proofs(local):
     """local: {segment_index: proof ndarray}.  Returns the merged dict on rank 0 (None elsewhere).  Host objects travel over the
     gloo side group when the main backend is RCCL (no detour through device memory)."""
+    global _HOST_GROUP
     if not dist.is_initialized():
         return dict(local)
+    if dist.get_backend() == "nccl" and _HOST_GROUP is None:
+        # created on first use (a collective call: every rank gathers or none does): gloo announces its connections on STDOUT, and a run
+        # that gathers nothing -- the driver's scaling runs -- must print nothing but rank 0's JSON line
+        _HOST_GROUP = dist.new_group(backend="gloo")
     out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
     dist.gather_object(local, out, dst=0, group=_HOST_GROUP)
     if dist.get_rank() != 0:
