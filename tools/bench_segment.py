@@ -6,7 +6,7 @@ The traces are the committed test segment (tests/golden/segment12.npz) tiled to 
 (the reference's default segment size, emulator/src/utils.rs:6) or of a 2^20-cycle one -- rows repeat, so the witness is not
 valid across the seams; the prover does not care, the numbers are timings only.  No oracle, no fixture builders.
 
-  python tools/bench_segment.py [16|20]        prints one JSON object
+  python tools/bench_segment.py [16|20] [single]   prints one JSON object (single: without the concurrent-context runs, e.g. under rocprofv3)
   from tools.bench_segment import small_segment_rate   (bench.py's `segment_2_16` key)
 """
 import json
@@ -116,6 +116,6 @@ if __name__ == "__main__":
     lc = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     out = segment_rate(c, lc)
     out["memory_live_cached"] = c.memory()
-    if lc == 16:
+    if lc == 16 and "single" not in sys.argv[2:]:
         out["concurrent"] = [concurrent_segment_rate(0, 16, k) for k in (2, 4, 8)]
     print(json.dumps(out, indent=1))

@@ -87,13 +87,18 @@ ctl_dev_owner::~ctl_dev_owner() {
 }
 
 // ------------------------------------------------------------------ K6 kernels
-// helper columns + per-row sum of all terms of CtlZData `zi`
-__global__ __launch_bounds__(256) void k_ctl_terms(ctl_dev d, uint32_t zi, const gl_t* __restrict__ trace, size_t n,
-                                                   gl_t* __restrict__ helpers /* num_helpers x n or null */, gl_t* __restrict__ hsum,
-                                                   int* __restrict__ bad) {
+// helper columns + per-row sum of all terms of CtlZData zi0 + blockIdx.y (a run of Zs in one launch): helper columns of Z zi start at
+// aux + (helper columns of the Zs before it) * n, the row sums go to hsum_all + zi * n
+__global__ __launch_bounds__(256) void k_ctl_terms(ctl_dev d, uint32_t zi0, const gl_t* __restrict__ trace, size_t n,
+                                                   gl_t* __restrict__ aux, gl_t* __restrict__ hsum_all, int* __restrict__ bad) {
     size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
+    const uint32_t zi = zi0 + blockIdx.y;
     const zkm_ctl_z z = d.zs[zi];
+    size_t hstart = 0;
+    for (uint32_t k = 0; k < zi; k++) hstart += d.zs[k].num_helpers;     // (wave-uniform scalar loads; a table has at most a few dozen Zs)
+    gl_t* const helpers = z.num_helpers ? aux + hstart * n : nullptr;
+    gl_t* const hsum = hsum_all + (size_t)zi * n;
     const uint32_t* ids = d.colset_ids + z.colset_off;
     const gl_t* lv = trace + row;
     bool next_ok = row + 1 < n;
@@ -146,22 +151,26 @@ __global__ __launch_bounds__(256) void k_ctl_rowsum(const gl_t* __restrict__ hel
     hsum[row] = total;
 }
 
-// additive suffix scan, segments of 64:  totals[s] = sum of segment s
-__global__ void k_sum_totals(const gl_t* __restrict__ a, size_t m, gl_t* __restrict__ out) {
+// additive suffix scans of nb arrays of length m at stride `stride` (blockIdx.y = array), segments of 64:  totals[b][s] = sum of segment s
+__global__ void k_sum_totals(const gl_t* __restrict__ a, size_t stride, size_t m, gl_t* __restrict__ out) {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t nseg = (m + 63) / 64;
     if (s >= nseg) return;
+    a += (size_t)blockIdx.y * stride;
     size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
     gl_t acc = 0;
     for (size_t k = s * 64; k < end; k++) acc = gl_add(acc, a[k]);
-    out[s] = acc;
+    out[(size_t)blockIdx.y * nseg + s] = acc;
 }
-// S[k] = a[k] + S[k+1] inside each segment, carry-in = upper[s+1]
-__global__ void k_sum_scan(const gl_t* __restrict__ a, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ out) {
+// S[k] = a[k] + S[k+1] inside each segment, carry-in = upper[s+1]   (upper: [array][nupper])
+__global__ void k_sum_scan(const gl_t* __restrict__ a, size_t stride, size_t m, const gl_t* __restrict__ upper, size_t nupper,
+                           gl_t* __restrict__ out, size_t out_stride) {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t nseg = (m + 63) / 64;
     if (s >= nseg) return;
-    gl_t acc = (upper && s + 1 < nupper) ? upper[s + 1] : 0;
+    a += (size_t)blockIdx.y * stride;
+    out += (size_t)blockIdx.y * out_stride;
+    gl_t acc = (upper && s + 1 < nupper) ? upper[(size_t)blockIdx.y * nupper + s + 1] : 0;
     size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
     for (size_t k = end; k-- > s * 64;) {
         acc = gl_add(acc, a[k]);
@@ -169,27 +178,34 @@ __global__ void k_sum_scan(const gl_t* __restrict__ a, size_t m, const gl_t* __r
     }
 }
 
-// out[k] = sum_{m >= k} a[m]   (out may alias a)
-static void suffix_sum(zkm_ctx* c, const gl_t* a, size_t n, gl_t* out) {
-    struct level { gl_t* t; size_t m; };
-    std::vector<level> lv{{const_cast<gl_t*>(a), n}};
+// out[b][k] = sum_{m >= k} a[b][m] for nb arrays (a[b] = a + b * a_stride, out[b] = out + b * out_stride; out may alias a): one launch per
+// level for all arrays -- the Z columns of a table are built together (a table of the reference has up to 28 of them)
+static void suffix_sum(zkm_ctx* c, const gl_t* a, size_t a_stride, size_t n, size_t nb, gl_t* out, size_t out_stride) {
+    if (!nb) return;
+    struct level { const gl_t* t; size_t stride, m; };
+    std::vector<level> lv{{a, a_stride, n}};
+    std::vector<void*> tmp;
     while (lv.back().m > 64) {
         size_t nseg = (lv.back().m + 63) / 64;
-        gl_t* t = (gl_t*)c->alloc(nseg * sizeof(gl_t));
-        hipLaunchKernelGGL(k_sum_totals, dim3((nseg + 63) / 64), dim3(64), 0, c->stream, lv.back().t, lv.back().m, t);
-        lv.push_back({t, nseg});
+        gl_t* t = (gl_t*)c->alloc(nb * nseg * sizeof(gl_t));
+        tmp.push_back(t);
+        hipLaunchKernelGGL(k_sum_totals, dim3((unsigned)((nseg + 63) / 64), (unsigned)nb), dim3(64), 0, c->stream, lv.back().t, lv.back().stride,
+                           lv.back().m, t);
+        lv.push_back({t, nseg, nseg});
     }
     std::vector<gl_t*> S(lv.size(), nullptr);
     for (size_t l = lv.size(); l-- > 0;) {
         size_t nseg = (lv[l].m + 63) / 64;
         const gl_t* upper = l + 1 < lv.size() ? S[l + 1] : nullptr;
         size_t nupper = l + 1 < lv.size() ? lv[l + 1].m : 0;
-        S[l] = l == 0 ? out : (gl_t*)c->alloc(lv[l].m * sizeof(gl_t));
-        hipLaunchKernelGGL(k_sum_scan, dim3((nseg + 63) / 64), dim3(64), 0, c->stream, lv[l].t, lv[l].m, upper, nupper, S[l]);
+        if (l == 0) S[l] = out;
+        else { S[l] = (gl_t*)c->alloc(nb * lv[l].m * sizeof(gl_t)); tmp.push_back(S[l]); }
+        hipLaunchKernelGGL(k_sum_scan, dim3((unsigned)((nseg + 63) / 64), (unsigned)nb), dim3(64), 0, c->stream, lv[l].t, lv[l].stride, lv[l].m,
+                           upper, nupper, S[l], l == 0 ? out_stride : lv[l].m);
     }
     ZKM_HIP_CHECK(hipGetLastError());
     // no host sync: the temporaries go back to the caching allocator, whose blocks are only ever reused by later work on this stream
-    for (size_t l = 1; l < lv.size(); l++) { c->release(lv[l].t); c->release(S[l]); }
+    for (void* q : tmp) c->release(q);
 }
 
 // logUp: x[i] = hsum[i] - frequencies[i] / (challenge + table[i])   (lookup.rs:100-116)
@@ -211,39 +227,40 @@ __global__ __launch_bounds__(256) void k_prefix_from_suffix(const gl_t* __restri
 // aux (device, naux x n) = helper columns (zs order) ++ Z columns
 void zkm_ctl_data_device(zkm_ctx* c, const ctl_dev_owner& own, const gl_t* d_trace, unsigned log_n, gl_t* d_aux) {
     size_t n = (size_t)1 << log_n;
-    gl_t* d_hsum = (gl_t*)c->alloc(n * sizeof(gl_t));
+    const std::vector<zkm_ctl_z>& zs = own.h_zs;             // (host copy kept by upload(): no round trip for the launch planning)
+    const size_t nzs = zs.size();
+    gl_t* const d_hsum_all = (gl_t*)c->alloc((nzs ? nzs : 1) * n * sizeof(gl_t));   // the per-row sums of every Z, scanned together below
     int* d_bad = (int*)c->alloc(sizeof(int));
     ZKM_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
-    // host copy of num_helpers (the descriptor blob is on the device)
-    std::vector<zkm_ctl_z> zs(own.d.nzs);
-    if (own.d.nzs) ZKM_HIP_CHECK(hipMemcpyAsync(zs.data(), own.d.zs, own.d.nzs * sizeof(zkm_ctl_z), hipMemcpyDeviceToHost, c->stream));
-    c->sync();
+    // Zs with many helper columns on a short table spread their column sets over blockIdx.y (few workgroups per launch otherwise);
+    // every other run of consecutive Zs is ONE launch (blockIdx.y = Z)
+    auto wide = [&](uint32_t i) { return zs[i].num_helpers >= 4 && (n >> 8) < 4096; };
     size_t hstart = 0;
-    for (uint32_t i = 0; i < own.d.nzs; i++) {
-        gl_t* helpers = zs[i].num_helpers ? d_aux + hstart * n : nullptr;
-        {
-            static const char* const names[] = {"ctl_terms_2^0", "ctl_terms_2^1", "ctl_terms_2^2", "ctl_terms_2^3", "ctl_terms_2^4", "ctl_terms_2^5", "ctl_terms_2^6", "ctl_terms_2^7", "ctl_terms_2^8", "ctl_terms_2^9", "ctl_terms_2^10", "ctl_terms_2^11", "ctl_terms_2^12", "ctl_terms_2^13", "ctl_terms_2^14", "ctl_terms_2^15", "ctl_terms_2^16", "ctl_terms_2^17", "ctl_terms_2^18", "ctl_terms_2^19", "ctl_terms_2^20", "ctl_terms_2^21", "ctl_terms_2^22", "ctl_terms_2^23", "ctl_terms_2^24"};
-            unsigned lg = 0; while (((size_t)1 << lg) < n && lg < 24) lg++;
-            zkm_prof_scope ps(c, getenv("ZKM_CTL_PROF") ? names[lg] : "ctl_terms");
+    for (uint32_t i = 0; i < nzs;) {
+        zkm_prof_scope ps(c, "ctl_terms");
+        if (wide(i)) {
+            gl_t* helpers = d_aux + hstart * n;
             const uint32_t nh = zs[i].num_helpers;
-            if (helpers && nh >= 4 && (n >> 8) * 1 < 4096) {  // few workgroups per launch otherwise: spread the column sets over blockIdx.y
-                hipLaunchKernelGGL(k_ctl_helper, dim3((n + 255) / 256, nh), dim3(256), 0, c->stream, own.d, i, d_trace, n, helpers, d_bad);
-                hipLaunchKernelGGL(k_ctl_rowsum, dim3((n + 255) / 256), dim3(256), 0, c->stream, helpers, nh, n, d_hsum);
-            } else {
-                hipLaunchKernelGGL(k_ctl_terms, dim3((n + 255) / 256), dim3(256), 0, c->stream, own.d, i, d_trace, n, helpers, d_hsum, d_bad);
-            }
-            ZKM_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(k_ctl_helper, dim3((n + 255) / 256, nh), dim3(256), 0, c->stream, own.d, i, d_trace, n, helpers, d_bad);
+            hipLaunchKernelGGL(k_ctl_rowsum, dim3((n + 255) / 256), dim3(256), 0, c->stream, helpers, nh, n, d_hsum_all + (size_t)i * n);
+            hstart += nh;
+            i++;
+        } else {
+            uint32_t run = 0;
+            while (i + run < nzs && !wide(i + run)) { hstart += zs[i + run].num_helpers; run++; }
+            hipLaunchKernelGGL(k_ctl_terms, dim3((n + 255) / 256, run), dim3(256), 0, c->stream, own.d, i, d_trace, n, d_aux, d_hsum_all, d_bad);
+            i += run;
         }
-        {
-            zkm_prof_scope ps(c, "ctl_suffix_sum");
-            suffix_sum(c, d_hsum, n, d_aux + ((size_t)own.d.total_helpers + i) * n);
-        }
-        hstart += zs[i].num_helpers;
+        ZKM_HIP_CHECK(hipGetLastError());
+    }
+    {
+        zkm_prof_scope ps(c, "ctl_suffix_sum");
+        suffix_sum(c, d_hsum_all, n, n, nzs, d_aux + (size_t)own.d.total_helpers * n, n);
     }
     int bad = 0;
     ZKM_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->sync();
-    c->release(d_hsum);
+    c->release(d_hsum_all);
     c->release(d_bad);
     if (bad) throw std::runtime_error("Non-binary filter?");
 }
@@ -360,7 +377,7 @@ static void lookup_helper_columns_device(zkm_ctx* c, const zkm_ctl_table* table,
                                d_hsum, d_x);
             ZKM_HIP_CHECK(hipGetLastError());
         }
-        suffix_sum(c, d_x, n, d_hsum);
+        suffix_sum(c, d_x, n, n, 1, d_hsum, n);
         hipLaunchKernelGGL(k_prefix_from_suffix, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_hsum, n, d_out + nh * n);
         ZKM_HIP_CHECK(hipGetLastError());
         int bad = 0;
