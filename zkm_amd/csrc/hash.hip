@@ -68,16 +68,16 @@ __global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ 
     *reinterpret_cast<ulonglong2*>(d + 2) = make_ulonglong2(s[2], s[3]);
 }
 
-__global__ void k_merkle_leaves_wide(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests);
-static size_t wide_max_leaves();
+__global__ void k_merkle_leaves_quad(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests);
+static size_t quad_max_leaves();
 
 void zkm_launch_merkle_leaves(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests) {
     // rows of <= 4 elements are copied, not hashed (hash_or_noop): profile them under their own name
     zkm_prof_scope ps(c, ncols <= 4 ? "merkle_leaves_copy" : "merkle_leaves");
-    if (ncols > 4 && nrows <= wide_max_leaves())
+    if (ncols > 4 && nrows <= quad_max_leaves())
         // short, wide matrices (Keccak: 2431 columns x a few thousand rows): one lane per leaf leaves the machine empty and pays one
-        // permutation's full latency per 8 columns; 16 lanes per leaf cut that latency to a third and fill 16x the lanes
-        hipLaunchKernelGGL(k_merkle_leaves_wide, dim3((nrows * 16 + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
+        // permutation's full latency per 8 columns; four lanes per leaf cut that latency to a third and fill 4x the lanes
+        hipLaunchKernelGGL(k_merkle_leaves_quad, dim3((nrows * 4 + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
     else
         hipLaunchKernelGGL(k_merkle_leaves, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
     ZKM_HIP_CHECK(hipGetLastError());
@@ -206,53 +206,97 @@ __global__ __launch_bounds__(256) void k_merkle_fused(merkle_fused_args p) {
     }
 }
 
-// ---- one permutation across 12 lanes (small tree levels) ----
-// The top levels of every tree hold too few nodes to fill the machine, so a launch costs one permutation's LATENCY (~35 us for
-// the one-lane-per-hash form: ~18k dependent-ish instructions).  Here a hash owns a 16-lane row of the wave (lanes 0..11 = the
-// twelve state words): every round is constant add, x^7 (lane 0 only in the partial rounds), and the circulant MDS with the
-// twelve rotated neighbours fetched by ds_bpermute -- the textbook rounds (poseidon_stark.rs:65-95, 164-169, 239-251, 310-345),
-// 30 x ~190 instructions per lane instead of ~18k, i.e. a quarter of the latency at ~5x the total work.  Used when a level has
-// fewer than 2^15 nodes (k_merkle_fused_wide).  Bit-exact with poseidon_permute (the fused partial rounds are an algebraic regrouping).
-__device__ __forceinline__ uint64_t poseidon_permute_wide(uint64_t x, unsigned lane) {
-    const unsigned idx = lane & 15, base = lane & ~15u;
-    const bool active = idx < 12;
-    int src[12];
+// ---- one permutation across FOUR lanes (short matrices, small tree levels) ----
+// Where a launch holds too few hashes to fill the machine it costs a permutation's LATENCY (~27 us for the one-lane-per-hash form on a
+// wave that has its SIMD to itself: 12k dependent-ish instructions).  Here a hash owns a quad of lanes; lane q holds the state words
+// q, q + 4, q + 8.  Every round is the textbook one (poseidon_stark.rs:65-95, 164-169, 239-251, 310-345): constant add (folded into
+// the accumulators of the previous linear layer), x^7 on the lane's three words (word 0 only in the partial rounds), and the circulant
+// MDS out[r] = sum_j C[(j - r) mod 12] s[j] with the nine foreign words fetched by DPP quad permutes (v_mov_b32 dpp: no LDS, no
+// ds_bpermute).  For output word r = q + 4a and the input word in slot b of lane (q + k) mod 4 the coefficient is
+// C[k + 4 ((b - a + 2 [q + k >= 4]) mod 3)]: it depends on (k, (b - a) mod 3) and the lane -- twelve per-lane multipliers set up once.
+// ~5.3k instructions per permutation and wave (16 hashes): the latency of the 16-lane form this replaces (rounds 1-2; 5.7k, four
+// hashes per wave, ds_bpermute) at a QUARTER of its issue slots -- 330 wave instructions per hash against 1430, 190 for the
+// one-lane form.  Bit-exact with poseidon_permute (the fused partial rounds there are an algebraic regrouping).
+struct poseidon_quad {
+    uint32_t coef[4][3];
+    uint32_t diag;    // the +8 on the (0, 0) entry: lane 0, output slot 0, own slot 0
+    unsigned q;
+    __device__ __forceinline__ explicit poseidon_quad(unsigned lane) : q(lane & 3) {
+        constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
 #pragma unroll
-    for (int i = 1; i < 12; i++) src[i] = (int)(base + (idx + i) % 12);
-    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    const uint32_t diag = idx == 0 ? 8u : 0u;
-    const gl_t* rcp = PC::ZKM_POSEIDON_RC + (active ? idx : 0);
-    x = gl_add_loose(x, rcp[0]);
+        for (int k = 0; k < 4; k++) {
+            const bool wrap = q + k >= 4;
+#pragma unroll
+            for (int t = 0; t < 3; t++) coef[k][t] = wrap ? C[k + 4 * ((t + 2) % 3)] : C[k + 4 * t];
+        }
+        diag = q == 0 ? 8u : 0u;
+    }
+};
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_fetch(uint32_t v) {   // lane q reads lane (q + k) mod 4 of its quad: quad_perm [k, k+1, k+2, k+3]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+// s[a] = state word q + 4a (any uint64 representatives); out: canonical.  Every lane of the wave must call this (DPP reads neighbours).
+__device__ __forceinline__ void poseidon_permute_quad(uint64_t (&s)[3], const poseidon_quad& Q) {
+    const gl_t* rcp = PC::ZKM_POSEIDON_RC + Q.q;
+#pragma unroll
+    for (int a = 0; a < 3; a++) s[a] = gl_add_loose(s[a], rcp[4 * a]);
 #pragma unroll 1
     for (int r = 0; r < 30; r++) {
-        const bool full = r < 4 || r >= 26;
-        const uint64_t y = poseidon_sbox7(x);
-        x = (full || idx == 0) ? y : x;
-        const uint64_t k = r + 1 < 30 ? rcp[(r + 1) * 12] : 0;
-        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-        uint64_t al = (uint64_t)(uint32_t)k + (uint64_t)lo * (C[0] + diag), ah = (k >> 32) + (uint64_t)hi * (C[0] + diag);
-#pragma unroll
-        for (int i = 1; i < 12; i++) {
-            al += (uint64_t)(uint32_t)__shfl((int)lo, src[i]) * C[i];
-            ah += (uint64_t)(uint32_t)__shfl((int)hi, src[i]) * C[i];
+        const bool full = r < 4 || r >= 26;                 // (uniform)
+        {
+            const uint64_t y = poseidon_sbox7(s[0]);
+            s[0] = (full || Q.q == 0) ? y : s[0];
         }
-        x = poseidon_fold(al, ah);
+        if (full) {
+            s[1] = poseidon_sbox7(s[1]);
+            s[2] = poseidon_sbox7(s[2]);
+        }
+        uint32_t lo[4][3], hi[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            lo[0][b] = (uint32_t)s[b];
+            hi[0][b] = (uint32_t)(s[b] >> 32);
+            lo[1][b] = quad_fetch<0x39>(lo[0][b]); hi[1][b] = quad_fetch<0x39>(hi[0][b]);   // quad_perm [1, 2, 3, 0]
+            lo[2][b] = quad_fetch<0x4E>(lo[0][b]); hi[2][b] = quad_fetch<0x4E>(hi[0][b]);   // quad_perm [2, 3, 0, 1]
+            lo[3][b] = quad_fetch<0x93>(lo[0][b]); hi[3][b] = quad_fetch<0x93>(hi[0][b]);   // quad_perm [3, 0, 1, 2]
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const uint64_t kc = r + 1 < 30 ? rcp[(r + 1) * 12 + 4 * a] : 0;   // the next round's constant rides in the accumulators
+            uint64_t al = (uint32_t)kc, ah = kc >> 32;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    const uint32_t m = Q.coef[k][(b - a + 3) % 3];
+                    al += (uint64_t)lo[k][b] * m;
+                    ah += (uint64_t)hi[k][b] * m;
+                }
+            if (a == 0) {
+                al += (uint64_t)lo[0][0] * Q.diag;
+                ah += (uint64_t)hi[0][0] * Q.diag;
+            }
+            s[a] = poseidon_fold(al, ah);
+        }
     }
-    return gl_canon(x);
+#pragma unroll
+    for (int a = 0; a < 3; a++) s[a] = gl_canon(s[a]);
 }
 
-// Small levels, fused: a workgroup (256 threads = 16 hash slots of 16 lanes) owns a subtree with 2^J children (J <= 6) and climbs
-// its J levels through LDS -- ceil(2^(J-k) / 16) rounds of wide permutations at level k -- instead of one launch per level: the top
-// of a tree is a chain of dependent permutations (one wide permutation ~10 us), and every launch boundary added its gap to it.
-struct merkle_fused_wide_args {
+// Small levels, fused: a workgroup (256 threads = 64 hash slots of 4 lanes) owns a subtree with 2^J children (J <= 7) and climbs its J
+// levels through LDS -- ceil(2^(J-k-1) / 64) rounds of quad permutations at level k -- instead of one launch per level: the top of a
+// tree is a chain of dependent permutations, and every launch boundary added its gap to it.
+struct merkle_fused_quad_args {
     const gl_t* children;   // level l: nsub * 2^J digests
-    gl_t* parents[6];       // levels l + 1 .. l + J
-    uint32_t J;             // levels in this launch (1 .. 6)
+    gl_t* parents[7];       // levels l + 1 .. l + J
+    uint32_t J;             // levels in this launch (1 .. 7)
 };
 
-__global__ __launch_bounds__(256) void k_merkle_fused_wide(merkle_fused_wide_args p) {
-    __shared__ uint64_t sh[2][64 * 4];                    // digests of the current level of this subtree (AoS, as in HBM)
-    const unsigned tid = threadIdx.x, lane = tid & 63, idx = lane & 15, slot = tid >> 4;
+__global__ __launch_bounds__(256) void k_merkle_fused_quad(merkle_fused_quad_args p) {
+    __shared__ uint64_t sh[2][128 * 4];                   // digests of the current level of this subtree (AoS, as in HBM)
+    const unsigned tid = threadIdx.x, q = tid & 3, slot = tid >> 2, wave_slot0 = (tid >> 6) << 4;
+    const poseidon_quad Q(tid);
     const unsigned C = 1u << p.J;
     {
         const gl_t* src = p.children + (size_t)blockIdx.x * C * 4;
@@ -264,66 +308,68 @@ __global__ __launch_bounds__(256) void k_merkle_fused_wide(merkle_fused_wide_arg
         const uint64_t* in = sh[lvl & 1];
         uint64_t* out = sh[(lvl + 1) & 1];
         gl_t* g = p.parents[lvl] + (size_t)blockIdx.x * np * 4;
-        if ((slot & ~3u) >= np) return;                  // this wave has no node here or above: leave (the barrier only counts survivors)
-        for (unsigned h0 = 0; h0 < np; h0 += 16) {
-            // (a wave holds four slots; one with no live slot in this round skips it -- uniform over the wave)
-            if (h0 + (slot & ~3u) >= np) continue;
+        if (wave_slot0 >= np) return;                     // this wave has no node here or above: leave (the barrier only counts survivors)
+        for (unsigned h0 = 0; h0 < np; h0 += 64) {
+            if (h0 + wave_slot0 >= np) continue;          // (a wave holds sixteen slots; uniform over the wave)
             const unsigned h = h0 + slot;
-            const bool live = h < np;                     // uniform over the 16-lane row; every lane of the wave shuffles
-            uint64_t x = (live && idx < 8) ? in[8 * h + idx] : 0;
-            x = poseidon_permute_wide(x, lane);
-            if (live && idx < 4) {
-                out[4 * h + idx] = x;
-                g[4 * h + idx] = x;
+            const bool live = h < np;                     // uniform over the quad; every lane of the wave takes part in the DPP moves
+            uint64_t s[3] = {live ? in[8 * h + q] : 0, live ? in[8 * h + 4 + q] : 0, 0};
+            poseidon_permute_quad(s, Q);
+            if (live) {
+                out[4 * h + q] = s[0];
+                g[4 * h + q] = s[0];
             }
         }
         __syncthreads();
     }
 }
 
-// Column-major leaves, one leaf per 16-lane row (see poseidon_permute_wide): lanes 0..7 of the row fetch the next eight columns of
-// their leaf (overwrite-mode absorb: a ragged tail overwrites only the words that exist), all 12 lanes permute.  Bit-exact with
-// k_merkle_leaves.  Used when the matrix has at most wide_max_leaves() rows.
-__global__ __launch_bounds__(256) void k_merkle_leaves_wide(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride,
+// Column-major leaves, one leaf per quad: lane q fetches columns c + q and c + 4 + q of its leaf for the absorb step at column c
+// (overwrite-mode absorb: a ragged tail overwrites only the words that exist).  Bit-exact with k_merkle_leaves.  Used when the matrix
+// has at most quad_max_leaves() rows.
+__global__ __launch_bounds__(256) void k_merkle_leaves_quad(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride,
                                                             gl_t* __restrict__ digests) {
-    const unsigned lane = threadIdx.x & 63, idx = lane & 15;
-    const size_t leaf = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const bool live = leaf < nrows;  // uniform over the 16-lane row; every lane of the wave takes part in the shuffles
-    uint64_t x = 0;
+    const unsigned q = threadIdx.x & 3;
+    const size_t leaf = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const bool live = leaf < nrows;  // uniform over the quad; every lane of the wave takes part in the DPP moves
+    const poseidon_quad Q(threadIdx.x);
+    uint64_t s[3] = {0, 0, 0};
     for (size_t c = 0; c < ncols; c += 8) {
-        if (live && idx < 8 && c + idx < ncols) x = lde[(c + idx) * col_stride + leaf];
-        x = poseidon_permute_wide(x, lane);
+        if (live && c + q < ncols) s[0] = lde[(c + q) * col_stride + leaf];
+        if (live && c + 4 + q < ncols) s[1] = lde[(c + 4 + q) * col_stride + leaf];
+        poseidon_permute_quad(s, Q);
     }
-    if (live && idx < 4) digests[4 * leaf + idx] = x;
+    if (live) digests[4 * leaf + q] = s[0];
 }
-// Rows up to which a leaf gets a 16-lane row (k_merkle_leaves_wide).  One absorb step takes ~10 us in the 16-lane form while every SIMD
-// holds at most one such wave (4096 rows), ~21 us with two (8192), ~41 us with four (16384) -- against ~27 us for the one-lane form
-// on a wave that has its SIMD to itself, which it has for these heights (4096 rows = 64 waves).  Beyond 4096 rows the wide form
-// is at best a little faster alone and occupies the whole machine for it (7.5x the instructions): the other tables of the segment,
-// committed side by side on the lanes, and other contexts want those slots.
-static size_t wide_max_leaves() { return 4096; }
+// Rows up to which a leaf gets a quad of lanes.  One absorb step takes ~10 us in the quad form while a SIMD holds at most one such wave
+// (16384 rows = 1024 waves), against ~27 us for the one-lane form on a wave that has its SIMD to itself (16384 rows = 256 waves); it
+// costs 1.7x the instructions per hash (the 16-lane form of rounds 1-2: 7.5x, which is why that one stopped at 4096 rows).
+static size_t quad_max_leaves() { return 16384; }
 
-
-// FRI layer leaves, one hash per 16-lane row (small layers): word m of leaf k is component m & 1 of value k * arity + (m >> 1).
-__global__ __launch_bounds__(256) void k_merkle_leaves_ext_wide(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nleaves,
+// FRI layer leaves, one hash per quad (small layers): word m of leaf k is component m & 1 of value k * arity + (m >> 1).
+__global__ __launch_bounds__(256) void k_merkle_leaves_ext_quad(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nleaves,
                                                                 unsigned arity, gl_t* __restrict__ digests) {
-    const unsigned lane = threadIdx.x & 63, idx = lane & 15;
-    const size_t k = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const unsigned q = threadIdx.x & 3;
+    const size_t k = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const bool live = k < nleaves;
-    const gl_t* col = (idx & 1) ? c1 : c0;
-    uint64_t x = 0;
+    const poseidon_quad Q(threadIdx.x);
+    const gl_t* col = (q & 1) ? c1 : c0;                  // words q and q + 4 have the parity of q
+    uint64_t s[3] = {0, 0, 0};
     for (unsigned m = 0; m < 2 * arity; m += 8) {
-        if (live && idx < 8) x = col[k * arity + ((m + idx) >> 1)];
-        x = poseidon_permute_wide(x, lane);
+        if (live) {
+            s[0] = col[k * arity + ((m + q) >> 1)];
+            s[1] = col[k * arity + ((m + 4 + q) >> 1)];
+        }
+        poseidon_permute_quad(s, Q);
     }
-    if (live && idx < 4) digests[4 * k + idx] = x;
+    if (live) digests[4 * k + q] = s[0];
 }
 
 void zkm_launch_merkle_leaves_ext(zkm_ctx* c, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests) {
     if (arity % 4 || 2 * arity <= 4) throw std::runtime_error("merkle_leaves_ext: unsupported arity");
     zkm_prof_scope ps(c, "merkle_leaves_ext");
-    if (nleaves <= 4096)   // small layers: one hash per 16-lane row
-        hipLaunchKernelGGL(k_merkle_leaves_ext_wide, dim3((nleaves * 16 + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
+    if (nleaves <= 16384)   // small layers: one hash per quad of lanes
+        hipLaunchKernelGGL(k_merkle_leaves_ext_quad, dim3((nleaves * 4 + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
     else
         hipLaunchKernelGGL(k_merkle_leaves_ext, dim3((nleaves + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
     ZKM_HIP_CHECK(hipGetLastError());
@@ -341,12 +387,12 @@ size_t zkm_merkle_layout(unsigned log_leaves, unsigned cap_height, std::vector<s
 }
 
 // All digest levels above the leaves, up to the cap: fused launches (k_merkle_fused: <= 3 levels, one hash per lane, while the first
-// level of the launch has >= 2^15 nodes; k_merkle_fused_wide: <= 6 levels, 16 lanes per hash, below that).  A 2^22-leaf tree with a
+// level of the launch has >= 2^15 nodes; k_merkle_fused_quad: <= 7 levels, four lanes per hash, below that).  A 2^22-leaf tree with a
 // 16-digest cap (18 levels) is 3 + 2 launches instead of 18.  (Measured and dropped, profiles/r03_merkle_inner_levels.txt: a lane
 // reducing a 16-node subtree by itself -- no barrier, 15 back-to-back permutations -- leaves 4096 waves for a 2^22-leaf tree, four per
-// SIMD, and the permutation needs five to saturate the issue port: 2.65 G permutations/s against 2.7 here and 3.33 in the leaf kernel.)  The 16-lane form takes a quarter of the latency of a permutation but
-// 7.5x its issue slots (1.4k instead of 190 wave instructions per hash), so it is kept to the levels where a launch is nothing but
-// latency: with several contexts proving side by side the slots it would waste on 2^13 .. 2^16-node levels belong to the others.
+// SIMD, and the permutation needs five to saturate the issue port: 2.65 G permutations/s against 2.7 here and 3.33 in the leaf kernel.)
+// The four-lane form takes ~40 % of the latency of a permutation at 1.7x its issue slots (330 instead of 190 wave instructions per
+// hash), so it is kept to the levels where a launch is mostly latency.
 void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves,
                             unsigned cap_height) {
     const unsigned top = log_leaves - cap_height;
@@ -363,13 +409,13 @@ void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>
             hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(((size_t)1 << log_p1) / 256)), dim3(256), 0, c->stream, a);
             l += a.levels;
         } else {
-            merkle_fused_wide_args a{};
+            merkle_fused_quad_args a{};
             a.children = digests + level_off[l];
-            unsigned J = rem < 6 ? rem : 6;
+            unsigned J = rem < 7 ? rem : 7;
             if (J > log_p1 + 1) J = log_p1 + 1;           // (a subtree cannot have more children than the level)
             a.J = J;
             for (unsigned k = 0; k < J; k++) a.parents[k] = digests + level_off[l + 1 + k];
-            hipLaunchKernelGGL(k_merkle_fused_wide, dim3((unsigned)(((size_t)2 << log_p1) >> J)), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL(k_merkle_fused_quad, dim3((unsigned)(((size_t)2 << log_p1) >> J)), dim3(256), 0, c->stream, a);
             l += J;
         }
         ZKM_HIP_CHECK(hipGetLastError());
