@@ -285,6 +285,17 @@ class Oracle:
                                                _ptr(np.ascontiguousarray(nv, dtype=np.uint64)), int(is_first), int(is_last), _ptr(out), out.size)
         return out[:n]
 
+    def constraint_evals(self, table_id, rows, log_witness, rate_bits, alpha):
+        """stark_testing.rs:21-70: constraint values of `table_id` on the low-degree extension `rows` (ncols x size, natural order)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        size = (1 << log_witness) << rate_bits
+        assert rows.ndim == 2 and rows.shape[1] == size
+        out = np.zeros(size, dtype=np.uint64)
+        self.lib.zko_constraint_evals.restype = None
+        self.lib.zko_constraint_evals.argtypes = [C.c_int, u64p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint64, u64p]
+        self.lib.zko_constraint_evals(table_id, _ptr(rows), rows.shape[0], log_witness, rate_bits, int(alpha), _ptr(out))
+        return out
+
     def poseidon_eval_row(self, row, alphas):
         row = np.ascontiguousarray(row, dtype=np.uint64)
         al = np.ascontiguousarray(alphas, dtype=np.uint64)

@@ -243,6 +243,37 @@ long zko_debug_row_constraints(int table_id, const uint64_t* lv, const uint64_t*
     return (long)k.nrec;
 }
 
+/* The reference's low-degree test of a table's constraints (prover/src/stark_testing.rs:21-70, test_stark_low_degree), evaluation half:
+ * rows = ncols x size evaluations (column-major) of random polynomials of degree < witness_size on the subgroup of order
+ * size = witness_size << rate_bits, natural order; out[i] = the alpha-accumulated constraint value at point i with the frame
+ * (row i, row i + 2^rate_bits), z_last = w_size^i - w_witness^-1 and the two Lagrange selectors lde'd the same way (:29-52). */
+void zko_constraint_evals(int table_id, const uint64_t* rows, size_t ncols, unsigned log_witness, unsigned rate_bits, uint64_t alpha,
+                          uint64_t* out) {
+    const unsigned log_size = log_witness + rate_bits;
+    const size_t size = (size_t)1 << log_size, w = (size_t)1 << log_witness;
+    gl_t* lf = (gl_t*)calloc(2 * size, sizeof(gl_t));
+    gl_t* ll = lf + size;
+    lf[0] = 1; ll[w - 1] = 1;                                      /* PolynomialValues::selector(WITNESS_SIZE, i) */
+    zko_ntt(lf, 1, log_witness, 1, 0); zko_ntt(ll, 1, log_witness, 1, 0);
+    zko_ntt(lf, 1, log_size, 0, 0); zko_ntt(ll, 1, log_size, 0, 0); /* .lde(rate_bits): zero-padded coefficients, plain subgroup */
+    const gl_t last = gl_inv(gl_root_of_unity(log_witness)), ws = gl_root_of_unity(log_size);
+    gl_t* lv = (gl_t*)malloc(sizeof(gl_t) * 2 * ncols);
+    gl_t* nv = lv + ncols;
+    gl_t x = 1;
+    for (size_t i = 0; i < size; i++) {
+        const size_t in = (i + ((size_t)1 << rate_bits)) % size;
+        for (size_t c = 0; c < ncols; c++) { lv[c] = rows[c * size + i]; nv[c] = rows[c * size + in]; }
+        b_consumer k;
+        memset(&k, 0, sizeof k);
+        k.nalphas = 1; k.alphas[0] = alpha;
+        k.z_last = gl_sub(x, last); k.l_first = lf[i]; k.l_last = ll[i];
+        b_eval_table(table_id, lv, nv, &k);
+        out[i] = gl_canon(k.acc[0]);
+        x = gl_mul(x, ws);
+    }
+    free(lv); free(lf);
+}
+
 /* ------------------------------------------------------------------ config */
 void zko_standard_config(zko_stark_config* c) {
     c->rate_bits = 2; c->cap_height = 4; c->pow_bits = 16; c->num_challenges = 2;

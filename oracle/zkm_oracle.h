@@ -183,6 +183,10 @@ void zko_quotient_poseidon(const zko_batch* trace, const zko_batch* aux, const u
 long zko_debug_constraints(int table_id, const uint64_t* trace, size_t W, unsigned log_n, long* bad_row, long* bad_index);
 long zko_debug_row_constraints(int table_id, const uint64_t* lv, const uint64_t* nv, int is_first, int is_last, uint64_t* out, size_t cap);
 void zko_poseidon_eval_row(const uint64_t* local, const uint64_t* alphas, size_t nalphas, uint64_t* acc_out);
+/* stark_testing.rs:21-70 (test_stark_low_degree): alpha-accumulated constraint values of a table on a low-degree extension of random
+ * witness polynomials (rows: ncols x (2^log_witness << rate_bits), column-major, natural order, plain subgroup) */
+void zko_constraint_evals(int table_id, const uint64_t* rows, size_t ncols, unsigned log_witness, unsigned rate_bits, uint64_t alpha,
+                          uint64_t* out);
 
 #ifdef __cplusplus
 }

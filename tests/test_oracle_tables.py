@@ -9,6 +9,7 @@ from . import logic_fixtures
 from .sponge_fixtures import ops_for_rows
 
 EMPTY = np.zeros(0, dtype=np.uint64)
+P = 0xFFFFFFFF00000001
 
 
 def test_logic_trace_ops(oracle):
@@ -344,3 +345,28 @@ def test_sha_extend_reference_vector(oracle):
     # and against the reference's W: w[16] = extend(w[1], w[14], w[0], w[9])
     inp = np.array([REF_SHA_W[1], REF_SHA_W[14], REF_SHA_W[0], REF_SHA_W[9]], dtype="<u4").view(np.uint8)
     assert _le4(oracle.sha_extend_trace(inp, [0], 2).reshape(78, 4), 0, 0) == REF_SHA_W[16] == 34013193
+
+
+# ---- the reference's per-table low-degree test (every *_stark.rs `test_stark_degree` -> stark_testing.rs:21-70)
+@pytest.mark.parametrize("table_id", list(range(12)))
+def test_stark_degree(oracle, table_id):
+    """Random witness polynomials of degree < 32, extended by log2_ceil(constraint_degree + 1) = 2 bits on the plain subgroup; the
+    alpha-combined constraint polynomial must have degree <= 32 * 3 - 1 (constraint_degree() is 3 for every table: stark.rs /
+    each *_stark.rs).  A constraint transcribed with one factor too many (in the oracle or, through the parity tests, in
+    constraints_dev.h) shows up here as a non-zero top coefficient; the witness satisfies nothing, so nothing cancels by accident."""
+    from zkm_amd import tables as T
+    W, log_w, rate_bits, degree = T.WIDTH[table_id], 5, 2, 3
+    size = (1 << log_w) << rate_bits
+    rng = np.random.default_rng(1000 + table_id)
+    coeffs = np.zeros((W, size), dtype=np.uint64)
+    coeffs[:, :1 << log_w] = rng.integers(0, P, size=(W, 1 << log_w), dtype=np.uint64)   # random_low_degree_matrix (:141-149)
+    rows = oracle.ntt(coeffs, log_w + rate_bits).reshape(W, size)
+    alpha = int(rng.integers(1, P, dtype=np.uint64))
+    evals = oracle.constraint_evals(table_id, rows, log_w, rate_bits, alpha)
+    assert evals.any(), "a random witness must violate the constraints"
+    poly = oracle.ntt(evals, log_w + rate_bits, inverse=True)
+    nz = np.nonzero(poly)[0]
+    assert nz.max() <= (1 << log_w) * degree - 1, "constraint polynomial of table %d has degree %d" % (table_id, nz.max())
+    # ... and the evaluation is not vacuous: products of two columns (degree 2 * 31) occur in every table; the sponge tables stop at
+    # 2 * 31 + 1 (quadratic transition constraints times z_last), the others have cubic terms
+    assert nz.max() >= 2 * ((1 << log_w) - 1)
