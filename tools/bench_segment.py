@@ -101,10 +101,22 @@ def concurrent_segment_rate(device, log_cycles, nctx, reps=6):
     return {"contexts": nctx, "segments_per_context": reps, "segments_per_s": nctx * reps / wall, "ms_per_segment_amortised": wall * 1e3 / (nctx * reps)}
 
 
+def multi_process_rate(procs, nctx, reps=8):
+    """The same with the contexts spread over `procs` host processes (tools/bench_segment_procs.py): every process has its own HIP
+    runtime, so launches of different processes do not queue behind one another on the host."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_segment_procs.py"), str(procs), str(nctx), str(reps)],
+                       capture_output=True, text=True, timeout=300)
+    if r.returncode != 0:
+        raise RuntimeError("bench_segment_procs failed: " + r.stderr[-400:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
 def small_segment_rate(ctx, device=0):
     out = segment_rate(ctx, 16)
     try:
         out["concurrent"] = [concurrent_segment_rate(device, 16, k) for k in (2, 4, 8)]
+        out["concurrent_processes"] = [multi_process_rate(p, k) for p, k in ((2, 4), (4, 2))]
     except Exception as e:  # the single-context figure stands on its own
         out["concurrent_error"] = str(e)
     return out
@@ -118,4 +130,5 @@ if __name__ == "__main__":
     out["memory_live_cached"] = c.memory()
     if lc == 16 and "single" not in sys.argv[2:]:
         out["concurrent"] = [concurrent_segment_rate(0, 16, k) for k in (2, 4, 8)]
+        out["concurrent_processes"] = [multi_process_rate(p, k) for p, k in ((2, 4), (4, 2))]
     print(json.dumps(out, indent=1))

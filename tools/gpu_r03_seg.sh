@@ -10,5 +10,5 @@ python - <<P
 import json
 for f in ("seg16", "seg20"):
     s = json.load(open("$O/%s.json" % f))
-    print(f, {k: round(s[k], 2) for k in ("ms_per_segment", "kernel_ms_per_segment", "launches_per_segment")}, s["stage_ms"], s["kernel_ms"], s.get("launches"), [(c["contexts"], round(c["segments_per_s"], 1)) for c in s.get("concurrent", [])])
+    print(f, {k: round(s[k], 2) for k in ("ms_per_segment", "kernel_ms_per_segment", "launches_per_segment")}, s["stage_ms"], s["kernel_ms"], s.get("launches"), [(c["contexts"], round(c["segments_per_s"], 1)) for c in s.get("concurrent", [])], [(c["processes"], c["contexts_per_process"], round(c["segments_per_s"], 1)) for c in s.get("concurrent_processes", [])])
 P

@@ -626,18 +626,26 @@ __global__ __launch_bounds__(256) void k_fri_fold(const gl_t* __restrict__ c0, c
 }
 
 // ------------------------------------------------------------------ K14: proof of work
-// Smallest candidate w such that Poseidon(state with w written at `pos`)[7] has >= pow_bits leading zeros.
+// Smallest candidate w such that Poseidon(state with w written at `pos`)[7] has >= pow_bits leading zeros.  One launch: thread t tries
+// base + t, base + t + stride, ... below `limit` and stops as soon as a smaller hit is known (device-scope atomic on `best`), so a
+// launch costs about one permutation's latency per 2^pow_bits / stride-th of the expected number of trials -- no host round trip
+// between the rounds, no candidates tried beyond the round of the first hit.
 struct pow_state { uint64_t s[12]; };
-__global__ __launch_bounds__(256) void k_pow_search(pow_state st, unsigned pos, unsigned pow_bits, uint64_t base, unsigned long long* best) {
-    uint64_t w = base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t s[12];
+__global__ __launch_bounds__(256) void k_pow_search(pow_state st, unsigned pos, unsigned pow_bits, uint64_t base, uint64_t limit,
+                                                    unsigned long long* best) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+    for (uint64_t w = base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < limit; w += stride) {
+        if (w > __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        uint64_t s[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = st.s[i];
+        for (int i = 0; i < 12; i++) s[i] = st.s[i];
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-        if ((unsigned)i == pos) s[i] = w;
-    poseidon_permute(s);
-    if ((s[7] >> (64 - pow_bits)) == 0) atomicMin(best, (unsigned long long)w);
+        for (int i = 0; i < 8; i++)
+            if ((unsigned)i == pos) s[i] = w;
+        poseidon_permute(s);
+        if ((s[7] >> (64 - pow_bits)) == 0) atomicMin(best, (unsigned long long)w);
+    }
 }
 
 // ------------------------------------------------------------------ query gather
@@ -827,15 +835,14 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
             unsigned long long* d_best = (unsigned long long*)c->alloc(8);
             scratch.push_back(d_best);
             unsigned long long best = ~0ULL;
-            // candidates per launch: 4 x the expected number of trials (a hit in the first launch with probability 1 - e^-4), then 2^20
-            const unsigned first_bits = cfg->pow_bits + 2 < 8 ? 8 : (cfg->pow_bits + 2 > 20 ? 20 : cfg->pow_bits + 2);
-            uint64_t span = (uint64_t)1 << first_bits;
-            for (uint64_t base = 0; best == ~0ULL; base += span, span = (uint64_t)1 << 20) {
+            // 2^16 candidates per round (one wave per SIMD), up to 2^6 rounds per launch (a launch without a hit: probability e^-64 at 16 bits)
+            const uint64_t stride = (uint64_t)1 << 16, span = stride << 6;
+            for (uint64_t base = 0; best == ~0ULL; base += span) {
                 if (base > ((uint64_t)1 << 40)) throw std::runtime_error("Proof of work failed. This is highly unlikely!");
                 ZKM_HIP_CHECK(hipMemsetAsync(d_best, 0xff, 8, c->stream));
                 {
                     zkm_prof_scope ps(c, "fri_pow_search");
-                    hipLaunchKernelGGL(k_pow_search, dim3(span / 256), dim3(256), 0, c->stream, st, ch->n_in, cfg->pow_bits, base, d_best);
+                    hipLaunchKernelGGL(k_pow_search, dim3(stride / 256), dim3(256), 0, c->stream, st, ch->n_in, cfg->pow_bits, base, base + span, d_best);
                     ZKM_HIP_CHECK(hipGetLastError());
                 }
                 ZKM_HIP_CHECK(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c->stream));
