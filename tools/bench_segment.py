@@ -105,8 +105,9 @@ def multi_process_rate(procs, nctx, reps=8):
     """The same with the contexts spread over `procs` host processes (tools/bench_segment_procs.py): every process has its own HIP
     runtime, so launches of different processes do not queue behind one another on the host."""
     import subprocess
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=str(max(2, 16 // procs)))   # ~16 hardware queues on the GPU in total (csrc/core.hip)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_segment_procs.py"), str(procs), str(nctx), str(reps)],
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=300, env=env)
     if r.returncode != 0:
         raise RuntimeError("bench_segment_procs failed: " + r.stderr[-400:])
     return json.loads(r.stdout.strip().splitlines()[-1])

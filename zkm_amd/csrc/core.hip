@@ -117,6 +117,13 @@ const zkm_table_lookup* zkm_table_lookups(int table_id, size_t* n) {
     return nullptr;
 }
 
+// The HIP runtime spreads the streams of a process over GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share one queue
+// run their kernels one after the other.  A process proving small segments with k contexts has k x (1 + ZKM_COMMIT_LANES) streams whose
+// kernels are short and meant to overlap: with 8 contexts, 43 segments/s at 4 queues, 50 at 8, 57 at 16, 47 at 32
+// (profiles/r03_hw_queues.txt; the 2^20-row proofs do not care).  The variable is read when the runtime initialises, i.e. at the first
+// HIP call of the process: set it when this library is loaded, unless the operator has chosen a value.
+__attribute__((constructor)) static void zkm_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 extern "C" {
 
 const char* zkm_version(void) { return "zkm-hip 0.1 (gfx950)"; }
