@@ -81,6 +81,37 @@ uint64_t* zkm_ctx::staging(size_t words) {
     }
     return h_staging;
 }
+void zkm_ctx::download(std::initializer_list<xfer> xs) {
+    if (!h_xfer) ZKM_HIP_CHECK(hipHostMalloc((void**)&h_xfer, XFER_DOWN + XFER_UP));
+    size_t off = 0;
+    for (const xfer& x : xs) {
+        if (!x.bytes) continue;
+        const bool small = off + x.bytes <= XFER_DOWN;
+        ZKM_HIP_CHECK(hipMemcpyAsync(small ? (void*)(h_xfer + off) : x.dst, x.src, x.bytes, hipMemcpyDeviceToHost, stream));
+        if (small) off += (x.bytes + 63) & ~(size_t)63;
+    }
+    sync();
+    off = 0;
+    for (const xfer& x : xs) {
+        if (!x.bytes || off + x.bytes > XFER_DOWN) continue;
+        memcpy(x.dst, h_xfer + off, x.bytes);
+        off += (x.bytes + 63) & ~(size_t)63;
+    }
+}
+void zkm_ctx::upload(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    if (bytes > XFER_UP / 4) {   // large: straight from the caller's memory, and waited for (the runtime may pin `src` and copy later)
+        ZKM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        sync();
+        return;
+    }
+    if (!h_xfer) ZKM_HIP_CHECK(hipHostMalloc((void**)&h_xfer, XFER_DOWN + XFER_UP));
+    if (up_off + bytes > XFER_UP) sync();                        // the ring is full: wait for the uploads in flight (sync() rewinds it)
+    char* slot = h_xfer + XFER_DOWN + up_off;
+    memcpy(slot, src, bytes);
+    ZKM_HIP_CHECK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, stream));
+    up_off += (bytes + 63) & ~(size_t)63;
+}
 hipEvent_t zkm_ctx::get_event() {
     if (!event_pool.empty()) {
         hipEvent_t e = event_pool.back();
@@ -118,7 +149,7 @@ const zkm_table_lookup* zkm_table_lookups(int table_id, size_t* n) {
 }
 
 // The HIP runtime spreads the streams of a process over GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share one queue
-// run their kernels one after the other.  A process proving small segments with k contexts has k x (1 + ZKM_COMMIT_LANES) streams whose
+// run their kernels one after the other.  A process proving small segments with k contexts has k x ZKM_COMMIT_LANES streams (+ copy streams) whose
 // kernels are short and meant to overlap: with 8 contexts, 43 segments/s at 4 queues, 50 at 8, 57 at 16, 47 at 32
 // (profiles/r03_hw_queues.txt; the 2^20-row proofs do not care).  The variable is read when the runtime initialises, i.e. at the first
 // HIP call of the process: set it when this library is loaded, unless the operator has chosen a value.
@@ -157,6 +188,7 @@ void zkm_ctx_destroy(zkm_ctx* c) {
     for (auto& r : c->prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->h_staging) (void)hipHostFree(c->h_staging);
+    if (c->h_xfer) (void)hipHostFree(c->h_xfer);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -65,8 +65,7 @@ void ctl_dev_owner::upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z
     if (nids) memcpy(&h[o_ids], colset_ids, nids * 4);
     blob = c->alloc(total);
     h_zs.assign(zs, zs + nzs);
-    ZKM_HIP_CHECK(hipMemcpyAsync(blob, h.data(), total, hipMemcpyHostToDevice, c->stream));
-    c->sync();
+    c->upload(blob, h.data(), total);   // (staged through the context's pinned ring or by the runtime: `h` may go)
     char* b = (char*)blob;
     d.columns = (const zkm_column*)(b + o_cols);
     d.term_coeff = (const uint64_t*)(b + o_coeff);
@@ -258,8 +257,7 @@ void zkm_ctl_data_device(zkm_ctx* c, const ctl_dev_owner& own, const gl_t* d_tra
         suffix_sum(c, d_hsum_all, n, n, nzs, d_aux + (size_t)own.d.total_helpers * n, n);
     }
     int bad = 0;
-    ZKM_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    c->sync();
+    c->download(&bad, d_bad, sizeof(int));
     c->release(d_hsum_all);
     c->release(d_bad);
     if (bad) throw std::runtime_error("Non-binary filter?");
@@ -381,8 +379,7 @@ static void lookup_helper_columns_device(zkm_ctx* c, const zkm_ctl_table* table,
         hipLaunchKernelGGL(k_prefix_from_suffix, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_hsum, n, d_out + nh * n);
         ZKM_HIP_CHECK(hipGetLastError());
         int bad = 0;
-        ZKM_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        c->sync();
+        c->download(&bad, d_bad, sizeof(int));
         for (void* p : tmp) c->release(p);
         tmp.clear();
         if (bad) throw std::runtime_error("Non-binary filter?");

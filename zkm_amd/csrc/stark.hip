@@ -274,7 +274,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     gl_t w_n = gl_root_of_unity(log_n), last = gl_inv(w_n);
     gl_t n_inv = gl_inv((gl_t)(((uint64_t)1 << log_n) % GL_P));
     gl_t* d_alphas = (gl_t*)c->alloc(4 * sizeof(gl_t));
-    ZKM_HIP_CHECK(hipMemcpyAsync(d_alphas, alphas_host, nalphas * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+    c->upload(d_alphas, alphas_host, nalphas * sizeof(gl_t));
     gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
     {
         static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory", "quotient_poseidon_sponge", "quotient_sha_extend", "quotient_sha_extend_sponge", "quotient_sha_compress",
@@ -347,7 +347,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
         } else {
             ctl_chunk* d_plan = (ctl_chunk*)c->alloc(plan.size() * sizeof(ctl_chunk));
             gl_t* d_tmp = (gl_t*)c->alloc(plan.size() * nalphas * size * sizeof(gl_t));
-            ZKM_HIP_CHECK(hipMemcpyAsync(d_plan, plan.data(), plan.size() * sizeof(ctl_chunk), hipMemcpyHostToDevice, c->stream));
+            c->upload(d_plan, plan.data(), plan.size() * sizeof(ctl_chunk));
             dim3 grid2((unsigned)((size + 255) / 256), (unsigned)plan.size());
             if (nalphas == 1) {
                 hipLaunchKernelGGL((k_quotient_ctl_chunk<1>), grid2, block, 0, c->stream, trace->lde, aux->lde, lde_bits, ctl, d_plan, NL, d_alphas, wpow,
@@ -470,8 +470,7 @@ static std::vector<std::vector<open_vals>> eval_batches(zkm_ctx* c, const std::v
         ZKM_HIP_CHECK(hipGetLastError());
     }
     std::vector<gl_t> part(words);
-    ZKM_HIP_CHECK(hipMemcpyAsync(part.data(), d_part.p, words * sizeof(gl_t), hipMemcpyDeviceToHost, c->stream));
-    c->sync();
+    c->download(part.data(), d_part.p, words * sizeof(gl_t));
     // chunk ch contributes z^(exponent of its first position) * partial (natural order: z^(ch * chunk_len), i.e. Horner over the chunks)
     std::vector<gl2_t> f0(nchunks), f1(nchunks);
     for (size_t ch = 0; ch < nchunks; ch++) {
@@ -798,8 +797,7 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
             zkm_launch_merkle_leaves_ext(c, fl.values, fl.values + fl.len, (size_t)1 << fl.log_leaves, arity, fl.digests);
             zkm_merkle_build_inner(c, fl.digests, fl.level_off, fl.log_leaves, cfg->cap_height);
             uint64_t* capo = caps_out + l * C4;
-            ZKM_HIP_CHECK(hipMemcpyAsync(capo, fl.digests + fl.level_off[fl.log_leaves - cfg->cap_height], C4 * 8, hipMemcpyDeviceToHost, c->stream));
-            c->sync();
+            c->download(capo, fl.digests + fl.level_off[fl.log_leaves - cfg->cap_height], C4 * 8);
             zkm_challenger_observe(ch, capo, C4);
             gl2_t beta = challenger_get_ext(ch);
             size_t nout = clen >> cfg->arity_bits;
@@ -819,9 +817,7 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
         if (clen != F) throw std::runtime_error("internal: final polynomial length mismatch");
         {
             std::vector<gl_t> f(2 * clen);
-            ZKM_HIP_CHECK(hipMemcpyAsync(f.data(), d_coef0, clen * 8, hipMemcpyDeviceToHost, c->stream));
-            ZKM_HIP_CHECK(hipMemcpyAsync(f.data() + clen, d_coef1, clen * 8, hipMemcpyDeviceToHost, c->stream));
-            c->sync();
+            c->download({{f.data(), d_coef0, clen * 8}, {f.data() + clen, d_coef1, clen * 8}});
             uint64_t* fp = final_out;
             for (size_t i = 0; i < clen; i++) { fp[2 * i] = f[i]; fp[2 * i + 1] = f[clen + i]; }
             zkm_challenger_observe(ch, fp, 2 * clen);
@@ -845,8 +841,7 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
                     hipLaunchKernelGGL(k_pow_search, dim3(stride / 256), dim3(256), 0, c->stream, st, ch->n_in, cfg->pow_bits, base, base + span, d_best);
                     ZKM_HIP_CHECK(hipGetLastError());
                 }
-                ZKM_HIP_CHECK(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c->stream));
-                c->sync();
+                c->download(&best, d_best, 8);
             }
             uint64_t w = best;
             *pow_out = w;
@@ -861,7 +856,7 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
             for (size_t q = 0; q < nq; q++) xs[q] = zkm_challenger_get(ch) % N;
             uint64_t* d_xs = (uint64_t*)c->alloc(nq * 8);
             scratch.push_back(d_xs);
-            ZKM_HIP_CHECK(hipMemcpyAsync(d_xs, xs.data(), nq * 8, hipMemcpyHostToDevice, c->stream));
+            c->upload(d_xs, xs.data(), nq * 8);
             std::vector<gather_args> gav(1);
             gather_args& ga = gav[0];
             memset(&ga, 0, sizeof ga);
@@ -879,7 +874,7 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
             ga.nlayers = L; ga.arity_bits = cfg->arity_bits; ga.query_words = query_words;
             gather_args* d_ga = (gather_args*)c->alloc(sizeof(gather_args));
             scratch.push_back(d_ga);
-            ZKM_HIP_CHECK(hipMemcpyAsync(d_ga, &ga, sizeof ga, hipMemcpyHostToDevice, c->stream));
+            c->upload(d_ga, &ga, sizeof ga);
             gl_t* d_q = (gl_t*)c->alloc(nq * query_words * 8);
             scratch.push_back(d_q);
             {
@@ -887,8 +882,7 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
                 hipLaunchKernelGGL(k_gather_queries, dim3(nq), dim3(256), 0, c->stream, d_ga, d_xs, d_q);
                 ZKM_HIP_CHECK(hipGetLastError());
             }
-            ZKM_HIP_CHECK(hipMemcpyAsync(queries_out, d_q, nq * query_words * 8, hipMemcpyDeviceToHost, c->stream));
-            c->sync();
+            c->download(queries_out, d_q, nq * query_words * 8);
         }
 
     } catch (...) {
@@ -983,7 +977,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
                 if (!zkm_is_device_ptr(trace)) {
                     gl_t* d = (gl_t*)c->alloc(W * n * sizeof(gl_t));
                     scratch.push_back(d);
-                    ZKM_HIP_CHECK(hipMemcpyAsync(d, trace, W * n * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+                    c->upload(d, trace, W * n * sizeof(gl_t));
                     zkm_launch_canon(c, d, W * n);   // (host words may be any representative; the lookup kernels want canonical ones)
                     d_trace = d;
                 }
@@ -1071,7 +1065,7 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
         }
         gl_t* d_apow = (gl_t*)c->alloc(apow.size() * sizeof(gl_t));
         scratch.push_back(d_apow);
-        ZKM_HIP_CHECK(hipMemcpyAsync(d_apow, apow.data(), apow.size() * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+        c->upload(d_apow, apow.data(), apow.size() * sizeof(gl_t));
         gl_t* d_comp = (gl_t*)c->alloc(6 * n * sizeof(gl_t));
         scratch.push_back(d_comp);
         if (tb->coeff_s1 != abp->coeff_s1 || tb->coeff_s1 != qbp->coeff_s1) throw std::runtime_error("internal: coefficient layouts of the three oracles differ");
@@ -1229,7 +1223,7 @@ int zkm_fri_prove(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch* cons
         }
         gl_t* d_apow = (gl_t*)c->alloc(apow.size() * sizeof(gl_t));
         scratch.push_back(d_apow);
-        ZKM_HIP_CHECK(hipMemcpyAsync(d_apow, apow.data(), apow.size() * sizeof(gl_t), hipMemcpyHostToDevice, c->stream));
+        c->upload(d_apow, apow.data(), apow.size() * sizeof(gl_t));
         gl_t* d_comp = (gl_t*)c->alloc(2 * nbatches * n * sizeof(gl_t));
         scratch.push_back(d_comp);
         std::vector<const gl_t*> ptrs;
@@ -1240,7 +1234,7 @@ int zkm_fri_prove(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch* cons
         }
         const gl_t** d_ptrs = (const gl_t**)c->alloc(ptrs.size() * sizeof(gl_t*));
         scratch.push_back((void*)d_ptrs);
-        ZKM_HIP_CHECK(hipMemcpyAsync((void*)d_ptrs, ptrs.data(), ptrs.size() * sizeof(gl_t*), hipMemcpyHostToDevice, c->stream));
+        c->upload((void*)d_ptrs, ptrs.data(), ptrs.size() * sizeof(gl_t*));
         std::vector<fri_composite> comps;
         for (size_t b = 0; b < nbatches; b++) {
             zkm_prof_scope ps(c, "fri_combine");
@@ -1363,8 +1357,7 @@ int zkm_quotient(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_bat
         gl_t* d = dev ? out_coeffs : tmp.as<gl_t>();
         quotient_device(c, table_id, trace, aux, own, nullptr, alphas, nalphas, d);
         if (!dev) {
-            ZKM_HIP_CHECK(hipMemcpyAsync(out_coeffs, d, words * 8, hipMemcpyDeviceToHost, c->stream));
-            c->sync();
+            c->download(out_coeffs, d, words * 8);
         }
     } catch (const std::exception& e) {
         return fail(err, e.what());

@@ -9,6 +9,7 @@
 #include <tuple>
 #include <stdexcept>
 #include <string>
+#include <initializer_list>
 #include <vector>
 
 #include "../../include/zkm_hip.h"
@@ -72,13 +73,25 @@ struct zkm_ctx {
     void ensure_twiddles(unsigned log_n);
     const gl_t* pow_table(uint64_t shift, unsigned log_n);  // lo: 2^ceil(log_n/2) entries, then hi
     uint64_t* staging(size_t words);
+    // Small transfers of the transcript round trips (caps, opening partials, FRI final polynomial, proof-of-work witness, query rounds
+    // down; challenge powers, query indices, descriptors up) go through pinned memory: a copy from / to pageable memory is staged by the
+    // runtime inside the call (a blit into its own pinned buffer, a host copy, and both of them behind the runtime's locks).
+    struct xfer { void* dst; const void* src; size_t bytes; };
+    void download(std::initializer_list<xfer> xs);               // all device -> host, then ONE stream synchronisation
+    void download(void* dst, const void* src, size_t bytes) { download({xfer{dst, src, bytes}}); }
+    void upload(void* dst, const void* src, size_t bytes);       // host -> device on the stream; `src` may be reused on return
+    char* h_xfer = nullptr;                                      // [0, XFER_DOWN): downloads, [XFER_DOWN, XFER_DOWN + XFER_UP): upload ring
+    size_t up_off = 0;
+    static constexpr size_t XFER_DOWN = (size_t)1 << 20, XFER_UP = (size_t)1 << 18;
     hipEvent_t get_event();
     size_t prof_begin(const char* name);   // returns the record's index (scopes nest: a stage scope holds kernel scopes)
     void prof_end(size_t idx);
-    void sync() { ZKM_HIP_CHECK(hipStreamSynchronize(stream)); }
+    void sync() { ZKM_HIP_CHECK(hipStreamSynchronize(stream)); up_off = 0; }
 };
 
+#ifndef ZKM_COMMIT_LANES
 #define ZKM_COMMIT_LANES 4   // trace commitments in flight per context (the context itself + 3 lanes)
+#endif
 
 // RAII owner of one scratch block from the context's allocator (released on every exit path)
 struct zkm_scratch {
