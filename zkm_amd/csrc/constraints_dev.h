@@ -301,6 +301,139 @@ __device__ void eval_keccak_constraints(const gl_t* __restrict__ lv, size_t cs, 
 #undef NV
 }
 
+// The same constraints for SHORT Keccak tables (a 2^16-cycle segment has 2^11 rows: 4096 quotient points = 64 waves for 797 constraints
+// over 2431 columns, 2.9 ms of one wave per sixteenth SIMD): 25 threads per point.  Part p = 5x + y evaluates, in emission order, C'[x, z]
+// and the diff check for 13 (12) values of z, and the A, A'' and transition constraints of lane (x, y); part 0 also takes the three flag
+// constraints and the four A''[0, 0] / iota ones.  A part runs the same Horner recurrence acc = acc * alpha + c over the constraints it
+// owns and jumps over the others by multiplying with alpha^gap (apw[a * (KECCAK_NUM_CONSTRAINTS + 1) + e] = alpha_a^e): the 25 partial
+// values of a point add up to what eval_keccak_constraints leaves in acc -- the same polynomial in alpha, term by term, and field addition
+// is exact.
+#define KECCAK_NUM_CONSTRAINTS 797
+#define KECCAK_CONSTRAINT_PARTS 25
+template <int NA>
+__device__ void eval_keccak_constraints_part(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k, int part,
+                                             const gl_t* __restrict__ apw) {
+    using namespace kk;
+    const gl_t* __restrict__ nv = lv + dnext;
+#define LV(c) lv[(size_t)(c) * cs]
+#define NV(c) nv[(size_t)(c) * cs]
+    const int x = part / 5, y = part % 5, z0 = 13 * y, z1 = z0 + 13 < 64 ? z0 + 13 : 64;
+    int pos = 0;   // emission index of the next constraint
+    auto jump = [&](int to) {
+        const int gap = to - pos;
+        if (gap) {
+#pragma unroll
+            for (int a = 0; a < NA; a++) k.acc[a] = gl_mul(k.acc[a], apw[a * (KECCAK_NUM_CONSTRAINTS + 1) + gap]);
+        }
+        pos = to;
+    };
+    const gl_t final_step = LV(23);
+    const gl_t not_final = gl_sub(1, final_step);
+    gl_t rc0 = 0, rc1 = 0, rc3 = 0, rc7 = 0, rc15 = 0, rc31 = 0, rc63 = 0;
+    if (part == 0) {
+        k.constraint(gl_mul(final_step, gl_sub(final_step, 1)));
+        k.constraint(gl_mul(not_final, final_step));
+        gl_t sum_flags = 0;
+        constexpr const uint64_t (&RC)[24] = KECCAK_RC_DEV;
+#pragma unroll
+        for (int r = 0; r < 24; r++) {
+            gl_t f = LV(r);
+            sum_flags = gl_add(sum_flags, f);
+            if (RC[r] & 1) rc0 = gl_add(rc0, f);
+            if (RC[r] >> 1 & 1) rc1 = gl_add(rc1, f);
+            if (RC[r] >> 3 & 1) rc3 = gl_add(rc3, f);
+            if (RC[r] >> 7 & 1) rc7 = gl_add(rc7, f);
+            if (RC[r] >> 15 & 1) rc15 = gl_add(rc15, f);
+            if (RC[r] >> 31 & 1) rc31 = gl_add(rc31, f);
+            if (RC[r] >> 63 & 1) rc63 = gl_add(rc63, f);
+        }
+        k.constraint(gl_mul(gl_mul(sum_flags, not_final), gl_sub(NV(TIMESTAMP), LV(TIMESTAMP))));
+        pos = 3;
+    }
+    // C'[x, z], z0 <= z < z1: constraints 3 + 64 x + z
+    jump(3 + 64 * x + z0);
+#pragma unroll 1
+    for (int z = z0; z < z1; z++) {
+        gl_t v = xor_gen(LV(reg_c(x, z)), xor_gen(LV(reg_c(mod5(x + 4), z)), LV(reg_c(mod5(x + 1), (z + 63) & 63))));
+        k.constraint(gl_sub(LV(reg_cp(x, z)), v));
+    }
+    pos += z1 - z0;
+    // A[x, y] limbs: constraints 323 + 2 (5 x + y) + half
+    jump(323 + 2 * part);
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        gl_t acc = 0;
+#pragma unroll 2
+        for (int z = 32 * half + 31; z >= 32 * half; z--)
+            acc = gl_add(gl_add(acc, acc), xor_gen(LV(reg_ap(x, y, z)), xor_gen(LV(reg_c(x, z)), LV(reg_cp(x, z)))));
+        k.constraint(gl_sub(acc, LV(reg_a(x, y) + half)));
+    }
+    pos += 2;
+    // diff check: constraints 373 + 64 x + z
+    jump(373 + 64 * x + z0);
+#pragma unroll 1
+    for (int z = z0; z < z1; z++) {
+        gl_t sum = LV(reg_ap(x, 0, z));
+#pragma unroll
+        for (int i = 1; i < 5; i++) sum = gl_add(sum, LV(reg_ap(x, i, z)));
+        gl_t diff = gl_sub(sum, LV(reg_cp(x, z)));
+        k.constraint(gl_mul(gl_mul(diff, gl_sub(diff, 2)), gl_sub(diff, 4)));
+    }
+    pos += z1 - z0;
+    // A''[x, y]: constraints 693 + 2 (5 x + y) + half
+    jump(693 + 2 * part);
+    {
+        int x1 = mod5(x + 1), x2 = mod5(x + 2);
+        int a0 = (x + 3 * y) % 5, a1 = (x1 + 3 * y) % 5, a2 = (x2 + 3 * y) % 5;
+        int base0 = reg_ap(a0, x, 0), base1 = reg_ap(a1, x1, 0), base2 = reg_ap(a2, x2, 0);
+        int r0 = 64 - ROT[a0][x], r1 = 64 - ROT[a1][x1], r2 = 64 - ROT[a2][x2];
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            gl_t acc = 0;
+#pragma unroll 2
+            for (int z = 32 * half + 31; z >= 32 * half; z--) {
+                gl_t b0 = LV(base0 + ((z + r0) & 63)), b1 = LV(base1 + ((z + r1) & 63)), b2 = LV(base2 + ((z + r2) & 63));
+                acc = gl_add(gl_add(acc, acc), xor_gen(b0, gl_mul(gl_sub(1, b1), b2)));
+            }
+            k.constraint(gl_sub(acc, LV(reg_app(x, y) + half)));
+        }
+    }
+    pos += 2;
+    if (part == 0) {
+        // A''[0, 0] bit decomposition and the iota output: constraints 743 .. 746
+        jump(743);
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            gl_t acc = 0;
+#pragma unroll 4
+            for (int z = 32 * half + 31; z >= 32 * half; z--) acc = gl_add(gl_add(acc, acc), LV(APP00_BITS + z));
+            k.constraint(gl_sub(acc, LV(reg_app(0, 0) + half)));
+        }
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            gl_t acc = 0;
+#pragma unroll 1
+            for (int z = 32 * half + 31; z >= 32 * half; z--) {
+                gl_t rc = z == 0 ? rc0 : z == 1 ? rc1 : z == 3 ? rc3 : z == 7 ? rc7 : z == 15 ? rc15 : z == 31 ? rc31 : z == 63 ? rc63 : 0;
+                acc = gl_add(gl_add(acc, acc), xor_gen(LV(APP00_BITS + z), rc));
+            }
+            k.constraint(gl_sub(acc, LV(APPP00 + half)));
+        }
+        pos += 4;
+    }
+    // transitions: constraints 747 + 2 (5 x + y) + half
+    jump(747 + 2 * part);
+    {
+        const gl_t not_last_t = gl_mul(not_final, k.z_last);
+#pragma unroll
+        for (int half = 0; half < 2; half++) k.constraint(gl_mul(not_last_t, gl_sub(LV(reg_appp(x, y) + half), NV(reg_a(x, y) + half))));
+    }
+    pos += 2;
+    jump(KECCAK_NUM_CONSTRAINTS);
+#undef LV
+#undef NV
+}
+
 // PoseidonSpongeStark (poseidon_sponge/poseidon_sponge_stark.rs:383-478; columns poseidon_sponge/columns.rs:17-66)
 template <int NA>
 __device__ void eval_poseidon_sponge_constraints(const gl_t* __restrict__ lv, size_t cs, ptrdiff_t dnext, consumer_t<NA>& k) {

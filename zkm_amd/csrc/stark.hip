@@ -183,6 +183,29 @@ __global__ __launch_bounds__(256, (TABLE == ZKM_TABLE_CPU || TABLE == ZKM_TABLE_
     for (int a = 0; a < NA; a++) out[(size_t)a * size + q.i] = k.acc[a];
 }
 
+// Short Keccak tables: KECCAK_CONSTRAINT_PARTS threads per point (constraints_dev.h, eval_keccak_constraints_part); blockIdx.y = part.
+template <int NA>
+__global__ __launch_bounds__(256) void k_quotient_keccak_parts(const gl_t* __restrict__ trace, unsigned lde_bits, const gl_t* alphas,
+                                                               const gl_t* __restrict__ wpow, gl_t gn, gl_t last, gl_t w_n, gl_t n_inv,
+                                                               const gl_t* __restrict__ apw, gl_t* __restrict__ tmp /* [part][NA][size] */) {
+    size_t N = (size_t)1 << lde_bits;
+    size_t size = N >> 1;
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= size) return;
+    consumer_t<NA> k;
+    const quotient_point q = quotient_setup<NA>(j, lde_bits, alphas, wpow, gn, last, w_n, n_inv, k);
+    eval_keccak_constraints_part<NA>(trace + j, N, (ptrdiff_t)q.jn - (ptrdiff_t)j, k, (int)blockIdx.y, apw);
+#pragma unroll
+    for (int a = 0; a < NA; a++) tmp[((size_t)blockIdx.y * NA + a) * size + q.i] = k.acc[a];
+}
+__global__ __launch_bounds__(256) void k_sum_parts(const gl_t* __restrict__ tmp, unsigned nparts, size_t words, gl_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    gl_t acc = 0;
+    for (unsigned p = 0; p < nparts; p++) acc = gl_add(acc, tmp[(size_t)p * words + i]);
+    out[i] = acc;
+}
+
 template <int NA>
 __global__ __launch_bounds__(256) void k_quotient_ctl(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux, unsigned lde_bits, ctl_dev ctl,
                                                       uint32_t num_lookup_cols, const gl_t* alphas, const gl_t* __restrict__ wpow, gl_t gn,
@@ -284,6 +307,25 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
     hipLaunchKernelGGL((k_quotient<T, NA>), grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, lookups, d_alphas, wpow, gn, \
                        last, w_n, n_inv, d_vals)
+        if (table_id == ZKM_TABLE_KECCAK && size <= ((size_t)1 << 15)) {
+            // short table: 25 threads per point, then the sum of the parts (constraints_dev.h)
+            std::vector<gl_t> apw(nalphas * (KECCAK_NUM_CONSTRAINTS + 1));
+            for (size_t a = 0; a < nalphas; a++) {
+                gl_t p = 1;
+                for (size_t e = 0; e <= KECCAK_NUM_CONSTRAINTS; e++) { apw[a * (KECCAK_NUM_CONSTRAINTS + 1) + e] = p; p = gl_mul(p, gl_canon(alphas_host[a])); }
+            }
+            zkm_scratch d_apw(c, apw.size() * sizeof(gl_t)), d_tmp(c, (size_t)KECCAK_CONSTRAINT_PARTS * nalphas * size * sizeof(gl_t));
+            c->upload(d_apw.p, apw.data(), apw.size() * sizeof(gl_t));
+            dim3 gridp((unsigned)((size + 255) / 256), KECCAK_CONSTRAINT_PARTS);
+            if (nalphas == 1)
+                hipLaunchKernelGGL((k_quotient_keccak_parts<1>), gridp, block, 0, c->stream, trace->lde, lde_bits, d_alphas, wpow, gn, last, w_n, n_inv,
+                                   d_apw.as<gl_t>(), d_tmp.as<gl_t>());
+            else
+                hipLaunchKernelGGL((k_quotient_keccak_parts<2>), gridp, block, 0, c->stream, trace->lde, lde_bits, d_alphas, wpow, gn, last, w_n, n_inv,
+                                   d_apw.as<gl_t>(), d_tmp.as<gl_t>());
+            hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((nalphas * size + 255) / 256)), block, 0, c->stream, d_tmp.as<gl_t>(),
+                               (unsigned)KECCAK_CONSTRAINT_PARTS, nalphas * size, d_vals);
+        } else
         switch (table_id * 2 + (int)nalphas - 1) {
             case 0: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON, 1); break;
             case 1: ZKM_LAUNCH_QUOTIENT(ZKM_TABLE_POSEIDON, 2); break;
@@ -539,72 +581,109 @@ __global__ __launch_bounds__(256) void k_fri_combine(const gl_t* __restrict__ tc
     comp[5 * n + i] = z1;
 }
 
-// divide_by_linear as a hierarchical suffix scan with segments of 64, for ALL batches of the instance in one set of
+// Short, wide tables (Keccak: 2431 columns x 2^11 rows): one thread per coefficient index leaves the machine empty and walks thousands
+// of columns serially (1 ms for that table).  Here blockIdx.y takes a slice of the W + A + Q polynomials and writes its partial sums
+// (trace + aux part, quotient part, CTL part) to part[slice][6][n]; k_fri_combine_sum adds the slices.  Field addition is exact, so the
+// result is the same words as k_fri_combine's.
+__global__ __launch_bounds__(256) void k_fri_combine_slice(const gl_t* __restrict__ tc, size_t W, const gl_t* __restrict__ ac, size_t A,
+                                                           const gl_t* __restrict__ qc, size_t Q, size_t ctl_start,
+                                                           const gl_t* __restrict__ apow, size_t n, size_t per_slice,
+                                                           gl_t* __restrict__ part /* [slices][6][n] */) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t j0 = (size_t)blockIdx.y * per_slice, total = W + A + Q;
+    const size_t j1 = j0 + per_slice < total ? j0 + per_slice : total;
+    gl_t a0 = 0, a1 = 0, q0 = 0, q1 = 0, z0 = 0, z1 = 0;
+    for (size_t j = j0; j < j1; j++) {
+        if (j < W + A) {
+            const gl_t v = j < W ? tc[j * n + i] : ac[(j - W) * n + i];
+            a0 = gl_add(a0, gl_mul(v, apow[2 * j]));
+            a1 = gl_add(a1, gl_mul(v, apow[2 * j + 1]));
+            if (j >= W + ctl_start) {
+                const size_t k = j - W - ctl_start;
+                z0 = gl_add(z0, gl_mul(v, apow[2 * k]));
+                z1 = gl_add(z1, gl_mul(v, apow[2 * k + 1]));
+            }
+        } else {
+            const gl_t v = qc[(j - W - A) * n + i];
+            q0 = gl_add(q0, gl_mul(v, apow[2 * j]));
+            q1 = gl_add(q1, gl_mul(v, apow[2 * j + 1]));
+        }
+    }
+    gl_t* o = part + (size_t)blockIdx.y * 6 * n + i;
+    o[0] = a0; o[n] = a1; o[2 * n] = q0; o[3 * n] = q1; o[4 * n] = z0; o[5 * n] = z1;
+}
+__global__ __launch_bounds__(256) void k_fri_combine_sum(const gl_t* __restrict__ part, unsigned slices, size_t n, gl_t* __restrict__ comp) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gl_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (unsigned s = 0; s < slices; s++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = gl_add(t[k], part[((size_t)s * 6 + k) * n + i]);
+    comp[2 * n + i] = t[0];
+    comp[3 * n + i] = t[1];
+    comp[i] = gl_add(t[0], t[2]);
+    comp[n + i] = gl_add(t[1], t[3]);
+    comp[4 * n + i] = t[4];
+    comp[5 * n + i] = t[5];
+}
+
+// divide_by_linear as a hierarchical suffix scan with segments of FRI_SEG, for ALL batches of the instance in one set of
 // launches (blockIdx.y = batch; the STARK instance has three: zeta, g zeta, 1).  Per batch b: q_b = (comp_b(X) - comp_b(z_b)) / (X - z_b),
 // q_b[k - 1] = S_b[k] with S_b[k] = a_b[k] + z_b S_b[k + 1]; the final polynomial is sum_b w_b q_b, w_b = prod_{b' > b} shift_b'
 // (plonky2 accumulates final = final * alpha^(#polys of the batch) + quotient, batch by batch: the same sum, regrouped).
+// A thread walks ONE segment of ONE batch -- a chain of FRI_SEG dependent extension-field multiply-adds; the weighted sum over the
+// batches is a separate element-wise launch.  (Until round 3: segments of 64 and the bottom level walking all batches in one
+// thread, 192 dependent steps: 158 us per table in a 2^16-cycle segment, whatever its size.)
 #define FRI_MAX_BATCHES 8
+#define FRI_SEG 32
 struct seg_batches {
     uint32_t nb;
     const gl_t* a0[FRI_MAX_BATCHES];   // this level's arrays of every batch (level 0: the composite polynomials)
     const gl_t* a1[FRI_MAX_BATCHES];
-    gl2_t z[FRI_MAX_BATCHES];          // z_b^(64^level)
+    gl2_t z[FRI_MAX_BATCHES];          // z_b^(FRI_SEG^level)
     gl2_t w[FRI_MAX_BATCHES];          // weight of the batch in the final sum (bottom level)
 };
-// totals:  out_b[s] = sum_{k<64} a_b[64 s + k] z_b^k          (out: [batch][2][nseg])
+// totals:  out_b[s] = sum_{k<FRI_SEG} a_b[FRI_SEG s + k] z_b^k          (out: [batch][2][nseg])
 __global__ void k_seg_totals(seg_batches p, size_t m, gl_t* __restrict__ out) {
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + 63) / 64;
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + FRI_SEG - 1) / FRI_SEG;
     const unsigned b = blockIdx.y;
     if (s >= nseg) return;
     const gl_t *a0 = p.a0[b], *a1 = p.a1[b];
     const gl2_t z = p.z[b];
     gl2_t acc{0, 0};
-    const size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
-    for (size_t k = end; k-- > s * 64;) acc = gl2_add(gl2_mul(acc, z), gl2_t{a0[k], a1[k]});
+    const size_t end = (s + 1) * FRI_SEG < m ? (s + 1) * FRI_SEG : m;
+    for (size_t k = end; k-- > s * FRI_SEG;) acc = gl2_add(gl2_mul(acc, z), gl2_t{a0[k], a1[k]});
     out[(2 * b) * nseg + s] = acc.c0;
     out[(2 * b + 1) * nseg + s] = acc.c1;
 }
-// scan of an upper level:  S_b[k] = a_b[k] + z_b S_b[k+1] inside each segment, carry-in = upper_b[s+1] (0 past the end)
+// scan of a level:  S_b[k] = a_b[k] + z_b S_b[k+1] inside each segment, carry-in = upper_b[s+1] (0 past the end)
 // (upper: [batch][2][nupper] suffix values of the level above, or null at the top; out: [batch][2][m])
 __global__ void k_seg_scan(seg_batches p, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ out) {
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + 63) / 64;
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + FRI_SEG - 1) / FRI_SEG;
     const unsigned b = blockIdx.y;
     if (s >= nseg) return;
     const gl_t *a0 = p.a0[b], *a1 = p.a1[b];
     const gl2_t z = p.z[b];
     gl2_t acc{0, 0};
     if (upper && s + 1 < nupper) acc = gl2_t{upper[(2 * b) * nupper + s + 1], upper[(2 * b + 1) * nupper + s + 1]};
-    const size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
-    for (size_t k = end; k-- > s * 64;) {
+    const size_t end = (s + 1) * FRI_SEG < m ? (s + 1) * FRI_SEG : m;
+    for (size_t k = end; k-- > s * FRI_SEG;) {
         acc = gl2_add(gl2_mul(acc, z), gl2_t{a0[k], a1[k]});
         out[(2 * b) * m + k] = acc.c0;
         out[(2 * b + 1) * m + k] = acc.c1;
     }
 }
-// bottom level: fin[k - 1] = sum_b w_b S_b[k] (the dropped remainders are the S_b[0]), fin[m - 1] = 0
-__global__ void k_seg_scan_final(seg_batches p, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ f0,
-                                 gl_t* __restrict__ f1) {
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + 63) / 64;
-    if (s >= nseg) return;
-    gl2_t acc[FRI_MAX_BATCHES];                              // (fixed trip counts + a uniform guard: the accumulators stay in registers)
-#pragma unroll
-    for (unsigned b = 0; b < FRI_MAX_BATCHES; b++) {
-        acc[b] = gl2_t{0, 0};
-        if (b < p.nb && upper && s + 1 < nupper) acc[b] = gl2_t{upper[(2 * b) * nupper + s + 1], upper[(2 * b + 1) * nupper + s + 1]};
-    }
-    const size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
-    if (end == m) { f0[m - 1] = 0; f1[m - 1] = 0; }
-    for (size_t k = end; k-- > s * 64;) {
-        gl2_t f{0, 0};
-#pragma unroll
-        for (unsigned b = 0; b < FRI_MAX_BATCHES; b++) {
-            if (b < p.nb) {
-                acc[b] = gl2_add(gl2_mul(acc[b], p.z[b]), gl2_t{p.a0[b][k], p.a1[b][k]});
-                f = gl2_add(f, gl2_mul(acc[b], p.w[b]));
-            }
-        }
-        if (k > 0) { f0[k - 1] = f.c0; f1[k - 1] = f.c1; }
-    }
+// fin[k - 1] = sum_b w_b S_b[k] (the dropped remainders are the S_b[0]), fin[m - 1] = 0      (suf: [batch][2][m], bottom level)
+__global__ __launch_bounds__(256) void k_seg_combine(seg_batches p, size_t m, const gl_t* __restrict__ suf, gl_t* __restrict__ f0,
+                                                     gl_t* __restrict__ f1) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    gl2_t f{0, 0};
+    if (i + 1 < m)
+        for (unsigned b = 0; b < p.nb; b++) f = gl2_add(f, gl2_mul(gl2_t{suf[(2 * b) * m + i + 1], suf[(2 * b + 1) * m + i + 1]}, p.w[b]));
+    f0[i] = f.c0;
+    f1[i] = f.c1;
 }
 
 struct fri_composite;
@@ -713,9 +792,9 @@ static void divide_accumulate_all(zkm_ctx* c, const std::vector<fri_composite>& 
     const unsigned nb = (unsigned)comps.size();
     if (nb == 0 || nb > FRI_MAX_BATCHES) throw std::runtime_error("FRI: 1..8 opening batches");
     zkm_prof_scope ps(c, "fri_divide_linear");
-    // level sizes: n, ceil(n / 64), ... down to <= 64
+    // level sizes: n, ceil(n / FRI_SEG), ... down to <= FRI_SEG
     std::vector<size_t> m{n};
-    while (m.back() > 64) m.push_back((m.back() + 63) / 64);
+    while (m.back() > FRI_SEG) m.push_back((m.back() + FRI_SEG - 1) / FRI_SEG);
     const size_t L = m.size();
     std::vector<seg_batches> lv(L);
     std::vector<gl_t*> tot(L, nullptr), suf(L, nullptr);   // tot[l]: [nb][2][m[l]] totals feeding level l (l >= 1); suf[l]: suffix values of level l
@@ -735,22 +814,19 @@ static void divide_accumulate_all(zkm_ctx* c, const std::vector<fri_composite>& 
         for (unsigned b = 0; b < nb; b++) {
             lv[l].a0[b] = tot[l] + (2 * b) * m[l];
             lv[l].a1[b] = tot[l] + (2 * b + 1) * m[l];
-            lv[l].z[b] = gl2_pow(lv[l - 1].z[b], 64);
+            lv[l].z[b] = gl2_pow(lv[l - 1].z[b], FRI_SEG);
         }
     }
-    // top-down: suffix values of each level
+    // top-down: suffix values of each level, then the weighted sum of the bottom level's
     for (size_t l = L; l-- > 0;) {
-        const size_t nseg = (m[l] + 63) / 64;
+        const size_t nseg = (m[l] + FRI_SEG - 1) / FRI_SEG;
         const gl_t* upper = l + 1 < L ? suf[l + 1] : nullptr;
         const size_t nupper = l + 1 < L ? m[l + 1] : 0;
-        if (l == 0) {
-            hipLaunchKernelGGL(k_seg_scan_final, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, c->stream, lv[0], m[0], upper, nupper, f0, f1);
-        } else {
-            suf[l] = (gl_t*)c->alloc(2 * nb * m[l] * sizeof(gl_t));
-            tmp.push_back(suf[l]);
-            hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)((nseg + 63) / 64), nb), dim3(64), 0, c->stream, lv[l], m[l], upper, nupper, suf[l]);
-        }
+        suf[l] = (gl_t*)c->alloc(2 * nb * m[l] * sizeof(gl_t));
+        tmp.push_back(suf[l]);
+        hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)((nseg + 63) / 64), nb), dim3(64), 0, c->stream, lv[l], m[l], upper, nupper, suf[l]);
     }
+    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, lv[0], n, suf[0], f0, f1);
     ZKM_HIP_CHECK(hipGetLastError());
     // no host sync: released blocks are only reused by later work on this stream
     for (void* q : tmp) c->release(q);
@@ -1071,8 +1147,22 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
         if (tb->coeff_s1 != abp->coeff_s1 || tb->coeff_s1 != qbp->coeff_s1) throw std::runtime_error("internal: coefficient layouts of the three oracles differ");
         {
             zkm_prof_scope ps(c, "fri_combine");
-            hipLaunchKernelGGL(k_fri_combine, dim3((n + 255) / 256), dim3(256), 0, c->stream, tb->coeffs, W, abp->coeffs, A, qbp->coeffs, y.Q,
-                               total_helpers, d_apow, n, d_comp);
+            const size_t npoly = W + A + y.Q;
+            // slices of >= 32 polynomials while the launch stays below ~2^17 threads (two waves per SIMD)
+            size_t slices = npoly / 32 < 1 ? 1 : npoly / 32;
+            while (slices > 1 && slices * n > ((size_t)1 << 17)) slices >>= 1;
+            if (slices >= 4) {
+                const size_t per = (npoly + slices - 1) / slices;
+                slices = (npoly + per - 1) / per;
+                gl_t* d_part = (gl_t*)c->alloc(slices * 6 * n * sizeof(gl_t));
+                scratch.push_back(d_part);
+                hipLaunchKernelGGL(k_fri_combine_slice, dim3((n + 255) / 256, (unsigned)slices), dim3(256), 0, c->stream, tb->coeffs, W, abp->coeffs, A,
+                                   qbp->coeffs, y.Q, total_helpers, d_apow, n, per, d_part);
+                hipLaunchKernelGGL(k_fri_combine_sum, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_part, (unsigned)slices, n, d_comp);
+            } else {
+                hipLaunchKernelGGL(k_fri_combine, dim3((n + 255) / 256), dim3(256), 0, c->stream, tb->coeffs, W, abp->coeffs, A, qbp->coeffs, y.Q,
+                                   total_helpers, d_apow, n, d_comp);
+            }
             ZKM_HIP_CHECK(hipGetLastError());
         }
         if (tb->coeff_s1) {
