@@ -49,3 +49,10 @@ print("gap histogram (us bucket: count):", dict(sorted(hist.items())))
 print("longest gaps (us, at ms offset): before -> after")
 for g, a, b, off in sorted(gaps, key=lambda x: -x[0])[:14]:
     print("  %8.1f us at %6.2f ms  %s -> %s" % (g / 1e3, off / 1e6, a, b))
+tot_by = defaultdict(lambda: [0, 0])
+for s_, e_, n_ in seg:
+    tot_by[n_][0] += e_ - s_
+    tot_by[n_][1] += 1
+print("kernel time in the window (ms, launches, mean us):")
+for n_, (t_, k_) in sorted(tot_by.items(), key=lambda kv: -kv[1][0])[:30]:
+    print("  %7.3f ms %4d %8.1f us  %s" % (t_ / 1e6, k_, t_ / k_ / 1e3, n_))

@@ -81,8 +81,73 @@ uint64_t* zkm_ctx::staging(size_t words) {
     }
     return h_staging;
 }
+// Small downloads (a cap, opening partials, a proof-of-work witness: up to XFER_KERNEL bytes) by a one-workgroup kernel that writes the
+// words into pinned host memory and then a sequence number into a flag the host spins on: the transcript's round trips cost the GPU's
+// write latency over PCIe instead of a blit + completion signal + the runtime waking the waiting thread (~40 us per round trip, ~120
+// round trips in a twelve-table segment).
+struct down_args {
+    const uint32_t* src[4];
+    uint32_t* dst[4];
+    uint32_t words[4];   // 32-bit words
+    uint32_t n;
+};
+__global__ __launch_bounds__(1024) void k_download(down_args a, uint64_t* flag, uint64_t seq) {
+    for (uint32_t s = 0; s < a.n; s++)
+        for (uint32_t i = threadIdx.x; i < a.words[s]; i += 1024) a.dst[s][i] = a.src[s][i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void zkm_ctx::ensure_xfer() {
+    if (h_xfer) return;
+    ZKM_HIP_CHECK(hipHostMalloc((void**)&h_xfer, XFER_DOWN + XFER_UP + 64, hipHostMallocCoherent));
+    memset(h_xfer + XFER_DOWN + XFER_UP, 0, 64);
+}
 void zkm_ctx::download(std::initializer_list<xfer> xs) {
-    if (!h_xfer) ZKM_HIP_CHECK(hipHostMalloc((void**)&h_xfer, XFER_DOWN + XFER_UP));
+    ensure_xfer();
+    constexpr size_t XFER_KERNEL = (size_t)1 << 16;
+    size_t total = 0, nx = 0;
+    bool words_ok = true;
+    for (const xfer& x : xs) {
+        total += (x.bytes + 63) & ~(size_t)63;
+        nx += x.bytes != 0;
+        words_ok = words_ok && x.bytes % 4 == 0 && (uintptr_t)x.src % 4 == 0;
+    }
+    if (nx && nx <= 4 && total <= XFER_KERNEL && words_ok) {
+        down_args a{};
+        size_t off = 0;
+        for (const xfer& x : xs) {
+            if (!x.bytes) continue;
+            a.src[a.n] = (const uint32_t*)x.src;
+            a.dst[a.n] = (uint32_t*)(h_xfer + off);
+            a.words[a.n] = (uint32_t)(x.bytes / 4);
+            a.n++;
+            off += (x.bytes + 63) & ~(size_t)63;
+        }
+        uint64_t* flag = (uint64_t*)(h_xfer + XFER_DOWN + XFER_UP);
+        const uint64_t seq = ++down_seq;
+        hipLaunchKernelGGL(k_download, dim3(1), dim3(1024), 0, stream, a, flag, seq);
+        ZKM_HIP_CHECK(hipGetLastError());
+        for (uint64_t spins = 1;; spins++) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+            if (spins % 8192 == 0) {                              // every few tens of microseconds: has the stream failed (or finished unseen)?
+                hipError_t e = hipStreamQuery(stream);
+                if (e == hipSuccess) break;                       // (complete: the words are in host memory whatever the flag's cache line says)
+                if (e != hipErrorNotReady) ZKM_HIP_CHECK(e);
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        up_off = 0;                                               // everything queued before the kernel has completed, uploads included
+        off = 0;
+        for (const xfer& x : xs) {
+            if (!x.bytes) continue;
+            memcpy(x.dst, h_xfer + off, x.bytes);
+            off += (x.bytes + 63) & ~(size_t)63;
+        }
+        return;
+    }
     size_t off = 0;
     for (const xfer& x : xs) {
         if (!x.bytes) continue;
@@ -105,7 +170,7 @@ void zkm_ctx::upload(void* dst, const void* src, size_t bytes) {
         sync();
         return;
     }
-    if (!h_xfer) ZKM_HIP_CHECK(hipHostMalloc((void**)&h_xfer, XFER_DOWN + XFER_UP));
+    ensure_xfer();
     if (up_off + bytes > XFER_UP) sync();                        // the ring is full: wait for the uploads in flight (sync() rewinds it)
     char* slot = h_xfer + XFER_DOWN + up_off;
     memcpy(slot, src, bytes);

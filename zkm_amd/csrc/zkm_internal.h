@@ -80,7 +80,10 @@ struct zkm_ctx {
     void download(std::initializer_list<xfer> xs);               // all device -> host, then ONE stream synchronisation
     void download(void* dst, const void* src, size_t bytes) { download({xfer{dst, src, bytes}}); }
     void upload(void* dst, const void* src, size_t bytes);       // host -> device on the stream; `src` may be reused on return
-    char* h_xfer = nullptr;                                      // [0, XFER_DOWN): downloads, [XFER_DOWN, XFER_DOWN + XFER_UP): upload ring
+    char* h_xfer = nullptr;                                      // [0, XFER_DOWN): downloads, [XFER_DOWN, XFER_DOWN + XFER_UP): upload ring,
+                                                                 // then one cache line for the completion flag of k_download
+    uint64_t down_seq = 0;
+    void ensure_xfer();
     size_t up_off = 0;
     static constexpr size_t XFER_DOWN = (size_t)1 << 20, XFER_UP = (size_t)1 << 18;
     hipEvent_t get_event();
