@@ -69,12 +69,17 @@ __global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ 
 }
 
 __global__ void k_merkle_leaves_quad(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests);
+__global__ void k_merkle_leaves_wide(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests);
 static size_t quad_max_leaves();
+static size_t wide_max_leaves();
 
 void zkm_launch_merkle_leaves(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests) {
     // rows of <= 4 elements are copied, not hashed (hash_or_noop): profile them under their own name
     zkm_prof_scope ps(c, ncols <= 4 ? "merkle_leaves_copy" : "merkle_leaves");
-    if (ncols > 4 && nrows <= quad_max_leaves())
+    if (ncols > 4 && nrows <= wide_max_leaves())
+        // the shortest matrices: 16 lanes per leaf, the lowest latency per absorb step
+        hipLaunchKernelGGL(k_merkle_leaves_wide, dim3((nrows * 16 + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
+    else if (ncols > 4 && nrows <= quad_max_leaves())
         // short, wide matrices (Keccak: 2431 columns x a few thousand rows): one lane per leaf leaves the machine empty and pays one
         // permutation's full latency per 8 columns; four lanes per leaf cut that latency to a third and fill 4x the lanes
         hipLaunchKernelGGL(k_merkle_leaves_quad, dim3((nrows * 4 + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
@@ -204,6 +209,117 @@ __global__ __launch_bounds__(256) void k_merkle_fused(merkle_fused_args p) {
         // kernel needs every slot it can get (one permutation per lane is ~12k dependent-ish instructions).
         if (tid >= (width >> 1)) return;
     }
+}
+
+// ---- one permutation across 12 lanes of a 16-lane row (the smallest tree levels and matrices) ----
+// The top levels of every tree hold too few nodes to fill the machine, so a launch costs one permutation's LATENCY: ~40 us for the
+// one-lane-per-hash form on a wave alone on its SIMD (12k instructions), ~24 us for the four-lane form below (5.7k), ~13 us here
+// (3.2k).  A hash owns a 16-lane row of the wave (lanes 0..11 = the twelve state words): every round is constant add, x^7 (lane 0
+// only in the partial rounds), and the circulant MDS with the twelve rotated neighbours fetched by ds_bpermute -- the textbook rounds
+// (poseidon_stark.rs:65-95, 164-169, 239-251, 310-345).  800 wave instructions per hash (four-lane form 360, one lane 190): for
+// launches of <= 4096 hashes, where nothing else competes for the issue slots of the chain.  Bit-exact with poseidon_permute (the
+// fused partial rounds there are an algebraic regrouping).
+__device__ __forceinline__ uint64_t poseidon_permute_wide(uint64_t x, unsigned lane) {
+    const unsigned idx = lane & 15, base = lane & ~15u;
+    const bool active = idx < 12;
+    int src[12];
+#pragma unroll
+    for (int i = 1; i < 12; i++) src[i] = (int)(base + (idx + i) % 12);
+    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const uint32_t diag = idx == 0 ? 8u : 0u;
+    const gl_t* rcp = PC::ZKM_POSEIDON_RC + (active ? idx : 0);
+    x = gl_add_loose(x, rcp[0]);
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+        const bool full = r < 4 || r >= 26;
+        const uint64_t y = poseidon_sbox7(x);
+        x = (full || idx == 0) ? y : x;
+        const uint64_t k = r + 1 < 30 ? rcp[(r + 1) * 12] : 0;
+        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+        uint64_t al = (uint64_t)(uint32_t)k + (uint64_t)lo * (C[0] + diag), ah = (k >> 32) + (uint64_t)hi * (C[0] + diag);
+#pragma unroll
+        for (int i = 1; i < 12; i++) {
+            al += (uint64_t)(uint32_t)__shfl((int)lo, src[i]) * C[i];
+            ah += (uint64_t)(uint32_t)__shfl((int)hi, src[i]) * C[i];
+        }
+        x = poseidon_fold(al, ah);
+    }
+    return gl_canon(x);
+}
+
+// Small levels, fused: a workgroup (256 threads = 16 hash slots of 16 lanes) owns a subtree with 2^J children (J <= 6) and climbs
+// its J levels through LDS -- ceil(2^(J-k) / 16) rounds of wide permutations at level k -- instead of one launch per level: the top
+// of a tree is a chain of dependent permutations (one wide permutation ~10 us), and every launch boundary added its gap to it.
+struct merkle_fused_wide_args {
+    const gl_t* children;   // level l: nsub * 2^J digests
+    gl_t* parents[6];       // levels l + 1 .. l + J
+    uint32_t J;             // levels in this launch (1 .. 6)
+};
+
+__global__ __launch_bounds__(256) void k_merkle_fused_wide(merkle_fused_wide_args p) {
+    __shared__ uint64_t sh[2][64 * 4];                    // digests of the current level of this subtree (AoS, as in HBM)
+    const unsigned tid = threadIdx.x, lane = tid & 63, idx = lane & 15, slot = tid >> 4;
+    const unsigned C = 1u << p.J;
+    {
+        const gl_t* src = p.children + (size_t)blockIdx.x * C * 4;
+        for (unsigned w = tid; w < C * 4; w += 256) sh[0][w] = src[w];
+    }
+    __syncthreads();
+    for (unsigned lvl = 0; lvl < p.J; lvl++) {
+        const unsigned np = C >> (lvl + 1);               // parents of this level in the subtree
+        const uint64_t* in = sh[lvl & 1];
+        uint64_t* out = sh[(lvl + 1) & 1];
+        gl_t* g = p.parents[lvl] + (size_t)blockIdx.x * np * 4;
+        if ((slot & ~3u) >= np) return;                  // this wave has no node here or above: leave (the barrier only counts survivors)
+        for (unsigned h0 = 0; h0 < np; h0 += 16) {
+            // (a wave holds four slots; one with no live slot in this round skips it -- uniform over the wave)
+            if (h0 + (slot & ~3u) >= np) continue;
+            const unsigned h = h0 + slot;
+            const bool live = h < np;                     // uniform over the 16-lane row; every lane of the wave shuffles
+            uint64_t x = (live && idx < 8) ? in[8 * h + idx] : 0;
+            x = poseidon_permute_wide(x, lane);
+            if (live && idx < 4) {
+                out[4 * h + idx] = x;
+                g[4 * h + idx] = x;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Column-major leaves, one leaf per 16-lane row (see poseidon_permute_wide): lanes 0..7 of the row fetch the next eight columns of
+// their leaf (overwrite-mode absorb: a ragged tail overwrites only the words that exist), all 12 lanes permute.  Bit-exact with
+// k_merkle_leaves.  Used when the matrix has at most wide_max_leaves() rows.
+__global__ __launch_bounds__(256) void k_merkle_leaves_wide(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride,
+                                                            gl_t* __restrict__ digests) {
+    const unsigned lane = threadIdx.x & 63, idx = lane & 15;
+    const size_t leaf = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = leaf < nrows;  // uniform over the 16-lane row; every lane of the wave takes part in the shuffles
+    uint64_t x = 0;
+    for (size_t c = 0; c < ncols; c += 8) {
+        if (live && idx < 8 && c + idx < ncols) x = lde[(c + idx) * col_stride + leaf];
+        x = poseidon_permute_wide(x, lane);
+    }
+    if (live && idx < 4) digests[4 * leaf + idx] = x;
+}
+// Rows up to which a leaf gets a 16-lane row (k_merkle_leaves_wide).  One absorb step takes ~13 us in the 16-lane form while every SIMD
+// holds at most one such wave (4096 rows), ~21 us with two (8192), ~41 us with four (16384); the four-lane form takes over there.
+static size_t wide_max_leaves() { return 4096; }
+
+
+// FRI layer leaves, one hash per 16-lane row (small layers): word m of leaf k is component m & 1 of value k * arity + (m >> 1).
+__global__ __launch_bounds__(256) void k_merkle_leaves_ext_wide(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nleaves,
+                                                                unsigned arity, gl_t* __restrict__ digests) {
+    const unsigned lane = threadIdx.x & 63, idx = lane & 15;
+    const size_t k = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = k < nleaves;
+    const gl_t* col = (idx & 1) ? c1 : c0;
+    uint64_t x = 0;
+    for (unsigned m = 0; m < 2 * arity; m += 8) {
+        if (live && idx < 8) x = col[k * arity + ((m + idx) >> 1)];
+        x = poseidon_permute_wide(x, lane);
+    }
+    if (live && idx < 4) digests[4 * k + idx] = x;
 }
 
 // ---- one permutation across FOUR lanes (short matrices, small tree levels) ----
@@ -368,7 +484,9 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_ext_quad(const gl_t* __re
 void zkm_launch_merkle_leaves_ext(zkm_ctx* c, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests) {
     if (arity % 4 || 2 * arity <= 4) throw std::runtime_error("merkle_leaves_ext: unsupported arity");
     zkm_prof_scope ps(c, "merkle_leaves_ext");
-    if (nleaves <= 16384)   // small layers: one hash per quad of lanes
+    if (nleaves <= 4096)    // the smallest layers: one hash per 16-lane row
+        hipLaunchKernelGGL(k_merkle_leaves_ext_wide, dim3((nleaves * 16 + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
+    else if (nleaves <= 16384)   // small layers: one hash per quad of lanes
         hipLaunchKernelGGL(k_merkle_leaves_ext_quad, dim3((nleaves * 4 + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
     else
         hipLaunchKernelGGL(k_merkle_leaves_ext, dim3((nleaves + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
@@ -387,7 +505,8 @@ size_t zkm_merkle_layout(unsigned log_leaves, unsigned cap_height, std::vector<s
 }
 
 // All digest levels above the leaves, up to the cap: fused launches (k_merkle_fused: <= 3 levels, one hash per lane, while the first
-// level of the launch has >= 2^15 nodes; k_merkle_fused_quad: <= 7 levels, four lanes per hash, below that).  A 2^22-leaf tree with a
+// level of the launch has >= 2^15 nodes; k_merkle_fused_quad: four lanes per hash, the two levels with 2^14 and 2^13 parents;
+// k_merkle_fused_wide: <= 6 levels, 16 lanes per hash, from 2^12 parents on).  A 2^22-leaf tree with a
 // 16-digest cap (18 levels) is 3 + 2 launches instead of 18.  (Measured and dropped, profiles/r03_merkle_inner_levels.txt: a lane
 // reducing a 16-node subtree by itself -- no barrier, 15 back-to-back permutations -- leaves 4096 waves for a 2^22-leaf tree, four per
 // SIMD, and the permutation needs five to saturate the issue port: 2.65 G permutations/s against 2.7 here and 3.33 in the leaf kernel.)
@@ -408,11 +527,19 @@ void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>
             for (unsigned k = 0; k < a.levels; k++) a.parents[k] = digests + level_off[l + 1 + k];
             hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(((size_t)1 << log_p1) / 256)), dim3(256), 0, c->stream, a);
             l += a.levels;
+        } else if (log_p1 <= 12) {
+            merkle_fused_wide_args a{};
+            a.children = digests + level_off[l];
+            unsigned J = rem < 6 ? rem : 6;
+            if (J > log_p1 + 1) J = log_p1 + 1;           // (a subtree cannot have more children than the level)
+            a.J = J;
+            for (unsigned k = 0; k < J; k++) a.parents[k] = digests + level_off[l + 1 + k];
+            hipLaunchKernelGGL(k_merkle_fused_wide, dim3((unsigned)(((size_t)2 << log_p1) >> J)), dim3(256), 0, c->stream, a);
+            l += J;
         } else {
             merkle_fused_quad_args a{};
             a.children = digests + level_off[l];
-            unsigned J = rem < 7 ? rem : 7;
-            if (J > log_p1 + 1) J = log_p1 + 1;           // (a subtree cannot have more children than the level)
+            unsigned J = rem < log_p1 - 12 ? rem : log_p1 - 12;   // the levels with 2^14 and 2^13 parents
             a.J = J;
             for (unsigned k = 0; k < J; k++) a.parents[k] = digests + level_off[l + 1 + k];
             hipLaunchKernelGGL(k_merkle_fused_quad, dim3((unsigned)(((size_t)2 << log_p1) >> J)), dim3(256), 0, c->stream, a);

@@ -674,6 +674,32 @@ __global__ void k_seg_scan(seg_batches p, size_t m, const gl_t* __restrict__ upp
         out[(2 * b + 1) * m + k] = acc.c1;
     }
 }
+// bottom level of LONG polynomials (>= 2^21 coefficients: enough segments to fill the machine, and the suffix values of every batch
+// would be 6 n words written and read again): all batches in one thread, fin[k - 1] = sum_b w_b S_b[k] formed on the fly
+__global__ void k_seg_scan_final(seg_batches p, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ f0,
+                                 gl_t* __restrict__ f1) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + FRI_SEG - 1) / FRI_SEG;
+    if (s >= nseg) return;
+    gl2_t acc[FRI_MAX_BATCHES];                              // (fixed trip counts + a uniform guard: the accumulators stay in registers)
+#pragma unroll
+    for (unsigned b = 0; b < FRI_MAX_BATCHES; b++) {
+        acc[b] = gl2_t{0, 0};
+        if (b < p.nb && upper && s + 1 < nupper) acc[b] = gl2_t{upper[(2 * b) * nupper + s + 1], upper[(2 * b + 1) * nupper + s + 1]};
+    }
+    const size_t end = (s + 1) * FRI_SEG < m ? (s + 1) * FRI_SEG : m;
+    if (end == m) { f0[m - 1] = 0; f1[m - 1] = 0; }
+    for (size_t k = end; k-- > s * FRI_SEG;) {
+        gl2_t f{0, 0};
+#pragma unroll
+        for (unsigned b = 0; b < FRI_MAX_BATCHES; b++) {
+            if (b < p.nb) {
+                acc[b] = gl2_add(gl2_mul(acc[b], p.z[b]), gl2_t{p.a0[b][k], p.a1[b][k]});
+                f = gl2_add(f, gl2_mul(acc[b], p.w[b]));
+            }
+        }
+        if (k > 0) { f0[k - 1] = f.c0; f1[k - 1] = f.c1; }
+    }
+}
 // fin[k - 1] = sum_b w_b S_b[k] (the dropped remainders are the S_b[0]), fin[m - 1] = 0      (suf: [batch][2][m], bottom level)
 __global__ __launch_bounds__(256) void k_seg_combine(seg_batches p, size_t m, const gl_t* __restrict__ suf, gl_t* __restrict__ f0,
                                                      gl_t* __restrict__ f1) {
@@ -822,11 +848,15 @@ static void divide_accumulate_all(zkm_ctx* c, const std::vector<fri_composite>& 
         const size_t nseg = (m[l] + FRI_SEG - 1) / FRI_SEG;
         const gl_t* upper = l + 1 < L ? suf[l + 1] : nullptr;
         const size_t nupper = l + 1 < L ? m[l + 1] : 0;
+        if (l == 0 && n >= ((size_t)1 << 21)) {
+            hipLaunchKernelGGL(k_seg_scan_final, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, c->stream, lv[0], n, upper, nupper, f0, f1);
+            break;
+        }
         suf[l] = (gl_t*)c->alloc(2 * nb * m[l] * sizeof(gl_t));
         tmp.push_back(suf[l]);
         hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)((nseg + 63) / 64), nb), dim3(64), 0, c->stream, lv[l], m[l], upper, nupper, suf[l]);
+        if (l == 0) hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, lv[0], n, suf[0], f0, f1);
     }
-    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, lv[0], n, suf[0], f0, f1);
     ZKM_HIP_CHECK(hipGetLastError());
     // no host sync: released blocks are only reused by later work on this stream
     for (void* q : tmp) c->release(q);
