@@ -548,10 +548,8 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
     }
     zkm_merkle_build_inner(c, b->digests, b->level_off, b->lde_bits(), b->cap_height);
     size_t capw = (size_t)4 << b->cap_height;
-    uint64_t* st = c->staging(capw);
-    ZKM_HIP_CHECK(hipMemcpyAsync(st, b->digests + b->level_off[b->top()], capw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    c->sync();
-    b->cap.assign(st, st + capw);
+    b->cap.resize(capw);
+    c->download(b->cap.data(), b->digests + b->level_off[b->top()], capw * sizeof(uint64_t));
 }
 
 // out[i * ncols + col] = lde[col][bitrev((index_start + i) * step)]: lanes run along i, so reads of one column are scattered
