@@ -42,6 +42,13 @@ size_t zkm_ctx_resident_bytes(const zkm_ctx* ctx);
 /* Return every cached (not live) block to the device (the free lists are exact-size: a segment of many table shapes leaves one
  * cached block per distinct size behind). */
 void zkm_ctx_trim(zkm_ctx* ctx);
+/* Size thresholds at which the library switches between two kernels that produce the same words (every switch has a parity test on
+ * both sides, tests/test_gpu_prove.py::test_tuning_*).  Keys:
+ *   "ingest_chunk_cols"         columns per chunk of the pipelined host ingest (default 32; 0 = one monolithic upload)
+ *   "keccak_parts_max_points"   quotient domains of a Keccak table up to this many points use 25 threads per point (default 2^15)
+ *   "fri_fused_division_min"    polynomials from this many coefficients on divide by (X - z) with all batches in one thread (default 2^21)
+ * An unknown key is an error.  Applies to the context and its commit lanes. */
+int zkm_ctx_set_tuning(zkm_ctx* ctx, const char* key, uint64_t value, char** err);
 /* Pinned host memory (N3, trace ingest): host-resident traces (the reference's Vec<PolynomialValues>, prover.rs:144-167) are
  * uploaded in column chunks on a copy stream while earlier chunks are transformed and hashed; that overlap needs page-locked
  * source memory.  Either let the witness generator write into zkm_host_alloc memory, or zkm_host_register its own buffers once.

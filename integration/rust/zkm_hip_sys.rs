@@ -75,6 +75,7 @@ extern "C" {
     pub fn zkm_ctx_memory(ctx: *const zkm_ctx, live_bytes: *mut usize, cached_bytes: *mut usize);
     pub fn zkm_ctx_resident_bytes(ctx: *const zkm_ctx) -> usize;
     pub fn zkm_ctx_trim(ctx: *mut zkm_ctx);
+    pub fn zkm_ctx_set_tuning(ctx: *mut zkm_ctx, key: *const c_char, value: u64, err: *mut *mut c_char) -> c_int;
     pub fn zkm_dev_alloc(ctx: *mut zkm_ctx, bytes: usize, out: *mut *mut c_void, err: *mut *mut c_char) -> c_int;
     pub fn zkm_dev_free(ctx: *mut zkm_ctx, p: *mut c_void) -> c_int;
     pub fn zkm_dev_upload(ctx: *mut zkm_ctx, dst_dev: *mut c_void, src_host: *const c_void, bytes: usize, err: *mut *mut c_char) -> c_int;

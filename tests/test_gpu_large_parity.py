@@ -152,7 +152,7 @@ def test_sha_witness_kernels_reference_vectors(ctx):
     assert _le4(tr, 0, 0) == 40965
 
 
-def test_pipelined_host_ingest_equals_monolithic(zkm, oracle, monkeypatch):
+def test_pipelined_host_ingest_equals_monolithic(zkm, oracle):
     """Host-resident values (the reference's Vec<PolynomialValues>, prover.rs:144-167) are uploaded in column chunks on a copy
     stream and absorbed chunk by chunk (k_merkle_leaves_chunk); the commitment must not depend on the chunking, the source
     memory kind (pageable / pinned) or the ragged last chunk."""
@@ -162,15 +162,15 @@ def test_pipelined_host_ingest_equals_monolithic(zkm, oracle, monkeypatch):
         vals = rand_field(rng, ncols << log_n)
         want = oracle.batch_from_values(vals, ncols, log_n)
         caps = []
-        for chunk in ("0", "8", "32"):  # (log_n 13: the smallest height the pipelined path takes)
-            monkeypatch.setenv("ZKM_INGEST_CHUNK", chunk)
+        for chunk in (0, 8, 32):  # (log_n 13: the smallest height the pipelined path takes)
             c = zkm.Context(0)
+            c.set_tuning("ingest_chunk_cols", chunk)
             b = zkm.PolynomialBatch.from_values(c, vals, ncols, log_n)
             assert (b.cap() == want.cap()).all() and (b.coeffs() == want.coeffs()).all(), (ncols, chunk)
             for i in (0, 5, (4 << log_n) - 1):
                 assert (b.leaf(i) == want.leaf(i)).all() and (b.merkle_path(i) == want.merkle_path(i)).all()
             b.free()
-            if chunk == "32":
+            if chunk == 32:
                 pinned = c.pinned_array(vals.size)
                 pinned[:] = vals
                 b = zkm.PolynomialBatch.from_values(c, pinned, ncols, log_n)

@@ -294,3 +294,61 @@ def test_concurrent_contexts_are_bit_exact(ctx, zkm):
     for t in traces.values():
         t.free()
     aux.free()
+
+
+# ---- zkm_ctx_set_tuning: both sides of every kernel-selection threshold produce the same words
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [9, 13])
+def test_tuning_fri_division_variants_agree(zkm, oracle, log_n):
+    """Division by (X - z): one batch per thread + a combine launch (default below 2^21 coefficients) against all batches in one
+    thread (default from 2^21 on, covered at full size by test_prove_openings_bit_exact[22]) -- forced both ways at small sizes."""
+    W, A, Q, Z = 13, 4, 4, 2
+    rng = np.random.default_rng(92)
+    n = 1 << log_n
+    tv, av, qc = (rng.integers(0, P, k * n, dtype=np.uint64) for k in (W, A, Q))
+    blobs = []
+    for threshold in (1 << 30, 1):
+        c = zkm.Context(0)
+        c.set_tuning("fri_fused_division_min", threshold)
+        tb, ab = zkm.PolynomialBatch.from_values(c, tv, W, log_n), zkm.PolynomialBatch.from_values(c, av, A, log_n)
+        qb = zkm.PolynomialBatch.from_coeffs(c, qc, Q, log_n)
+        ch = zkm.challenger_new()
+        zkm.challenger_observe(ch, [7, 8, 9])
+        blobs.append(c.prove_openings(tb, ab, qb, Z, challenger=ch))
+        for b in (tb, ab, qb):
+            b.free()
+        c.close()
+    assert (blobs[0] == blobs[1]).all()
+    otb, oab = oracle.batch_from_values(tv, W, log_n), oracle.batch_from_values(av, A, log_n)
+    oqb = oracle.batch_from_coeffs(qc, Q, log_n)
+    och = oracle.challenger()
+    oracle.observe(och, [7, 8, 9])
+    assert (blobs[0] == oracle.prove_openings(otb, oab, oqb, Z, och)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nalphas", [1, 2])
+def test_tuning_keccak_quotient_variants_agree(zkm, oracle, nalphas):
+    """KeccakStark constraints: 25 threads per point (default up to 2^15 points) against one thread per point (default beyond;
+    verified at 2^15 rows by test_large_tables_gpu_proof_verifies) -- both forced at 2^6 rows, both equal to the oracle."""
+    from zkm_amd import tables as T
+    from .test_gpu_tables import table_trace
+    log_n, W = 6, T.WIDTH[T.TABLE_KECCAK]
+    trace = table_trace(oracle, T.TABLE_KECCAK, log_n)
+    rng = np.random.default_rng(6)
+    aux = rng.integers(0, 1 << 63, 3 << log_n, dtype=np.uint64)
+    alphas = [int(x) for x in rng.integers(1, 1 << 62, nalphas)]
+    want = oracle.quotient(oracle.batch_from_values(trace, W, log_n), oracle.batch_from_values(aux, 3, log_n), [2], alphas, table_id=T.TABLE_KECCAK)
+    for max_points in (1 << 15, 0):
+        c = zkm.Context(0)
+        c.set_tuning("keccak_parts_max_points", max_points)
+        tb, ab = zkm.PolynomialBatch.from_values(c, trace, W, log_n), zkm.PolynomialBatch.from_values(c, aux, 3, log_n)
+        assert (c.quotient(tb, ab, [2], alphas, table_id=T.TABLE_KECCAK) == want).all(), max_points
+        tb.free(); ab.free()
+        c.close()
+
+
+@pytest.mark.gpu
+def test_tuning_rejects_unknown_keys(ctx, zkm):
+    with pytest.raises(zkm.ZkmError):
+        ctx.set_tuning("no_such_threshold", 1)

@@ -27,7 +27,7 @@ TABLE_SHA_EXTEND, TABLE_SHA_EXTEND_SPONGE, TABLE_SHA_COMPRESS, TABLE_SHA_COMPRES
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
-    "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_memory", "zkm_ctx_resident_bytes", "zkm_ctx_trim", "zkm_table_enum_index", "zkm_host_alloc", "zkm_host_free",
+    "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_memory", "zkm_ctx_resident_bytes", "zkm_ctx_trim", "zkm_ctx_set_tuning", "zkm_table_enum_index", "zkm_host_alloc", "zkm_host_free",
     "zkm_host_register", "zkm_host_unregister", "zkm_all_stark_ctls", "zkm_all_stark_ctl_table", "zkm_prove_segment", "zkm_prove_segment_columns", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
     "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_field_selftest", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_commit_columns", "zkm_batch_free",
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_lde_rows", "zkm_batch_leaf", "zkm_batch_merkle_path",
@@ -133,6 +133,7 @@ def load():
         "zkm_ctx_memory": (None, [cp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "zkm_ctx_resident_bytes": (C.c_size_t, [cp]),
         "zkm_ctx_trim": (None, [cp]),
+        "zkm_ctx_set_tuning": (C.c_int, [cp, C.c_char_p, C.c_uint64, err]),
         "zkm_all_stark_ctls": (C.c_int, [cpp, C.POINTER(C.c_size_t), cpp, C.POINTER(C.c_size_t)]),
         "zkm_all_stark_ctl_table": (cp, [C.c_int]),
         "zkm_prove_segment": (C.c_int, [cp, C.POINTER(StarkConfig), C.POINTER(C.c_void_p), C.POINTER(C.c_uint), u64p, C.c_size_t, u64p,
@@ -295,6 +296,11 @@ class Context:
     def trim(self):
         """Return the allocator's cached blocks to the device."""
         self.L.zkm_ctx_trim(self.h)
+
+    def set_tuning(self, key, value):
+        """Kernel-selection thresholds (include/zkm_hip.h: zkm_ctx_set_tuning); every setting yields the same words."""
+        err = C.c_char_p()
+        _check(self.L.zkm_ctx_set_tuning(self.h, key.encode(), int(value), C.byref(err)), err)
 
     def synchronize(self):
         err = C.c_char_p()

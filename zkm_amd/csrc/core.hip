@@ -56,6 +56,8 @@ void zkm_ctx::ensure_lanes(size_t k) {
         l->device = device;
         l->num_cus = num_cus;
         l->ingest_chunk_cols = ingest_chunk_cols;
+        l->keccak_parts_max_points = keccak_parts_max_points;
+        l->fri_fused_division_min = fri_fused_division_min;
         hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
             delete l;
@@ -236,7 +238,6 @@ int zkm_ctx_create(int device, zkm_ctx** out, char** err) {
     ZKM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
     ZKM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    if (const char* e = getenv("ZKM_INGEST_CHUNK")) c->ingest_chunk_cols = (size_t)strtoul(e, nullptr, 10);  // tuning / A-B switch
     *out = c;
     ZKM_API_END(err)
 }
@@ -256,6 +257,21 @@ void zkm_ctx_destroy(zkm_ctx* c) {
     if (c->h_xfer) (void)hipHostFree(c->h_xfer);
     (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) {
+    ZKM_API_BEGIN
+    if (!c || !key) throw std::runtime_error("zkm_ctx_set_tuning: null argument");
+    const std::string k(key);
+    auto set = [&](zkm_ctx* x) {
+        if (k == "ingest_chunk_cols") x->ingest_chunk_cols = (size_t)value;
+        else if (k == "keccak_parts_max_points") x->keccak_parts_max_points = (size_t)value;
+        else if (k == "fri_fused_division_min") x->fri_fused_division_min = (size_t)value;
+        else throw std::runtime_error("zkm_ctx_set_tuning: unknown key '" + k + "'");
+    };
+    set(c);
+    for (zkm_ctx* l : c->lanes) set(l);
+    ZKM_API_END(err)
 }
 
 int zkm_ctx_synchronize(zkm_ctx* c, char** err) {

@@ -307,7 +307,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
     hipLaunchKernelGGL((k_quotient<T, NA>), grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, lookups, d_alphas, wpow, gn, \
                        last, w_n, n_inv, d_vals)
-        if (table_id == ZKM_TABLE_KECCAK && size <= ((size_t)1 << 15)) {
+        if (table_id == ZKM_TABLE_KECCAK && size <= c->keccak_parts_max_points) {
             // short table: 25 threads per point, then the sum of the parts (constraints_dev.h)
             std::vector<gl_t> apw(nalphas * (KECCAK_NUM_CONSTRAINTS + 1));
             for (size_t a = 0; a < nalphas; a++) {
@@ -848,7 +848,7 @@ static void divide_accumulate_all(zkm_ctx* c, const std::vector<fri_composite>& 
         const size_t nseg = (m[l] + FRI_SEG - 1) / FRI_SEG;
         const gl_t* upper = l + 1 < L ? suf[l + 1] : nullptr;
         const size_t nupper = l + 1 < L ? m[l + 1] : 0;
-        if (l == 0 && n >= ((size_t)1 << 21)) {
+        if (l == 0 && n >= c->fri_fused_division_min) {
             hipLaunchKernelGGL(k_seg_scan_final, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, c->stream, lv[0], n, upper, nupper, f0, f1);
             break;
         }

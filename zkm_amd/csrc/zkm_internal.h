@@ -38,7 +38,9 @@ struct zkm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host -> device ingest, overlapped with the compute stream (created on first use)
-    size_t ingest_chunk_cols = 32;      // columns per ingest chunk (ZKM_INGEST_CHUNK; 0 = monolithic upload)
+    size_t ingest_chunk_cols = 32;      // columns per ingest chunk (0 = monolithic upload)           } zkm_ctx_set_tuning
+    size_t keccak_parts_max_points = (size_t)1 << 15;   // k_quotient_keccak_parts up to this many points  }
+    size_t fri_fused_division_min = (size_t)1 << 21;    // k_seg_scan_final from this many coefficients    }
     int num_cus = 256;
     // profiling
     bool profiling = false;
