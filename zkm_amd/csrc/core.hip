@@ -1,4 +1,5 @@
 // core.hip -- context, memory, profiling, Fiat-Shamir transcript and the PolynomialBatch part of the C ABI.
+#include <sched.h>
 #include <algorithm>
 
 #include "poseidon_dev.h"
@@ -137,8 +138,9 @@ void zkm_ctx::download(std::initializer_list<xfer> xs) {
                 if (e == hipSuccess) break;                       // (complete: the words are in host memory whatever the flag's cache line says)
                 if (e != hipErrorNotReady) ZKM_HIP_CHECK(e);
             }
+            if (spins > 32768) sched_yield();                     // a long wait (the GPU is busy with other contexts): let other threads run
 #if defined(__x86_64__)
-            __builtin_ia32_pause();
+            else __builtin_ia32_pause();
 #endif
         }
         up_off = 0;                                               // everything queued before the kernel has completed, uploads included
