@@ -132,6 +132,8 @@ struct quotient_point {
     size_t j, jn;
     uint32_t i;
 };
+// the (<= 2) constraint challenges travel in the kernel-argument segment: no device copy, no upload per table
+struct alpha_args { gl_t v[2]; };
 template <int NA>
 __device__ __forceinline__ quotient_point quotient_setup(size_t j, unsigned lde_bits, const gl_t* __restrict__ alphas, const gl_t* __restrict__ wpow,
                                                          gl_t gn, gl_t last, gl_t w_n, gl_t n_inv, consumer_t<NA>& k) {
@@ -167,9 +169,10 @@ __device__ __forceinline__ quotient_point quotient_setup(size_t j, unsigned lde_
 // -- the same polynomial in alpha, so the values are identical.
 template <int TABLE, int NA>
 __global__ __launch_bounds__(256, (TABLE == ZKM_TABLE_CPU || TABLE == ZKM_TABLE_POSEIDON || TABLE == ZKM_TABLE_ARITHMETIC ? 4 : 1)) void k_quotient(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux,
-                                                           unsigned log_n, unsigned lde_bits, lookup_dev lookups, const gl_t* alphas,
+                                                           unsigned log_n, unsigned lde_bits, lookup_dev lookups, alpha_args alphas_v,
                                                            const gl_t* __restrict__ wpow /* w_{4n}^t two-level table */,
                                                            gl_t gn, gl_t last, gl_t w_n, gl_t n_inv, gl_t* __restrict__ out) {
+    const gl_t* const alphas = alphas_v.v;
     size_t N = (size_t)1 << lde_bits;
     size_t size = N >> 1;
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,9 +188,10 @@ __global__ __launch_bounds__(256, (TABLE == ZKM_TABLE_CPU || TABLE == ZKM_TABLE_
 
 // Short Keccak tables: KECCAK_CONSTRAINT_PARTS threads per point (constraints_dev.h, eval_keccak_constraints_part); blockIdx.y = part.
 template <int NA>
-__global__ __launch_bounds__(256) void k_quotient_keccak_parts(const gl_t* __restrict__ trace, unsigned lde_bits, const gl_t* alphas,
+__global__ __launch_bounds__(256) void k_quotient_keccak_parts(const gl_t* __restrict__ trace, unsigned lde_bits, alpha_args alphas_v,
                                                                const gl_t* __restrict__ wpow, gl_t gn, gl_t last, gl_t w_n, gl_t n_inv,
                                                                const gl_t* __restrict__ apw, gl_t* __restrict__ tmp /* [part][NA][size] */) {
+    const gl_t* const alphas = alphas_v.v;
     size_t N = (size_t)1 << lde_bits;
     size_t size = N >> 1;
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,8 +212,9 @@ __global__ __launch_bounds__(256) void k_sum_parts(const gl_t* __restrict__ tmp,
 
 template <int NA>
 __global__ __launch_bounds__(256) void k_quotient_ctl(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux, unsigned lde_bits, ctl_dev ctl,
-                                                      uint32_t num_lookup_cols, const gl_t* alphas, const gl_t* __restrict__ wpow, gl_t gn,
+                                                      uint32_t num_lookup_cols, alpha_args alphas_v, const gl_t* __restrict__ wpow, gl_t gn,
                                                       gl_t zh_inv0, gl_t zh_inv1, gl_t last, gl_t w_n, gl_t n_inv, gl_t* __restrict__ out) {
+    const gl_t* const alphas = alphas_v.v;
     size_t N = (size_t)1 << lde_bits;
     size_t size = N >> 1;
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -229,9 +234,10 @@ struct ctl_chunk {
 };
 template <int NA>
 __global__ __launch_bounds__(256) void k_quotient_ctl_chunk(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux, unsigned lde_bits, ctl_dev ctl,
-                                                            const ctl_chunk* __restrict__ chunks, uint32_t num_lookup_cols, const gl_t* alphas,
+                                                            const ctl_chunk* __restrict__ chunks, uint32_t num_lookup_cols, alpha_args alphas_v,
                                                             const gl_t* __restrict__ wpow, gl_t gn, gl_t last, gl_t w_n, gl_t n_inv,
                                                             gl_t* __restrict__ tmp /* [chunk][NA][size] */) {
+    const gl_t* const alphas = alphas_v.v;
     size_t N = (size_t)1 << lde_bits;
     size_t size = N >> 1;
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,8 +252,9 @@ __global__ __launch_bounds__(256) void k_quotient_ctl_chunk(const gl_t* __restri
         tmp[((size_t)blockIdx.y * NA + a) * size + q.i] = gl_mul(k.acc[a], gl_pow(k.alpha[a], ch.tail));
 }
 template <int NA>
-__global__ __launch_bounds__(256) void k_quotient_ctl_sum(const gl_t* __restrict__ tmp, uint32_t nchunks, uint32_t nconstraints, const gl_t* alphas,
+__global__ __launch_bounds__(256) void k_quotient_ctl_sum(const gl_t* __restrict__ tmp, uint32_t nchunks, uint32_t nconstraints, alpha_args alphas_v,
                                                           gl_t zh_inv0, gl_t zh_inv1, size_t size, gl_t* __restrict__ out) {
+    const gl_t* const alphas = alphas_v.v;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= size) return;
     gl_t zi = (i & 1) ? zh_inv1 : zh_inv0;
@@ -296,8 +303,8 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     gl_t zh0 = gl_inv(gl_sub(gn, 1)), zh1 = gl_inv(gl_sub(gl_neg(gn), 1));
     gl_t w_n = gl_root_of_unity(log_n), last = gl_inv(w_n);
     gl_t n_inv = gl_inv((gl_t)(((uint64_t)1 << log_n) % GL_P));
-    gl_t* d_alphas = (gl_t*)c->alloc(4 * sizeof(gl_t));
-    c->upload(d_alphas, alphas_host, nalphas * sizeof(gl_t));
+    alpha_args d_alphas{};
+    for (size_t a = 0; a < nalphas && a < 2; a++) d_alphas.v[a] = alphas_host[a];
     gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
     {
         static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory", "quotient_poseidon_sponge", "quotient_sha_extend", "quotient_sha_extend_sponge", "quotient_sha_compress",
@@ -410,7 +417,6 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     // coset_ifft(g) of each challenge's evaluations (prover.rs:784-788)
     zkm_ntt_natural(c, d_vals, d_out, nalphas, size, size, log_q, true, GL_GENERATOR);
     c->release(d_vals);  // stream-ordered reuse: no host sync needed
-    c->release(d_alphas);
 }
 
 // ------------------------------------------------------------------ K10: openings
@@ -753,26 +759,34 @@ __global__ __launch_bounds__(256) void k_pow_search(pow_state st, unsigned pos, 
 }
 
 // ------------------------------------------------------------------ query gather
-struct gather_oracle { const gl_t* lde; const gl_t* digests; uint32_t ncols, nsib; uint64_t N; uint64_t level_off[32]; };
-struct gather_layer { const gl_t *c0, *c1, *digests; uint32_t nsib; uint64_t level_off[32]; };
+// Everything the gather needs travels in the kernel-argument segment (no descriptor / index uploads per table): level l of a tree
+// with 2^log_leaves leaf digests starts at word 4 (2^(log_leaves + 1) - 2^(log_leaves - l + 1)) of its digest array
+// (zkm_merkle_layout), and the query indices are at most ZKM_FRI_MAX_QUERIES words.
+struct gather_oracle { const gl_t* lde; const gl_t* digests; uint32_t ncols, nsib; };
+struct gather_layer { const gl_t *c0, *c1, *digests; uint32_t nsib, log_leaves; };
 #define ZKM_FRI_MAX_ORACLES 8
-struct gather_args {  // (lives in device memory: larger than the kernel-argument segment)
+#define ZKM_FRI_MAX_QUERIES 128
+struct gather_args {
     gather_oracle o[ZKM_FRI_MAX_ORACLES];
     gather_layer l[8];
-    uint32_t noracles, nlayers, arity_bits, _pad;
+    uint32_t noracles, nlayers, arity_bits, lde_bits;
     uint64_t query_words;
 };
-__global__ void k_gather_queries(const gather_args* __restrict__ gp, const uint64_t* __restrict__ xs, gl_t* __restrict__ out) {
-    const gather_args& g = *gp;
-    uint64_t x = xs[blockIdx.x];
+struct gather_queries { uint32_t x[ZKM_FRI_MAX_QUERIES]; };   // x < 2^lde_bits <= 2^32
+__device__ __forceinline__ size_t merkle_level_offset(unsigned log_leaves, unsigned lvl) {
+    return (((size_t)2 << log_leaves) - ((size_t)2 << (log_leaves - lvl))) * 4;
+}
+__global__ void k_gather_queries(gather_args g, gather_queries qs, gl_t* __restrict__ out) {
+    uint64_t x = qs.x[blockIdx.x];
+    const uint64_t N = (uint64_t)1 << g.lde_bits;
     gl_t* o = out + (size_t)blockIdx.x * g.query_words;
     for (uint32_t k = 0; k < g.noracles; k++) {
         const gather_oracle& r = g.o[k];
-        for (uint32_t c = threadIdx.x; c < r.ncols; c += blockDim.x) o[c] = r.lde[(size_t)c * r.N + x];
+        for (uint32_t c = threadIdx.x; c < r.ncols; c += blockDim.x) o[c] = r.lde[(size_t)c * N + x];
         o += r.ncols;
         for (uint32_t e = threadIdx.x; e < r.nsib * 4; e += blockDim.x) {
             uint32_t lvl = e >> 2;
-            o[e] = r.digests[r.level_off[lvl] + 4 * ((x >> lvl) ^ 1) + (e & 3)];
+            o[e] = r.digests[merkle_level_offset(g.lde_bits, lvl) + 4 * ((x >> lvl) ^ 1) + (e & 3)];
         }
         o += r.nsib * 4;
     }
@@ -784,7 +798,7 @@ __global__ void k_gather_queries(const gather_args* __restrict__ gp, const uint6
         o += 2 * arity;
         for (uint32_t e = threadIdx.x; e < r.nsib * 4; e += blockDim.x) {
             uint32_t lvl = e >> 2;
-            o[e] = r.digests[r.level_off[lvl] + 4 * ((x >> lvl) ^ 1) + (e & 3)];
+            o[e] = r.digests[merkle_level_offset(r.log_leaves, lvl) + 4 * ((x >> lvl) ^ 1) + (e & 3)];
         }
         o += r.nsib * 4;
     }
@@ -958,34 +972,27 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
 
         // query rounds
         {
-            std::vector<uint64_t> xs(nq);
-            for (size_t q = 0; q < nq; q++) xs[q] = zkm_challenger_get(ch) % N;
-            uint64_t* d_xs = (uint64_t*)c->alloc(nq * 8);
-            scratch.push_back(d_xs);
-            c->upload(d_xs, xs.data(), nq * 8);
-            std::vector<gather_args> gav(1);
-            gather_args& ga = gav[0];
-            memset(&ga, 0, sizeof ga);
+            if (nq > ZKM_FRI_MAX_QUERIES || lde_bits > 32) throw std::runtime_error("FRI: at most 128 query rounds on domains of at most 2^32 points");
+            gather_queries qs{};
+            for (size_t q = 0; q < nq; q++) qs.x[q] = (uint32_t)(zkm_challenger_get(ch) % N);
+            gather_args ga{};
             ga.noracles = (uint32_t)noracles;
-                    for (size_t k = 0; k < noracles; k++) {
+            for (size_t k = 0; k < noracles; k++) {
+                if (orc[k]->lde_bits() != lde_bits) throw std::runtime_error("internal: oracle of another domain size in the query gather");
                 ga.o[k].lde = orc[k]->lde; ga.o[k].digests = orc[k]->digests; ga.o[k].ncols = (uint32_t)orc[k]->ncols;
-                ga.o[k].nsib = lde_bits - cfg->cap_height; ga.o[k].N = N;
-                for (size_t i = 0; i < orc[k]->level_off.size() && i < 32; i++) ga.o[k].level_off[i] = orc[k]->level_off[i];
+                ga.o[k].nsib = lde_bits - cfg->cap_height;
             }
             for (unsigned l = 0; l < L; l++) {
                 ga.l[l].c0 = layers[l].values; ga.l[l].c1 = layers[l].values + layers[l].len; ga.l[l].digests = layers[l].digests;
                 ga.l[l].nsib = layers[l].log_leaves - cfg->cap_height;
-                for (size_t i = 0; i < layers[l].level_off.size() && i < 32; i++) ga.l[l].level_off[i] = layers[l].level_off[i];
+                ga.l[l].log_leaves = layers[l].log_leaves;
             }
-            ga.nlayers = L; ga.arity_bits = cfg->arity_bits; ga.query_words = query_words;
-            gather_args* d_ga = (gather_args*)c->alloc(sizeof(gather_args));
-            scratch.push_back(d_ga);
-            c->upload(d_ga, &ga, sizeof ga);
+            ga.nlayers = L; ga.arity_bits = cfg->arity_bits; ga.lde_bits = lde_bits; ga.query_words = query_words;
             gl_t* d_q = (gl_t*)c->alloc(nq * query_words * 8);
             scratch.push_back(d_q);
             {
                 zkm_prof_scope ps(c, "fri_gather_queries");
-                hipLaunchKernelGGL(k_gather_queries, dim3(nq), dim3(256), 0, c->stream, d_ga, d_xs, d_q);
+                hipLaunchKernelGGL(k_gather_queries, dim3(nq), dim3(256), 0, c->stream, ga, qs, d_q);
                 ZKM_HIP_CHECK(hipGetLastError());
             }
             c->download(queries_out, d_q, nq * query_words * 8);
