@@ -133,7 +133,16 @@ def gather_proofs(local):
     if dist.get_backend() == "nccl" and _HOST_GROUP is None:
         # created on first use (a collective call: every rank gathers or none does): gloo announces its connections on STDOUT, and a run
         # that gathers nothing -- the driver's scaling runs -- must print nothing but rank 0's JSON line
-        _HOST_GROUP = dist.new_group(backend="gloo")
+        # (... and the announcement itself goes to stderr: the descriptor is swapped while the group connects)
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            _HOST_GROUP = dist.new_group(backend="gloo")
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
     dist.gather_object(local, out, dst=0, group=_HOST_GROUP)
     if dist.get_rank() != 0:
