@@ -34,30 +34,41 @@ __device__ __forceinline__ uint64_t rotl64(uint64_t v, unsigned r) {
     return ((uint64_t)nh << 32) | nl;
 }
 
-// One Keccak-f round on a[x + 5y] (theta, rho, pi, chi, then iota with `rc`; pass rc = 0 to stop before iota).
+// Three-input bit functions in one instruction (v_bitop3_b32, new on gfx950; the truth table is the function applied to the column
+// patterns 0xF0, 0xCC, 0xAA of the three operands).  The compiler forms it for 32-bit chi but not for 64-bit values or for xor chains,
+// so the 64-bit helpers split the halves by hand: a Keccak-f round is 180 instructions instead of 260.
+__device__ __forceinline__ uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) {
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0x96);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0x96);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t chi_64(uint64_t a, uint64_t b, uint64_t c) {   // a ^ (~b & c): 0xF0 ^ (~0xCC & 0xAA) = 0xD2
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0xD2);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0xD2);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// One Keccak-f round on a[x + 5y] (theta, rho, pi, chi, then iota with `rc`; pass rc = 0 to stop before iota).  Theta's
+// D[x] = C[x - 1] ^ rotl(C[x + 1], 1) is never formed: it enters each lane as the second and third operand of one xor3.
 __device__ __forceinline__ void keccak_round_dev(uint64_t (&a)[25], uint64_t rc) {
     constexpr unsigned RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-    uint64_t cx[5], b[25];
+    uint64_t cx[5], cr[5], b[25];
 #pragma unroll
-    for (int x = 0; x < 5; x++) cx[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+    for (int x = 0; x < 5; x++) cx[x] = xor3_64(xor3_64(a[x], a[x + 5], a[x + 10]), a[x + 15], a[x + 20]);
 #pragma unroll
-    for (int x = 0; x < 5; x++) {
-        uint64_t d = cx[(x + 4) % 5] ^ rotl64(cx[(x + 1) % 5], 1);
-#pragma unroll
-        for (int y = 0; y < 5; y++) a[x + 5 * y] ^= d;
-    }
+    for (int x = 0; x < 5; x++) cr[x] = rotl64(cx[x], 1);
 #pragma unroll
     for (int x = 0; x < 5; x++)
 #pragma unroll
         for (int y = 0; y < 5; y++) {
             unsigned r = RHO[x + 5 * y];
-            uint64_t v = a[x + 5 * y];
+            uint64_t v = xor3_64(a[x + 5 * y], cx[(x + 4) % 5], cr[(x + 1) % 5]);
             b[y + 5 * ((2 * x + 3 * y) % 5)] = r ? rotl64(v, r) : v;
         }
 #pragma unroll
     for (int y = 0; y < 5; y++)
 #pragma unroll
-        for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        for (int x = 0; x < 5; x++) a[x + 5 * y] = chi_64(b[x + 5 * y], b[(x + 1) % 5 + 5 * y], b[(x + 2) % 5 + 5 * y]);
     a[0] ^= rc;
 }
 
