@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Soak: k contexts (one host thread each) prove the SAME twelve-table 2^16-cycle segment r times side by side; every proof must
+equal the first one word for word (the prover is deterministic: any difference is a race -- allocator reuse across streams, the
+pinned transfer ring, the download flag, the commit lanes).   python tools/soak_segments.py [contexts=8] [reps=30]"""
+import os
+import sys
+import threading
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import zkm_amd  # noqa: E402
+from tools.bench_segment import tiled_segment  # noqa: E402
+
+nctx = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+ctxs = [zkm_amd.Context(0) for _ in range(nctx)]
+data = [tiled_segment(c, 16) for c in ctxs]
+ref, _, _ = ctxs[0].prove_segment(*data[0], public_values=[1, 2, 3])
+ref = np.array(ref, copy=True)
+bad = []
+
+
+def work(i):
+    c, (bufs, logs) = ctxs[i], data[i]
+    for r in range(reps):
+        p, _, _ = c.prove_segment(bufs, logs, public_values=[1, 2, 3])
+        if p.shape != ref.shape or not (p == ref).all():
+            bad.append((i, r, int(np.nonzero(p != ref)[0][0]) if p.shape == ref.shape else -1))
+            return
+
+
+th = [threading.Thread(target=work, args=(i,)) for i in range(nctx)]
+for t in th:
+    t.start()
+for t in th:
+    t.join()
+print("soak: %d contexts x %d segments, %d words each: %s" % (nctx, reps, ref.size, "all equal" if not bad else "MISMATCH %r" % bad[:4]))
+sys.exit(1 if bad else 0)
