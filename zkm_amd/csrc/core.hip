@@ -103,7 +103,11 @@ __global__ __launch_bounds__(1024) void k_download(down_args a, uint64_t* flag, 
 }
 void zkm_ctx::ensure_xfer() {
     if (h_xfer) return;
-    ZKM_HIP_CHECK(hipHostMalloc((void**)&h_xfer, XFER_DOWN + XFER_UP + 64, hipHostMallocCoherent));
+    if (hipHostMalloc((void**)&h_xfer, XFER_DOWN + XFER_UP + 64, hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();   // (a runtime that refuses the explicit flag: the default pinned allocation is coherent on this platform too)
+        h_xfer = nullptr;
+        ZKM_HIP_CHECK(hipHostMalloc((void**)&h_xfer, XFER_DOWN + XFER_UP + 64, hipHostMallocDefault));
+    }
     memset(h_xfer + XFER_DOWN + XFER_UP, 0, 64);
 }
 void zkm_ctx::download(std::initializer_list<xfer> xs) {
