@@ -606,9 +606,8 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
         // columns -- as long as the copies kept this way stay within a quarter of the memory that is free now (all twelve commitments
         // -- coefficients + 4x LDE + digests -- are alive at the same time, and a full-size Keccak table alone is 20 GB of values).
         // A trace beyond that budget is dropped after its commitment and uploaded again when its table is proven.
-        size_t free_b = 0, total_b = 0, kept = 0;
-        ZKM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        const size_t keep_limit = free_b / 4;
+        size_t kept = 0, keep_limit = 0;
+        bool have_limit = false;                       // (hipMemGetInfo is a driver round trip: only asked when a trace is host-resident)
         std::vector<char> keep(ntables, 0), host(ntables, 0);
         std::vector<size_t> big, small;
         {
@@ -620,6 +619,12 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
                 if (!tables[t].trace && !tables[t].columns) throw std::runtime_error("zkm_prove_with_traces: table without a trace");
                 const size_t bytes = (tables[t].ncols << tables[t].log_n) * sizeof(gl_t);
                 host[t] = tables[t].columns || !zkm_is_device_ptr(tables[t].trace);   // (column pointers are gathered into one device block)
+                if (host[t] && !have_limit) {
+                    size_t free_b = 0, total_b = 0;
+                    ZKM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+                    keep_limit = free_b / 4;
+                    have_limit = true;
+                }
                 keep[t] = host[t] && kept + bytes <= keep_limit;
                 if (keep[t]) kept += bytes;
                 ((bytes << cfg->rate_bits) > ((size_t)1 << 30) ? big : small).push_back(t);
