@@ -50,6 +50,27 @@ def test_host_challenger_matches_oracle(zkm, oracle):
     assert list(a.state) == list(b.state)
 
 
+def test_host_permutation_edge_states_match_oracle(zkm, oracle):
+    """The host-side permutation (csrc/host_poseidon.hip: sparse partial rounds, 128-bit accumulation, vectorised MDS) on the states
+    that exercise its carries and borrows: all-zero, all p - 1, single words at the limb boundaries, long runs of random blocks --
+    through the Challenger (the only way host code reaches it), against the oracle's independent permutation."""
+    P = zkm.P
+    edge = [0, 1, 2, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, P - 1, P - 2, P - (1 << 32), (1 << 63), (1 << 63) - 1, P >> 1]
+    rng = np.random.default_rng(12)
+    blocks = [[e] * 8 for e in edge]
+    blocks += [[edge[(i + k) % len(edge)] for k in range(8)] for i in range(len(edge))]
+    blocks += [[int(x) for x in rng.integers(0, P, 8, dtype=np.uint64)] for _ in range(3000)]
+    a, b = zkm.challenger_new(), oracle.challenger()
+    for i, blk in enumerate(blocks):
+        zkm.challenger_observe(a, blk)
+        oracle.observe(b, blk)
+        if i % 64 == 0 or i < 30:
+            assert list(a.state) == list(b.state), i
+    assert list(a.state) == list(b.state)
+    for _ in range(8):
+        assert zkm.challenger_get(a) == oracle.challenge(b)
+
+
 def test_proof_layout_sizes_agree(zkm, oracle):
     cfg_o = oracle.standard_config()
     cfg = zkm.StarkConfig()

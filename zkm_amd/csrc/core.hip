@@ -413,7 +413,7 @@ int zkm_profile_get(zkm_ctx* c, size_t i, const char** name, uint64_t* launches,
 // plonky2 Challenger: overwrite-mode duplex sponge over the Poseidon permutation.
 }  // extern "C"
 
-void zkm_host_poseidon_permute(uint64_t st[12]) { poseidon_permute(st); }
+// (zkm_host_poseidon_permute: host_poseidon.hip)
 
 extern "C" {
 void zkm_challenger_init(zkm_challenger* ch) { memset(ch, 0, sizeof *ch); }

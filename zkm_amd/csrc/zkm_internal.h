@@ -214,6 +214,7 @@ void zkm_prove_single_table_aux(zkm_ctx* c, int table_id, const zkm_stark_config
                                 const uint32_t* colset_ids, size_t nzs, const uint64_t* lookup_challenges, zkm_challenger* ch, uint64_t* proof);
 void zkm_launch_canon(zkm_ctx* c, gl_t* v, size_t total);   // v[i] = canonical representative of v[i], in place
 void zkm_host_poseidon_permute(uint64_t st[12]);
+void zkm_host_poseidon_permute_reference(uint64_t st[12]);   // poseidon_dev.h compiled for the host (cross-check)
 // ---- hash.hip (LogicStark witness)
 // ---- tables' own logUp lookups (core.hip: definitions; ctl.hip: helper columns)
 struct zkm_table_lookup { uint32_t ncols; const uint32_t* cols; uint32_t table_col, freq_col; };
