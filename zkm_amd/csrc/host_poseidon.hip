@@ -59,8 +59,14 @@ struct acc192 {
 
 // circulant MDS (+ 8 on the diagonal entry (0, 0)) on 32-bit halves: out_r = sum_j C[(j - r) mod 12] s_j.  REXT[12 + r - j] is that
 // coefficient, contiguous in r: the inner loops are plain multiply-adds of 32-bit values into 64-bit lanes.
-alignas(64) const uint64_t REXT[24] = {17, 20, 34, 18, 39, 13, 13, 28, 2, 16, 41, 15,      // REXT[k] = C[(12 - k) mod 12], k = 0 .. 11
-                                       17, 20, 34, 18, 39, 13, 13, 28, 2, 16, 41, 15};
+struct rext_table {
+    alignas(64) uint64_t v[24];
+    rext_table() {                                        // REXT[k] = C[(12 - k) mod 12], twice: from the one parameter table
+        for (int k = 0; k < 24; k++) v[k] = pc_host::ZKM_POSEIDON_MDS_CIRC[(24 - k) % 12];
+    }
+};
+const rext_table REXT_TABLE;
+const uint64_t* const REXT = REXT_TABLE.v;
 __attribute__((target_clones("avx2", "default"))) void mds_layer(uint64_t s[12]) {
     alignas(64) uint64_t al[12], ah[12];
     for (int r = 0; r < 12; r++) { al[r] = 0; ah[r] = 0; }
@@ -72,8 +78,8 @@ __attribute__((target_clones("avx2", "default"))) void mds_layer(uint64_t s[12])
             ah[r] += c[r] * hi;
         }
     }
-    al[0] += 8 * (uint64_t)(uint32_t)s[0];
-    ah[0] += 8 * (s[0] >> 32);
+    al[0] += pc_host::ZKM_POSEIDON_MDS_DIAG[0] * (uint64_t)(uint32_t)s[0];   // (the only non-zero diagonal entry: 8)
+    ah[0] += pc_host::ZKM_POSEIDON_MDS_DIAG[0] * (s[0] >> 32);
     for (int r = 0; r < 12; r++) s[r] = red128((u128)al[r] + ((u128)ah[r] << 32));       // both < 2^42
 }
 
