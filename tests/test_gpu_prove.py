@@ -352,3 +352,29 @@ def test_tuning_keccak_quotient_variants_agree(zkm, oracle, nalphas):
 def test_tuning_rejects_unknown_keys(ctx, zkm):
     with pytest.raises(zkm.ZkmError):
         ctx.set_tuning("no_such_threshold", 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,W", [(8, 70), (12, 9)])
+def test_tuning_poseidon_forms_agree(zkm, oracle, log_n, W):
+    """One lane, four lanes or sixteen lanes per hash (leaves, tree levels, FRI layers): every choice of the two thresholds gives the
+    commitments and the openings proof of the oracle."""
+    A, Q, Z = 4, 4, 2
+    rng = np.random.default_rng(93)
+    n = 1 << log_n
+    tv, av, qc = (rng.integers(0, P, k * n, dtype=np.uint64) for k in (W, A, Q))
+    otb, oab, oqb = oracle.batch_from_values(tv, W, log_n), oracle.batch_from_values(av, A, log_n), oracle.batch_from_coeffs(qc, Q, log_n)
+    want = oracle.prove_openings(otb, oab, oqb, Z)
+    for wide, quad in ((0, 0), (0, 1 << 30), (1 << 30, 1 << 30), (64, 512), (1024, 16384)):
+        c = zkm.Context(0)
+        c.set_tuning("wide_max_hashes", wide)
+        c.set_tuning("quad_max_hashes", quad)
+        tb, ab = zkm.PolynomialBatch.from_values(c, tv, W, log_n), zkm.PolynomialBatch.from_values(c, av, A, log_n)
+        qb = zkm.PolynomialBatch.from_coeffs(c, qc, Q, log_n)
+        assert (tb.cap() == otb.cap()).all() and (qb.cap() == oqb.cap()).all(), (wide, quad)
+        for lvl in range(0, log_n + 2 - 4, 3):
+            assert (tb.digest_layer(lvl) == otb.digest_layer(lvl)).all(), (wide, quad, lvl)
+        assert (c.prove_openings(tb, ab, qb, Z) == want).all(), (wide, quad)
+        for b in (tb, ab, qb):
+            b.free()
+        c.close()

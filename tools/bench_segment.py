@@ -73,7 +73,7 @@ def segment_rate(ctx, log_cycles, reps=3):
                     "scopes of those two phases overlap too -- wall_over_kernel_sum below 1 means concurrency, not a faster clock"}
 
 
-def concurrent_segment_rate(device, log_cycles, nctx, reps=6):
+def concurrent_segment_rate(device, log_cycles, nctx, reps=6, tuning=None):
     """`nctx` host threads, each with its OWN context (own stream, allocator, transcript) on the same GPU, proving independent
     segments at the same time: in the launch-bound regime of small segments the GPU interleaves their kernels, so the per-level
     Merkle / per-layer FRI latencies of one segment are filled with the work of the others.  Segments are independent proofs
@@ -81,6 +81,9 @@ def concurrent_segment_rate(device, log_cycles, nctx, reps=6):
     import threading
     import zkm_amd
     ctxs = [zkm_amd.Context(device) for _ in range(nctx)]
+    for c in ctxs:
+        for k, v in (tuning or {}).items():
+            c.set_tuning(k, v)
     data = [tiled_segment(c, log_cycles) for c in ctxs]
     for c, (bufs, logs) in zip(ctxs, data):
         c.prove_segment(bufs, logs, public_values=[1, 2, 3])

@@ -59,6 +59,8 @@ void zkm_ctx::ensure_lanes(size_t k) {
         l->ingest_chunk_cols = ingest_chunk_cols;
         l->keccak_parts_max_points = keccak_parts_max_points;
         l->fri_fused_division_min = fri_fused_division_min;
+        l->wide_max_hashes = wide_max_hashes;
+        l->quad_max_hashes = quad_max_hashes;
         hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
             delete l;
@@ -273,6 +275,8 @@ int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) 
         if (k == "ingest_chunk_cols") x->ingest_chunk_cols = (size_t)value;
         else if (k == "keccak_parts_max_points") x->keccak_parts_max_points = (size_t)value;
         else if (k == "fri_fused_division_min") x->fri_fused_division_min = (size_t)value;
+        else if (k == "wide_max_hashes") x->wide_max_hashes = (size_t)value;
+        else if (k == "quad_max_hashes") x->quad_max_hashes = (size_t)value;
         else throw std::runtime_error("zkm_ctx_set_tuning: unknown key '" + k + "'");
     };
     set(c);

@@ -70,16 +70,14 @@ __global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ 
 
 __global__ void k_merkle_leaves_quad(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests);
 __global__ void k_merkle_leaves_wide(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests);
-static size_t quad_max_leaves();
-static size_t wide_max_leaves();
 
 void zkm_launch_merkle_leaves(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests) {
     // rows of <= 4 elements are copied, not hashed (hash_or_noop): profile them under their own name
     zkm_prof_scope ps(c, ncols <= 4 ? "merkle_leaves_copy" : "merkle_leaves");
-    if (ncols > 4 && nrows <= wide_max_leaves())
+    if (ncols > 4 && nrows <= c->wide_max_hashes)
         // the shortest matrices: 16 lanes per leaf, the lowest latency per absorb step
         hipLaunchKernelGGL(k_merkle_leaves_wide, dim3((nrows * 16 + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
-    else if (ncols > 4 && nrows <= quad_max_leaves())
+    else if (ncols > 4 && nrows <= c->quad_max_hashes)
         // short, wide matrices (Keccak: 2431 columns x a few thousand rows): one lane per leaf leaves the machine empty and pays one
         // permutation's full latency per 8 columns; four lanes per leaf cut that latency to a third and fill 4x the lanes
         hipLaunchKernelGGL(k_merkle_leaves_quad, dim3((nrows * 4 + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
@@ -217,7 +215,7 @@ __global__ __launch_bounds__(256) void k_merkle_fused(merkle_fused_args p) {
 // (3.2k).  A hash owns a 16-lane row of the wave (lanes 0..11 = the twelve state words): every round is constant add, x^7 (lane 0
 // only in the partial rounds), and the circulant MDS with the twelve rotated neighbours fetched by ds_bpermute -- the textbook rounds
 // (poseidon_stark.rs:65-95, 164-169, 239-251, 310-345).  800 wave instructions per hash (four-lane form 360, one lane 190): for
-// launches of <= 4096 hashes, where nothing else competes for the issue slots of the chain.  Bit-exact with poseidon_permute (the
+// launches of <= 1024 hashes (zkm_ctx::wide_max_hashes), where the chain is all there is.  Bit-exact with poseidon_permute (the
 // fused partial rounds there are an algebraic regrouping).
 __device__ __forceinline__ uint64_t poseidon_permute_wide(uint64_t x, unsigned lane) {
     const unsigned idx = lane & 15, base = lane & ~15u;
@@ -289,7 +287,7 @@ __global__ __launch_bounds__(256) void k_merkle_fused_wide(merkle_fused_wide_arg
 
 // Column-major leaves, one leaf per 16-lane row (see poseidon_permute_wide): lanes 0..7 of the row fetch the next eight columns of
 // their leaf (overwrite-mode absorb: a ragged tail overwrites only the words that exist), all 12 lanes permute.  Bit-exact with
-// k_merkle_leaves.  Used when the matrix has at most wide_max_leaves() rows.
+// k_merkle_leaves.  Used when the matrix has at most zkm_ctx::wide_max_hashes rows.
 __global__ __launch_bounds__(256) void k_merkle_leaves_wide(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride,
                                                             gl_t* __restrict__ digests) {
     const unsigned lane = threadIdx.x & 63, idx = lane & 15;
@@ -304,7 +302,9 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_wide(const gl_t* __restri
 }
 // Rows up to which a leaf gets a 16-lane row (k_merkle_leaves_wide).  One absorb step takes ~13 us in the 16-lane form while every SIMD
 // holds at most one such wave (4096 rows), ~21 us with two (8192), ~41 us with four (16384); the four-lane form takes over there.
-static size_t wide_max_leaves() { return 4096; }
+// zkm_ctx::wide_max_hashes = 1024: up to 4096 the 16-lane form is the fastest for a context alone, but it spends 4.2x the issue slots
+// of the one-lane form, and with four or more contexts on the GPU those slots are somebody else's work (2^16-cycle segments, 1 / 4 / 8
+// contexts: 24.5 / 52.5 / 51.8 segments/s at 4096, 25.5 / 56.9 / 59.0 at 1024 -- profiles/r03_hw_queues.txt).
 
 
 // FRI layer leaves, one hash per 16-lane row (small layers): word m of leaf k is component m & 1 of value k * arity + (m >> 1).
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_merkle_fused_quad(merkle_fused_quad_arg
 
 // Column-major leaves, one leaf per quad: lane q fetches columns c + q and c + 4 + q of its leaf for the absorb step at column c
 // (overwrite-mode absorb: a ragged tail overwrites only the words that exist).  Bit-exact with k_merkle_leaves.  Used when the matrix
-// has at most quad_max_leaves() rows.
+// has at most zkm_ctx::quad_max_hashes rows.
 __global__ __launch_bounds__(256) void k_merkle_leaves_quad(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride,
                                                             gl_t* __restrict__ digests) {
     const unsigned q = threadIdx.x & 3;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_quad(const gl_t* __restri
 // Rows up to which a leaf gets a quad of lanes.  One absorb step takes ~10 us in the quad form while a SIMD holds at most one such wave
 // (16384 rows = 1024 waves), against ~27 us for the one-lane form on a wave that has its SIMD to itself (16384 rows = 256 waves); it
 // costs 1.7x the instructions per hash (the 16-lane form of rounds 1-2: 7.5x, which is why that one stopped at 4096 rows).
-static size_t quad_max_leaves() { return 16384; }
+// (zkm_ctx::quad_max_hashes = 16384)
 
 // FRI layer leaves, one hash per quad (small layers): word m of leaf k is component m & 1 of value k * arity + (m >> 1).
 __global__ __launch_bounds__(256) void k_merkle_leaves_ext_quad(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nleaves,
@@ -484,9 +484,9 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_ext_quad(const gl_t* __re
 void zkm_launch_merkle_leaves_ext(zkm_ctx* c, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests) {
     if (arity % 4 || 2 * arity <= 4) throw std::runtime_error("merkle_leaves_ext: unsupported arity");
     zkm_prof_scope ps(c, "merkle_leaves_ext");
-    if (nleaves <= 4096)    // the smallest layers: one hash per 16-lane row
+    if (nleaves <= c->wide_max_hashes)    // the smallest layers: one hash per 16-lane row
         hipLaunchKernelGGL(k_merkle_leaves_ext_wide, dim3((nleaves * 16 + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
-    else if (nleaves <= 16384)   // small layers: one hash per quad of lanes
+    else if (nleaves <= c->quad_max_hashes)   // small layers: one hash per quad of lanes
         hipLaunchKernelGGL(k_merkle_leaves_ext_quad, dim3((nleaves * 4 + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
     else
         hipLaunchKernelGGL(k_merkle_leaves_ext, dim3((nleaves + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
@@ -520,14 +520,15 @@ void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>
         zkm_prof_scope ps(c, "merkle_compress");
         const unsigned log_p1 = log_leaves - l - 1;       // log2(#parents) of the first level made
         const unsigned rem = top - l;
-        if (log_p1 >= 15) {
+        const size_t p1 = (size_t)1 << log_p1;
+        if (p1 > c->quad_max_hashes && p1 > c->wide_max_hashes && log_p1 >= 8) {   // (the one-lane kernel works on blocks of 256 parents)
             merkle_fused_args a{};
             a.children = digests + level_off[l];
             a.levels = rem < 3 ? rem : 3;
             for (unsigned k = 0; k < a.levels; k++) a.parents[k] = digests + level_off[l + 1 + k];
             hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(((size_t)1 << log_p1) / 256)), dim3(256), 0, c->stream, a);
             l += a.levels;
-        } else if (log_p1 <= 12) {
+        } else if (p1 <= c->wide_max_hashes) {
             merkle_fused_wide_args a{};
             a.children = digests + level_off[l];
             unsigned J = rem < 6 ? rem : 6;
@@ -539,7 +540,8 @@ void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>
         } else {
             merkle_fused_quad_args a{};
             a.children = digests + level_off[l];
-            unsigned J = rem < log_p1 - 12 ? rem : log_p1 - 12;   // the levels with 2^14 and 2^13 parents
+            unsigned J = 1;                                  // the levels that are still too large for the 16-lane form (default: 2^14 and 2^13 parents)
+            while (J < rem && J < 7 && J <= log_p1 && (p1 >> J) > c->wide_max_hashes) J++;
             a.J = J;
             for (unsigned k = 0; k < J; k++) a.parents[k] = digests + level_off[l + 1 + k];
             hipLaunchKernelGGL(k_merkle_fused_quad, dim3((unsigned)(((size_t)2 << log_p1) >> J)), dim3(256), 0, c->stream, a);
