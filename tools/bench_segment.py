@@ -111,8 +111,10 @@ def concurrent_segment_rate(device, log_cycles, nctx, reps=6, tuning=None):
 
 
 def multi_process_rate(procs, nctx, reps=8):
-    """The same with the contexts spread over `procs` host processes (tools/bench_segment_procs.py): every process has its own HIP
-    runtime, so launches of different processes do not queue behind one another on the host."""
+    """The same with the contexts in `procs` fresh host processes (tools/bench_segment_procs.py): every process has its own HIP runtime,
+    so launches of different processes do not queue behind one another on the host; 1 x k is the deployment shape itself -- a prover
+    process with k contexts and nothing else in it (the in-process `concurrent` figures share bench.py's process with its four
+    headline contexts and torch)."""
     import subprocess
     env = dict(os.environ, GPU_MAX_HW_QUEUES=str(max(2, 16 // procs)))   # ~16 hardware queues on the GPU in total (csrc/core.hip)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_segment_procs.py"), str(procs), str(nctx), str(reps)],
@@ -126,7 +128,7 @@ def small_segment_rate(ctx, device=0):
     out = segment_rate(ctx, 16)
     try:
         out["concurrent"] = [concurrent_segment_rate(device, 16, k) for k in (2, 4, 8)]
-        out["concurrent_processes"] = [multi_process_rate(p, k) for p, k in ((2, 4), (4, 2))]
+        out["concurrent_processes"] = [multi_process_rate(p, k) for p, k in ((1, 8), (2, 4), (4, 2))]
     except Exception as e:  # the single-context figure stands on its own
         out["concurrent_error"] = str(e)
     return out
@@ -140,5 +142,5 @@ if __name__ == "__main__":
     out["memory_live_cached"] = c.memory()
     if lc == 16 and "single" not in sys.argv[2:]:
         out["concurrent"] = [concurrent_segment_rate(0, 16, k) for k in (2, 4, 8)]
-        out["concurrent_processes"] = [multi_process_rate(p, k) for p, k in ((2, 4), (4, 2))]
+        out["concurrent_processes"] = [multi_process_rate(p, k) for p, k in ((1, 8), (2, 4), (4, 2))]
     print(json.dumps(out, indent=1))
