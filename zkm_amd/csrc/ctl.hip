@@ -532,21 +532,58 @@ size_t zkm_all_proof_words(const zkm_stark_config* cfg, const zkm_table_input* t
 // rows whose launches cannot fill the GPU and are chains of latency-bound steps (small Merkle levels, cap downloads): `small`
 // tables are pulled from one queue, largest first; `big` ones (LDE over 1 GiB: they fill the machine on their own) stay on the
 // context.  fn(worker context, table index); the first exception stops the queue and is rethrown on the caller.
+// Estimated time of committing `ncols` columns of 2^log_n rows (seconds; rate 4): every 8 columns are one absorb step of the leaf
+// sponge, and a step costs the larger of the permutation's latency in the form the matrix gets (hash.hip: 16 lanes per leaf up to
+// wide_max_hashes rows, four lanes up to quad_max_hashes, one lane beyond) and the time the whole machine needs for that many hashes.
+static double commit_cost_estimate(const zkm_ctx* c, size_t ncols, unsigned log_n, unsigned rate_bits) {
+    const double rows = (double)((size_t)1 << (log_n + rate_bits));
+    const double full_rate = 3.3e9;                        // one-lane permutations per second of the whole GPU
+    double lat, rate;
+    if (rows <= (double)c->wide_max_hashes) { lat = 13e-6; rate = full_rate / 4.2; }
+    else if (rows <= (double)c->quad_max_hashes) { lat = 24e-6; rate = full_rate / 1.9; }
+    else { lat = 40e-6; rate = full_rate; }
+    const double step = rows / rate > lat ? rows / rate : lat;
+    return (double)((ncols + 7) / 8) * step + rows * (double)ncols * 2.5e-11 + 2e-4;    // + transforms (~25 ps per LDE word) + launches
+}
+
+// Independent per-table jobs on the context and its commit lanes (one host thread each).  `big` tables run first, on the context
+// itself; the others are assigned to the workers AHEAD of time, longest first onto the least loaded worker (cost[t] = estimated
+// seconds) -- not pulled from a queue: a worker that gets the same tables on every call finds every block it needs in its own
+// exact-size allocator cache from the second segment on (a dynamic queue kept hitting hipMalloc for ten or more calls: 37 -- 53 ms
+// per 2^16-cycle segment depending on who had grabbed what), and the memory the lanes cache stays that of ONE assignment.
 template <class F>
-static void run_on_lanes(zkm_ctx* c, const std::vector<size_t>& big, const std::vector<size_t>& small, F&& fn) {
+static void run_on_lanes(zkm_ctx* c, const std::vector<size_t>& big, const std::vector<size_t>& small, const std::vector<double>& cost,
+                         F&& fn) {
     const size_t nlanes = small.size() >= 2 ? std::min<size_t>(ZKM_COMMIT_LANES, small.size()) - 1 : 0;
     c->ensure_lanes(nlanes);
-    std::atomic<size_t> next{0};
+    std::vector<std::vector<size_t>> mine(nlanes + 1);
+    {
+        std::vector<double> load(nlanes + 1, 0.0);
+        for (size_t t : big) load[0] += cost[t];
+        std::vector<size_t> order(small);
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+        for (size_t t : order) {
+            size_t w = 0;
+            for (size_t k = 1; k <= nlanes; k++)
+                if (load[k] < load[w]) w = k;
+            mine[w].push_back(t);
+            load[w] += cost[t];
+        }
+    }
+    std::atomic<bool> failed{false};
     std::vector<std::exception_ptr> errs(nlanes + 1);
     auto work = [&](zkm_ctx* w, size_t slot, bool take_big) {
         try {
             ZKM_HIP_CHECK(hipSetDevice(c->device));
             if (take_big)
                 for (size_t t : big) fn(w, t);
-            for (size_t i = next.fetch_add(1); i < small.size(); i = next.fetch_add(1)) fn(w, small[i]);
+            for (size_t t : mine[slot]) {
+                if (failed.load()) break;                    // another worker threw: stop starting new tables
+                fn(w, t);
+            }
         } catch (...) {
             errs[slot] = std::current_exception();
-            next.store(small.size());                    // stop handing out work
+            failed.store(true);
         }
     };
     std::vector<std::thread> threads;
@@ -631,7 +668,9 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
             }
             std::sort(small.begin(), small.end(),
                       [&](size_t a, size_t b) { return (tables[a].ncols << tables[a].log_n) > (tables[b].ncols << tables[b].log_n); });
-            run_on_lanes(c, big, small, [&](zkm_ctx* w, size_t t) {
+            std::vector<double> cost(ntables, 0.0);
+            for (size_t t = 0; t < ntables; t++) cost[t] = commit_cost_estimate(c, tables[t].ncols, tables[t].log_n, cfg->rate_bits);
+            run_on_lanes(c, big, small, cost, [&](zkm_ctx* w, size_t t) {
                 if (keep[t]) {
                     d_traces[t] = (gl_t*)w->alloc((tables[t].ncols << tables[t].log_n) * sizeof(gl_t));
                     d_owner[t] = w;
@@ -652,7 +691,11 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
         // "compute CTL data" :191-200 and each table's "compute auxiliary polynomials commitment" :511-522 (with its "compute lookup helper
         // columns" :475-493) depend on the CTL challenges only, not on the transcript of the table proofs: all tables' auxiliary
         // commitments are built now, side by side (run_on_lanes).  The transcript then observes them in table order, below.
-        run_on_lanes(c, big, small, [&](zkm_ctx* w, size_t t) {
+        std::vector<double> aux_cost(ntables, 0.0);          // CTL data + lookup columns read the trace once; then an `naux`-column commitment
+        for (size_t t = 0; t < ntables; t++)
+            aux_cost[t] = commit_cost_estimate(c, tz[t].naux + zkm_num_lookup_columns(tables[t].table_id, cfg), tables[t].log_n, cfg->rate_bits) +
+                          (double)(tables[t].ncols << tables[t].log_n) * 1e-10;
+        run_on_lanes(c, big, small, aux_cost, [&](zkm_ctx* w, size_t t) {
             if (tz[t].naux == 0) return;   // ("No CTL?" -- reported by prove_single_table in table order, prover.rs:509)
             const size_t n = (size_t)1 << tables[t].log_n, W = tables[t].ncols;
             const size_t NL = zkm_num_lookup_columns(tables[t].table_id, cfg), A = NL + tz[t].naux;
