@@ -87,7 +87,7 @@ BENCH_WORKER = textwrap.dedent("""
     torch.cuda.mem_get_info = lambda d=None: (200 << 30, 288 << 30)
     torch.cuda.get_device_properties = lambda d: types.SimpleNamespace(multi_processor_count=256)
     real_init = zd.init
-    zd.init = lambda backend=None: real_init("gloo")
+    zd.init = lambda backend=None: real_init(%r)
     NCTX = %d
     sys.argv = ["bench.py", "--gpus", "2", "--segments", "7", "--warmup", "1", "--log-n", "10", "--no-cpu-baseline", "--no-extras",
                 "--contexts", str(NCTX)]
@@ -107,13 +107,16 @@ BENCH_WORKER = textwrap.dedent("""
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("nctx", [1, 2])
-def test_bench_sharding_path_two_rank_gloo(tmp_path, nctx):
+@pytest.mark.parametrize("nctx,backend", [(1, "gloo"), (2, "gloo"), (2, "nccl")])
+def test_bench_sharding_path_two_rank_gloo(tmp_path, nctx, backend):
+    """backend "nccl": what the driver's multi-GPU run asks for.  There is no GPU here, so RCCL cannot come up -- the probe child of
+    every rank fails, the ranks agree on that over the gloo control group, and the job must finish on gloo and say so."""
     script = tmp_path / "bench_worker.py"
-    script.write_text(BENCH_WORKER % (ROOT, nctx, os.path.join(ROOT, "bench.py")))
+    script.write_text(BENCH_WORKER % (ROOT, backend, nctx, os.path.join(ROOT, "bench.py")))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(29517 + nctx), str(script)], capture_output=True, text=True, timeout=300, env=env)
+                        "127.0.0.1", "--master-port", str(29517 + nctx + (10 if backend == "nccl" else 0)), str(script)],
+                       capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "RANK0 OK" in r.stdout and "RANK1 OK" in r.stdout
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -124,6 +127,12 @@ def test_bench_sharding_path_two_rank_gloo(tmp_path, nctx):
     assert j["config"]["contexts_per_gpu"] == nctx and j["single_context"]["ms_per_step"] > 0
     assert j["timed_segments"] == 7 and j["timed_segments_per_gpu"] == 4 and j["config"]["distinct_traces_per_gpu"] == 4
     assert j["config"]["proofs_gathered_on_rank0"] == 7            # gathered over the process group after the clock stopped
+    if backend == "nccl":
+        assert j["config"]["process_group"].startswith("gloo (nccl failed: child-process probe failed"), j["config"]["process_group"]
+        assert "RCCL unavailable" in r.stderr
+    else:
+        assert j["config"]["process_group"] == "gloo"
+    assert j["config"]["preflight"]["world"] == 2 and r.stderr.count("zkm preflight rank=") == 2     # one pre-flight line per rank
     assert j["value"] > 0 and abs(j["value"] * j["ms_per_step"] * 4 / 7 / 1e3 - 1) < 1e-6   # value = total / elapsed, ms_per_step = elapsed / 4
 
 
@@ -193,3 +202,28 @@ def test_cpu_pinning_splits_the_allowed_cpus(monkeypatch):
     info = zd.pin_to_gpu(0, 1)
     assert info["pinned"] and info["how"] == "numa" and set_to["cpus"] == allowed[:max(1, len(allowed) // 2)]
     assert zd._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_forced_process_group_at_world_1():
+    """ZKM_FORCE_PG=1: a single process still builds the process group (the world-1 rehearsal of the RCCL path on a one-GPU box).  Here:
+    gloo requested -> gloo; nccl requested without a GPU -> probe fails -> gloo, with the reason recorded."""
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        from zkm_amd import dist as zd
+        assert zd.init(sys.argv[1]) == (1, 0, 0)
+        import torch.distributed as dist
+        assert dist.is_initialized() and dist.get_world_size() == 1
+        zd.barrier()
+        assert zd.max_over_ranks(1.25) == 1.25
+        assert list(zd.gather_proofs({3: np.arange(4)})) == [3]
+        print("PG", zd.process_group_info()["process_group"])
+        zd.shutdown()
+    """) % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["ZKM_FORCE_PG"] = "1"
+    for want, expect in (("gloo", "PG gloo\n"), ("nccl", "PG gloo (nccl failed: child-process probe failed")):
+        r = subprocess.run([sys.executable, "-c", code, want], capture_output=True, text=True, timeout=240, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert expect in r.stdout, r.stdout + r.stderr

@@ -3,8 +3,8 @@
 The reference proves segments one after another in one process (prover/examples/utils/src/utils.rs:57-68,
 105-133); segments are independent proofs, so the MI355X design is one process per GPU, round-robin
 assignment, and a host-side gather of the finished proofs (a few hundred KB each).  torch.distributed
-(backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests) carries only the barrier and the max-over-ranks
-time; the proof gather goes over a gloo side group (host memory to host memory, outside the clock).
+carries only the barrier and the max-over-ranks time (RCCL, i.e. backend "nccl" on ROCm, once it has been seen to
+work; gloo otherwise and in the CPU tests) and the proof gather (always the gloo control group, outside the clock).
 """
 import os
 import time
@@ -12,7 +12,6 @@ import time
 import torch
 import torch.distributed as dist
 
-_HOST_GROUP = None  # gloo side group for host-side object collectives when the main backend is nccl
 
 
 def env_world():
@@ -89,19 +88,167 @@ def pin_to_gpu(local_rank, local_world, device=None):
     return {"pinned": True, "how": how, "cpus": len(cpus), "first_cpu": cpus[0], "last_cpu": cpus[-1]}
 
 
+# The process group.  The CONTROL plane is always a gloo group (host memory, TCP on 127.0.0.1): rendezvous, agreement between the
+# ranks, and the gather of the finished proofs.  RCCL ("nccl") is a second group that carries what the clock needs -- the barrier
+# and the max-over-ranks time -- and is adopted only after every rank has seen it work: first in a throw-away child process per rank
+# (a hang there is killed by a timeout instead of hanging the job), then in this process, with the ranks agreeing on the outcome over
+# gloo.  Any failure leaves the job on gloo and says so in the bench line: RCCL carries one barrier and one MAX, it must not be able
+# to zero a measurement.
+_PG = {"group": None, "backend": None, "device": None, "info": None}
+
+
+def _quiet_stdout(fn):
+    """gloo announces its connections on STDOUT; rank 0's stdout must carry nothing but the JSON line: swap the descriptor while it connects."""
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        return fn()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def _all_agree(ok):
+    """True iff `ok` on every rank (MIN over the gloo control group)."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def _rccl_probe(world, rank, device, timeout_s):
+    """Run zkm_amd/rccl_probe.py as a child of every rank: its own RCCL communicator over a file store, barrier + all_reduce(MAX) on a
+    device tensor.  Returns (ok, detail)."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    box = [tempfile.mkdtemp(prefix="zkm_rccl_probe_") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    store = os.path.join(box[0], "store")
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_probe.py"), store, str(rank), str(world), str(device),
+           str(max(5, int(timeout_s) - 10))]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        line = ([l for l in r.stdout.splitlines() if l.startswith("{")] or ["{}"])[-1]
+        detail = json.loads(line)
+        ok = r.returncode == 0 and bool(detail.get("ok"))
+        if not ok:
+            detail.setdefault("error", (r.stderr.strip().splitlines() or ["exit code %d" % r.returncode])[-1][:300])
+    except subprocess.TimeoutExpired:
+        ok, detail = False, {"error": "probe timed out after %d s (killed)" % timeout_s}
+    except Exception as e:  # noqa: BLE001 -- whatever went wrong, the job continues on gloo
+        ok, detail = False, {"error": "%s: %s" % (type(e).__name__, e)}
+    detail["wall_s"] = round(time.perf_counter() - t0, 3)
+    all_ok = _all_agree(ok)
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(box[0], ignore_errors=True)
+    return all_ok, detail
+
+
+def _rccl_adopt(world, rank, device):
+    """Create the RCCL group in this process and run the two collectives the clock uses.  (ok-on-every-rank, detail)."""
+    import datetime
+    detail, g, ok = {}, None, False
+    t0 = time.perf_counter()
+    try:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # RCCL needs dmabuf IPC on this driver stack
+        dev = torch.device("cuda", device)
+        g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=int(os.environ.get("ZKM_RCCL_TIMEOUT_S", "300"))), device_id=dev)
+        detail["new_group_s"] = round(time.perf_counter() - t0, 3)
+        t1 = time.perf_counter()
+        dist.barrier(group=g, device_ids=[device])
+        t = torch.tensor([float(rank)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=g)
+        torch.cuda.synchronize(dev)
+        detail["first_barrier_allreduce_s"] = round(time.perf_counter() - t1, 3)
+        ok = float(t.item()) == float(world - 1)
+        if not ok:
+            detail["error"] = "all_reduce(MAX) of the ranks returned %r, expected %d" % (t.item(), world - 1)
+    except Exception as e:  # noqa: BLE001
+        detail["error"] = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:300] if str(e) else "")
+    return (_all_agree(ok), detail, g)
+
+
 def init(backend=None):
-    """Initialise the process group from torchrun's environment (no-op for a single process)."""
+    """Initialise the process group from torchrun's environment.  A single process does nothing unless ZKM_FORCE_PG=1 (the world-1
+    rehearsal of the whole RCCL path on the one GPU a development box has).  backend: "nccl" (RCCL; default when a GPU is visible) or
+    "gloo".  Returns (world, rank, local_rank); process_group_info() tells what was adopted."""
     world, rank, local_rank = env_world()
-    if world > 1 and not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        kw = {}
-        if backend == "nccl":
-            # RCCL needs dmabuf IPC on this driver stack (the image exports it; keep it for any env built by hand)
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dev = torch.cuda.current_device()   # the caller has set the rank's device (bench.py: check_gpus -> set_device)
-            kw["device_id"] = torch.device("cuda", dev)
-        dist.init_process_group(backend, **kw)
+    force = os.environ.get("ZKM_FORCE_PG") == "1"
+    if dist.is_initialized() or (world == 1 and not force):
+        return world, rank, local_rank
+    if world == 1:
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    want = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    t0 = time.perf_counter()
+    _quiet_stdout(lambda: dist.init_process_group("gloo"))
+    info = {"requested": want, "control": "gloo", "control_init_s": round(time.perf_counter() - t0, 3)}
+    _PG.update(group=None, backend="gloo", device=None, info=info)
+    if want == "nccl":
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0   # the caller has set the rank's device (bench.py)
+        ok, why = True, None
+        if os.environ.get("ZKM_RCCL_PROBE", "1") != "0":
+            ok, info["probe"] = _rccl_probe(world, rank, device, int(os.environ.get("ZKM_RCCL_PROBE_TIMEOUT_S", "180")))
+            why = None if ok else "child-process probe failed on at least one rank (this rank: %s)" % info["probe"].get("error", "ok")
+        if ok:
+            ok, info["adopt"], g = _rccl_adopt(world, rank, device)
+            if ok:
+                _PG.update(group=g, backend="nccl", device=device)
+            else:
+                why = "in-process group failed on at least one rank (this rank: %s)" % info["adopt"].get("error", "ok")
+        info["process_group"] = "nccl" if ok else "gloo (nccl failed: %s)" % why
+        if not ok and rank == 0:
+            import sys
+            print("zkm_amd.dist: RCCL unavailable, barrier and max-over-ranks stay on gloo: %s" % why, file=sys.stderr)
+    else:
+        info["process_group"] = "gloo"
     return world, rank, local_rank
+
+
+def process_group_info():
+    """What init() adopted: {"process_group": "nccl" | "gloo" | "gloo (nccl failed: ...)", "probe": ..., "adopt": ...}; None without a group."""
+    return _PG["info"]
+
+
+def backend():
+    return _PG["backend"] if dist.is_initialized() else None
+
+
+def preflight(device, world, rank, local_rank, need_bytes=0, free_bytes=None, pin=None, what=""):
+    """Before the clock: one line per rank on stderr with what a failed multi-GPU run is usually explained by -- visible devices, free
+    HBM against what this rank is about to allocate, hardware queues, CPU affinity, the process group adopted.  Returns the same as a
+    dict (rank 0's goes into the bench line).  Raises SystemExit only when the memory cannot fit."""
+    import sys
+    ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if free_bytes is None and ngpu:
+        free_bytes = torch.cuda.mem_get_info(device)[0]
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        ncpu = os.cpu_count()
+    info = {"rank": rank, "world": world, "local_rank": local_rank, "device": device, "gpus_visible": ngpu,
+            "free_hbm_gib": round((free_bytes or 0) / 2.0**30, 1), "need_hbm_gib": round(need_bytes / 2.0**30, 1), "need": what,
+            "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+            "cpus_allowed": ncpu, "pinned": bool(pin and pin.get("pinned")),
+            "process_group": (_PG["info"] or {}).get("process_group", "none (single process)")}
+    print("zkm preflight " + " ".join("%s=%s" % (k, str(v).replace(" ", "_")) for k, v in info.items()), file=sys.stderr, flush=True)
+    if free_bytes is not None and need_bytes > free_bytes:
+        raise SystemExit("zkm_amd.dist: rank %d needs %.1f GiB of HBM on device %d (%s) but %.1f GiB are free" % (
+            rank, need_bytes / 2.0**30, device, what, free_bytes / 2.0**30))
+    return info
 
 
 def assign_segments(num_segments, world, rank):
@@ -110,7 +257,11 @@ def assign_segments(num_segments, world, rank):
 
 
 def barrier():
-    if dist.is_initialized():
+    if not dist.is_initialized():
+        return
+    if _PG["backend"] == "nccl":
+        dist.barrier(group=_PG["group"], device_ids=[_PG["device"]])
+    else:
         dist.barrier()
 
 
@@ -118,33 +269,22 @@ def max_over_ranks(seconds):
     """Whole-job time = the slowest rank."""
     if not dist.is_initialized():
         return float(seconds)
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if _PG["backend"] == "nccl":
+        t = torch.tensor([seconds], dtype=torch.float64, device=torch.device("cuda", _PG["device"]))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_PG["group"])
+    else:
+        t = torch.tensor([seconds], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def gather_proofs(local):
-    """local: {segment_index: proof ndarray}.  Returns the merged dict on rank 0 (None elsewhere).  Host objects travel over the
-    gloo side group when the main backend is RCCL (no detour through device memory)."""
-    global _HOST_GROUP
+    """local: {segment_index: proof ndarray}.  Returns the merged dict on rank 0 (None elsewhere).  Host objects travel over the gloo
+    control group (host memory to host memory, no detour through the device), after the clock has stopped."""
     if not dist.is_initialized():
         return dict(local)
-    if dist.get_backend() == "nccl" and _HOST_GROUP is None:
-        # created on first use (a collective call: every rank gathers or none does): gloo announces its connections on STDOUT, and a run
-        # that gathers nothing -- the driver's scaling runs -- must print nothing but rank 0's JSON line
-        # (... and the announcement itself goes to stderr: the descriptor is swapped while the group connects)
-        import sys
-        sys.stdout.flush()
-        saved = os.dup(1)
-        try:
-            os.dup2(2, 1)
-            _HOST_GROUP = dist.new_group(backend="gloo")
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
     out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
-    dist.gather_object(local, out, dst=0, group=_HOST_GROUP)
+    dist.gather_object(local, out, dst=0)
     if dist.get_rank() != 0:
         return None
     merged = {}
@@ -157,10 +297,12 @@ def gather_proofs(local):
 
 
 def shutdown():
-    global _HOST_GROUP
     if dist.is_initialized():
-        dist.destroy_process_group()
-    _HOST_GROUP = None
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 -- the measurement is printed already; a teardown error must not turn the exit code
+            pass
+    _PG.update(group=None, backend=None, device=None)
 
 
 def run_workers(prove_fn, segments, workers):
