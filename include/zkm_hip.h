@@ -51,6 +51,13 @@ void zkm_ctx_trim(zkm_ctx* ctx);
  *   "quad_max_hashes"           up to this many a quad of lanes (default 16384): the latency forms of the Poseidon permutation, at
  *                               4.2x / 1.9x the issue slots of the one-lane form.  0 and 0: one lane per hash everywhere (a GPU shared
  *                               by many contexts proving small segments may prefer throughput; measured in profiles/r03_hw_queues.txt)
+ *   "block_after_us"            a transcript round trip (cap, opening partials, proof-of-work witness coming down) is waited for by
+ *                               polling a flag in pinned memory; after this many microseconds (default 50) a thread of a CROWDED
+ *                               process -- more than half as many threads waiting as CPUs the process may run on -- parks on a
+ *                               blocking-sync event instead, leaving its core to the other contexts.  0: always park.
+ *   "debug_fail_allocs"         TEST HOOK: the next `value` device allocations of the context and its lanes fail on their first
+ *                               attempt as if out of memory, so the recovery path (trim the caches -- this context's, then the
+ *                               parent's and the sibling lanes' -- and retry) runs; proofs are unchanged (tests/test_segment.py)
  * An unknown key is an error.  Applies to the context and its commit lanes. */
 int zkm_ctx_set_tuning(zkm_ctx* ctx, const char* key, uint64_t value, char** err);
 /* Pinned host memory (N3, trace ingest): host-resident traces (the reference's Vec<PolynomialValues>, prover.rs:144-167) are

@@ -213,6 +213,32 @@ def test_segment_at_2_16_cycle_heights_is_bit_exact(ctx, zkm, oracle):
 
 
 @pytest.mark.gpu
+def test_out_of_memory_retry_while_lanes_are_active(zkm):
+    """the allocator's out-of-memory path trims caches -- its own, then the parent's and the sibling lanes' -- while the
+    commit lanes of the same segment are allocating and releasing on their own threads.  The "debug_fail_allocs" hook makes device
+    allocations fail on their first attempt (every second one also on the retry, which sends it into the family path); the proofs of
+    such a segment must equal those of an undisturbed one, repeatedly, and the memory accounting must come back to zero."""
+    import os
+    seg = np.load(os.path.join(os.path.dirname(__file__), "golden", "segment12.npz"))
+    log_n = [int(x) for x in seg["log_n"]]
+    traces = [seg["t%d" % i] for i in range(12)]
+    c = zkm.Context(0)
+    try:
+        want, wchal, woffs = c.prove_segment(traces, log_n, public_values=[1, 2, 3])     # also fills every cache
+        for rounds, k in enumerate((40, 400, 100000)):
+            c.set_tuning("debug_fail_allocs", k)
+            got, chal, offs = c.prove_segment(traces, log_n, public_values=[1, 2, 3])
+            assert offs == woffs and (chal == wchal).all() and (got == want).all(), (rounds, k)
+        c.set_tuning("debug_fail_allocs", 0)
+        got, chal, offs = c.prove_segment(traces, log_n, public_values=[1, 2, 3])
+        assert (got == want).all()
+        live, cached = c.memory()
+        assert live == c.resident_bytes()
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_segments_proven_side_by_side_are_bit_exact(ctx, zkm):
     """Twelve-table segments from three contexts working at the same time (host traces: each call uploads, commits and proves)
     equal the segment proof of one context working alone."""

@@ -1,6 +1,9 @@
 // core.hip -- context, memory, profiling, Fiat-Shamir transcript and the PolynomialBatch part of the C ABI.
 #include <sched.h>
+#include <time.h>
+#include <stdio.h>
 #include <algorithm>
+#include <atomic>
 
 #include "poseidon_dev.h"
 #include "zkm_internal.h"
@@ -25,35 +28,67 @@ static int fail(char** err, const std::string& msg) {
     return 0;
 
 // ------------------------------------------------------------------ ctx
+// The allocator of a context is used by ONE thread at a time (its owner, or the lane thread of run_on_lanes) -- except for the
+// out-of-memory path, which reaches into the caches of the parent and sibling contexts: every allocator therefore has a mutex, held
+// for the map operations only (never across hipMalloc of another context's lock: one lock at a time, no ordering to get wrong).
 void* zkm_ctx::alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;
-    auto it = free_blocks.find(bytes);
     void* p = nullptr;
-    if (it != free_blocks.end()) {
-        p = it->second;
-        free_blocks.erase(it);
-    } else {
-        hipError_t e = hipMalloc(&p, bytes);
+    {
+        std::lock_guard<std::mutex> g(alloc_mu);
+        auto it = free_blocks.find(bytes);
+        if (it != free_blocks.end()) {
+            p = it->second;
+            free_blocks.erase(it);
+            live_blocks[p] = bytes;
+            return p;
+        }
+    }
+    zkm_ctx* const root = parent ? parent : this;
+    // (test hook, zkm_ctx_set_tuning "debug_fail_allocs" = k: the next k first attempts of the family fail as if out of memory, so the
+    // retry path -- trimming caches while the lanes work -- runs where a test can watch it)
+    const int ticket = root->debug_fail_allocs.load(std::memory_order_relaxed) > 0 ? root->debug_fail_allocs.fetch_sub(1) : 0;
+    const bool inject = ticket > 0;
+    hipError_t e = inject ? hipErrorOutOfMemory : hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // Drop the caches and retry once (the failed call's error must not stay behind as the "last error" of the next launch check):
+        // this context's own cache first, then -- gigabytes may sit cached next door while this lane starves -- the caches of the
+        // family (parent and sibling lanes).  Only CACHED blocks are freed, under their owner's lock; nothing another thread is using.
+        (void)hipGetLastError();
+        trim_self();
+        e = (inject && (ticket & 1)) ? hipErrorOutOfMemory : hipMalloc(&p, bytes);   // (the hook sends some requests on to the family path)
         if (e != hipSuccess) {
-            // drop the cache and retry once; the failed call's error must not stay behind as the "last error" of the next launch check
             (void)hipGetLastError();
-            trim();
+            if (root != this) root->trim_self();
+            for (zkm_ctx* l : root->lanes)
+                if (l != this) l->trim_self();
             ZKM_HIP_CHECK(hipMalloc(&p, bytes));
         }
     }
+    std::lock_guard<std::mutex> g(alloc_mu);
     live_blocks[p] = bytes;
     return p;
 }
-void zkm_ctx::trim() {
-    (void)hipStreamSynchronize(stream);  // cached blocks may still be in use by queued kernels
-    if (copy_stream) (void)hipStreamSynchronize(copy_stream);  // ... or be the target of an upload still in flight
-    for (auto& kv : free_blocks) (void)hipFree(kv.second);
-    free_blocks.clear();
-    for (zkm_ctx* l : lanes) l->trim();
+// Cached blocks may still be read or written by kernels queued on the owner's streams (a block is released as soon as the host is
+// done with it, not the GPU): the streams are drained before anything is freed.  hipStreamSynchronize from a foreign thread is safe.
+void zkm_ctx::trim_self() {
+    std::multimap<size_t, void*> drop;
+    {
+        std::lock_guard<std::mutex> g(alloc_mu);
+        drop.swap(free_blocks);                                // from here on nobody can be handed these blocks again ...
+    }
+    (void)hipStreamSynchronize(stream);                        // ... and what was queued on them before has completed after this
+    if (copy_stream) (void)hipStreamSynchronize(copy_stream);  // (or was the target of an upload in flight)
+    for (auto& kv : drop) (void)hipFree(kv.second);
+}
+void zkm_ctx::trim() {   // public: between calls (zkm_ctx_trim)
+    trim_self();
+    for (zkm_ctx* l : lanes) l->trim_self();
 }
 void zkm_ctx::ensure_lanes(size_t k) {
     while (lanes.size() < k) {
         zkm_ctx* l = new zkm_ctx();
+        l->parent = this;
         l->device = device;
         l->num_cus = num_cus;
         l->ingest_chunk_cols = ingest_chunk_cols;
@@ -72,6 +107,7 @@ void zkm_ctx::ensure_lanes(size_t k) {
 }
 void zkm_ctx::release(void* p) {
     if (!p) return;
+    std::lock_guard<std::mutex> g(alloc_mu);
     auto it = live_blocks.find(p);
     if (it == live_blocks.end()) return;
     free_blocks.emplace(it->second, p);
@@ -112,6 +148,52 @@ void zkm_ctx::ensure_xfer() {
     }
     memset(h_xfer + XFER_DOWN + XFER_UP, 0, 64);
 }
+// Waiting for the flag.  A spinning thread sees the words ~40 us earlier than one the runtime has to wake -- as long as it has a core
+// to spin on.  The deployed shape is 8 ranks x k contexts x ZKM_COMMIT_LANES threads on one host, each rank confined to its GPU's share
+// of the cores (zkm_amd/dist.py pin_to_gpu): once the threads waiting in this process outnumber half of the CPUs it may run on,
+// spinning steals the cores the other contexts need to launch their kernels.  So: spin for `block_after_us` (default 50 us: most round
+// trips of an idle GPU end inside it); after that, a crowded process parks the thread on a blocking-sync event (interrupt-driven
+// wake-up) while an uncrowded one keeps polling with sched_yield.
+static std::atomic<int> g_waiting{0};
+static int allowed_cpus() {
+    static const int n = [] {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return (int)CPU_COUNT(&set);
+        return 1 << 20;
+    }();
+    return n;
+}
+static inline uint64_t now_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+void zkm_ctx::wait_flag(const uint64_t* flag, uint64_t seq) {
+    struct waiter { waiter() { g_waiting.fetch_add(1, std::memory_order_relaxed); } ~waiter() { g_waiting.fetch_sub(1, std::memory_order_relaxed); } } w;
+    const uint64_t t0 = now_ns(), spin_ns = (parent ? parent : this)->block_after_us * 1000ull;
+    for (uint64_t spins = 1;; spins++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return;
+        if (spins % 256 == 0 && now_ns() - t0 > spin_ns) {
+            if (2 * g_waiting.load(std::memory_order_relaxed) > allowed_cpus() || spin_ns == 0) {
+                if (!block_event) ZKM_HIP_CHECK(hipEventCreateWithFlags(&block_event, hipEventBlockingSync | hipEventDisableTiming));
+                ZKM_HIP_CHECK(hipEventRecord(block_event, stream));      // behind k_download on the in-order stream
+                ZKM_HIP_CHECK(hipEventSynchronize(block_event));         // (complete: the words are in host memory whatever the flag's cache line says)
+                blocked_waits++;
+                return;
+            }
+            if (spins % 8192 == 0) {                                  // has the stream failed (or finished unseen)?
+                hipError_t e = hipStreamQuery(stream);
+                if (e == hipSuccess) return;
+                if (e != hipErrorNotReady) ZKM_HIP_CHECK(e);
+            }
+            sched_yield();                                            // a long wait (the GPU is busy with other contexts): let other threads run
+        }
+#if defined(__x86_64__)
+        else __builtin_ia32_pause();
+#endif
+    }
+}
 void zkm_ctx::download(std::initializer_list<xfer> xs) {
     ensure_xfer();
     constexpr size_t XFER_KERNEL = (size_t)1 << 16;
@@ -137,18 +219,7 @@ void zkm_ctx::download(std::initializer_list<xfer> xs) {
         const uint64_t seq = ++down_seq;
         hipLaunchKernelGGL(k_download, dim3(1), dim3(1024), 0, stream, a, flag, seq);
         ZKM_HIP_CHECK(hipGetLastError());
-        for (uint64_t spins = 1;; spins++) {
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
-            if (spins % 8192 == 0) {                              // every few tens of microseconds: has the stream failed (or finished unseen)?
-                hipError_t e = hipStreamQuery(stream);
-                if (e == hipSuccess) break;                       // (complete: the words are in host memory whatever the flag's cache line says)
-                if (e != hipErrorNotReady) ZKM_HIP_CHECK(e);
-            }
-            if (spins > 32768) sched_yield();                     // a long wait (the GPU is busy with other contexts): let other threads run
-#if defined(__x86_64__)
-            else __builtin_ia32_pause();
-#endif
-        }
+        wait_flag(flag, seq);
         up_off = 0;                                               // everything queued before the kernel has completed, uploads included
         off = 0;
         for (const xfer& x : xs) {
@@ -227,8 +298,14 @@ const zkm_table_lookup* zkm_table_lookups(int table_id, size_t* n) {
 // run their kernels one after the other.  A process proving small segments with k contexts has k x ZKM_COMMIT_LANES streams (+ copy streams) whose
 // kernels are short and meant to overlap: with 8 contexts, 43 segments/s at 4 queues, 50 at 8, 57 at 16, 47 at 32
 // (profiles/r03_hw_queues.txt; the 2^20-row proofs do not care).  The variable is read when the runtime initialises, i.e. at the first
-// HIP call of the process: set it when this library is loaded, unless the operator has chosen a value.
-__attribute__((constructor)) static void zkm_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// HIP call of the PROCESS: it belongs to the launcher (bench.py, tools/run_config3.sh, the Rust host's main()) -- a
+// shared library does not edit the environment of the process that loads it.  zkm_ctx_create reports an unset variable once, on stderr.
+static void zkm_hw_queues_hint() {
+    static std::atomic<bool> said{false};
+    if (getenv("GPU_MAX_HW_QUEUES") || getenv("ZKM_QUIET") || said.exchange(true)) return;
+    fprintf(stderr, "zkm-hip: GPU_MAX_HW_QUEUES is not set (runtime default: 4 hardware queues); small-segment throughput with several "
+                    "contexts is ~25 %% higher with GPU_MAX_HW_QUEUES=16 exported before the first HIP call (see INTEGRATION.md)\n");
+}
 
 extern "C" {
 
@@ -246,6 +323,7 @@ int zkm_ctx_create(int device, zkm_ctx** out, char** err) {
     ZKM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
     ZKM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    zkm_hw_queues_hint();
     *out = c;
     ZKM_API_END(err)
 }
@@ -263,6 +341,7 @@ void zkm_ctx_destroy(zkm_ctx* c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->h_staging) (void)hipHostFree(c->h_staging);
     if (c->h_xfer) (void)hipHostFree(c->h_xfer);
+    if (c->block_event) (void)hipEventDestroy(c->block_event);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -277,6 +356,8 @@ int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) 
         else if (k == "fri_fused_division_min") x->fri_fused_division_min = (size_t)value;
         else if (k == "wide_max_hashes") x->wide_max_hashes = (size_t)value;
         else if (k == "quad_max_hashes") x->quad_max_hashes = (size_t)value;
+        else if (k == "block_after_us") x->block_after_us = value;
+        else if (k == "debug_fail_allocs") { if (x == c) x->debug_fail_allocs.store((int)value); }
         else throw std::runtime_error("zkm_ctx_set_tuning: unknown key '" + k + "'");
     };
     set(c);

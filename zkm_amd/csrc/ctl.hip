@@ -576,7 +576,10 @@ static void run_on_lanes(zkm_ctx* c, const std::vector<size_t>& big, const std::
         try {
             ZKM_HIP_CHECK(hipSetDevice(c->device));
             if (take_big)
-                for (size_t t : big) fn(w, t);
+                for (size_t t : big) {
+                    if (failed.load()) break;                // a lane threw: do not commit the remaining big tables before reporting it
+                    fn(w, t);
+                }
             for (size_t t : mine[slot]) {
                 if (failed.load()) break;                    // another worker threw: stop starting new tables
                 fn(w, t);

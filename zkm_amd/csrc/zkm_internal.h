@@ -5,7 +5,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <stdexcept>
 #include <string>
@@ -54,6 +56,9 @@ struct zkm_ctx {
     // caching allocator: exact-size free lists
     std::multimap<size_t, void*> free_blocks;
     std::map<void*, size_t> live_blocks;
+    std::mutex alloc_mu;                // guards the two maps (the out-of-memory path of a relative trims this cache from its thread)
+    zkm_ctx* parent = nullptr;          // of a commit lane: the context that owns it
+    std::atomic<int> debug_fail_allocs{0};   // test hook (root context only): pretend the next k hipMalloc first attempts fail
     // twiddles
     zkm_twiddles tw;
     // power tables for coset scaling: key (shift, log_n) -> device ptr [lo table 2^h | hi table 2^(log_n-h)]
@@ -73,7 +78,8 @@ struct zkm_ctx {
 
     void* alloc(size_t bytes);
     void release(void* p);
-    void trim();  // hipFree every cached (not live) block
+    void trim_self();  // hipFree every cached (not live) block of THIS allocator (any thread: used by a relative's out-of-memory retry)
+    void trim();       // ... and of the lanes; only between calls
     void ensure_twiddles(unsigned log_n);
     const gl_t* pow_table(uint64_t shift, unsigned log_n);  // lo: 2^ceil(log_n/2) entries, then hi
     uint64_t* staging(size_t words);
@@ -87,6 +93,10 @@ struct zkm_ctx {
     char* h_xfer = nullptr;                                      // [0, XFER_DOWN): downloads, [XFER_DOWN, XFER_DOWN + XFER_UP): upload ring,
                                                                  // then one cache line for the completion flag of k_download
     uint64_t down_seq = 0;
+    void wait_flag(const uint64_t* flag, uint64_t seq);          // spin, then (crowded process) block: core.hip
+    uint64_t block_after_us = 50;                                // } zkm_ctx_set_tuning "block_after_us" (0: always block)
+    hipEvent_t block_event = nullptr;
+    uint64_t blocked_waits = 0;                                  // round trips that ended in the blocking wait (diagnostic)
     void ensure_xfer();
     size_t up_off = 0;
     static constexpr size_t XFER_DOWN = (size_t)1 << 20, XFER_UP = (size_t)1 << 18;
