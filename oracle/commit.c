@@ -12,10 +12,19 @@
  * Storage mirrors the HIP product: LDE kept column-major with rows already in bit-reversed order
  * (lde[c*N + j] = natural evaluation bitrev(j)), so "leaf j" is row j across columns.
  */
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 #include "zkm_oracle.h"
 #include "gl.h"
+
+/* Threads of the LONG row-/column-parallel regions (leaf hashing, per-column LDE of a big batch): these scale to every core of the
+ * host, unlike the many short regions whose fork/join cost caps the default (oracle_py.py _default_threads).  0 = the default. */
+static int g_wide_threads = 0;
+void zko_set_wide_threads(int n) { g_wide_threads = n > 0 ? n : 0; }
+static int wide_threads(size_t work_words) {
+    return (g_wide_threads > 0 && work_words >= ((size_t)1 << 24)) ? g_wide_threads : omp_get_max_threads();
+}
 
 uint64_t zko_gl_mul(uint64_t a, uint64_t b) { return gl_mul(a, b); }
 uint64_t zko_gl_inv(uint64_t a) { return gl_inv(a); }
@@ -108,7 +117,7 @@ static void merkle_build_inner(merkle_t* m) {
         size_t cnt = (size_t)1 << (m->log_leaves - l);
         const uint64_t* ch = m->nodes + m->off[l - 1];
         uint64_t* pa = m->nodes + m->off[l];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(wide_threads(cnt * 64))
         for (size_t i = 0; i < cnt; i++) zko_poseidon_two_to_one(ch + 8 * i, ch + 8 * i + 4, pa + 4 * i);
     }
 }
@@ -157,7 +166,7 @@ static zko_batch* batch_finish(zko_batch* b) {
     unsigned log_N = b->log_n + b->rate_bits;
     b->lde = (gl_t*)malloc(sizeof(gl_t) * b->ncols * N);
     gl_t* tw = make_twiddles(log_N, gl_root_of_unity(log_N));
-#pragma omp parallel
+#pragma omp parallel num_threads(wide_threads(b->ncols * N))
     {
         gl_t* tmp = (gl_t*)malloc(sizeof(gl_t) * N);
 #pragma omp for schedule(dynamic)
@@ -175,7 +184,7 @@ static zko_batch* batch_finish(zko_batch* b) {
     /* leaves: row j across columns */
     merkle_t* m = (merkle_t*)malloc(sizeof(merkle_t));
     merkle_alloc(m, log_N, b->cap_height);
-#pragma omp parallel
+#pragma omp parallel num_threads(wide_threads(b->ncols * N))
     {
         gl_t* row = (gl_t*)malloc(sizeof(gl_t) * b->ncols);
 #pragma omp for schedule(static)

@@ -96,6 +96,12 @@ class Oracle:
         self._gomp.omp_set_num_threads(int(n))
         self.threads = int(n)
 
+    def set_wide_threads(self, n):
+        """Threads of the long row-/column-parallel regions of a big commitment (leaf hashing, per-column LDE, lower Merkle levels):
+        they scale to every host core, the short regions do not.  0: same as set_threads."""
+        self.lib.zko_set_wide_threads(int(n))
+        self.wide_threads = int(n)
+
     def get_threads(self):
         if self._gomp is None:
             self._gomp = C.CDLL("libgomp.so.1")

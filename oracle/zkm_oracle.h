@@ -71,6 +71,7 @@ typedef struct {
 void zko_challenger_init(zko_challenger*);
 void zko_challenger_observe(zko_challenger*, const uint64_t* elems, size_t n);
 uint64_t zko_challenger_get(zko_challenger*);
+void zko_set_wide_threads(int n);   /* threads of the long row-parallel regions (0 = same as the rest) */
 void zko_challenger_compact(zko_challenger*, uint64_t state_out[12]);
 
 /* ---- synthetic PoseidonStark trace (poseidon_stark.rs:104-160) ---- */

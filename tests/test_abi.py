@@ -154,3 +154,167 @@ def test_rust_sys_block_names_every_export(zkm):
     text = open(os.path.join(ROOT, "integration", "rust", "zkm_hip_sys.rs")).read()
     rust = set(re.findall(r"pub fn (zkm_[a-z0-9_]+)\s*\(", text))
     assert rust == set(header_functions()), rust ^ set(header_functions())
+
+
+# ------------------------------------------------------------------ struct layouts: header == ctypes / numpy mirrors == Rust mirror
+def c_layouts(tmp_path):
+    """sizeof / offsetof of every struct of include/zkm_hip.h, from the C compiler (tools/abi_layout.c built with gcc as C99)."""
+    import json
+    import subprocess
+    exe = str(tmp_path / "abi_layout")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tools", "abi_layout.c")])
+    return json.loads(subprocess.check_output([exe]))
+
+
+def header_structs():
+    """{struct name: [field names in declaration order]} parsed from the header text (comments stripped)."""
+    text = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "zkm_hip.h")).read(), flags=re.S)
+    out = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(zkm_[a-z0-9_]+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in filter(None, (d.strip() for d in body.split(";"))):
+            # "const uint64_t* const* columns" / "uint32_t a, b" / "size_t x[3], y": the names are the identifiers before , [ or the end
+            decl = re.sub(r"\[[^\]]*\]", "", decl)
+            first, *rest = decl.split(",")
+            fields.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", first)[-1])
+            fields += [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", r)[-1] for r in rest]
+        out[name] = fields
+    return out
+
+
+def test_abi_layout_tool_covers_every_header_struct(tmp_path):
+    """tools/abi_layout.c must list every struct of the header with every field, in order: a field added to the header and forgotten
+    there (or in a mirror, below) is an error here, not a silent hole in the lock."""
+    lay = c_layouts(tmp_path)
+    hdr = header_structs()
+    assert set(lay) == set(hdr), set(lay) ^ set(hdr)
+    for name, fields in hdr.items():
+        assert [f[0] for f in lay[name]["fields"]] == fields, name
+        # fields tile the struct without overlap, in order
+        end = 0
+        for _, off, size in lay[name]["fields"]:
+            assert off >= end, name
+            end = off + size
+        assert end <= lay[name]["size"], name
+
+
+def test_python_mirrors_match_the_c_layout(zkm, tmp_path):
+    """The ctypes Structures and numpy dtypes that cross the C ABI (zkm_amd/__init__.py, zkm_amd/ctl.py) against the compiler's layout:
+    total size, and offset + size of every field in declaration order."""
+    import numpy as np
+    lay = c_layouts(tmp_path)
+    mirrors = zkm.abi_mirrors()
+    assert set(mirrors) == set(lay), set(mirrors) ^ set(lay)
+    for name, m in mirrors.items():
+        want = [(off, size) for _, off, size in lay[name]["fields"]]
+        if isinstance(m, np.dtype):
+            got = [(m.fields[f][1], m.fields[f][0].itemsize) for f in m.names]
+            size = m.itemsize
+            if name == "zkm_cross_table_lookup":      # the nested zkm_ctl_side `looked` is flattened into two u32 in the dtype
+                got = got[:2] + [(got[2][0], got[2][1] + got[3][1])]
+                assert m.names[2:] == ("looked_table", "looked_colset") and got[2][1] == lay["zkm_ctl_side"]["size"]
+            names = None
+        else:
+            got = [(getattr(m, f).offset, getattr(m, f).size) for f, _ in m._fields_]
+            size = C.sizeof(m)
+            names = [f for f, _ in m._fields_]
+        assert size == lay[name]["size"], (name, size, lay[name]["size"])
+        assert got == want, (name, got, want)
+        if names is not None:
+            assert names == [f[0] for f in lay[name]["fields"]], name
+
+
+RUST_PRIM = {"u64": (8, 8), "usize": (8, 8), "u32": (4, 4), "c_uint": (4, 4), "c_int": (4, 4), "i32": (4, 4), "u8": (1, 1)}
+
+
+def rust_structs():
+    """{name: [(field, type text)]} of the #[repr(C)] structs in integration/rust/zkm_hip_sys.rs (uncompiled here: parsed)."""
+    text = open(os.path.join(ROOT, "integration", "rust", "zkm_hip_sys.rs")).read()
+    text = re.sub(r"//[^\n]*", "", text)
+    out = {}
+    for m in re.finditer(r"#\[repr\(C\)\][^{;]*?pub struct (zkm_[a-z0-9_]+)\s*\{(.*?)\}", text, flags=re.S):
+        fields = []
+        for f in filter(None, (x.strip() for x in re.split(r",(?![^\[]*\])", m.group(2)))):
+            fm = re.match(r"(?:pub\s+)?([A-Za-z_][A-Za-z0-9_]*)\s*:\s*(.+)$", f, flags=re.S)
+            assert fm, (m.group(1), f)
+            fields.append((fm.group(1), " ".join(fm.group(2).split())))
+        out[m.group(1)] = fields
+    return out
+
+
+def rust_type_layout(ty, structs, memo):
+    """(size, align) of a Rust type under repr(C) on x86-64 / LP64."""
+    if ty.startswith("*const") or ty.startswith("*mut"):
+        return 8, 8
+    arr = re.match(r"\[(.+);\s*(\d+)\]$", ty)
+    if arr:
+        s, a = rust_type_layout(arr.group(1).strip(), structs, memo)
+        return s * int(arr.group(2)), a
+    if ty in RUST_PRIM:
+        return RUST_PRIM[ty]
+    assert ty in structs, "unknown Rust type %r" % ty
+    return rust_struct_layout(ty, structs, memo)[:2]
+
+
+def rust_struct_layout(name, structs, memo):
+    if name not in memo:
+        off, align, fields = 0, 1, []
+        for f, ty in structs[name]:
+            s, a = rust_type_layout(ty, structs, memo)
+            off = (off + a - 1) // a * a
+            fields.append((f, off, s))
+            off += s
+            align = max(align, a)
+        memo[name] = ((off + align - 1) // align * align, align, fields)
+    return memo[name]
+
+
+def test_rust_mirror_matches_the_c_layout(tmp_path):
+    """The #[repr(C)] structs of integration/rust/zkm_hip_sys.rs, laid out by the repr(C) rules (fields in order, each aligned to its
+    type, size rounded to the struct's alignment), against the compiler's layout of the header -- names, offsets, sizes, total size."""
+    lay = c_layouts(tmp_path)
+    structs = rust_structs()
+    opaque = {k for k, v in structs.items() if [f for f, _ in v] == ["_p"]}
+    assert opaque == {"zkm_ctx", "zkm_batch"}
+    assert set(structs) - opaque == set(lay), (set(structs) - opaque) ^ set(lay)
+    memo = {}
+    for name in lay:
+        size, align, fields = rust_struct_layout(name, structs, memo)
+        assert [list(f) for f in fields] == lay[name]["fields"], (name, fields, lay[name]["fields"])
+        assert (size, align) == (lay[name]["size"], lay[name]["align"]), name
+
+
+def build_c_smoke(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_smoke")
+    libdir = os.path.join(ROOT, "zkm_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "c_smoke.c"), "-L" + libdir, "-lzkmhip", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_pure_c_caller_builds_and_reports_errors(zkm, oracle, tmp_path):
+    """tools/c_smoke.c: the header used from pedantic C99 and linked against libzkmhip.so with no Python in the process.  Without a GPU
+    the run must end in the library's error channel (nonzero status + malloc'd message), not in a crash."""
+    import subprocess
+    import numpy as np
+    from zkm_amd import tables as T
+    exe = build_c_smoke(tmp_path)
+    seg = np.load(os.path.join(ROOT, "tests", "golden", "segment12.npz"))
+    log_n = [int(x) for x in seg["log_n"]]
+    ctl_tables, ctls = T.all_cross_table_lookups()
+    tables = [(T.TABLE_ENUM_ORDER[i], seg["t%d" % i], T.WIDTH[T.TABLE_ENUM_ORDER[i]], log_n[i], ctl_tables[i]) for i in range(12)]
+    img = zkm.segment_image(tables, ctls, public_values=[1, 2, 3])
+    path = tmp_path / "segment.zkmtrace"
+    img.tofile(path)
+    r = subprocess.run([exe, str(path), str(tmp_path / "proofs.bin")], capture_output=True, text=True, timeout=120)
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stderr
+    else:
+        assert r.returncode == 1 and "c_smoke: zkm_ctx_create:" in r.stderr, (r.returncode, r.stderr)
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"NOTATRACE" + b"\0" * 119)
+    r = subprocess.run([exe, str(bad), str(tmp_path / "p.bin")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "magic" in r.stderr

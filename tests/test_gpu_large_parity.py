@@ -104,7 +104,8 @@ def test_proof_is_bit_exact_2_20(ctx, zkm, oracle_proof_2_20):
     if os.path.isdir(out):
         import json
         json.dump({"what": "CPU oracle (scalar C restatement, OpenMP), one full prove_single_table of PoseidonStark 262 x 2^20 (seed 100)",
-                   "full_size_s": oracle_proof_2_20["seconds"], "threads": oracle_proof_2_20["threads"], "host_cores": os.cpu_count(),
+                   "full_size_s": oracle_proof_2_20["seconds"], "threads": oracle_proof_2_20["threads"],
+                   "wide_threads": oracle_proof_2_20.get("wide_threads"), "host_cores": os.cpu_count(),
                    "stage_s": dict(zip(["compute trace commitment", "compute auxiliary polynomials commitment", "compute quotient polys",
                                         "compute quotient commitment", "openings (StarkOpeningSet::new)", "compute openings proof: combine + final LDE",
                                         "compute openings proof: commit phase + PoW", "compute openings proof: query rounds"], oracle_proof_2_20["stage_s"]))},

@@ -213,6 +213,33 @@ def test_segment_at_2_16_cycle_heights_is_bit_exact(ctx, zkm, oracle):
 
 
 @pytest.mark.gpu
+def test_pure_c_caller_proves_the_segment_image(ctx, zkm, oracle, tmp_path):
+    """tools/c_smoke.c (pedantic C99, linked against libzkmhip.so, no Python in the process) proves the twelve-table test segment from a
+    ZKMTRACE file: its proof blobs equal the ctypes path's and the oracle's word for word."""
+    import os
+    import subprocess
+    from zkm_amd import tables as T
+    from tests.test_abi import build_c_smoke
+    exe = build_c_smoke(tmp_path)
+    seg = np.load(os.path.join(os.path.dirname(__file__), "golden", "segment12.npz"))
+    log_n = [int(x) for x in seg["log_n"]]
+    ctl_tables, ctls = T.all_cross_table_lookups()
+    tables = [(T.TABLE_ENUM_ORDER[i], seg["t%d" % i], T.WIDTH[T.TABLE_ENUM_ORDER[i]], log_n[i], ctl_tables[i]) for i in range(12)]
+    img = zkm.segment_image(tables, ctls, public_values=[1, 2, 3])
+    path = tmp_path / "segment.zkmtrace"
+    img.tofile(path)
+    out = tmp_path / "proofs.bin"
+    r = subprocess.run([exe, str(path), str(out)], capture_output=True, text=True, timeout=300, env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(out, dtype=np.uint64)
+    want, chal, offs = ctx.prove_segment_image(img)
+    assert got.size == want.size and (got == want).all()
+    ref, rchal, _ = oracle.prove_with_traces(tables, ctls, public_values=[1, 2, 3])
+    assert (got == ref).all()
+    assert "ok %d words, 12 tables, beta0 %016x" % (want.size, int(chal[0])) in r.stdout
+
+
+@pytest.mark.gpu
 def test_out_of_memory_retry_while_lanes_are_active(zkm):
     """the allocator's out-of-memory path trims caches -- its own, then the parent's and the sibling lanes' -- while the
     commit lanes of the same segment are allocating and releasing on their own threads.  The "debug_fail_allocs" hook makes device

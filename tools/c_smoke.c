@@ -1,0 +1,74 @@
+/* tools/c_smoke.c -- the C ABI used from plain C99, no Python anywhere: read a ZKMTRACE segment image from a file, prove it with
+ * zkm_prove_segment_image, write the proof blobs to a file.  The reference-side caller of this boundary is Rust over FFI
+ * (its only existing FFI has this very shape: recursion/src/snark/snarks.rs:7-20, 39-59 -- int status, char** message
+ * freed by the caller); this file is the proof that include/zkm_hip.h is usable as it stands by a C compiler in pedantic mode.
+ *
+ *   gcc -std=c99 -pedantic -Wall -Werror -Iinclude tools/c_smoke.c -Lzkm_amd/csrc -lzkmhip -Wl,-rpath,$PWD/zkm_amd/csrc \
+ *       -Wl,-rpath-link,/opt/rocm/lib -o c_smoke
+ *   ./c_smoke segment.zkmtrace proofs.bin        exit code 0 and "ok <words> words, <ntables> tables" on success
+ *
+ * tests/test_abi.py builds it (CPU suite: compiles, links, reports the missing GPU through the error channel) and
+ * tests/test_segment.py runs it on the GPU box and compares the blob with the Python path's and the oracle's.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "zkm_hip.h"
+
+static int die(const char* what, char* err) {
+    fprintf(stderr, "c_smoke: %s: %s\n", what, err ? err : "(no message)");
+    free(err); /* the library's messages are malloc'd: the caller frees */
+    return 1;
+}
+
+int main(int argc, char** argv) {
+    FILE* f;
+    long bytes;
+    uint64_t *image, *proofs, challenges[8];
+    size_t words, proof_words = 0, offsets[65], ntables, k;
+    zkm_ctx* ctx = NULL;
+    zkm_stark_config cfg;
+    char* err = NULL;
+
+    if (argc != 3) {
+        fprintf(stderr, "usage: %s <segment image> <proofs out>\n", argv[0]);
+        return 2;
+    }
+    f = fopen(argv[1], "rb");
+    if (!f) return die("cannot open the image", NULL);
+    fseek(f, 0, SEEK_END);
+    bytes = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (bytes < 64 || bytes % 8) return die("not a segment image (size)", NULL);
+    words = (size_t)bytes / 8;
+    image = (uint64_t*)malloc((size_t)bytes);
+    if (!image || fread(image, 8, words, f) != words) return die("short read", NULL);
+    fclose(f);
+    if (memcmp(image, "ZKMTRACE", 8) != 0) return die("not a segment image (magic)", NULL);
+    ntables = (size_t)image[2];
+    if (ntables > 64) return die("too many tables for this tool", NULL);
+
+    printf("%s\n", zkm_version());
+    zkm_standard_config(&cfg);
+    if (zkm_ctx_create(0, &ctx, &err)) return die("zkm_ctx_create", err);
+    /* first call: sizes only */
+    if (zkm_prove_segment_image(ctx, &cfg, image, words, NULL, &proof_words, offsets, NULL, &err)) return die("sizing", err);
+    proofs = (uint64_t*)malloc(proof_words * 8);
+    if (!proofs) return die("out of host memory", NULL);
+    if (zkm_prove_segment_image(ctx, &cfg, image, words, proofs, &proof_words, offsets, challenges, &err)) return die("proving", err);
+    zkm_ctx_destroy(ctx);
+
+    f = fopen(argv[2], "wb");
+    if (!f || fwrite(proofs, 8, proof_words, f) != proof_words) return die("cannot write the proofs", NULL);
+    fclose(f);
+    for (k = 0; k < ntables; k++) {
+        zkm_proof_layout lay;
+        if (zkm_proof_get_layout(proofs + offsets[k], &lay) || lay.total_words != offsets[k + 1] - offsets[k])
+            return die("a proof blob does not describe itself", NULL);
+    }
+    printf("ok %lu words, %lu tables, beta0 %016llx\n", (unsigned long)proof_words, (unsigned long)ntables, (unsigned long long)challenges[0]);
+    free(proofs);
+    free(image);
+    return 0;
+}

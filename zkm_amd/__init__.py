@@ -84,6 +84,27 @@ class StarkConfig(C.Structure):
                 ("rate_bits", "cap_height", "pow_bits", "num_challenges", "num_queries", "arity_bits", "final_poly_bits")]
 
 
+class FriPoly(C.Structure):
+    """zkm_fri_poly: one polynomial of a FRI batch = (oracle index, column index)."""
+    _fields_ = [("oracle", C.c_uint32), ("poly", C.c_uint32)]
+
+
+class FriBatch(C.Structure):
+    """zkm_fri_batch: the polynomials opened at one point (FriBatchInfo, stark.rs:127-148)."""
+    _fields_ = [("point", C.c_uint64 * 2), ("polys", C.c_void_p), ("npolys", C.c_size_t)]
+
+
+def abi_mirrors():
+    """Every struct of include/zkm_hip.h -> its Python mirror (a ctypes Structure or a numpy dtype); tests/test_abi.py compares
+    size and field offsets of each with what the C compiler says (tools/abi_layout.c)."""
+    from . import ctl
+    return {"zkm_challenger": Challenger, "zkm_stark_config": StarkConfig, "zkm_proof_layout": ProofLayout,
+            "zkm_proof_query_layout": ProofQueryLayout, "zkm_column": ctl.COLUMN_DT, "zkm_colset": ctl.COLSET_DT,
+            "zkm_ctl_table": ctl.CtlTableStruct, "zkm_ctl_z": ctl.CTLZ_DT, "zkm_ctl_side": ctl.SIDE_DT,
+            "zkm_cross_table_lookup": ctl.CTL_DT, "zkm_table_input": ctl.TableInputStruct, "zkm_fri_poly": FriPoly,
+            "zkm_fri_batch": FriBatch}
+
+
 _lib = None
 
 
@@ -616,8 +637,6 @@ class Context:
         if not words:
             raise ZkmError("zkm_fri_proof_words: unsupported configuration")
 
-        class FriBatch(C.Structure):
-            _fields_ = [("point", C.c_uint64 * 2), ("polys", C.c_void_p), ("npolys", C.c_size_t)]
         keep, arr = [], (FriBatch * len(batches))()
         for i, (pt, polys) in enumerate(batches):
             a = np.array(polys, dtype=np.uint32).reshape(-1, 2)
