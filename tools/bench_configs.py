@@ -38,6 +38,20 @@ def fri_algorithmic_bytes(n, W, A, Q, Z, rate_bits=2, arity_bits=4, layers=5):
     return {"K11_combine": k11, "K12_final_lde": k12, "K13_commit_fold": k13, "total": k11 + k12 + k13}
 
 
+PMC_SYMBOLS = {"fri_combine": ["k_fri_combine"], "fri_fold": ["k_fri_fold"],
+               "fri_divide_linear": ["k_seg_totals", "k_seg_scan", "k_seg_scan_final", "k_seg_combine"]}
+
+
+def load_pmc(name):
+    """profiles/<name> (tools/summarize_config_pmc.py) if it was collected on THIS code (bench.py's fingerprint), else (None, False)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        from bench import code_fingerprint
+        return d, d.get("code_fingerprint") == code_fingerprint()
+    except Exception:  # noqa: BLE001
+        return None, False
+
+
 def fri_2_22(ctx, log_n=22, reps=3):
     import zkm_amd
     W, A, Q, Z = 13, 4, 4, 2
@@ -73,14 +87,42 @@ def fri_2_22(ctx, log_n=22, reps=3):
     dv.free()
     alg = fri_algorithmic_bytes(n, W, A, Q, Z)
     kernel_ms = {k: round(v[1] / reps, 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1]) if not k.startswith("stage/")}
+    # Per kernel, against the HBM roofline: the bytes the kernel must move (each input word read once, each output word written once)
+    # / its own HIP-event time.  (SURVEY 8(d)'s K11 figure counts the trace and auxiliary polynomials once per opening batch; the
+    # combination kernel reads every coefficient ONCE and forms all batches in that pass, so its own figure is smaller than K11.)
+    folds, m = 0, n
+    for _ in range(5):
+        folds += 16 * m + 16 * (m >> 4)
+        m >>= 4
+    kernel_alg = {"fri_combine": 8 * n * (W + A + Q) + 3 * 16 * n,          # W + A + Q polynomials in, three F2 composites out
+                  "fri_divide_linear": 3 * 16 * n + 16 * n,                  # three composites in, the final F2 polynomial out
+                  "fri_fold": folds}                                          # every layer's coefficients in, 1/16 of them out
+    pmc, fresh = load_pmc("fri_2_22_pmc.json")
+    per_kernel = {}
+    for name, syms in PMC_SYMBOLS.items():
+        if name not in rec or not rec[name][1]:
+            continue
+        ms = rec[name][1] / reps
+        e = {"ms_per_call": round(ms, 4), "launches_per_call": rec[name][0] / reps, "algorithmic_bytes": kernel_alg[name],
+             "achieved_GBps": kernel_alg[name] / ms / 1e6, "frac_of_hbm_peak": kernel_alg[name] / ms / 1e6 / HBM_PEAK_GBS}
+        if fresh:
+            calls = pmc.get("calls_profiled", reps + 1)
+            tr = sum(pmc["kernels"].get(sy, {}).get("fetch_size_bytes_total", 0) + pmc["kernels"].get(sy, {}).get("write_size_bytes_total", 0) for sy in syms)
+            e["traffic_bytes"] = tr / calls
+            e["traffic_GBps"] = tr / calls / ms / 1e6
+            e["traffic_frac_of_hbm_peak"] = tr / calls / ms / 1e6 / HBM_PEAK_GBS
+        per_kernel[name] = e
     out = {"workload": "prove_openings on 13 + 4 + 4 polynomials of 2^%d coefficients (seed 4), LDE 2^%d F2 values, folds 4 x %d, PoW 16 bits, "
                        "37 queries; BASELINE.json configs[3]" % (log_n, log_n + 2, 5),
            "ms": dt * 1e3, "proof_words": int(proof.size), "kernel_ms": kernel_ms, "kernel_ms_sum": round(sum(kernel_ms.values()), 3),
            "launches": int(sum(v[0] for k, v in rec.items() if not k.startswith("stage/")) / reps),
-           "algorithmic_bytes": alg, "achieved_GBps": alg["total"] / dt / 1e9, "frac_of_hbm_peak": alg["total"] / dt / 1e9 / HBM_PEAK_GBS,
+           "per_kernel_hbm": per_kernel,
+           "algorithmic_bytes_survey_8d": alg,
            "commit_trace_13_cols_ms": commit_trace_s * 1e3, "commit_three_oracles_first_call_ms": commit_first_s * 1e3,
-           "note": "achieved = SURVEY 8(d) K11-K13 bytes / wall time of the call (transcript round trips, PoW and query gathers included); "
-                   "counter traffic: profiles/r03_fri_2_22_pmc.json"}
+           "note": "per_kernel_hbm: each FRI kernel's own bytes / its own HIP-event time against 8 TB/s (traffic_* = FETCH_SIZE x 2 + WRITE_SIZE of "
+                   "separate rocprofv3 --pmc passes, %s); the call as a whole is not an HBM figure -- over half of its kernel time is "
+                   "Poseidon hashing of the five layer trees (merkle_leaves_ext, merkle_compress), which is VALU-bound" %
+                   ("profiles/fri_2_22_pmc.json" if fresh else "absent: no fresh counter file for this code, run tools/gpu_configs.sh")}
     for b in (tb, ab, qb):
         b.free()
     return out
@@ -112,15 +154,27 @@ def keccak_sponge_2_20(ctx, log_n=20, reps=3):
     n = 1 << log_n
     data, off, meta, rows, nops = sponge_ops(5, n)
     buf, used = ctx.keccak_sponge_trace(data, off, meta, log_n)        # warm-up
-    ctx.profile(True)
-    ctx.profile_reset()
     ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         ctx.keccak_sponge_trace(data, off, meta, log_n, out=buf)
     ctx.synchronize()
+    witness_host_s = (time.perf_counter() - t0) / reps                  # message bytes (124 MB) in pageable host memory: upload on the clock
+    # the measured configuration: message bytes resident in HBM, like every other input of this file
+    padded = np.zeros((data.size + 7) // 8 * 8, dtype=np.uint8)
+    padded[:data.size] = data
+    d_data = ctx.alloc(padded.size // 8).upload(padded.view(np.uint64))
+    ctx.keccak_sponge_trace(d_data, off, meta, log_n, out=buf)
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.keccak_sponge_trace(d_data, off, meta, log_n, out=buf)
+    ctx.synchronize()
     witness_s = (time.perf_counter() - t0) / reps
     rec_w = ctx.profile_records()
+    d_data.free()
     b = zkm_amd.PolynomialBatch.from_values(ctx, buf, W, log_n)          # warm-up
     b.free()
     ctx.profile_reset()
@@ -147,7 +201,9 @@ def keccak_sponge_2_20(ctx, log_n=20, reps=3):
     kf_ms = rec_k["keccakf"][1] / rec_k["keccakf"][0]
     return {"workload": "KeccakSpongeStark 470 cols x 2^%d rows: %d seeded random messages (seed 5, lengths uniform in [1, 1088) bytes), %d rows used "
                         "= %d Keccak-f permutations; witness kernel, then from_values; BASELINE.json configs[4]" % (log_n, nops, rows, rows),
-            "witness_ms": witness_s * 1e3, "witness_kernel_ms": kw_ms, "witness_memset_note": "the call zero-fills the 3.9 GB table first (sparse stores after)",
+            "witness_ms": witness_s * 1e3, "witness_kernel_ms": kw_ms, "witness_ms_host_inputs": witness_host_s * 1e3,
+            "witness_note": "witness_ms: message bytes resident in HBM (offsets and per-operation words still come from the host: 3.6 MB); "
+                            "witness_ms_host_inputs: the %.0f MB of message bytes start in pageable host memory and are uploaded inside the call" % (data.size / 1e6),
             "keccakf_permutations": rows, "witness_permutations_per_s": rows / (kw_ms / 1e3),
             "witness_bytes_written": 8 * W * n, "witness_call_GBps": 8 * W * n / witness_s / 1e9,
             "commit_ms": commit_s * 1e3, "commit_kernel_ms": {k2: round(v[1] / reps, 3) for k2, v in sorted(rec_c.items(), key=lambda kv: -kv[1][1]) if not k2.startswith("stage/")},

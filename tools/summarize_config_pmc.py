@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Digest of the rocprofv3 passes of tools/gpu_r03_configs.sh: per-kernel HBM bytes (FETCH_SIZE doubled per MI355X_MICROARCH.md,
-WRITE_SIZE; both in KiB) and durations for BASELINE configs 4 (fri) and 5 (sponge).  Writes <dir>/<workload>_pmc.json."""
+"""Digest of the rocprofv3 passes of tools/gpu_configs.sh: per-kernel HBM bytes (FETCH_SIZE doubled per MI355X_MICROARCH.md,
+WRITE_SIZE; both in KiB) and durations for BASELINE configs 4 (fri) and 5 (sponge).  Writes <dir>/<workload>_pmc.json, stamped with
+bench.py's code fingerprint (tools/bench_configs.py quotes counter bytes only from a file collected on the code it runs)."""
 import collections
 import csv
 import glob
@@ -9,6 +10,8 @@ import os
 import sys
 
 out = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import code_fingerprint  # noqa: E402
 for wl in ("fri", "sponge"):
     res = {}
     f = os.path.join(out, "%s_kernel_stats.csv" % wl)
@@ -30,7 +33,8 @@ for wl in ("fri", "sponge"):
     tot_f = sum(v.get("fetch_size_bytes_total", 0) for v in res.values())
     tot_w = sum(v.get("write_size_bytes_total", 0) for v in res.values())
     tot_ns = sum(v.get("stats", {}).get("total_ns", 0) for v in res.values())
-    digest = {"workload": wl, "note": "totals over the whole profiled command (tools/bench_configs.py %s: warm-up + 3 timed repetitions + set-up); "
+    digest = {"workload": wl, "code_fingerprint": code_fingerprint(), "calls_profiled": 4,
+              "note": "totals over the whole profiled command (tools/bench_configs.py %s: warm-up + 3 timed repetitions + set-up); "
                                       "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % wl,
               "total_fetch_bytes": tot_f, "total_write_bytes": tot_w, "total_kernel_ms": tot_ns / 1e6,
               "aggregate_GBps_over_kernel_time": (tot_f + tot_w) / max(tot_ns, 1), "kernels": res}

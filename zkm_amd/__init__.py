@@ -373,14 +373,18 @@ class Context:
         """KeccakSpongeStark::generate_trace on the GPU (keccak_sponge_stark.rs:222-444).  inputs: uint8 array of all
         operations' bytes, input_off: nops+1 offsets, meta: nops x 4 (context, segment, virt_base, timestamp).
         Returns (DeviceBuffer of 470 x 2^log_n words, rows used)."""
-        inputs = np.ascontiguousarray(inputs, dtype=np.uint8)
+        if isinstance(inputs, DeviceBuffer):      # message bytes already in HBM (packed into a word buffer): no upload inside the call
+            in_ptr = C.c_void_p(inputs.ptr)
+        else:
+            inputs = np.ascontiguousarray(inputs, dtype=np.uint8)
+            in_ptr = inputs.ctypes.data_as(C.c_void_p)
         input_off = np.ascontiguousarray(input_off, dtype=np.uint64)
         meta = np.ascontiguousarray(meta, dtype=np.uint64)
         nops = input_off.size - 1
         out = out or self.alloc(KECCAK_SPONGE_COLS << log_n)
         used = C.c_size_t()
         err = C.c_char_p()
-        _check(self.L.zkm_keccak_sponge_trace(self.h, inputs.ctypes.data_as(C.c_void_p), input_off.ctypes.data_as(u64p),
+        _check(self.L.zkm_keccak_sponge_trace(self.h, in_ptr, input_off.ctypes.data_as(u64p),
                                               meta.ctypes.data_as(u64p), nops, log_n, _data_ptr(out), C.byref(used), C.byref(err)), err)
         return out, used.value
 
