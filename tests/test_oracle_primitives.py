@@ -90,3 +90,17 @@ def test_keccak_known_answers(oracle):
     assert len(oracle.keccak256(bytes([1, 2, 3]))) == 32
     long = bytes(range(200)) * 3  # multi-block, rate 136
     assert oracle.keccak256(long) != oracle.keccak256(long[:-1])
+
+
+def test_device_round_constants_are_canonical():
+    """poseidon_dev.h adds the first round's constants with gl_add_lc (loose + CANONICAL -> one possible wrap): every entry of the
+    constant tables the kernels read must be < p.  Parsed from the generated include (tools/gen_poseidon_constants.py)."""
+    import os
+    import re
+    P = 0xFFFFFFFF00000001
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zkm_amd", "csrc", "poseidon_constants.inc")).read()
+    tables = re.findall(r"ZKM_CONST uint64_t (ZKM_POSEIDON_\w+)((?:\[\d+\])+)\s*=\s*\{(.*?)\};", text, flags=re.S)
+    assert any(name == "ZKM_POSEIDON_RC" for name, _, _ in tables)
+    for name, _, body in tables:
+        vals = [int(v.rstrip("ULul"), 0) for v in re.findall(r"0x[0-9a-fA-F]+(?:ULL|UL|U)?|\b\d+(?:ULL|UL|U)?\b", body)]
+        assert vals and all(v < P for v in vals), name

@@ -201,7 +201,7 @@ struct ntt_round {
     }
     template <bool INV>
     __device__ static __forceinline__ void compute_pow2(gl_t (&x)[8]) {
-        static_assert(q == 0 && top == 2, "compute_pow2: the three lowest stages");
+        static_assert(top == 2, "compute_pow2: three stages");   // (as a round of its own: the three LOWEST stages, q == 0, m == 0)
         if (!INV) {
             bfly_pow2<0, false>(x[0], x[4]); bfly_pow2<24, false>(x[1], x[5]);
             __builtin_amdgcn_sched_barrier(0);
@@ -225,6 +225,34 @@ struct ntt_round {
         __builtin_amdgcn_sched_barrier(0);
         bfly_pow2<0, false>(x[4], x[5]); bfly_pow2<0, false>(x[6], x[7]);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    // The same three stages with the twiddles FACTORED OUT of the butterflies (radix-8 decimation in frequency).  The stage twiddles
+    // of a round are w_top[j] = W w_8^j, w_mid[j] = W^2 w_4^j, w_bot = W^4 for ONE W = w_N'^a' per thread (load_tw), and
+    // w_8 = 2^24, w_4 = 2^48 are shifts in this field, so the twelve butterflies with twelve general products are
+    //     y = DFT_8(x) with shift twiddles only (compute_pow2: 5 shift-multiplies, 7 plain butterflies),
+    //     then  slot j *= W^bitrev3(j)   (7 general products; slot j of the in-place DIF holds output bitrev3(j))
+    // -- the same field elements, 7 general products + 5 shifts instead of 12 general products per 8 points and round.
+    // f[k - 1] = W^k, k = 1 .. 7 (factored_tw below).
+    template <bool INV>
+    __device__ static __forceinline__ void compute_fact(gl_t (&x)[8], const gl_t (&f)[7]) {
+        compute_pow2<INV>(x);
+        x[1] = gl_mul_loose(x[1], f[3]); x[2] = gl_mul_loose(x[2], f[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        x[3] = gl_mul_loose(x[3], f[5]); x[4] = gl_mul_loose(x[4], f[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        x[5] = gl_mul_loose(x[5], f[4]); x[6] = gl_mul_loose(x[6], f[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        x[7] = gl_mul_loose(x[7], f[6]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // stage twiddles of a full round (load_tw: w[0] = W, w[4] = W^2, w[6] = W^4) -> the powers W^1 .. W^7
+    __device__ static __forceinline__ void factored_tw(gl_t (&f)[7], const gl_t (&w)[7]) {
+        static_assert(top == 2, "factored_tw: a full three-stage round");
+        f[0] = w[0]; f[1] = w[4]; f[3] = w[6];
+        f[2] = gl_mul(w[0], w[4]);
+        f[4] = gl_mul(w[0], w[6]);
+        f[5] = gl_mul(w[4], w[6]);
+        f[6] = gl_mul(f[2], w[6]);
     }
     // First round of a x4 zero-padded transform (coset LDE): only x[0], x[1] are non-zero, so the first two stages are
     // plain twiddle multiplications -- bfly(u, 0) = (u, u w) -- 6 products instead of 8 butterflies.
@@ -788,19 +816,26 @@ __global__ __launch_bounds__(512, 6) void k_ntt_blk12(ntt_big_args p) {
 
     // round-1 twiddles (one set per thread) stay in registers; those of rounds 2 and 3 only depend on the lane (64 x 7 and 8 x 7
     // words) and are re-read from LDS when needed -- 28 VGPRs
+    // (all three in the FACTORED form: the powers W^1 .. W^7 of the round's one twiddle, ntt_round::compute_fact)
     gl_t w1[7];
-    R::load_tw(w1, p.tw, 0, 9, (size_t)tid);
+    {
+        gl_t w[7];
+        R::load_tw(w, p.tw, 0, 9, (size_t)tid);
+        R::factored_tw(w1, w);
+    }
     gl_t* const twl = lds + 8 * SB;
     if (tid < 64) {
-        gl_t w[7];
+        gl_t w[7], f[7];
         R::load_tw(w, p.tw, 0, 6, (size_t)tid);
+        R::factored_tw(f, w);
 #pragma unroll
-        for (int k = 0; k < 7; k++) twl[k * 64 + tid] = w[k];
+        for (int k = 0; k < 7; k++) twl[k * 64 + tid] = f[k];
     } else if (tid < 72) {
-        gl_t w[7];
+        gl_t w[7], f[7];
         R::load_tw(w, p.tw, 0, 3, (size_t)(tid - 64));
+        R::factored_tw(f, w);
 #pragma unroll
-        for (int k = 0; k < 7; k++) twl[448 + k * 8 + (tid - 64)] = w[k];
+        for (int k = 0; k < 7; k++) twl[448 + k * 8 + (tid - 64)] = f[k];
     }
     __syncthreads();
 
@@ -811,7 +846,7 @@ __global__ __launch_bounds__(512, 6) void k_ntt_blk12(ntt_big_args p) {
         gl_t x[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = dst[tid + NT * j];
-        R::compute(x, w1);                                        // stages 11, 10, 9
+        R::template compute_fact<INV>(x, w1);                     // stages 11, 10, 9
         __syncthreads();                                               // the previous block's readers are done with the image
 #pragma unroll
         for (int j = 0; j < 8; j++) lds[j * SB + a1] = x[j];
@@ -830,7 +865,7 @@ __global__ __launch_bounds__(512, 6) void k_ntt_blk12(ntt_big_args p) {
         gl_t w[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) w[k] = twl[k * 64 + l];
-        R::compute(x, w);                                         // stages 8, 7, 6
+        R::template compute_fact<INV>(x, w);                      // stages 8, 7, 6
 #pragma unroll
         for (int j = 0; j < 8; j++) sub[a2 + 72 * j] = x[j];
         ZKM_WAVE_SYNC();
@@ -838,7 +873,7 @@ __global__ __launch_bounds__(512, 6) void k_ntt_blk12(ntt_big_args p) {
         for (int j = 0; j < 8; j++) x[j] = sub[a3 + 8 * j + (l7 ^ j)];
 #pragma unroll
         for (int k = 0; k < 7; k++) w[k] = twl[448 + k * 8 + l7];
-        R::compute(x, w);                                         // stages 5, 4, 3
+        R::template compute_fact<INV>(x, w);                      // stages 5, 4, 3
 #pragma unroll
         for (int j = 0; j < 8; j++) sub[a3 + 8 * j + (l7 ^ j)] = x[j];
         ZKM_WAVE_SYNC();

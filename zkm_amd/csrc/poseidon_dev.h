@@ -224,7 +224,8 @@ GL_HD void poseidon_permute_out(uint64_t s[12], int out) {
     const uint64_t* rc0 = PC::ZKM_POSEIDON_RC;
     POSEIDON_OPAQUE_PTR(rc0);
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add_loose(s[i], rc0[i]);
+    for (int i = 0; i < 12; i++) s[i] = gl_add_lc(s[i], rc0[i]);   // loose + CANONICAL round constant (tests/test_oracle_primitives.py
+                                                                   // checks every table entry < p): one correction, not two (gl_dev.h)
 #pragma unroll 1
     for (int r = 0; r < 8; r++) {
         POSEIDON_REGION("full_sbox");
