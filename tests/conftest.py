@@ -52,7 +52,8 @@ def oracle_proof_2_20(oracle):
     n = 1 << log_n
     old = oracle.get_threads()
     oracle.set_threads(min(64, os.cpu_count() or 1))
-    oracle.set_wide_threads(os.cpu_count() or 1)      # leaf hashing / per-column LDE on every core (85 % of the oracle's proof)
+    # (all 256 cores for the row-parallel stages were measured in r04_a: 94.6 s against 72.6 s on 64 threads -- the leaf gather is
+    # memory-latency bound; profiles/cpu_oracle_full_size.json "all_cores")
     try:
         trace = oracle.poseidon_trace(100, n, log_n)
         aux = np.zeros(4 * n, dtype=np.uint64)
@@ -61,8 +62,7 @@ def oracle_proof_2_20(oracle):
         secs = time.time() - t0
     finally:
         oracle.set_threads(old)
-        oracle.set_wide_threads(0)
     out = {"xor": int(np.bitwise_xor.reduce(trace)), "sample": trace[::4099].copy(), "proof": proof, "seconds": secs, "stage_s": stages,
-           "threads": min(64, os.cpu_count() or 1), "wide_threads": os.cpu_count() or 1}
+           "threads": min(64, os.cpu_count() or 1), "wide_threads": None}
     del trace
     return out

@@ -109,7 +109,7 @@ def test_proof_is_bit_exact_2_20(ctx, zkm, oracle_proof_2_20):
                    "stage_s": dict(zip(["compute trace commitment", "compute auxiliary polynomials commitment", "compute quotient polys",
                                         "compute quotient commitment", "openings (StarkOpeningSet::new)", "compute openings proof: combine + final LDE",
                                         "compute openings proof: commit phase + PoW", "compute openings proof: query rounds"], oracle_proof_2_20["stage_s"]))},
-                  open(os.path.join(out, "cpu_oracle_full_size.json"), "w"), indent=1)
+                  open(os.path.join(out, "cpu_oracle_full_size_64_threads.json"), "w"), indent=1)
 
 
 @pytest.mark.parametrize("log_n", [17, 18, 19, 22])

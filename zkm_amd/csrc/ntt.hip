@@ -834,8 +834,10 @@ __global__ __launch_bounds__(512, 6) void k_ntt_blk12(ntt_big_args p) {
         gl_t w[7], f[7];
         R::load_tw(w, p.tw, 0, 3, (size_t)(tid - 64));
         R::factored_tw(f, w);
+        // INV: the scale n^-1 rides on the third round's factors (slot 0, which has none, is multiplied there by hand): one product per
+        // eight words instead of eight on the way out
 #pragma unroll
-        for (int k = 0; k < 7; k++) twl[448 + k * 8 + (tid - 64)] = f[k];
+        for (int k = 0; k < 7; k++) twl[448 + k * 8 + (tid - 64)] = INV ? gl_mul(f[k], p.scale) : f[k];
     }
     __syncthreads();
 
@@ -874,16 +876,14 @@ __global__ __launch_bounds__(512, 6) void k_ntt_blk12(ntt_big_args p) {
 #pragma unroll
         for (int k = 0; k < 7; k++) w[k] = twl[448 + k * 8 + l7];
         R::template compute_fact<INV>(x, w);                      // stages 5, 4, 3
+        if (INV) x[0] = gl_mul_loose(x[0], p.scale);
 #pragma unroll
         for (int j = 0; j < 8; j++) sub[a3 + 8 * j + (l7 ^ j)] = x[j];
         ZKM_WAVE_SYNC();
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = sub[a4 + (l7 ^ j)];
         R::template compute_pow2<INV>(x);                         // stages 2, 1, 0
-        if (INV) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) x[j] = gl_mul(x[j], p.scale);   // (canonical)
-        } else if (p.canon_out) {
+        if (INV || p.canon_out) {
 #pragma unroll
             for (int j = 0; j < 8; j++) x[j] = gl_canon(x[j]);
         }
@@ -988,6 +988,57 @@ struct ct_round : ntt_round<S, K> {
         v = gl_sub_rr(u, t);
         u = gl_add_rr(u, t);
     }
+    // A full round with the block twiddles FACTORED OUT (radix-8 decimation in time).  The seven W of a round are powers of one
+    // number up to shifts: with rho = W(k + 2, 4Q) they are  w[3..6] = rho {1, w_4, w_8, w_8^3},  w[1..2] = rho^2 {1, w_4},  w[0] = rho^4
+    // (W(k, q)^2 = W(k - 1, q / 2) and the bit-reversed exponent of an odd block adds half a turn of the next root), so with
+    // z_j = rho^j x_j every rho cancels out of the butterflies: the round is  z = x .* rho^(0..7)  (7 general products) followed by
+    // an 8-point transform whose twiddles are w_4 = 2^48, w_8 = 2^24, w_8^3 = 2^72 -- 5 shift-multiplies instead of 12 general
+    // products.  The same field elements as compute().  f[j - 1] = rho^j (factored_tw).
+    template <int E>
+    __device__ static __forceinline__ void bfly_pow2(gl_t& u, gl_t& v) {
+        const uint64_t t = E ? gl_mul_pow2<(E ? E : 1)>(v) : v;
+        v = gl_sub_rr(u, t);
+        u = gl_add_rr(u, t);
+    }
+    __device__ static __forceinline__ void compute_fact(gl_t (&x)[8], const gl_t (&f)[7]) {
+        static_assert(B::top == 2, "compute_fact: a full three-stage round");
+        x[1] = gl_mul_loose(x[1], f[0]); x[2] = gl_mul_loose(x[2], f[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        x[3] = gl_mul_loose(x[3], f[2]); x[4] = gl_mul_loose(x[4], f[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        x[5] = gl_mul_loose(x[5], f[4]); x[6] = gl_mul_loose(x[6], f[5]);
+        __builtin_amdgcn_sched_barrier(0);
+        x[7] = gl_mul_loose(x[7], f[6]);
+        __builtin_amdgcn_sched_barrier(0);
+        bfly_pow2<0>(x[0], x[4]); bfly_pow2<0>(x[1], x[5]);
+        __builtin_amdgcn_sched_barrier(0);
+        bfly_pow2<0>(x[2], x[6]); bfly_pow2<0>(x[3], x[7]);
+        __builtin_amdgcn_sched_barrier(0);
+        bfly_pow2<0>(x[0], x[2]); bfly_pow2<0>(x[1], x[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        bfly_pow2<48>(x[4], x[6]); bfly_pow2<48>(x[5], x[7]);
+        __builtin_amdgcn_sched_barrier(0);
+        bfly_pow2<0>(x[0], x[1]); bfly_pow2<48>(x[2], x[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        bfly_pow2<24>(x[4], x[5]); bfly_pow2<72>(x[6], x[7]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // block twiddles of a full round (load: w[3] = rho, w[1] = rho^2, w[0] = rho^4) -> rho^1 .. rho^7
+    // UNI: the inputs are wave-uniform (SGPRs): so are the products -- back to SGPRs they go
+    template <bool UNI>
+    __device__ static __forceinline__ void factored_tw(gl_t (&f)[7], const gl_t (&w)[7]) {
+        f[0] = w[3]; f[1] = w[1]; f[3] = w[0];
+        f[2] = gl_mul(w[3], w[1]);
+        f[4] = gl_mul(w[3], w[0]);
+        f[5] = gl_mul(w[1], w[0]);
+        f[6] = gl_mul(f[2], w[0]);
+        if (UNI) {
+#pragma unroll
+            for (int k : {2, 4, 5, 6})
+                f[k] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(f[k] >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)f[k]);
+        }
+    }
     __device__ static __forceinline__ void compute(gl_t (&x)[8], const gl_t (&w)[7]) {
         if (B::top >= 2) {
             bfly(x[0], x[4], w[0]); bfly(x[1], x[5], w[0]);
@@ -1034,6 +1085,17 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
     R0::template load<(RUNS || LT + R0::q >= 6)>(w0, ct, rgA);
     if (NR > 1) R1::template load<(LT + R1::q >= 6)>(w1, ct, rg);
     if (NR > 2) R2::template load<(LT + R2::q >= 6)>(w2, ct, rg);
+    // full rounds run in the factored form (ct_round::compute_fact): their twiddle sets become the powers rho^1 .. rho^7
+    constexpr bool F0 = R0::top == 2, F1 = NR > 1 && R1::top == 2, F2 = NR > 2 && R2::top == 2;
+    if (F0) { gl_t f[7]; R0::template factored_tw<(RUNS || LT + R0::q >= 6)>(f, w0);
+#pragma unroll
+        for (int k = 0; k < 7; k++) w0[k] = f[k]; }
+    if (F1) { gl_t f[7]; R1::template factored_tw<(LT + R1::q >= 6)>(f, w1);
+#pragma unroll
+        for (int k = 0; k < 7; k++) w1[k] = f[k]; }
+    if (F2) { gl_t f[7]; R2::template factored_tw<(LT + R2::q >= 6)>(f, w2);
+#pragma unroll
+        for (int k = 0; k < 7; k++) w2[k] = f[k]; }
 
     // (shift w_n^i_lo)^t_lo for the 8 rows this thread stores
     gl_t post[8];
@@ -1074,7 +1136,8 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
         for (int j = 0; j < 8; j++) x[j] = nx[j];
         if (col + 1 < col1) fetch(col + 1);
         __builtin_amdgcn_sched_barrier(0);
-        R0::compute(x, w0);
+        if constexpr (F0) R0::compute_fact(x, w0);
+        else R0::compute(x, w0);
         if (NR > 1) {
             gl_t* const img = lds + (ex & 1) * IMG;
             ex++;
@@ -1089,7 +1152,8 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
                 __syncthreads();
                 R1::lds_read(img, T, b, rg, x);
             }
-            R1::compute(x, w1);
+            if constexpr (F1) R1::compute_fact(x, w1);
+            else R1::compute(x, w1);
         }
         if (NR > 2) {
             gl_t* const img = lds + (ex & 1) * IMG;
@@ -1097,7 +1161,8 @@ __global__ __launch_bounds__(512, 4) void k_lde_upper(lde_upper_args p) {
             R1::lds_write(img, T, b, rg, x);
             __syncthreads();
             R2::lds_read(img, T, b, rg, x);
-            R2::compute(x, w2);
+            if constexpr (F2) R2::compute_fact(x, w2);
+            else R2::compute(x, w2);
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
