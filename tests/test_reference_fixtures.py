@@ -219,3 +219,107 @@ def test_hip_proofs(ctx, zkm, oracle, fixtures):
     got = ctx.prove_single_table(trace, g["log_n"], np.zeros(4 * n, dtype=np.uint64), g["num_helpers"], ncols=2431, table_id=zkm.TABLE_KECCAK)
     check_blob(got, u64(g["blob_up_to_pow"]), u64(g["first_query_round"]), lambda p: oracle.verify(p, 4, g["num_helpers"], ncols=2431, table_id=3))
     trace.free()
+
+
+# ------------------------------------------------------------------ the whole segment: what prove_with_traces adds (ref_dump_all_proof)
+ALL_FILES = ("reference_all_proof.json",)
+
+
+def have_reference_all():
+    return os.path.exists(os.path.join(GOLD, "reference_all_proof.json")) and any(
+        os.path.exists(os.path.join(GOLD, "reference_all_proof_traces" + ext)) for ext in (".bin", ".npz"))
+
+
+@pytest.fixture(scope="module")
+def self_all_dir(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("self_all_proof"))
+    SELF.main_all_proof(d)
+    return d
+
+
+@pytest.fixture(params=["self", "reference"])
+def all_proof(request, self_all_dir):
+    """(fixture dict, traces, ncols, log_n) of a whole-segment dump: tools/ref_dump/ref_dump.rs::ref_dump_all_proof run on the reference
+    (tests/golden/reference_all_proof.json + its trace file, .bin or packed .npz), or the same schema written by the oracle."""
+    if request.param == "reference":
+        if not have_reference_all():
+            pytest.skip("no reference-made whole-segment fixture under tests/golden/ (see tools/ref_dump/README.md)")
+        d = GOLD
+    else:
+        d = self_all_dir
+    g = json.load(open(os.path.join(d, "reference_all_proof.json")))
+    path = os.path.join(d, g["traces_file"])
+    if not os.path.exists(path):
+        path = os.path.splitext(path)[0] + ".npz"
+    traces, ncols, log_n = SELF.read_traces(path)
+    return g, traces, ncols, log_n
+
+
+def segment_inputs(g, traces, ncols, log_n):
+    from zkm_amd import tables as T
+    assert [t["name"] for t in g["tables"]] == SELF.TABLE_NAMES, "App. C: Table::all() order (all_stark.rs:117-134)"
+    assert ncols == [T.WIDTH[T.TABLE_ENUM_ORDER[i]] for i in range(12)], "table widths (NUM_COLUMNS of every stark) -- N3 trace ingest"
+    assert [t["log_n"] for t in g["tables"]] == log_n
+    ctl_tables, ctls = T.all_cross_table_lookups()
+    tables = [(T.TABLE_ENUM_ORDER[i], traces[i], ncols[i], log_n[i], ctl_tables[i]) for i in range(12)]
+    return tables, ctls, ctl_tables
+
+
+def check_all_proof(g, proofs, chal, offs, ctl_data_fn, log_n):
+    """The comparisons shared by the oracle (CPU) and HIP (GPU) runs, in transcript order; each names what it depends on."""
+    from zkm_amd import ctl as zc
+    from zkm_amd import tables as T
+    blobs = [proofs[offs[t]:offs[t + 1]] for t in range(12)]
+    c4 = (1 << g["config"]["cap_height"]) * 4
+    for t in range(12):
+        same(blobs[t][28:28 + c4], g["trace_caps"][t], "trace cap of %s -- A.3 FFT, A.5 leaf order, A.4/A.6 hashing (PolynomialBatch::from_values, "
+             "prover.rs:144-167); N3: column order of the witness generator's tables" % SELF.TABLE_NAMES[t])
+    same(chal, g["ctl_challenges"], "CTL challenges -- transcript seed: the twelve trace caps in Table::all() order (prover.rs:182-185), then "
+         "observe_public_values (8 + 8 root limbs, one element per userdata byte: get_challenges.rs:14-21, 91-105), then beta before gamma "
+         "per challenge (cross_table_lookup.rs:560-576); App. A.7 Challenger")
+    _, ctls = T.all_cross_table_lookups()
+    for t, (zs, ids) in enumerate(zc.derive_zs(12, ctls, chal)):
+        d, name = g["ctl_data"][t], SELF.TABLE_NAMES[t]
+        assert len(zs) == d["num_zs"], "%s: number of CtlZData -- cross_table_lookup_data's loop order (cross_table_lookup.rs:634-703)" % name
+        assert [int(x) for x in zs["num_helpers"]] == d["num_helpers"], "%s: helper columns per Z -- looking entries of one table grouped (group_by, :807; " \
+            "ceil(k / 2) helpers for k > 1 column sets, :474-481, constraint degree 3)" % name
+        assert [int(x) for x in zs["ncolsets"]] == d["num_colsets"], "%s: column sets per Z (looking entries per table, all_stark.rs:136-542)" % name
+        same(zs["beta"], d["beta"], "%s: challenge of each Z (every lookup x every challenge, lookup-major)" % name)
+        n = 1 << log_n[t]
+        aux = np.asarray(ctl_data_fn(t, zs, ids)).reshape(-1, n)
+        nh = int(zs["num_helpers"].sum())
+        same(aux[nh:, 0], d["z_first"], "%s: Z(1) of every Z -- partial_sums runs from the LAST row up (cross_table_lookup.rs:841-872), "
+             "filter / column linear forms of all_stark.rs, combine with beta, gamma (:494-504)" % name)
+        same(aux[nh:, n - 1], d["z_last"], "%s: last row of every Z" % name)
+        hf = np.concatenate([u64(h) for h in d["helper_first"]]) if nh else np.zeros(0, dtype=np.uint64)
+        same(aux[:nh, 0], hf, "%s: first row of every helper column (get_helper_cols :709-797: pairwise sums of 1 / combined, filtered rows zeroed)" % name)
+    # the table proofs on the shared transcript, in order: a reference PoW witness that differs from ours (rayon find_any) changes the
+    # transcript of every later table, so the comparison stops at the first table whose witness differs
+    for t in range(12):
+        want = u64(g["proofs"][t]["blob_up_to_pow"])
+        assert blobs[t].size == g["proofs"][t]["blob_words"], "%s: proof size (auxiliary column count, FRI layers for this height)" % SELF.TABLE_NAMES[t]
+        sections, upto = blob_sections(want)
+        for name, a, b, why in sections:
+            if name != "pow_witness":
+                same(blobs[t][a:b], want[a:b], "%s proof, %s -- depends on %s; shared transcript prover.rs:234-438 (init state = compact() "
+                     "of the previous table's final state)" % (SELF.TABLE_NAMES[t], name, why))
+        if int(blobs[t][upto - 1]) != int(want[upto - 1]):
+            break
+    return t
+
+
+def test_oracle_all_proof(oracle, all_proof):
+    g, traces, ncols, log_n = all_proof
+    tables, ctls, ctl_tables = segment_inputs(g, traces, ncols, log_n)
+    proofs, chal, offs = oracle.prove_with_traces(tables, ctls, public_values=g["public_values_words"])
+    check_all_proof(g, proofs, chal, offs, lambda t, zs, ids: oracle.ctl_data(ctl_tables[t], zs, ids, traces[t], ncols[t], log_n[t]), log_n)
+    assert oracle.verify_all(tables, ctls, proofs, chal, public_values=g["public_values_words"]) == 0
+
+
+@pytest.mark.gpu
+def test_hip_all_proof(ctx, zkm, all_proof):
+    """zkm_prove_segment (the shipped AllStark description, csrc/all_stark_ctl.inc) on the dumped traces and public values."""
+    g, traces, ncols, log_n = all_proof
+    tables, ctls, ctl_tables = segment_inputs(g, traces, ncols, log_n)
+    proofs, chal, offs = ctx.prove_segment(traces, log_n, public_values=g["public_values_words"])
+    check_all_proof(g, proofs, chal, offs, lambda t, zs, ids: ctx.ctl_data(ctl_tables[t], zs, ids, traces[t], ncols[t], log_n[t]), log_n)

@@ -112,5 +112,85 @@ def main(out_dir):
                "first_query_round": ints(blob[upto:upto + rw])}, open(os.path.join(out_dir, "reference_keccak_proof.json"), "w"))
 
 
+TABLE_NAMES = ["Arithmetic", "Cpu", "Poseidon", "PoseidonSponge", "Keccak", "KeccakSponge", "ShaExtend", "ShaExtendSponge", "ShaCompress",
+               "ShaCompressSponge", "Logic", "Memory"]   # Table::all(), all_stark.rs:117-134
+
+
+def write_traces_bin(path, traces, ncols, log_n):
+    """ref_dump.rs::ref_dump_all_proof's trace file: magic, ntables, (ncols, log_n) per table, then the tables column-major."""
+    with open(path, "wb") as f:
+        f.write(b"ZKMTBLS1")
+        f.write(np.array([len(traces)] + [v for t in range(len(traces)) for v in (ncols[t], log_n[t])], dtype="<u8").tobytes())
+        for t in traces:
+            f.write(np.ascontiguousarray(t, dtype="<u8").tobytes())
+
+
+def read_traces(path):
+    """-> (traces, ncols, log_n) from the dumper's .bin or from the .npz tools/ref_dump/pack_traces.py makes of it."""
+    if path.endswith(".npz"):
+        z = np.load(path)
+        k = len(z["log_n"])
+        return [z["t%d" % i] for i in range(k)], [int(x) for x in z["ncols"]], [int(x) for x in z["log_n"]]
+    raw = np.fromfile(path, dtype="<u8")
+    assert raw[0] == int.from_bytes(b"ZKMTBLS1", "little"), "not a ZKMTBLS1 trace file"
+    k = int(raw[1])
+    ncols, log_n = [int(x) for x in raw[2:2 + 2 * k:2]], [int(x) for x in raw[3:3 + 2 * k:2]]
+    out, off = [], 2 + 2 * k
+    for t in range(k):
+        words = ncols[t] << log_n[t]
+        out.append(raw[off:off + words].astype(np.uint64))
+        off += words
+    assert off == raw.size, "trailing words in the trace file"
+    return out, ncols, log_n
+
+
+def blob_up_to_pow(blob):
+    w, a, q, z, cap, layers, fin = (int(blob[i]) for i in (2, 3, 4, 5, 6, 7, 8))
+    cap = 1 << cap
+    return 16 + 12 + 3 * cap * 4 + 4 * w + 4 * a + z + 2 * q + layers * cap * 4 + 2 * fin + 1
+
+
+def main_all_proof(out_dir):
+    """reference_all_proof.json + reference_all_proof_traces.bin with the schema of ref_dump.rs::ref_dump_all_proof, computed by the
+    CPU oracle from the committed twelve-table test segment (tests/golden/segment12.npz).  SELF data: schema exercise only."""
+    from oracle.oracle_py import Oracle
+    from zkm_amd import ctl as zc
+    from zkm_amd import tables as T
+    o = Oracle()
+    os.makedirs(out_dir, exist_ok=True)
+    seg = np.load(os.path.join(ROOT, "tests", "golden", "segment12.npz"))
+    log_n = [int(x) for x in seg["log_n"]]
+    traces = [seg["t%d" % i] for i in range(12)]
+    ncols = [T.WIDTH[T.TABLE_ENUM_ORDER[i]] for i in range(12)]
+    write_traces_bin(os.path.join(out_dir, "reference_all_proof_traces.bin"), traces, ncols, log_n)
+    ctl_tables, ctls = T.all_cross_table_lookups()
+    tables = [(T.TABLE_ENUM_ORDER[i], traces[i], ncols[i], log_n[i], ctl_tables[i]) for i in range(12)]
+    pub = list(range(1, 9)) + list(range(11, 19)) + [i & 0xFF for i in range(32)]   # 8 + 8 root limbs, 32 userdata bytes
+    proofs, chal, offs = o.prove_with_traces(tables, ctls, public_values=pub)
+    caps, plist, ctl_dump = [], [], []
+    for t in range(12):
+        blob = proofs[offs[t]:offs[t + 1]]
+        c4 = (1 << int(blob[6])) * 4
+        caps.append(ints(blob[28:28 + c4]))
+        plist.append({"blob_words": int(blob.size), "blob_up_to_pow": ints(blob[:blob_up_to_pow(blob)])})
+    for t, (zs, ids) in enumerate(zc.derive_zs(12, ctls, chal)):
+        n = 1 << log_n[t]
+        aux = o.ctl_data(ctl_tables[t], zs, ids, traces[t], ncols[t], log_n[t]).reshape(-1, n)
+        nh = [int(x) for x in zs["num_helpers"]]
+        hoff = np.concatenate([[0], np.cumsum(nh)]).astype(int)
+        zcols = aux[sum(nh):]
+        ctl_dump.append({"num_zs": len(zs), "num_helpers": nh, "num_colsets": [int(x) for x in zs["ncolsets"]],
+                         "beta": ints(zs["beta"]), "gamma": ints(zs["gamma"]), "z_first": ints(zcols[:, 0]), "z_last": ints(zcols[:, n - 1]),
+                         "helper_first": [ints(aux[hoff[k]:hoff[k + 1], 0]) for k in range(len(zs))]})
+    json.dump({"schema": 1, "source": "SELF (CPU oracle) -- not reference data",
+               "program": {"elf": "tests/golden/segment12.npz", "args": [], "seg_size": 0, "segment": 0, "segments": 1, "total_steps": 0},
+               "config": {"rate_bits": 2, "cap_height": 4, "num_challenges": 2},
+               "tables": [{"name": TABLE_NAMES[i], "enum_index": i, "ncols": ncols[i], "log_n": log_n[i]} for i in range(12)],
+               "traces_file": "reference_all_proof_traces.bin", "public_values_words": pub, "trace_caps": caps, "ctl_challenges": ints(chal),
+               "ctl_data": ctl_dump, "proofs": plist}, open(os.path.join(out_dir, "reference_all_proof.json"), "w"))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "ref_dump_self")
+    d = sys.argv[1] if len(sys.argv) > 1 else "ref_dump_self"
+    main(d)
+    main_all_proof(d)

@@ -9,7 +9,9 @@
 //!      cp integration/rust/proof_blob.rs    $REF/prover/src/proof_blob.rs
 //!      add to $REF/prover/src/lib.rs:       pub mod proof_blob;   #[cfg(test)] mod ref_dump;
 //!   2. ZKM_REF_DUMP_DIR=/tmp/ref cargo test --release -p zkm-prover ref_dump -- --nocapture
-//!   3. cp /tmp/ref/reference_*.json <this repo>/tests/golden/
+//!   3. cp /tmp/ref/reference_*.json /tmp/ref/reference_all_proof_traces.bin <this repo>/tests/golden/
+//!      (the trace file of the whole-segment dump is ~10 MB at the default 1024-cycle segment; `python tools/ref_dump/pack_traces.py`
+//!      turns it into a compressed .npz a fraction of that size -- the tests read either)
 //!   4. python -m pytest tests/test_reference_fixtures.py            (CPU: oracle vs fixtures)
 //!      python -m pytest tests/test_reference_fixtures.py -m gpu     (GPU: HIP path vs fixtures)
 //!
@@ -217,4 +219,142 @@ fn ref_dump_keccak_proof() {
         "schema": 1, "table": "KeccakStark", "seed": seed, "num_perms": num_perms, "log_n": commit.degree_log, "ncols": trace.len(),
         "aux": "zeros, 2 x (1 helper + Z)", "num_helpers": [1, 1], "blob_words": blob.len(),
         "blob_up_to_pow": &blob[..header_to_pow], "first_query_round": &blob[header_to_pow..header_to_pow + round_words]}));
+}
+
+/// The whole-segment dump: everything `prove_with_traces` (prover.rs:130-232) adds on top of the single-table proofs above -- the
+/// twelve traces of a REAL segment, the twelve-cap + public-values transcript seed (:182-190, get_challenges.rs:91-105), the CTL
+/// challenge draw (cross_table_lookup.rs:560-576), `cross_table_lookup_data`'s per-table Z / helper order (:634-703, group_by :807) and
+/// the twelve proofs on the shared challenger (:234-438).
+///
+/// Input: the reference's own test program `emulator/test-vectors/hello` with the arguments of emulator/src/tests.rs:54, split into
+/// segments of ZKM_REF_DUMP_SEG_SIZE cycles (default 1024: tables of 2^6 .. 2^12 rows, a ~10 MB trace file), segment 0.
+/// Output: `reference_all_proof.json` + `reference_all_proof_traces.bin` (the witness generator's `[Vec<PolynomialValues<F>>; 12]`,
+/// generation/mod.rs:25-76, flattened column-major as util.rs:37-46 lays a table out):
+///     u64 magic "ZKMTBLS1", u64 ntables, ntables x (u64 ncols, u64 log_n), then per table ncols x 2^log_n canonical u64, little-endian.
+/// tests/test_reference_fixtures.py feeds the traces to `zkm_prove_segment` (HIP) and to the oracle's prove_with_traces and compares
+/// every dumped quantity; each assertion names the SURVEY App. C item it depends on.
+#[test]
+fn ref_dump_all_proof() {
+    use std::io::{BufReader, Write};
+
+    use plonky2::iop::challenger::Challenger;
+    use zkm_emulator::utils::{load_elf_with_patch, split_prog_into_segs};
+
+    use crate::all_stark::{AllStark, Table, NUM_TABLES};
+    use crate::cpu::kernel::assembler::segment_kernel;
+    use crate::cross_table_lookup::{cross_table_lookup_data, get_grand_product_challenge_set};
+    use crate::generation::generate_traces;
+    use crate::get_challenges::observe_public_values;
+    use crate::prover::prove_with_traces;
+    use crate::stark::Stark;
+
+    let seg_size: usize = std::env::var("ZKM_REF_DUMP_SEG_SIZE").ok().and_then(|s| s.parse().ok()).unwrap_or(1024);
+    let elf = std::env::var("ZKM_REF_DUMP_ELF").unwrap_or_else(|_| "../emulator/test-vectors/hello".into());
+    let seg_dir = out_dir().join("segments");
+    let state = load_elf_with_patch(&elf, vec!["aab", "ccd"]);
+    let (total_steps, seg_num, _state) = split_prog_into_segs(state, seg_dir.to_str().unwrap(), "", seg_size);
+    let kernel = segment_kernel("", "", "", BufReader::new(fs::File::open(seg_dir.join("0")).unwrap()));
+
+    let all_stark = AllStark::<F, D>::default();
+    let config = StarkConfig::standard_fast_config();
+    let (rate_bits, cap_height) = (config.fri_config.rate_bits, config.fri_config.cap_height);
+    let mut timing = TimingTree::default();
+    let (traces, public_values, _outputs) = generate_traces::<F, C, D>(&all_stark, &kernel, &config, &mut timing).unwrap();
+
+    // ---- the traces, as the prover receives them
+    let mut bin: Vec<u8> = vec![];
+    bin.extend_from_slice(b"ZKMTBLS1");
+    bin.extend_from_slice(&(NUM_TABLES as u64).to_le_bytes());
+    let mut shapes = vec![];
+    for (t, table) in traces.iter().zip(Table::all()) {
+        let log_n = t[0].len().trailing_zeros() as u64;
+        bin.extend_from_slice(&(t.len() as u64).to_le_bytes());
+        bin.extend_from_slice(&log_n.to_le_bytes());
+        shapes.push(json!({"name": format!("{:?}", table), "enum_index": table as usize, "ncols": t.len(), "log_n": log_n}));
+    }
+    for t in traces.iter() {
+        for col in t.iter() {
+            for x in col.values.iter() {
+                bin.extend_from_slice(&x.to_canonical_u64().to_le_bytes());
+            }
+        }
+    }
+    fs::File::create(out_dir().join("reference_all_proof_traces.bin")).unwrap().write_all(&bin).unwrap();
+
+    // ---- prover.rs:144-190 by hand: commitments, transcript seed, CTL challenges
+    let commitments: Vec<PolynomialBatch<F, C, D>> = traces
+        .iter()
+        .map(|t| PolynomialBatch::<F, C, D>::from_values(t.clone(), rate_bits, false, cap_height, &mut timing, None))
+        .collect();
+    let trace_caps: Vec<Vec<u64>> = commitments.iter().map(|c| digest_words(&c.merkle_tree.cap.0)).collect();
+    let mut challenger = Challenger::<F, PoseidonHash>::new();
+    for c in &commitments {
+        challenger.observe_cap(&c.merkle_tree.cap);
+    }
+    observe_public_values::<F, C, D>(&mut challenger, &public_values).unwrap();
+    // the words observe_public_values absorbs, in order (get_challenges.rs:14-21, 91-105): 8 + 8 root limbs, then one element per userdata byte
+    let mut public_words: Vec<u64> = vec![];
+    public_words.extend(public_values.roots_before.root.iter().map(|&x| x as u64));
+    public_words.extend(public_values.roots_after.root.iter().map(|&x| x as u64));
+    public_words.extend(public_values.userdata.iter().map(|&x| x as u64));
+    let ctl_challenges = get_grand_product_challenge_set(&mut challenger, config.num_challenges);
+    let challenges_flat: Vec<u64> =
+        ctl_challenges.challenges.iter().flat_map(|c| [c.beta.to_canonical_u64(), c.gamma.to_canonical_u64()]).collect();
+    let challenger_state_after_ctl_challenges = words(challenger.compact().as_ref());
+
+    // ---- prover.rs:191-200: CtlData per table -- the Z order and helper counts are what the auxiliary commitment is built from
+    let ctl_data = cross_table_lookup_data::<F, D>(
+        &traces,
+        &all_stark.cross_table_lookups,
+        &ctl_challenges,
+        all_stark.arithmetic_stark.constraint_degree(),
+    );
+    let ctl_dump: Vec<Value> = ctl_data
+        .iter()
+        .map(|d| {
+            let zs = &d.zs_columns;
+            json!({
+                "num_zs": zs.len(),
+                "num_helpers": zs.iter().map(|z| z.helper_columns.len()).collect::<Vec<_>>(),
+                "num_colsets": zs.iter().map(|z| z.columns.len()).collect::<Vec<_>>(),
+                "beta": zs.iter().map(|z| z.challenge.beta.to_canonical_u64()).collect::<Vec<_>>(),
+                "gamma": zs.iter().map(|z| z.challenge.gamma.to_canonical_u64()).collect::<Vec<_>>(),
+                "z_first": zs.iter().map(|z| z.z.values[0].to_canonical_u64()).collect::<Vec<_>>(),
+                "z_last": zs.iter().map(|z| z.z.values[z.z.values.len() - 1].to_canonical_u64()).collect::<Vec<_>>(),
+                "helper_first": zs.iter().map(|z| z.helper_columns.iter().map(|h| h.values[0].to_canonical_u64()).collect::<Vec<_>>()).collect::<Vec<_>>(),
+            })
+        })
+        .collect();
+    drop(ctl_data);
+
+    // ---- the proof itself, through the reference's own entry point (same inputs: same transcript)
+    let proof = prove_with_traces::<F, C, D>(&all_stark, &config, traces, public_values, &mut timing).unwrap();
+    let proofs: Vec<Value> = proof
+        .stark_proofs
+        .iter()
+        .map(|p| {
+            let blob = stark_proof_to_blob::<F, C, D>(p, &config);
+            let (w, a, q, z) = (blob[2] as usize, blob[3] as usize, blob[4] as usize, blob[5] as usize);
+            let (cap, layers, fin) = (1usize << blob[6], blob[7] as usize, blob[8] as usize);
+            let upto = 16 + 12 + 3 * cap * 4 + 4 * w + 4 * a + z + 2 * q + layers * cap * 4 + 2 * fin + 1;
+            json!({"blob_words": blob.len(), "blob_up_to_pow": &blob[..upto]})
+        })
+        .collect();
+    let proof_challenges: Vec<u64> =
+        proof.ctl_challenges.challenges.iter().flat_map(|c| [c.beta.to_canonical_u64(), c.gamma.to_canonical_u64()]).collect();
+    assert_eq!(proof_challenges, challenges_flat, "the hand-built transcript seed must be the one prove_with_traces used");
+
+    write("reference_all_proof.json", &json!({
+        "schema": 1, "source": "zkMIPS/zkm prover + zkMIPS/plonky2@zkm_dev via tools/ref_dump/ref_dump.rs::ref_dump_all_proof",
+        "program": {"elf": elf, "args": ["aab", "ccd"], "seg_size": seg_size, "segment": 0, "segments": seg_num, "total_steps": total_steps},
+        "config": {"rate_bits": rate_bits, "cap_height": cap_height, "num_challenges": config.num_challenges},
+        "tables": shapes, "traces_file": "reference_all_proof_traces.bin",
+        "public_values_words": public_words,
+        "trace_caps": trace_caps,
+        "ctl_challenges": challenges_flat,
+        "challenger_state_after_ctl_challenges": challenger_state_after_ctl_challenges,
+        "ctl_data": ctl_dump,
+        "proofs": proofs,
+        "pow_note": "each blob stops after its pow_witness; the witness itself may differ between runs of the reference (rayon find_any, App. A.9), and with it the transcript of every LATER table -- compare table k only while the witnesses of tables < k coincide",
+    }));
 }

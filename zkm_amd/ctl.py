@@ -132,3 +132,25 @@ def pack_tables(tables):
         else:
             arr[i] = TableInputStruct(tid, ptr, ncols, log_n, C.addressof(st), None)
     return arr, keep
+
+
+def derive_zs(ntables, ctls, challenges):
+    """The CtlZData of every table in the order cross_table_lookup_data builds them (cross_table_lookup.rs:634-703): for each lookup,
+    for each challenge (beta, gamma): one Z per run of consecutive looking entries of the same table (group_by, :807; its helper
+    columns pair the run's column sets, :474-481), then one Z for the looked table.  ctls as pack_ctls takes them; challenges = flat
+    [beta0, gamma0, beta1, gamma1, ...].  Returns [(zs array (CTLZ_DT), colset_ids array)] per table -- the host-side twin of
+    csrc/ctl.hip derive_zs, for tests that want a table's CtlData on its own (Context.ctl_data / Oracle.ctl_data)."""
+    entries = [[] for _ in range(ntables)]
+    nch = len(challenges) // 2
+    for looking, looked in ctls:
+        for ch in range(nch):
+            beta, gamma = int(challenges[2 * ch]), int(challenges[2 * ch + 1])
+            i = 0
+            while i < len(looking):
+                j = i
+                while j < len(looking) and looking[j][0] == looking[i][0]:
+                    j += 1
+                entries[looking[i][0]].append(([cs for _, cs in looking[i:j]], beta, gamma))
+                i = j
+            entries[looked[0]].append(([looked[1]], beta, gamma))
+    return [make_zs(e) if e else (np.zeros(0, dtype=CTLZ_DT), np.zeros(0, dtype=np.uint32)) for e in entries]
