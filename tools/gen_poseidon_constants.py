@@ -180,7 +180,7 @@ def main():
         rc, circ, diag = ref["ALL_ROUND_CONSTANTS"], ref["MDS_MATRIX_CIRC"], ref["MDS_MATRIX_DIAG"]
     else:
         cur = parse_inc_arrays(open(OUTS[0]).read())
-        rc, circ, diag = cur["ZKM_POSEIDON_RC"], cur["ZKM_POSEIDON_MDS_CIRC"], cur["ZKM_POSEIDON_MDS_DIAG"]
+        rc, circ, diag = cur["ZKM_POSEIDON_RC"][:WIDTH * N_ROUNDS], cur["ZKM_POSEIDON_MDS_CIRC"], cur["ZKM_POSEIDON_MDS_DIAG"]
         ref = None
     assert len(rc) == WIDTH * N_ROUNDS and len(circ) == WIDTH and len(diag) == WIDTH
 
@@ -206,7 +206,9 @@ def main():
         "#ifndef ZKM_CONST",
         "#define ZKM_CONST static const",
         "#endif",
-        fmt("ZKM_POSEIDON_RC", [WIDTH * N_ROUNDS], rc),
+        "/* (one more row of zeros after the 30 x 12 round constants: \"the constants added after the last round\", so that code which",
+        " * folds the NEXT round's constants into a linear layer reads row r + 1 unconditionally) */",
+        fmt("ZKM_POSEIDON_RC", [WIDTH * (N_ROUNDS + 1)], rc + [0] * WIDTH),
         fmt("ZKM_POSEIDON_MDS_CIRC", [WIDTH], circ),
         fmt("ZKM_POSEIDON_MDS_DIAG", [WIDTH], diag),
         fmt("ZKM_POSEIDON_FAST_FIRST_RC", [WIDTH], first_round),

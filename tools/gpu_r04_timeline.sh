@@ -10,5 +10,5 @@ rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python $R/tools/benc
 cd $R
 F=$(find $O/trace -name "*kernel_trace.csv" | head -1)
 python tools/segment_timeline.py $F 4 > $O/timeline.txt 2>&1; head -70 $O/timeline.txt
-python tools/segment_phases.py $F > $O/phases.txt 2>&1; cat $O/phases.txt
+python tools/segment_phases.py $F --lanes > $O/phases.txt 2>&1; cat $O/phases.txt
 rm -rf $O/trace

@@ -48,3 +48,20 @@ for t, b in enumerate(bounds):
     print("  table %2d: %6.2f ms wall, %3d launches, busy %5.2f ms | %s" % (t, w, len(part), busy(part) / 1e6,
                                                                            ", ".join("%s %.0f us" % (n[:28], v / 1e3) for n, v in top)))
     start = b + 1
+
+# ---- the parallel phases in detail: every launch of >= 80 us with its queue, start offset and duration (who is the critical lane?)
+qcol = "Queue_Id" if "Queue_Id" in rows[0] else None
+if qcol and "--lanes" in sys.argv:
+    evq = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[:44], r[qcol]) for r in rows)
+    lo, hi = par[0][0], seg[first_q][0]
+    print("parallel phases, launches >= 80 us (offset ms, duration us, queue, kernel):")
+    for s, e, n, q in evq:
+        if lo <= s < hi and e - s >= 80000:
+            print("  %7.3f %8.1f  q%-3s %s" % ((s - lo) / 1e6, (e - s) / 1e3, q, n))
+    per_q = {}
+    for s, e, n, q in evq:
+        if lo <= s < hi:
+            per_q.setdefault(q, []).append((s, e))
+    print("per queue in the parallel phases: launches, busy ms, first start, last end (ms)")
+    for q, iv in sorted(per_q.items()):
+        print("  q%-3s %4d %7.2f %7.2f %7.2f" % (q, len(iv), sum(e - s for s, e in iv) / 1e6, (min(s for s, _ in iv) - lo) / 1e6, (max(e for _, e in iv) - lo) / 1e6))

@@ -85,6 +85,19 @@ void zkm_ctx::trim() {   // public: between calls (zkm_ctx_trim)
     trim_self();
     for (zkm_ctx* l : lanes) l->trim_self();
 }
+// A stream of the library.  ZKM_CU_MASK_HALF = 0 | 1 (measurement aid, read per call): the stream may only use one half of the GPU's
+// compute units (mask bits [0, n/2) or [n/2, n)) -- tools/contention_test.py uses it to find out what a latency-bound launch loses to
+// a throughput-bound one sharing its CUs.
+static hipError_t zkm_stream_create(hipStream_t* st, int num_cus) {
+    const char* half = getenv("ZKM_CU_MASK_HALF");
+    if (half && (half[0] == '0' || half[0] == '1') && num_cus >= 64) {
+        std::vector<uint32_t> mask((size_t)(num_cus + 31) / 32, 0);
+        const int lo = half[0] == '0' ? 0 : num_cus / 2, hi = half[0] == '0' ? num_cus / 2 : num_cus;
+        for (int i = lo; i < hi; i++) mask[i / 32] |= 1u << (i % 32);
+        return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+    }
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
 void zkm_ctx::ensure_lanes(size_t k) {
     while (lanes.size() < k) {
         zkm_ctx* l = new zkm_ctx();
@@ -96,7 +109,7 @@ void zkm_ctx::ensure_lanes(size_t k) {
         l->fri_fused_division_min = fri_fused_division_min;
         l->wide_max_hashes = wide_max_hashes;
         l->quad_max_hashes = quad_max_hashes;
-        hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
+        hipError_t e = zkm_stream_create(&l->stream, num_cus);
         if (e != hipSuccess) {
             delete l;
             ZKM_HIP_CHECK(e);
@@ -322,7 +335,7 @@ int zkm_ctx_create(int device, zkm_ctx** out, char** err) {
     hipDeviceProp_t prop;
     ZKM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
-    ZKM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    ZKM_HIP_CHECK(zkm_stream_create(&c->stream, c->num_cus));
     zkm_hw_queues_hint();
     *out = c;
     ZKM_API_END(err)
