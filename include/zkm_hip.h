@@ -46,7 +46,7 @@ void zkm_ctx_trim(zkm_ctx* ctx);
  * both sides, tests/test_gpu_prove.py::test_tuning_*).  Keys:
  *   "ingest_chunk_cols"         columns per chunk of the pipelined host ingest (default 32; 0 = one monolithic upload)
  *   "keccak_parts_max_points"   quotient domains of a Keccak table up to this many points use 25 threads per point (default 2^15)
- *   "fri_fused_division_min"    polynomials from this many coefficients on divide by (X - z) with all batches in one thread (default 2^21)
+ *   "fri_fused_division_min"    polynomials from this many coefficients on divide by (X - z) with all batches in one workgroup (default: never)
  *   "wide_max_hashes"           hashing launches of up to this many hashes give each hash a 16-lane row (default 1024), and
  *   "quad_max_hashes"           up to this many a quad of lanes (default 16384): the latency forms of the Poseidon permutation, at
  *                               4.2x / 1.9x the issue slots of the one-lane form.  0 and 0: one lane per hash everywhere (a GPU shared

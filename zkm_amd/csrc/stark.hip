@@ -650,61 +650,99 @@ struct seg_batches {
     gl2_t z[FRI_MAX_BATCHES];          // z_b^(FRI_SEG^level)
     gl2_t w[FRI_MAX_BATCHES];          // weight of the batch in the final sum (bottom level)
 };
+// A thread's segment is FRI_SEG consecutive words of each array, and the walk over it is a dependent chain: with one 8-byte load per
+// step the lanes of a wave sit 256 B apart and every step fetched a whole line from HBM for 8 bytes of it (config 4: 6.4 GB of traffic
+// for 0.27 GB of data, profiles/r04_e).  All three kernels therefore work on LDS TILES: the 64 segments of a 64-thread workgroup
+// (2048 consecutive words) are loaded with lane-contiguous accesses into rows of FRI_SEG + 1 words (a thread walking its own row is
+// bank-conflict free), results that are arrays over k go back the same way.  Words past the end of the array read as zero -- the
+// carry into the last segment is zero, so the chain stays zero there.
+#define SEG_TILE (64 * FRI_SEG)
+#define SEG_ROW (FRI_SEG + 1)
+__device__ __forceinline__ void seg_tile_load(gl_t* __restrict__ t, const gl_t* __restrict__ a, size_t base, size_t m) {
+    for (unsigned e = threadIdx.x; e < SEG_TILE; e += 64) {
+        const size_t k = base + e;
+        t[(e / FRI_SEG) * SEG_ROW + e % FRI_SEG] = k < m ? a[k] : 0;
+    }
+}
 // totals:  out_b[s] = sum_{k<FRI_SEG} a_b[FRI_SEG s + k] z_b^k          (out: [batch][2][nseg])
-__global__ void k_seg_totals(seg_batches p, size_t m, gl_t* __restrict__ out) {
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + FRI_SEG - 1) / FRI_SEG;
+__global__ __launch_bounds__(64) void k_seg_totals(seg_batches p, size_t m, gl_t* __restrict__ out) {
+    __shared__ gl_t t0[64 * SEG_ROW], t1[64 * SEG_ROW];
+    const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x, nseg = (m + FRI_SEG - 1) / FRI_SEG;
     const unsigned b = blockIdx.y;
+    seg_tile_load(t0, p.a0[b], (size_t)blockIdx.x * SEG_TILE, m);
+    seg_tile_load(t1, p.a1[b], (size_t)blockIdx.x * SEG_TILE, m);
+    __syncthreads();
     if (s >= nseg) return;
-    const gl_t *a0 = p.a0[b], *a1 = p.a1[b];
     const gl2_t z = p.z[b];
     gl2_t acc{0, 0};
-    const size_t end = (s + 1) * FRI_SEG < m ? (s + 1) * FRI_SEG : m;
-    for (size_t k = end; k-- > s * FRI_SEG;) acc = gl2_add(gl2_mul(acc, z), gl2_t{a0[k], a1[k]});
+    const gl_t *r0 = t0 + threadIdx.x * SEG_ROW, *r1 = t1 + threadIdx.x * SEG_ROW;
+    for (unsigned k = FRI_SEG; k-- > 0;) acc = gl2_add(gl2_mul(acc, z), gl2_t{r0[k], r1[k]});
     out[(2 * b) * nseg + s] = acc.c0;
     out[(2 * b + 1) * nseg + s] = acc.c1;
 }
 // scan of a level:  S_b[k] = a_b[k] + z_b S_b[k+1] inside each segment, carry-in = upper_b[s+1] (0 past the end)
 // (upper: [batch][2][nupper] suffix values of the level above, or null at the top; out: [batch][2][m])
-__global__ void k_seg_scan(seg_batches p, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ out) {
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + FRI_SEG - 1) / FRI_SEG;
+__global__ __launch_bounds__(64) void k_seg_scan(seg_batches p, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ out) {
+    __shared__ gl_t t0[64 * SEG_ROW], t1[64 * SEG_ROW];
+    const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x, base = (size_t)blockIdx.x * SEG_TILE;
     const unsigned b = blockIdx.y;
-    if (s >= nseg) return;
-    const gl_t *a0 = p.a0[b], *a1 = p.a1[b];
-    const gl2_t z = p.z[b];
-    gl2_t acc{0, 0};
-    if (upper && s + 1 < nupper) acc = gl2_t{upper[(2 * b) * nupper + s + 1], upper[(2 * b + 1) * nupper + s + 1]};
-    const size_t end = (s + 1) * FRI_SEG < m ? (s + 1) * FRI_SEG : m;
-    for (size_t k = end; k-- > s * FRI_SEG;) {
-        acc = gl2_add(gl2_mul(acc, z), gl2_t{a0[k], a1[k]});
-        out[(2 * b) * m + k] = acc.c0;
-        out[(2 * b + 1) * m + k] = acc.c1;
+    seg_tile_load(t0, p.a0[b], base, m);
+    seg_tile_load(t1, p.a1[b], base, m);
+    __syncthreads();
+    {
+        const gl2_t z = p.z[b];
+        gl2_t acc{0, 0};
+        if (upper && s + 1 < nupper) acc = gl2_t{upper[(2 * b) * nupper + s + 1], upper[(2 * b + 1) * nupper + s + 1]};
+        gl_t *r0 = t0 + threadIdx.x * SEG_ROW, *r1 = t1 + threadIdx.x * SEG_ROW;
+        for (unsigned k = FRI_SEG; k-- > 0;) {                 // (a segment past the end: zeros in, zero carry, zeros out -- never stored)
+            acc = gl2_add(gl2_mul(acc, z), gl2_t{r0[k], r1[k]});
+            r0[k] = acc.c0;
+            r1[k] = acc.c1;
+        }
+    }
+    __syncthreads();
+    for (unsigned e = threadIdx.x; e < SEG_TILE; e += 64) {
+        const size_t k = base + e;
+        if (k < m) {
+            out[(2 * b) * m + k] = t0[(e / FRI_SEG) * SEG_ROW + e % FRI_SEG];
+            out[(2 * b + 1) * m + k] = t1[(e / FRI_SEG) * SEG_ROW + e % FRI_SEG];
+        }
     }
 }
 // bottom level of LONG polynomials (>= 2^21 coefficients: enough segments to fill the machine, and the suffix values of every batch
-// would be 6 n words written and read again): all batches in one thread, fin[k - 1] = sum_b w_b S_b[k] formed on the fly
-__global__ void k_seg_scan_final(seg_batches p, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ f0,
-                                 gl_t* __restrict__ f1) {
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nseg = (m + FRI_SEG - 1) / FRI_SEG;
-    if (s >= nseg) return;
-    gl2_t acc[FRI_MAX_BATCHES];                              // (fixed trip counts + a uniform guard: the accumulators stay in registers)
-#pragma unroll
-    for (unsigned b = 0; b < FRI_MAX_BATCHES; b++) {
-        acc[b] = gl2_t{0, 0};
-        if (b < p.nb && upper && s + 1 < nupper) acc[b] = gl2_t{upper[(2 * b) * nupper + s + 1], upper[(2 * b + 1) * nupper + s + 1]};
-    }
-    const size_t end = (s + 1) * FRI_SEG < m ? (s + 1) * FRI_SEG : m;
-    if (end == m) { f0[m - 1] = 0; f1[m - 1] = 0; }
-    for (size_t k = end; k-- > s * FRI_SEG;) {
-        gl2_t f{0, 0};
-#pragma unroll
-        for (unsigned b = 0; b < FRI_MAX_BATCHES; b++) {
-            if (b < p.nb) {
-                acc[b] = gl2_add(gl2_mul(acc[b], p.z[b]), gl2_t{p.a0[b][k], p.a1[b][k]});
-                f = gl2_add(f, gl2_mul(acc[b], p.w[b]));
-            }
+// would be 6 n words written and read again): all batches in one workgroup, one after the other through the same input tile, with
+// fin[k - 1] = sum_b w_b S_b[k] accumulated in an output tile
+__global__ __launch_bounds__(64) void k_seg_scan_final(seg_batches p, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ f0,
+                                                       gl_t* __restrict__ f1) {
+    extern __shared__ __attribute__((aligned(16))) gl_t seg_lds[];   // four tiles: 66 KB (launched with the raised dynamic-LDS limit)
+    gl_t *const t0 = seg_lds, *const t1 = t0 + 64 * SEG_ROW, *const g0 = t1 + 64 * SEG_ROW, *const g1 = g0 + 64 * SEG_ROW;
+    const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x, base = (size_t)blockIdx.x * SEG_TILE;
+    gl_t *r0 = t0 + threadIdx.x * SEG_ROW, *r1 = t1 + threadIdx.x * SEG_ROW, *q0 = g0 + threadIdx.x * SEG_ROW, *q1 = g1 + threadIdx.x * SEG_ROW;
+    for (unsigned b = 0; b < p.nb; b++) {
+        if (b) __syncthreads();                                // everyone is done with the previous batch's tile
+        seg_tile_load(t0, p.a0[b], base, m);
+        seg_tile_load(t1, p.a1[b], base, m);
+        __syncthreads();
+        const gl2_t z = p.z[b], w = p.w[b];
+        gl2_t acc{0, 0};
+        if (upper && s + 1 < nupper) acc = gl2_t{upper[(2 * b) * nupper + s + 1], upper[(2 * b + 1) * nupper + s + 1]};
+        for (unsigned k = FRI_SEG; k-- > 0;) {
+            acc = gl2_add(gl2_mul(acc, z), gl2_t{r0[k], r1[k]});
+            gl2_t f = gl2_mul(acc, w);
+            if (b) f = gl2_add(f, gl2_t{q0[k], q1[k]});
+            q0[k] = f.c0;
+            q1[k] = f.c1;
         }
-        if (k > 0) { f0[k - 1] = f.c0; f1[k - 1] = f.c1; }
     }
+    __syncthreads();
+    for (unsigned e = threadIdx.x; e < SEG_TILE; e += 64) {   // word k of the tile is fin[k - 1]
+        const size_t k = base + e;
+        if (k > 0 && k < m) {
+            f0[k - 1] = g0[(e / FRI_SEG) * SEG_ROW + e % FRI_SEG];
+            f1[k - 1] = g1[(e / FRI_SEG) * SEG_ROW + e % FRI_SEG];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { f0[m - 1] = 0; f1[m - 1] = 0; }
 }
 // fin[k - 1] = sum_b w_b S_b[k] (the dropped remainders are the S_b[0]), fin[m - 1] = 0      (suf: [batch][2][m], bottom level)
 __global__ __launch_bounds__(256) void k_seg_combine(seg_batches p, size_t m, const gl_t* __restrict__ suf, gl_t* __restrict__ f0,
@@ -725,12 +763,27 @@ static void divide_accumulate_all(zkm_ctx* c, const std::vector<fri_composite>& 
 
 // ------------------------------------------------------------------ K13: FRI fold
 // c'_j = sum_{i < arity} beta^i c_{arity j + i}   (reduce_with_powers per chunk)
-__global__ __launch_bounds__(256) void k_fri_fold(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nout, unsigned arity,
-                                                  gl2_t beta, gl_t* __restrict__ o0, gl_t* __restrict__ o1) {
-    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// A thread's 16 coefficients are one 128-byte line of each array: read with one 8-byte load per step they were fetched from HBM again
+// and again (lanes 128 B apart, the lines evicted between steps: 850 MB of traffic for 76 MB of data in config 4, profiles/r04_e).  The
+// workgroup's 64 x arity coefficients therefore come in with lane-contiguous loads into an LDS tile (row stride arity + 1: the walk
+// over one's own row is bank-conflict free) and are read from there.
+#define FRI_FOLD_MAX_ARITY 16
+__global__ __launch_bounds__(64) void k_fri_fold(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nout, unsigned arity,
+                                                 gl2_t beta, gl_t* __restrict__ o0, gl_t* __restrict__ o1) {
+    __shared__ gl_t t0[64 * (FRI_FOLD_MAX_ARITY + 1)], t1[64 * (FRI_FOLD_MAX_ARITY + 1)];
+    const size_t j0 = (size_t)blockIdx.x * 64, total = nout * arity, base = j0 * arity;
+    const unsigned tid = threadIdx.x, rs = arity + 1;
+    for (unsigned e = tid; e < 64 * arity; e += 64) {
+        const size_t k = base + e;
+        const unsigned at = (e / arity) * rs + e % arity;
+        t0[at] = k < total ? c0[k] : 0;
+        t1[at] = k < total ? c1[k] : 0;
+    }
+    __syncthreads();
+    const size_t j = j0 + tid;
     if (j >= nout) return;
     gl2_t acc{0, 0};
-    for (unsigned i = arity; i-- > 0;) acc = gl2_add(gl2_mul(acc, beta), gl2_t{c0[j * arity + i], c1[j * arity + i]});
+    for (unsigned i = arity; i-- > 0;) acc = gl2_add(gl2_mul(acc, beta), gl2_t{t0[tid * rs + i], t1[tid * rs + i]});
     o0[j] = acc.c0;
     o1[j] = acc.c1;
 }
@@ -863,7 +916,14 @@ static void divide_accumulate_all(zkm_ctx* c, const std::vector<fri_composite>& 
         const gl_t* upper = l + 1 < L ? suf[l + 1] : nullptr;
         const size_t nupper = l + 1 < L ? m[l + 1] : 0;
         if (l == 0 && n >= c->fri_fused_division_min) {
-            hipLaunchKernelGGL(k_seg_scan_final, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, c->stream, lv[0], n, upper, nupper, f0, f1);
+            static std::atomic<uint64_t> lds_ok{0};             // (hipFuncSetAttribute is per device; setting it twice is harmless)
+            const uint64_t bit = (uint64_t)1 << (c->device & 63);
+            if (!(lds_ok.load(std::memory_order_acquire) & bit)) {
+                ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_seg_scan_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                lds_ok.fetch_or(bit, std::memory_order_release);
+            }
+            hipLaunchKernelGGL(k_seg_scan_final, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 4 * 64 * SEG_ROW * sizeof(gl_t), c->stream, lv[0], n,
+                               upper, nupper, f0, f1);
             break;
         }
         suf[l] = (gl_t*)c->alloc(2 * nb * m[l] * sizeof(gl_t));
@@ -925,7 +985,8 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
             scratch.push_back(d_new);
             {
                 zkm_prof_scope ps(c, "fri_fold");
-                hipLaunchKernelGGL(k_fri_fold, dim3((nout + 255) / 256), dim3(256), 0, c->stream, d_coef0, d_coef1, nout, arity, beta, d_new, d_new + nout);
+                if (arity > FRI_FOLD_MAX_ARITY) throw std::runtime_error("FRI: arity above 16");
+                hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((nout + 63) / 64)), dim3(64), 0, c->stream, d_coef0, d_coef1, nout, arity, beta, d_new, d_new + nout);
                 ZKM_HIP_CHECK(hipGetLastError());
             }
             d_coef0 = d_new;

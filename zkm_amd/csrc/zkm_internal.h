@@ -42,7 +42,8 @@ struct zkm_ctx {
     hipStream_t copy_stream = nullptr;  // host -> device ingest, overlapped with the compute stream (created on first use)
     size_t ingest_chunk_cols = 32;      // columns per ingest chunk (0 = monolithic upload)           } zkm_ctx_set_tuning
     size_t keccak_parts_max_points = (size_t)1 << 15;   // k_quotient_keccak_parts up to this many points  }
-    size_t fri_fused_division_min = (size_t)1 << 21;    // k_seg_scan_final from this many coefficients    }
+    size_t fri_fused_division_min = ~(size_t)0;         // k_seg_scan_final from this many coefficients (default: never -- since the
+                                                        // LDS-tiled kernels of round 4 the per-batch scans are faster at every size)  }
     size_t wide_max_hashes = 1024;      // launches of up to this many hashes use 16 lanes per hash (latency form)   } 0 / 0: one lane
     size_t quad_max_hashes = 16384;     // ... and up to this many four lanes per hash                                } per hash always
     int num_cus = 256;
