@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void k_fri_combine_sum(const gl_t* __restrict_
     comp[5 * n + i] = t[5];
 }
 
-// divide_by_linear as a hierarchical suffix scan with segments of FRI_SEG, for ALL batches of the instance in one set of
+// divide_by_linear as a hierarchical suffix scan with segments of FRI_SEG (profiles/HISTORY.md), for ALL batches of the instance in one set of
 // launches (blockIdx.y = batch; the STARK instance has three: zeta, g zeta, 1).  Per batch b: q_b = (comp_b(X) - comp_b(z_b)) / (X - z_b),
 // q_b[k - 1] = S_b[k] with S_b[k] = a_b[k] + z_b S_b[k + 1]; the final polynomial is sum_b w_b q_b, w_b = prod_{b' > b} shift_b'
 // (plonky2 accumulates final = final * alpha^(#polys of the batch) + quotient, batch by batch: the same sum, regrouped).
