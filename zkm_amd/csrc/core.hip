@@ -167,6 +167,8 @@ void zkm_ctx::ensure_xfer() {
 // spinning steals the cores the other contexts need to launch their kernels.  So: spin for `block_after_us` (default 50 us: most round
 // trips of an idle GPU end inside it); after that, a crowded process parks the thread on a blocking-sync event (interrupt-driven
 // wake-up) while an uncrowded one keeps polling with sched_yield.
+static std::atomic<int> g_live_contexts{0};
+int zkm_live_contexts() { return g_live_contexts.load(std::memory_order_relaxed); }
 static std::atomic<int> g_waiting{0};
 static int allowed_cpus() {
     static const int n = [] {
@@ -337,12 +339,14 @@ int zkm_ctx_create(int device, zkm_ctx** out, char** err) {
     c->num_cus = prop.multiProcessorCount;
     ZKM_HIP_CHECK(zkm_stream_create(&c->stream, c->num_cus));
     zkm_hw_queues_hint();
+    g_live_contexts.fetch_add(1, std::memory_order_relaxed);
     *out = c;
     ZKM_API_END(err)
 }
 
 void zkm_ctx_destroy(zkm_ctx* c) {
     if (!c) return;
+    if (!c->parent) g_live_contexts.fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(c->device);
     for (zkm_ctx* l : c->lanes) zkm_ctx_destroy(l);
     c->lanes.clear();

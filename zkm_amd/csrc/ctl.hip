@@ -662,7 +662,9 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
                 if (host[t] && !have_limit) {
                     size_t free_b = 0, total_b = 0;
                     ZKM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-                    keep_limit = free_b / 4;
+                    // (a quarter of what is free NOW -- shared with every other context of this process working on the same GPU, each of
+                    // which asks the same question on its own: divided by their number)
+                    keep_limit = free_b / 4 / (size_t)std::max(1, zkm_live_contexts());
                     have_limit = true;
                 }
                 keep[t] = host[t] && kept + bytes <= keep_limit;

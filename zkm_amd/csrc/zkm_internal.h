@@ -214,6 +214,7 @@ void zkm_intt_digit(zkm_ctx*, const gl_t* values, size_t cs_in, gl_t* coeffs, si
 void zkm_coeff_layout_convert(zkm_ctx*, const gl_t* in, size_t cs_in, gl_t* out, size_t cs_out, size_t ncols, unsigned log_n, bool to_natural);
 
 // ---- core.hip
+int zkm_live_contexts();   // contexts of this process that exist right now (zkm_ctx_create .. zkm_ctx_destroy; lanes not counted)
 // dev_values (optional, ncols x n words of device memory): host values are uploaded THERE and stay (the caller reuses them, e.g. for
 // the CTL columns of prove_with_traces) instead of being staged inside the batch's LDE buffer.
 // src_cols (optional, instead of src): one pointer per column (each n words, host or device).
