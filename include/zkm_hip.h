@@ -53,6 +53,11 @@ void zkm_ctx_trim(zkm_ctx* ctx);
  *                               every tree level of >= 256 parents (the levels below that, a few hundred hashes per tree, keep the
  *                               quad form: the one-lane kernel works on blocks of 256 parents); a GPU shared by many contexts
  *                               proving small segments may prefer throughput -- measured in profiles/r03_hw_queues.txt
+ *   "commit_lanes"              trace / auxiliary commitments of one segment built side by side (default 4: the context and three
+ *                               lanes, one stream and host thread each; 1 = everything on the context's own stream)
+ *   "throughput_profile"        1: the settings for MANY contexts per GPU proving small segments (commit_lanes 1, wide_max_hashes 256,
+ *                               quad_max_hashes 4096: 16 contexts reach 74-75 segments/s of 2^16 cycles against 57-59 for 8 contexts
+ *                               with the defaults, profiles/r04_throughput_profile.txt); 0: the defaults again
  *   "block_after_us"            a transcript round trip (cap, opening partials, proof-of-work witness coming down) is waited for by
  *                               polling a flag in pinned memory; after this many microseconds (default 50) a thread of a CROWDED
  *                               process -- more than half as many threads waiting as CPUs the process may run on -- parks on a

@@ -300,8 +300,8 @@ def test_concurrent_contexts_are_bit_exact(ctx, zkm):
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_n", [9, 13])
 def test_tuning_fri_division_variants_agree(zkm, oracle, log_n):
-    """Division by (X - z): one batch per thread + a combine launch (default below 2^21 coefficients) against all batches in one
-    thread (default from 2^21 on, covered at full size by test_prove_openings_bit_exact[22]) -- forced both ways at small sizes."""
+    """Division by (X - z): one batch per workgroup column + a combine launch (the default at every size since round 4) against all
+    batches in one workgroup (k_seg_scan_final, behind the "fri_fused_division_min" threshold) -- forced both ways at small sizes."""
     W, A, Q, Z = 13, 4, 4, 2
     rng = np.random.default_rng(92)
     n = 1 << log_n

@@ -210,6 +210,20 @@ def test_segment_at_2_16_cycle_heights_is_bit_exact(ctx, zkm, oracle):
     assert list(offs) == list(roffs) and (chal == rchal).all()
     bad = np.nonzero(got != ref)[0]
     assert bad.size == 0, "first differing word %d (table %d)" % (bad[0], int(np.searchsorted(offs, bad[0], side="right")) - 1)
+    # the throughput profile (one stream per context, latency forms of the permutation only for tiny launches: at these heights the
+    # leaves of the 2^13 / 2^14-row matrices move from the quad to the one-lane form, those of 2^10 rows from 16 lanes to a quad, and
+    # every commitment runs on the context's own stream) must give the same words
+    c2 = zkm.Context(0)
+    try:
+        c2.set_tuning("throughput_profile", 1)
+        got2, chal2, offs2 = c2.prove_segment(traces, log_n, public_values=[1, 2, 3])
+        assert list(offs2) == list(offs) and (chal2 == chal).all() and (got2 == got).all()
+        c2.set_tuning("throughput_profile", 0)
+        c2.set_tuning("commit_lanes", 2)
+        got3, _, _ = c2.prove_segment(traces, log_n, public_values=[1, 2, 3])
+        assert (got3 == got).all()
+    finally:
+        c2.close()
 
 
 @pytest.mark.gpu

@@ -73,14 +73,19 @@ def segment_rate(ctx, log_cycles, reps=3):
                     "scopes of those two phases overlap too -- wall_over_kernel_sum below 1 means concurrency, not a faster clock"}
 
 
-def concurrent_segment_rate(device, log_cycles, nctx, reps=6, tuning=None):
+def concurrent_segment_rate(device, log_cycles, nctx, reps=6, tuning=None, cu_parts=0):
     """`nctx` host threads, each with its OWN context (own stream, allocator, transcript) on the same GPU, proving independent
     segments at the same time: in the launch-bound regime of small segments the GPU interleaves their kernels, so the per-level
     Merkle / per-layer FRI latencies of one segment are filled with the work of the others.  Segments are independent proofs
     (prover/examples/utils/src/utils.rs:57-68), so this is the same sharding as across GPUs, applied within one."""
     import threading
     import zkm_amd
-    ctxs = [zkm_amd.Context(device) for _ in range(nctx)]
+    ctxs = []
+    for i in range(nctx):
+        if cu_parts:                                   # measurement aid: context i confined to part i % cu_parts of the CUs (csrc/core.hip)
+            os.environ["ZKM_CU_MASK_PART"] = "%d/%d" % (i % cu_parts, cu_parts)
+        ctxs.append(zkm_amd.Context(device))
+    os.environ.pop("ZKM_CU_MASK_PART", None)
     for c in ctxs:
         for k, v in (tuning or {}).items():
             c.set_tuning(k, v)
@@ -124,10 +129,24 @@ def multi_process_rate(procs, nctx, reps=8):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+THROUGHPUT = {"throughput_profile": 1}   # zkm_ctx_set_tuning: one stream per context, latency forms of the permutation for tiny launches only
+
+
+def throughput_rates(device, contexts=(8, 12, 16)):
+    """Many contexts per GPU in the throughput profile (include/zkm_hip.h "throughput_profile"; profiles/r04_throughput_profile.txt)."""
+    out = []
+    for k in contexts:
+        r = concurrent_segment_rate(device, 16, k, reps=5, tuning=THROUGHPUT)
+        r["profile"] = "throughput (commit_lanes 1, wide_max_hashes 256, quad_max_hashes 4096)"
+        out.append(r)
+    return out
+
+
 def small_segment_rate(ctx, device=0):
     out = segment_rate(ctx, 16)
     try:
         out["concurrent"] = [concurrent_segment_rate(device, 16, k) for k in (2, 4, 8)]
+        out["concurrent_throughput_profile"] = throughput_rates(device)
         out["concurrent_processes"] = [multi_process_rate(p, k) for p, k in ((1, 8), (2, 4), (4, 2))]
     except Exception as e:  # the single-context figure stands on its own
         out["concurrent_error"] = str(e)
@@ -142,5 +161,6 @@ if __name__ == "__main__":
     out["memory_live_cached"] = c.memory()
     if lc == 16 and "single" not in sys.argv[2:]:
         out["concurrent"] = [concurrent_segment_rate(0, 16, k) for k in (2, 4, 8)]
+        out["concurrent_throughput_profile"] = throughput_rates(0)
         out["concurrent_processes"] = [multi_process_rate(p, k) for p, k in ((1, 8), (2, 4), (4, 2))]
     print(json.dumps(out, indent=1))

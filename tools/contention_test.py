@@ -5,7 +5,7 @@ commitments while the CPU table's leaf hashing, one lane per row, fills the mach
 
 Context K commits a Keccak-shaped table (2431 x 2^11) over and over, context C a CPU-shaped one (259 x 2^16); K's leaf kernel time comes
 from the library's HIP-event profile.  Cases: K alone; K next to C; the same with the two contexts confined to disjoint halves of the
-CUs (ZKM_CU_MASK_HALF, csrc/core.hip).      python tools/contention_test.py  -> one JSON line per case
+CUs (ZKM_CU_MASK_PART, csrc/core.hip).      python tools/contention_test.py  -> one JSON line per case
 """
 import json
 import os
@@ -26,11 +26,11 @@ P = 0xFFFFFFFF00000001
 def case(name, mask_k, mask_c, with_c, reps=4):
     def make(mask):
         if mask is None:
-            os.environ.pop("ZKM_CU_MASK_HALF", None)
+            os.environ.pop("ZKM_CU_MASK_PART", None)
         else:
-            os.environ["ZKM_CU_MASK_HALF"] = mask
+            os.environ["ZKM_CU_MASK_PART"] = mask
         c = zkm_amd.Context(0)
-        os.environ.pop("ZKM_CU_MASK_HALF", None)
+        os.environ.pop("ZKM_CU_MASK_PART", None)
         return c
     ck, cc = make(mask_k), make(mask_c)
     rng = np.random.default_rng(1)
@@ -71,5 +71,5 @@ def case(name, mask_k, mask_c, with_c, reps=4):
 if __name__ == "__main__":
     case("keccak table alone", None, None, False)
     case("next to the CPU table's commitment (shared CUs)", None, None, True)
-    case("disjoint halves of the CUs", "0", "1", True)
-    case("keccak alone on half of the CUs", "0", None, False)
+    case("disjoint halves of the CUs", "0/2", "1/2", True)
+    case("keccak alone on half of the CUs", "0/2", None, False)

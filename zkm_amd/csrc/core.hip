@@ -85,14 +85,13 @@ void zkm_ctx::trim() {   // public: between calls (zkm_ctx_trim)
     trim_self();
     for (zkm_ctx* l : lanes) l->trim_self();
 }
-// A stream of the library.  ZKM_CU_MASK_HALF = 0 | 1 (measurement aid, read per call): the stream may only use one half of the GPU's
-// compute units (mask bits [0, n/2) or [n/2, n)) -- tools/contention_test.py uses it to find out what a latency-bound launch loses to
-// a throughput-bound one sharing its CUs.
-static hipError_t zkm_stream_create(hipStream_t* st, int num_cus) {
-    const char* half = getenv("ZKM_CU_MASK_HALF");
-    if (half && (half[0] == '0' || half[0] == '1') && num_cus >= 64) {
+// A stream of the library.  ZKM_CU_MASK_PART = "k/n" (measurement aid, read when a context is created; its lanes inherit it): the
+// context's streams may only use the k-th of n equal parts of the GPU's compute units (mask bits [k N/n, (k+1) N/n)) --
+// tools/contention_test.py and tools/bench_segment.py use it to find out what launches of different contexts cost each other.
+static hipError_t zkm_stream_create(hipStream_t* st, int num_cus, int part_k, int part_n) {
+    if (part_n > 1 && part_k >= 0 && part_k < part_n && num_cus >= 8 * part_n) {
         std::vector<uint32_t> mask((size_t)(num_cus + 31) / 32, 0);
-        const int lo = half[0] == '0' ? 0 : num_cus / 2, hi = half[0] == '0' ? num_cus / 2 : num_cus;
+        const int lo = (int)((long)num_cus * part_k / part_n), hi = (int)((long)num_cus * (part_k + 1) / part_n);
         for (int i = lo; i < hi; i++) mask[i / 32] |= 1u << (i % 32);
         return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
     }
@@ -109,7 +108,9 @@ void zkm_ctx::ensure_lanes(size_t k) {
         l->fri_fused_division_min = fri_fused_division_min;
         l->wide_max_hashes = wide_max_hashes;
         l->quad_max_hashes = quad_max_hashes;
-        hipError_t e = zkm_stream_create(&l->stream, num_cus);
+        l->cu_part_k = cu_part_k;
+        l->cu_part_n = cu_part_n;
+        hipError_t e = zkm_stream_create(&l->stream, num_cus, cu_part_k, cu_part_n);
         if (e != hipSuccess) {
             delete l;
             ZKM_HIP_CHECK(e);
@@ -337,7 +338,11 @@ int zkm_ctx_create(int device, zkm_ctx** out, char** err) {
     hipDeviceProp_t prop;
     ZKM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
-    ZKM_HIP_CHECK(zkm_stream_create(&c->stream, c->num_cus));
+    if (const char* part = getenv("ZKM_CU_MASK_PART")) {
+        int k = -1, n = 0;
+        if (sscanf(part, "%d/%d", &k, &n) == 2) { c->cu_part_k = k; c->cu_part_n = n; }
+    }
+    ZKM_HIP_CHECK(zkm_stream_create(&c->stream, c->num_cus, c->cu_part_k, c->cu_part_n));
     zkm_hw_queues_hint();
     g_live_contexts.fetch_add(1, std::memory_order_relaxed);
     *out = c;
@@ -374,6 +379,16 @@ int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) 
         else if (k == "wide_max_hashes") x->wide_max_hashes = (size_t)value;
         else if (k == "quad_max_hashes") x->quad_max_hashes = (size_t)value;
         else if (k == "block_after_us") x->block_after_us = value;
+        else if (k == "commit_lanes") x->commit_lanes = value < 1 ? 1 : (value > 8 ? 8 : (size_t)value);
+        else if (k == "throughput_profile") {
+            // MANY contexts on one GPU proving small segments (profiles/r04_throughput_profile.txt): one stream per context -- the runtime
+            // has ~16 hardware queues, and streams that share one run behind each other's long kernels -- and the latency forms of the
+            // permutation only where a launch is tiny (with a dozen independent chains in flight the issue slots they cost are somebody
+            // else's work).  0 restores the defaults of a context that has the GPU (nearly) to itself.
+            x->commit_lanes = value ? 1 : ZKM_COMMIT_LANES;
+            x->wide_max_hashes = value ? 256 : 1024;
+            x->quad_max_hashes = value ? 4096 : 16384;
+        }
         else if (k == "debug_fail_allocs") { if (x == c) x->debug_fail_allocs.store((int)value); }
         else throw std::runtime_error("zkm_ctx_set_tuning: unknown key '" + k + "'");
     };

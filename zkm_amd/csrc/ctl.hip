@@ -554,7 +554,7 @@ static double commit_cost_estimate(const zkm_ctx* c, size_t ncols, unsigned log_
 template <class F>
 static void run_on_lanes(zkm_ctx* c, const std::vector<size_t>& big, const std::vector<size_t>& small, const std::vector<double>& cost,
                          F&& fn) {
-    const size_t nlanes = small.size() >= 2 ? std::min<size_t>(ZKM_COMMIT_LANES, small.size()) - 1 : 0;
+    const size_t nlanes = small.size() >= 2 ? std::min<size_t>(std::max<size_t>(1, c->commit_lanes), small.size()) - 1 : 0;
     c->ensure_lanes(nlanes);
     std::vector<std::vector<size_t>> mine(nlanes + 1);
     {

@@ -30,6 +30,10 @@ struct zkm_prof_rec {
     hipEvent_t start, stop;
 };
 
+#ifndef ZKM_COMMIT_LANES
+#define ZKM_COMMIT_LANES 4   // trace commitments in flight per context (the context itself + 3 lanes)
+#endif
+
 struct zkm_twiddles {
     gl_t* fwd = nullptr;  // per-stage tables concatenated: entry (1<<s) + j = w_{2^(s+1)}^j, j < 2^s
     gl_t* inv = nullptr;  // same with inverse roots
@@ -44,9 +48,11 @@ struct zkm_ctx {
     size_t keccak_parts_max_points = (size_t)1 << 15;   // k_quotient_keccak_parts up to this many points  }
     size_t fri_fused_division_min = ~(size_t)0;         // k_seg_scan_final from this many coefficients (default: never -- since the
                                                         // LDS-tiled kernels of round 4 the per-batch scans are faster at every size)  }
+    size_t commit_lanes = ZKM_COMMIT_LANES;   // trace / auxiliary commitments of one segment in flight (this context + lanes)   } zkm_ctx_set_tuning
     size_t wide_max_hashes = 1024;      // launches of up to this many hashes use 16 lanes per hash (latency form)   } 0 / 0: one lane
     size_t quad_max_hashes = 16384;     // ... and up to this many four lanes per hash                                } per hash always
     int num_cus = 256;
+    int cu_part_k = -1, cu_part_n = 0;   // measurement aid (ZKM_CU_MASK_PART): the streams of this context are confined to one part of the CUs
     // profiling
     bool profiling = false;
     std::vector<zkm_prof_rec> prof;
@@ -107,9 +113,6 @@ struct zkm_ctx {
     void sync() { ZKM_HIP_CHECK(hipStreamSynchronize(stream)); up_off = 0; }
 };
 
-#ifndef ZKM_COMMIT_LANES
-#define ZKM_COMMIT_LANES 4   // trace commitments in flight per context (the context itself + 3 lanes)
-#endif
 
 // RAII owner of one scratch block from the context's allocator (released on every exit path)
 struct zkm_scratch {
