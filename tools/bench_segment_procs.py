@@ -19,6 +19,9 @@ def worker(rank, nctx, reps, start, done, out):
     import zkm_amd
     from tools.bench_segment import tiled_segment
     ctxs = [zkm_amd.Context(int(os.environ.get("ZKM_BENCH_DEVICE", "0"))) for _ in range(nctx)]
+    for kv in filter(None, os.environ.get("ZKM_SEG_TUNING", "").split(",")):      # "key=value,...": zkm_ctx_set_tuning on every context
+        for c in ctxs:
+            c.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
     data = [tiled_segment(c, 16) for c in ctxs]
     for c, (bufs, logs) in zip(ctxs, data):
         c.prove_segment(bufs, logs, public_values=[1, 2, 3])
