@@ -115,13 +115,13 @@ def concurrent_segment_rate(device, log_cycles, nctx, reps=6, tuning=None, cu_pa
     return {"contexts": nctx, "segments_per_context": reps, "segments_per_s": nctx * reps / wall, "ms_per_segment_amortised": wall * 1e3 / (nctx * reps)}
 
 
-def multi_process_rate(procs, nctx, reps=8):
+def multi_process_rate(procs, nctx, reps=8, tuning=""):
     """The same with the contexts in `procs` fresh host processes (tools/bench_segment_procs.py): every process has its own HIP runtime,
     so launches of different processes do not queue behind one another on the host; 1 x k is the deployment shape itself -- a prover
     process with k contexts and nothing else in it (the in-process `concurrent` figures share bench.py's process with its four
     headline contexts and torch)."""
     import subprocess
-    env = dict(os.environ, GPU_MAX_HW_QUEUES=str(max(2, 16 // procs)))   # ~16 hardware queues on the GPU in total (csrc/core.hip)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=str(max(2, 16 // procs)), ZKM_SEG_TUNING=tuning)   # ~16 hardware queues on the GPU in total
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_segment_procs.py"), str(procs), str(nctx), str(reps)],
                        capture_output=True, text=True, timeout=300, env=env)
     if r.returncode != 0:
@@ -133,11 +133,13 @@ THROUGHPUT = {"throughput_profile": 1}   # zkm_ctx_set_tuning: one stream per co
 
 
 def throughput_rates(device, contexts=(8, 12, 16)):
-    """Many contexts per GPU in the throughput profile (include/zkm_hip.h "throughput_profile"; profiles/r04_throughput_profile.txt)."""
+    """Many contexts per GPU in the throughput profile (include/zkm_hip.h "throughput_profile"; profiles/r04_throughput_profile.txt), each
+    measurement in a FRESH process with nothing else in it: the profile is about the number of streams a process maps onto the runtime's
+    hardware queues, and the contexts of the calling process (bench.py: four headline contexts and their lanes) would count too."""
     out = []
     for k in contexts:
-        r = concurrent_segment_rate(device, 16, k, reps=5, tuning=THROUGHPUT)
-        r["profile"] = "throughput (commit_lanes 1, wide_max_hashes 256, quad_max_hashes 4096)"
+        r = multi_process_rate(1, k, reps=5, tuning="throughput_profile=1")
+        r["profile"] = "throughput (commit_lanes 1, wide_max_hashes 256, quad_max_hashes 4096), fresh process"
         out.append(r)
     return out
 
