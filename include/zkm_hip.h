@@ -53,6 +53,10 @@ void zkm_ctx_trim(zkm_ctx* ctx);
  *                               every tree level of >= 256 parents (the levels below that, a few hundred hashes per tree, keep the
  *                               quad form: the one-lane kernel works on blocks of 256 parents); a GPU shared by many contexts
  *                               proving small segments may prefer throughput -- measured in profiles/r03_hw_queues.txt
+ *   "small_ntt"                 transforms of 2^9 .. 2^13 points (inverse transforms and coset-LDE blocks of short tables, quotient
+ *                               chunks, FRI layers) in ONE launch, a column per workgroup (default 1); 0: two strided passes
+ *   "tree_tail"                 Merkle trees of up to 2^15 leaves built in ONE launch that also delivers the cap to the host (default 1);
+ *                               0: up to three launches for the levels and a download kernel
  *   "commit_lanes"              trace / auxiliary commitments of one segment built side by side (default 4: the context and three
  *                               lanes, one stream and host thread each; 1 = everything on the context's own stream)
  *   "throughput_profile"        1: the settings for MANY contexts per GPU proving small segments (commit_lanes 1, wide_max_hashes 256,

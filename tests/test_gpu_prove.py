@@ -378,3 +378,37 @@ def test_tuning_poseidon_forms_agree(zkm, oracle, log_n, W):
         for b in (tb, ab, qb):
             b.free()
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,W", [(5, 9), (7, 13), (9, 70), (11, 33), (13, 9), (14, 5)])
+def test_tuning_single_launch_small_paths_agree(zkm, oracle, log_n, W):
+    """Round 4's single-launch paths for short tables -- whole transforms of 2^9 .. 2^13 points in one workgroup (k_ntt_small: inverse
+    transform natural -> natural, coset LDE as four blocks) and the tree tail that climbs from <= 2^11 nodes to the cap and delivers it
+    to the host itself (k_merkle_tail) -- against the two-pass transforms and the level kernels + download: coefficients, every digest
+    layer, cap and the openings proof, both ways, equal to the oracle's.  Heights on both sides of each size limit."""
+    A, Q, Z = 4, 4, 2
+    rng = np.random.default_rng(94)
+    n = 1 << log_n
+    tv, av, qc = (rng.integers(0, P, k * n, dtype=np.uint64) for k in (W, A, Q))
+    otb, oab, oqb = oracle.batch_from_values(tv, W, log_n), oracle.batch_from_values(av, A, log_n), oracle.batch_from_coeffs(qc, Q, log_n)
+    want = oracle.prove_openings(otb, oab, oqb, Z)
+    for small_ntt, tree_tail in ((1, 1), (0, 0), (1, 0), (0, 1)):
+        c = zkm.Context(0)
+        c.set_tuning("small_ntt", small_ntt)
+        c.set_tuning("tree_tail", tree_tail)
+        tb, ab = zkm.PolynomialBatch.from_values(c, tv, W, log_n), zkm.PolynomialBatch.from_values(c, av, A, log_n)
+        qb = zkm.PolynomialBatch.from_coeffs(c, qc, Q, log_n)
+        key = (small_ntt, tree_tail)
+        assert (tb.coeffs() == otb.coeffs()).all(), key
+        assert (tb.cap() == otb.cap()).all() and (ab.cap() == oab.cap()).all() and (qb.cap() == oqb.cap()).all(), key
+        for lvl in range(0, log_n + 2 - 4 + 1):
+            assert (tb.digest_layer(lvl) == otb.digest_layer(lvl)).all(), (key, lvl)
+        for i in (0, 1, 4 * n - 1):
+            assert (tb.lde_row(i) == otb.lde_row(i)).all(), (key, i)
+        assert (c.prove_openings(tb, ab, qb, Z) == want).all(), key
+        for b in (tb, ab, qb):
+            b.free()
+        live, _ = c.memory()
+        assert live == c.resident_bytes(), key          # (the tail kernel's ticket word is resident, nothing else stays behind)
+        c.close()

@@ -220,6 +220,8 @@ def test_segment_at_2_16_cycle_heights_is_bit_exact(ctx, zkm, oracle):
         assert list(offs2) == list(offs) and (chal2 == chal).all() and (got2 == got).all()
         c2.set_tuning("throughput_profile", 0)
         c2.set_tuning("commit_lanes", 2)
+        c2.set_tuning("small_ntt", 0)          # ... and the two-pass transforms / level kernels + download instead of round 4's
+        c2.set_tuning("tree_tail", 0)          # single-launch paths for short tables
         got3, _, _ = c2.prove_segment(traces, log_n, public_values=[1, 2, 3])
         assert (got3 == got).all()
     finally:

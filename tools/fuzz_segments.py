@@ -21,6 +21,8 @@ rng = np.random.default_rng(seed)
 o = oracle_py.Oracle()
 o.set_threads(min(64, os.cpu_count() or 1))
 ctx = zkm_amd.Context(0)
+for kv in filter(None, os.environ.get("ZKM_SEG_TUNING", "").split(",")):   # "key=value,...": zkm_ctx_set_tuning
+    ctx.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 seg = np.load(os.path.join(ROOT, "tests", "golden", "segment12.npz"))
 base = [int(x) for x in seg["log_n"]]
 ctl_tables, ctls = T.all_cross_table_lookups()

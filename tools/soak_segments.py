@@ -15,6 +15,9 @@ from tools.bench_segment import tiled_segment  # noqa: E402
 nctx = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 ctxs = [zkm_amd.Context(0) for _ in range(nctx)]
+for kv in filter(None, os.environ.get("ZKM_SEG_TUNING", "").split(",")):   # "key=value,...": zkm_ctx_set_tuning on every context
+    for c_ in ctxs:
+        c_.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 data = [tiled_segment(c, 16) for c in ctxs]
 ref, _, _ = ctxs[0].prove_segment(*data[0], public_values=[1, 2, 3])
 ref = np.array(ref, copy=True)

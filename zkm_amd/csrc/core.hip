@@ -108,6 +108,9 @@ void zkm_ctx::ensure_lanes(size_t k) {
         l->fri_fused_division_min = fri_fused_division_min;
         l->wide_max_hashes = wide_max_hashes;
         l->quad_max_hashes = quad_max_hashes;
+        l->small_ntt = small_ntt;
+        l->tree_tail = tree_tail;
+        l->commit_lanes = commit_lanes;
         l->cu_part_k = cu_part_k;
         l->cu_part_n = cu_part_n;
         hipError_t e = zkm_stream_create(&l->stream, num_cus, cu_part_k, cu_part_n);
@@ -209,6 +212,24 @@ void zkm_ctx::wait_flag(const uint64_t* flag, uint64_t seq) {
         else __builtin_ia32_pause();
 #endif
     }
+}
+uint64_t zkm_ctx::xfer_begin(size_t bytes, uint64_t** host_slot, uint64_t** flag, unsigned** counter) {
+    ensure_xfer();
+    if (bytes > XFER_DOWN) throw std::runtime_error("internal: xfer_begin beyond the pinned download area");
+    if (!d_counter) {
+        d_counter = (unsigned*)alloc(64);
+        resident_bytes += 64;
+        ZKM_HIP_CHECK(hipMemsetAsync(d_counter, 0, 64, stream));
+    }
+    *host_slot = (uint64_t*)h_xfer;
+    *flag = (uint64_t*)(h_xfer + XFER_DOWN + XFER_UP);
+    *counter = d_counter;
+    return ++down_seq;
+}
+void zkm_ctx::xfer_finish(uint64_t seq, void* dst, size_t bytes) {
+    wait_flag((const uint64_t*)(h_xfer + XFER_DOWN + XFER_UP), seq);
+    up_off = 0;                                               // everything queued before the kernel has completed, uploads included
+    memcpy(dst, h_xfer, bytes);
 }
 void zkm_ctx::download(std::initializer_list<xfer> xs) {
     ensure_xfer();
@@ -379,6 +400,8 @@ int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) 
         else if (k == "wide_max_hashes") x->wide_max_hashes = (size_t)value;
         else if (k == "quad_max_hashes") x->quad_max_hashes = (size_t)value;
         else if (k == "block_after_us") x->block_after_us = value;
+        else if (k == "small_ntt") x->small_ntt = value ? 1 : 0;
+        else if (k == "tree_tail") x->tree_tail = value ? 1 : 0;
         else if (k == "commit_lanes") x->commit_lanes = value < 1 ? 1 : (value > 8 ? 8 : (size_t)value);
         else if (k == "throughput_profile") {
             // MANY contexts on one GPU proving small segments (profiles/r04_throughput_profile.txt): one stream per context -- the runtime
@@ -685,10 +708,9 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
         ZKM_HIP_CHECK(hipMemcpyAsync(nat.p, b->coeffs, ncols * n * sizeof(gl_t), hipMemcpyDeviceToDevice, c->stream));
         zkm_coeff_layout_convert(c, nat.as<gl_t>(), n, b->coeffs, n, ncols, b->log_n, /*to_natural=*/false);
     }
-    zkm_merkle_build_inner(c, b->digests, b->level_off, b->lde_bits(), b->cap_height);
     size_t capw = (size_t)4 << b->cap_height;
     b->cap.resize(capw);
-    c->download(b->cap.data(), b->digests + b->level_off[b->top()], capw * sizeof(uint64_t));
+    zkm_merkle_build_inner_cap(c, b->digests, b->level_off, b->lde_bits(), b->cap_height, b->cap.data());
 }
 
 // out[i * ncols + col] = lde[col][bitrev((index_start + i) * step)]: lanes run along i, so reads of one column are scattered

@@ -975,9 +975,8 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
             size_t dwords = zkm_merkle_layout(fl.log_leaves, cfg->cap_height, fl.level_off);
             fl.digests = (gl_t*)c->alloc(dwords * sizeof(gl_t));
             zkm_launch_merkle_leaves_ext(c, fl.values, fl.values + fl.len, (size_t)1 << fl.log_leaves, arity, fl.digests);
-            zkm_merkle_build_inner(c, fl.digests, fl.level_off, fl.log_leaves, cfg->cap_height);
             uint64_t* capo = caps_out + l * C4;
-            c->download(capo, fl.digests + fl.level_off[fl.log_leaves - cfg->cap_height], C4 * 8);
+            zkm_merkle_build_inner_cap(c, fl.digests, fl.level_off, fl.log_leaves, cfg->cap_height, capo);
             zkm_challenger_observe(ch, capo, C4);
             gl2_t beta = challenger_get_ext(ch);
             size_t nout = clen >> cfg->arity_bits;

@@ -48,6 +48,7 @@ struct zkm_ctx {
     size_t keccak_parts_max_points = (size_t)1 << 15;   // k_quotient_keccak_parts up to this many points  }
     size_t fri_fused_division_min = ~(size_t)0;         // k_seg_scan_final from this many coefficients (default: never -- since the
                                                         // LDS-tiled kernels of round 4 the per-batch scans are faster at every size)  }
+    size_t small_ntt = 1;               // transforms of 2^9 .. 2^13 points in one launch (k_ntt_small); 0: the two-pass plan          } zkm_ctx_set_tuning
     size_t commit_lanes = ZKM_COMMIT_LANES;   // trace / auxiliary commitments of one segment in flight (this context + lanes)   } zkm_ctx_set_tuning
     size_t wide_max_hashes = 1024;      // launches of up to this many hashes use 16 lanes per hash (latency form)   } 0 / 0: one lane
     size_t quad_max_hashes = 16384;     // ... and up to this many four lanes per hash                                } per hash always
@@ -105,6 +106,12 @@ struct zkm_ctx {
     hipEvent_t block_event = nullptr;
     uint64_t blocked_waits = 0;                                  // round trips that ended in the blocking wait (diagnostic)
     void ensure_xfer();
+    // a kernel that delivers a small result to the host ITSELF (hash.hip k_merkle_tail): xfer_begin hands out the pinned slot, the flag,
+    // a zeroed device word for "last workgroup publishes" and the sequence number to publish; xfer_finish waits for it and copies out
+    uint64_t xfer_begin(size_t bytes, uint64_t** host_slot, uint64_t** flag, unsigned** counter);
+    void xfer_finish(uint64_t seq, void* dst, size_t bytes);
+    unsigned* d_counter = nullptr;
+    size_t tree_tail = 1;               // trees of <= 2^15 leaves in one launch incl. the cap's trip to the host; 0: levels + download      } zkm_ctx_set_tuning
     size_t up_off = 0;
     static constexpr size_t XFER_DOWN = (size_t)1 << 20, XFER_UP = (size_t)1 << 18;
     hipEvent_t get_event();
@@ -190,6 +197,11 @@ void zkm_launch_keccak_sponge_trace(zkm_ctx*, const uint8_t* d_inputs, const uin
 // build all digest layers above level 0; fills level_off and returns total words needed (call with digests==nullptr to size)
 size_t zkm_merkle_layout(unsigned log_leaves, unsigned cap_height, std::vector<size_t>& level_off);
 void zkm_merkle_build_inner(zkm_ctx*, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height);
+// ... and the cap into cap_out (host, 4 << cap_height words): one launch for small trees (zkm_merkle_tail), levels + download otherwise
+void zkm_merkle_build_inner_cap(zkm_ctx*, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height,
+                                uint64_t* cap_out);
+bool zkm_merkle_tail(zkm_ctx*, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height, uint64_t* cap_out,
+                     unsigned l0);
 
 // ---- ntt.hip
 // in-place, natural -> bit-reversed order, forward or inverse roots, no scaling
