@@ -26,12 +26,16 @@ typedef unsigned __int128 u128_t;
 
 static inline gl_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
 
+/* (branch-free: whether a sum wraps is a coin flip on field data, and a mispredicted branch costs more than the addition -- the
+ * sparse partial rounds of the permutation alone are ~480 of these per permutation) */
 static inline gl_t gl_add(gl_t a, gl_t b) {
     uint64_t s = a + b;
-    if (s < a || s >= GL_P) s -= GL_P;
-    return s;
+    return s - ((0 - (uint64_t)((s < a) | (s >= GL_P))) & GL_P);
 }
-static inline gl_t gl_sub(gl_t a, gl_t b) { return a >= b ? a - b : a - b + GL_P; }
+static inline gl_t gl_sub(gl_t a, gl_t b) {
+    uint64_t d = a - b;
+    return d + ((0 - (uint64_t)(a < b)) & GL_P);
+}
 static inline gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
 
 static inline gl_t gl_reduce128(u128_t x) {
