@@ -51,7 +51,9 @@ def oracle_proof_2_20(oracle):
     log_n = 20
     n = 1 << log_n
     old = oracle.get_threads()
-    oracle.set_threads(min(64, os.cpu_count() or 1))
+    from bench import cpu_quota
+    threads = max(1, min(64, os.cpu_count() or 1, cpu_quota() or 64))      # (the GPU boxes grant 16 CPUs of the 256 they show)
+    oracle.set_threads(threads)
     # (all 256 cores for the row-parallel stages were measured in r04_a: 94.6 s against 72.6 s on 64 threads -- the leaf gather is
     # memory-latency bound; profiles/cpu_oracle_full_size.json "all_cores")
     try:
@@ -63,6 +65,6 @@ def oracle_proof_2_20(oracle):
     finally:
         oracle.set_threads(old)
     out = {"xor": int(np.bitwise_xor.reduce(trace)), "sample": trace[::4099].copy(), "proof": proof, "seconds": secs, "stage_s": stages,
-           "threads": min(64, os.cpu_count() or 1), "wide_threads": None}
+           "threads": threads, "wide_threads": None, "cpu_quota": cpu_quota()}
     del trace
     return out

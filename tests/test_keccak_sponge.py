@@ -109,7 +109,7 @@ def test_config5_sponge_table_2_20_rows_witness_and_commit(ctx, zkm, oracle):
     # and every hash of the tree) and a sample of coefficient columns
     import os
     old = oracle.get_threads()
-    oracle.set_threads(min(64, os.cpu_count() or 1))
+    oracle.set_threads(min(64, os.cpu_count() or 1, __import__("bench").cpu_quota() or 64))   # (the GPU boxes grant 16 CPUs of the 256 they show)
     try:
         trace = buf.download()
         want, wused = oracle.keccak_sponge_trace(data, off, meta, log_n)

@@ -174,12 +174,30 @@ void zkm_ctx::ensure_xfer() {
 static std::atomic<int> g_live_contexts{0};
 int zkm_live_contexts() { return g_live_contexts.load(std::memory_order_relaxed); }
 static std::atomic<int> g_waiting{0};
-static int allowed_cpus() {
-    static const int n = [] {
+static int allowed_cpus() {      // the affinity mask, capped by the container's CPU quota (cgroup v2 cpu.max / v1 cfs_quota: a box that
+    static const int n = [] {    // shows 256 CPUs may grant 16 -- the GPU boxes of this build do)
+        int cpus = 1 << 20;
         cpu_set_t set;
         CPU_ZERO(&set);
-        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return (int)CPU_COUNT(&set);
-        return 1 << 20;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) cpus = (int)CPU_COUNT(&set);
+        long long quota = -1, period = 100000;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(h, "%lld", &period) != 1) period = 100000;
+                fclose(h);
+            }
+        }
+        if (quota > 0 && period > 0) {
+            const int q = (int)((quota + period - 1) / period);
+            if (q >= 1 && q < cpus) cpus = q;
+        }
+        return cpus;
     }();
     return n;
 }
