@@ -74,6 +74,7 @@ BENCH_WORKER = textwrap.dedent("""
         def prove_single_table(self, trace, log_n, aux, nh):
             proved.append(trace.seed); time.sleep(0.01); return np.full(5, trace.seed, dtype=np.uint64)
         def synchronize(self): pass
+        def set_tuning(self, key, value): pass
         def profile(self, on): pass
         def profile_reset(self): pass
         def profile_records(self): return {"merkle_leaves": (len(proved), 1.0 * len(proved)), "ntt_pass_strided": (3, 0.5)}
