@@ -642,7 +642,11 @@ __global__ __launch_bounds__(256) void k_fri_combine_sum(const gl_t* __restrict_
 // batches is a separate element-wise launch.  (Until round 3: segments of 64 and the bottom level walking all batches in one
 // thread, 192 dependent steps: 158 us per table in a 2^16-cycle segment, whatever its size.)
 #define FRI_MAX_BATCHES 8
-#define FRI_SEG 32
+// (segment length: the chain a thread walks.  With the LDS tiles the kernels are chains of dependent extension-field steps at low
+// occupancy, so shorter segments -- more, cheaper levels -- win: 2^22 coefficients, three batches: 0.70 ms at 32, 0.46 at 16, 0.36 at 8)
+#ifndef FRI_SEG
+#define FRI_SEG 8
+#endif
 struct seg_batches {
     uint32_t nb;
     const gl_t* a0[FRI_MAX_BATCHES];   // this level's arrays of every batch (level 0: the composite polynomials)
@@ -653,7 +657,7 @@ struct seg_batches {
 // A thread's segment is FRI_SEG consecutive words of each array, and the walk over it is a dependent chain: with one 8-byte load per
 // step the lanes of a wave sit 256 B apart and every step fetched a whole line from HBM for 8 bytes of it (config 4: 6.4 GB of traffic
 // for 0.27 GB of data, profiles/r04_e).  All three kernels therefore work on LDS TILES: the 64 segments of a 64-thread workgroup
-// (2048 consecutive words) are loaded with lane-contiguous accesses into rows of FRI_SEG + 1 words (a thread walking its own row is
+// (64 x FRI_SEG consecutive words) are loaded with lane-contiguous accesses into rows of FRI_SEG + 1 words (a thread walking its own row is
 // bank-conflict free), results that are arrays over k go back the same way.  Words past the end of the array read as zero -- the
 // carry into the last segment is zero, so the chain stays zero there.
 #define SEG_TILE (64 * FRI_SEG)
