@@ -59,6 +59,11 @@ void zkm_ctx_trim(zkm_ctx* ctx);
  *                               0: up to three launches for the levels and a download kernel
  *   "commit_lanes"              trace / auxiliary commitments of one segment built side by side (default 4: the context and three
  *                               lanes, one stream and host thread each; 1 = everything on the context's own stream)
+ *   "pow_round_log"             the proof-of-work search tries 2^this candidates per round of its one launch (default 17; 8 .. 22);
+ *                               the witness found is the smallest one whatever the value
+ *   "aux_pipeline"              a segment whose tables are all short (no LDE over 1 GiB), commit_lanes > 1: the lanes build the auxiliary
+ *                               commitments of tables 1.. BEHIND the proofs of the earlier tables instead of all of them before the
+ *                               first proof (default 1; same transcript, same proofs); 0: all auxiliary commitments first
  *   "throughput_profile"        1: the settings for MANY contexts per GPU proving small segments (commit_lanes 1, wide_max_hashes 256,
  *                               quad_max_hashes 4096: 16 contexts reach 74-75 segments/s of 2^16 cycles against 57-59 for 8 contexts
  *                               with the defaults, profiles/r04_throughput_profile.txt); 0: the defaults again

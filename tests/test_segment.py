@@ -222,8 +222,13 @@ def test_segment_at_2_16_cycle_heights_is_bit_exact(ctx, zkm, oracle):
         c2.set_tuning("commit_lanes", 2)
         c2.set_tuning("small_ntt", 0)          # ... and the two-pass transforms / level kernels + download instead of round 4's
         c2.set_tuning("tree_tail", 0)          # single-launch paths for short tables
-        got3, _, _ = c2.prove_segment(traces, log_n, public_values=[1, 2, 3])
+        c2.set_tuning("aux_pipeline", 0)       # all auxiliary commitments before the first table proof (the default builds tables 1..'s
+        got3, _, _ = c2.prove_segment(traces, log_n, public_values=[1, 2, 3])    # behind the proofs of the earlier tables)
         assert (got3 == got).all()
+        c2.set_tuning("commit_lanes", 8)       # ... and the pipelined form with seven lanes dealing the tables differently
+        c2.set_tuning("aux_pipeline", 1)
+        got4, _, _ = c2.prove_segment(traces, log_n, public_values=[1, 2, 3])
+        assert (got4 == got).all()
     finally:
         c2.close()
 

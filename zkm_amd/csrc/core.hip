@@ -420,6 +420,8 @@ int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) 
         else if (k == "block_after_us") x->block_after_us = value;
         else if (k == "small_ntt") x->small_ntt = value ? 1 : 0;
         else if (k == "tree_tail") x->tree_tail = value ? 1 : 0;
+        else if (k == "pow_round_log") x->pow_round_log = value < 8 ? 8 : (value > 22 ? 22 : (unsigned)value);
+        else if (k == "aux_pipeline") x->aux_pipeline = value ? 1 : 0;
         else if (k == "commit_lanes") x->commit_lanes = value < 1 ? 1 : (value > 8 ? 8 : (size_t)value);
         else if (k == "throughput_profile") {
             // MANY contexts on one GPU proving small segments (profiles/r04_throughput_profile.txt): one stream per context -- the runtime

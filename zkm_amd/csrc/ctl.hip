@@ -8,7 +8,9 @@
 #define GL_REDUCE_BRANCHFREE 1   // (gl_dev.h: these kernels interleave independent products at low occupancy)
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <exception>
+#include <mutex>
 #include <thread>
 
 #include "ctl_dev.h"
@@ -619,6 +621,19 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
         for (auto b : aux_commits) zkm_batch_free(b);
         drop_traces();
     };
+    struct background {            // lanes building auxiliary commitments behind the table proofs (below)
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<char> ready;
+        std::vector<std::exception_ptr> errs;
+        std::vector<std::thread> threads;
+        std::atomic<bool> failed{false};
+        void join() {
+            for (auto& th : threads)
+                if (th.joinable()) th.join();
+            threads.clear();
+        }
+    } bg;
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         if (ntables == 12) {  // a whole AllStark segment: the transcript only matches the reference's in Table::all() order
@@ -700,7 +715,7 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
         for (size_t t = 0; t < ntables; t++)
             aux_cost[t] = commit_cost_estimate(c, tz[t].naux + zkm_num_lookup_columns(tables[t].table_id, cfg), tables[t].log_n, cfg->rate_bits) +
                           (double)(tables[t].ncols << tables[t].log_n) * 1e-10;
-        run_on_lanes(c, big, small, aux_cost, [&](zkm_ctx* w, size_t t) {
+        auto aux_job = [&](zkm_ctx* w, size_t t) {
             if (tz[t].naux == 0) return;   // ("No CTL?" -- reported by prove_single_table in table order, prover.rs:509)
             const size_t n = (size_t)1 << tables[t].log_n, W = tables[t].ncols;
             const size_t NL = zkm_num_lookup_columns(tables[t].table_id, cfg), A = NL + tz[t].naux;
@@ -732,10 +747,8 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
             aux_commits[t] = ab;   // (owned from here on: freed with the others on every exit path)
             zkm_batch_build(ab, d_all.as<uint64_t>(), true);
             w->sync();             // d_all / `again` go back to the lane's allocator when this returns
-        });
-        drop_traces();             // the device copies of the traces have served their purpose (commitment, CTL data, lookup columns)
-        // "compute all proofs given commitments" :234-438: tables in order, one transcript
-        for (size_t t = 0; t < ntables; t++) {
+        };
+        auto prove_table = [&](size_t t) {   // "compute all proofs given commitments" :234-438: tables in order, one transcript
             try {
                 if (!aux_commits[t]) throw std::runtime_error("No CTL? aux column count does not match the CTL description");  // prover.rs:509
                 zkm_challenger local = ch;
@@ -745,11 +758,72 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
             } catch (const std::exception& e) {
                 throw std::runtime_error("table " + std::to_string(t) + ": " + e.what());
             }
+        };
+        const size_t bg_lanes =
+            (big.empty() && c->aux_pipeline && ntables >= 3) ? std::min<size_t>(std::max<size_t>(1, c->commit_lanes), ntables - 1) - 1 : 0;
+        if (bg_lanes == 0) {
+            run_on_lanes(c, big, small, aux_cost, aux_job);
+            drop_traces();         // the device copies of the traces have served their purpose (commitment, CTL data, lookup columns)
+            for (size_t t = 0; t < ntables; t++) prove_table(t);
+        } else {
+            // A segment of short tables (no table fills the GPU on its own): the table proofs are ONE chain of latency-bound steps on
+            // the context's stream, and the auxiliary commitment of a LATER table is not needed before that table's turn -- the lanes
+            // build them behind the proofs of the earlier tables (dealt to the lanes in proof order, the same deal every segment, so
+            // that each lane finds its blocks in its own allocator cache; the context builds table 0's and starts proving).  The
+            // transcript is what it was: every cap is observed inside its table's proof, in table order.
+            c->ensure_lanes(bg_lanes);
+            bg.ready.assign(ntables, 0);
+            bg.errs.assign(bg_lanes, nullptr);
+            struct stop_and_join {     // (an exception on this thread unwinds what the lanes refer to: they are stopped and joined first)
+                background& b;
+                ~stop_and_join() {
+                    if (!b.threads.empty()) b.failed.store(true);
+                    b.join();
+                }
+            } guard{bg};
+            for (size_t k = 0; k < bg_lanes; k++)
+                bg.threads.emplace_back([&, k]() {
+                    zkm_ctx* w = c->lanes[k];
+                    try {
+                        ZKM_HIP_CHECK(hipSetDevice(c->device));
+                        for (size_t t = 1 + k; t < ntables; t += bg_lanes) {
+                            if (bg.failed.load()) break;
+                            aux_job(w, t);
+                            std::lock_guard<std::mutex> g(bg.mu);
+                            bg.ready[t] = 1;
+                            bg.cv.notify_all();
+                        }
+                    } catch (...) {
+                        bg.errs[k] = std::current_exception();
+                        bg.failed.store(true);
+                    }
+                    std::lock_guard<std::mutex> g(bg.mu);      // (whatever happened: nobody waits for this lane any more)
+                    for (size_t t = 1 + k; t < ntables; t += bg_lanes) bg.ready[t] = 1;
+                    bg.cv.notify_all();
+                });
+            aux_job(c, 0);
+            for (size_t t = 0; t < ntables; t++) {
+                if (t) {
+                    zkm_prof_scope st(c, "stage/wait for auxiliary polynomials commitment");
+                    std::unique_lock<std::mutex> g(bg.mu);
+                    bg.cv.wait(g, [&] { return bg.ready[t] != 0; });
+                }
+                if (bg.failed.load()) break;
+                prove_table(t);
+            }
+            bg.join();
+            for (auto& e : bg.errs)
+                if (e) std::rethrow_exception(e);
+            drop_traces();
         }
     } catch (const std::exception& e) {
+        bg.failed.store(true);
+        bg.join();
         drop_all();
         return fail(err, e.what());
     } catch (...) {
+        bg.failed.store(true);
+        bg.join();
         drop_all();
         return fail(err, "zkm_prove_with_traces: unknown error");
     }

@@ -1015,8 +1015,10 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
             unsigned long long* d_best = (unsigned long long*)c->alloc(8);
             scratch.push_back(d_best);
             unsigned long long best = ~0ULL;
-            // 2^16 candidates per round (one wave per SIMD), up to 2^6 rounds per launch (a launch without a hit: probability e^-64 at 16 bits)
-            const uint64_t stride = (uint64_t)1 << 16, span = stride << 6;
+            // 2^pow_round_log candidates per round (17: two waves per SIMD -- a wave alone issues at half the SIMD's rate, so the round is
+            // barely longer than with one, and it holds the hit with probability 0.86 instead of 0.63 at 16 bits), up to 2^6 rounds
+            // per launch (a launch without a hit: probability e^-128)
+            const uint64_t stride = (uint64_t)1 << c->pow_round_log, span = stride << 6;
             for (uint64_t base = 0; best == ~0ULL; base += span) {
                 if (base > ((uint64_t)1 << 40)) throw std::runtime_error("Proof of work failed. This is highly unlikely!");
                 ZKM_HIP_CHECK(hipMemsetAsync(d_best, 0xff, 8, c->stream));

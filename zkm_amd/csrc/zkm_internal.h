@@ -49,6 +49,8 @@ struct zkm_ctx {
     size_t fri_fused_division_min = ~(size_t)0;         // k_seg_scan_final from this many coefficients (default: never -- since the
                                                         // LDS-tiled kernels of round 4 the per-batch scans are faster at every size)  }
     size_t small_ntt = 1;               // transforms of 2^9 .. 2^13 points in one launch (k_ntt_small); 0: the two-pass plan          } zkm_ctx_set_tuning
+    unsigned pow_round_log = 17;        // proof-of-work search: 2^this candidates per round of the search launch                          } zkm_ctx_set_tuning
+    int aux_pipeline = 1;               // segments of short tables: lanes build later tables' auxiliary commitments behind the proofs      } zkm_ctx_set_tuning
     size_t commit_lanes = ZKM_COMMIT_LANES;   // trace / auxiliary commitments of one segment in flight (this context + lanes)   } zkm_ctx_set_tuning
     size_t wide_max_hashes = 1024;      // launches of up to this many hashes use 16 lanes per hash (latency form)   } 0 / 0: one lane
     size_t quad_max_hashes = 16384;     // ... and up to this many four lanes per hash                                } per hash always
