@@ -6,7 +6,7 @@ timeout 900 python -m pytest tests/test_segment.py -m gpu -x -q 2>&1 | tail -5 >
 for t in "aux_pipeline=0" "aux_pipeline=1" "aux_pipeline=1,commit_lanes=3" "aux_pipeline=1,commit_lanes=6" "aux_pipeline=1,commit_lanes=8" "aux_pipeline=0" "aux_pipeline=1"; do
   ZKM_SEG_TUNING="$t" timeout 300 python tools/auxpipe_ab.py 30 1 >> $O 2>&1
 done
-# (the "prio" lines of profiles/r04_auxpipe.txt: context stream at the highest, lane streams at the lowest priority -- an experiment
+# (the "prio" lines of profiles/r04_segment_latency_round2.txt: context stream at the highest, lane streams at the lowest priority -- an experiment
 #  behind an environment variable that was removed again after it showed no effect)
 for t in "aux_pipeline=0" "aux_pipeline=1" "aux_pipeline=0,commit_lanes=2" "aux_pipeline=1,commit_lanes=2"; do
   ZKM_SEG_TUNING="$t" timeout 300 python tools/auxpipe_ab.py 6 8 >> $O 2>&1

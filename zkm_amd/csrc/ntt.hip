@@ -488,31 +488,71 @@ struct ntt_small_args {
     const gl_t* pre_tab_k[4];  // per coset (blockIdx.y): in[i] *= table(i), or null
     size_t out_off_k[4];
 };
+#define ZKM_WAVE_SYNC()                                      \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+// n / 8 threads, four butterflies per thread and stage.  The stages whose butterflies span 512 words or more exchange across waves
+// (a workgroup barrier each: L - 9 of them); after those every wave owns 512 consecutive words and runs the remaining nine stages
+// on its own -- a wave's LDS instructions execute in order, no workgroup barrier.  The stage tables (tw[h + j], all of [1, n)) are
+// copied to LDS once: a global load per stage was a round trip to L2 between two barriers, eleven times per workgroup.
 __global__ __launch_bounds__(1024) void k_ntt_small(ntt_small_args p) {
     extern __shared__ __attribute__((aligned(16))) gl_t lds[];
-    const unsigned L = p.log_n, n = 1u << L, tid = threadIdx.x, T = blockDim.x;
+    const unsigned L = p.log_n, n = 1u << L, tid = threadIdx.x, T = blockDim.x;   // T = n / 8
+    gl_t* const twl = lds + n;
     const gl_t* __restrict__ src = p.in + (size_t)blockIdx.x * p.cs_in;
     const gl_t* __restrict__ pre = p.pre_tab_k[blockIdx.y];
-    for (unsigned e = tid; e < n; e += T) {
-        gl_t v = src[e];
-        if (pre) v = gl_mul_loose(v, pow_lookup(pre, L, e));
-        lds[e] = v;
+    {
+        gl_t v[8], w[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { v[k] = src[tid + T * k]; w[k] = p.tw[tid + T * k]; }
+        if (pre) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = gl_mul_loose(v[k], pow_lookup(pre, L, tid + T * k));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { lds[tid + T * k] = v[k]; twl[tid + T * k] = w[k]; }
     }
     __syncthreads();
-#pragma unroll 1
-    for (unsigned s = L; s-- > 0;) {
+    auto stage = [&](unsigned s, unsigned b0, unsigned bstep, unsigned base) {
         const unsigned h = 1u << s;
-        const gl_t* __restrict__ tws = p.tw + h;
-        for (unsigned b = tid; b < (n >> 1); b += T) {
-            const unsigned j = b & (h - 1), i = ((b >> s) << (s + 1)) | j;
-            const uint64_t u = lds[i], v = lds[i + h];
-            lds[i] = gl_add_rr(u, v);
-            lds[i + h] = s ? gl_mul_loose(gl_sub_rr(u, v), tws[j]) : gl_sub_rr(u, v);   // (the last stage's twiddle is 1)
+        unsigned idx[4];
+        uint64_t u[4], v[4], w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned b = b0 + bstep * k, j = b & (h - 1);
+            idx[k] = base + (((b >> s) << (s + 1)) | j);
+            u[k] = lds[idx[k]];
+            v[k] = lds[idx[k] + h];
+            w[k] = twl[h + j];
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            lds[idx[k]] = gl_add_rr(u[k], v[k]);
+            lds[idx[k] + h] = s ? gl_mul_loose(gl_sub_rr(u[k], v[k]), w[k]) : gl_sub_rr(u[k], v[k]);   // (the last stage's twiddle is 1)
+        }
+    };
+    unsigned s = L;
+#pragma unroll 1
+    while (s > 9) {
+        s--;
+        stage(s, tid, T, 0);
         __syncthreads();
     }
+    const unsigned lane = tid & 63, base = (tid >> 6) << 9, wstep = T < 64 ? T : 64;   // (transforms below 2^9 points: part of one wave)
+#pragma unroll 1
+    while (s > 0) {
+        s--;
+        stage(s, lane, wstep, base);
+        ZKM_WAVE_SYNC();
+    }
+    __syncthreads();
     gl_t* __restrict__ dst = p.out + (size_t)blockIdx.x * p.cs_out + p.out_off_k[blockIdx.y];
-    for (unsigned e = tid; e < n; e += T) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const unsigned e = tid + T * k;
         gl_t v = lds[p.natural_out ? bitrev32(e, L) : e];
         if (p.post_scale != 1) v = gl_mul_loose(v, p.post_scale);
         if (p.post_tab) v = gl_mul_loose(v, pow_lookup(p.post_tab, L, e));
@@ -520,10 +560,14 @@ __global__ __launch_bounds__(1024) void k_ntt_small(ntt_small_args p) {
     }
 }
 static bool ntt_small_ok(unsigned log_n) { return log_n >= 9 && log_n <= 13; }
+template <typename K>
+static void ntt_allow_big_lds(zkm_ctx* c, K kernel, std::atomic<uint64_t>& done);
 static void launch_ntt_small(zkm_ctx* c, const ntt_small_args& a, size_t ncols, unsigned ncoset, const char* name) {
-    const unsigned n = 1u << a.log_n, threads = (n >> 1) < 1024 ? (n >> 1) : 1024;
+    static std::atomic<uint64_t> lds_ok{0};
+    const unsigned n = 1u << a.log_n;
     zkm_prof_scope ps(c, name);
-    hipLaunchKernelGGL(k_ntt_small, dim3((unsigned)ncols, ncoset), dim3(threads), (size_t)n * sizeof(gl_t), c->stream, a);
+    if (2 * (size_t)n * sizeof(gl_t) > 64 * 1024) ntt_allow_big_lds(c, k_ntt_small, lds_ok);
+    hipLaunchKernelGGL(k_ntt_small, dim3((unsigned)ncols, ncoset), dim3(n >> 3), 2 * (size_t)n * sizeof(gl_t), c->stream, a);
     ZKM_HIP_CHECK(hipGetLastError());
 }
 
@@ -855,12 +899,7 @@ __global__ __launch_bounds__((1 << SA) * 8) void k_ntt_big(ntt_big_args p) {
 // before the round-1 stores: the previous block's readers must be done; one after them) against five and nine in k_ntt_big<6>.
 // 78 VGPRs and 41 KB of LDS: three workgroups per CU, whose waves cover each other's memory latency -- measured better than two
 // workgroups with a register prefetch of the next block and two alternating LDS images (5.17 vs 5.49 ms for 262 x 2^22).
-#define ZKM_WAVE_SYNC()                                      \
-    do {                                                     \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                     \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
+// (ZKM_WAVE_SYNC: defined above k_ntt_small)
 
 // INV: inverse roots (the table passed in p.tw, the negated powers of two of the last round) and the scale n^-1 on the way out.
 // PERM: the block is stored in the DIGIT order of the coefficient layout (zkm_coeff_exponent, zkm_internal.h) instead of in place:
