@@ -156,6 +156,22 @@ __global__ __launch_bounds__(1024) void k_download(down_args a, uint64_t* flag, 
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// Larger downloads that still fit the pinned area (a table's query rounds: 0.1 .. 1 MB): many workgroups write the words into pinned host
+// memory, the last one to finish (a ticket) publishes the sequence number -- no blit, no completion signal, no stream synchronisation
+__global__ __launch_bounds__(256) void k_download_wide(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16, uint64_t* flag,
+                                                       uint64_t seq, unsigned* counter) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned ticket = atomicAdd(counter, 1u);
+        if (ticket == gridDim.x - 1) {
+            *counter = 0;
+            __threadfence_system();
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 void zkm_ctx::ensure_xfer() {
     if (h_xfer) return;
     if (hipHostMalloc((void**)&h_xfer, XFER_DOWN + XFER_UP + 64, hipHostMallocCoherent) != hipSuccess) {
@@ -283,6 +299,22 @@ void zkm_ctx::download(std::initializer_list<xfer> xs) {
             off += (x.bytes + 63) & ~(size_t)63;
         }
         return;
+    }
+    if (nx == 1 && total <= XFER_DOWN) {
+        const xfer* one = nullptr;
+        for (const xfer& x : xs)
+            if (x.bytes) one = &x;
+        if (one->bytes % 16 == 0 && (uintptr_t)one->src % 16 == 0) {
+            uint64_t *slot, *flag;
+            unsigned* counter;
+            const uint64_t seq = xfer_begin(one->bytes, &slot, &flag, &counter);
+            const uint32_t n16 = (uint32_t)(one->bytes / 16);
+            const unsigned grid = std::min<unsigned>(64, (n16 + 255) / 256);
+            hipLaunchKernelGGL(k_download_wide, dim3(grid), dim3(256), 0, stream, (const uint4*)one->src, (uint4*)slot, n16, flag, seq, counter);
+            ZKM_HIP_CHECK(hipGetLastError());
+            xfer_finish(seq, one->dst, one->bytes);
+            return;
+        }
     }
     size_t off = 0;
     for (const xfer& x : xs) {

@@ -365,8 +365,11 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     {
         zkm_prof_scope ps(c, "quotient_ctl");
         dim3 grid((size + 255) / 256), block(256);
-        // chunk plan: at most CHUNK helper checks per chunk, the closing checks with the last chunk of their Z
-        const uint32_t CHUNK = 4;
+        // chunk plan: at most CHUNK helper checks per chunk, the closing checks with the last chunk of their Z.  A thread's work is a
+        // chain of column-combination evaluations whatever the table's height: on short tables (a launch cannot fill the GPU anyway)
+        // one helper check per chunk -- four times the workgroups, a quarter of the chain (KeccakSponge at 2^8 rows: 340 us per launch)
+        const bool short_table = size <= ((size_t)1 << 15);
+        const uint32_t CHUNK = short_table ? 1 : 4;
         std::vector<ctl_chunk> plan;
         uint32_t K = 0, hstart = 0;
         std::vector<uint32_t> kend;
@@ -385,7 +388,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             hstart += own.h_zs[zi].num_helpers;
         }
         for (size_t i = 0; i < plan.size(); i++) plan[i].tail = K - kend[i];
-        const bool chunked = plan.size() >= 8 && size <= ((size_t)1 << 18);
+        const bool chunked = plan.size() >= (short_table ? 2u : 8u) && size <= ((size_t)1 << 18);
         if (!chunked) {
             if (nalphas == 1)
                 hipLaunchKernelGGL((k_quotient_ctl<1>), grid, block, 0, c->stream, trace->lde, aux->lde, lde_bits, ctl, NL, d_alphas, wpow, gn, zh0, zh1,
@@ -408,7 +411,8 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
                 hipLaunchKernelGGL((k_quotient_ctl_sum<2>), grid, block, 0, c->stream, d_tmp, (uint32_t)plan.size(), K, d_alphas, zh0, zh1, size, d_vals);
             }
             ZKM_HIP_CHECK(hipGetLastError());
-            c->sync();  // `plan` (pageable host memory) must outlive the copy
+            // (no host sync: upload() has copied `plan` into the pinned ring -- or waited itself if it was too large for it -- and the
+            // blocks released here are only reused by later work on this stream)
             c->release(d_plan);
             c->release(d_tmp);
         }
@@ -1107,7 +1111,9 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
         for (size_t i = 0; i < ctl_table->nterms; i++)
             if (ctl_table->term_col[i] >= W) throw std::runtime_error("CTL description: trace column index out of range");
 
-    memset(proof, 0, y.total * sizeof(uint64_t));
+    // (the query rounds -- nine tenths of the blob, 2 MB for the Keccak table -- are written in full by the download at the end of
+    // fri_finish: zeroing them here was 0.2 ms of host time per segment in front of the table's first launch)
+    memset(proof, 0, y.o_queries * sizeof(uint64_t));
     proof[0] = ZKM_PROOF_MAGIC; proof[1] = log_n; proof[2] = W; proof[3] = A; proof[4] = y.Q; proof[5] = Z; proof[6] = y.cap;
     proof[7] = y.L; proof[8] = y.F; proof[9] = y.nq; proof[10] = cfg->rate_bits; proof[11] = cfg->arity_bits;
 
