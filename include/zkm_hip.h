@@ -65,7 +65,7 @@ void zkm_ctx_trim(zkm_ctx* ctx);
  *                               commitments of tables 1.. BEHIND the proofs of the earlier tables instead of all of them before the
  *                               first proof (default 1; same transcript, same proofs); 0: all auxiliary commitments first
  *   "throughput_profile"        1: the settings for MANY contexts per GPU proving small segments (commit_lanes 1, wide_max_hashes 256,
- *                               quad_max_hashes 4096: 16 contexts reach 74-75 segments/s of 2^16 cycles against 57-59 for 8 contexts
+ *                               quad_max_hashes 4096, pow_round_log 16: 16 contexts reach 74-75 segments/s of 2^16 cycles against 57-59 for 8 contexts
  *                               with the defaults, profiles/r04_throughput_profile.txt); 0: the defaults again
  *   "block_after_us"            a transcript round trip (cap, opening partials, proof-of-work witness coming down) is waited for by
  *                               polling a flag in pinned memory; after this many microseconds (default 50) a thread of a CROWDED
