@@ -318,3 +318,21 @@ def test_pure_c_caller_builds_and_reports_errors(zkm, oracle, tmp_path):
     bad.write_bytes(b"NOTATRACE" + b"\0" * 119)
     r = subprocess.run([exe, str(bad), str(tmp_path / "p.bin")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "magic" in r.stderr
+
+
+def test_every_tuning_key_is_documented_in_the_header():
+    """zkm_ctx_set_tuning's keys live in core.hip; include/zkm_hip.h is what an integrator reads: the two lists must be the same, and
+    INTEGRATION.md must not name a key that does not exist."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    core = open(os.path.join(root, "zkm_amd", "csrc", "core.hip")).read()
+    body = core[core.index("int zkm_ctx_set_tuning("):]
+    body = body[:body.index("ZKM_API_END")]
+    code_keys = set(re.findall(r'k == "([a-z_0-9]+)"', body))
+    header = open(os.path.join(root, "include", "zkm_hip.h")).read()
+    doc_keys = set(re.findall(r'^ \*   "([a-z_0-9]+)"', header, flags=re.M))
+    assert code_keys and code_keys == doc_keys, (sorted(code_keys - doc_keys), sorted(doc_keys - code_keys))
+    integ = open(os.path.join(root, "INTEGRATION.md")).read()
+    named = set(re.findall(r'zkm_ctx_set_tuning\([^)]*?"([a-z_0-9]+)"', integ)) | set(re.findall(r'set_tuning\("([a-z_0-9]+)"', integ))
+    assert named <= code_keys, sorted(named - code_keys)
