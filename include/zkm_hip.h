@@ -48,8 +48,8 @@ void zkm_ctx_trim(zkm_ctx* ctx);
  *   "keccak_parts_max_points"   quotient domains of a Keccak table up to this many points use 25 threads per point (default 2^15)
  *   "fri_fused_division_min"    polynomials from this many coefficients on divide by (X - z) with all batches in one workgroup (default: never)
  *   "wide_max_hashes"           hashing launches of up to this many hashes give each hash a 16-lane row (default 1024), and
- *   "quad_max_hashes"           up to this many a quad of lanes (default 16384): the latency forms of the Poseidon permutation, at
- *                               4.2x / 1.9x the issue slots of the one-lane form.  0 and 0: one lane per hash for every leaf and
+ *   "quad_max_hashes"           up to this many a quad of lanes (default 32768): the latency forms of the Poseidon permutation, at
+ *                               4.2x / 1.45x the issue slots of the one-lane form.  0 and 0: one lane per hash for every leaf and
  *                               every tree level of >= 256 parents (the levels below that, a few hundred hashes per tree, keep the
  *                               quad form: the one-lane kernel works on blocks of 256 parents); a GPU shared by many contexts
  *                               proving small segments may prefer throughput -- measured in profiles/r03_hw_queues.txt

@@ -365,7 +365,7 @@ def test_tuning_poseidon_forms_agree(zkm, oracle, log_n, W):
     tv, av, qc = (rng.integers(0, P, k * n, dtype=np.uint64) for k in (W, A, Q))
     otb, oab, oqb = oracle.batch_from_values(tv, W, log_n), oracle.batch_from_values(av, A, log_n), oracle.batch_from_coeffs(qc, Q, log_n)
     want = oracle.prove_openings(otb, oab, oqb, Z)
-    for wide, quad in ((0, 0), (0, 1 << 30), (1 << 30, 1 << 30), (64, 512), (1024, 16384)):
+    for wide, quad in ((0, 0), (0, 1 << 30), (1 << 30, 1 << 30), (64, 512), (1024, 32768)):
         c = zkm.Context(0)
         c.set_tuning("wide_max_hashes", wide)
         c.set_tuning("quad_max_hashes", quad)

@@ -31,7 +31,9 @@ __global__ __launch_bounds__(256) void k_chain(uint64_t* out, size_t nhash, int 
     } else if (FORM == 1) {                            // a quad per hash: lane q holds words q, q + 4, q + 8
         const size_t h = t >> 2;
         const unsigned q = t & 3;
-        const poseidon_quad Q(threadIdx.x);
+        __shared__ __attribute__((aligned(16))) uint32_t qtab[ZKM_QUAD_TAB_WORDS];
+        quad_tab_load(qtab);
+        const poseidon_quad Q(threadIdx.x, qtab);
         uint64_t s[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) s[a] = mix(h * 12 + q + 4 * a + 1);

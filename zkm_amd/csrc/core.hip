@@ -462,7 +462,7 @@ int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) 
             // else's work).  0 restores the defaults of a context that has the GPU (nearly) to itself.
             x->commit_lanes = value ? 1 : ZKM_COMMIT_LANES;
             x->wide_max_hashes = value ? 256 : 1024;
-            x->quad_max_hashes = value ? 4096 : 16384;
+            x->quad_max_hashes = value ? 4096 : 32768;
             x->pow_round_log = value ? 16 : 17;                 // (half-filled SIMDs are somebody else's slots here: 76.3 vs 75.4 segments/s)
         }
         else if (k == "debug_fail_allocs") { if (x == c) x->debug_fail_allocs.store((int)value); }

@@ -542,7 +542,7 @@ static double commit_cost_estimate(const zkm_ctx* c, size_t ncols, unsigned log_
     const double full_rate = 3.3e9;                        // one-lane permutations per second of the whole GPU
     double lat, rate;
     if (rows <= (double)c->wide_max_hashes) { lat = 13e-6; rate = full_rate / 4.2; }
-    else if (rows <= (double)c->quad_max_hashes) { lat = 24e-6; rate = full_rate / 1.9; }
+    else if (rows <= (double)c->quad_max_hashes) { lat = 16e-6; rate = full_rate / 1.45; }
     else { lat = 40e-6; rate = full_rate; }
     const double step = rows / rate > lat ? rows / rate : lat;
     return (double)((ncols + 7) / 8) * step + rows * (double)ncols * 2.5e-11 + 2e-4;    // + transforms (~25 ps per LDE word) + launches

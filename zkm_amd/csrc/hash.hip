@@ -318,7 +318,9 @@ __global__ __launch_bounds__(256) void k_merkle_fused_quad(merkle_fused_quad_arg
     ZKM_RAISE_PRIO();
     __shared__ uint64_t sh[2][128 * 4];                   // digests of the current level of this subtree (AoS, as in HBM)
     const unsigned tid = threadIdx.x, q = tid & 3, slot = tid >> 2, wave_slot0 = (tid >> 6) << 4;
-    const poseidon_quad Q(tid);
+    __shared__ __attribute__((aligned(16))) uint32_t qtab[ZKM_QUAD_TAB_WORDS];
+    quad_tab_load(qtab);
+    const poseidon_quad Q(tid, qtab);
     const unsigned C = 1u << p.J;
     {
         const gl_t* src = p.children + (size_t)blockIdx.x * C * 4;
@@ -355,7 +357,9 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_quad(const gl_t* __restri
     const unsigned q = threadIdx.x & 3;
     const size_t leaf = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const bool live = leaf < nrows;  // uniform over the quad; every lane of the wave takes part in the DPP moves
-    const poseidon_quad Q(threadIdx.x);
+    __shared__ __attribute__((aligned(16))) uint32_t qtab[ZKM_QUAD_TAB_WORDS];
+    quad_tab_load(qtab);
+    const poseidon_quad Q(threadIdx.x, qtab);
     uint64_t s[3] = {0, 0, 0};
     for (size_t c = 0; c < ncols; c += 8) {
         if (live && c + q < ncols) s[0] = lde[(c + q) * col_stride + leaf];
@@ -364,10 +368,10 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_quad(const gl_t* __restri
     }
     if (live) digests[4 * leaf + q] = s[0];
 }
-// Rows up to which a leaf gets a quad of lanes.  One absorb step takes ~10 us in the quad form while a SIMD holds at most one such wave
-// (16384 rows = 1024 waves), against ~27 us for the one-lane form on a wave that has its SIMD to itself (16384 rows = 256 waves); it
-// costs 1.7x the instructions per hash (the 16-lane form of rounds 1-2: 7.5x, which is why that one stopped at 4096 rows).
-// (zkm_ctx::quad_max_hashes = 16384)
+// Rows up to which a leaf gets a quad of lanes.  One absorb step takes ~16 us in the quad form while a SIMD holds at most one such wave
+// (16384 rows = 1024 waves; ~21 us with two, 32768 rows), against ~39 us for the one-lane form on a wave that has its SIMD to itself;
+// it costs 1.45x the instructions per hash since its partial rounds are fused (poseidon_lat_dev.h; 1.9x and 24 us before that).
+// (zkm_ctx::quad_max_hashes = 32768)
 
 // FRI layer leaves, one hash per quad (small layers): word m of leaf k is component m & 1 of value k * arity + (m >> 1).
 __global__ __launch_bounds__(256) void k_merkle_leaves_ext_quad(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nleaves,
@@ -376,7 +380,9 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_ext_quad(const gl_t* __re
     const unsigned q = threadIdx.x & 3;
     const size_t k = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const bool live = k < nleaves;
-    const poseidon_quad Q(threadIdx.x);
+    __shared__ __attribute__((aligned(16))) uint32_t qtab[ZKM_QUAD_TAB_WORDS];
+    quad_tab_load(qtab);
+    const poseidon_quad Q(threadIdx.x, qtab);
     const gl_t* col = (q & 1) ? c1 : c0;                  // words q and q + 4 have the parity of q
     uint64_t s[3] = {0, 0, 0};
     for (unsigned m = 0; m < 2 * arity; m += 8) {
@@ -427,7 +433,9 @@ __global__ __launch_bounds__(256) void k_merkle_tail(merkle_tail_args p) {
         for (unsigned w = tid; w < C * 4; w += blockDim.x) buf0[w] = src[w];
     }
     __syncthreads();
-    const poseidon_quad Q(tid);
+    __shared__ __attribute__((aligned(16))) uint32_t qtab[ZKM_QUAD_TAB_WORDS];
+    quad_tab_load(qtab);
+    const poseidon_quad Q(tid, qtab);
     for (unsigned lvl = 0; lvl < p.J; lvl++) {
         const unsigned np = C >> (lvl + 1);
         const uint64_t* in = (lvl & 1) ? buf1 : buf0;
@@ -487,7 +495,7 @@ bool zkm_merkle_tail(zkm_ctx* c, gl_t* digests, const std::vector<size_t>& level
     static std::atomic<uint64_t> lds_ok{0};
     const uint64_t bit = (uint64_t)1 << (c->device & 63);
     if (!(lds_ok.load(std::memory_order_acquire) & bit)) {
-        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_merkle_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_merkle_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // (96 KB at J = 11; the static table of the quad form comes on top)
         lds_ok.fetch_or(bit, std::memory_order_release);
     }
     merkle_tail_args a{};

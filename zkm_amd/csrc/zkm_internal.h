@@ -53,7 +53,7 @@ struct zkm_ctx {
     int aux_pipeline = 1;               // segments of short tables: lanes build later tables' auxiliary commitments behind the proofs      } zkm_ctx_set_tuning
     size_t commit_lanes = ZKM_COMMIT_LANES;   // trace / auxiliary commitments of one segment in flight (this context + lanes)   } zkm_ctx_set_tuning
     size_t wide_max_hashes = 1024;      // launches of up to this many hashes use 16 lanes per hash (latency form)   } 0 / 0: one lane
-    size_t quad_max_hashes = 16384;     // ... and up to this many four lanes per hash                                } per hash always
+    size_t quad_max_hashes = 32768;     // ... and up to this many four lanes per hash                                } per hash always
     int num_cus = 256;
     int cu_part_k = -1, cu_part_n = 0;   // measurement aid (ZKM_CU_MASK_PART): the streams of this context are confined to one part of the CUs
     // profiling
