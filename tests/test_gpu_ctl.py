@@ -128,3 +128,22 @@ def test_lookup_helper_columns_match_oracle(ctx, oracle, nlook):
     want = oracle.lookup_helper_columns(t, sets, table_col, freq_col, ch, trace, 262, log_n)
     assert got.size == ((nlook + 1) // 2 + 1) << log_n
     assert (got == want).all()
+
+
+def test_error_in_a_table_proof_while_lanes_build_later_commitments(ctx, zkm, oracle):
+    """A segment of short tables proves table t while the commit lanes are still building the auxiliary commitments of the tables after
+    it (zkm_ctx_set_tuning "aux_pipeline").  A table that takes part in no lookup fails in its turn with the reference's message
+    (prover.rs:509); the lanes are stopped and joined before anything they refer to goes away, nothing leaks, and the same context
+    proves the complete instance afterwards, word for word."""
+    tables, ctls = build(oracle)
+    for bad_ctls in ([ctls[0]], [ctls[1]]):          # table 3 / tables 1 and 2 without a lookup
+        with pytest.raises(zkm.ZkmError, match="No CTL"):
+            ctx.prove_with_traces(tables, bad_ctls)
+    live, cached = ctx.memory()
+    assert live == ctx.resident_bytes()
+    want, wchal, woffs = oracle.prove_with_traces(tables, ctls)
+    for pipelined in (1, 0):
+        ctx.set_tuning("aux_pipeline", pipelined)
+        got, chal, offs = ctx.prove_with_traces(tables, ctls)
+        assert offs == woffs and (chal == wchal).all() and (got == want).all()
+    ctx.set_tuning("aux_pipeline", 1)
