@@ -136,11 +136,13 @@ def test_error_in_a_table_proof_while_lanes_build_later_commitments(ctx, zkm, or
     (prover.rs:509); the lanes are stopped and joined before anything they refer to goes away, nothing leaks, and the same context
     proves the complete instance afterwards, word for word."""
     tables, ctls = build(oracle)
+    ctx.prove_with_traces(tables, ctls)              # (tables and caches of the session's context are in place)
+    live0, _ = ctx.memory()
     for bad_ctls in ([ctls[0]], [ctls[1]]):          # table 3 / tables 1 and 2 without a lookup
         with pytest.raises(zkm.ZkmError, match="No CTL"):
             ctx.prove_with_traces(tables, bad_ctls)
     live, cached = ctx.memory()
-    assert live == ctx.resident_bytes()
+    assert live == live0
     want, wchal, woffs = oracle.prove_with_traces(tables, ctls)
     for pipelined in (1, 0):
         ctx.set_tuning("aux_pipeline", pipelined)

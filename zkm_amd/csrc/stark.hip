@@ -454,16 +454,19 @@ struct lazy_sum {
         return gl_canon(r);
     }
 };
+// (CPB columns per workgroup: 4 amortises the power loads when the launch fills the machine anyway; 1 when it would be a few hundred
+// workgroups -- tables of 2^16 / 2^17 rows: four times the waves for the same work)
+template <int CPB>
 __global__ __launch_bounds__(256) void k_open_partials(const gl_t* __restrict__ coeffs, unsigned log_n, size_t ncols,
                                                        const gl_t* __restrict__ pw, gl_t* __restrict__ partial /* [col][chunk][5] */) {
     __shared__ gl_t red[256 * 5];
     const unsigned chunk_log = log_n < OPEN_CHUNK_LOG ? log_n : OPEN_CHUNK_LOG;
     const size_t chunk_len = (size_t)1 << chunk_log, nchunks = (size_t)1 << (log_n - chunk_log);
-    const size_t col0 = (size_t)blockIdx.y * OPEN_CPB, chunk = blockIdx.x;
+    const size_t col0 = (size_t)blockIdx.y * CPB, chunk = blockIdx.x;
     const unsigned t = threadIdx.x;
-    lazy_sum acc[OPEN_CPB][5];
+    lazy_sum acc[CPB][5];
 #pragma unroll
-    for (int c = 0; c < OPEN_CPB; c++)
+    for (int c = 0; c < CPB; c++)
 #pragma unroll
         for (int q = 0; q < 5; q++) acc[c][q] = lazy_sum{0, 0};
     for (size_t idx = t; idx < chunk_len; idx += 256) {
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(256) void k_open_partials(const gl_t* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 4; q++) p[q] = pw[(size_t)q * chunk_len + idx];
 #pragma unroll
-        for (int c = 0; c < OPEN_CPB; c++) {
+        for (int c = 0; c < CPB; c++) {
             // (columns past the end of the batch read column ncols - 1 again; their sums are never stored)
             const size_t col = col0 + c < ncols ? col0 + c : ncols - 1;
             const gl_t cv = coeffs[(col << log_n) + chunk * chunk_len + idx];
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(256) void k_open_partials(const gl_t* __restrict__ 
         }
     }
 #pragma unroll
-    for (int c = 0; c < OPEN_CPB; c++) {
+    for (int c = 0; c < CPB; c++) {
 #pragma unroll
         for (int q = 0; q < 5; q++) red[t * 5 + q] = acc[c][q].value();
         __syncthreads();
@@ -515,8 +518,12 @@ static std::vector<std::vector<open_vals>> eval_batches(zkm_ctx* c, const std::v
         hipLaunchKernelGGL(k_open_powers, dim3((chunk_len + 255) / 256), dim3(256), 0, c->stream, z0, z1, chunk_len, b0->coeff_s1, d_pw.as<gl_t>());
         size_t col0 = 0;
         for (const zkm_batch* b : bs) {
-            hipLaunchKernelGGL(k_open_partials, dim3(nchunks, (b->ncols + OPEN_CPB - 1) / OPEN_CPB), dim3(256), 0, c->stream, b->coeffs, log_n,
-                               b->ncols, d_pw.as<gl_t>(), d_part.as<gl_t>() + col0 * nchunks * 5);
+            if (nchunks * ((b->ncols + OPEN_CPB - 1) / OPEN_CPB) < 1024)
+                hipLaunchKernelGGL(k_open_partials<1>, dim3(nchunks, b->ncols), dim3(256), 0, c->stream, b->coeffs, log_n, b->ncols, d_pw.as<gl_t>(),
+                                   d_part.as<gl_t>() + col0 * nchunks * 5);
+            else
+                hipLaunchKernelGGL(k_open_partials<OPEN_CPB>, dim3(nchunks, (b->ncols + OPEN_CPB - 1) / OPEN_CPB), dim3(256), 0, c->stream, b->coeffs,
+                                   log_n, b->ncols, d_pw.as<gl_t>(), d_part.as<gl_t>() + col0 * nchunks * 5);
             col0 += b->ncols;
         }
         ZKM_HIP_CHECK(hipGetLastError());
