@@ -260,6 +260,14 @@ uint64_t zkm_ctx::xfer_begin(size_t bytes, uint64_t** host_slot, uint64_t** flag
     *counter = d_counter;
     return ++down_seq;
 }
+unsigned long long* zkm_ctx::pow_best() {
+    if (!d_pow_best) {
+        d_pow_best = (unsigned long long*)alloc(8);
+        resident_bytes += 8;
+        ZKM_HIP_CHECK(hipMemsetAsync(d_pow_best, 0xff, 8, stream));
+    }
+    return d_pow_best;
+}
 void zkm_ctx::xfer_finish(uint64_t seq, void* dst, size_t bytes) {
     wait_flag((const uint64_t*)(h_xfer + XFER_DOWN + XFER_UP), seq);
     up_off = 0;                                               // everything queued before the kernel has completed, uploads included

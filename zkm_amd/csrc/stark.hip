@@ -809,8 +809,11 @@ __global__ __launch_bounds__(64) void k_fri_fold(const gl_t* __restrict__ c0, co
 // launch costs about one permutation's latency per 2^pow_bits / stride-th of the expected number of trials -- no host round trip
 // between the rounds, no candidates tried beyond the round of the first hit.
 struct pow_state { uint64_t s[12]; };
+// The launch delivers its result ITSELF: the workgroup that finishes last (a ticket) writes `best` into pinned host memory, then the
+// sequence number the host polls for, and leaves `best` = all ones and the ticket counter = 0 for the next search -- no memset launch in
+// front, no download launch behind (two launches and their gaps per table proof).
 __global__ __launch_bounds__(256) void k_pow_search(pow_state st, unsigned pos, unsigned pow_bits, uint64_t base, uint64_t limit,
-                                                    unsigned long long* best) {
+                                                    unsigned long long* best, unsigned* counter, uint64_t* host_out, uint64_t* flag, uint64_t seq) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 #pragma unroll 1
     for (uint64_t w = base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < limit; w += stride) {
@@ -823,6 +826,19 @@ __global__ __launch_bounds__(256) void k_pow_search(pow_state st, unsigned pos, 
             if ((unsigned)i == pos) s[i] = w;
         poseidon_permute(s);
         if ((s[7] >> (64 - pow_bits)) == 0) atomicMin(best, (unsigned long long)w);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned ticket = atomicAdd(counter, 1u);
+        if (ticket == gridDim.x - 1) {
+            __threadfence();
+            *host_out = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(best, ~0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *counter = 0;
+            __threadfence_system();
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1023,8 +1039,7 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
             pow_state st;
             memcpy(st.s, ch->state, sizeof st.s);
             for (uint32_t i = 0; i < ch->n_in; i++) st.s[i] = ch->in_buf[i];
-            unsigned long long* d_best = (unsigned long long*)c->alloc(8);
-            scratch.push_back(d_best);
+            unsigned long long* d_best = c->pow_best();      // all ones between searches (the kernel leaves it that way)
             unsigned long long best = ~0ULL;
             // 2^pow_round_log candidates per round (17: two waves per SIMD -- a wave alone issues at half the SIMD's rate, so the round is
             // barely longer than with one, and it holds the hit with probability 0.86 instead of 0.63 at 16 bits), up to 2^6 rounds
@@ -1032,13 +1047,16 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
             const uint64_t stride = (uint64_t)1 << c->pow_round_log, span = stride << 6;
             for (uint64_t base = 0; best == ~0ULL; base += span) {
                 if (base > ((uint64_t)1 << 40)) throw std::runtime_error("Proof of work failed. This is highly unlikely!");
-                ZKM_HIP_CHECK(hipMemsetAsync(d_best, 0xff, 8, c->stream));
+                uint64_t *host_slot, *flag;
+                unsigned* counter;
+                const uint64_t seq = c->xfer_begin(8, &host_slot, &flag, &counter);
                 {
                     zkm_prof_scope ps(c, "fri_pow_search");
-                    hipLaunchKernelGGL(k_pow_search, dim3(stride / 256), dim3(256), 0, c->stream, st, ch->n_in, cfg->pow_bits, base, base + span, d_best);
+                    hipLaunchKernelGGL(k_pow_search, dim3(stride / 256), dim3(256), 0, c->stream, st, ch->n_in, cfg->pow_bits, base, base + span, d_best,
+                                       counter, host_slot, flag, seq);
                     ZKM_HIP_CHECK(hipGetLastError());
                 }
-                c->download(&best, d_best, 8);
+                c->xfer_finish(seq, &best, 8);
             }
             uint64_t w = best;
             *pow_out = w;

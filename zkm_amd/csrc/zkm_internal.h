@@ -113,6 +113,8 @@ struct zkm_ctx {
     uint64_t xfer_begin(size_t bytes, uint64_t** host_slot, uint64_t** flag, unsigned** counter);
     void xfer_finish(uint64_t seq, void* dst, size_t bytes);
     unsigned* d_counter = nullptr;
+    unsigned long long* d_pow_best = nullptr;                    // the proof-of-work search's result word: all ones between searches
+    unsigned long long* pow_best();
     size_t tree_tail = 1;               // trees of <= 2^15 leaves in one launch incl. the cap's trip to the host; 0: levels + download      } zkm_ctx_set_tuning
     size_t up_off = 0;
     static constexpr size_t XFER_DOWN = (size_t)1 << 20, XFER_UP = (size_t)1 << 18;
