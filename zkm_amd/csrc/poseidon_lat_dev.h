@@ -7,13 +7,27 @@
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 // ---- one permutation across 12 lanes of a 16-lane row (the smallest tree levels and matrices) ----
-// The top levels of every tree hold too few nodes to fill the machine, so a launch costs one permutation's LATENCY: ~40 us for the
-// one-lane-per-hash form on a wave alone on its SIMD (12k instructions), ~24 us for the four-lane form below (5.7k), ~13 us here
-// (3.2k).  A hash owns a 16-lane row of the wave (lanes 0..11 = the twelve state words): every round is constant add, x^7 (lane 0
-// only in the partial rounds), and the circulant MDS with the twelve rotated neighbours fetched by ds_bpermute -- the textbook rounds
-// (poseidon_stark.rs:65-95, 164-169, 239-251, 310-345).  800 wave instructions per hash (four-lane form 360, one lane 190): for
-// launches of <= 1024 hashes (zkm_ctx::wide_max_hashes), where the chain is all there is.  Bit-exact with poseidon_permute (the
-// fused partial rounds there are an algebraic regrouping).
+// The top levels of every tree hold too few nodes to fill the machine, so a launch costs one permutation's LATENCY: ~39 us for the
+// one-lane-per-hash form on a wave alone on its SIMD (12k instructions), ~16 us for the four-lane form below, ~12 us here.  A hash
+// owns a 16-lane row of the wave (lanes 0..11 = the twelve state words); a textbook round is constant add, x^7 (lane 0 only in the
+// partial rounds) and the circulant MDS with the eleven rotated neighbours fetched by ds_bpermute (poseidon_stark.rs:65-95, 164-169,
+// 239-251, 310-345).  Four hashes per wave: for launches of <= 1024 hashes (zkm_ctx::wide_max_hashes), where the chain is all there
+// is.  Bit-exact with poseidon_permute.
+// Partial rounds fused three at a time as in the other two forms (poseidon_dev.h poseidon_partial_group): every lane fetches the twelve
+// words once (24 ds_bpermute instead of 66 for three textbook rounds), computes delta1 and delta2 for itself with the uniform rows 0 of
+// M and M^2, and its own output word with row idx of M^3 -- twelve per-lane multipliers + M^2[idx][0], M[idx][0], read from a constant
+// table on entry (four 16-byte loads, consumed four rounds later).  Rounds 24 and 25 stay textbook.
+struct wide_tab_t { uint32_t v[16][16]; };
+constexpr wide_tab_t make_wide_tab() {
+    wide_tab_t t{};
+    for (int i = 0; i < 12; i++) {
+        for (int j = 0; j < 12; j++) t.v[i][j] = pc_host::ZKM_POSEIDON_M3[i][j];
+        t.v[i][12] = pc_host::ZKM_POSEIDON_M2[i][0];
+        t.v[i][13] = poseidon_m1(i, 0);
+    }
+    return t;
+}
+static __device__ __constant__ const wide_tab_t ZKM_WIDE_TAB = make_wide_tab();
 __device__ __forceinline__ uint64_t poseidon_permute_wide(uint64_t x, unsigned lane) {
     const unsigned idx = lane & 15, base = lane & ~15u;
     const bool active = idx < 12;
@@ -23,25 +37,82 @@ __device__ __forceinline__ uint64_t poseidon_permute_wide(uint64_t x, unsigned l
     constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     const uint32_t diag = idx == 0 ? 8u : 0u;
     const gl_t* rcp = PC::ZKM_POSEIDON_RC + (active ? idx : 0);
-    x = gl_add_loose(x, rcp[0]);
-#pragma unroll 1
-    for (int r = 0; r < 30; r++) {
-        const bool full = r < 4 || r >= 26;
-        const uint64_t y = poseidon_sbox7(x);
-        x = (full || idx == 0) ? y : x;
-        const uint64_t k = r + 1 < 30 ? rcp[(r + 1) * 12] : 0;
-        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    uint32_t m3[16];
+    {
+        const uint4* tp = reinterpret_cast<const uint4*>(&ZKM_WIDE_TAB.v[active ? idx : 0][0]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint4 v = tp[i];
+            m3[4 * i] = v.x; m3[4 * i + 1] = v.y; m3[4 * i + 2] = v.z; m3[4 * i + 3] = v.w;
+        }
+    }
+    auto textbook_linear = [&](uint64_t v, uint64_t k) {      // M v + k for this lane's word
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
         uint64_t al = (uint64_t)(uint32_t)k + (uint64_t)lo * (C[0] + diag), ah = (k >> 32) + (uint64_t)hi * (C[0] + diag);
 #pragma unroll
         for (int i = 1; i < 12; i++) {
             al += (uint64_t)(uint32_t)__shfl((int)lo, src[i]) * C[i];
             ah += (uint64_t)(uint32_t)__shfl((int)hi, src[i]) * C[i];
         }
-        x = poseidon_fold(al, ah);
+        return poseidon_fold(al, ah);
+    };
+    x = gl_add_loose(x, rcp[0]);
+#pragma unroll 1
+    for (int r = 0; r < 8; r++) {                               // the eight full rounds; the partial rounds hang off round 3
+        x = poseidon_sbox7(x);
+        if (r == 3) {
+#pragma unroll 1
+            for (int g = 0; g < 7; g++) {                       // linear layers of rounds 3g+3 .. 3g+5, s-boxes of rounds 3g+4 .. 3g+6
+                const uint64_t c1 = PC::ZKM_POSEIDON_FUSED_C1[g], c2 = PC::ZKM_POSEIDON_FUSED_C2[g];
+                const uint64_t c3 = PC::ZKM_POSEIDON_FUSED_C3[g][active ? idx : 0];
+                uint32_t lo[12], hi[12];
+                {
+                    const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+#pragma unroll
+                    for (int j = 0; j < 12; j++) {
+                        lo[j] = (uint32_t)__shfl((int)xl, (int)(base + j));
+                        hi[j] = (uint32_t)__shfl((int)xh, (int)(base + j));
+                    }
+                }
+                uint64_t al = (uint32_t)c1, ah = c1 >> 32;
+#pragma unroll
+                for (int j = 0; j < 12; j++) {
+                    al += (uint64_t)lo[j] * poseidon_m1(0, j);
+                    ah += (uint64_t)hi[j] * poseidon_m1(0, j);
+                }
+                const uint64_t d1 = poseidon_sbox_delta(poseidon_fold(al, ah));
+                const uint32_t d1l = (uint32_t)d1, d1h = (uint32_t)(d1 >> 32);
+                al = (uint64_t)d1l * poseidon_m1(0, 0) + (uint32_t)c2;
+                ah = (uint64_t)d1h * poseidon_m1(0, 0) + (c2 >> 32);
+#pragma unroll
+                for (int j = 0; j < 12; j++) {
+                    al += (uint64_t)lo[j] * PC::ZKM_POSEIDON_M2[0][j];
+                    ah += (uint64_t)hi[j] * PC::ZKM_POSEIDON_M2[0][j];
+                }
+                const uint64_t d2 = poseidon_sbox_delta(poseidon_fold(al, ah));
+                const uint32_t d2l = (uint32_t)d2, d2h = (uint32_t)(d2 >> 32);
+                al = (uint64_t)d1l * m3[12] + (uint64_t)d2l * m3[13] + (uint32_t)c3;
+                ah = (uint64_t)d1h * m3[12] + (uint64_t)d2h * m3[13] + (c3 >> 32);
+#pragma unroll
+                for (int j = 0; j < 12; j++) {
+                    al += (uint64_t)lo[j] * m3[j];
+                    ah += (uint64_t)hi[j] * m3[j];
+                }
+                x = poseidon_fold(al, ah);
+                const uint64_t y = poseidon_sbox7(x);
+                x = idx == 0 ? y : x;
+            }
+            x = textbook_linear(x, rcp[25 * 12]);               // rounds 24 and 25, textbook
+            const uint64_t y = poseidon_sbox7(x);
+            x = idx == 0 ? y : x;
+            x = textbook_linear(x, rcp[26 * 12]);
+        } else {
+            const int next = (r < 3 ? r : 22 + r) + 1;          // full round r < 3 is round r, r > 3 is round 22 + r
+            x = textbook_linear(x, next < 30 ? rcp[next * 12] : 0);
+        }
     }
     return gl_canon(x);
 }
-
 
 // ---- one permutation across FOUR lanes (short matrices, small tree levels) ----
 // Where a launch holds too few hashes to fill the machine it costs a permutation's LATENCY (~27 us for the one-lane-per-hash form on a
