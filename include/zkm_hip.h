@@ -61,6 +61,8 @@ void zkm_ctx_trim(zkm_ctx* ctx);
  *                               lanes, one stream and host thread each; 1 = everything on the context's own stream)
  *   "pow_round_log"             the proof-of-work search tries 2^this candidates per round of its one launch (default 17; 8 .. 22);
  *                               the witness found is the smallest one whatever the value
+ *   "max_stack"                 zkm_prove_segments: segments per lock-step group (default and maximum 32; 1 = one segment at a time, the
+ *                               path of zkm_prove_segment); a table's group is also bounded by 65535 stacked columns (Keccak: 26 segments)
  *   "aux_pipeline"              a segment whose tables are all short (no LDE over 1 GiB), commit_lanes > 1: the lanes build the auxiliary
  *                               commitments of tables 1.. BEHIND the proofs of the earlier tables instead of all of them before the
  *                               first proof (default 1; same transcript, same proofs); 0: all auxiliary commitments first
@@ -432,6 +434,25 @@ int zkm_prove_segment(zkm_ctx* ctx, const zkm_stark_config* cfg, const uint64_t*
 int zkm_prove_segment_columns(zkm_ctx* ctx, const zkm_stark_config* cfg, const uint64_t* const* const* columns, const unsigned* log_n,
                               const uint64_t* public_values, size_t npublic, uint64_t* proofs_out, size_t* proof_offsets_out,
                               uint64_t* ctl_challenges_out, char** err);
+
+/* K INDEPENDENT segments in lock-step: the reference proves the segments of a program one after the other, each a prove_with_traces
+ * on its own transcript (prover/examples/utils/src/utils.rs:57-68, 105-133; prover.rs:130-232).  Here the K segments of one call
+ * advance through every stage of prove_with_traces TOGETHER: for every table, the segments whose table has the same height form a
+ * group (at most "max_stack", see zkm_ctx_set_tuning; heights may differ between segments -- a table's segments of another height form
+ * another group), a group's trace / auxiliary / quotient commitments, CTL data, constraint evaluation, openings, FRI layers, proof of
+ * work and query gathers are ONE launch (or group of launches) for all its segments, and each of its transcript round trips (caps,
+ * opening partials, final polynomial, proof-of-work witness, query rounds) brings the words of all of them down together.  The
+ * transcripts stay per segment, on the host; every proof blob and every challenge is word for word what zkm_prove_segment returns
+ * for that segment alone (tests/test_segments_batch.py).  A 2^16-cycle segment is mostly tables of 2^6 .. 2^13 rows whose launches
+ * cannot fill the GPU one segment at a time: K of them do.
+ *   traces[s][t]        table t (Table::all() order) of segment s: zkm_table_width x 2^log_n[s][t] words, host or device
+ *   public_values[s]    npublic[s] words (arrays may be NULL when no segment has public values)
+ *   proofs_out[s]       zkm_prove_segment(.., proofs_out = NULL, ..) sizes a segment's buffer and gives its thirteen offsets
+ *   ctl_challenges_out[s]   2 * num_challenges words
+ * A failure leaves every output undefined (no partial results). */
+int zkm_prove_segments(zkm_ctx* ctx, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* traces,
+                       const unsigned* const* log_n, const uint64_t* const* public_values, const size_t* npublic, uint64_t* const* proofs_out,
+                       uint64_t* const* ctl_challenges_out, char** err);
 
 /* a10 alone (BASELINE config 4): PolynomialBatch::prove_openings (call site prover.rs:618-628) for the STARK FRI
  * instance (stark.rs:91-148: batches at zeta, g*zeta and 1 over the trace / auxiliary / quotient oracles) on three

@@ -1,0 +1,110 @@
+"""zkm_prove_segments: K independent segments in lock-step (one launch per stage for all segments whose table has the same height).
+Every proof blob and every CTL challenge must be word for word what the single-segment path (zkm_prove_segment) and the CPU oracle's
+prove_with_traces (restating prover/src/prover.rs:130-438) produce for that segment alone."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _segment(variant, heights=None):
+    """The committed twelve-table test segment, rows rotated by `variant` (filters stay binary: neither prover looks at validity across
+    the seam) and tiled to `heights` (log2 rows per table) where given: (traces, log_n)."""
+    from zkm_amd import tables as T
+    seg = np.load(os.path.join(ROOT, "tests", "golden", "segment12.npz"))
+    base = [int(x) for x in seg["log_n"]]
+    traces, log_n = [], []
+    for i in range(12):
+        w = T.WIDTH[T.TABLE_ENUM_ORDER[i]]
+        t = seg["t%d" % i].reshape(w, -1)
+        if variant:
+            t = np.roll(t, variant * (i + 1), axis=1)
+        L = base[i] if heights is None else max(heights[i], base[i])
+        traces.append(np.ascontiguousarray(np.tile(t, (1, 1 << (L - base[i])))).reshape(-1))
+        log_n.append(L)
+    return traces, log_n
+
+
+@pytest.mark.gpu
+def test_lockstep_segments_equal_single_segment_proofs_and_oracle(ctx, zkm, oracle):
+    """Four segments of the base heights (one group of four per table): lock-step == one at a time == oracle."""
+    from zkm_amd import tables as T
+    segs = []
+    for v in range(4):
+        tr, lg = _segment(v)
+        segs.append((tr, lg, [1 + v, 2, 3 + 7 * v]))
+    got = ctx.prove_segments(segs)
+    ctl_tables, ctls = T.all_cross_table_lookups()
+    for v, (tr, lg, pub) in enumerate(segs):
+        one, chal1, offs1 = ctx.prove_segment(tr, lg, public_values=pub)
+        proofs, chal, offs = got[v]
+        assert list(offs) == list(offs1) and (chal == chal1).all()
+        bad = np.nonzero(proofs != one)[0]
+        assert bad.size == 0, "segment %d: first differing word %d (table %d)" % (v, bad[0], int(np.searchsorted(offs, bad[0], side="right")) - 1)
+        tables = [(T.TABLE_ENUM_ORDER[i], tr[i], T.WIDTH[T.TABLE_ENUM_ORDER[i]], lg[i], ctl_tables[i]) for i in range(12)]
+        ref, rchal, _ = oracle.prove_with_traces(tables, ctls, public_values=pub)
+        assert (proofs == ref).all() and (chal == rchal).all()
+        if v == 0:      # (the rotated variants are not valid witnesses across the seam: the provers do not care, the verifier does)
+            assert oracle.verify_all(tables, ctls, proofs, chal, public_values=pub) == 0
+
+
+@pytest.mark.gpu
+def test_lockstep_segments_of_ragged_heights_and_small_stacks(ctx, zkm):
+    """Segments whose tables differ in height form one group per height; max_stack splits groups; every stacking gives the words
+    of the single-segment path."""
+    base = _segment(0)[1]
+    hs = [list(base), [h + 1 for h in base], list(base), [h + (i % 2) for i, h in enumerate(base)], [h + 1 for h in base]]
+    segs = []
+    for v, h in enumerate(hs):
+        tr, lg = _segment(v, h)
+        segs.append((tr, lg, [v, v + 1]))
+    want = [ctx.prove_segment(tr, lg, public_values=pub) for tr, lg, pub in segs]
+    c2 = zkm.Context(0)
+    try:
+        for stack in (32, 2, 3):
+            c2.set_tuning("max_stack", stack)
+            got = c2.prove_segments(segs)
+            for v in range(len(segs)):
+                assert list(got[v][2]) == list(want[v][2]) and (got[v][1] == want[v][1]).all()
+                bad = np.nonzero(got[v][0] != want[v][0])[0]
+                assert bad.size == 0, "max_stack %d, segment %d: first differing word %d" % (stack, v, bad[0])
+        c2.set_tuning("max_stack", 32)
+        c2.set_tuning("throughput_profile", 1)        # one stream, latency forms for tiny launches only
+        got = c2.prove_segments(segs)
+        for v in range(len(segs)):
+            assert (got[v][0] == want[v][0]).all()
+        c2.set_tuning("throughput_profile", 0)
+        c2.set_tuning("small_ntt", 0)
+        c2.set_tuning("tree_tail", 0)
+        c2.set_tuning("aux_pipeline", 0)
+        got = c2.prove_segments(segs[:3])
+        for v in range(3):
+            assert (got[v][0] == want[v][0]).all()
+    finally:
+        c2.close()
+
+
+@pytest.mark.gpu
+def test_lockstep_segments_from_device_buffers_at_2_16_cycle_heights(ctx, zkm):
+    """Three segments at the table heights of a 2^16-cycle segment (tools/bench_segment.py), traces resident in HBM: every table's
+    group of three == the single-segment path."""
+    from tools.bench_segment import HEIGHTS
+    segs, bufs = [], []
+    for v in range(3):
+        tr, lg = _segment(v, HEIGHTS[16])
+        d = [ctx.alloc(t.size).upload(t) for t in tr]
+        bufs.append(d)
+        segs.append((d, lg, [5, v]))
+    try:
+        want = [ctx.prove_segment(d, lg, public_values=pub) for d, lg, pub in segs]
+        got = ctx.prove_segments(segs)
+        for v in range(3):
+            assert list(got[v][2]) == list(want[v][2]) and (got[v][1] == want[v][1]).all()
+            bad = np.nonzero(got[v][0] != want[v][0])[0]
+            assert bad.size == 0, "segment %d: first differing word %d (table %d)" % (v, bad[0], int(np.searchsorted(want[v][2], bad[0], side="right")) - 1)
+    finally:
+        for d in bufs:
+            for b in d:
+                b.free()

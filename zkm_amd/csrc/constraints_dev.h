@@ -656,19 +656,19 @@ __device__ void eval_memory_constraints(const gl_t* __restrict__ lv, size_t cs, 
 // cross_table_lookup.rs:1006-1058 with beta = 1, gamma = challenge, no filters).  Passed by value: a few words.
 struct lookup_dev {
     uint32_t nlookups, nch;
-    gl_t challenges[4];
     struct { uint32_t ncols, col_off, table_col, freq_col; } lk[2];
     uint32_t cols[24];
 };
 template <int NA>
-__device__ void eval_lookup_constraints(const lookup_dev& d, const gl_t* __restrict__ lv, size_t N, const gl_t* __restrict__ aux,
-                                        size_t j, size_t jn, consumer_t<NA>& k) {
+__device__ void eval_lookup_constraints(const lookup_dev& d, const gl_t* __restrict__ challenges /* nch: this segment's */,
+                                        const gl_t* __restrict__ lv, size_t N, const gl_t* __restrict__ aux, size_t j, size_t jn,
+                                        consumer_t<NA>& k) {
     uint32_t start = 0;
     for (uint32_t l = 0; l < d.nlookups; l++) {
         const uint32_t ncols = d.lk[l].ncols, nh = (ncols + 1) / 2;
         const uint32_t* cols = d.cols + d.lk[l].col_off;
         for (uint32_t c = 0; c < d.nch; c++) {
-            const gl_t ch = d.challenges[c];
+            const gl_t ch = challenges[c];
             gl_t hsum = 0;
             for (uint32_t q = 0; q < nh; q++) {
                 gl_t h = aux[(size_t)(start + q) * N + j];

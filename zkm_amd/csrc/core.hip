@@ -111,6 +111,8 @@ void zkm_ctx::ensure_lanes(size_t k) {
         l->small_ntt = small_ntt;
         l->tree_tail = tree_tail;
         l->commit_lanes = commit_lanes;
+        l->max_stack = max_stack;
+        l->pow_round_log = pow_round_log;
         l->cu_part_k = cu_part_k;
         l->cu_part_n = cu_part_n;
         hipError_t e = zkm_stream_create(&l->stream, num_cus, cu_part_k, cu_part_n);
@@ -172,14 +174,37 @@ __global__ __launch_bounds__(256) void k_download_wide(const uint4* __restrict__
         }
     }
 }
+static char* pinned_alloc(size_t bytes) {
+    char* p = nullptr;
+    if (hipHostMalloc((void**)&p, bytes, hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();   // (a runtime that refuses the explicit flag: the default pinned allocation is coherent on this platform too)
+        p = nullptr;
+        ZKM_HIP_CHECK(hipHostMalloc((void**)&p, bytes, hipHostMallocDefault));
+    }
+    return p;
+}
 void zkm_ctx::ensure_xfer() {
     if (h_xfer) return;
-    if (hipHostMalloc((void**)&h_xfer, XFER_DOWN + XFER_UP + 64, hipHostMallocCoherent) != hipSuccess) {
-        (void)hipGetLastError();   // (a runtime that refuses the explicit flag: the default pinned allocation is coherent on this platform too)
-        h_xfer = nullptr;
-        ZKM_HIP_CHECK(hipHostMalloc((void**)&h_xfer, XFER_DOWN + XFER_UP + 64, hipHostMallocDefault));
+    h_xfer = pinned_alloc(XFER_UP + 64);
+    memset(h_xfer + XFER_UP, 0, 64);
+    ensure_down(XFER_DOWN);
+}
+// The download area grows with the largest transfer seen (a lock-step group of K segments brings K caps, K sets of opening partials, K
+// tables' query rounds down in one trip): power-of-two sizes up to XFER_DOWN_MAX; nothing is in flight into the old area when it goes
+// (downloads are waited for before their caller returns).
+void zkm_ctx::ensure_down(size_t bytes) {
+    if (bytes <= down_cap) return;
+    if (bytes > XFER_DOWN_MAX) throw std::runtime_error("internal: download beyond the pinned area's maximum");
+    size_t cap = down_cap ? down_cap : XFER_DOWN;
+    while (cap < bytes) cap <<= 1;
+    if (h_down) {
+        ZKM_HIP_CHECK(hipStreamSynchronize(stream));
+        (void)hipHostFree(h_down);
+        h_down = nullptr;
+        down_cap = 0;
     }
-    memset(h_xfer + XFER_DOWN + XFER_UP, 0, 64);
+    h_down = pinned_alloc(cap);
+    down_cap = cap;
 }
 // Waiting for the flag.  A spinning thread sees the words ~40 us earlier than one the runtime has to wake -- as long as it has a core
 // to spin on.  The deployed shape is 8 ranks x k contexts x ZKM_COMMIT_LANES threads on one host, each rank confined to its GPU's share
@@ -249,29 +274,29 @@ void zkm_ctx::wait_flag(const uint64_t* flag, uint64_t seq) {
 }
 uint64_t zkm_ctx::xfer_begin(size_t bytes, uint64_t** host_slot, uint64_t** flag, unsigned** counter) {
     ensure_xfer();
-    if (bytes > XFER_DOWN) throw std::runtime_error("internal: xfer_begin beyond the pinned download area");
+    ensure_down(bytes);
     if (!d_counter) {
         d_counter = (unsigned*)alloc(64);
         resident_bytes += 64;
         ZKM_HIP_CHECK(hipMemsetAsync(d_counter, 0, 64, stream));
     }
-    *host_slot = (uint64_t*)h_xfer;
-    *flag = (uint64_t*)(h_xfer + XFER_DOWN + XFER_UP);
+    *host_slot = (uint64_t*)h_down;
+    *flag = (uint64_t*)(h_xfer + XFER_UP);
     *counter = d_counter;
     return ++down_seq;
 }
 unsigned long long* zkm_ctx::pow_best() {
     if (!d_pow_best) {
-        d_pow_best = (unsigned long long*)alloc(8);
-        resident_bytes += 8;
-        ZKM_HIP_CHECK(hipMemsetAsync(d_pow_best, 0xff, 8, stream));
+        d_pow_best = (unsigned long long*)alloc(8 * ZKM_MAX_SEG);      // one word per search of a stack
+        resident_bytes += 8 * ZKM_MAX_SEG;
+        ZKM_HIP_CHECK(hipMemsetAsync(d_pow_best, 0xff, 8 * ZKM_MAX_SEG, stream));
     }
     return d_pow_best;
 }
 void zkm_ctx::xfer_finish(uint64_t seq, void* dst, size_t bytes) {
-    wait_flag((const uint64_t*)(h_xfer + XFER_DOWN + XFER_UP), seq);
+    wait_flag((const uint64_t*)(h_xfer + XFER_UP), seq);
     up_off = 0;                                               // everything queued before the kernel has completed, uploads included
-    memcpy(dst, h_xfer, bytes);
+    memcpy(dst, h_down, bytes);
 }
 void zkm_ctx::download(std::initializer_list<xfer> xs) {
     ensure_xfer();
@@ -283,18 +308,19 @@ void zkm_ctx::download(std::initializer_list<xfer> xs) {
         nx += x.bytes != 0;
         words_ok = words_ok && x.bytes % 4 == 0 && (uintptr_t)x.src % 4 == 0;
     }
+    if (total <= XFER_DOWN_MAX) ensure_down(total);
     if (nx && nx <= 4 && total <= XFER_KERNEL && words_ok) {
         down_args a{};
         size_t off = 0;
         for (const xfer& x : xs) {
             if (!x.bytes) continue;
             a.src[a.n] = (const uint32_t*)x.src;
-            a.dst[a.n] = (uint32_t*)(h_xfer + off);
+            a.dst[a.n] = (uint32_t*)(h_down + off);
             a.words[a.n] = (uint32_t)(x.bytes / 4);
             a.n++;
             off += (x.bytes + 63) & ~(size_t)63;
         }
-        uint64_t* flag = (uint64_t*)(h_xfer + XFER_DOWN + XFER_UP);
+        uint64_t* flag = (uint64_t*)(h_xfer + XFER_UP);
         const uint64_t seq = ++down_seq;
         hipLaunchKernelGGL(k_download, dim3(1), dim3(1024), 0, stream, a, flag, seq);
         ZKM_HIP_CHECK(hipGetLastError());
@@ -303,12 +329,12 @@ void zkm_ctx::download(std::initializer_list<xfer> xs) {
         off = 0;
         for (const xfer& x : xs) {
             if (!x.bytes) continue;
-            memcpy(x.dst, h_xfer + off, x.bytes);
+            memcpy(x.dst, h_down + off, x.bytes);
             off += (x.bytes + 63) & ~(size_t)63;
         }
         return;
     }
-    if (nx == 1 && total <= XFER_DOWN) {
+    if (nx == 1 && total <= down_cap) {
         const xfer* one = nullptr;
         for (const xfer& x : xs)
             if (x.bytes) one = &x;
@@ -327,15 +353,15 @@ void zkm_ctx::download(std::initializer_list<xfer> xs) {
     size_t off = 0;
     for (const xfer& x : xs) {
         if (!x.bytes) continue;
-        const bool small = off + x.bytes <= XFER_DOWN;
-        ZKM_HIP_CHECK(hipMemcpyAsync(small ? (void*)(h_xfer + off) : x.dst, x.src, x.bytes, hipMemcpyDeviceToHost, stream));
+        const bool small = off + x.bytes <= down_cap;
+        ZKM_HIP_CHECK(hipMemcpyAsync(small ? (void*)(h_down + off) : x.dst, x.src, x.bytes, hipMemcpyDeviceToHost, stream));
         if (small) off += (x.bytes + 63) & ~(size_t)63;
     }
     sync();
     off = 0;
     for (const xfer& x : xs) {
-        if (!x.bytes || off + x.bytes > XFER_DOWN) continue;
-        memcpy(x.dst, h_xfer + off, x.bytes);
+        if (!x.bytes || off + x.bytes > down_cap) continue;
+        memcpy(x.dst, h_down + off, x.bytes);
         off += (x.bytes + 63) & ~(size_t)63;
     }
 }
@@ -348,7 +374,7 @@ void zkm_ctx::upload(void* dst, const void* src, size_t bytes) {
     }
     ensure_xfer();
     if (up_off + bytes > XFER_UP) sync();                        // the ring is full: wait for the uploads in flight (sync() rewinds it)
-    char* slot = h_xfer + XFER_DOWN + up_off;
+    char* slot = h_xfer + up_off;
     memcpy(slot, src, bytes);
     ZKM_HIP_CHECK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, stream));
     up_off += (bytes + 63) & ~(size_t)63;
@@ -442,6 +468,7 @@ void zkm_ctx_destroy(zkm_ctx* c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->h_staging) (void)hipHostFree(c->h_staging);
     if (c->h_xfer) (void)hipHostFree(c->h_xfer);
+    if (c->h_down) (void)hipHostFree(c->h_down);
     if (c->block_event) (void)hipEventDestroy(c->block_event);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -463,6 +490,7 @@ int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) 
         else if (k == "pow_round_log") x->pow_round_log = value < 8 ? 8 : (value > 22 ? 22 : (unsigned)value);
         else if (k == "aux_pipeline") x->aux_pipeline = value ? 1 : 0;
         else if (k == "commit_lanes") x->commit_lanes = value < 1 ? 1 : (value > 8 ? 8 : (size_t)value);
+        else if (k == "max_stack") x->max_stack = value < 1 ? 1 : (value > ZKM_MAX_SEG ? ZKM_MAX_SEG : (size_t)value);
         else if (k == "throughput_profile") {
             // MANY contexts on one GPU proving small segments (profiles/r04_throughput_profile.txt): one stream per context -- the runtime
             // has ~16 hardware queues, and streams that share one run behind each other's long kernels -- and the latency forms of the
@@ -667,16 +695,31 @@ void zkm_launch_canon(zkm_ctx* c, gl_t* v, size_t total) {
 
 // src_cols (optional, instead of src): one pointer per column, each to n words -- the reference's Vec<PolynomialValues<F>> is one heap
 // allocation per column (prover.rs:154-163), so the Rust side hands the column pointers over instead of flattening 2 GiB on the host.
-void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t* dev_values, const uint64_t* const* src_cols) {
+// A stacked batch (b->nseg > 1: the same-shaped polynomials of nseg segments, zkm_internal.h) takes its source as ONE block of nseg x
+// ncols x n words (src), as nseg x ncols column pointers (src_cols), or as one pointer per segment (seg_srcs: ncols x n words each, host
+// or device -- the traces of the segments of a lock-step group); everything below then works on nseg * ncols columns.
+void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t* dev_values, const uint64_t* const* src_cols,
+                     const uint64_t* const* seg_srcs) {
     zkm_ctx* c = b->ctx;
-    size_t n = b->n(), N = b->N(), ncols = b->ncols;
+    const size_t nseg = b->nseg;
+    size_t n = b->n(), N = b->N(), ncols = b->ncols * nseg;   // (ncols: all columns of the stack)
     if (b->log_n + b->rate_bits > 30) throw std::runtime_error("polynomial batch too large");
-    if (!src && !src_cols) throw std::runtime_error("polynomial batch: no source");
+    if (nseg == 0 || nseg > ZKM_MAX_SEG) throw std::runtime_error("polynomial batch: bad segment count");
+    if (ncols > 65535 && nseg > 1) throw std::runtime_error("polynomial batch: too many stacked columns");
+    if (!src && !src_cols && !seg_srcs) throw std::runtime_error("polynomial batch: no source");
     if (src_cols)
         for (size_t i = 0; i < ncols; i++)
             if (!src_cols[i]) throw std::runtime_error("polynomial batch: null column pointer");
+    if (seg_srcs)
+        for (size_t i = 0; i < nseg; i++)
+            if (!seg_srcs[i]) throw std::runtime_error("polynomial batch: null segment pointer");
     // columns [c0, c0 + nc) of the source to dst (column stride n) on stream st
     auto copy_cols = [&](gl_t* dst, size_t c0, size_t nc, hipMemcpyKind kind, hipStream_t st) {
+        if (seg_srcs) {     // (whole stack only)
+            for (size_t sg = 0; sg < nseg; sg++)
+                ZKM_HIP_CHECK(hipMemcpyAsync(dst + sg * b->ncols * n, seg_srcs[sg], b->ncols * n * sizeof(gl_t), hipMemcpyDefault, st));
+            return;
+        }
         if (!src_cols) {
             ZKM_HIP_CHECK(hipMemcpyAsync(dst, src + c0 * n, nc * n * sizeof(gl_t), kind, st));
             return;
@@ -697,12 +740,13 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
         else zkm_ntt_natural_ex(c, vals, n, b->lde + c0 * N, n, b->coeffs + c0 * n, n, nc, b->log_n, /*inverse=*/true, 0);
     };
     size_t dwords = zkm_merkle_layout(b->lde_bits(), b->cap_height, b->level_off);
-    b->digests = (gl_t*)c->alloc(dwords * sizeof(gl_t));
-    bool dev = !src_cols && zkm_is_device_ptr(src);   // (column pointers are staged like host values, wherever each one lives)
+    b->dig_words = dwords;
+    b->digests = (gl_t*)c->alloc(nseg * dwords * sizeof(gl_t));
+    bool dev = !src_cols && !seg_srcs && zkm_is_device_ptr(src);   // (column / segment pointers are staged like host values, wherever each one lives)
     hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const size_t CH = c->ingest_chunk_cols;
     bool leaves_done = false;
-    if (src_is_values && !dev && CH && CH % 8 == 0 && ncols >= 2 * CH && b->log_n >= 13) {  // (short tables: one upload, wide leaf hashing)
+    if (src_is_values && !dev && nseg == 1 && CH && CH % 8 == 0 && ncols >= 2 * CH && b->log_n >= 13) {  // (short tables: one upload, wide leaf hashing)
         // Host-resident values (prover.rs:144-167: the traces arrive as Vec<PolynomialValues>): pipelined ingest.  The upload is
         // split into chunks of CH columns on the copy stream; the compute stream transforms (iNTT, LDE) and ABSORBS chunk k
         // (leaf sponge, hash.hip k_merkle_leaves_chunk) while chunk k + 1 .. are in flight, so PCIe time hides behind hashing.
@@ -761,7 +805,7 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
     }
     if (!leaves_done) {
         zkm_lde_bitrev(c, b->coeffs, b->lde, ncols, b->log_n, b->rate_bits, GL_GENERATOR, src_is_values ? s1 : 0);
-        zkm_launch_merkle_leaves(c, b->lde, N, ncols, N, b->digests);
+        zkm_launch_merkle_leaves(c, b->lde, N, b->ncols, N, b->digests, nseg, b->lde_seg(), dwords);
     }
     if (!src_is_values && s1) {
         // from_coeffs: the LDE above read the caller's natural order; the batch keeps the coefficients in the common layout
@@ -770,8 +814,8 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
         zkm_coeff_layout_convert(c, nat.as<gl_t>(), n, b->coeffs, n, ncols, b->log_n, /*to_natural=*/false);
     }
     size_t capw = (size_t)4 << b->cap_height;
-    b->cap.resize(capw);
-    zkm_merkle_build_inner_cap(c, b->digests, b->level_off, b->lde_bits(), b->cap_height, b->cap.data());
+    b->cap.resize(nseg * capw);
+    zkm_merkle_build_inner_cap(c, b->digests, b->level_off, b->lde_bits(), b->cap_height, b->cap.data(), nseg, dwords);
 }
 
 // out[i * ncols + col] = lde[col][bitrev((index_start + i) * step)]: lanes run along i, so reads of one column are scattered

@@ -18,8 +18,16 @@
 
 // ------------------------------------------------------------------ descriptor upload + validation
 void ctl_dev_owner::upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, bool lookup_mode,
-                           size_t trace_ncols) {
+                           size_t trace_ncols, size_t nseg) {
     c = ctx;
+    if (nseg == 0 || nseg > ZKM_MAX_SEG) throw std::runtime_error("CTL description: bad segment count");
+    // (a stacked description: zs holds nseg lists of nzs entries that differ in their challenges only -- segment s of a launch reads list s)
+    for (size_t sg = 1; sg < nseg; sg++)
+        for (size_t i = 0; i < nzs; i++) {
+            const zkm_ctl_z &a = zs[i], &b = zs[sg * nzs + i];
+            if (a.ncolsets != b.ncolsets || a.colset_off != b.colset_off || a.num_helpers != b.num_helpers)
+                throw std::runtime_error("CTL description: the segments of a stack must share the lookup structure");
+        }
     static const zkm_ctl_table empty{};
     if (!t) t = &empty;
     size_t nids = 0, th = 0;
@@ -56,13 +64,13 @@ void ctl_dev_owner::upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z
     // one blob: [columns | term_coeff | colsets | zs | term_col | filter_idx | colset_ids]
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t o_cols = 0, o_coeff = al(o_cols + t->ncolumns * sizeof(zkm_column)), o_sets = al(o_coeff + t->nterms * 8);
-    size_t o_zs = al(o_sets + t->ncolsets * sizeof(zkm_colset)), o_tc = al(o_zs + nzs * sizeof(zkm_ctl_z));
+    size_t o_zs = al(o_sets + t->ncolsets * sizeof(zkm_colset)), o_tc = al(o_zs + nseg * nzs * sizeof(zkm_ctl_z));
     size_t o_fi = al(o_tc + t->nterms * 4), o_ids = al(o_fi + t->nfilter_idx * 4), total = al(o_ids + nids * 4) + 16;
     std::vector<char> h(total, 0);
     if (t->ncolumns) memcpy(&h[o_cols], t->columns, t->ncolumns * sizeof(zkm_column));
     if (t->nterms) { memcpy(&h[o_coeff], t->term_coeff, t->nterms * 8); memcpy(&h[o_tc], t->term_col, t->nterms * 4); }
     if (t->ncolsets) memcpy(&h[o_sets], t->colsets, t->ncolsets * sizeof(zkm_colset));
-    if (nzs) memcpy(&h[o_zs], zs, nzs * sizeof(zkm_ctl_z));
+    if (nzs) memcpy(&h[o_zs], zs, nseg * nzs * sizeof(zkm_ctl_z));
     if (t->nfilter_idx) memcpy(&h[o_fi], t->filter_idx, t->nfilter_idx * 4);
     if (nids) memcpy(&h[o_ids], colset_ids, nids * 4);
     blob = c->alloc(total);
@@ -90,10 +98,17 @@ ctl_dev_owner::~ctl_dev_owner() {
 // ------------------------------------------------------------------ K6 kernels
 // helper columns + per-row sum of all terms of CtlZData zi0 + blockIdx.y (a run of Zs in one launch): helper columns of Z zi start at
 // aux + (helper columns of the Zs before it) * n, the row sums go to hsum_all + zi * n
+// (blockIdx.z = segment of a stack: its trace / auxiliary columns start trace_seg / aux_seg words after the previous segment's, its row
+// sums nzs * n words, and it reads its own list of CtlZData -- its own challenges)
 __global__ __launch_bounds__(256) void k_ctl_terms(ctl_dev d, uint32_t zi0, const gl_t* __restrict__ trace, size_t n,
-                                                   gl_t* __restrict__ aux, gl_t* __restrict__ hsum_all, int* __restrict__ bad) {
+                                                   gl_t* __restrict__ aux, gl_t* __restrict__ hsum_all, int* __restrict__ bad, size_t trace_seg,
+                                                   size_t aux_seg) {
     size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
+    trace += (size_t)blockIdx.z * trace_seg;
+    aux += (size_t)blockIdx.z * aux_seg;
+    hsum_all += (size_t)blockIdx.z * d.nzs * n;
+    d.zs += (size_t)blockIdx.z * d.nzs;
     const uint32_t zi = zi0 + blockIdx.y;
     const zkm_ctl_z z = d.zs[zi];
     size_t hstart = 0;
@@ -124,10 +139,12 @@ __global__ __launch_bounds__(256) void k_ctl_terms(ctl_dev d, uint32_t zi0, cons
 // Tables with many looking column sets and few rows (KeccakSponge: 136 + 34 sets, a few thousand rows) are latency-bound in
 // k_ctl_terms (one thread walks every set of its row); here blockIdx.y picks the helper column, and k_ctl_rowsum adds them up.
 __global__ __launch_bounds__(256) void k_ctl_helper(ctl_dev d, uint32_t zi, const gl_t* __restrict__ trace, size_t n, gl_t* __restrict__ helpers,
-                                                    int* __restrict__ bad) {
+                                                    int* __restrict__ bad, size_t trace_seg, size_t aux_seg) {
     size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
-    const zkm_ctl_z z = d.zs[zi];
+    trace += (size_t)blockIdx.z * trace_seg;
+    helpers += (size_t)blockIdx.z * aux_seg;
+    const zkm_ctl_z z = d.zs[(size_t)blockIdx.z * d.nzs + zi];
     const uint32_t* ids = d.colset_ids + z.colset_off;
     const uint32_t j = blockIdx.y;
     const gl_t* lv = trace + row;
@@ -144,20 +161,25 @@ __global__ __launch_bounds__(256) void k_ctl_helper(ctl_dev d, uint32_t zi, cons
     }
     helpers[(size_t)j * n + row] = h;
 }
-__global__ __launch_bounds__(256) void k_ctl_rowsum(const gl_t* __restrict__ helpers, uint32_t nh, size_t n, gl_t* __restrict__ hsum) {
+__global__ __launch_bounds__(256) void k_ctl_rowsum(const gl_t* __restrict__ helpers, uint32_t nh, size_t n, gl_t* __restrict__ hsum, size_t aux_seg,
+                                                    size_t hsum_seg) {
     size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
+    helpers += (size_t)blockIdx.z * aux_seg;
+    hsum += (size_t)blockIdx.z * hsum_seg;
     gl_t total = 0;
     for (uint32_t j = 0; j < nh; j++) total = gl_add(total, helpers[(size_t)j * n + row]);
     hsum[row] = total;
 }
 
 // additive suffix scans of nb arrays of length m at stride `stride` (blockIdx.y = array), segments of 64:  totals[b][s] = sum of segment s
-__global__ void k_sum_totals(const gl_t* __restrict__ a, size_t stride, size_t m, gl_t* __restrict__ out) {
+// (blockIdx.z = segment of a stack: a += z * a_seg; the totals of all arrays of a segment are contiguous)
+__global__ void k_sum_totals(const gl_t* __restrict__ a, size_t stride, size_t m, gl_t* __restrict__ out, size_t a_seg) {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t nseg = (m + 63) / 64;
     if (s >= nseg) return;
-    a += (size_t)blockIdx.y * stride;
+    a += (size_t)blockIdx.y * stride + (size_t)blockIdx.z * a_seg;
+    out += (size_t)blockIdx.z * gridDim.y * nseg;
     size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
     gl_t acc = 0;
     for (size_t k = s * 64; k < end; k++) acc = gl_add(acc, a[k]);
@@ -165,12 +187,13 @@ __global__ void k_sum_totals(const gl_t* __restrict__ a, size_t stride, size_t m
 }
 // S[k] = a[k] + S[k+1] inside each segment, carry-in = upper[s+1]   (upper: [array][nupper])
 __global__ void k_sum_scan(const gl_t* __restrict__ a, size_t stride, size_t m, const gl_t* __restrict__ upper, size_t nupper,
-                           gl_t* __restrict__ out, size_t out_stride) {
+                           gl_t* __restrict__ out, size_t out_stride, size_t a_seg, size_t out_seg) {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t nseg = (m + 63) / 64;
     if (s >= nseg) return;
-    a += (size_t)blockIdx.y * stride;
-    out += (size_t)blockIdx.y * out_stride;
+    a += (size_t)blockIdx.y * stride + (size_t)blockIdx.z * a_seg;
+    out += (size_t)blockIdx.y * out_stride + (size_t)blockIdx.z * out_seg;
+    if (upper) upper += (size_t)blockIdx.z * gridDim.y * nupper;
     gl_t acc = (upper && s + 1 < nupper) ? upper[(size_t)blockIdx.y * nupper + s + 1] : 0;
     size_t end = (s + 1) * 64 < m ? (s + 1) * 64 : m;
     for (size_t k = end; k-- > s * 64;) {
@@ -181,18 +204,20 @@ __global__ void k_sum_scan(const gl_t* __restrict__ a, size_t stride, size_t m, 
 
 // out[b][k] = sum_{m >= k} a[b][m] for nb arrays (a[b] = a + b * a_stride, out[b] = out + b * out_stride; out may alias a): one launch per
 // level for all arrays -- the Z columns of a table are built together (a table of the reference has up to 28 of them)
-static void suffix_sum(zkm_ctx* c, const gl_t* a, size_t a_stride, size_t n, size_t nb, gl_t* out, size_t out_stride) {
+static void suffix_sum(zkm_ctx* c, const gl_t* a, size_t a_stride, size_t n, size_t nb, gl_t* out, size_t out_stride, size_t nstack = 1,
+                       size_t a_seg = 0, size_t out_seg = 0) {
     if (!nb) return;
-    struct level { const gl_t* t; size_t stride, m; };
-    std::vector<level> lv{{a, a_stride, n}};
+    const unsigned z = (unsigned)nstack;
+    struct level { const gl_t* t; size_t stride, m, seg; };
+    std::vector<level> lv{{a, a_stride, n, a_seg}};
     std::vector<void*> tmp;
     while (lv.back().m > 64) {
         size_t nseg = (lv.back().m + 63) / 64;
-        gl_t* t = (gl_t*)c->alloc(nb * nseg * sizeof(gl_t));
+        gl_t* t = (gl_t*)c->alloc(nstack * nb * nseg * sizeof(gl_t));
         tmp.push_back(t);
-        hipLaunchKernelGGL(k_sum_totals, dim3((unsigned)((nseg + 63) / 64), (unsigned)nb), dim3(64), 0, c->stream, lv.back().t, lv.back().stride,
-                           lv.back().m, t);
-        lv.push_back({t, nseg, nseg});
+        hipLaunchKernelGGL(k_sum_totals, dim3((unsigned)((nseg + 63) / 64), (unsigned)nb, z), dim3(64), 0, c->stream, lv.back().t, lv.back().stride,
+                           lv.back().m, t, lv.back().seg);
+        lv.push_back({t, nseg, nseg, nb * nseg});
     }
     std::vector<gl_t*> S(lv.size(), nullptr);
     for (size_t l = lv.size(); l-- > 0;) {
@@ -200,9 +225,9 @@ static void suffix_sum(zkm_ctx* c, const gl_t* a, size_t a_stride, size_t n, siz
         const gl_t* upper = l + 1 < lv.size() ? S[l + 1] : nullptr;
         size_t nupper = l + 1 < lv.size() ? lv[l + 1].m : 0;
         if (l == 0) S[l] = out;
-        else { S[l] = (gl_t*)c->alloc(nb * lv[l].m * sizeof(gl_t)); tmp.push_back(S[l]); }
-        hipLaunchKernelGGL(k_sum_scan, dim3((unsigned)((nseg + 63) / 64), (unsigned)nb), dim3(64), 0, c->stream, lv[l].t, lv[l].stride, lv[l].m,
-                           upper, nupper, S[l], l == 0 ? out_stride : lv[l].m);
+        else { S[l] = (gl_t*)c->alloc(nstack * nb * lv[l].m * sizeof(gl_t)); tmp.push_back(S[l]); }
+        hipLaunchKernelGGL(k_sum_scan, dim3((unsigned)((nseg + 63) / 64), (unsigned)nb, z), dim3(64), 0, c->stream, lv[l].t, lv[l].stride, lv[l].m,
+                           upper, nupper, S[l], l == 0 ? out_stride : lv[l].m, lv[l].seg, l == 0 ? out_seg : nb * lv[l].m);
     }
     ZKM_HIP_CHECK(hipGetLastError());
     // no host sync: the temporaries go back to the caching allocator, whose blocks are only ever reused by later work on this stream
@@ -210,53 +235,65 @@ static void suffix_sum(zkm_ctx* c, const gl_t* a, size_t a_stride, size_t n, siz
 }
 
 // logUp: x[i] = hsum[i] - frequencies[i] / (challenge + table[i])   (lookup.rs:100-116)
-__global__ __launch_bounds__(256) void k_lookup_x(ctl_dev d, uint32_t table_col, uint32_t freq_col, gl_t challenge,
+// (segment blockIdx.z of a stack: its challenge is the gamma of its CtlZData list's only entry)
+__global__ __launch_bounds__(256) void k_lookup_x(ctl_dev d, uint32_t table_col, uint32_t freq_col,
                                                   const gl_t* __restrict__ trace, size_t n, const gl_t* __restrict__ hsum,
-                                                  gl_t* __restrict__ x) {
+                                                  gl_t* __restrict__ x, size_t trace_seg) {
     size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
+    trace += (size_t)blockIdx.z * trace_seg;
+    hsum += (size_t)blockIdx.z * n;
+    x += (size_t)blockIdx.z * n;
+    const gl_t challenge = d.zs[(size_t)blockIdx.z * d.nzs].gamma;
     bool next_ok = row + 1 < n;
     gl_t tinv = gl_inv(gl_add(challenge, ctl_eval_column(d, table_col, trace + row, n, 1, next_ok)));
     x[row] = gl_sub(hsum[row], gl_mul(ctl_eval_column(d, freq_col, trace + row, n, 1, next_ok), tinv));
 }
 // exclusive prefix sum from the suffix sums: z[k] = S[0] - S[k]
-__global__ __launch_bounds__(256) void k_prefix_from_suffix(const gl_t* __restrict__ S, size_t n, gl_t* __restrict__ z) {
+__global__ __launch_bounds__(256) void k_prefix_from_suffix(const gl_t* __restrict__ S, size_t n, gl_t* __restrict__ z, size_t z_seg) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    S += (size_t)blockIdx.z * n;
+    z += (size_t)blockIdx.z * z_seg;
     if (k < n) z[k] = gl_sub(S[0], S[k]);
 }
 
-// aux (device, naux x n) = helper columns (zs order) ++ Z columns
-void zkm_ctl_data_device(zkm_ctx* c, const ctl_dev_owner& own, const gl_t* d_trace, unsigned log_n, gl_t* d_aux) {
+// aux (device, naux x n) = helper columns (zs order) ++ Z columns.  A stacked description (own: nseg lists of CtlZData): segment s reads
+// the trace at d_trace + s * trace_seg and writes its columns at d_aux + s * aux_seg.
+void zkm_ctl_data_device(zkm_ctx* c, const ctl_dev_owner& own, const gl_t* d_trace, unsigned log_n, gl_t* d_aux, size_t nseg, size_t trace_seg,
+                         size_t aux_seg) {
     size_t n = (size_t)1 << log_n;
     const std::vector<zkm_ctl_z>& zs = own.h_zs;             // (host copy kept by upload(): no round trip for the launch planning)
     const size_t nzs = zs.size();
-    gl_t* const d_hsum_all = (gl_t*)c->alloc((nzs ? nzs : 1) * n * sizeof(gl_t));   // the per-row sums of every Z, scanned together below
+    const unsigned z = (unsigned)nseg;
+    gl_t* const d_hsum_all = (gl_t*)c->alloc(nseg * (nzs ? nzs : 1) * n * sizeof(gl_t));   // the per-row sums of every Z, scanned together below
     int* d_bad = (int*)c->alloc(sizeof(int));
     ZKM_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
     // Zs with many helper columns on a short table spread their column sets over blockIdx.y (few workgroups per launch otherwise);
     // every other run of consecutive Zs is ONE launch (blockIdx.y = Z)
-    auto wide = [&](uint32_t i) { return zs[i].num_helpers >= 4 && (n >> 8) < 4096; };
+    auto wide = [&](uint32_t i) { return zs[i].num_helpers >= 4 && ((n * nseg) >> 8) < 4096; };
     size_t hstart = 0;
     for (uint32_t i = 0; i < nzs;) {
         zkm_prof_scope ps(c, "ctl_terms");
         if (wide(i)) {
             gl_t* helpers = d_aux + hstart * n;
             const uint32_t nh = zs[i].num_helpers;
-            hipLaunchKernelGGL(k_ctl_helper, dim3((n + 255) / 256, nh), dim3(256), 0, c->stream, own.d, i, d_trace, n, helpers, d_bad);
-            hipLaunchKernelGGL(k_ctl_rowsum, dim3((n + 255) / 256), dim3(256), 0, c->stream, helpers, nh, n, d_hsum_all + (size_t)i * n);
+            hipLaunchKernelGGL(k_ctl_helper, dim3((n + 255) / 256, nh, z), dim3(256), 0, c->stream, own.d, i, d_trace, n, helpers, d_bad, trace_seg, aux_seg);
+            hipLaunchKernelGGL(k_ctl_rowsum, dim3((n + 255) / 256, 1, z), dim3(256), 0, c->stream, helpers, nh, n, d_hsum_all + (size_t)i * n, aux_seg,
+                               nzs * n);
             hstart += nh;
             i++;
         } else {
             uint32_t run = 0;
             while (i + run < nzs && !wide(i + run)) { hstart += zs[i + run].num_helpers; run++; }
-            hipLaunchKernelGGL(k_ctl_terms, dim3((n + 255) / 256, run), dim3(256), 0, c->stream, own.d, i, d_trace, n, d_aux, d_hsum_all, d_bad);
+            hipLaunchKernelGGL(k_ctl_terms, dim3((n + 255) / 256, run, z), dim3(256), 0, c->stream, own.d, i, d_trace, n, d_aux, d_hsum_all, d_bad,
+                               trace_seg, aux_seg);
             i += run;
         }
         ZKM_HIP_CHECK(hipGetLastError());
     }
     {
         zkm_prof_scope ps(c, "ctl_suffix_sum");
-        suffix_sum(c, d_hsum_all, n, n, nzs, d_aux + (size_t)own.d.total_helpers * n, n);
+        suffix_sum(c, d_hsum_all, n, n, nzs, d_aux + (size_t)own.d.total_helpers * n, n, nseg, nzs * n, aux_seg);
     }
     int bad = 0;
     c->download(&bad, d_bad, sizeof(int));
@@ -334,7 +371,7 @@ int zkm_ctl_data(zkm_ctx* c, const zkm_ctl_table* table, const zkm_ctl_z* zs, co
         if (!tdev) ZKM_HIP_CHECK(hipMemcpyAsync(d_trace, trace, ncols * n * 8, hipMemcpyHostToDevice, c->stream));
         gl_t* d_aux = adev ? aux_out : (gl_t*)c->alloc(own.naux * n * 8);
         try {
-            zkm_ctl_data_device(c, own, d_trace, log_n, d_aux);
+            zkm_ctl_data_device(c, own, d_trace, log_n, d_aux, 1, 0, 0);
             if (!adev) ZKM_HIP_CHECK(hipMemcpyAsync(aux_out, d_aux, own.naux * n * 8, hipMemcpyDeviceToHost, c->stream));
             c->sync();
         } catch (...) {
@@ -353,32 +390,36 @@ int zkm_ctl_data(zkm_ctx* c, const zkm_ctl_table* table, const zkm_ctl_z* zs, co
 
 }  // extern "C"
 
-// (ceil(nlookup / 2) + 1) columns of n into d_out (device): helper columns then Z (lookup.rs:46-124)
+// (ceil(nlookup / 2) + 1) columns of n into d_out (device): helper columns then Z (lookup.rs:46-124).  A stack of nseg segments:
+// challenges[s] is segment s's, its trace starts trace_seg words and its output out_seg words after the previous segment's.
 static void lookup_helper_columns_device(zkm_ctx* c, const zkm_ctl_table* table, const uint32_t* colset_ids, size_t nlookup, uint32_t table_col,
-                                         uint32_t freq_col, uint64_t challenge, const gl_t* d_trace, size_t n, gl_t* d_out,
-                                         size_t trace_ncols = 0) {
+                                         uint32_t freq_col, const uint64_t* challenges, const gl_t* d_trace, size_t n, gl_t* d_out,
+                                         size_t trace_ncols = 0, size_t nseg = 1, size_t trace_seg = 0, size_t out_seg = 0) {
     std::vector<void*> tmp;
     size_t nh = (nlookup + 1) / 2;
-    zkm_ctl_z z{(uint32_t)nlookup, 0, (uint32_t)nh, 0, 1, challenge};  // GrandProductChallenge{beta: 1, gamma: challenge}
+    std::vector<zkm_ctl_z> zl(nseg);
+    for (size_t sg = 0; sg < nseg; sg++) zl[sg] = zkm_ctl_z{(uint32_t)nlookup, 0, (uint32_t)nh, 0, 1, challenges[sg]};  // GrandProductChallenge{beta: 1, gamma: challenge}
     ctl_dev_owner own;
-    own.upload(c, table, &z, colset_ids, 1, /*lookup_mode=*/true, trace_ncols);
+    own.upload(c, table, zl.data(), colset_ids, 1, /*lookup_mode=*/true, trace_ncols, nseg);
+    const unsigned z = (unsigned)nseg;
     try {
-        gl_t* d_hsum = (gl_t*)c->alloc(n * 8);
+        gl_t* d_hsum = (gl_t*)c->alloc(nseg * n * 8);
         tmp.push_back(d_hsum);
-        gl_t* d_x = (gl_t*)c->alloc(n * 8);
+        gl_t* d_x = (gl_t*)c->alloc(nseg * n * 8);
         tmp.push_back(d_x);
         int* d_bad = (int*)c->alloc(sizeof(int));
         tmp.push_back(d_bad);
         ZKM_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
         {
             zkm_prof_scope ps(c, "lookup_terms");
-            hipLaunchKernelGGL(k_ctl_terms, dim3((n + 255) / 256), dim3(256), 0, c->stream, own.d, 0u, d_trace, n, d_out, d_hsum, d_bad);
-            hipLaunchKernelGGL(k_lookup_x, dim3((n + 255) / 256), dim3(256), 0, c->stream, own.d, table_col, freq_col, challenge, d_trace, n,
-                               d_hsum, d_x);
+            hipLaunchKernelGGL(k_ctl_terms, dim3((n + 255) / 256, 1, z), dim3(256), 0, c->stream, own.d, 0u, d_trace, n, d_out, d_hsum, d_bad, trace_seg,
+                               out_seg);
+            hipLaunchKernelGGL(k_lookup_x, dim3((n + 255) / 256, 1, z), dim3(256), 0, c->stream, own.d, table_col, freq_col, d_trace, n, d_hsum, d_x,
+                               trace_seg);
             ZKM_HIP_CHECK(hipGetLastError());
         }
-        suffix_sum(c, d_x, n, n, 1, d_hsum, n);
-        hipLaunchKernelGGL(k_prefix_from_suffix, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_hsum, n, d_out + nh * n);
+        suffix_sum(c, d_x, n, n, 1, d_hsum, n, nseg, n, n);
+        hipLaunchKernelGGL(k_prefix_from_suffix, dim3((n + 255) / 256, 1, z), dim3(256), 0, c->stream, d_hsum, n, d_out + nh * n, out_seg);
         ZKM_HIP_CHECK(hipGetLastError());
         int bad = 0;
         c->download(&bad, d_bad, sizeof(int));
@@ -395,8 +436,9 @@ static void lookup_helper_columns_device(zkm_ctx* c, const zkm_ctl_table* table,
 // A table's own logUp lookups (Stark::lookups()): every use in the reference is Column::single columns without filters
 // (memory_stark.rs:476-483, arithmetic_stark.rs:269-276).  Writes zkm_num_lookup_columns() columns of n into d_out:
 // per lookup, per challenge: helper columns then Z (prover.rs:475-493).
+// Stacked: challenges = nseg x nch (segment-major); segment s reads d_trace + s * trace_seg and writes d_out + s * out_seg.
 void zkm_table_lookup_columns_device(zkm_ctx* c, int table_id, const uint64_t* challenges, size_t nch, const gl_t* d_trace, size_t n,
-                                     gl_t* d_out) {
+                                     gl_t* d_out, size_t nseg, size_t trace_seg, size_t out_seg) {
     size_t nl = 0, off = 0;
     const zkm_table_lookup* defs = zkm_table_lookups(table_id, &nl);
     for (size_t l = 0; l < nl; l++) {
@@ -414,7 +456,10 @@ void zkm_table_lookup_columns_device(zkm_ctx* c, int table_id, const uint64_t* c
         }
         zkm_ctl_table t{cols.data(), cols.size(), tc.data(), tf.data(), tc.size(), sets.data(), sets.size(), nullptr, 0};
         for (size_t k = 0; k < nch; k++) {
-            lookup_helper_columns_device(c, &t, ids.data(), d.ncols, d.ncols, d.ncols + 1, challenges[k], d_trace, n, d_out + off * n);
+            std::vector<uint64_t> chk(nseg);
+            for (size_t sg = 0; sg < nseg; sg++) chk[sg] = challenges[sg * nch + k];
+            lookup_helper_columns_device(c, &t, ids.data(), d.ncols, d.ncols, d.ncols + 1, chk.data(), d_trace, n, d_out + off * n, 0, nseg, trace_seg,
+                                         out_seg);
             off += (d.ncols + 1) / 2 + 1;
         }
     }
@@ -442,7 +487,7 @@ int zkm_lookup_helper_columns(zkm_ctx* c, const zkm_ctl_table* table, const uint
         if (!tdev) { tmp.push_back(d_trace); ZKM_HIP_CHECK(hipMemcpyAsync(d_trace, trace, ncols * n * 8, hipMemcpyHostToDevice, c->stream)); }
         gl_t* d_out = odev ? out : (gl_t*)c->alloc((nh + 1) * n * 8);
         if (!odev) tmp.push_back(d_out);
-        lookup_helper_columns_device(c, table, colset_ids, nlookup, table_col, freq_col, challenge, d_trace, n, d_out, ncols);
+        lookup_helper_columns_device(c, table, colset_ids, nlookup, table_col, freq_col, &challenge, d_trace, n, d_out, ncols);
         if (!odev) ZKM_HIP_CHECK(hipMemcpyAsync(out, d_out, (nh + 1) * n * 8, hipMemcpyDeviceToHost, c->stream));
         c->sync();
         for (void* p : tmp) c->release(p);
@@ -537,8 +582,8 @@ size_t zkm_all_proof_words(const zkm_stark_config* cfg, const zkm_table_input* t
 // Estimated time of committing `ncols` columns of 2^log_n rows (seconds; rate 4): every 8 columns are one absorb step of the leaf
 // sponge, and a step costs the larger of the permutation's latency in the form the matrix gets (hash.hip: 16 lanes per leaf up to
 // wide_max_hashes rows, four lanes up to quad_max_hashes, one lane beyond) and the time the whole machine needs for that many hashes.
-static double commit_cost_estimate(const zkm_ctx* c, size_t ncols, unsigned log_n, unsigned rate_bits) {
-    const double rows = (double)((size_t)1 << (log_n + rate_bits));
+static double commit_cost_estimate(const zkm_ctx* c, size_t ncols, unsigned log_n, unsigned rate_bits, size_t nstack = 1) {
+    const double rows = (double)((size_t)1 << (log_n + rate_bits)) * (double)nstack;   // (the rows of a stack are hashed in one launch)
     const double full_rate = 3.3e9;                        // one-lane permutations per second of the whole GPU
     double lat, rate;
     if (rows <= (double)c->wide_max_hashes) { lat = 13e-6; rate = full_rate / 4.2; }
@@ -599,26 +644,49 @@ static void run_on_lanes(zkm_ctx* c, const std::vector<size_t>& big, const std::
         if (e) std::rethrow_exception(e);
 }
 
-extern "C" {
+// ------------------------------------------------------------------ prove_with_traces for K segments in lock-step
+// The segments of one call share the table list (ids, widths, column-set descriptions) and the cross-table lookups; heights may differ.
+// For every table the segments are partitioned by height into GROUPS of at most ZKM_MAX_SEG: a group's trace, auxiliary and quotient
+// commitments are stacked batches (zkm_internal.h), its CTL data / quotient / openings / FRI stages are one launch (or group of launches)
+// for all its segments, and each of its transcript round trips brings all its segments' words down together.  Per segment the
+// transcript is exactly prove_with_traces' (prover.rs:130-232, 234-438): all trace caps in table order, the public values, the CTL
+// challenges, then the tables in order, each continuing the segment's challenger.  One segment = one group of one per table.
+struct seg_io {
+    const zkm_table_input* tables;   // ntables entries
+    const uint64_t* pub;
+    size_t npub;
+    uint64_t* proofs;                // per-table blobs concatenated
+    uint64_t* challenges;            // num_challenges (beta, gamma) pairs out
+};
+struct table_group {
+    size_t t = 0;                    // table
+    std::vector<size_t> segs;        // its segments (call order)
+    unsigned log_n = 0;
+    zkm_batch* commit = nullptr;
+    zkm_batch* aux = nullptr;
+    gl_t* d_traces = nullptr;        // stacked device copy of the trace values (segs.size() x ncols x n), or null: read in place
+    zkm_ctx* d_owner = nullptr;      // ... from the allocator of the context (commit lane) that made it
+    bool host = false, keep = false;
+};
 
-int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_table_input* tables, size_t ntables,
-                          const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls, const uint64_t* pub,
-                          size_t npub, uint64_t* proofs, uint64_t* challenges, char** err) {
-    std::vector<zkm_batch*> commits(ntables, nullptr), aux_commits(ntables, nullptr);
-    std::vector<gl_t*> d_traces(ntables, nullptr);  // device copies of host-resident traces: uploaded ONCE (with the commitment), reused below
-    std::vector<zkm_ctx*> d_owner(ntables, nullptr);  // ... each from the allocator of the context (commit lane) that uploaded it
+static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const seg_io* io, size_t ntables,
+                                const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls) {
+    std::vector<table_group> groups;
     auto drop_traces = [&]() {
         (void)hipStreamSynchronize(c->stream);
-        for (size_t t = 0; t < d_traces.size(); t++) {
-            if (d_traces[t]) (d_owner[t] ? d_owner[t] : c)->release(d_traces[t]);
-            d_traces[t] = nullptr;
+        for (table_group& g : groups) {
+            if (g.d_traces) (g.d_owner ? g.d_owner : c)->release(g.d_traces);
+            g.d_traces = nullptr;
         }
     };
     auto drop_all = [&]() {
         (void)hipStreamSynchronize(c->stream);
         for (zkm_ctx* l : c->lanes) (void)hipStreamSynchronize(l->stream);
-        for (auto b : commits) zkm_batch_free(b);
-        for (auto b : aux_commits) zkm_batch_free(b);
+        for (table_group& g : groups) {
+            zkm_batch_free(g.commit);
+            zkm_batch_free(g.aux);
+            g.commit = g.aux = nullptr;
+        }
         drop_traces();
     };
     struct background {            // lanes building auxiliary commitments behind the table proofs (below)
@@ -636,135 +704,241 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
     } bg;
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (nseg == 0) return;
+        const zkm_table_input* T0 = io[0].tables;
+        for (size_t s = 0; s < nseg; s++) {
+            if (!io[s].tables || !io[s].proofs || !io[s].challenges) throw std::runtime_error("zkm_prove_with_traces: null argument");
+            for (size_t t = 0; t < ntables; t++) {
+                const zkm_table_input& a = io[s].tables[t];
+                if (a.table_id != T0[t].table_id || a.ncols != T0[t].ncols || a.ctl != T0[t].ctl)
+                    throw std::runtime_error("zkm_prove_segments: the segments of one call must share the table list and its lookup description");
+                if (a.ncols == 0 || a.log_n > 30) throw std::runtime_error("zkm_prove_with_traces: bad table shape");
+                if (!a.trace && !a.columns) throw std::runtime_error("zkm_prove_with_traces: table without a trace");
+            }
+        }
         if (ntables == 12) {  // a whole AllStark segment: the transcript only matches the reference's in Table::all() order
             bool all = true, ordered = true;
             for (size_t t = 0; t < 12; t++) {
-                int e = zkm_table_enum_index(tables[t].table_id);
+                int e = zkm_table_enum_index(T0[t].table_id);
                 all = all && e >= 0;
                 ordered = ordered && e == (int)t;
             }
             bool distinct = all;
             for (size_t a = 0; a < 12 && distinct; a++)
                 for (size_t b = a + 1; b < 12; b++)
-                    if (tables[a].table_id == tables[b].table_id) distinct = false;
+                    if (T0[a].table_id == T0[b].table_id) distinct = false;
             if (distinct && !ordered)
                 throw std::runtime_error("zkm_prove_with_traces: the twelve tables must be given in the reference's Table enum order "
                                          "(all_stark.rs:96-110; see zkm_table_enum_index)");
         }
-        std::vector<size_t> offs(ntables + 1);
-        if (!zkm_all_proof_words(cfg, tables, ntables, ctls, sides, nctls, offs.data()) && ntables)
-            throw std::runtime_error("zkm_prove_with_traces: malformed cross-table lookups");
+        std::vector<std::vector<size_t>> offs(nseg, std::vector<size_t>(ntables + 1));
+        for (size_t s = 0; s < nseg; s++)
+            if (!zkm_all_proof_words(cfg, io[s].tables, ntables, ctls, sides, nctls, offs[s].data()) && ntables)
+                throw std::runtime_error("zkm_prove_with_traces: malformed cross-table lookups");
+        // the structure of every table's CtlZData list (no challenges yet): the number of auxiliary columns bounds the stack height
+        const auto tz0 = derive_zs(ntables, ctls, sides, nctls, cfg->num_challenges, nullptr);
+        // groups: per table, segments of equal height, at most max_stack (and 65535 stacked columns: a grid dimension of the transforms)
+        std::vector<std::vector<size_t>> where(ntables, std::vector<size_t>(nseg));     // group of (table, segment)
+        std::vector<std::vector<size_t>> pos(ntables, std::vector<size_t>(nseg));       // ... and the segment's position in it
+        for (size_t t = 0; t < ntables; t++) {
+            const size_t widest = std::max<size_t>(T0[t].ncols, tz0[t].naux + zkm_num_lookup_columns(T0[t].table_id, cfg));
+            size_t cap = std::min<size_t>(std::max<size_t>(1, c->max_stack), ZKM_MAX_SEG);
+            cap = std::max<size_t>(1, std::min<size_t>(cap, 65535 / std::max<size_t>(1, widest)));
+            std::vector<char> done(nseg, 0);
+            for (size_t s = 0; s < nseg; s++) {
+                if (done[s]) continue;
+                table_group g;
+                g.t = t;
+                g.log_n = io[s].tables[t].log_n;
+                for (size_t r = s; r < nseg && g.segs.size() < cap; r++)
+                    if (!done[r] && io[r].tables[t].log_n == g.log_n) {
+                        done[r] = 1;
+                        where[t][r] = groups.size();
+                        pos[t][r] = g.segs.size();
+                        g.segs.push_back(r);
+                    }
+                groups.push_back(std::move(g));
+            }
+        }
+        const size_t njobs = groups.size();
         // "compute all trace commitments" prover.rs:144-167
-        zkm_challenger ch;
-        zkm_challenger_init(&ch);
+        std::vector<zkm_challenger> ch(nseg);
+        for (auto& x : ch) zkm_challenger_init(&x);
         // Host-resident traces are uploaded once, with their commitment, and the device copy is reused for the table's CTL / lookup
         // columns -- as long as the copies kept this way stay within a quarter of the memory that is free now (all twelve commitments
         // -- coefficients + 4x LDE + digests -- are alive at the same time, and a full-size Keccak table alone is 20 GB of values).
-        // A trace beyond that budget is dropped after its commitment and uploaded again when its table is proven.
+        // A trace beyond that budget is dropped after its commitment and uploaded again when its table is proven.  (A group of several
+        // segments always keeps its stacked copy: its kernels read ONE block.)
         size_t kept = 0, keep_limit = 0;
         bool have_limit = false;                       // (hipMemGetInfo is a driver round trip: only asked when a trace is host-resident)
-        std::vector<char> keep(ntables, 0), host(ntables, 0);
         std::vector<size_t> big, small;
         {
             zkm_prof_scope st(c, "stage/compute all trace commitments");
             // The commitments do not depend on each other -- only the transcript does, and it starts after them (prover.rs:144-167 is a
             // plain loop; :182-185 observes the caps in table order): run_on_lanes.
-            for (size_t t = 0; t < ntables; t++) {
-                if (tables[t].ncols == 0 || tables[t].log_n > 30) throw std::runtime_error("zkm_prove_with_traces: bad table shape");
-                if (!tables[t].trace && !tables[t].columns) throw std::runtime_error("zkm_prove_with_traces: table without a trace");
-                const size_t bytes = (tables[t].ncols << tables[t].log_n) * sizeof(gl_t);
-                host[t] = tables[t].columns || !zkm_is_device_ptr(tables[t].trace);   // (column pointers are gathered into one device block)
-                if (host[t] && !have_limit) {
-                    size_t free_b = 0, total_b = 0;
-                    ZKM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-                    // (a quarter of what is free NOW -- shared with every other context of this process working on the same GPU, each of
-                    // which asks the same question on its own: divided by their number)
-                    keep_limit = free_b / 4 / (size_t)std::max(1, zkm_live_contexts());
-                    have_limit = true;
+            for (size_t j = 0; j < njobs; j++) {
+                table_group& g = groups[j];
+                const zkm_table_input& a = io[g.segs[0]].tables[g.t];
+                const size_t bytes = (a.ncols << g.log_n) * sizeof(gl_t) * g.segs.size();
+                g.host = false;
+                for (size_t s : g.segs) {
+                    const zkm_table_input& b = io[s].tables[g.t];
+                    g.host = g.host || b.columns || !zkm_is_device_ptr(b.trace);   // (column pointers are gathered into one device block)
                 }
-                keep[t] = host[t] && kept + bytes <= keep_limit;
-                if (keep[t]) kept += bytes;
-                ((bytes << cfg->rate_bits) > ((size_t)1 << 30) ? big : small).push_back(t);
+                if (g.segs.size() > 1) {
+                    g.keep = true;
+                } else {
+                    if (g.host && !have_limit) {
+                        size_t free_b = 0, total_b = 0;
+                        ZKM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+                        // (a quarter of what is free NOW -- shared with every other context of this process working on the same GPU, each of
+                        // which asks the same question on its own: divided by their number)
+                        keep_limit = free_b / 4 / (size_t)std::max(1, zkm_live_contexts());
+                        have_limit = true;
+                    }
+                    g.keep = g.host && kept + bytes <= keep_limit;
+                    if (g.keep) kept += bytes;
+                }
+                ((bytes << cfg->rate_bits) > ((size_t)1 << 30) ? big : small).push_back(j);
             }
-            std::sort(small.begin(), small.end(),
-                      [&](size_t a, size_t b) { return (tables[a].ncols << tables[a].log_n) > (tables[b].ncols << tables[b].log_n); });
-            std::vector<double> cost(ntables, 0.0);
-            for (size_t t = 0; t < ntables; t++) cost[t] = commit_cost_estimate(c, tables[t].ncols, tables[t].log_n, cfg->rate_bits);
-            run_on_lanes(c, big, small, cost, [&](zkm_ctx* w, size_t t) {
-                if (keep[t]) {
-                    d_traces[t] = (gl_t*)w->alloc((tables[t].ncols << tables[t].log_n) * sizeof(gl_t));
-                    d_owner[t] = w;
+            auto words = [&](size_t j) { return (T0[groups[j].t].ncols << groups[j].log_n) * groups[j].segs.size(); };
+            std::sort(small.begin(), small.end(), [&](size_t a, size_t b) { return words(a) > words(b); });
+            std::vector<double> cost(njobs, 0.0);
+            for (size_t j = 0; j < njobs; j++)
+                cost[j] = commit_cost_estimate(c, T0[groups[j].t].ncols, groups[j].log_n, cfg->rate_bits, groups[j].segs.size());
+            run_on_lanes(c, big, small, cost, [&](zkm_ctx* w, size_t j) {
+                table_group& g = groups[j];
+                const size_t W = T0[g.t].ncols, n = (size_t)1 << g.log_n, G = g.segs.size();
+                if (g.keep) {
+                    g.d_traces = (gl_t*)w->alloc(G * W * n * sizeof(gl_t));
+                    g.d_owner = w;
                 }
-                commits[t] = zkm_batch_commit_values_keep(w, tables[t].trace, tables[t].ncols, tables[t].log_n, cfg->rate_bits, cfg->cap_height,
-                                                          d_traces[t], tables[t].columns);
+                if (G == 1) {
+                    const zkm_table_input& a = io[g.segs[0]].tables[g.t];
+                    g.commit = zkm_batch_commit_values_keep(w, a.trace, W, g.log_n, cfg->rate_bits, cfg->cap_height, g.d_traces, a.columns);
+                    return;
+                }
+                zkm_batch* b = new zkm_batch();
+                b->ctx = w; b->ncols = W; b->nseg = G; b->log_n = g.log_n; b->rate_bits = cfg->rate_bits; b->cap_height = cfg->cap_height;
+                g.commit = b;      // (owned from here on: freed on every exit path)
+                bool any_cols = false;
+                for (size_t s : g.segs) any_cols = any_cols || io[s].tables[g.t].columns;
+                if (any_cols) {    // one pointer per column of every segment
+                    std::vector<const uint64_t*> cols(G * W);
+                    for (size_t k = 0; k < G; k++) {
+                        const zkm_table_input& a = io[g.segs[k]].tables[g.t];
+                        for (size_t i = 0; i < W; i++) cols[k * W + i] = a.columns ? a.columns[i] : a.trace + i * n;
+                    }
+                    zkm_batch_build(b, nullptr, true, g.d_traces, cols.data());
+                } else {
+                    std::vector<const uint64_t*> srcs(G);
+                    for (size_t k = 0; k < G; k++) srcs[k] = io[g.segs[k]].tables[g.t].trace;
+                    zkm_batch_build(b, nullptr, true, g.d_traces, nullptr, srcs.data());
+                }
             });
-            for (size_t t = 0; t < ntables; t++) zkm_challenger_observe(&ch, commits[t]->cap.data(), commits[t]->cap.size());  // :182-185
         }
-        zkm_challenger_observe(&ch, pub, npub);  // :187 observe_public_values
-        for (unsigned k = 0; k < cfg->num_challenges; k++) {  // :190, beta then gamma (cross_table_lookup.rs:560-566)
-            challenges[2 * k] = zkm_challenger_get(&ch);
-            challenges[2 * k + 1] = zkm_challenger_get(&ch);
+        const size_t C4 = (size_t)4 << cfg->cap_height;
+        const unsigned nch = cfg->num_challenges;
+        for (size_t s = 0; s < nseg; s++) {
+            for (size_t t = 0; t < ntables; t++)   // :182-185
+                zkm_challenger_observe(&ch[s], groups[where[t][s]].commit->cap.data() + pos[t][s] * C4, C4);
+            zkm_challenger_observe(&ch[s], io[s].pub, io[s].npub);  // :187 observe_public_values
+            for (unsigned k = 0; k < nch; k++) {  // :190, beta then gamma (cross_table_lookup.rs:560-566)
+                io[s].challenges[2 * k] = zkm_challenger_get(&ch[s]);
+                io[s].challenges[2 * k + 1] = zkm_challenger_get(&ch[s]);
+            }
         }
-        auto tz = derive_zs(ntables, ctls, sides, nctls, cfg->num_challenges, challenges);
-        uint64_t lookup_ch[4];  // the betas of the CTL challenges (prover.rs:468-474)
-        for (unsigned k = 0; k < cfg->num_challenges; k++) lookup_ch[k] = challenges[2 * k];
+        std::vector<std::vector<table_zs>> tz(nseg);
+        for (size_t s = 0; s < nseg; s++) tz[s] = derive_zs(ntables, ctls, sides, nctls, nch, io[s].challenges);
+        // per group: its segments' CtlZData lists one after the other (same structure, own challenges), and the betas of the CTL
+        // challenges as lookup challenges (prover.rs:468-474)
+        std::vector<std::vector<zkm_ctl_z>> gzs(njobs);
+        std::vector<std::vector<uint64_t>> glookup(njobs);
+        for (size_t j = 0; j < njobs; j++)
+            for (size_t s : groups[j].segs) {
+                const table_zs& z = tz[s][groups[j].t];
+                gzs[j].insert(gzs[j].end(), z.zs.begin(), z.zs.end());
+                for (unsigned k = 0; k < nch; k++) glookup[j].push_back(io[s].challenges[2 * k]);
+            }
         // "compute CTL data" :191-200 and each table's "compute auxiliary polynomials commitment" :511-522 (with its "compute lookup helper
         // columns" :475-493) depend on the CTL challenges only, not on the transcript of the table proofs: all tables' auxiliary
         // commitments are built now, side by side (run_on_lanes).  The transcript then observes them in table order, below.
-        std::vector<double> aux_cost(ntables, 0.0);          // CTL data + lookup columns read the trace once; then an `naux`-column commitment
-        for (size_t t = 0; t < ntables; t++)
-            aux_cost[t] = commit_cost_estimate(c, tz[t].naux + zkm_num_lookup_columns(tables[t].table_id, cfg), tables[t].log_n, cfg->rate_bits) +
-                          (double)(tables[t].ncols << tables[t].log_n) * 1e-10;
-        auto aux_job = [&](zkm_ctx* w, size_t t) {
-            if (tz[t].naux == 0) return;   // ("No CTL?" -- reported by prove_single_table in table order, prover.rs:509)
-            const size_t n = (size_t)1 << tables[t].log_n, W = tables[t].ncols;
-            const size_t NL = zkm_num_lookup_columns(tables[t].table_id, cfg), A = NL + tz[t].naux;
+        std::vector<double> aux_cost(njobs, 0.0);          // CTL data + lookup columns read the trace once; then an `naux`-column commitment
+        for (size_t j = 0; j < njobs; j++) {
+            const size_t t = groups[j].t;
+            aux_cost[j] = commit_cost_estimate(c, tz0[t].naux + zkm_num_lookup_columns(T0[t].table_id, cfg), groups[j].log_n, cfg->rate_bits,
+                                               groups[j].segs.size()) +
+                          (double)((T0[t].ncols << groups[j].log_n) * groups[j].segs.size()) * 1e-10;
+        }
+        auto aux_job = [&](zkm_ctx* w, size_t j) {
+            table_group& g = groups[j];
+            const size_t t = g.t, G = g.segs.size();
+            if (tz0[t].naux == 0) return;   // ("No CTL?" -- reported by prove_single_table in table order, prover.rs:509)
+            const size_t n = (size_t)1 << g.log_n, W = T0[t].ncols;
+            const size_t NL = zkm_num_lookup_columns(T0[t].table_id, cfg), A = NL + tz0[t].naux;
             ctl_dev_owner own;
-            own.upload(w, tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), false, W);
-            const gl_t* d_trace = d_traces[t] ? d_traces[t] : tables[t].trace;
-            zkm_scratch again(w, (!d_traces[t] && host[t]) ? W * n * sizeof(gl_t) : 8);
-            if (!d_traces[t] && host[t]) {   // (over the keep budget: second upload)
+            own.upload(w, T0[t].ctl, gzs[j].data(), tz0[t].ids.data(), tz0[t].zs.size(), false, W, G);
+            const zkm_table_input& a0 = io[g.segs[0]].tables[t];
+            const gl_t* d_trace = g.d_traces ? g.d_traces : a0.trace;
+            zkm_scratch again(w, (!g.d_traces && g.host) ? W * n * sizeof(gl_t) : 8);
+            if (!g.d_traces && g.host) {   // (one segment, over the keep budget: second upload)
                 gl_t* d = again.as<gl_t>();
-                if (tables[t].columns)
-                    for (size_t i = 0; i < W; i++) ZKM_HIP_CHECK(hipMemcpyAsync(d + i * n, tables[t].columns[i], n * sizeof(gl_t), hipMemcpyDefault, w->stream));
+                if (a0.columns)
+                    for (size_t i = 0; i < W; i++) ZKM_HIP_CHECK(hipMemcpyAsync(d + i * n, a0.columns[i], n * sizeof(gl_t), hipMemcpyDefault, w->stream));
                 else
-                    ZKM_HIP_CHECK(hipMemcpyAsync(d, tables[t].trace, W * n * sizeof(gl_t), hipMemcpyHostToDevice, w->stream));
+                    ZKM_HIP_CHECK(hipMemcpyAsync(d, a0.trace, W * n * sizeof(gl_t), hipMemcpyHostToDevice, w->stream));
                 zkm_launch_canon(w, d, W * n);   // (as zkm_batch_build does for the copies it keeps)
                 d_trace = d;
             }
-            zkm_scratch d_all(w, A * n * sizeof(gl_t));   // [lookup helper columns | CTL helper columns and Zs], prover.rs:497-508
+            zkm_scratch d_all(w, G * A * n * sizeof(gl_t));   // per segment [lookup helper columns | CTL helper columns and Zs], prover.rs:497-508
             {
                 zkm_prof_scope st(w, "stage/compute CTL data");
-                zkm_ctl_data_device(w, own, d_trace, tables[t].log_n, d_all.as<gl_t>() + NL * n);
+                zkm_ctl_data_device(w, own, d_trace, g.log_n, d_all.as<gl_t>() + NL * n, G, W * n, A * n);
             }
             if (NL) {
                 zkm_prof_scope st(w, "stage/compute lookup helper columns");
-                zkm_table_lookup_columns_device(w, tables[t].table_id, lookup_ch, cfg->num_challenges, d_trace, n, d_all.as<gl_t>());
+                zkm_table_lookup_columns_device(w, T0[t].table_id, glookup[j].data(), nch, d_trace, n, d_all.as<gl_t>(), G, W * n, A * n);
             }
             zkm_prof_scope st(w, "stage/compute auxiliary polynomials commitment");
             zkm_batch* ab = new zkm_batch();
-            ab->ctx = w; ab->ncols = A; ab->log_n = tables[t].log_n; ab->rate_bits = cfg->rate_bits; ab->cap_height = cfg->cap_height;
-            aux_commits[t] = ab;   // (owned from here on: freed with the others on every exit path)
+            ab->ctx = w; ab->ncols = A; ab->nseg = G; ab->log_n = g.log_n; ab->rate_bits = cfg->rate_bits; ab->cap_height = cfg->cap_height;
+            g.aux = ab;            // (owned from here on: freed with the others on every exit path)
             zkm_batch_build(ab, d_all.as<uint64_t>(), true);
             w->sync();             // d_all / `again` go back to the lane's allocator when this returns
+            // the device copy of the traces has served its purpose (commitment, CTL data, lookup columns): back to its owner's allocator
+            // NOW, not after the last table proof (nothing reads it any more and w's stream is drained)
+            if (g.d_traces) {
+                (g.d_owner ? g.d_owner : c)->release(g.d_traces);
+                g.d_traces = nullptr;
+            }
         };
-        auto prove_table = [&](size_t t) {   // "compute all proofs given commitments" :234-438: tables in order, one transcript
+        auto prove_group = [&](size_t j) {   // "compute all proofs given commitments" :234-438: tables in order, one transcript per segment
+            table_group& g = groups[j];
+            const size_t t = g.t;
             try {
-                if (!aux_commits[t]) throw std::runtime_error("No CTL? aux column count does not match the CTL description");  // prover.rs:509
-                zkm_challenger local = ch;
-                zkm_prove_single_table_aux(c, tables[t].table_id, cfg, tables[t].ncols, tables[t].log_n, commits[t], aux_commits[t], tz[t].naux,
-                                           tables[t].ctl, tz[t].zs.data(), tz[t].ids.data(), tz[t].zs.size(), lookup_ch, &local, proofs + offs[t]);
-                ch = local;
+                if (!g.aux) throw std::runtime_error("No CTL? aux column count does not match the CTL description");  // prover.rs:509
+                std::vector<zkm_challenger> local(g.segs.size());
+                std::vector<zkm_challenger*> chs(g.segs.size());
+                std::vector<uint64_t*> proofs(g.segs.size());
+                for (size_t k = 0; k < g.segs.size(); k++) {
+                    local[k] = ch[g.segs[k]];
+                    chs[k] = &local[k];
+                    proofs[k] = io[g.segs[k]].proofs + offs[g.segs[k]][t];
+                }
+                zkm_prove_single_table_aux(c, T0[t].table_id, cfg, T0[t].ncols, g.log_n, g.commit, g.aux, tz0[t].naux, T0[t].ctl, gzs[j].data(),
+                                           tz0[t].ids.data(), tz0[t].zs.size(), glookup[j].data(), chs, proofs);
+                for (size_t k = 0; k < g.segs.size(); k++) ch[g.segs[k]] = local[k];
             } catch (const std::exception& e) {
                 throw std::runtime_error("table " + std::to_string(t) + ": " + e.what());
             }
         };
+        // (groups are numbered table by table: job order is proof order)
         const size_t bg_lanes =
-            (big.empty() && c->aux_pipeline && ntables >= 3) ? std::min<size_t>(std::max<size_t>(1, c->commit_lanes), ntables - 1) - 1 : 0;
+            (big.empty() && c->aux_pipeline && njobs >= 3) ? std::min<size_t>(std::max<size_t>(1, c->commit_lanes), njobs - 1) - 1 : 0;
         if (bg_lanes == 0) {
             run_on_lanes(c, big, small, aux_cost, aux_job);
             drop_traces();         // the device copies of the traces have served their purpose (commitment, CTL data, lookup columns)
-            for (size_t t = 0; t < ntables; t++) prove_table(t);
+            for (size_t j = 0; j < njobs; j++) prove_group(j);
         } else {
             // A segment of short tables (no table fills the GPU on its own): the table proofs are ONE chain of latency-bound steps on
             // the context's stream, and the auxiliary commitment of a LATER table is not needed before that table's turn -- the lanes
@@ -772,7 +946,7 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
             // that each lane finds its blocks in its own allocator cache; the context builds table 0's and starts proving).  The
             // transcript is what it was: every cap is observed inside its table's proof, in table order.
             c->ensure_lanes(bg_lanes);
-            bg.ready.assign(ntables, 0);
+            bg.ready.assign(njobs, 0);
             bg.errs.assign(bg_lanes, nullptr);
             struct stop_and_join {     // (an exception on this thread unwinds what the lanes refer to: they are stopped and joined first)
                 background& b;
@@ -786,11 +960,11 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
                     zkm_ctx* w = c->lanes[k];
                     try {
                         ZKM_HIP_CHECK(hipSetDevice(c->device));
-                        for (size_t t = 1 + k; t < ntables; t += bg_lanes) {
+                        for (size_t j = 1 + k; j < njobs; j += bg_lanes) {
                             if (bg.failed.load()) break;
-                            aux_job(w, t);
+                            aux_job(w, j);
                             std::lock_guard<std::mutex> g(bg.mu);
-                            bg.ready[t] = 1;
+                            bg.ready[j] = 1;
                             bg.cv.notify_all();
                         }
                     } catch (...) {
@@ -798,36 +972,69 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
                         bg.failed.store(true);
                     }
                     std::lock_guard<std::mutex> g(bg.mu);      // (whatever happened: nobody waits for this lane any more)
-                    for (size_t t = 1 + k; t < ntables; t += bg_lanes) bg.ready[t] = 1;
+                    for (size_t j = 1 + k; j < njobs; j += bg_lanes) bg.ready[j] = 1;
                     bg.cv.notify_all();
                 });
             aux_job(c, 0);
-            for (size_t t = 0; t < ntables; t++) {
-                if (t) {
+            for (size_t j = 0; j < njobs; j++) {
+                if (j) {
                     zkm_prof_scope st(c, "stage/wait for auxiliary polynomials commitment");
                     std::unique_lock<std::mutex> g(bg.mu);
-                    bg.cv.wait(g, [&] { return bg.ready[t] != 0; });
+                    bg.cv.wait(g, [&] { return bg.ready[j] != 0; });
                 }
                 if (bg.failed.load()) break;
-                prove_table(t);
+                prove_group(j);
             }
             bg.join();
             for (auto& e : bg.errs)
                 if (e) std::rethrow_exception(e);
             drop_traces();
         }
-    } catch (const std::exception& e) {
-        bg.failed.store(true);
-        bg.join();
-        drop_all();
-        return fail(err, e.what());
     } catch (...) {
         bg.failed.store(true);
         bg.join();
         drop_all();
-        return fail(err, "zkm_prove_with_traces: unknown error");
+        throw;
     }
     drop_all();
+}
+
+extern "C" {
+
+int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_table_input* tables, size_t ntables,
+                          const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls, const uint64_t* pub,
+                          size_t npub, uint64_t* proofs, uint64_t* challenges, char** err) {
+    try {
+        if (!c || !cfg || (!tables && ntables)) throw std::runtime_error("zkm_prove_with_traces: null argument");
+        seg_io io{tables, pub, npub, proofs, challenges};
+        prove_segments_impl(c, cfg, 1, &io, ntables, ctls, sides, nctls);
+    } catch (const std::exception& e) {
+        return fail(err, e.what());
+    } catch (...) {
+        return fail(err, "zkm_prove_with_traces: unknown error");
+    }
+    return 0;
+}
+
+int zkm_prove_segments(zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* traces, const unsigned* const* log_n,
+                       const uint64_t* const* pub, const size_t* npub, uint64_t* const* proofs, uint64_t* const* challenges, char** err) {
+    try {
+        if (!c || !cfg || !traces || !log_n || !proofs || !challenges) throw std::runtime_error("zkm_prove_segments: null argument");
+        std::vector<std::vector<zkm_table_input>> tables(nseg, std::vector<zkm_table_input>(12));
+        std::vector<seg_io> io(nseg);
+        for (size_t s = 0; s < nseg; s++) {
+            if (!traces[s] || !log_n[s] || !proofs[s] || !challenges[s]) throw std::runtime_error("zkm_prove_segments: null segment");
+            for (int t = 0; t < 12; t++)
+                tables[s][t] = zkm_table_input{AS_TABLE_IDS[t], traces[s][t], AS_TABLE_WIDTH[t], log_n[s][t], &AS_CTL_TABLES[t], nullptr};
+            io[s] = seg_io{tables[s].data(), pub ? pub[s] : nullptr, npub ? npub[s] : 0, proofs[s], challenges[s]};
+            if (io[s].npub && !io[s].pub) throw std::runtime_error("zkm_prove_segments: null public values");
+        }
+        prove_segments_impl(c, cfg, nseg, io.data(), 12, AS_CTLS, AS_SIDES, AS_NCTLS);
+    } catch (const std::exception& e) {
+        return fail(err, e.what());
+    } catch (...) {
+        return fail(err, "zkm_prove_segments: unknown error");
+    }
     return 0;
 }
 

@@ -59,7 +59,8 @@ struct ctl_dev_owner {
     ctl_dev d{};
     size_t naux = 0;
     // lookup_mode: logUp lookups keep a helper column even for a single looking column (lookup.rs:34-38)
+    // nseg > 1: zs = nseg lists of nzs entries (the same structure, each segment's own challenges); kernels index list blockIdx.z
     void upload(zkm_ctx* ctx, const zkm_ctl_table* t, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs, bool lookup_mode = false,
-                size_t trace_ncols = 0);  // trace_ncols != 0: every term_col must be < trace_ncols
+                size_t trace_ncols = 0, size_t nseg = 1);  // trace_ncols != 0: every term_col must be < trace_ncols
     ~ctl_dev_owner();
 };

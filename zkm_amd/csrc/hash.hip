@@ -49,10 +49,14 @@ void zkm_launch_poseidon_permute(zkm_ctx* c, gl_t* states, size_t k) {
 }
 
 // ------------------------------------------------------------------ Merkle leaves (column-major rows)
+// (every leaf / tree kernel: blockIdx.z = segment of a stacked batch, zkm_internal.h -- its matrix starts lde_seg words, its digest
+// block dig_seg words after the previous segment's)
 __global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ lde, size_t nrows, size_t ncols,
-                                                       size_t col_stride, gl_t* __restrict__ digests) {
+                                                       size_t col_stride, gl_t* __restrict__ digests, size_t lde_seg, size_t dig_seg) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nrows) return;
+    lde += (size_t)blockIdx.z * lde_seg;
+    digests += (size_t)blockIdx.z * dig_seg;
     uint64_t s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
@@ -84,21 +88,30 @@ __global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ 
     *reinterpret_cast<ulonglong2*>(d + 2) = make_ulonglong2(s[2], s[3]);
 }
 
-__global__ void k_merkle_leaves_quad(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests);
-__global__ void k_merkle_leaves_wide(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests);
+__global__ void k_merkle_leaves_quad(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests,
+                                     size_t lde_seg, size_t dig_seg);
+__global__ void k_merkle_leaves_wide(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests,
+                                     size_t lde_seg, size_t dig_seg);
 
-void zkm_launch_merkle_leaves(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests) {
+void zkm_launch_merkle_leaves(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests, size_t nseg,
+                              size_t lde_seg, size_t dig_seg) {
     // rows of <= 4 elements are copied, not hashed (hash_or_noop): profile them under their own name
     zkm_prof_scope ps(c, ncols <= 4 ? "merkle_leaves_copy" : "merkle_leaves");
-    if (ncols > 4 && nrows <= c->wide_max_hashes)
+    if (nseg == 0 || nseg > 65535) throw std::runtime_error("merkle_leaves: bad segment count");
+    const size_t hashes = nrows * nseg;    // the launch's hashes decide the form of the permutation: the segments of a stacked batch fill the machine together
+    const unsigned z = (unsigned)nseg;
+    if (ncols > 4 && hashes <= c->wide_max_hashes)
         // the shortest matrices: 16 lanes per leaf, the lowest latency per absorb step
-        hipLaunchKernelGGL(k_merkle_leaves_wide, dim3((nrows * 16 + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
-    else if (ncols > 4 && nrows <= c->quad_max_hashes)
+        hipLaunchKernelGGL(k_merkle_leaves_wide, dim3((nrows * 16 + 255) / 256, 1, z), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests,
+                           lde_seg, dig_seg);
+    else if (ncols > 4 && hashes <= c->quad_max_hashes)
         // short, wide matrices (Keccak: 2431 columns x a few thousand rows): one lane per leaf leaves the machine empty and pays one
         // permutation's full latency per 8 columns; four lanes per leaf cut that latency to a third and fill 4x the lanes
-        hipLaunchKernelGGL(k_merkle_leaves_quad, dim3((nrows * 4 + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
+        hipLaunchKernelGGL(k_merkle_leaves_quad, dim3((nrows * 4 + 255) / 256, 1, z), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests,
+                           lde_seg, dig_seg);
     else
-        hipLaunchKernelGGL(k_merkle_leaves, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests);
+        hipLaunchKernelGGL(k_merkle_leaves, dim3((nrows + 255) / 256, 1, z), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests, lde_seg,
+                           dig_seg);
     ZKM_HIP_CHECK(hipGetLastError());
 }
 
@@ -153,9 +166,10 @@ void zkm_launch_merkle_leaves_chunk(zkm_ctx* c, const gl_t* lde, size_t nrows, s
 
 // leaves of a FRI layer: leaf k = arity consecutive F2 values (bit-reversed order), flattened c0,c1,c0,c1..
 __global__ __launch_bounds__(256) void k_merkle_leaves_ext(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1,
-                                                           size_t nleaves, unsigned arity, gl_t* __restrict__ digests) {
+                                                           size_t nleaves, unsigned arity, gl_t* __restrict__ digests, size_t val_seg, size_t dig_seg) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nleaves) return;
+    c0 += (size_t)blockIdx.z * val_seg; c1 += (size_t)blockIdx.z * val_seg; digests += (size_t)blockIdx.z * dig_seg;
     uint64_t s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
@@ -185,6 +199,7 @@ struct merkle_fused_args {
     const gl_t* children;   // level l: 2 * nparents digests
     gl_t* parents[3];       // levels l + 1 .. l + 3
     uint32_t levels;        // 1 .. 3
+    size_t dig_seg;         // blockIdx.z-th tree: every pointer + blockIdx.z * dig_seg
 };
 
 __global__ __launch_bounds__(256) void k_merkle_fused(merkle_fused_args p) {
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(256) void k_merkle_fused(merkle_fused_args p) {
     const unsigned tid = threadIdx.x;
     uint64_t s[12];
     {
-        const ulonglong2* ch = reinterpret_cast<const ulonglong2*>(p.children + 8 * ((size_t)blockIdx.x * 256 + tid));
+        const ulonglong2* ch = reinterpret_cast<const ulonglong2*>(p.children + (size_t)blockIdx.z * p.dig_seg + 8 * ((size_t)blockIdx.x * 256 + tid));
         ulonglong2 a = ch[0], b = ch[1], cc = ch[2], d = ch[3];
         s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = cc.x; s[5] = cc.y; s[6] = d.x; s[7] = d.y;
     }
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(256) void k_merkle_fused(merkle_fused_args p) {
 #pragma unroll
         for (int w = 8; w < 12; w++) s[w] = 0;
         poseidon_permute_out(s, POSEIDON_OUT_DIGEST);
-        uint64_t* o = p.parents[lvl] + 4 * ((size_t)blockIdx.x * width + tid);
+        uint64_t* o = p.parents[lvl] + (size_t)blockIdx.z * p.dig_seg + 4 * ((size_t)blockIdx.x * width + tid);
         *reinterpret_cast<ulonglong2*>(o) = make_ulonglong2(s[0], s[1]);
         *reinterpret_cast<ulonglong2*>(o + 2) = make_ulonglong2(s[2], s[3]);
         if (lvl + 1 < p.levels) {
@@ -232,6 +247,7 @@ struct merkle_fused_wide_args {
     const gl_t* children;   // level l: nsub * 2^J digests
     gl_t* parents[6];       // levels l + 1 .. l + J
     uint32_t J;             // levels in this launch (1 .. 6)
+    size_t dig_seg;
 };
 
 __global__ __launch_bounds__(256) void k_merkle_fused_wide(merkle_fused_wide_args p) {
@@ -239,8 +255,9 @@ __global__ __launch_bounds__(256) void k_merkle_fused_wide(merkle_fused_wide_arg
     __shared__ uint64_t sh[2][64 * 4];                    // digests of the current level of this subtree (AoS, as in HBM)
     const unsigned tid = threadIdx.x, lane = tid & 63, idx = lane & 15, slot = tid >> 4;
     const unsigned C = 1u << p.J;
+    const size_t seg_off = (size_t)blockIdx.z * p.dig_seg;
     {
-        const gl_t* src = p.children + (size_t)blockIdx.x * C * 4;
+        const gl_t* src = p.children + seg_off + (size_t)blockIdx.x * C * 4;
         for (unsigned w = tid; w < C * 4; w += 256) sh[0][w] = src[w];
     }
     __syncthreads();
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(256) void k_merkle_fused_wide(merkle_fused_wide_arg
         const unsigned np = C >> (lvl + 1);               // parents of this level in the subtree
         const uint64_t* in = sh[lvl & 1];
         uint64_t* out = sh[(lvl + 1) & 1];
-        gl_t* g = p.parents[lvl] + (size_t)blockIdx.x * np * 4;
+        gl_t* g = p.parents[lvl] + seg_off + (size_t)blockIdx.x * np * 4;
         if ((slot & ~3u) >= np) return;                  // this wave has no node here or above: leave (the barrier only counts survivors)
         for (unsigned h0 = 0; h0 < np; h0 += 16) {
             // (a wave holds four slots; one with no live slot in this round skips it -- uniform over the wave)
@@ -270,8 +287,10 @@ __global__ __launch_bounds__(256) void k_merkle_fused_wide(merkle_fused_wide_arg
 // their leaf (overwrite-mode absorb: a ragged tail overwrites only the words that exist), all 12 lanes permute.  Bit-exact with
 // k_merkle_leaves.  Used when the matrix has at most zkm_ctx::wide_max_hashes rows.
 __global__ __launch_bounds__(256) void k_merkle_leaves_wide(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride,
-                                                            gl_t* __restrict__ digests) {
+                                                            gl_t* __restrict__ digests, size_t lde_seg, size_t dig_seg) {
     ZKM_RAISE_PRIO();
+    lde += (size_t)blockIdx.z * lde_seg;
+    digests += (size_t)blockIdx.z * dig_seg;
     const unsigned lane = threadIdx.x & 63, idx = lane & 15;
     const size_t leaf = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const bool live = leaf < nrows;  // uniform over the 16-lane row; every lane of the wave takes part in the shuffles
@@ -291,8 +310,9 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_wide(const gl_t* __restri
 
 // FRI layer leaves, one hash per 16-lane row (small layers): word m of leaf k is component m & 1 of value k * arity + (m >> 1).
 __global__ __launch_bounds__(256) void k_merkle_leaves_ext_wide(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nleaves,
-                                                                unsigned arity, gl_t* __restrict__ digests) {
+                                                                unsigned arity, gl_t* __restrict__ digests, size_t val_seg, size_t dig_seg) {
     ZKM_RAISE_PRIO();
+    c0 += (size_t)blockIdx.z * val_seg; c1 += (size_t)blockIdx.z * val_seg; digests += (size_t)blockIdx.z * dig_seg;
     const unsigned lane = threadIdx.x & 63, idx = lane & 15;
     const size_t k = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const bool live = k < nleaves;
@@ -312,6 +332,7 @@ struct merkle_fused_quad_args {
     const gl_t* children;   // level l: nsub * 2^J digests
     gl_t* parents[7];       // levels l + 1 .. l + J
     uint32_t J;             // levels in this launch (1 .. 7)
+    size_t dig_seg;
 };
 
 __global__ __launch_bounds__(256) void k_merkle_fused_quad(merkle_fused_quad_args p) {
@@ -322,8 +343,9 @@ __global__ __launch_bounds__(256) void k_merkle_fused_quad(merkle_fused_quad_arg
     quad_tab_load(qtab);
     const poseidon_quad Q(tid, qtab);
     const unsigned C = 1u << p.J;
+    const size_t seg_off = (size_t)blockIdx.z * p.dig_seg;
     {
-        const gl_t* src = p.children + (size_t)blockIdx.x * C * 4;
+        const gl_t* src = p.children + seg_off + (size_t)blockIdx.x * C * 4;
         for (unsigned w = tid; w < C * 4; w += 256) sh[0][w] = src[w];
     }
     __syncthreads();
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(256) void k_merkle_fused_quad(merkle_fused_quad_arg
         const unsigned np = C >> (lvl + 1);               // parents of this level in the subtree
         const uint64_t* in = sh[lvl & 1];
         uint64_t* out = sh[(lvl + 1) & 1];
-        gl_t* g = p.parents[lvl] + (size_t)blockIdx.x * np * 4;
+        gl_t* g = p.parents[lvl] + seg_off + (size_t)blockIdx.x * np * 4;
         if (wave_slot0 >= np) return;                     // this wave has no node here or above: leave (the barrier only counts survivors)
         for (unsigned h0 = 0; h0 < np; h0 += 64) {
             if (h0 + wave_slot0 >= np) continue;          // (a wave holds sixteen slots; uniform over the wave)
@@ -352,8 +374,10 @@ __global__ __launch_bounds__(256) void k_merkle_fused_quad(merkle_fused_quad_arg
 // (overwrite-mode absorb: a ragged tail overwrites only the words that exist).  Bit-exact with k_merkle_leaves.  Used when the matrix
 // has at most zkm_ctx::quad_max_hashes rows.
 __global__ __launch_bounds__(256) void k_merkle_leaves_quad(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride,
-                                                            gl_t* __restrict__ digests) {
+                                                            gl_t* __restrict__ digests, size_t lde_seg, size_t dig_seg) {
     ZKM_RAISE_PRIO();
+    lde += (size_t)blockIdx.z * lde_seg;
+    digests += (size_t)blockIdx.z * dig_seg;
     const unsigned q = threadIdx.x & 3;
     const size_t leaf = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const bool live = leaf < nrows;  // uniform over the quad; every lane of the wave takes part in the DPP moves
@@ -375,8 +399,9 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_quad(const gl_t* __restri
 
 // FRI layer leaves, one hash per quad (small layers): word m of leaf k is component m & 1 of value k * arity + (m >> 1).
 __global__ __launch_bounds__(256) void k_merkle_leaves_ext_quad(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nleaves,
-                                                                unsigned arity, gl_t* __restrict__ digests) {
+                                                                unsigned arity, gl_t* __restrict__ digests, size_t val_seg, size_t dig_seg) {
     ZKM_RAISE_PRIO();
+    c0 += (size_t)blockIdx.z * val_seg; c1 += (size_t)blockIdx.z * val_seg; digests += (size_t)blockIdx.z * dig_seg;
     const unsigned q = threadIdx.x & 3;
     const size_t k = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const bool live = k < nleaves;
@@ -395,15 +420,22 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_ext_quad(const gl_t* __re
     if (live) digests[4 * k + q] = s[0];
 }
 
-void zkm_launch_merkle_leaves_ext(zkm_ctx* c, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests) {
+void zkm_launch_merkle_leaves_ext(zkm_ctx* c, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests, size_t nseg,
+                                  size_t val_seg, size_t dig_seg) {
     if (arity % 4 || 2 * arity <= 4) throw std::runtime_error("merkle_leaves_ext: unsupported arity");
+    if (nseg == 0 || nseg > 65535) throw std::runtime_error("merkle_leaves_ext: bad segment count");
     zkm_prof_scope ps(c, "merkle_leaves_ext");
-    if (nleaves <= c->wide_max_hashes)    // the smallest layers: one hash per 16-lane row
-        hipLaunchKernelGGL(k_merkle_leaves_ext_wide, dim3((nleaves * 16 + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
-    else if (nleaves <= c->quad_max_hashes)   // small layers: one hash per quad of lanes
-        hipLaunchKernelGGL(k_merkle_leaves_ext_quad, dim3((nleaves * 4 + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
+    const size_t hashes = nleaves * nseg;
+    const unsigned z = (unsigned)nseg;
+    if (hashes <= c->wide_max_hashes)    // the smallest layers: one hash per 16-lane row
+        hipLaunchKernelGGL(k_merkle_leaves_ext_wide, dim3((nleaves * 16 + 255) / 256, 1, z), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests,
+                           val_seg, dig_seg);
+    else if (hashes <= c->quad_max_hashes)   // small layers: one hash per quad of lanes
+        hipLaunchKernelGGL(k_merkle_leaves_ext_quad, dim3((nleaves * 4 + 255) / 256, 1, z), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests,
+                           val_seg, dig_seg);
     else
-        hipLaunchKernelGGL(k_merkle_leaves_ext, dim3((nleaves + 255) / 256), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests);
+        hipLaunchKernelGGL(k_merkle_leaves_ext, dim3((nleaves + 255) / 256, 1, z), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests, val_seg,
+                           dig_seg);
     ZKM_HIP_CHECK(hipGetLastError());
 }
 
@@ -417,10 +449,11 @@ struct merkle_tail_args {
     const gl_t* children;   // level 0: gridDim.x * 2^J digests
     gl_t* parents[11];      // levels 1 .. J
     uint32_t J, wide_np_max;
-    uint64_t* host_cap;     // pinned: gridDim.x digests
+    uint64_t* host_cap;     // pinned: gridDim.z x gridDim.x digests
     uint64_t* flag;
     uint64_t seq;
     unsigned* counter;      // device word, zero between launches
+    size_t dig_seg;         // blockIdx.z-th tree
 };
 __global__ __launch_bounds__(256) void k_merkle_tail(merkle_tail_args p) {
     ZKM_RAISE_PRIO();
@@ -428,8 +461,10 @@ __global__ __launch_bounds__(256) void k_merkle_tail(merkle_tail_args p) {
     const unsigned tid = threadIdx.x, lane = tid & 63, C = 1u << p.J;
     uint64_t* const buf0 = tail_lds;             // C digests
     uint64_t* const buf1 = tail_lds + 4 * C;     // C / 2 digests
+    const size_t seg_off = (size_t)blockIdx.z * p.dig_seg;
+    uint64_t* const host_cap = p.host_cap + 4 * ((size_t)blockIdx.z * gridDim.x + blockIdx.x);
     {
-        const gl_t* src = p.children + (size_t)blockIdx.x * C * 4;
+        const gl_t* src = p.children + seg_off + (size_t)blockIdx.x * C * 4;
         for (unsigned w = tid; w < C * 4; w += blockDim.x) buf0[w] = src[w];
     }
     __syncthreads();
@@ -440,7 +475,7 @@ __global__ __launch_bounds__(256) void k_merkle_tail(merkle_tail_args p) {
         const unsigned np = C >> (lvl + 1);
         const uint64_t* in = (lvl & 1) ? buf1 : buf0;
         uint64_t* out = (lvl & 1) ? buf0 : buf1;
-        gl_t* g = p.parents[lvl] + (size_t)blockIdx.x * np * 4;
+        gl_t* g = p.parents[lvl] + seg_off + (size_t)blockIdx.x * np * 4;
         if (np > p.wide_np_max) {                                  // a quad of lanes per hash: blockDim / 4 hashes per round
             const unsigned q = tid & 3, slot = tid >> 2, wave_slot0 = (tid >> 6) << 4;
             for (unsigned h0 = 0; h0 < np; h0 += blockDim.x >> 2) {
@@ -452,7 +487,7 @@ __global__ __launch_bounds__(256) void k_merkle_tail(merkle_tail_args p) {
                 if (live) {
                     out[4 * h + q] = st[0];
                     g[4 * h + q] = st[0];
-                    if (np == 1) p.host_cap[4 * (size_t)blockIdx.x + q] = st[0];
+                    if (np == 1) host_cap[q] = st[0];
                 }
             }
         } else {                                                   // 16 lanes per hash: blockDim / 16 hashes per round
@@ -466,7 +501,7 @@ __global__ __launch_bounds__(256) void k_merkle_tail(merkle_tail_args p) {
                 if (live && idx < 4) {
                     out[4 * h + idx] = x;
                     g[4 * h + idx] = x;
-                    if (np == 1) p.host_cap[4 * (size_t)blockIdx.x + idx] = x;
+                    if (np == 1) host_cap[idx] = x;
                 }
             }
         }
@@ -477,7 +512,7 @@ __global__ __launch_bounds__(256) void k_merkle_tail(merkle_tail_args p) {
     __syncthreads();
     if (tid == 0) {
         const unsigned ticket = atomicAdd(p.counter, 1u);
-        if (ticket == gridDim.x - 1) {
+        if (ticket == gridDim.x * gridDim.z - 1) {
             *p.counter = 0;
             __threadfence_system();
             __hip_atomic_store(p.flag, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -487,7 +522,7 @@ __global__ __launch_bounds__(256) void k_merkle_tail(merkle_tail_args p) {
 // true: the levels above the leaves were built and the cap is in cap_out (host); false: not a tree this kernel takes
 // (l0: the level the kernel starts from -- its "leaves" are the 2^(log_leaves - l0) nodes of level l0)
 bool zkm_merkle_tail(zkm_ctx* c, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height, uint64_t* cap_out,
-                     unsigned l0) {
+                     unsigned l0, size_t nseg, size_t dig_seg) {
     const unsigned J = log_leaves - l0 - cap_height;
     if (!c->tree_tail || J == 0 || J > 11 || cap_height > 6) return false;
     // (a first level the tuning gives to the one-lane form -- more parents than both latency thresholds -- stays with the level kernels)
@@ -502,9 +537,10 @@ bool zkm_merkle_tail(zkm_ctx* c, gl_t* digests, const std::vector<size_t>& level
     a.children = digests + level_off[l0];
     for (unsigned k = 0; k < J; k++) a.parents[k] = digests + level_off[l0 + 1 + k];
     a.J = J;
+    a.dig_seg = dig_seg;
     a.wide_np_max = c->wide_max_hashes ? 16 : 0;                      // 16 lanes per hash where a level is ONE round of them (16 slots per
                                                                       // 256 threads: 15.6 us against 24 us for a round of quads)
-    const size_t capw = (size_t)4 << cap_height;
+    const size_t capw = ((size_t)4 << cap_height) * nseg;
     const uint64_t seq = c->xfer_begin(capw * 8, &a.host_cap, &a.flag, &a.counter);
     a.seq = seq;
     const size_t C = (size_t)1 << J;
@@ -513,7 +549,7 @@ bool zkm_merkle_tail(zkm_ctx* c, gl_t* digests, const std::vector<size_t>& level
     if (threads < 64) threads = 64;
     {
         zkm_prof_scope ps(c, "merkle_compress");
-        hipLaunchKernelGGL(k_merkle_tail, dim3(1u << cap_height), dim3(threads), (C * 4 + C * 2) * sizeof(uint64_t), c->stream, a);
+        hipLaunchKernelGGL(k_merkle_tail, dim3(1u << cap_height, 1, (unsigned)nseg), dim3(threads), (C * 4 + C * 2) * sizeof(uint64_t), c->stream, a);
         ZKM_HIP_CHECK(hipGetLastError());
     }
     c->xfer_finish(seq, cap_out, capw * 8);
@@ -540,46 +576,63 @@ size_t zkm_merkle_layout(unsigned log_leaves, unsigned cap_height, std::vector<s
 // The four-lane form takes ~40 % of the latency of a permutation at 1.7x its issue slots (330 instead of 190 wave instructions per
 // hash), so it is kept to the levels where a launch is mostly latency.
 void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves,
-                            unsigned cap_height) {
+                            unsigned cap_height, size_t nseg, size_t dig_seg) {
     const unsigned top = log_leaves - cap_height;
+    const unsigned z = (unsigned)nseg;
     unsigned l = 0;                                        // level of the children of the next launch
     while (l < top) {
         zkm_prof_scope ps(c, "merkle_compress");
         const unsigned log_p1 = log_leaves - l - 1;       // log2(#parents) of the first level made
         const unsigned rem = top - l;
-        const size_t p1 = (size_t)1 << log_p1;
-        if (p1 > c->quad_max_hashes && p1 > c->wide_max_hashes && log_p1 >= 8) {   // (the one-lane kernel works on blocks of 256 parents)
+        const size_t p1 = (size_t)1 << log_p1, h1 = p1 * nseg;   // (h1: hashes of the launch's first level over all stacked trees)
+        if (h1 > c->quad_max_hashes && h1 > c->wide_max_hashes && log_p1 >= 8) {   // (the one-lane kernel works on blocks of 256 parents)
             merkle_fused_args a{};
+            a.dig_seg = dig_seg;
             a.children = digests + level_off[l];
             a.levels = rem < 3 ? rem : 3;
             for (unsigned k = 0; k < a.levels; k++) a.parents[k] = digests + level_off[l + 1 + k];
-            hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(((size_t)1 << log_p1) / 256)), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(((size_t)1 << log_p1) / 256), 1, z), dim3(256), 0, c->stream, a);
             l += a.levels;
-        } else if (p1 <= c->wide_max_hashes) {
+        } else if (h1 <= c->wide_max_hashes) {
             merkle_fused_wide_args a{};
+            a.dig_seg = dig_seg;
             a.children = digests + level_off[l];
             unsigned J = rem < 6 ? rem : 6;
             if (J > log_p1 + 1) J = log_p1 + 1;           // (a subtree cannot have more children than the level)
             a.J = J;
             for (unsigned k = 0; k < J; k++) a.parents[k] = digests + level_off[l + 1 + k];
-            hipLaunchKernelGGL(k_merkle_fused_wide, dim3((unsigned)(((size_t)2 << log_p1) >> J)), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL(k_merkle_fused_wide, dim3((unsigned)(((size_t)2 << log_p1) >> J), 1, z), dim3(256), 0, c->stream, a);
             l += J;
         } else {
             merkle_fused_quad_args a{};
+            a.dig_seg = dig_seg;
             a.children = digests + level_off[l];
             unsigned J = 1;                                  // the levels that are still too large for the 16-lane form (default: 2^14 and 2^13 parents)
-            while (J < rem && J < 7 && J <= log_p1 && (p1 >> J) > c->wide_max_hashes) J++;
+            while (J < rem && J < 7 && J <= log_p1 && (h1 >> J) > c->wide_max_hashes) J++;
             a.J = J;
             for (unsigned k = 0; k < J; k++) a.parents[k] = digests + level_off[l + 1 + k];
-            hipLaunchKernelGGL(k_merkle_fused_quad, dim3((unsigned)(((size_t)2 << log_p1) >> J)), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL(k_merkle_fused_quad, dim3((unsigned)(((size_t)2 << log_p1) >> J), 1, z), dim3(256), 0, c->stream, a);
             l += J;
         }
         ZKM_HIP_CHECK(hipGetLastError());
     }
 }
 
+// caps of nseg stacked trees from their cap levels: one download (segment s: 4 << cap_height words at digests + s * dig_seg + level_off[top])
+static void download_caps(zkm_ctx* c, const gl_t* digests, size_t cap_off, unsigned cap_height, uint64_t* cap_out, size_t nseg, size_t dig_seg) {
+    const size_t capw = (size_t)4 << cap_height;
+    if (nseg == 1) {
+        c->download(cap_out, digests + cap_off, capw * sizeof(uint64_t));
+        return;
+    }
+    zkm_scratch tmp(c, nseg * capw * sizeof(gl_t));
+    ZKM_HIP_CHECK(hipMemcpy2DAsync(tmp.p, capw * sizeof(gl_t), digests + cap_off, dig_seg * sizeof(gl_t), capw * sizeof(gl_t), nseg,
+                                   hipMemcpyDeviceToDevice, c->stream));
+    c->download(cap_out, tmp.p, nseg * capw * sizeof(uint64_t));
+}
+
 void zkm_merkle_build_inner_cap(zkm_ctx* c, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height,
-                                uint64_t* cap_out) {
+                                uint64_t* cap_out, size_t nseg, size_t dig_seg) {
     // A workgroup of the tail kernel owns everything under one cap entry, and a chain of permutations is fastest with ONE wave per SIMD
     // (tools/ubench_perm_latency.hip: 24 us per quad permutation alone, 46 us with four waves per SIMD): 256 threads, 64 quads per
     // round.  From 2^11 nodes on a level is one round; with more to start from the first levels took several rounds on 16 CUs while
@@ -589,19 +642,19 @@ void zkm_merkle_build_inner_cap(zkm_ctx* c, gl_t* digests, const std::vector<siz
     if (c->tree_tail && log_leaves <= 24 && log_leaves >= cap_height + 1) {
         const unsigned l0 = log_leaves > TAIL_LOG ? log_leaves - TAIL_LOG : 0;
         if (log_leaves - l0 > cap_height) {
-            if (l0) zkm_merkle_build_inner(c, digests, level_off, log_leaves, log_leaves - l0);    // levels 1 .. l0 ("cap" = level l0)
-            if (zkm_merkle_tail(c, digests, level_off, log_leaves, cap_height, cap_out, l0)) return;
+            if (l0) zkm_merkle_build_inner(c, digests, level_off, log_leaves, log_leaves - l0, nseg, dig_seg);    // levels 1 .. l0 ("cap" = level l0)
+            if (zkm_merkle_tail(c, digests, level_off, log_leaves, cap_height, cap_out, l0, nseg, dig_seg)) return;
             // (refused: finish with the level kernels from where we are -- build_inner starts at level 0, so only without a head start)
             if (l0) {
                 std::vector<size_t> rest(level_off.begin() + l0, level_off.end());
-                zkm_merkle_build_inner(c, digests, rest, log_leaves - l0, cap_height);
-                c->download(cap_out, digests + level_off[log_leaves - cap_height], ((size_t)4 << cap_height) * sizeof(uint64_t));
+                zkm_merkle_build_inner(c, digests, rest, log_leaves - l0, cap_height, nseg, dig_seg);
+                download_caps(c, digests, level_off[log_leaves - cap_height], cap_height, cap_out, nseg, dig_seg);
                 return;
             }
         }
     }
-    zkm_merkle_build_inner(c, digests, level_off, log_leaves, cap_height);
-    c->download(cap_out, digests + level_off[log_leaves - cap_height], ((size_t)4 << cap_height) * sizeof(uint64_t));
+    zkm_merkle_build_inner(c, digests, level_off, log_leaves, cap_height, nseg, dig_seg);
+    download_caps(c, digests, level_off[log_leaves - cap_height], cap_height, cap_out, nseg, dig_seg);
 }
 
 // ------------------------------------------------------------------ Keccak-f[1600] batch (K15)

@@ -132,8 +132,10 @@ struct quotient_point {
     size_t j, jn;
     uint32_t i;
 };
-// the (<= 2) constraint challenges travel in the kernel-argument segment: no device copy, no upload per table
-struct alpha_args { gl_t v[2]; };
+// the (<= 2) constraint challenges of every segment of a stack travel in the kernel-argument segment (seg_gl2: v[2 s + a]): no device
+// copy, no upload per table.  Every quotient kernel takes its segment from blockIdx.z: the segment's columns start W N (trace) / A N
+// (auxiliary) words after the previous segment's, its outputs NA * size words.
+typedef seg_gl2 alpha_args;
 template <int NA>
 __device__ __forceinline__ quotient_point quotient_setup(size_t j, unsigned lde_bits, const gl_t* __restrict__ alphas, const gl_t* __restrict__ wpow,
                                                          gl_t gn, gl_t last, gl_t w_n, gl_t n_inv, consumer_t<NA>& k) {
@@ -170,18 +172,24 @@ __device__ __forceinline__ quotient_point quotient_setup(size_t j, unsigned lde_
 template <int TABLE, int NA>
 __global__ __launch_bounds__(256, (TABLE == ZKM_TABLE_CPU || TABLE == ZKM_TABLE_POSEIDON || TABLE == ZKM_TABLE_ARITHMETIC ? 4 : 1)) void k_quotient(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux,
                                                            unsigned log_n, unsigned lde_bits, lookup_dev lookups, alpha_args alphas_v,
+                                                           seg_gl2 lookup_ch,
                                                            const gl_t* __restrict__ wpow /* w_{4n}^t two-level table */,
-                                                           gl_t gn, gl_t last, gl_t w_n, gl_t n_inv, gl_t* __restrict__ out) {
-    const gl_t* const alphas = alphas_v.v;
+                                                           gl_t gn, gl_t last, gl_t w_n, gl_t n_inv, gl_t* __restrict__ out, size_t trace_seg,
+                                                           size_t aux_seg) {
+    const gl_t* const alphas = alphas_v.v + 2 * blockIdx.z;
     size_t N = (size_t)1 << lde_bits;
     size_t size = N >> 1;
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= size) return;
+    trace += (size_t)blockIdx.z * trace_seg;
+    aux += (size_t)blockIdx.z * aux_seg;
+    out += (size_t)blockIdx.z * NA * size;
     consumer_t<NA> k;
     const quotient_point q = quotient_setup<NA>(j, lde_bits, alphas, wpow, gn, last, w_n, n_inv, k);
     eval_table_constraints<TABLE, NA>(trace + j, N, (ptrdiff_t)q.jn - (ptrdiff_t)j, k);
     // auxiliary columns: the table's lookup helper columns first, then the CTL helper columns and Zs (prover.rs:495-508)
-    if constexpr (TABLE == ZKM_TABLE_MEMORY || TABLE == ZKM_TABLE_ARITHMETIC) eval_lookup_constraints<NA>(lookups, trace + j, N, aux, j, q.jn, k);
+    if constexpr (TABLE == ZKM_TABLE_MEMORY || TABLE == ZKM_TABLE_ARITHMETIC)
+        eval_lookup_constraints<NA>(lookups, lookup_ch.v + 2 * blockIdx.z, trace + j, N, aux, j, q.jn, k);
 #pragma unroll
     for (int a = 0; a < NA; a++) out[(size_t)a * size + q.i] = k.acc[a];
 }
@@ -190,12 +198,16 @@ __global__ __launch_bounds__(256, (TABLE == ZKM_TABLE_CPU || TABLE == ZKM_TABLE_
 template <int NA>
 __global__ __launch_bounds__(256) void k_quotient_keccak_parts(const gl_t* __restrict__ trace, unsigned lde_bits, alpha_args alphas_v,
                                                                const gl_t* __restrict__ wpow, gl_t gn, gl_t last, gl_t w_n, gl_t n_inv,
-                                                               const gl_t* __restrict__ apw, gl_t* __restrict__ tmp /* [part][NA][size] */) {
-    const gl_t* const alphas = alphas_v.v;
+                                                               const gl_t* __restrict__ apw /* [segment][NA][K + 1] */,
+                                                               gl_t* __restrict__ tmp /* [segment][part][NA][size] */, size_t trace_seg) {
+    const gl_t* const alphas = alphas_v.v + 2 * blockIdx.z;
     size_t N = (size_t)1 << lde_bits;
     size_t size = N >> 1;
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= size) return;
+    trace += (size_t)blockIdx.z * trace_seg;
+    apw += (size_t)blockIdx.z * NA * (KECCAK_NUM_CONSTRAINTS + 1);
+    tmp += (size_t)blockIdx.z * gridDim.y * NA * size;
     consumer_t<NA> k;
     const quotient_point q = quotient_setup<NA>(j, lde_bits, alphas, wpow, gn, last, w_n, n_inv, k);
     eval_keccak_constraints_part<NA>(trace + j, N, (ptrdiff_t)q.jn - (ptrdiff_t)j, k, (int)blockIdx.y, apw);
@@ -205,6 +217,8 @@ __global__ __launch_bounds__(256) void k_quotient_keccak_parts(const gl_t* __res
 __global__ __launch_bounds__(256) void k_sum_parts(const gl_t* __restrict__ tmp, unsigned nparts, size_t words, gl_t* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= words) return;
+    tmp += (size_t)blockIdx.z * nparts * words;
+    out += (size_t)blockIdx.z * words;
     gl_t acc = 0;
     for (unsigned p = 0; p < nparts; p++) acc = gl_add(acc, tmp[(size_t)p * words + i]);
     out[i] = acc;
@@ -213,12 +227,17 @@ __global__ __launch_bounds__(256) void k_sum_parts(const gl_t* __restrict__ tmp,
 template <int NA>
 __global__ __launch_bounds__(256) void k_quotient_ctl(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux, unsigned lde_bits, ctl_dev ctl,
                                                       uint32_t num_lookup_cols, alpha_args alphas_v, const gl_t* __restrict__ wpow, gl_t gn,
-                                                      gl_t zh_inv0, gl_t zh_inv1, gl_t last, gl_t w_n, gl_t n_inv, gl_t* __restrict__ out) {
-    const gl_t* const alphas = alphas_v.v;
+                                                      gl_t zh_inv0, gl_t zh_inv1, gl_t last, gl_t w_n, gl_t n_inv, gl_t* __restrict__ out,
+                                                      size_t trace_seg, size_t aux_seg) {
+    const gl_t* const alphas = alphas_v.v + 2 * blockIdx.z;
     size_t N = (size_t)1 << lde_bits;
     size_t size = N >> 1;
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= size) return;
+    trace += (size_t)blockIdx.z * trace_seg;
+    aux += (size_t)blockIdx.z * aux_seg;
+    out += (size_t)blockIdx.z * NA * size;
+    ctl.zs += (size_t)blockIdx.z * ctl.nzs;
     consumer_t<NA> k;
     const quotient_point q = quotient_setup<NA>(j, lde_bits, alphas, wpow, gn, last, w_n, n_inv, k);
 #pragma unroll
@@ -236,12 +255,16 @@ template <int NA>
 __global__ __launch_bounds__(256) void k_quotient_ctl_chunk(const gl_t* __restrict__ trace, const gl_t* __restrict__ aux, unsigned lde_bits, ctl_dev ctl,
                                                             const ctl_chunk* __restrict__ chunks, uint32_t num_lookup_cols, alpha_args alphas_v,
                                                             const gl_t* __restrict__ wpow, gl_t gn, gl_t last, gl_t w_n, gl_t n_inv,
-                                                            gl_t* __restrict__ tmp /* [chunk][NA][size] */) {
-    const gl_t* const alphas = alphas_v.v;
+                                                            gl_t* __restrict__ tmp /* [segment][chunk][NA][size] */, size_t trace_seg, size_t aux_seg) {
+    const gl_t* const alphas = alphas_v.v + 2 * blockIdx.z;
     size_t N = (size_t)1 << lde_bits;
     size_t size = N >> 1;
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= size) return;
+    trace += (size_t)blockIdx.z * trace_seg;
+    aux += (size_t)blockIdx.z * aux_seg;
+    tmp += (size_t)blockIdx.z * gridDim.y * NA * size;
+    ctl.zs += (size_t)blockIdx.z * ctl.nzs;
     const ctl_chunk ch = chunks[blockIdx.y];
     consumer_t<NA> k;
     const quotient_point q = quotient_setup<NA>(j, lde_bits, alphas, wpow, gn, last, w_n, n_inv, k);
@@ -254,9 +277,11 @@ __global__ __launch_bounds__(256) void k_quotient_ctl_chunk(const gl_t* __restri
 template <int NA>
 __global__ __launch_bounds__(256) void k_quotient_ctl_sum(const gl_t* __restrict__ tmp, uint32_t nchunks, uint32_t nconstraints, alpha_args alphas_v,
                                                           gl_t zh_inv0, gl_t zh_inv1, size_t size, gl_t* __restrict__ out) {
-    const gl_t* const alphas = alphas_v.v;
+    const gl_t* const alphas = alphas_v.v + 2 * blockIdx.z;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= size) return;
+    tmp += (size_t)blockIdx.z * nchunks * NA * size;
+    out += (size_t)blockIdx.z * NA * size;
     gl_t zi = (i & 1) ? zh_inv1 : zh_inv0;
 #pragma unroll
     for (int a = 0; a < NA; a++) {
@@ -266,11 +291,16 @@ __global__ __launch_bounds__(256) void k_quotient_ctl_sum(const gl_t* __restrict
     }
 }
 
-// quotient polys: d_out = nalphas x 2n natural-order coefficients (device)
+// quotient polys: d_out = nalphas x 2n natural-order coefficients (device) -- per segment of the stack (trace / aux: stacked batches of
+// the same nseg; alphas_host: nseg x nalphas; lookup_challenges: nseg x nalphas; own: a description with nseg lists of CtlZData)
 static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_batch* aux, const ctl_dev_owner& own,
                             const uint64_t* lookup_challenges, const gl_t* alphas_host, size_t nalphas, gl_t* d_out) {
     lookup_dev lookups{};
+    seg_gl2 lookup_ch{};
     uint32_t NL = 0;
+    const size_t nseg = trace->nseg;
+    if (aux->nseg != nseg || nseg == 0 || nseg > ZKM_MAX_SEG) throw std::runtime_error("zkm_quotient: batches of different stacks");
+    const unsigned z = (unsigned)nseg;
     {
         size_t nl = 0;
         const zkm_table_lookup* defs = zkm_table_lookups(table_id, &nl);
@@ -286,7 +316,8 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             off += defs[l].ncols;
             NL += ((defs[l].ncols + 1) / 2 + 1) * (uint32_t)nalphas;
         }
-        for (size_t i = 0; nl && i < nalphas; i++) lookups.challenges[i] = lookup_challenges[i];
+        for (size_t sg = 0; nl && sg < nseg; sg++)
+            for (size_t i = 0; i < nalphas; i++) lookup_ch.v[2 * sg + i] = lookup_challenges[sg * nalphas + i];
     }
     if (zkm_table_width(table_id) == 0 || trace->ncols != zkm_table_width(table_id))
         throw std::runtime_error("zkm_quotient: unknown table id, or the trace width does not match the table");
@@ -297,6 +328,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     const ctl_dev& ctl = own.d;
     unsigned log_n = trace->log_n, lde_bits = log_n + 2, log_q = log_n + 1;
     size_t size = (size_t)1 << log_q;
+    const size_t trace_seg = trace->lde_seg(), aux_seg = aux->lde_seg();
     gl_t w4 = gl_root_of_unity(lde_bits);
     const gl_t* wpow = c->pow_table(w4, lde_bits);
     gl_t gn = gl_exp_pow2(GL_GENERATOR, log_n);
@@ -304,33 +336,39 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     gl_t w_n = gl_root_of_unity(log_n), last = gl_inv(w_n);
     gl_t n_inv = gl_inv((gl_t)(((uint64_t)1 << log_n) % GL_P));
     alpha_args d_alphas{};
-    for (size_t a = 0; a < nalphas && a < 2; a++) d_alphas.v[a] = alphas_host[a];
-    gl_t* d_vals = (gl_t*)c->alloc(nalphas * size * sizeof(gl_t));
+    for (size_t sg = 0; sg < nseg; sg++)
+        for (size_t a = 0; a < nalphas && a < 2; a++) d_alphas.v[2 * sg + a] = alphas_host[sg * nalphas + a];
+    gl_t* d_vals = (gl_t*)c->alloc(nseg * nalphas * size * sizeof(gl_t));
     {
         static const char* const names[] = {"quotient_poseidon", "quotient_logic", "quotient_keccak_sponge", "quotient_keccak", "quotient_memory", "quotient_poseidon_sponge", "quotient_sha_extend", "quotient_sha_extend_sponge", "quotient_sha_compress",
                                             "quotient_sha_compress_sponge", "quotient_arithmetic", "quotient_cpu"};
         zkm_prof_scope ps(c, names[table_id]);
-        dim3 grid((size + 255) / 256), block(256);
+        dim3 grid((size + 255) / 256, 1, z), block(256);
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
-    hipLaunchKernelGGL((k_quotient<T, NA>), grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, lookups, d_alphas, wpow, gn, \
-                       last, w_n, n_inv, d_vals)
-        if (table_id == ZKM_TABLE_KECCAK && size <= c->keccak_parts_max_points) {
+    hipLaunchKernelGGL((k_quotient<T, NA>), grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, lookups, d_alphas, lookup_ch, wpow, gn, \
+                       last, w_n, n_inv, d_vals, trace_seg, aux_seg)
+        if (table_id == ZKM_TABLE_KECCAK && size * nseg <= c->keccak_parts_max_points) {
             // short table: 25 threads per point, then the sum of the parts (constraints_dev.h)
-            std::vector<gl_t> apw(nalphas * (KECCAK_NUM_CONSTRAINTS + 1));
-            for (size_t a = 0; a < nalphas; a++) {
-                gl_t p = 1;
-                for (size_t e = 0; e <= KECCAK_NUM_CONSTRAINTS; e++) { apw[a * (KECCAK_NUM_CONSTRAINTS + 1) + e] = p; p = gl_mul(p, gl_canon(alphas_host[a])); }
-            }
-            zkm_scratch d_apw(c, apw.size() * sizeof(gl_t)), d_tmp(c, (size_t)KECCAK_CONSTRAINT_PARTS * nalphas * size * sizeof(gl_t));
+            const size_t per = nalphas * (KECCAK_NUM_CONSTRAINTS + 1);
+            std::vector<gl_t> apw(nseg * per);
+            for (size_t sg = 0; sg < nseg; sg++)
+                for (size_t a = 0; a < nalphas; a++) {
+                    gl_t p = 1;
+                    for (size_t e = 0; e <= KECCAK_NUM_CONSTRAINTS; e++) {
+                        apw[sg * per + a * (KECCAK_NUM_CONSTRAINTS + 1) + e] = p;
+                        p = gl_mul(p, gl_canon(alphas_host[sg * nalphas + a]));
+                    }
+                }
+            zkm_scratch d_apw(c, apw.size() * sizeof(gl_t)), d_tmp(c, nseg * (size_t)KECCAK_CONSTRAINT_PARTS * nalphas * size * sizeof(gl_t));
             c->upload(d_apw.p, apw.data(), apw.size() * sizeof(gl_t));
-            dim3 gridp((unsigned)((size + 255) / 256), KECCAK_CONSTRAINT_PARTS);
+            dim3 gridp((unsigned)((size + 255) / 256), KECCAK_CONSTRAINT_PARTS, z);
             if (nalphas == 1)
                 hipLaunchKernelGGL((k_quotient_keccak_parts<1>), gridp, block, 0, c->stream, trace->lde, lde_bits, d_alphas, wpow, gn, last, w_n, n_inv,
-                                   d_apw.as<gl_t>(), d_tmp.as<gl_t>());
+                                   d_apw.as<gl_t>(), d_tmp.as<gl_t>(), trace_seg);
             else
                 hipLaunchKernelGGL((k_quotient_keccak_parts<2>), gridp, block, 0, c->stream, trace->lde, lde_bits, d_alphas, wpow, gn, last, w_n, n_inv,
-                                   d_apw.as<gl_t>(), d_tmp.as<gl_t>());
-            hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((nalphas * size + 255) / 256)), block, 0, c->stream, d_tmp.as<gl_t>(),
+                                   d_apw.as<gl_t>(), d_tmp.as<gl_t>(), trace_seg);
+            hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((nalphas * size + 255) / 256), 1, z), block, 0, c->stream, d_tmp.as<gl_t>(),
                                (unsigned)KECCAK_CONSTRAINT_PARTS, nalphas * size, d_vals);
         } else
         switch (table_id * 2 + (int)nalphas - 1) {
@@ -364,11 +402,11 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     }
     {
         zkm_prof_scope ps(c, "quotient_ctl");
-        dim3 grid((size + 255) / 256), block(256);
+        dim3 grid((size + 255) / 256, 1, z), block(256);
         // chunk plan: at most CHUNK helper checks per chunk, the closing checks with the last chunk of their Z.  A thread's work is a
         // chain of column-combination evaluations whatever the table's height: on short tables (a launch cannot fill the GPU anyway)
         // one helper check per chunk -- four times the workgroups, a quarter of the chain (KeccakSponge at 2^8 rows: 340 us per launch)
-        const bool short_table = size <= ((size_t)1 << 15);
+        const bool short_table = size * nseg <= ((size_t)1 << 15);
         const uint32_t CHUNK = short_table ? 1 : 4;
         std::vector<ctl_chunk> plan;
         uint32_t K = 0, hstart = 0;
@@ -388,26 +426,26 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             hstart += own.h_zs[zi].num_helpers;
         }
         for (size_t i = 0; i < plan.size(); i++) plan[i].tail = K - kend[i];
-        const bool chunked = plan.size() >= (short_table ? 2u : 8u) && size <= ((size_t)1 << 18);
+        const bool chunked = plan.size() >= (short_table ? 2u : 8u) && size * nseg <= ((size_t)1 << 18);
         if (!chunked) {
             if (nalphas == 1)
                 hipLaunchKernelGGL((k_quotient_ctl<1>), grid, block, 0, c->stream, trace->lde, aux->lde, lde_bits, ctl, NL, d_alphas, wpow, gn, zh0, zh1,
-                                   last, w_n, n_inv, d_vals);
+                                   last, w_n, n_inv, d_vals, trace_seg, aux_seg);
             else
                 hipLaunchKernelGGL((k_quotient_ctl<2>), grid, block, 0, c->stream, trace->lde, aux->lde, lde_bits, ctl, NL, d_alphas, wpow, gn, zh0, zh1,
-                                   last, w_n, n_inv, d_vals);
+                                   last, w_n, n_inv, d_vals, trace_seg, aux_seg);
         } else {
             ctl_chunk* d_plan = (ctl_chunk*)c->alloc(plan.size() * sizeof(ctl_chunk));
-            gl_t* d_tmp = (gl_t*)c->alloc(plan.size() * nalphas * size * sizeof(gl_t));
+            gl_t* d_tmp = (gl_t*)c->alloc(nseg * plan.size() * nalphas * size * sizeof(gl_t));
             c->upload(d_plan, plan.data(), plan.size() * sizeof(ctl_chunk));
-            dim3 grid2((unsigned)((size + 255) / 256), (unsigned)plan.size());
+            dim3 grid2((unsigned)((size + 255) / 256), (unsigned)plan.size(), z);
             if (nalphas == 1) {
                 hipLaunchKernelGGL((k_quotient_ctl_chunk<1>), grid2, block, 0, c->stream, trace->lde, aux->lde, lde_bits, ctl, d_plan, NL, d_alphas, wpow,
-                                   gn, last, w_n, n_inv, d_tmp);
+                                   gn, last, w_n, n_inv, d_tmp, trace_seg, aux_seg);
                 hipLaunchKernelGGL((k_quotient_ctl_sum<1>), grid, block, 0, c->stream, d_tmp, (uint32_t)plan.size(), K, d_alphas, zh0, zh1, size, d_vals);
             } else {
                 hipLaunchKernelGGL((k_quotient_ctl_chunk<2>), grid2, block, 0, c->stream, trace->lde, aux->lde, lde_bits, ctl, d_plan, NL, d_alphas, wpow,
-                                   gn, last, w_n, n_inv, d_tmp);
+                                   gn, last, w_n, n_inv, d_tmp, trace_seg, aux_seg);
                 hipLaunchKernelGGL((k_quotient_ctl_sum<2>), grid, block, 0, c->stream, d_tmp, (uint32_t)plan.size(), K, d_alphas, zh0, zh1, size, d_vals);
             }
             ZKM_HIP_CHECK(hipGetLastError());
@@ -419,7 +457,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
         ZKM_HIP_CHECK(hipGetLastError());
     }
     // coset_ifft(g) of each challenge's evaluations (prover.rs:784-788)
-    zkm_ntt_natural(c, d_vals, d_out, nalphas, size, size, log_q, true, GL_GENERATOR);
+    zkm_ntt_natural(c, d_vals, d_out, nseg * nalphas, size, size, log_q, true, GL_GENERATOR);
     c->release(d_vals);  // stream-ordered reuse: no host sync needed
 }
 
@@ -434,9 +472,13 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
 #define OPEN_CPB 4
 // pw[.][k] = z^(exponent of position k of a column): the batch's coefficient layout (zkm_coeff_exponent) is a permutation of the BITS
 // of the position, so the exponent of position chunk * chunk_len + k is e(k) + e(chunk * chunk_len) and the table of one chunk serves all.
-__global__ __launch_bounds__(256) void k_open_powers(gl2_t z0, gl2_t z1, unsigned chunk_len, unsigned coeff_s1, gl_t* __restrict__ pw /* [4][chunk_len] */) {
+// (blockIdx.z = segment of a stack: its own two points, its own table)
+__global__ __launch_bounds__(256) void k_open_powers(seg_gl2 z0s, seg_gl2 z1s, unsigned chunk_len, unsigned coeff_s1,
+                                                     gl_t* __restrict__ pw /* [segment][4][chunk_len] */) {
     unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= chunk_len) return;
+    const gl2_t z0{z0s.v[2 * blockIdx.z], z0s.v[2 * blockIdx.z + 1]}, z1{z1s.v[2 * blockIdx.z], z1s.v[2 * blockIdx.z + 1]};
+    pw += (size_t)blockIdx.z * 4 * chunk_len;
     const uint64_t e = zkm_coeff_exponent(k, coeff_s1);
     gl2_t p0 = gl2_pow(z0, e), p1 = gl2_pow(z1, e);
     pw[k] = p0.c0; pw[chunk_len + k] = p0.c1; pw[2 * chunk_len + k] = p1.c0; pw[3 * chunk_len + k] = p1.c1;
@@ -458,10 +500,14 @@ struct lazy_sum {
 // workgroups -- tables of 2^16 / 2^17 rows: four times the waves for the same work)
 template <int CPB>
 __global__ __launch_bounds__(256) void k_open_partials(const gl_t* __restrict__ coeffs, unsigned log_n, size_t ncols,
-                                                       const gl_t* __restrict__ pw, gl_t* __restrict__ partial /* [col][chunk][5] */) {
+                                                       const gl_t* __restrict__ pw, gl_t* __restrict__ partial /* [col][chunk][5] */,
+                                                       size_t coeff_seg, size_t partial_seg) {
     __shared__ gl_t red[256 * 5];
     const unsigned chunk_log = log_n < OPEN_CHUNK_LOG ? log_n : OPEN_CHUNK_LOG;
     const size_t chunk_len = (size_t)1 << chunk_log, nchunks = (size_t)1 << (log_n - chunk_log);
+    coeffs += (size_t)blockIdx.z * coeff_seg;
+    pw += (size_t)blockIdx.z * 4 * chunk_len;
+    partial += (size_t)blockIdx.z * partial_seg;
     const size_t col0 = (size_t)blockIdx.y * CPB, chunk = blockIdx.x;
     const unsigned t = threadIdx.x;
     lazy_sum acc[CPB][5];
@@ -501,61 +547,69 @@ __global__ __launch_bounds__(256) void k_open_partials(const gl_t* __restrict__ 
 struct open_vals { gl2_t at_z0, at_z1; gl_t at_one; };
 
 // evaluate every polynomial of the batches (same height, same coefficient layout) at z0, z1 (F2) and 1: one power table, one launch
-// per batch, one download
-static std::vector<std::vector<open_vals>> eval_batches(zkm_ctx* c, const std::vector<const zkm_batch*>& bs, gl2_t z0, gl2_t z1) {
+// per batch, one download.  Stacked batches (nseg segments each): z0 / z1 hold one point per segment, out[s][batch][poly].
+static std::vector<std::vector<std::vector<open_vals>>> eval_batches(zkm_ctx* c, const std::vector<const zkm_batch*>& bs, const gl2_t* z0,
+                                                                     const gl2_t* z1) {
     const zkm_batch* b0 = bs.at(0);
+    const size_t nseg = b0->nseg;
     const unsigned log_n = b0->log_n, chunk_log = log_n < OPEN_CHUNK_LOG ? log_n : OPEN_CHUNK_LOG, chunk_len = 1u << chunk_log;
     const size_t nchunks = (size_t)1 << (log_n - chunk_log);
     size_t total_cols = 0;
     for (const zkm_batch* b : bs) {
-        if (b->log_n != log_n || b->coeff_s1 != b0->coeff_s1) throw std::runtime_error("internal: openings of batches with different shapes");
+        if (b->log_n != log_n || b->coeff_s1 != b0->coeff_s1 || b->nseg != nseg) throw std::runtime_error("internal: openings of batches with different shapes");
         total_cols += b->ncols;
     }
-    const size_t words = total_cols * nchunks * 5;
-    zkm_scratch d_part(c, words * sizeof(gl_t)), d_pw(c, (size_t)4 * chunk_len * sizeof(gl_t));
+    if (nseg == 0 || nseg > ZKM_MAX_SEG) throw std::runtime_error("internal: openings of a stack of unsupported size");
+    const unsigned z = (unsigned)nseg;
+    const size_t words_seg = total_cols * nchunks * 5, words = nseg * words_seg;
+    zkm_scratch d_part(c, words * sizeof(gl_t)), d_pw(c, nseg * 4 * chunk_len * sizeof(gl_t));
     {
         zkm_prof_scope ps(c, "open_partials");
-        hipLaunchKernelGGL(k_open_powers, dim3((chunk_len + 255) / 256), dim3(256), 0, c->stream, z0, z1, chunk_len, b0->coeff_s1, d_pw.as<gl_t>());
+        seg_gl2 z0s{}, z1s{};
+        for (size_t sg = 0; sg < nseg; sg++) { z0s.v[2 * sg] = z0[sg].c0; z0s.v[2 * sg + 1] = z0[sg].c1; z1s.v[2 * sg] = z1[sg].c0; z1s.v[2 * sg + 1] = z1[sg].c1; }
+        hipLaunchKernelGGL(k_open_powers, dim3((chunk_len + 255) / 256, 1, z), dim3(256), 0, c->stream, z0s, z1s, chunk_len, b0->coeff_s1, d_pw.as<gl_t>());
         size_t col0 = 0;
         for (const zkm_batch* b : bs) {
-            if (nchunks * ((b->ncols + OPEN_CPB - 1) / OPEN_CPB) < 1024)
-                hipLaunchKernelGGL(k_open_partials<1>, dim3(nchunks, b->ncols), dim3(256), 0, c->stream, b->coeffs, log_n, b->ncols, d_pw.as<gl_t>(),
-                                   d_part.as<gl_t>() + col0 * nchunks * 5);
+            if (nseg * nchunks * ((b->ncols + OPEN_CPB - 1) / OPEN_CPB) < 1024)
+                hipLaunchKernelGGL(k_open_partials<1>, dim3(nchunks, b->ncols, z), dim3(256), 0, c->stream, b->coeffs, log_n, b->ncols, d_pw.as<gl_t>(),
+                                   d_part.as<gl_t>() + col0 * nchunks * 5, b->coeff_seg(), words_seg);
             else
-                hipLaunchKernelGGL(k_open_partials<OPEN_CPB>, dim3(nchunks, (b->ncols + OPEN_CPB - 1) / OPEN_CPB), dim3(256), 0, c->stream, b->coeffs,
-                                   log_n, b->ncols, d_pw.as<gl_t>(), d_part.as<gl_t>() + col0 * nchunks * 5);
+                hipLaunchKernelGGL(k_open_partials<OPEN_CPB>, dim3(nchunks, (b->ncols + OPEN_CPB - 1) / OPEN_CPB, z), dim3(256), 0, c->stream, b->coeffs,
+                                   log_n, b->ncols, d_pw.as<gl_t>(), d_part.as<gl_t>() + col0 * nchunks * 5, b->coeff_seg(), words_seg);
             col0 += b->ncols;
         }
         ZKM_HIP_CHECK(hipGetLastError());
     }
     std::vector<gl_t> part(words);
     c->download(part.data(), d_part.p, words * sizeof(gl_t));
-    // chunk ch contributes z^(exponent of its first position) * partial (natural order: z^(ch * chunk_len), i.e. Horner over the chunks)
+    std::vector<std::vector<std::vector<open_vals>>> all(nseg);
     std::vector<gl2_t> f0(nchunks), f1(nchunks);
-    for (size_t ch = 0; ch < nchunks; ch++) {
-        const uint64_t e = zkm_coeff_exponent((uint32_t)(ch << chunk_log), b0->coeff_s1);
-        f0[ch] = gl2_pow(z0, e);
-        f1[ch] = gl2_pow(z1, e);
-    }
-    std::vector<std::vector<open_vals>> out;
-    size_t col0 = 0;
-    for (const zkm_batch* b : bs) {
-        std::vector<open_vals> o(b->ncols);
-        for (size_t col = 0; col < b->ncols; col++) {
-            gl2_t a0{0, 0}, a1{0, 0};
-            gl_t sum = 0;
-            for (size_t ch = 0; ch < nchunks; ch++) {
-                const gl_t* q = &part[((col0 + col) * nchunks + ch) * 5];
-                a0 = gl2_add(a0, gl2_mul(f0[ch], gl2_t{q[0], q[1]}));
-                a1 = gl2_add(a1, gl2_mul(f1[ch], gl2_t{q[2], q[3]}));
-                sum = gl_add(sum, q[4]);
-            }
-            o[col] = open_vals{a0, a1, sum};
+    for (size_t sg = 0; sg < nseg; sg++) {
+        // chunk ch contributes z^(exponent of its first position) * partial (natural order: z^(ch * chunk_len), i.e. Horner over the chunks)
+        for (size_t ch = 0; ch < nchunks; ch++) {
+            const uint64_t e = zkm_coeff_exponent((uint32_t)(ch << chunk_log), b0->coeff_s1);
+            f0[ch] = gl2_pow(z0[sg], e);
+            f1[ch] = gl2_pow(z1[sg], e);
         }
-        out.push_back(std::move(o));
-        col0 += b->ncols;
+        size_t col0 = 0;
+        for (const zkm_batch* b : bs) {
+            std::vector<open_vals> o(b->ncols);
+            for (size_t col = 0; col < b->ncols; col++) {
+                gl2_t a0{0, 0}, a1{0, 0};
+                gl_t sum = 0;
+                for (size_t ch = 0; ch < nchunks; ch++) {
+                    const gl_t* q = &part[sg * words_seg + ((col0 + col) * nchunks + ch) * 5];
+                    a0 = gl2_add(a0, gl2_mul(f0[ch], gl2_t{q[0], q[1]}));
+                    a1 = gl2_add(a1, gl2_mul(f1[ch], gl2_t{q[2], q[3]}));
+                    sum = gl_add(sum, q[4]);
+                }
+                o[col] = open_vals{a0, a1, sum};
+            }
+            all[sg].push_back(std::move(o));
+            col0 += b->ncols;
+        }
     }
-    return out;
+    return all;
 }
 
 // ------------------------------------------------------------------ K11: FRI batch combination
@@ -565,9 +619,13 @@ static std::vector<std::vector<open_vals>> eval_batches(zkm_ctx* c, const std::v
 __global__ __launch_bounds__(256) void k_fri_combine(const gl_t* __restrict__ tc, size_t W, const gl_t* __restrict__ ac, size_t A,
                                                      const gl_t* __restrict__ qc, size_t Q, size_t ctl_start,
                                                      const gl_t* __restrict__ apow /* [(W+A+Q)][2] */, size_t n,
-                                                     gl_t* __restrict__ comp /* [3][2][n] */) {
+                                                     gl_t* __restrict__ comp /* [3][2][n] */, size_t apow_seg) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // (blockIdx.z = segment of a stack: its coefficient columns follow the previous segment's, its own powers of its own alpha)
+    tc += (size_t)blockIdx.z * W * n; ac += (size_t)blockIdx.z * A * n; qc += (size_t)blockIdx.z * Q * n;
+    apow += (size_t)blockIdx.z * apow_seg;
+    comp += (size_t)blockIdx.z * 6 * n;
     gl_t a0 = 0, a1 = 0, z0 = 0, z1 = 0;
     size_t j = 0;
     for (size_t cidx = 0; cidx < W; cidx++, j++) {
@@ -605,9 +663,12 @@ __global__ __launch_bounds__(256) void k_fri_combine(const gl_t* __restrict__ tc
 __global__ __launch_bounds__(256) void k_fri_combine_slice(const gl_t* __restrict__ tc, size_t W, const gl_t* __restrict__ ac, size_t A,
                                                            const gl_t* __restrict__ qc, size_t Q, size_t ctl_start,
                                                            const gl_t* __restrict__ apow, size_t n, size_t per_slice,
-                                                           gl_t* __restrict__ part /* [slices][6][n] */) {
+                                                           gl_t* __restrict__ part /* [segment][slices][6][n] */, size_t apow_seg) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    tc += (size_t)blockIdx.z * W * n; ac += (size_t)blockIdx.z * A * n; qc += (size_t)blockIdx.z * Q * n;
+    apow += (size_t)blockIdx.z * apow_seg;
+    part += (size_t)blockIdx.z * gridDim.y * 6 * n;
     const size_t j0 = (size_t)blockIdx.y * per_slice, total = W + A + Q;
     const size_t j1 = j0 + per_slice < total ? j0 + per_slice : total;
     gl_t a0 = 0, a1 = 0, q0 = 0, q1 = 0, z0 = 0, z1 = 0;
@@ -633,6 +694,8 @@ __global__ __launch_bounds__(256) void k_fri_combine_slice(const gl_t* __restric
 __global__ __launch_bounds__(256) void k_fri_combine_sum(const gl_t* __restrict__ part, unsigned slices, size_t n, gl_t* __restrict__ comp) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    part += (size_t)blockIdx.z * slices * 6 * n;
+    comp += (size_t)blockIdx.z * 6 * n;
     gl_t t[6] = {0, 0, 0, 0, 0, 0};
     for (unsigned s = 0; s < slices; s++)
 #pragma unroll
@@ -662,9 +725,13 @@ struct seg_batches {
     uint32_t nb;
     const gl_t* a0[FRI_MAX_BATCHES];   // this level's arrays of every batch (level 0: the composite polynomials)
     const gl_t* a1[FRI_MAX_BATCHES];
-    gl2_t z[FRI_MAX_BATCHES];          // z_b^(FRI_SEG^level)
-    gl2_t w[FRI_MAX_BATCHES];          // weight of the batch in the final sum (bottom level)
+    // Stacked proofs (blockIdx.z = segment): every array of segment s starts a_seg words after segment s - 1's, and the points / weights
+    // are per segment: zw[(s * nb + b) * 2] = z_b^(FRI_SEG^level), [.. + 1] = weight of the batch in the final sum
+    size_t a_seg;
+    const gl2_t* zw;
 };
+__device__ __forceinline__ gl2_t seg_point(const seg_batches& p, unsigned b) { return p.zw[((size_t)blockIdx.z * p.nb + b) * 2]; }
+__device__ __forceinline__ gl2_t seg_weight(const seg_batches& p, unsigned b) { return p.zw[((size_t)blockIdx.z * p.nb + b) * 2 + 1]; }
 // A thread's segment is FRI_SEG consecutive words of each array, and the walk over it is a dependent chain: with one 8-byte load per
 // step the lanes of a wave sit 256 B apart and every step fetched a whole line from HBM for 8 bytes of it (config 4: 6.4 GB of traffic
 // for 0.27 GB of data, profiles/r04_e).  All three kernels therefore work on LDS TILES: the 64 segments of a 64-thread workgroup
@@ -684,11 +751,12 @@ __global__ __launch_bounds__(64) void k_seg_totals(seg_batches p, size_t m, gl_t
     __shared__ gl_t t0[64 * SEG_ROW], t1[64 * SEG_ROW];
     const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x, nseg = (m + FRI_SEG - 1) / FRI_SEG;
     const unsigned b = blockIdx.y;
-    seg_tile_load(t0, p.a0[b], (size_t)blockIdx.x * SEG_TILE, m);
-    seg_tile_load(t1, p.a1[b], (size_t)blockIdx.x * SEG_TILE, m);
+    seg_tile_load(t0, p.a0[b] + (size_t)blockIdx.z * p.a_seg, (size_t)blockIdx.x * SEG_TILE, m);
+    seg_tile_load(t1, p.a1[b] + (size_t)blockIdx.z * p.a_seg, (size_t)blockIdx.x * SEG_TILE, m);
     __syncthreads();
     if (s >= nseg) return;
-    const gl2_t z = p.z[b];
+    out += (size_t)blockIdx.z * 2 * gridDim.y * nseg;
+    const gl2_t z = seg_point(p, b);
     gl2_t acc{0, 0};
     const gl_t *r0 = t0 + threadIdx.x * SEG_ROW, *r1 = t1 + threadIdx.x * SEG_ROW;
     for (unsigned k = FRI_SEG; k-- > 0;) acc = gl2_add(gl2_mul(acc, z), gl2_t{r0[k], r1[k]});
@@ -701,11 +769,13 @@ __global__ __launch_bounds__(64) void k_seg_scan(seg_batches p, size_t m, const 
     __shared__ gl_t t0[64 * SEG_ROW], t1[64 * SEG_ROW];
     const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x, base = (size_t)blockIdx.x * SEG_TILE;
     const unsigned b = blockIdx.y;
-    seg_tile_load(t0, p.a0[b], base, m);
-    seg_tile_load(t1, p.a1[b], base, m);
+    seg_tile_load(t0, p.a0[b] + (size_t)blockIdx.z * p.a_seg, base, m);
+    seg_tile_load(t1, p.a1[b] + (size_t)blockIdx.z * p.a_seg, base, m);
     __syncthreads();
+    if (upper) upper += (size_t)blockIdx.z * 2 * gridDim.y * nupper;
+    out += (size_t)blockIdx.z * 2 * gridDim.y * m;
     {
-        const gl2_t z = p.z[b];
+        const gl2_t z = seg_point(p, b);
         gl2_t acc{0, 0};
         if (upper && s + 1 < nupper) acc = gl2_t{upper[(2 * b) * nupper + s + 1], upper[(2 * b + 1) * nupper + s + 1]};
         gl_t *r0 = t0 + threadIdx.x * SEG_ROW, *r1 = t1 + threadIdx.x * SEG_ROW;
@@ -733,12 +803,15 @@ __global__ __launch_bounds__(64) void k_seg_scan_final(seg_batches p, size_t m, 
     gl_t *const t0 = seg_lds, *const t1 = t0 + 64 * SEG_ROW, *const g0 = t1 + 64 * SEG_ROW, *const g1 = g0 + 64 * SEG_ROW;
     const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x, base = (size_t)blockIdx.x * SEG_TILE;
     gl_t *r0 = t0 + threadIdx.x * SEG_ROW, *r1 = t1 + threadIdx.x * SEG_ROW, *q0 = g0 + threadIdx.x * SEG_ROW, *q1 = g1 + threadIdx.x * SEG_ROW;
+    if (upper) upper += (size_t)blockIdx.z * 2 * p.nb * nupper;
+    f0 += (size_t)blockIdx.z * 2 * m;
+    f1 += (size_t)blockIdx.z * 2 * m;
     for (unsigned b = 0; b < p.nb; b++) {
         if (b) __syncthreads();                                // everyone is done with the previous batch's tile
-        seg_tile_load(t0, p.a0[b], base, m);
-        seg_tile_load(t1, p.a1[b], base, m);
+        seg_tile_load(t0, p.a0[b] + (size_t)blockIdx.z * p.a_seg, base, m);
+        seg_tile_load(t1, p.a1[b] + (size_t)blockIdx.z * p.a_seg, base, m);
         __syncthreads();
-        const gl2_t z = p.z[b], w = p.w[b];
+        const gl2_t z = seg_point(p, b), w = seg_weight(p, b);
         gl2_t acc{0, 0};
         if (upper && s + 1 < nupper) acc = gl2_t{upper[(2 * b) * nupper + s + 1], upper[(2 * b + 1) * nupper + s + 1]};
         for (unsigned k = FRI_SEG; k-- > 0;) {
@@ -764,17 +837,21 @@ __global__ __launch_bounds__(256) void k_seg_combine(seg_batches p, size_t m, co
                                                      gl_t* __restrict__ f1) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
+    suf += (size_t)blockIdx.z * 2 * p.nb * m;
+    f0 += (size_t)blockIdx.z * 2 * m;
+    f1 += (size_t)blockIdx.z * 2 * m;
     gl2_t f{0, 0};
     if (i + 1 < m)
-        for (unsigned b = 0; b < p.nb; b++) f = gl2_add(f, gl2_mul(gl2_t{suf[(2 * b) * m + i + 1], suf[(2 * b + 1) * m + i + 1]}, p.w[b]));
+        for (unsigned b = 0; b < p.nb; b++) f = gl2_add(f, gl2_mul(gl2_t{suf[(2 * b) * m + i + 1], suf[(2 * b + 1) * m + i + 1]}, seg_weight(p, b)));
     f0[i] = f.c0;
     f1[i] = f.c1;
 }
 
 struct fri_composite;
 // fin = sum over the batches (in order) of: fin * shift_b + (comp_b(X) - comp_b(z_b)) / (X - z_b), re-padded to n coefficients.
-// fin is written completely (no zero-fill needed).
-static void divide_accumulate_all(zkm_ctx* c, const std::vector<fri_composite>& comps, size_t n, gl_t* f0, gl_t* f1);
+// fin is written completely (no zero-fill needed).  Stacked: comps[s] = segment s's composites (pointers: segment 0's, the others'
+// comp_seg words further per segment), fin of segment s at f0 / f1 + s * 2 n.
+static void divide_accumulate_all(zkm_ctx* c, const std::vector<std::vector<fri_composite>>& comps, size_t comp_seg, size_t n, gl_t* f0, gl_t* f1);
 
 // ------------------------------------------------------------------ K13: FRI fold
 // c'_j = sum_{i < arity} beta^i c_{arity j + i}   (reduce_with_powers per chunk)
@@ -782,11 +859,16 @@ static void divide_accumulate_all(zkm_ctx* c, const std::vector<fri_composite>& 
 // and again (lanes 128 B apart, the lines evicted between steps: 850 MB of traffic for 76 MB of data in config 4, profiles/r04_e).  The
 // workgroup's 64 x arity coefficients therefore come in with lane-contiguous loads into an LDS tile (row stride arity + 1: the walk
 // over one's own row is bank-conflict free) and are read from there.
-#define FRI_FOLD_MAX_ARITY 16
+// (tile rows of arity + 1 words in dynamic LDS: any arity_bits the config check admits, 2 .. 6 -- ADVICE r04)
+// (blockIdx.z = segment of a stack: its own beta; its arrays [2][total] in, [2][nout] out follow the previous segment's)
 __global__ __launch_bounds__(64) void k_fri_fold(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nout, unsigned arity,
-                                                 gl2_t beta, gl_t* __restrict__ o0, gl_t* __restrict__ o1) {
-    __shared__ gl_t t0[64 * (FRI_FOLD_MAX_ARITY + 1)], t1[64 * (FRI_FOLD_MAX_ARITY + 1)];
+                                                 seg_gl2 betas, gl_t* __restrict__ o0, gl_t* __restrict__ o1) {
+    extern __shared__ __attribute__((aligned(16))) gl_t fold_lds[];   // two tiles of 64 rows of arity + 1 words
+    gl_t *const t0 = fold_lds, *const t1 = fold_lds + 64 * (arity + 1);
+    const gl2_t beta{betas.v[2 * blockIdx.z], betas.v[2 * blockIdx.z + 1]};
     const size_t j0 = (size_t)blockIdx.x * 64, total = nout * arity, base = j0 * arity;
+    c0 += (size_t)blockIdx.z * 2 * total; c1 += (size_t)blockIdx.z * 2 * total;
+    o0 += (size_t)blockIdx.z * 2 * nout; o1 += (size_t)blockIdx.z * 2 * nout;
     const unsigned tid = threadIdx.x, rs = arity + 1;
     for (unsigned e = tid; e < 64 * arity; e += 64) {
         const size_t k = base + e;
@@ -812,9 +894,19 @@ struct pow_state { uint64_t s[12]; };
 // The launch delivers its result ITSELF: the workgroup that finishes last (a ticket) writes `best` into pinned host memory, then the
 // sequence number the host polls for, and leaves `best` = all ones and the ticket counter = 0 for the next search -- no memset launch in
 // front, no download launch behind (two launches and their gaps per table proof).
-__global__ __launch_bounds__(256) void k_pow_search(pow_state st, unsigned pos, unsigned pow_bits, uint64_t base, uint64_t limit,
-                                                    unsigned long long* best, unsigned* counter, uint64_t* host_out, uint64_t* flag, uint64_t seq) {
+// Stacked searches (blockIdx.y = segment): sts[s] = segment s's transcript state (device array), pos.v[s] the word its candidate goes
+// to, best[s] / host_out[s] its result; a segment whose witness is already known (done.v[s] != 0: found by an earlier launch) is skipped.
+struct seg_u32 { uint32_t v[ZKM_MAX_SEG]; };
+__global__ __launch_bounds__(256) void k_pow_search(const pow_state* __restrict__ sts, seg_u32 pos_v, seg_u32 done, unsigned pow_bits, uint64_t base,
+                                                    uint64_t limit, unsigned long long* best, unsigned* counter, uint64_t* host_out, uint64_t* flag,
+                                                    uint64_t seq) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const unsigned pos = pos_v.v[blockIdx.y];
+    best += blockIdx.y;
+    if (done.v[blockIdx.y]) limit = 0;
+    pow_state st;
+#pragma unroll
+    for (int i = 0; i < 12; i++) st.s[i] = sts[blockIdx.y].s[i];
 #pragma unroll 1
     for (uint64_t w = base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < limit; w += stride) {
         if (w > __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
@@ -831,10 +923,13 @@ __global__ __launch_bounds__(256) void k_pow_search(pow_state st, unsigned pos, 
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned ticket = atomicAdd(counter, 1u);
-        if (ticket == gridDim.x - 1) {
+        if (ticket == gridDim.x * gridDim.y - 1) {
             __threadfence();
-            *host_out = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(best, ~0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            best -= blockIdx.y;
+            for (unsigned sg = 0; sg < gridDim.y; sg++) {
+                host_out[sg] = __hip_atomic_load(best + sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(best + sg, ~0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             *counter = 0;
             __threadfence_system();
             __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -855,34 +950,41 @@ struct gather_args {
     gather_layer l[8];
     uint32_t noracles, nlayers, arity_bits, lde_bits;
     uint64_t query_words;
+    // stacked proofs (blockIdx.y = segment): oracle k's matrix / digests of segment s start lde_seg[k] / dig_seg[k] words after segment
+    // s - 1's, layer l's values / digests val_seg[l] / ldig_seg[l] words
+    size_t lde_seg[ZKM_FRI_MAX_ORACLES], dig_seg[ZKM_FRI_MAX_ORACLES], val_seg[8], ldig_seg[8];
 };
 struct gather_queries { uint32_t x[ZKM_FRI_MAX_QUERIES]; };   // x < 2^lde_bits <= 2^32
 __device__ __forceinline__ size_t merkle_level_offset(unsigned log_leaves, unsigned lvl) {
     return (((size_t)2 << log_leaves) - ((size_t)2 << (log_leaves - lvl))) * 4;
 }
-__global__ void k_gather_queries(gather_args g, gather_queries qs, gl_t* __restrict__ out) {
-    uint64_t x = qs.x[blockIdx.x];
+__global__ void k_gather_queries(gather_args g, const uint32_t* __restrict__ qs /* [segment][queries] */, gl_t* __restrict__ out) {
+    const size_t sg = blockIdx.y;
+    uint64_t x = qs[sg * gridDim.x + blockIdx.x];
     const uint64_t N = (uint64_t)1 << g.lde_bits;
-    gl_t* o = out + (size_t)blockIdx.x * g.query_words;
+    gl_t* o = out + (sg * gridDim.x + blockIdx.x) * g.query_words;
     for (uint32_t k = 0; k < g.noracles; k++) {
         const gather_oracle& r = g.o[k];
-        for (uint32_t c = threadIdx.x; c < r.ncols; c += blockDim.x) o[c] = r.lde[(size_t)c * N + x];
+        const gl_t* lde = r.lde + sg * g.lde_seg[k];
+        const gl_t* dig = r.digests + sg * g.dig_seg[k];
+        for (uint32_t c = threadIdx.x; c < r.ncols; c += blockDim.x) o[c] = lde[(size_t)c * N + x];
         o += r.ncols;
         for (uint32_t e = threadIdx.x; e < r.nsib * 4; e += blockDim.x) {
             uint32_t lvl = e >> 2;
-            o[e] = r.digests[merkle_level_offset(g.lde_bits, lvl) + 4 * ((x >> lvl) ^ 1) + (e & 3)];
+            o[e] = dig[merkle_level_offset(g.lde_bits, lvl) + 4 * ((x >> lvl) ^ 1) + (e & 3)];
         }
         o += r.nsib * 4;
     }
     uint32_t arity = 1u << g.arity_bits;
     for (uint32_t l = 0; l < g.nlayers; l++) {
         const gather_layer& r = g.l[l];
+        const gl_t *c0 = r.c0 + sg * g.val_seg[l], *c1 = r.c1 + sg * g.val_seg[l], *dig = r.digests + sg * g.ldig_seg[l];
         x >>= g.arity_bits;
-        for (uint32_t e = threadIdx.x; e < 2 * arity; e += blockDim.x) o[e] = (e & 1) ? r.c1[x * arity + (e >> 1)] : r.c0[x * arity + (e >> 1)];
+        for (uint32_t e = threadIdx.x; e < 2 * arity; e += blockDim.x) o[e] = (e & 1) ? c1[x * arity + (e >> 1)] : c0[x * arity + (e >> 1)];
         o += 2 * arity;
         for (uint32_t e = threadIdx.x; e < r.nsib * 4; e += blockDim.x) {
             uint32_t lvl = e >> 2;
-            o[e] = r.digests[merkle_level_offset(r.log_leaves, lvl) + 4 * ((x >> lvl) ^ 1) + (e & 3)];
+            o[e] = dig[merkle_level_offset(r.log_leaves, lvl) + 4 * ((x >> lvl) ^ 1) + (e & 3)];
         }
         o += r.nsib * 4;
     }
@@ -895,10 +997,10 @@ static gl2_t challenger_get_ext(zkm_challenger* ch) {
 }
 
 struct fri_layer {
-    gl_t* values = nullptr;   // [2][len] bit-reversed
-    gl_t* digests = nullptr;
+    gl_t* values = nullptr;   // [segment][2][len] bit-reversed
+    gl_t* digests = nullptr;  // [segment][dig_words]
     std::vector<size_t> level_off;
-    size_t len = 0;
+    size_t len = 0, dig_words = 0;
     unsigned log_leaves = 0;
 };
 
@@ -912,66 +1014,96 @@ struct fri_composite {
     gl2_t point, shift;
 };
 
-static void divide_accumulate_all(zkm_ctx* c, const std::vector<fri_composite>& comps, size_t n, gl_t* f0, gl_t* f1) {
-    const unsigned nb = (unsigned)comps.size();
+static void divide_accumulate_all(zkm_ctx* c, const std::vector<std::vector<fri_composite>>& comps, size_t comp_seg, size_t n, gl_t* f0, gl_t* f1) {
+    const size_t nseg = comps.size();
+    if (nseg == 0 || nseg > ZKM_MAX_SEG) throw std::runtime_error("FRI: bad stack size");
+    const unsigned nb = (unsigned)comps[0].size(), z = (unsigned)nseg;
     if (nb == 0 || nb > FRI_MAX_BATCHES) throw std::runtime_error("FRI: 1..8 opening batches");
+    for (const auto& k : comps)
+        if (k.size() != nb) throw std::runtime_error("internal: FRI instances of a stack differ");
     zkm_prof_scope ps(c, "fri_divide_linear");
     // level sizes: n, ceil(n / FRI_SEG), ... down to <= FRI_SEG
     std::vector<size_t> m{n};
     while (m.back() > FRI_SEG) m.push_back((m.back() + FRI_SEG - 1) / FRI_SEG);
     const size_t L = m.size();
     std::vector<seg_batches> lv(L);
-    std::vector<gl_t*> tot(L, nullptr), suf(L, nullptr);   // tot[l]: [nb][2][m[l]] totals feeding level l (l >= 1); suf[l]: suffix values of level l
+    std::vector<gl_t*> tot(L, nullptr), suf(L, nullptr);   // tot[l]: [segment][nb][2][m[l]] totals feeding level l (l >= 1); suf[l]: suffix values of level l
     std::vector<void*> tmp;
-    gl2_t wacc{1, 0};
-    for (unsigned b = nb; b-- > 0;) {                      // w_b = product of the shifts of the batches after b
-        lv[0].w[b] = wacc;
-        wacc = gl2_mul(wacc, comps[b].shift);
+    // points and weights of every level and segment: zw[l][s][b] = (z_b^(FRI_SEG^l), w_b), w_b = product of the shifts of the batches after b
+    const size_t per_level = nseg * nb * 2;
+    std::vector<gl2_t> zw(L * per_level);
+    for (size_t sg = 0; sg < nseg; sg++) {
+        gl2_t wacc{1, 0};
+        for (unsigned b = nb; b-- > 0;) {
+            gl2_t zp = comps[sg][b].point;
+            for (size_t l = 0; l < L; l++) {
+                zw[l * per_level + (sg * nb + b) * 2] = zp;
+                zw[l * per_level + (sg * nb + b) * 2 + 1] = wacc;
+                zp = gl2_pow(zp, FRI_SEG);
+            }
+            wacc = gl2_mul(wacc, comps[sg][b].shift);
+        }
     }
-    for (unsigned b = 0; b < nb; b++) { lv[0].a0[b] = comps[b].c0; lv[0].a1[b] = comps[b].c1; lv[0].z[b] = comps[b].point; }
+    gl2_t* d_zw = (gl2_t*)c->alloc(zw.size() * sizeof(gl2_t));
+    tmp.push_back(d_zw);
+    c->upload(d_zw, zw.data(), zw.size() * sizeof(gl2_t));
+    for (unsigned b = 0; b < nb; b++) { lv[0].a0[b] = comps[0][b].c0; lv[0].a1[b] = comps[0][b].c1; }
     lv[0].nb = nb;
+    lv[0].a_seg = comp_seg;
+    lv[0].zw = d_zw;
     for (size_t l = 1; l < L; l++) {
-        tot[l] = (gl_t*)c->alloc(2 * nb * m[l] * sizeof(gl_t));
+        tot[l] = (gl_t*)c->alloc(nseg * 2 * nb * m[l] * sizeof(gl_t));
         tmp.push_back(tot[l]);
-        hipLaunchKernelGGL(k_seg_totals, dim3((unsigned)((m[l] + 63) / 64), nb), dim3(64), 0, c->stream, lv[l - 1], m[l - 1], tot[l]);
+        hipLaunchKernelGGL(k_seg_totals, dim3((unsigned)((m[l] + 63) / 64), nb, z), dim3(64), 0, c->stream, lv[l - 1], m[l - 1], tot[l]);
         lv[l] = lv[0];
         for (unsigned b = 0; b < nb; b++) {
             lv[l].a0[b] = tot[l] + (2 * b) * m[l];
             lv[l].a1[b] = tot[l] + (2 * b + 1) * m[l];
-            lv[l].z[b] = gl2_pow(lv[l - 1].z[b], FRI_SEG);
         }
+        lv[l].a_seg = 2 * nb * m[l];
+        lv[l].zw = d_zw + l * per_level;
     }
     // top-down: suffix values of each level, then the weighted sum of the bottom level's
     for (size_t l = L; l-- > 0;) {
-        const size_t nseg = (m[l] + FRI_SEG - 1) / FRI_SEG;
+        const size_t nsegm = (m[l] + FRI_SEG - 1) / FRI_SEG;
         const gl_t* upper = l + 1 < L ? suf[l + 1] : nullptr;
         const size_t nupper = l + 1 < L ? m[l + 1] : 0;
         if (l == 0 && n >= c->fri_fused_division_min) {
-            static std::atomic<uint64_t> lds_ok{0};             // (hipFuncSetAttribute is per device; setting it twice is harmless)
-            const uint64_t bit = (uint64_t)1 << (c->device & 63);
-            if (!(lds_ok.load(std::memory_order_acquire) & bit)) {
-                ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_seg_scan_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                lds_ok.fetch_or(bit, std::memory_order_release);
+            const size_t lds = 4 * 64 * SEG_ROW * sizeof(gl_t);
+            if (lds > 64 * 1024) {                                  // (only a build with longer segments needs the raised limit -- ADVICE r04)
+                static std::atomic<uint64_t> lds_ok{0};             // (hipFuncSetAttribute is per device; setting it twice is harmless)
+                const uint64_t bit = (uint64_t)1 << (c->device & 63);
+                if (!(lds_ok.load(std::memory_order_acquire) & bit)) {
+                    ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_seg_scan_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    lds_ok.fetch_or(bit, std::memory_order_release);
+                }
             }
-            hipLaunchKernelGGL(k_seg_scan_final, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 4 * 64 * SEG_ROW * sizeof(gl_t), c->stream, lv[0], n,
-                               upper, nupper, f0, f1);
+            hipLaunchKernelGGL(k_seg_scan_final, dim3((unsigned)((nsegm + 63) / 64), 1, z), dim3(64), lds, c->stream, lv[0], n, upper, nupper, f0, f1);
             break;
         }
-        suf[l] = (gl_t*)c->alloc(2 * nb * m[l] * sizeof(gl_t));
+        suf[l] = (gl_t*)c->alloc(nseg * 2 * nb * m[l] * sizeof(gl_t));
         tmp.push_back(suf[l]);
-        hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)((nseg + 63) / 64), nb), dim3(64), 0, c->stream, lv[l], m[l], upper, nupper, suf[l]);
-        if (l == 0) hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, lv[0], n, suf[0], f0, f1);
+        hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)((nsegm + 63) / 64), nb, z), dim3(64), 0, c->stream, lv[l], m[l], upper, nupper, suf[l]);
+        if (l == 0) hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((n + 255) / 256), 1, z), dim3(256), 0, c->stream, lv[0], n, suf[0], f0, f1);
     }
     ZKM_HIP_CHECK(hipGetLastError());
     // no host sync: released blocks are only reused by later work on this stream
     for (void* q : tmp) c->release(q);
 }
 
-static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, const std::vector<fri_composite>& comps,
-                       const zkm_batch* const* orc, size_t noracles, zkm_challenger* ch, unsigned L, size_t F, size_t nq, size_t query_words,
-                       uint64_t* caps_out, uint64_t* final_out, uint64_t* pow_out, uint64_t* queries_out) {
+// Everything of a FRI proof after the alpha-combination, for a STACK of independent proofs of the same shape (one proof: vectors of
+// length 1): comps[s] = proof s's composites (pointers: proof 0's; proof s's are s * comp_seg words further), orc = the stacked initial
+// oracles, chs[s] = proof s's transcript, caps_out[s] etc. its output fields.  Every stage is ONE launch (or group of launches) for all
+// proofs, and every transcript round trip brings the words of all of them down together.
+static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, const std::vector<std::vector<fri_composite>>& comps, size_t comp_seg,
+                       const zkm_batch* const* orc, size_t noracles, const std::vector<zkm_challenger*>& chs, unsigned L, size_t F, size_t nq,
+                       size_t query_words, const std::vector<uint64_t*>& caps_out, const std::vector<uint64_t*>& final_out,
+                       const std::vector<uint64_t*>& pow_out, const std::vector<uint64_t*>& queries_out) {
     if (noracles == 0 || noracles > ZKM_FRI_MAX_ORACLES) throw std::runtime_error("FRI: 1..8 initial oracles");
     if (L > 8) throw std::runtime_error("too many FRI layers");
+    const size_t nseg = comps.size();
+    if (nseg == 0 || nseg > ZKM_MAX_SEG || chs.size() != nseg) throw std::runtime_error("FRI: bad stack size");
+    const unsigned z = (unsigned)nseg;
     const size_t n = (size_t)1 << log_n, C4 = (size_t)4 << cfg->cap_height;
     const unsigned lde_bits = log_n + cfg->rate_bits;
     const size_t N = (size_t)1 << lde_bits;
@@ -983,114 +1115,159 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
         for (void* p : scratch) c->release(p);
     };
     try {
-        gl_t* d_fin = (gl_t*)c->alloc(2 * n * sizeof(gl_t));  // final poly coefficients [2][n]
+        gl_t* d_fin = (gl_t*)c->alloc(nseg * 2 * n * sizeof(gl_t));  // final poly coefficients [segment][2][n]
         scratch.push_back(d_fin);
-        divide_accumulate_all(c, comps, n, d_fin, d_fin + n);
+        divide_accumulate_all(c, comps, comp_seg, n, d_fin, d_fin + n);
 
         // commit phase: coefficients stay in d_fin (length clen, implicitly zero-padded x4)
         size_t clen = n;
         unsigned clog = log_n;
         gl_t shift = GL_GENERATOR;
         unsigned arity = 1u << cfg->arity_bits;
-        gl_t* d_coef0 = d_fin;      // c0 array (clen)
-        gl_t* d_coef1 = d_fin + n;  // c1 array
+        gl_t* d_coef = d_fin;       // [segment][2][clen]: c0 array, then c1
+        std::vector<uint64_t> capbuf(nseg * C4);
         for (unsigned l = 0; l < L; l++) {
             fri_layer& fl = layers[l];
             fl.len = clen << cfg->rate_bits;
-            fl.values = (gl_t*)c->alloc(2 * fl.len * sizeof(gl_t));
-            // values = coset_fft(shift) of the zero-padded coefficients, bit-reversed: two base-field columns
-            // (the two coefficient arrays are contiguous: [c0 | c1], column stride clen)
-            if (d_coef1 != d_coef0 + clen) throw std::runtime_error("internal: FRI coefficient arrays not contiguous");
-            zkm_lde_bitrev(c, d_coef0, fl.values, 2, clog, cfg->rate_bits, shift);
+            fl.values = (gl_t*)c->alloc(nseg * 2 * fl.len * sizeof(gl_t));
+            // values = coset_fft(shift) of the zero-padded coefficients, bit-reversed: two base-field columns per proof
+            // (the coefficient arrays are contiguous: [c0 | c1] per proof, column stride clen)
+            zkm_lde_bitrev(c, d_coef, fl.values, 2 * nseg, clog, cfg->rate_bits, shift);
             fl.log_leaves = clog + cfg->rate_bits - cfg->arity_bits;
             size_t dwords = zkm_merkle_layout(fl.log_leaves, cfg->cap_height, fl.level_off);
-            fl.digests = (gl_t*)c->alloc(dwords * sizeof(gl_t));
-            zkm_launch_merkle_leaves_ext(c, fl.values, fl.values + fl.len, (size_t)1 << fl.log_leaves, arity, fl.digests);
-            uint64_t* capo = caps_out + l * C4;
-            zkm_merkle_build_inner_cap(c, fl.digests, fl.level_off, fl.log_leaves, cfg->cap_height, capo);
-            zkm_challenger_observe(ch, capo, C4);
-            gl2_t beta = challenger_get_ext(ch);
+            fl.dig_words = dwords;
+            fl.digests = (gl_t*)c->alloc(nseg * dwords * sizeof(gl_t));
+            zkm_launch_merkle_leaves_ext(c, fl.values, fl.values + fl.len, (size_t)1 << fl.log_leaves, arity, fl.digests, nseg, 2 * fl.len, dwords);
+            zkm_merkle_build_inner_cap(c, fl.digests, fl.level_off, fl.log_leaves, cfg->cap_height, capbuf.data(), nseg, dwords);
+            seg_gl2 betas{};
+            for (size_t sg = 0; sg < nseg; sg++) {
+                uint64_t* capo = caps_out[sg] + l * C4;
+                memcpy(capo, capbuf.data() + sg * C4, C4 * sizeof(uint64_t));
+                zkm_challenger_observe(chs[sg], capo, C4);
+                gl2_t beta = challenger_get_ext(chs[sg]);
+                betas.v[2 * sg] = beta.c0; betas.v[2 * sg + 1] = beta.c1;
+            }
             size_t nout = clen >> cfg->arity_bits;
-            gl_t* d_new = (gl_t*)c->alloc(2 * nout * sizeof(gl_t));
+            gl_t* d_new = (gl_t*)c->alloc(nseg * 2 * nout * sizeof(gl_t));
             scratch.push_back(d_new);
             {
                 zkm_prof_scope ps(c, "fri_fold");
-                if (arity > FRI_FOLD_MAX_ARITY) throw std::runtime_error("FRI: arity above 16");
-                hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((nout + 63) / 64)), dim3(64), 0, c->stream, d_coef0, d_coef1, nout, arity, beta, d_new, d_new + nout);
+                const size_t lds = 2 * 64 * ((size_t)arity + 1) * sizeof(gl_t);
+                if (lds > 64 * 1024) {
+                    static std::atomic<uint64_t> lds_ok{0};
+                    const uint64_t bit = (uint64_t)1 << (c->device & 63);
+                    if (!(lds_ok.load(std::memory_order_acquire) & bit)) {
+                        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_fri_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        lds_ok.fetch_or(bit, std::memory_order_release);
+                    }
+                }
+                hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((nout + 63) / 64), 1, z), dim3(64), lds, c->stream, d_coef, d_coef + clen, nout, arity, betas,
+                                   d_new, d_new + nout);
                 ZKM_HIP_CHECK(hipGetLastError());
             }
-            d_coef0 = d_new;
-            d_coef1 = d_new + nout;
+            d_coef = d_new;
             clen = nout;
             clog -= cfg->arity_bits;
             shift = gl_pow(shift, arity);
         }
         if (clen != F) throw std::runtime_error("internal: final polynomial length mismatch");
         {
-            std::vector<gl_t> f(2 * clen);
-            c->download({{f.data(), d_coef0, clen * 8}, {f.data() + clen, d_coef1, clen * 8}});
-            uint64_t* fp = final_out;
-            for (size_t i = 0; i < clen; i++) { fp[2 * i] = f[i]; fp[2 * i + 1] = f[clen + i]; }
-            zkm_challenger_observe(ch, fp, 2 * clen);
+            std::vector<gl_t> f(nseg * 2 * clen);
+            c->download(f.data(), d_coef, nseg * 2 * clen * 8);
+            for (size_t sg = 0; sg < nseg; sg++) {
+                uint64_t* fp = final_out[sg];
+                const gl_t* fs = f.data() + sg * 2 * clen;
+                for (size_t i = 0; i < clen; i++) { fp[2 * i] = fs[i]; fp[2 * i + 1] = fs[clen + i]; }
+                zkm_challenger_observe(chs[sg], fp, 2 * clen);
+            }
         }
 
-        // proof of work (App. A.9), smallest witness
+        // proof of work (App. A.9), smallest witness of every proof
         {
-            pow_state st;
-            memcpy(st.s, ch->state, sizeof st.s);
-            for (uint32_t i = 0; i < ch->n_in; i++) st.s[i] = ch->in_buf[i];
-            unsigned long long* d_best = c->pow_best();      // all ones between searches (the kernel leaves it that way)
-            unsigned long long best = ~0ULL;
-            // 2^pow_round_log candidates per round (17: two waves per SIMD -- a wave alone issues at half the SIMD's rate, so the round is
-            // barely longer than with one, and it holds the hit with probability 0.86 instead of 0.63 at 16 bits), up to 2^6 rounds
-            // per launch (a launch without a hit: probability e^-128)
-            const uint64_t stride = (uint64_t)1 << c->pow_round_log, span = stride << 6;
-            for (uint64_t base = 0; best == ~0ULL; base += span) {
+            std::vector<pow_state> sts(nseg);
+            seg_u32 pos{}, done{};
+            for (size_t sg = 0; sg < nseg; sg++) {
+                memcpy(sts[sg].s, chs[sg]->state, sizeof sts[sg].s);
+                for (uint32_t i = 0; i < chs[sg]->n_in; i++) sts[sg].s[i] = chs[sg]->in_buf[i];
+                pos.v[sg] = chs[sg]->n_in;
+            }
+            pow_state* d_sts = (pow_state*)c->alloc(nseg * sizeof(pow_state));
+            scratch.push_back(d_sts);
+            c->upload(d_sts, sts.data(), nseg * sizeof(pow_state));
+            unsigned long long* d_best = c->pow_best();      // ZKM_MAX_SEG words, all ones between searches (the kernel leaves them that way)
+            std::vector<unsigned long long> best(nseg, ~0ULL), got(nseg);
+            // 2^pow_round_log candidates per round and proof (17 for a proof alone: two waves per SIMD -- a wave alone issues at half the
+            // SIMD's rate, so the round is barely longer than with one, and it holds the hit with probability 0.86 instead of 0.63 at 16
+            // bits; the searches of a stack share the machine: the round of each shrinks with their number, down to 2^12, so that the
+            // stack's round is still one launch-filling set of waves and few candidates are tried beyond the round of a proof's first hit),
+            // up to 2^6 rounds per launch (a launch without a hit: probability e^-128 for a proof alone)
+            unsigned round_log = c->pow_round_log;
+            for (size_t k = 1; k < nseg && round_log > 12; k <<= 1) round_log--;
+            const uint64_t stride = (uint64_t)1 << round_log, span = stride << 6;
+            size_t open = nseg;
+            for (uint64_t base = 0; open; base += span) {
                 if (base > ((uint64_t)1 << 40)) throw std::runtime_error("Proof of work failed. This is highly unlikely!");
                 uint64_t *host_slot, *flag;
                 unsigned* counter;
-                const uint64_t seq = c->xfer_begin(8, &host_slot, &flag, &counter);
+                const uint64_t seq = c->xfer_begin(8 * nseg, &host_slot, &flag, &counter);
                 {
                     zkm_prof_scope ps(c, "fri_pow_search");
-                    hipLaunchKernelGGL(k_pow_search, dim3(stride / 256), dim3(256), 0, c->stream, st, ch->n_in, cfg->pow_bits, base, base + span, d_best,
-                                       counter, host_slot, flag, seq);
+                    hipLaunchKernelGGL(k_pow_search, dim3(stride / 256, z), dim3(256), 0, c->stream, d_sts, pos, done, cfg->pow_bits, base, base + span,
+                                       d_best, counter, host_slot, flag, seq);
                     ZKM_HIP_CHECK(hipGetLastError());
                 }
-                c->xfer_finish(seq, &best, 8);
+                c->xfer_finish(seq, got.data(), 8 * nseg);
+                for (size_t sg = 0; sg < nseg; sg++)
+                    if (!done.v[sg] && got[sg] != ~0ULL) { best[sg] = got[sg]; done.v[sg] = 1; open--; }
             }
-            uint64_t w = best;
-            *pow_out = w;
-            zkm_challenger_observe(ch, &w, 1);
-            uint64_t resp = zkm_challenger_get(ch);
-            if ((resp >> (64 - cfg->pow_bits)) != 0) throw std::runtime_error("internal: proof-of-work response check failed");
+            for (size_t sg = 0; sg < nseg; sg++) {
+                uint64_t w = best[sg];
+                *pow_out[sg] = w;
+                zkm_challenger_observe(chs[sg], &w, 1);
+                uint64_t resp = zkm_challenger_get(chs[sg]);
+                if ((resp >> (64 - cfg->pow_bits)) != 0) throw std::runtime_error("internal: proof-of-work response check failed");
+            }
         }
 
         // query rounds
         {
             if (nq > ZKM_FRI_MAX_QUERIES || lde_bits > 32) throw std::runtime_error("FRI: at most 128 query rounds on domains of at most 2^32 points");
-            gather_queries qs{};
-            for (size_t q = 0; q < nq; q++) qs.x[q] = (uint32_t)(zkm_challenger_get(ch) % N);
+            std::vector<uint32_t> qs(nseg * nq);
+            for (size_t sg = 0; sg < nseg; sg++)
+                for (size_t q = 0; q < nq; q++) qs[sg * nq + q] = (uint32_t)(zkm_challenger_get(chs[sg]) % N);
+            uint32_t* d_qs = (uint32_t*)c->alloc(qs.size() * sizeof(uint32_t));
+            scratch.push_back(d_qs);
+            c->upload(d_qs, qs.data(), qs.size() * sizeof(uint32_t));
             gather_args ga{};
             ga.noracles = (uint32_t)noracles;
             for (size_t k = 0; k < noracles; k++) {
-                if (orc[k]->lde_bits() != lde_bits) throw std::runtime_error("internal: oracle of another domain size in the query gather");
+                if (orc[k]->lde_bits() != lde_bits || orc[k]->nseg != nseg) throw std::runtime_error("internal: oracle of another domain size in the query gather");
                 ga.o[k].lde = orc[k]->lde; ga.o[k].digests = orc[k]->digests; ga.o[k].ncols = (uint32_t)orc[k]->ncols;
                 ga.o[k].nsib = lde_bits - cfg->cap_height;
+                ga.lde_seg[k] = orc[k]->lde_seg(); ga.dig_seg[k] = orc[k]->dig_words;
             }
             for (unsigned l = 0; l < L; l++) {
                 ga.l[l].c0 = layers[l].values; ga.l[l].c1 = layers[l].values + layers[l].len; ga.l[l].digests = layers[l].digests;
                 ga.l[l].nsib = layers[l].log_leaves - cfg->cap_height;
                 ga.l[l].log_leaves = layers[l].log_leaves;
+                ga.val_seg[l] = 2 * layers[l].len; ga.ldig_seg[l] = layers[l].dig_words;
             }
             ga.nlayers = L; ga.arity_bits = cfg->arity_bits; ga.lde_bits = lde_bits; ga.query_words = query_words;
-            gl_t* d_q = (gl_t*)c->alloc(nq * query_words * 8);
+            const size_t qwords = nq * query_words;
+            gl_t* d_q = (gl_t*)c->alloc(nseg * qwords * 8);
             scratch.push_back(d_q);
             {
                 zkm_prof_scope ps(c, "fri_gather_queries");
-                hipLaunchKernelGGL(k_gather_queries, dim3(nq), dim3(256), 0, c->stream, ga, qs, d_q);
+                hipLaunchKernelGGL(k_gather_queries, dim3(nq, z), dim3(256), 0, c->stream, ga, d_qs, d_q);
                 ZKM_HIP_CHECK(hipGetLastError());
             }
-            c->download(queries_out, d_q, nq * query_words * 8);
+            if (nseg == 1) {
+                c->download(queries_out[0], d_q, qwords * 8);
+            } else {
+                std::vector<gl_t> all(nseg * qwords);
+                c->download(all.data(), d_q, nseg * qwords * 8);
+                for (size_t sg = 0; sg < nseg; sg++) memcpy(queries_out[sg], all.data() + sg * qwords, qwords * 8);
+            }
         }
 
     } catch (...) {
@@ -1100,16 +1277,23 @@ static void fri_finish(zkm_ctx* c, const zkm_stark_config* cfg, unsigned log_n, 
     cleanup();
 }
 
+// prove_single_table for a STACK of nseg = chs.size() independent proofs of the same table at the same height (one proof: vectors of
+// length 1, the single-table entry points): the commitments are stacked batches (zkm_internal.h), zs = nseg lists of CtlZData,
+// lookup_challenges = nseg x num_challenges, chs[s] / proofs[s] = proof s's transcript and output blob.  Every stage is one launch (or
+// group of launches) for all proofs; the transcripts advance side by side on the host between the round trips.
 static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t W, unsigned log_n,
                                const zkm_batch* trace_batch, const uint64_t* aux, size_t A_ctl, const zkm_ctl_table* ctl_table,
                                const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t Z, const uint64_t* lookup_challenges,
-                               zkm_challenger* ch, uint64_t* proof, const zkm_batch* aux_batch_in = nullptr,
+                               const std::vector<zkm_challenger*>& chs, const std::vector<uint64_t*>& proofs, const zkm_batch* aux_batch_in = nullptr,
                                const zkm_batch* quot_batch_in = nullptr) {
     // openings-only mode (zkm_prove_openings, BASELINE config 4): the three commitments exist already; the transcript
     // is compact -> zeta -> openings -> prove_openings.  aux_given (zkm_prove_with_traces): the auxiliary commitment was built ahead of
     // the transcript (it only depends on the CTL challenges); everything from observing its cap on runs here.
     const bool openings_only = quot_batch_in != nullptr;
     const bool aux_given = aux_batch_in != nullptr && !openings_only;
+    const size_t nseg = chs.size();
+    if (nseg == 0 || nseg > ZKM_MAX_SEG || proofs.size() != nseg) throw std::runtime_error("prove_single_table: bad stack size");
+    if (nseg > 1 && !(aux_given && trace_batch)) throw std::runtime_error("internal: a stack of proofs needs its stacked commitments");
     validate_config(cfg, log_n);  // before zkm_num_lookup_columns reads it; make_layout checks again
     // the table's own lookup helper columns come first among the auxiliary polynomials (prover.rs:467-508)
     const size_t NL = openings_only ? 0 : zkm_num_lookup_columns(table_id, cfg);
@@ -1131,27 +1315,27 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
     if (A_ctl == 0) throw std::runtime_error("No CTL? aux column count does not match the CTL description");  // prover.rs:509
     const size_t total_helpers = A - Z;  // index of the first CTL Z among the auxiliary polynomials
     ctl_dev_owner own;
-    if (!openings_only) own.upload(c, ctl_table, zs, colset_ids, Z, false, W);
+    if (!openings_only) own.upload(c, ctl_table, zs, colset_ids, Z, false, W, nseg);
     if (ctl_table && !openings_only)
         for (size_t i = 0; i < ctl_table->nterms; i++)
             if (ctl_table->term_col[i] >= W) throw std::runtime_error("CTL description: trace column index out of range");
 
     // (the query rounds -- nine tenths of the blob, 2 MB for the Keccak table -- are written in full by the download at the end of
     // fri_finish: zeroing them here was 0.2 ms of host time per segment in front of the table's first launch)
-    memset(proof, 0, y.o_queries * sizeof(uint64_t));
-    proof[0] = ZKM_PROOF_MAGIC; proof[1] = log_n; proof[2] = W; proof[3] = A; proof[4] = y.Q; proof[5] = Z; proof[6] = y.cap;
-    proof[7] = y.L; proof[8] = y.F; proof[9] = y.nq; proof[10] = cfg->rate_bits; proof[11] = cfg->arity_bits;
+    for (uint64_t* proof : proofs) {
+        memset(proof, 0, y.o_queries * sizeof(uint64_t));
+        proof[0] = ZKM_PROOF_MAGIC; proof[1] = log_n; proof[2] = W; proof[3] = A; proof[4] = y.Q; proof[5] = Z; proof[6] = y.cap;
+        proof[7] = y.L; proof[8] = y.F; proof[9] = y.nq; proof[10] = cfg->rate_bits; proof[11] = cfg->arity_bits;
+    }
 
     zkm_batch* own_trace = nullptr;
     zkm_batch *ab = nullptr, *qb = nullptr;
-    std::vector<fri_layer> layers(y.L);
     std::vector<void*> scratch;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(c->stream);
         zkm_batch_free(own_trace);
         zkm_batch_free(ab);
         zkm_batch_free(qb);
-        for (auto& l : layers) { c->release(l.values); c->release(l.digests); }
         for (void* p : scratch) c->release(p);
     };
     try {
@@ -1164,15 +1348,17 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             zkm_batch_build(own_trace, trace, true);
             tb = own_trace;
         }
-        if (tb->ncols != W || tb->log_n != log_n || tb->rate_bits != cfg->rate_bits || tb->cap_height != cfg->cap_height)
+        if (tb->ncols != W || tb->log_n != log_n || tb->rate_bits != cfg->rate_bits || tb->cap_height != cfg->cap_height || tb->nseg != nseg)
             throw std::runtime_error("trace commitment does not match the table shape / config");
 
-        zkm_challenger_compact(ch, proof + y.o_init);  // :466
-        uint64_t* caps = proof + y.o_caps;
-        memcpy(caps, tb->cap.data(), y.C * 4 * 8);
+        const size_t C4 = y.C * 4;
+        for (size_t sg = 0; sg < nseg; sg++) {
+            zkm_challenger_compact(chs[sg], proofs[sg] + y.o_init);  // :466
+            memcpy(proofs[sg] + y.o_caps, tb->cap.data() + sg * C4, C4 * 8);
+        }
         const zkm_batch *abp = aux_batch_in, *qbp = quot_batch_in;
         if (aux_given) {
-            if (abp->ncols != A || abp->log_n != log_n || abp->rate_bits != cfg->rate_bits || abp->cap_height != cfg->cap_height)
+            if (abp->ncols != A || abp->log_n != log_n || abp->rate_bits != cfg->rate_bits || abp->cap_height != cfg->cap_height || abp->nseg != nseg)
                 throw std::runtime_error("auxiliary commitment does not match the table shape / config");
         } else if (!openings_only) {
             // auxiliary commitment :511-522
@@ -1203,118 +1389,142 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
             abp = ab;
         }
         if (!openings_only) {
-            memcpy(caps + y.C * 4, abp->cap.data(), y.C * 4 * 8);
-            zkm_challenger_observe(ch, caps + y.C * 4, y.C * 4);  // :525
-            gl_t alphas[4];
-            for (unsigned i = 0; i < cfg->num_challenges; i++) alphas[i] = zkm_challenger_get(ch);  // :527
+            std::vector<gl_t> alphas(nseg * cfg->num_challenges);
+            for (size_t sg = 0; sg < nseg; sg++) {
+                uint64_t* caps = proofs[sg] + y.o_caps;
+                memcpy(caps + C4, abp->cap.data() + sg * C4, C4 * 8);
+                zkm_challenger_observe(chs[sg], caps + C4, C4);  // :525
+                for (unsigned i = 0; i < cfg->num_challenges; i++) alphas[sg * cfg->num_challenges + i] = zkm_challenger_get(chs[sg]);  // :527
+            }
 
             // quotient :543-587
-            gl_t* d_quot = (gl_t*)c->alloc(cfg->num_challenges * 2 * n * sizeof(gl_t));
+            gl_t* d_quot = (gl_t*)c->alloc(nseg * cfg->num_challenges * 2 * n * sizeof(gl_t));
             scratch.push_back(d_quot);
             {
                 zkm_prof_scope st(c, "stage/compute quotient polys");  // :543-559
-                quotient_device(c, table_id, tb, abp, own, lookup_challenges, alphas, cfg->num_challenges, d_quot);
+                quotient_device(c, table_id, tb, abp, own, lookup_challenges, alphas.data(), cfg->num_challenges, d_quot);
             }
             qb = new zkm_batch();
-            qb->ctx = c; qb->ncols = y.Q; qb->log_n = log_n; qb->rate_bits = cfg->rate_bits; qb->cap_height = cfg->cap_height;
+            qb->ctx = c; qb->ncols = y.Q; qb->nseg = nseg; qb->log_n = log_n; qb->rate_bits = cfg->rate_bits; qb->cap_height = cfg->cap_height;
             {
                 zkm_prof_scope st(c, "stage/compute quotient commitment");  // :576-587
-                zkm_batch_build(qb, d_quot, false);  // chunks [q0_lo, q0_hi, q1_lo, q1_hi] == d_quot viewed as Q columns of n
+                zkm_batch_build(qb, d_quot, false);  // chunks [q0_lo, q0_hi, q1_lo, q1_hi] == d_quot viewed as Q columns of n, proof after proof
             }
-            memcpy(caps + 2 * y.C * 4, qb->cap.data(), y.C * 4 * 8);
-            zkm_challenger_observe(ch, caps + 2 * y.C * 4, y.C * 4);  // :589
+            for (size_t sg = 0; sg < nseg; sg++) {
+                uint64_t* caps = proofs[sg] + y.o_caps;
+                memcpy(caps + 2 * C4, qb->cap.data() + sg * C4, C4 * 8);
+                zkm_challenger_observe(chs[sg], caps + 2 * C4, C4);  // :589
+            }
             qbp = qb;
         } else {
             for (const zkm_batch* b : {abp, qbp})
-                if (!b || b->log_n != log_n || b->rate_bits != cfg->rate_bits || b->cap_height != cfg->cap_height)
+                if (!b || b->log_n != log_n || b->rate_bits != cfg->rate_bits || b->cap_height != cfg->cap_height || b->nseg != nseg)
                     throw std::runtime_error("zkm_prove_openings: commitments do not match the table shape / config");
             if (abp->ncols != A || qbp->ncols != y.Q) throw std::runtime_error("zkm_prove_openings: unexpected number of polynomials");
-            memcpy(caps + y.C * 4, abp->cap.data(), y.C * 4 * 8);
-            memcpy(caps + 2 * y.C * 4, qbp->cap.data(), y.C * 4 * 8);
+            for (size_t sg = 0; sg < nseg; sg++) {
+                uint64_t* caps = proofs[sg] + y.o_caps;
+                memcpy(caps + C4, abp->cap.data() + sg * C4, C4 * 8);
+                memcpy(caps + 2 * C4, qbp->cap.data() + sg * C4, C4 * 8);
+            }
         }
 
-        gl2_t zeta = challenger_get_ext(ch);  // :591
+        std::vector<gl2_t> zeta(nseg), zeta_next(nseg);
         gl_t g = gl_root_of_unity(log_n);
-        if (gl2_eq(gl2_exp_pow2(zeta, log_n), gl2_t{1, 0})) throw std::runtime_error("Opening point is in the subgroup.");  // :596-599
-        gl2_t zeta_next = gl2_scalar_mul(zeta, g);
+        for (size_t sg = 0; sg < nseg; sg++) {
+            zeta[sg] = challenger_get_ext(chs[sg]);  // :591
+            if (gl2_eq(gl2_exp_pow2(zeta[sg], log_n), gl2_t{1, 0})) throw std::runtime_error("Opening point is in the subgroup.");  // :596-599
+            zeta_next[sg] = gl2_scalar_mul(zeta[sg], g);
+        }
 
         // openings proof.rs:299-334
-        uint64_t* op = proof + y.o_open;
-        uint64_t *o_local = op, *o_next = op + 2 * W, *o_aux = op + 4 * W, *o_auxn = o_aux + 2 * A, *o_ctl = o_auxn + 2 * A, *o_quot = o_ctl + Z;
         {
             zkm_prof_scope st(c, "stage/openings (StarkOpeningSet::new)");  // proof.rs:299-334, between two timed! scopes in the reference
-            auto ev = eval_batches(c, {tb, abp, qbp}, zeta, zeta_next);
-            const auto &tv = ev[0], &av = ev[1], &qv = ev[2];
-            for (size_t i = 0; i < W; i++) {
-                o_local[2 * i] = tv[i].at_z0.c0; o_local[2 * i + 1] = tv[i].at_z0.c1;
-                o_next[2 * i] = tv[i].at_z1.c0; o_next[2 * i + 1] = tv[i].at_z1.c1;
+            auto ev = eval_batches(c, {tb, abp, qbp}, zeta.data(), zeta_next.data());
+            for (size_t sg = 0; sg < nseg; sg++) {
+                uint64_t* op = proofs[sg] + y.o_open;
+                uint64_t *o_local = op, *o_next = op + 2 * W, *o_aux = op + 4 * W, *o_auxn = o_aux + 2 * A, *o_ctl = o_auxn + 2 * A, *o_quot = o_ctl + Z;
+                const auto &tv = ev[sg][0], &av = ev[sg][1], &qv = ev[sg][2];
+                for (size_t i = 0; i < W; i++) {
+                    o_local[2 * i] = tv[i].at_z0.c0; o_local[2 * i + 1] = tv[i].at_z0.c1;
+                    o_next[2 * i] = tv[i].at_z1.c0; o_next[2 * i + 1] = tv[i].at_z1.c1;
+                }
+                for (size_t i = 0; i < A; i++) {
+                    o_aux[2 * i] = av[i].at_z0.c0; o_aux[2 * i + 1] = av[i].at_z0.c1;
+                    o_auxn[2 * i] = av[i].at_z1.c0; o_auxn[2 * i + 1] = av[i].at_z1.c1;
+                    if (i >= total_helpers) o_ctl[i - total_helpers] = av[i].at_one;
+                }
+                for (size_t i = 0; i < y.Q; i++) { o_quot[2 * i] = qv[i].at_z0.c0; o_quot[2 * i + 1] = qv[i].at_z0.c1; }
             }
-            for (size_t i = 0; i < A; i++) {
-                o_aux[2 * i] = av[i].at_z0.c0; o_aux[2 * i + 1] = av[i].at_z0.c1;
-                o_auxn[2 * i] = av[i].at_z1.c0; o_auxn[2 * i + 1] = av[i].at_z1.c1;
-                if (i >= total_helpers) o_ctl[i - total_helpers] = av[i].at_one;
-            }
-            for (size_t i = 0; i < y.Q; i++) { o_quot[2 * i] = qv[i].at_z0.c0; o_quot[2 * i + 1] = qv[i].at_z0.c1; }
         }
-        // observe_openings(to_fri_openings) proof.rs:336-367
-        zkm_challenger_observe(ch, o_local, 2 * W);
-        zkm_challenger_observe(ch, o_aux, 2 * A);
-        zkm_challenger_observe(ch, o_quot, 2 * y.Q);
-        zkm_challenger_observe(ch, o_next, 2 * W);
-        zkm_challenger_observe(ch, o_auxn, 2 * A);
-        for (size_t i = 0; i < Z; i++) { uint64_t e[2] = {o_ctl[i], 0}; zkm_challenger_observe(ch, e, 2); }
-
         // ---- prove_openings (App. A.8)
         zkm_prof_scope st_fri(c, "stage/compute openings proof");  // prover.rs:618-628
-        gl2_t alpha = challenger_get_ext(ch);
-        size_t np0 = W + A + y.Q, np1 = W + A, np2 = Z;
-        std::vector<gl_t> apow(2 * (np0 + 1));
-        {
+        const size_t np0 = W + A + y.Q, np1 = W + A, np2 = Z, apow_seg = 2 * (np0 + 1);
+        std::vector<gl_t> apow(nseg * apow_seg);
+        for (size_t sg = 0; sg < nseg; sg++) {
+            zkm_challenger* ch = chs[sg];
+            uint64_t* op = proofs[sg] + y.o_open;
+            uint64_t *o_local = op, *o_next = op + 2 * W, *o_aux = op + 4 * W, *o_auxn = o_aux + 2 * A, *o_ctl = o_auxn + 2 * A, *o_quot = o_ctl + Z;
+            // observe_openings(to_fri_openings) proof.rs:336-367
+            zkm_challenger_observe(ch, o_local, 2 * W);
+            zkm_challenger_observe(ch, o_aux, 2 * A);
+            zkm_challenger_observe(ch, o_quot, 2 * y.Q);
+            zkm_challenger_observe(ch, o_next, 2 * W);
+            zkm_challenger_observe(ch, o_auxn, 2 * A);
+            for (size_t i = 0; i < Z; i++) { uint64_t e[2] = {o_ctl[i], 0}; zkm_challenger_observe(ch, e, 2); }
+            gl2_t alpha = challenger_get_ext(ch);
             gl2_t p{1, 0};
-            for (size_t j = 0; j <= np0; j++) { apow[2 * j] = p.c0; apow[2 * j + 1] = p.c1; p = gl2_mul(p, alpha); }
+            gl_t* ap = apow.data() + sg * apow_seg;
+            for (size_t j = 0; j <= np0; j++) { ap[2 * j] = p.c0; ap[2 * j + 1] = p.c1; p = gl2_mul(p, alpha); }
         }
         gl_t* d_apow = (gl_t*)c->alloc(apow.size() * sizeof(gl_t));
         scratch.push_back(d_apow);
         c->upload(d_apow, apow.data(), apow.size() * sizeof(gl_t));
-        gl_t* d_comp = (gl_t*)c->alloc(6 * n * sizeof(gl_t));
+        gl_t* d_comp = (gl_t*)c->alloc(nseg * 6 * n * sizeof(gl_t));
         scratch.push_back(d_comp);
         if (tb->coeff_s1 != abp->coeff_s1 || tb->coeff_s1 != qbp->coeff_s1) throw std::runtime_error("internal: coefficient layouts of the three oracles differ");
         {
             zkm_prof_scope ps(c, "fri_combine");
             const size_t npoly = W + A + y.Q;
+            const unsigned z = (unsigned)nseg;
             // slices of >= 32 polynomials while the launch stays below ~2^17 threads (two waves per SIMD)
             size_t slices = npoly / 32 < 1 ? 1 : npoly / 32;
-            while (slices > 1 && slices * n > ((size_t)1 << 17)) slices >>= 1;
+            while (slices > 1 && slices * n * nseg > ((size_t)1 << 17)) slices >>= 1;
             if (slices >= 4) {
                 const size_t per = (npoly + slices - 1) / slices;
                 slices = (npoly + per - 1) / per;
-                gl_t* d_part = (gl_t*)c->alloc(slices * 6 * n * sizeof(gl_t));
+                gl_t* d_part = (gl_t*)c->alloc(nseg * slices * 6 * n * sizeof(gl_t));
                 scratch.push_back(d_part);
-                hipLaunchKernelGGL(k_fri_combine_slice, dim3((n + 255) / 256, (unsigned)slices), dim3(256), 0, c->stream, tb->coeffs, W, abp->coeffs, A,
-                                   qbp->coeffs, y.Q, total_helpers, d_apow, n, per, d_part);
-                hipLaunchKernelGGL(k_fri_combine_sum, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_part, (unsigned)slices, n, d_comp);
+                hipLaunchKernelGGL(k_fri_combine_slice, dim3((n + 255) / 256, (unsigned)slices, z), dim3(256), 0, c->stream, tb->coeffs, W, abp->coeffs, A,
+                                   qbp->coeffs, y.Q, total_helpers, d_apow, n, per, d_part, apow_seg);
+                hipLaunchKernelGGL(k_fri_combine_sum, dim3((n + 255) / 256, 1, z), dim3(256), 0, c->stream, d_part, (unsigned)slices, n, d_comp);
             } else {
-                hipLaunchKernelGGL(k_fri_combine, dim3((n + 255) / 256), dim3(256), 0, c->stream, tb->coeffs, W, abp->coeffs, A, qbp->coeffs, y.Q,
-                                   total_helpers, d_apow, n, d_comp);
+                hipLaunchKernelGGL(k_fri_combine, dim3((n + 255) / 256, 1, z), dim3(256), 0, c->stream, tb->coeffs, W, abp->coeffs, A, qbp->coeffs, y.Q,
+                                   total_helpers, d_apow, n, d_comp, apow_seg);
             }
             ZKM_HIP_CHECK(hipGetLastError());
         }
         if (tb->coeff_s1) {
             // the combination is position-wise, so the six composite arrays come out in the batches' coefficient layout; the division by
             // (X - point) walks exponents in order
-            gl_t* d_nat = (gl_t*)c->alloc(6 * n * sizeof(gl_t));
+            gl_t* d_nat = (gl_t*)c->alloc(nseg * 6 * n * sizeof(gl_t));
             scratch.push_back(d_nat);
-            zkm_coeff_layout_convert(c, d_comp, n, d_nat, n, 6, log_n, /*to_natural=*/true);
+            zkm_coeff_layout_convert(c, d_comp, n, d_nat, n, 6 * nseg, log_n, /*to_natural=*/true);
             d_comp = d_nat;
         }
         // divide by (X - point), accumulate, commit phase, proof of work, query rounds: shared with zkm_fri_prove
         {
-            std::vector<fri_composite> comps = {{d_comp, d_comp + n, zeta, gl2_t{apow[2 * np0], apow[2 * np0 + 1]}},
-                                                {d_comp + 2 * n, d_comp + 3 * n, zeta_next, gl2_t{apow[2 * np1], apow[2 * np1 + 1]}},
-                                                {d_comp + 4 * n, d_comp + 5 * n, gl2_t{1, 0}, gl2_t{apow[2 * np2], apow[2 * np2 + 1]}}};
+            std::vector<std::vector<fri_composite>> comps(nseg);
+            std::vector<uint64_t*> caps_o(nseg), final_o(nseg), pow_o(nseg), queries_o(nseg);
+            for (size_t sg = 0; sg < nseg; sg++) {
+                const gl_t* ap = apow.data() + sg * apow_seg;
+                comps[sg] = {{d_comp, d_comp + n, zeta[sg], gl2_t{ap[2 * np0], ap[2 * np0 + 1]}},
+                             {d_comp + 2 * n, d_comp + 3 * n, zeta_next[sg], gl2_t{ap[2 * np1], ap[2 * np1 + 1]}},
+                             {d_comp + 4 * n, d_comp + 5 * n, gl2_t{1, 0}, gl2_t{ap[2 * np2], ap[2 * np2 + 1]}}};
+                caps_o[sg] = proofs[sg] + y.o_fri_caps; final_o[sg] = proofs[sg] + y.o_final; pow_o[sg] = proofs[sg] + y.o_pow;
+                queries_o[sg] = proofs[sg] + y.o_queries;
+            }
             const zkm_batch* orc[3] = {tb, abp, qbp};
-            fri_finish(c, cfg, log_n, comps, orc, 3, ch, y.L, y.F, y.nq, y.query_words, proof + y.o_fri_caps, proof + y.o_final, proof + y.o_pow,
-                       proof + y.o_queries);
+            fri_finish(c, cfg, log_n, comps, 6 * n, orc, 3, chs, y.L, y.F, y.nq, y.query_words, caps_o, final_o, pow_o, queries_o);
         }
     } catch (...) {
         cleanup();
@@ -1323,14 +1533,15 @@ static void prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config*
     cleanup();
 }
 
-// prove_single_table on an existing trace AND auxiliary commitment (zkm_prove_with_traces builds the auxiliary commitments of all
-// tables ahead of the transcript, side by side); throws
+// prove_single_table on existing (stacked) trace AND auxiliary commitments (zkm_prove_with_traces builds the auxiliary commitments of all
+// tables ahead of the transcript, side by side); zs = chs.size() lists of CtlZData, lookup_challenges = chs.size() x num_challenges; throws
 void zkm_prove_single_table_aux(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, size_t ncols, unsigned log_n, const zkm_batch* trace_batch,
                                 const zkm_batch* aux_batch, size_t naux_ctl, const zkm_ctl_table* table, const zkm_ctl_z* zs,
-                                const uint32_t* colset_ids, size_t nzs, const uint64_t* lookup_challenges, zkm_challenger* ch, uint64_t* proof) {
+                                const uint32_t* colset_ids, size_t nzs, const uint64_t* lookup_challenges, const std::vector<zkm_challenger*>& chs,
+                                const std::vector<uint64_t*>& proofs) {
     if (!trace_batch || !aux_batch) throw std::runtime_error("prove_single_table: commitments are required");
-    prove_single_table(c, table_id, cfg, nullptr, ncols, log_n, trace_batch, nullptr, naux_ctl, table, zs, colset_ids, nzs, lookup_challenges, ch,
-                       proof, aux_batch, nullptr);
+    prove_single_table(c, table_id, cfg, nullptr, ncols, log_n, trace_batch, nullptr, naux_ctl, table, zs, colset_ids, nzs, lookup_challenges, chs,
+                       proofs, aux_batch, nullptr);
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -1459,7 +1670,8 @@ int zkm_fri_prove(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch* cons
         const gl_t** d_ptrs = (const gl_t**)c->alloc(ptrs.size() * sizeof(gl_t*));
         scratch.push_back((void*)d_ptrs);
         c->upload((void*)d_ptrs, ptrs.data(), ptrs.size() * sizeof(gl_t*));
-        std::vector<fri_composite> comps;
+        std::vector<std::vector<fri_composite>> comps_v(1);
+        std::vector<fri_composite>& comps = comps_v[0];
         for (size_t b = 0; b < nbatches; b++) {
             zkm_prof_scope ps(c, "fri_combine");
             hipLaunchKernelGGL(k_fri_combine_generic, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_ptrs + first[b], batches[b].npolys, d_apow, n,
@@ -1476,8 +1688,10 @@ int zkm_fri_prove(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch* cons
             for (auto& k : comps) { k.c0 = d_nat + (k.c0 - d_comp); k.c1 = d_nat + (k.c1 - d_comp); }
         }
         ZKM_HIP_CHECK(hipStreamSynchronize(c->stream));  // host vectors (ptrs, apow) are consumed
-        fri_finish(c, cfg, log_n, comps, oracles, noracles, ch, y.L, y.F, cfg->num_queries, y.query_words, proof + y.o_caps, proof + y.o_final,
-                   proof + y.o_pow, proof + y.o_queries);
+        for (size_t k = 0; k < noracles; k++)
+            if (oracles[k]->nseg != 1) throw std::runtime_error("zkm_fri_prove: stacked batches are internal");
+        fri_finish(c, cfg, log_n, comps_v, 0, oracles, noracles, {ch}, y.L, y.F, cfg->num_queries, y.query_words, {proof + y.o_caps}, {proof + y.o_final},
+                   {proof + y.o_pow}, {proof + y.o_queries});
     } catch (const std::exception& e) {
         (void)hipStreamSynchronize(c->stream);
         for (void* q : scratch) c->release(q);
@@ -1526,7 +1740,7 @@ int zkm_prove_single_table_ctl(zkm_ctx* c, int table_id, const zkm_stark_config*
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         if (!trace && !trace_batch) throw std::runtime_error("zkm_prove_single_table: need trace values or a trace commitment");
         prove_single_table(c, table_id, cfg, trace, ncols, log_n, trace_batch, aux, naux, table, zs, colset_ids, nzs, lookup_challenges,
-                           &local, proof_out);
+                           {&local}, {proof_out});
     } catch (const std::exception& e) {
         return fail(err, e.what());
     } catch (...) {
@@ -1544,7 +1758,7 @@ int zkm_prove_openings(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_batch*
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         if (!trace_batch || !aux_batch || !quot_batch) throw std::runtime_error("zkm_prove_openings: three commitments are required");
         prove_single_table(c, -1, cfg, nullptr, trace_batch->ncols, trace_batch->log_n, trace_batch, nullptr, aux_batch->ncols, nullptr,
-                           nullptr, nullptr, nctl_zs, nullptr, &local, proof_out, aux_batch, quot_batch);
+                           nullptr, nullptr, nctl_zs, nullptr, {&local}, {proof_out}, aux_batch, quot_batch);
     } catch (const std::exception& e) {
         return fail(err, e.what());
     } catch (...) {
@@ -1593,7 +1807,8 @@ int zkm_eval_openings(zkm_ctx* c, const zkm_batch* b, const uint64_t zeta[2], ui
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         gl2_t z{zeta[0], zeta[1]};
-        auto v = eval_batches(c, {b}, z, z)[0];
+        if (b->nseg != 1) throw std::runtime_error("zkm_eval_openings: stacked batches are internal");
+        auto v = eval_batches(c, {b}, &z, &z)[0][0];
         for (size_t i = 0; i < b->ncols; i++) { out[2 * i] = v[i].at_z0.c0; out[2 * i + 1] = v[i].at_z0.c1; }
     } catch (const std::exception& e) {
         return fail(err, e.what());

@@ -30,6 +30,12 @@ struct zkm_prof_rec {
     hipEvent_t start, stop;
 };
 
+#ifndef ZKM_MAX_SEG
+#define ZKM_MAX_SEG 32       // segments one lock-step group may hold (per-segment challenges travel in kernel-argument arrays of this size)
+#endif
+struct seg_gl { gl_t v[ZKM_MAX_SEG]; };          // one base-field word per segment
+struct seg_gl2 { gl_t v[2 * ZKM_MAX_SEG]; };     // two per segment (an F2 element, or the <= 2 constraint challenges)
+
 #ifndef ZKM_COMMIT_LANES
 #define ZKM_COMMIT_LANES 4   // trace commitments in flight per context (the context itself + 3 lanes)
 #endif
@@ -52,6 +58,7 @@ struct zkm_ctx {
     unsigned pow_round_log = 17;        // proof-of-work search: 2^this candidates per round of the search launch                          } zkm_ctx_set_tuning
     int aux_pipeline = 1;               // segments of short tables: lanes build later tables' auxiliary commitments behind the proofs      } zkm_ctx_set_tuning
     size_t commit_lanes = ZKM_COMMIT_LANES;   // trace / auxiliary commitments of one segment in flight (this context + lanes)   } zkm_ctx_set_tuning
+    size_t max_stack = ZKM_MAX_SEG;     // segments of one lock-step group (zkm_prove_segments): 1 .. ZKM_MAX_SEG               } zkm_ctx_set_tuning
     size_t wide_max_hashes = 1024;      // launches of up to this many hashes use 16 lanes per hash (latency form)   } 0 / 0: one lane
     size_t quad_max_hashes = 32768;     // ... and up to this many four lanes per hash                                } per hash always
     int num_cus = 256;
@@ -100,7 +107,7 @@ struct zkm_ctx {
     void download(std::initializer_list<xfer> xs);               // all device -> host, then ONE stream synchronisation
     void download(void* dst, const void* src, size_t bytes) { download({xfer{dst, src, bytes}}); }
     void upload(void* dst, const void* src, size_t bytes);       // host -> device on the stream; `src` may be reused on return
-    char* h_xfer = nullptr;                                      // [0, XFER_DOWN): downloads, [XFER_DOWN, XFER_DOWN + XFER_UP): upload ring,
+    char* h_xfer = nullptr;                                      // [0, XFER_UP): upload ring,
                                                                  // then one cache line for the completion flag of k_download
     uint64_t down_seq = 0;
     void wait_flag(const uint64_t* flag, uint64_t seq);          // spin, then (crowded process) block: core.hip
@@ -117,7 +124,10 @@ struct zkm_ctx {
     unsigned long long* pow_best();
     size_t tree_tail = 1;               // trees of <= 2^15 leaves in one launch incl. the cap's trip to the host; 0: levels + download      } zkm_ctx_set_tuning
     size_t up_off = 0;
-    static constexpr size_t XFER_DOWN = (size_t)1 << 20, XFER_UP = (size_t)1 << 18;
+    char* h_down = nullptr;                                      // pinned download area, down_cap bytes (grows: ensure_down)
+    size_t down_cap = 0;
+    void ensure_down(size_t bytes);
+    static constexpr size_t XFER_DOWN = (size_t)1 << 20, XFER_DOWN_MAX = (size_t)1 << 28, XFER_UP = (size_t)1 << 18;
     hipEvent_t get_event();
     size_t prof_begin(const char* name);   // returns the record's index (scopes nest: a stage scope holds kernel scopes)
     void prof_end(size_t idx);
@@ -153,16 +163,24 @@ struct zkm_prof_scope {
     }
 };
 
+// A batch may hold the SAME-SHAPED polynomials of `nseg` independent segments (zkm_prove_segments: K segments advance through every
+// stage of prove_with_traces in lock-step, one launch per stage): segment s owns columns [s ncols, (s + 1) ncols) of the coefficient and
+// LDE matrices (column strides n and N as ever, so the transforms see nseg * ncols columns), its own block of dig_words digest words
+// (level_off is relative to the block) and cap words [s capw, (s + 1) capw).  Kernels take the segment from blockIdx.z.
 struct zkm_batch {
     zkm_ctx* ctx = nullptr;
-    size_t ncols = 0;
+    size_t ncols = 0;         // per segment
+    size_t nseg = 1;
     unsigned log_n = 0, rate_bits = 0, cap_height = 0;
-    gl_t* coeffs = nullptr;   // ncols x n; position P of a column = coefficient of X^zkm_coeff_exponent(P, coeff_s1)
+    gl_t* coeffs = nullptr;   // nseg x ncols x n; position P of a column = coefficient of X^zkm_coeff_exponent(P, coeff_s1)
     unsigned coeff_s1 = 0;    // 0: natural order; else the digit layout of the two-pass inverse transform (2^18 .. 2^20 rows)
-    gl_t* lde = nullptr;      // ncols x N, rows bit-reversed
-    gl_t* digests = nullptr;  // levels 0..top concatenated, 4 words per node
-    std::vector<size_t> level_off;  // word offsets
-    std::vector<uint64_t> cap;      // host copy, 4 << cap_height words
+    gl_t* lde = nullptr;      // nseg x ncols x N, rows bit-reversed
+    gl_t* digests = nullptr;  // per segment: levels 0..top concatenated, 4 words per node
+    size_t dig_words = 0;     // digest words of one segment's tree
+    std::vector<size_t> level_off;  // word offsets (within a segment's block)
+    std::vector<uint64_t> cap;      // host copy, nseg x (4 << cap_height) words
+    size_t coeff_seg() const { return ncols << log_n; }
+    size_t lde_seg() const { return ncols << (log_n + rate_bits); }
     size_t n() const { return (size_t)1 << log_n; }
     size_t N() const { return (size_t)1 << (log_n + rate_bits); }
     unsigned lde_bits() const { return log_n + rate_bits; }
@@ -184,14 +202,18 @@ void zkm_launch_poseidon_permute(zkm_ctx*, gl_t* states, size_t k);
 void zkm_launch_mul_selftest_branchfree(zkm_ctx*, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);  // stark.hip
 void zkm_launch_keccakf(zkm_ctx*, uint64_t* states, size_t k);
 // leaf digests of a column-major matrix (row j across ncols columns of stride `col_stride` words)
-void zkm_launch_merkle_leaves(zkm_ctx*, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests);
+// nseg > 1: segment s reads lde + s * lde_seg and writes digests + s * dig_seg (blockIdx.z)
+void zkm_launch_merkle_leaves(zkm_ctx*, const gl_t* lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* digests, size_t nseg = 1,
+                              size_t lde_seg = 0, size_t dig_seg = 0);
 // the same digests from column chunks: state = 12 x nrows words kept between the chunks of one matrix (see hash.hip)
 void zkm_launch_merkle_leaves_chunk(zkm_ctx*, const gl_t* lde, size_t nrows, size_t nc, size_t col_stride, gl_t* state, bool first,
                                     bool last, gl_t* digests);
 void zkm_ntt_natural_ex(zkm_ctx* c, const gl_t* in, size_t cs_in, gl_t* scratch, size_t cs_s, gl_t* out, size_t cs_out, size_t ncols,
                         unsigned log_n, bool inverse, uint64_t shift);
 // leaf digests of row-major leaves formed from F2 SoA arrays: leaf k = 16 consecutive (c0,c1) pairs
-void zkm_launch_merkle_leaves_ext(zkm_ctx*, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests);
+// (nseg > 1: segment s reads c0 / c1 + s * val_seg and writes digests + s * dig_seg)
+void zkm_launch_merkle_leaves_ext(zkm_ctx*, const gl_t* c0, const gl_t* c1, size_t nleaves, unsigned arity, gl_t* digests, size_t nseg = 1,
+                                  size_t val_seg = 0, size_t dig_seg = 0);
 void zkm_launch_poseidon_trace(zkm_ctx*, uint64_t seed, const uint64_t* d_inputs, const uint64_t* d_ts, size_t num_perms, unsigned log_n,
                                gl_t* out);
 void zkm_launch_poseidon_sponge_trace(zkm_ctx*, const uint8_t* d_inputs, const uint64_t* d_off, const uint64_t* d_meta,
@@ -200,12 +222,14 @@ void zkm_launch_keccak_sponge_trace(zkm_ctx*, const uint8_t* d_inputs, const uin
                                     const uint64_t* d_row_off, size_t nops, size_t rows_used, unsigned log_n, gl_t* out);
 // build all digest layers above level 0; fills level_off and returns total words needed (call with digests==nullptr to size)
 size_t zkm_merkle_layout(unsigned log_leaves, unsigned cap_height, std::vector<size_t>& level_off);
-void zkm_merkle_build_inner(zkm_ctx*, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height);
-// ... and the cap into cap_out (host, 4 << cap_height words): one launch for small trees (zkm_merkle_tail), levels + download otherwise
+// (nseg trees of the same shape, dig_seg words apart: one launch per group of levels for all of them)
+void zkm_merkle_build_inner(zkm_ctx*, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height,
+                            size_t nseg = 1, size_t dig_seg = 0);
+// ... and the caps into cap_out (host, nseg x (4 << cap_height) words): one launch for small trees (zkm_merkle_tail), levels + download otherwise
 void zkm_merkle_build_inner_cap(zkm_ctx*, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height,
-                                uint64_t* cap_out);
+                                uint64_t* cap_out, size_t nseg = 1, size_t dig_seg = 0);
 bool zkm_merkle_tail(zkm_ctx*, gl_t* digests, const std::vector<size_t>& level_off, unsigned log_leaves, unsigned cap_height, uint64_t* cap_out,
-                     unsigned l0);
+                     unsigned l0, size_t nseg = 1, size_t dig_seg = 0);
 
 // ---- ntt.hip
 // in-place, natural -> bit-reversed order, forward or inverse roots, no scaling
@@ -238,13 +262,14 @@ int zkm_live_contexts();   // contexts of this process that exist right now (zkm
 // the CTL columns of prove_with_traces) instead of being staged inside the batch's LDE buffer.
 // src_cols (optional, instead of src): one pointer per column (each n words, host or device).
 void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t* dev_values = nullptr,
-                     const uint64_t* const* src_cols = nullptr);
+                     const uint64_t* const* src_cols = nullptr, const uint64_t* const* seg_srcs = nullptr);
 zkm_batch* zkm_batch_commit_values_keep(zkm_ctx* c, const uint64_t* values, size_t ncols, unsigned log_n, unsigned rate_bits,
                                         unsigned cap_height, gl_t* dev_values, const uint64_t* const* columns = nullptr);
 // stark.hip: prove_single_table on an existing trace and auxiliary commitment (throws)
 void zkm_prove_single_table_aux(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, size_t ncols, unsigned log_n, const zkm_batch* trace_batch,
                                 const zkm_batch* aux_batch, size_t naux_ctl, const zkm_ctl_table* table, const zkm_ctl_z* zs,
-                                const uint32_t* colset_ids, size_t nzs, const uint64_t* lookup_challenges, zkm_challenger* ch, uint64_t* proof);
+                                const uint32_t* colset_ids, size_t nzs, const uint64_t* lookup_challenges, const std::vector<zkm_challenger*>& chs,
+                                const std::vector<uint64_t*>& proofs);
 void zkm_launch_canon(zkm_ctx* c, gl_t* v, size_t total);   // v[i] = canonical representative of v[i], in place
 void zkm_host_poseidon_permute(uint64_t st[12]);
 void zkm_host_poseidon_permute_reference(uint64_t st[12]);   // poseidon_dev.h compiled for the host (cross-check)
@@ -253,7 +278,7 @@ void zkm_host_poseidon_permute_reference(uint64_t st[12]);   // poseidon_dev.h c
 struct zkm_table_lookup { uint32_t ncols; const uint32_t* cols; uint32_t table_col, freq_col; };
 const zkm_table_lookup* zkm_table_lookups(int table_id, size_t* n);
 void zkm_table_lookup_columns_device(zkm_ctx* c, int table_id, const uint64_t* challenges, size_t nch, const gl_t* d_trace, size_t n,
-                                     gl_t* d_out);
+                                     gl_t* d_out, size_t nseg = 1, size_t trace_seg = 0, size_t out_seg = 0);
 void zkm_launch_sha_extend_trace(zkm_ctx* c, const uint8_t* d_inputs, const uint64_t* d_ts, size_t k, size_t n, gl_t* out);
 void zkm_launch_sha_extend_sponge_trace(zkm_ctx* c, const uint32_t* d_w16, const uint64_t* d_meta, size_t k, size_t n, gl_t* out);
 void zkm_launch_sha_compress_trace(zkm_ctx* c, bool sponge, const uint32_t* d_hx, const uint32_t* d_w, const uint64_t* d_meta, size_t k,
