@@ -73,7 +73,8 @@ void zkm_ctx_trim(zkm_ctx* ctx);
  *                               polling a flag in pinned memory; after this many microseconds (default 50) a thread of a CROWDED
  *                               process -- more than half as many threads waiting as CPUs the process may run on -- parks on a
  *                               blocking-sync event instead, leaving its core to the other contexts.  0: always park.
- *   "debug_fail_allocs"         TEST HOOK: the next `value` device allocations of the context and its lanes fail on their first
+ *   "debug_fail_allocs"         TEST HOOK, accepted only when the process environment holds ZKM_ENABLE_TEST_HOOKS=1 (an unknown key otherwise):
+ *                               the next `value` device allocations of the context and its lanes fail on their first
  *                               attempt as if out of memory, so the recovery path (trim the caches -- this context's, then the
  *                               parent's and the sibling lanes' -- and retry) runs; proofs are unchanged (tests/test_segment.py)
  * An unknown key is an error.  Applies to the context and its commit lanes. */
@@ -453,6 +454,11 @@ int zkm_prove_segment_columns(zkm_ctx* ctx, const zkm_stark_config* cfg, const u
 int zkm_prove_segments(zkm_ctx* ctx, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* traces,
                        const unsigned* const* log_n, const uint64_t* const* public_values, const size_t* npublic, uint64_t* const* proofs_out,
                        uint64_t* const* ctl_challenges_out, char** err);
+/* zkm_prove_segments with one pointer per column: columns[s][t][i] -> column i of table t of segment s (2^log_n[s][t] words) -- K of the
+ * reference's [Vec<PolynomialValues<F>>; NUM_TABLES] (prover.rs:130-142) as they come out of generate_traces, nothing flattened. */
+int zkm_prove_segments_columns(zkm_ctx* ctx, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* const* columns,
+                               const unsigned* const* log_n, const uint64_t* const* public_values, const size_t* npublic,
+                               uint64_t* const* proofs_out, uint64_t* const* ctl_challenges_out, char** err);
 
 /* a10 alone (BASELINE config 4): PolynomialBatch::prove_openings (call site prover.rs:618-628) for the STARK FRI
  * instance (stark.rs:91-148: batches at zeta, g*zeta and 1 over the trace / auxiliary / quotient oracles) on three

@@ -122,6 +122,56 @@ where
     Ok(AllProof { stark_proofs, ctl_challenges, public_values })
 }
 
+/// K independent segments in LOCK-STEP (zkm_prove_segments_columns, include/zkm_hip.h): the reference's driver proves the segments of
+/// a program one after the other (prover/examples/utils/src/utils.rs:57-68, 105-133), each a `prove_with_traces` on its own
+/// transcript; with the traces of K segments at hand (K calls of `generate_traces`, generation/mod.rs:25-76) this proves them in one
+/// library call -- one launch per stage for all segments whose table has the same height -- and returns K `AllProof`s, each word
+/// for word what `prove_with_traces_hip` returns for that segment alone.
+pub fn prove_segments_hip<F, C, const D: usize>(
+    ctx: *mut zkm_ctx,
+    config: &StarkConfig,
+    segments: &[([Vec<PolynomialValues<F>>; NUM_TABLES], PublicValues)],
+) -> Result<Vec<AllProof<F, C, D>>>
+where
+    F: RichField + Extendable<D>,
+    C: GenericConfig<D, F = F>,
+    C::Hasher: Hasher<F, Hash = HashOut<F>>,
+{
+    let cfg = zkm_config(config);
+    let k = segments.len();
+    let pubs: Vec<Vec<u64>> = segments.iter().map(|(_, pv)| public_values_words(pv)).collect();
+    let cols: Vec<Vec<Vec<*const u64>>> = segments.iter().map(|(tr, _)| tr.iter().map(|t| column_ptrs(t)).collect()).collect();
+    let tabs: Vec<Vec<*const *const u64>> = cols.iter().map(|seg| seg.iter().map(|v| v.as_ptr()).collect()).collect();
+    let log_n: Vec<Vec<u32>> = segments.iter().map(|(tr, _)| tr.iter().map(|t| t[0].len().trailing_zeros()).collect()).collect();
+    let mut err = std::ptr::null_mut();
+    // sizing pass per segment (proofs_out = NULL), then ONE proving call for all of them
+    let mut offs = vec![vec![0usize; NUM_TABLES + 1]; k];
+    for s in 0..k {
+        check(unsafe { zkm_prove_segment_columns(std::ptr::null_mut(), &cfg, tabs[s].as_ptr(), log_n[s].as_ptr(), pubs[s].as_ptr(), pubs[s].len(),
+                                         std::ptr::null_mut(), offs[s].as_mut_ptr(), std::ptr::null_mut(), &mut err) }, err)?;
+    }
+    let mut blobs: Vec<Vec<u64>> = offs.iter().map(|o| vec![0u64; o[NUM_TABLES]]).collect();
+    let mut chals: Vec<Vec<u64>> = (0..k).map(|_| vec![0u64; 2 * config.num_challenges]).collect();
+    let seg_ptrs: Vec<*const *const *const u64> = tabs.iter().map(|v| v.as_ptr()).collect();
+    let log_ptrs: Vec<*const u32> = log_n.iter().map(|v| v.as_ptr()).collect();
+    let pub_ptrs: Vec<*const u64> = pubs.iter().map(|v| v.as_ptr()).collect();
+    let pub_lens: Vec<usize> = pubs.iter().map(|v| v.len()).collect();
+    let blob_ptrs: Vec<*mut u64> = blobs.iter_mut().map(|v| v.as_mut_ptr()).collect();
+    let chal_ptrs: Vec<*mut u64> = chals.iter_mut().map(|v| v.as_mut_ptr()).collect();
+    check(unsafe { zkm_prove_segments_columns(ctx, &cfg, k, seg_ptrs.as_ptr(), log_ptrs.as_ptr(), pub_ptrs.as_ptr(), pub_lens.as_ptr(),
+                                      blob_ptrs.as_ptr(), chal_ptrs.as_ptr(), &mut err) }, err)?;
+    Ok(segments.iter().enumerate().map(|(s, (_, pv))| {
+        let stark_proofs: [StarkProofWithMetadata<F, C, D>; NUM_TABLES] =
+            core::array::from_fn(|t| stark_proof_from_blob::<F, C, D>(&blobs[s][offs[s][t]..offs[s][t + 1]]));
+        let ctl_challenges = GrandProductChallengeSet {
+            challenges: (0..config.num_challenges)
+                .map(|c| GrandProductChallenge { beta: F::from_canonical_u64(chals[s][2 * c]), gamma: F::from_canonical_u64(chals[s][2 * c + 1]) })
+                .collect(),
+        };
+        AllProof { stark_proofs, ctl_challenges, public_values: pv.clone() }
+    }).collect())
+}
+
 /// Body of `prove_single_table` (prover.rs:441-641) for the benchmark shape the reference's own tests use
 /// (poseidon_stark.rs:751-816, keccak_stark.rs:689-754): existing trace values, CtlData given as auxiliary columns.
 pub fn prove_single_table_hip<F, C, const D: usize>(

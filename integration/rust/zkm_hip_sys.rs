@@ -161,6 +161,13 @@ extern "C" {
     pub fn zkm_prove_segment_columns(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, columns: *const *const *const u64, log_n: *const c_uint,
                                      public_values: *const u64, npublic: usize, proofs_out: *mut u64, proof_offsets_out: *mut usize,
                                      ctl_challenges_out: *mut u64, err: *mut *mut c_char) -> c_int;
+    // K independent segments in lock-step (include/zkm_hip.h): traces[s][t] / columns[s][t][i], log_n[s][t], one output buffer per segment
+    pub fn zkm_prove_segments(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, nseg: usize, traces: *const *const *const u64,
+                              log_n: *const *const c_uint, public_values: *const *const u64, npublic: *const usize, proofs_out: *const *mut u64,
+                              ctl_challenges_out: *const *mut u64, err: *mut *mut c_char) -> c_int;
+    pub fn zkm_prove_segments_columns(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, nseg: usize, columns: *const *const *const *const u64,
+                                      log_n: *const *const c_uint, public_values: *const *const u64, npublic: *const usize,
+                                      proofs_out: *const *mut u64, ctl_challenges_out: *const *mut u64, err: *mut *mut c_char) -> c_int;
     pub fn zkm_fri_proof_words(cfg: *const zkm_stark_config, log_n: c_uint, oracle_cols: *const usize, noracles: usize) -> usize;
     pub fn zkm_fri_prove(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, oracles: *const *const zkm_batch, noracles: usize,
                          batches: *const zkm_fri_batch, nbatches: usize, challenger: *mut zkm_challenger, proof_out: *mut u64,

@@ -85,7 +85,9 @@ def test_proof_is_bit_exact_2_20(ctx, zkm, oracle_proof_2_20):
     proof bytes, every word.  The oracle's proof comes from the session fixture (computed once, about a minute on 64 host threads);
     the trace is compared through a checksum and a sample (the oracle regenerates it from the seed)."""
     if oracle_proof_2_20 is None:
-        pytest.skip("host has fewer than 32 cores: the 2^20-row oracle proof would take the suite's time limit (2^16 is compared above)")
+        # visible in the summary line ("1 xfailed"), not a silent skip: on such a host the word-for-word claim at 2^20 rows is NOT made
+        pytest.xfail("host shows fewer than 32 CPUs: the 2^20-row oracle proof would take the suite's time limit -- the full-size parity "
+                     "claim is not made on this host (2^16 rows are compared word for word above)")
     log_n = 20
     n = 1 << log_n
     trace_dev = ctx.poseidon_trace(100, n, log_n)             # bench.py's segment 0 (seed 100)

@@ -271,6 +271,10 @@ def test_out_of_memory_retry_while_lanes_are_active(zkm):
     log_n = [int(x) for x in seg["log_n"]]
     traces = [seg["t%d" % i] for i in range(12)]
     c = zkm.Context(0)
+    os.environ.pop("ZKM_ENABLE_TEST_HOOKS", None)
+    with pytest.raises(zkm.ZkmError, match="unknown key"):     # the hook is not a tuning: refused unless the process asked for test hooks
+        c.set_tuning("debug_fail_allocs", 1)
+    os.environ["ZKM_ENABLE_TEST_HOOKS"] = "1"
     try:
         want, wchal, woffs = c.prove_segment(traces, log_n, public_values=[1, 2, 3])     # also fills every cache
         for rounds, k in enumerate((40, 400, 100000)):
@@ -283,6 +287,7 @@ def test_out_of_memory_retry_while_lanes_are_active(zkm):
         live, cached = c.memory()
         assert live == c.resident_bytes()
     finally:
+        os.environ.pop("ZKM_ENABLE_TEST_HOOKS", None)
         c.close()
 
 

@@ -51,6 +51,27 @@ def test_lockstep_segments_equal_single_segment_proofs_and_oracle(ctx, zkm, orac
 
 
 @pytest.mark.gpu
+def test_lockstep_segments_from_column_pointers(ctx, zkm):
+    """zkm_prove_segments_columns: every table of every segment as one pointer per column (K of the reference's
+    [Vec<PolynomialValues<F>>; NUM_TABLES], prover.rs:130-142): the same words as the block form."""
+    from zkm_amd import tables as T
+    segs, col_segs = [], []
+    for v in range(3):
+        tr, lg = _segment(v)
+        segs.append((tr, lg, [9, v]))
+        cols = []
+        for i in range(12):
+            w = T.WIDTH[T.TABLE_ENUM_ORDER[i]]
+            m = tr[i].reshape(w, -1)
+            cols.append([np.ascontiguousarray(m[k]) for k in range(w)])
+        col_segs.append((cols, lg, [9, v]))
+    want = ctx.prove_segments(segs)
+    got = ctx.prove_segments(col_segs)
+    for v in range(3):
+        assert list(got[v][2]) == list(want[v][2]) and (got[v][1] == want[v][1]).all() and (got[v][0] == want[v][0]).all()
+
+
+@pytest.mark.gpu
 def test_lockstep_segments_of_ragged_heights_and_small_stacks(ctx, zkm):
     """Segments whose tables differ in height form one group per height; max_stack splits groups; every stacking gives the words
     of the single-segment path."""

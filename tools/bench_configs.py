@@ -201,11 +201,15 @@ def keccak_sponge_2_20(ctx, log_n=20, reps=3):
     kf_ms = rec_k["keccakf"][1] / rec_k["keccakf"][0]
     return {"workload": "KeccakSpongeStark 470 cols x 2^%d rows: %d seeded random messages (seed 5, lengths uniform in [1, 1088) bytes), %d rows used "
                         "= %d Keccak-f permutations; witness kernel, then from_values; BASELINE.json configs[4]" % (log_n, nops, rows, rows),
-            "witness_ms": witness_s * 1e3, "witness_kernel_ms": kw_ms, "witness_ms_host_inputs": witness_host_s * 1e3,
-            "witness_note": "witness_ms: message bytes resident in HBM (offsets and per-operation words still come from the host: 3.6 MB); "
-                            "witness_ms_host_inputs: the %.0f MB of message bytes start in pageable host memory and are uploaded inside the call" % (data.size / 1e6),
+            # (`witness_ms` keeps the meaning it had through round 3 -- host-resident message bytes, upload on the clock --
+            # and the device-resident variant has its own key, so same-named keys compare like with like across rounds)
+            "witness_ms": witness_host_s * 1e3, "witness_kernel_ms": kw_ms, "witness_ms_device_inputs": witness_s * 1e3,
+            "witness_note": "witness_ms: the %.0f MB of message bytes start in pageable host memory and are uploaded inside the call (the key's "
+                            "meaning in rounds 1-3; round 4 reported the device-resident figure under this name); witness_ms_device_inputs: message "
+                            "bytes resident in HBM (offsets and per-operation words still come from the host: 3.6 MB)" % (data.size / 1e6),
             "keccakf_permutations": rows, "witness_permutations_per_s": rows / (kw_ms / 1e3),
-            "witness_bytes_written": 8 * W * n, "witness_call_GBps": 8 * W * n / witness_s / 1e9,
+            "witness_bytes_written": 8 * W * n, "witness_call_GBps": 8 * W * n / witness_host_s / 1e9,
+            "witness_call_GBps_device_inputs": 8 * W * n / witness_s / 1e9,
             "commit_ms": commit_s * 1e3, "commit_kernel_ms": {k2: round(v[1] / reps, 3) for k2, v in sorted(rec_c.items(), key=lambda kv: -kv[1][1]) if not k2.startswith("stage/")},
             "keccakf_batch": {"states": k, "ms": kf_ms, "permutations_per_s": k / (kf_ms / 1e3), "GBps": 400.0 * k / (kf_ms / 1e3) / 1e9,
                               "frac_of_hbm_peak": 400.0 * k / (kf_ms / 1e3) / 1e9 / HBM_PEAK_GBS}}

@@ -115,6 +115,47 @@ def concurrent_segment_rate(device, log_cycles, nctx, reps=6, tuning=None, cu_pa
     return {"contexts": nctx, "segments_per_context": reps, "segments_per_s": nctx * reps / wall, "ms_per_segment_amortised": wall * 1e3 / (nctx * reps)}
 
 
+def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None):
+    """zkm_prove_segments: `nctx` host threads with one context each, every call proving `stack` independent segments in LOCK-STEP
+    (one launch per stage for all of them; include/zkm_hip.h).  The segments of a call share the tiled traces in HBM and differ in
+    their public values, so every segment has its own transcript, challenges and proof."""
+    import threading
+    import zkm_amd
+    ctxs = [zkm_amd.Context(device) for _ in range(nctx)]
+    for c in ctxs:
+        for k, v in (tuning or {}).items():
+            c.set_tuning(k, v)
+    data = [tiled_segment(c, log_cycles) for c in ctxs]
+    segs = [[(bufs, logs, [1, 2, 3, i, j]) for j in range(stack)] for i, (bufs, logs) in enumerate(data)]
+    for c, sg in zip(ctxs, segs):
+        c.prove_segments(sg)                      # warm-up: allocator, twiddles, power tables
+        c.synchronize()
+    start = threading.Barrier(nctx + 1)
+
+    def work(c, sg):
+        start.wait()
+        for _ in range(reps):
+            c.prove_segments(sg)
+        c.synchronize()
+    th = [threading.Thread(target=work, args=(c, sg)) for c, sg in zip(ctxs, segs)]
+    for t in th:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    mem = [c.memory() for c in ctxs]
+    for c, (bufs, _) in zip(ctxs, data):
+        for b in bufs:
+            b.free()
+        c.close()
+    total = nctx * stack * reps
+    return {"contexts": nctx, "segments_per_call": stack, "calls_per_context": reps, "segments_per_s": total / wall,
+            "ms_per_segment_amortised": wall * 1e3 / total, "ms_per_call": wall * 1e3 / reps, "tuning": tuning or {},
+            "memory_live_cached_GB": [round((m[0] + m[1]) / 2**30, 2) for m in mem]}
+
+
 def multi_process_rate(procs, nctx, reps=8, tuning=""):
     """The same with the contexts in `procs` fresh host processes (tools/bench_segment_procs.py): every process has its own HIP runtime,
     so launches of different processes do not queue behind one another on the host; 1 x k is the deployment shape itself -- a prover
@@ -144,12 +185,40 @@ def throughput_rates(device, contexts=(8, 12, 16)):
     return out
 
 
+def lockstep_rates(device, shapes=((4, 8), (8, 8)), reps=3):
+    """zkm_prove_segments (K segments per call in lock-step; include/zkm_hip.h) in a FRESH process per measurement (tools/sweep_lockstep.py):
+    contexts x segments per call, throughput profile.  With the VALU count of a lock-step segment from profiles/lockstep_valu_latest.json
+    (rocprofv3 --pmc SQ_INSTS_VALU pass of tools/gpu_lockstep_prof.sh, quoted while its code fingerprint matches) every rate also says
+    which fraction of the segment's own VALU-issue budget it is: instructions / (SIMDs x the leaf kernel's measured issue rate)."""
+    import subprocess
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", ZKM_BENCH_DEVICE=str(device))
+    specs = ["%d,%d,throughput_profile=1,reps=%d" % (g, k, reps) for g, k in shapes]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_lockstep.py")] + specs, capture_output=True, text=True, timeout=600, env=env)
+    if r.returncode != 0:
+        raise RuntimeError("sweep_lockstep failed: " + r.stderr[-400:])
+    out = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    try:
+        budget = json.load(open(os.path.join(ROOT, "profiles", "lockstep_valu_latest.json")))
+        from bench import code_fingerprint
+        if budget.get("code_fingerprint") == code_fingerprint():
+            for o in out:
+                if "ms_per_segment_amortised" in o:
+                    o["valu_budget_ms_per_segment"] = budget["budget_ms_per_segment"]
+                    o["valu_budget_frac"] = budget["budget_ms_per_segment"] / o["ms_per_segment_amortised"]
+            out.append({"valu_budget": budget})
+        else:
+            out.append({"valu_budget": "profiles/lockstep_valu_latest.json is stale for this code (fingerprint mismatch) -- rerun tools/gpu_lockstep_prof.sh"})
+    except Exception as e:  # noqa: BLE001
+        out.append({"valu_budget_error": str(e)})
+    return out
+
+
 def small_segment_rate(ctx, device=0):
     out = segment_rate(ctx, 16)
     try:
-        out["concurrent"] = [concurrent_segment_rate(device, 16, k) for k in (2, 4, 8)]
-        out["concurrent_throughput_profile"] = throughput_rates(device)
-        out["concurrent_processes"] = [multi_process_rate(p, k) for p, k in ((1, 8), (2, 4), (4, 2))]
+        out["lockstep"] = lockstep_rates(device)
+        out["concurrent"] = [concurrent_segment_rate(device, 16, k) for k in (4, 8)]
+        out["concurrent_throughput_profile"] = throughput_rates(device, contexts=(16,))
     except Exception as e:  # the single-context figure stands on its own
         out["concurrent_error"] = str(e)
     return out
@@ -162,6 +231,7 @@ if __name__ == "__main__":
     out = segment_rate(c, lc)
     out["memory_live_cached"] = c.memory()
     if lc == 16 and "single" not in sys.argv[2:]:
+        out["lockstep"] = lockstep_rates(0)
         out["concurrent"] = [concurrent_segment_rate(0, 16, k) for k in (2, 4, 8)]
         out["concurrent_throughput_profile"] = throughput_rates(0)
         out["concurrent_processes"] = [multi_process_rate(p, k) for p, k in ((1, 8), (2, 4), (4, 2))]

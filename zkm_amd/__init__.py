@@ -28,7 +28,7 @@ u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
     "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_memory", "zkm_ctx_resident_bytes", "zkm_ctx_trim", "zkm_ctx_set_tuning", "zkm_table_enum_index", "zkm_host_alloc", "zkm_host_free",
-    "zkm_host_register", "zkm_host_unregister", "zkm_all_stark_ctls", "zkm_all_stark_ctl_table", "zkm_prove_segment", "zkm_prove_segments", "zkm_prove_segment_columns", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
+    "zkm_host_register", "zkm_host_unregister", "zkm_all_stark_ctls", "zkm_all_stark_ctl_table", "zkm_prove_segment", "zkm_prove_segments", "zkm_prove_segments_columns", "zkm_prove_segment_columns", "zkm_ctx_synchronize", "zkm_ctx_stream", "zkm_dev_alloc", "zkm_dev_free",
     "zkm_dev_upload", "zkm_dev_download", "zkm_ntt", "zkm_field_selftest", "zkm_batch_commit_values", "zkm_batch_commit_coeffs", "zkm_batch_commit_columns", "zkm_batch_free",
     "zkm_batch_cap", "zkm_batch_coeffs", "zkm_batch_lde_row", "zkm_batch_lde_rows", "zkm_batch_leaf", "zkm_batch_merkle_path",
     "zkm_batch_digest_layer", "zkm_poseidon_permute_batch", "zkm_keccakf_batch", "zkm_poseidon_trace", "zkm_keccak_sponge_trace", "zkm_keccak_trace", "zkm_logic_trace",
@@ -161,6 +161,8 @@ def load():
                                         C.POINTER(C.c_size_t), u64p, err]),
         "zkm_prove_segments": (C.c_int, [cp, C.POINTER(StarkConfig), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), err]),
+        "zkm_prove_segments_columns": (C.c_int, [cp, C.POINTER(StarkConfig), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), err]),
         "zkm_prove_segment_columns": (C.c_int, [cp, C.POINTER(StarkConfig), C.POINTER(C.c_void_p), C.POINTER(C.c_uint), u64p, C.c_size_t, u64p,
                                                 C.POINTER(C.c_size_t), u64p, err]),
         "zkm_host_alloc": (C.c_int, [cp, C.c_size_t, cpp, err]),
@@ -609,16 +611,26 @@ class Context:
         K = len(segments)
         keep, ptr_arrays, log_arrays, pubs, sizes = [], [], [], [], []
         err = C.c_char_p()
+        by_columns = all(isinstance(t, (list, tuple)) for seg in segments for t in seg[0])
+        col_arrays = []
         for traces, log_ns, public_values in segments:
             assert len(traces) == 12 and len(log_ns) == 12
-            k = [t if isinstance(t, DeviceBuffer) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
-            keep.append(k)
-            ptr_arrays.append((C.c_void_p * 12)(*[_data_ptr(t).value for t in k]))
+            if by_columns:       # traces[t] = list of per-column arrays (each its own allocation, like Vec<PolynomialValues<F>>)
+                k = [[c if isinstance(c, DeviceBuffer) else np.ascontiguousarray(c, dtype=np.uint64) for c in t] for t in traces]
+                cols = [(C.c_void_p * len(t))(*[_data_ptr(c).value for c in t]) for t in k]
+                col_arrays.append(cols)
+                keep.append(k)
+                ptr_arrays.append((C.c_void_p * 12)(*[C.addressof(c) for c in cols]))
+            else:
+                k = [t if isinstance(t, DeviceBuffer) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
+                keep.append(k)
+                ptr_arrays.append((C.c_void_p * 12)(*[_data_ptr(t).value for t in k]))
             log_arrays.append((C.c_uint * 12)(*[int(x) for x in log_ns]))
             pubs.append(np.ascontiguousarray(public_values, dtype=np.uint64))
             offs = (C.c_size_t * 13)()
-            _check(self.L.zkm_prove_segment(None, C.byref(cfg), ptr_arrays[-1], log_arrays[-1], pubs[-1].ctypes.data_as(u64p), pubs[-1].size, None,
-                                            offs, None, C.byref(err)), err)
+            sizer = self.L.zkm_prove_segment_columns if by_columns else self.L.zkm_prove_segment
+            _check(sizer(None, C.byref(cfg), ptr_arrays[-1], log_arrays[-1], pubs[-1].ctypes.data_as(u64p), pubs[-1].size, None, offs, None,
+                         C.byref(err)), err)
             sizes.append(list(offs))
         proofs = [np.zeros(o[12], dtype=np.uint64) for o in sizes]
         chals = [np.zeros(2 * cfg.num_challenges, dtype=np.uint64) for _ in range(K)]
@@ -628,7 +640,8 @@ class Context:
         npv = (C.c_size_t * K)(*[p.size for p in pubs])
         po = (C.c_void_p * K)(*[p.ctypes.data for p in proofs])
         co = (C.c_void_p * K)(*[p.ctypes.data for p in chals])
-        _check(self.L.zkm_prove_segments(self.h, C.byref(cfg), K, tr, lg, pv, npv, po, co, C.byref(err)), err)
+        fn = self.L.zkm_prove_segments_columns if by_columns else self.L.zkm_prove_segments
+        _check(fn(self.h, C.byref(cfg), K, tr, lg, pv, npv, po, co, C.byref(err)), err)
         return [(proofs[i], chals[i], sizes[i]) for i in range(K)]
 
     def _prove_segment_columns(self, traces, log_ns, public_values, cfg):

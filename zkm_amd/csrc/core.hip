@@ -59,6 +59,8 @@ void* zkm_ctx::alloc(size_t bytes) {
         e = (inject && (ticket & 1)) ? hipErrorOutOfMemory : hipMalloc(&p, bytes);   // (the hook sends some requests on to the family path)
         if (e != hipSuccess) {
             (void)hipGetLastError();
+            // (root->lanes only grows in ensure_lanes, on the owner's thread BEFORE it starts the lane threads of a call -- never while they
+            // run: iterating it here, from a lane's thread, races with nothing)
             if (root != this) root->trim_self();
             for (zkm_ctx* l : root->lanes)
                 if (l != this) l->trim_self();
@@ -78,7 +80,12 @@ void zkm_ctx::trim_self() {
         drop.swap(free_blocks);                                // from here on nobody can be handed these blocks again ...
     }
     (void)hipStreamSynchronize(stream);                        // ... and what was queued on them before has completed after this
-    if (copy_stream) (void)hipStreamSynchronize(copy_stream);  // (or was the target of an upload in flight)
+    hipStream_t cs;
+    {
+        std::lock_guard<std::mutex> g(alloc_mu);               // (the owner publishes its copy stream under the same lock: zkm_batch_build)
+        cs = copy_stream;
+    }
+    if (cs) (void)hipStreamSynchronize(cs);                    // (or was the target of an upload in flight)
     for (auto& kv : drop) (void)hipFree(kv.second);
 }
 void zkm_ctx::trim() {   // public: between calls (zkm_ctx_trim)
@@ -501,7 +508,12 @@ int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) 
             x->quad_max_hashes = value ? 4096 : 32768;
             x->pow_round_log = value ? 16 : 17;                 // (half-filled SIMDs are somebody else's slots here: 76.3 vs 75.4 segments/s)
         }
-        else if (k == "debug_fail_allocs") { if (x == c) x->debug_fail_allocs.store((int)value); }
+        else if (k == "debug_fail_allocs") {
+            // test hook, not a tuning: only a process that asks for the hooks (ZKM_ENABLE_TEST_HOOKS=1 in its environment) may set it
+            const char* hooks = getenv("ZKM_ENABLE_TEST_HOOKS");
+            if (!hooks || strcmp(hooks, "1") != 0) throw std::runtime_error("zkm_ctx_set_tuning: unknown key '" + k + "'");
+            if (x == c) x->debug_fail_allocs.store((int)value);
+        }
         else throw std::runtime_error("zkm_ctx_set_tuning: unknown key '" + k + "'");
     };
     set(c);
@@ -751,7 +763,12 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
         // split into chunks of CH columns on the copy stream; the compute stream transforms (iNTT, LDE) and ABSORBS chunk k
         // (leaf sponge, hash.hip k_merkle_leaves_chunk) while chunk k + 1 .. are in flight, so PCIe time hides behind hashing.
         // Each chunk is staged in the LDE region of its own columns (or lands in dev_values), so there is no buffer to recycle.
-        if (!c->copy_stream) ZKM_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (!c->copy_stream) {   // (published under the allocator's lock: a relative's out-of-memory path reads it from its own thread)
+            hipStream_t cs = nullptr;
+            ZKM_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            std::lock_guard<std::mutex> g(c->alloc_mu);
+            c->copy_stream = cs;
+        }
         const size_t nchunks = (ncols + CH - 1) / CH;
         std::vector<hipEvent_t> ev;
         ev.reserve(nchunks + 1);

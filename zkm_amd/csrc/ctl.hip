@@ -1016,26 +1016,43 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
     return 0;
 }
 
-int zkm_prove_segments(zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* traces, const unsigned* const* log_n,
-                       const uint64_t* const* pub, const size_t* npub, uint64_t* const* proofs, uint64_t* const* challenges, char** err) {
+// traces[s][t] (one block per table) or columns[s][t][i] (one pointer per column) -- exactly one of the two is non-null
+static int prove_segments_entry(const char* what, zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* traces,
+                                const uint64_t* const* const* const* columns, const unsigned* const* log_n, const uint64_t* const* pub,
+                                const size_t* npub, uint64_t* const* proofs, uint64_t* const* challenges, char** err) {
     try {
-        if (!c || !cfg || !traces || !log_n || !proofs || !challenges) throw std::runtime_error("zkm_prove_segments: null argument");
+        if (!c || !cfg || (!traces && !columns) || !log_n || !proofs || !challenges) throw std::runtime_error(std::string(what) + ": null argument");
         std::vector<std::vector<zkm_table_input>> tables(nseg, std::vector<zkm_table_input>(12));
         std::vector<seg_io> io(nseg);
         for (size_t s = 0; s < nseg; s++) {
-            if (!traces[s] || !log_n[s] || !proofs[s] || !challenges[s]) throw std::runtime_error("zkm_prove_segments: null segment");
-            for (int t = 0; t < 12; t++)
-                tables[s][t] = zkm_table_input{AS_TABLE_IDS[t], traces[s][t], AS_TABLE_WIDTH[t], log_n[s][t], &AS_CTL_TABLES[t], nullptr};
+            if ((traces && !traces[s]) || (columns && !columns[s]) || !log_n[s] || !proofs[s] || !challenges[s])
+                throw std::runtime_error(std::string(what) + ": null segment");
+            for (int t = 0; t < 12; t++) {
+                if (columns && !columns[s][t]) throw std::runtime_error(std::string(what) + ": null table");
+                tables[s][t] = zkm_table_input{AS_TABLE_IDS[t], traces ? traces[s][t] : nullptr, AS_TABLE_WIDTH[t], log_n[s][t], &AS_CTL_TABLES[t],
+                                               columns ? columns[s][t] : nullptr};
+            }
             io[s] = seg_io{tables[s].data(), pub ? pub[s] : nullptr, npub ? npub[s] : 0, proofs[s], challenges[s]};
-            if (io[s].npub && !io[s].pub) throw std::runtime_error("zkm_prove_segments: null public values");
+            if (io[s].npub && !io[s].pub) throw std::runtime_error(std::string(what) + ": null public values");
         }
         prove_segments_impl(c, cfg, nseg, io.data(), 12, AS_CTLS, AS_SIDES, AS_NCTLS);
     } catch (const std::exception& e) {
         return fail(err, e.what());
     } catch (...) {
-        return fail(err, "zkm_prove_segments: unknown error");
+        return fail(err, std::string(what) + ": unknown error");
     }
     return 0;
+}
+
+int zkm_prove_segments(zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* traces, const unsigned* const* log_n,
+                       const uint64_t* const* pub, const size_t* npub, uint64_t* const* proofs, uint64_t* const* challenges, char** err) {
+    return prove_segments_entry("zkm_prove_segments", c, cfg, nseg, traces, nullptr, log_n, pub, npub, proofs, challenges, err);
+}
+
+int zkm_prove_segments_columns(zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* const* columns,
+                               const unsigned* const* log_n, const uint64_t* const* pub, const size_t* npub, uint64_t* const* proofs,
+                               uint64_t* const* challenges, char** err) {
+    return prove_segments_entry("zkm_prove_segments_columns", c, cfg, nseg, nullptr, columns, log_n, pub, npub, proofs, challenges, err);
 }
 
 }  // extern "C"

@@ -527,11 +527,21 @@ bool zkm_merkle_tail(zkm_ctx* c, gl_t* digests, const std::vector<size_t>& level
     if (!c->tree_tail || J == 0 || J > 11 || cap_height > 6) return false;
     // (a first level the tuning gives to the one-lane form -- more parents than both latency thresholds -- stays with the level kernels)
     if (((size_t)1 << (log_leaves - l0 - 1)) > c->quad_max_hashes && ((size_t)1 << (log_leaves - l0 - 1)) > c->wide_max_hashes) return false;
-    static std::atomic<uint64_t> lds_ok{0};
-    const uint64_t bit = (uint64_t)1 << (c->device & 63);
-    if (!(lds_ok.load(std::memory_order_acquire) & bit)) {
-        ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_merkle_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // (96 KB at J = 11; the static table of the quad form comes on top)
-        lds_ok.fetch_or(bit, std::memory_order_release);
+    // LDS: two level buffers of C and C / 2 digests (6 KB at the usual J = 7, 96 KB at J = 11) next to the static table of the quad form.
+    // Only a launch beyond the default 64 KB needs the raised limit; a part that cannot grant it keeps the level kernels.
+    const size_t tail_lds = (((size_t)1 << J) * 4 + ((size_t)1 << J) * 2) * sizeof(uint64_t);
+    if (tail_lds + ZKM_QUAD_TAB_WORDS * sizeof(uint32_t) > 64 * 1024) {
+        static std::atomic<uint64_t> lds_ok{0}, lds_bad{0};
+        const uint64_t bit = (uint64_t)1 << (c->device & 63);
+        if (lds_bad.load(std::memory_order_acquire) & bit) return false;
+        if (!(lds_ok.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void*)k_merkle_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
+                (void)hipGetLastError();
+                lds_bad.fetch_or(bit, std::memory_order_release);
+                return false;
+            }
+            lds_ok.fetch_or(bit, std::memory_order_release);
+        }
     }
     merkle_tail_args a{};
     a.children = digests + level_off[l0];
