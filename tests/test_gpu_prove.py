@@ -412,3 +412,25 @@ def test_tuning_single_launch_small_paths_agree(zkm, oracle, log_n, W):
         live, _ = c.memory()
         assert live == c.resident_bytes(), key          # (the tail kernel's ticket word is resident, nothing else stays behind)
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arity_bits,final_poly_bits,log_n", [(2, 3, 9), (3, 2, 10), (5, 4, 12), (6, 0, 13), (5, 5, 11)])
+def test_every_admitted_fri_arity_proves_like_the_oracle(ctx, zkm, oracle, arity_bits, final_poly_bits, log_n):
+    """validate_config admits arity_bits 2 .. 6, and the LDS-tiled fold kernel of round 4 stopped at arity 16 -- a config with
+    arity_bits 5 or 6 passed validation and failed after all commitments.  The fold tile is now sized by the arity (dynamic LDS): every
+    admitted arity proves, word for word like the oracle (FriReductionStrategy::ConstantArityBits, config.rs:25), and verifies."""
+    n = 1 << log_n
+    cfg = ctx.standard_config()
+    cfg.arity_bits, cfg.final_poly_bits = arity_bits, final_poly_bits
+    ocfg = oracle.standard_config()
+    ocfg.arity_bits, ocfg.final_poly_bits = arity_bits, final_poly_bits
+    trace_dev = ctx.poseidon_trace(seed=40 + arity_bits, num_perms=n - 5, log_n=log_n)
+    trace = trace_dev.download()
+    aux = np.zeros(4 * n, dtype=np.uint64)
+    got = ctx.prove_single_table(trace_dev, log_n, aux, [1, 1], cfg=cfg)
+    want = oracle.prove(trace, log_n, aux, [1, 1], cfg=ocfg)
+    assert got.size == want.size and (got == want).all()
+    assert oracle.verify(got, 4, [1, 1], cfg=ocfg) == 0
+    assert int(got[11]) == arity_bits
+    trace_dev.free()

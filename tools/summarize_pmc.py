@@ -54,6 +54,13 @@ if "FETCH_SIZE" in ml and "WRITE_SIZE" in ml:
             # GPU cycles of the launch (the counter is summed over the 8 XCDs) over its duration in the kernel-trace pass: the clock the
             # kernel really ran at, which is what its issue fractions should be taken against (nominal: 2.4 GHz)
             latest["k_merkle_leaves"]["clock_ghz_measured"] = ml["GRBM_GUI_ACTIVE"]["max"] / 8 / st["max_ns"]
+# the whole proof against the VALU-issue roof: wave-level VALU instructions of every kernel, per proof
+valu_all = sum(v["pmc"]["SQ_INSTS_VALU"]["sum"] for k, v in res.items() if "SQ_INSTS_VALU" in v.get("pmc", {}))
+if valu_all:
+    latest["whole_proof"] = {"valu_insts_per_proof": valu_all / proofs,
+                             "valu_insts_per_proof_by_kernel": {k: v["pmc"]["SQ_INSTS_VALU"]["sum"] / proofs for k, v in sorted(
+                                 res.items(), key=lambda kv: -kv[1].get("pmc", {}).get("SQ_INSTS_VALU", {}).get("sum", 0))[:12]
+                                 if "SQ_INSTS_VALU" in v.get("pmc", {})}}
 is_ntt = lambda k: "k_ntt_" in k or "k_lde_upper" in k   # every NTT / LDE kernel of ntt.hip
 fetch = sum(v["pmc"]["FETCH_SIZE"]["sum"] for k, v in res.items() if is_ntt(k) and "FETCH_SIZE" in v.get("pmc", {}))
 write = sum(v["pmc"]["WRITE_SIZE"]["sum"] for k, v in res.items() if is_ntt(k) and "WRITE_SIZE" in v.get("pmc", {}))
