@@ -513,6 +513,18 @@ int zkm_prove_segment_image(zkm_ctx* ctx, const zkm_stark_config* cfg, const uin
 
 int zkm_quotient(zkm_ctx* ctx, int table_id, const zkm_batch* trace, const zkm_batch* aux, const uint32_t* num_helpers,
                  size_t nctl_zs, const uint64_t* alphas, size_t nalphas, uint64_t* out_coeffs, char** err);
+/* check_constraints (prover.rs:793-910; the reference calls it under debug assertions, :529-541): evaluate the table's whole vanishing
+ * polynomial -- table constraints, the table's lookups, the cross-table-lookup checks, in eval_vanishing_poly's order
+ * (vanishing_poly.rs:17-46) -- on every row of the TRACE DOMAIN (rate_bits = 0: row i with next row i + 1 mod n, the Lagrange selectors
+ * are the indicators of the first / last row) with the given constraint challenges, and report whether every accumulator vanishes.
+ *   trace   ncols x 2^log_n trace values          aux   naux x 2^log_n auxiliary values: the table's lookup helper columns (zkm_num_lookup_columns,
+ *           as zkm_lookup_helper_columns makes them per challenge), then the CTL helper columns and Zs (zkm_ctl_data) -- prover.rs:497-508 order
+ *   table / zs / colset_ids / nzs, lookup_challenges   as zkm_prove_single_table_ctl
+ * Returns 0 and *first_failing_row = ~0 when all constraints hold; nonzero with the reference's message "Constraint failed in <Stark>"
+ * and the first failing row otherwise.  A debugging aid: not on the proving path. */
+int zkm_check_constraints(zkm_ctx* ctx, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t ncols, unsigned log_n,
+                          const uint64_t* aux, size_t naux, const zkm_ctl_table* table, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs,
+                          const uint64_t* lookup_challenges, const uint64_t* alphas, size_t nalphas, uint64_t* first_failing_row, char** err);
 /* a9: StarkOpeningSet::new building block (proof.rs:299-334): p(zeta) in F2 for every polynomial of the
  * batch; out = ncols x 2 words, host. */
 int zkm_eval_openings(zkm_ctx* ctx, const zkm_batch* b, const uint64_t zeta[2], uint64_t* out, char** err);

@@ -185,6 +185,11 @@ extern "C" {
     pub fn zkm_quotient(ctx: *mut zkm_ctx, table_id: c_int, trace: *const zkm_batch, aux: *const zkm_batch, num_helpers: *const u32, nctl_zs: usize,
                         alphas: *const u64, nalphas: usize, out_coeffs: *mut u64, err: *mut *mut c_char) -> c_int;
     pub fn zkm_eval_openings(ctx: *mut zkm_ctx, b: *const zkm_batch, zeta: *const u64, out: *mut u64, err: *mut *mut c_char) -> c_int;
+    // check_constraints (prover.rs:793-910): debugging aid, rc != 0 + "Constraint failed in <Stark>" and the first failing row
+    pub fn zkm_check_constraints(ctx: *mut zkm_ctx, table_id: c_int, cfg: *const zkm_stark_config, trace: *const u64, ncols: usize, log_n: c_uint,
+                                 aux: *const u64, naux: usize, table: *const zkm_ctl_table, zs: *const zkm_ctl_z, colset_ids: *const u32,
+                                 nzs: usize, lookup_challenges: *const u64, alphas: *const u64, nalphas: usize, first_failing_row: *mut u64,
+                                 err: *mut *mut c_char) -> c_int;
     // profiling
     pub fn zkm_profile_enable(ctx: *mut zkm_ctx, on: c_int);
     pub fn zkm_profile_reset(ctx: *mut zkm_ctx);

@@ -149,3 +149,67 @@ def test_error_in_a_table_proof_while_lanes_build_later_commitments(ctx, zkm, or
         got, chal, offs = ctx.prove_with_traces(tables, ctls)
         assert offs == woffs and (chal == wchal).all() and (got == want).all()
     ctx.set_tuning("aux_pipeline", 1)
+
+
+def test_check_constraints_entry_point(ctx, zkm, oracle):
+    """zkm_check_constraints == check_constraints (prover.rs:793-910): the whole vanishing polynomial (table constraints, CTL checks) on
+    every row of the trace domain.  A valid table with its real CTL data passes; a corrupted trace cell fails at the row the oracle's
+    constraint debugger names; a corrupted Z column fails the CTL checks although the table constraints hold."""
+    log_n = 8
+    n = 1 << log_n
+    trace = oracle.poseidon_trace(4, n - 7, log_n)
+    t, a, m, nx = rich_table()
+    zs, ids = make_zs([([a, m, m], 3, 5), ([a], 7, 11), ([m, nx], 13, 17), ([nx], 29, 31)])
+    aux = ctx.ctl_data(t, zs, ids, trace, 262, log_n)
+    alphas = [0x1234567 % P, 0xFEDCBA9876543210 % P]
+    assert ctx.check_constraints(trace, log_n, aux, t, zs, ids, alphas) is None
+    assert ctx.check_constraints(trace, log_n, aux, t, zs, ids, alphas[:1]) is None
+    # a corrupted trace cell: the first failing row is the oracle debugger's
+    bad = trace.copy()
+    r = 37
+    bad.reshape(262, n)[20][r] ^= 1
+    count, where = oracle.debug_constraints(0, bad, 262, log_n)
+    assert where is not None
+    got = ctx.check_constraints(bad, log_n, aux, t, zs, ids, alphas)
+    assert got is not None and got <= where[0] and got >= r - 1       # (the CTL checks read the same cell and may fire one row earlier)
+    # a corrupted running sum: only the cross-table checks see it
+    aux2 = aux.copy()
+    naux = aux.size >> log_n
+    aux2.reshape(naux, n)[naux - 1][100] = (int(aux2.reshape(naux, n)[naux - 1][100]) + 1) % P
+    got = ctx.check_constraints(trace, log_n, aux2, t, zs, ids, alphas)
+    assert got in (99, 100)
+    # the benchmark's fake CTL shape (helper columns, no column sets; poseidon_stark.rs:786-799) on the GPU witness
+    tr = ctx.poseidon_trace(seed=3, num_perms=n - 2, log_n=log_n)
+    assert ctx.check_constraints(tr, log_n, np.zeros(4 * n, dtype=np.uint64), None, [1, 1], None, alphas) is None
+    tr.free()
+
+
+def test_check_constraints_on_a_table_with_lookups(ctx, zkm, oracle):
+    """MemoryStark: its range-check lookup columns (memory_stark.rs:476-483: RANGE_CHECK looked up in COUNTER with FREQUENCIES) come
+    first among the auxiliary columns, per challenge helper column then Z (prover.rs:475-508)."""
+    from zkm_amd import tables as T
+    from zkm_amd.ctl import make_zs
+    from .test_oracle_tables import random_memory_ops
+    log_n = 8
+    n = 1 << log_n
+    trace, natural = oracle.memory_trace(random_memory_ops(log_n, 200), log_n)
+    assert natural == n
+    t = CtlTable()
+    cs = T.memory_ctl_data(t)
+    zs, ids = make_zs([([cs], 3, 5), ([cs], 7, 11)])
+    ctl_aux = ctx.ctl_data(t, zs, ids, trace, 13, log_n)
+    betas = [3, 7]                                     # the lookup challenges are the betas of the CTL challenges (prover.rs:468-474)
+    lt = CtlTable()
+    looking = lt.colset([lt.single(10)])
+    table_col, freq_col = lt.single(11), lt.single(12)
+    lk = [ctx.lookup_helper_columns(lt, [looking], table_col, freq_col, b, trace, 13, log_n) for b in betas]
+    aux = np.concatenate(lk + [ctl_aux])
+    assert aux.size == (4 + 2) * n
+    alphas = [5, 7]
+    assert ctx.check_constraints(trace, log_n, aux, t, zs, ids, alphas, ncols=13, table_id=T.TABLE_MEMORY, lookup_challenges=betas) is None
+    aux2 = aux.copy()
+    aux2[3] = (int(aux2[3]) + 1) % P                   # a helper value of the first lookup challenge
+    got = ctx.check_constraints(trace, log_n, aux2, t, zs, ids, alphas, ncols=13, table_id=T.TABLE_MEMORY, lookup_challenges=betas)
+    assert got in (2, 3)
+    with pytest.raises(zkm.ZkmError, match="lookup challenges"):
+        ctx.check_constraints(trace, log_n, aux, t, zs, ids, alphas, ncols=13, table_id=T.TABLE_MEMORY)

@@ -115,7 +115,7 @@ def concurrent_segment_rate(device, log_cycles, nctx, reps=6, tuning=None, cu_pa
     return {"contexts": nctx, "segments_per_context": reps, "segments_per_s": nctx * reps / wall, "ms_per_segment_amortised": wall * 1e3 / (nctx * reps)}
 
 
-def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None):
+def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, host=False):
     """zkm_prove_segments: `nctx` host threads with one context each, every call proving `stack` independent segments in LOCK-STEP
     (one launch per stage for all of them; include/zkm_hip.h).  The segments of a call share the tiled traces in HBM and differ in
     their public values, so every segment has its own transcript, challenges and proof."""
@@ -126,6 +126,19 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None):
         for k, v in (tuning or {}).items():
             c.set_tuning(k, v)
     data = [tiled_segment(c, log_cycles) for c in ctxs]
+    pinned = []
+    if host:
+        # the deployed input: traces in (pinned) HOST memory, as the CPU witness generator leaves them (generation/mod.rs:25-76) -- every
+        # call uploads its segments' ~0.3 GB each inside the clock; the contexts' uploads overlap each other's kernels
+        for i, (c, (bufs, logs)) in enumerate(zip(ctxs, data)):
+            hb = []
+            for b_ in bufs:
+                h = c.pinned_array(b_.words)
+                h[:] = b_.download()
+                b_.free()
+                hb.append(h)
+            pinned.append((c, hb))
+            data[i] = (hb, logs)
     segs = [[(bufs, logs, [1, 2, 3, i, j]) for j in range(stack)] for i, (bufs, logs) in enumerate(data)]
     for c, sg in zip(ctxs, segs):
         c.prove_segments(sg)                      # warm-up: allocator, twiddles, power tables
@@ -146,12 +159,16 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None):
         t.join()
     wall = time.perf_counter() - t0
     mem = [c.memory() for c in ctxs]
+    for c, hb in pinned:
+        for h in hb:
+            c.free_pinned(h)
     for c, (bufs, _) in zip(ctxs, data):
-        for b in bufs:
-            b.free()
+        if not host:
+            for b in bufs:
+                b.free()
         c.close()
     total = nctx * stack * reps
-    return {"contexts": nctx, "segments_per_call": stack, "calls_per_context": reps, "segments_per_s": total / wall,
+    return {"contexts": nctx, "segments_per_call": stack, "calls_per_context": reps, "segments_per_s": total / wall, "traces": "pinned host memory" if host else "HBM",
             "ms_per_segment_amortised": wall * 1e3 / total, "ms_per_call": wall * 1e3 / reps, "tuning": tuning or {},
             "memory_live_cached_GB": [round((m[0] + m[1]) / 2**30, 2) for m in mem]}
 

@@ -38,7 +38,7 @@ EXPORTS = [
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
     "zkm_prove_single_table", "zkm_prove_openings", "zkm_fri_prove", "zkm_fri_proof_words", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
     "zkm_proof_get_layout", "zkm_proof_get_query_layout", "zkm_segment_image_words", "zkm_segment_image_write", "zkm_prove_segment_image",
-    "zkm_quotient", "zkm_eval_openings", "zkm_profile_enable", "zkm_profile_reset",
+    "zkm_quotient", "zkm_eval_openings", "zkm_check_constraints", "zkm_profile_enable", "zkm_profile_reset",
     "zkm_profile_count", "zkm_profile_get", "zkm_version",
 ]
 
@@ -200,6 +200,8 @@ def load():
                                               C.POINTER(C.c_size_t), u64p, err]),
         "zkm_quotient": (C.c_int, [cp, C.c_int, cp, cp, C.POINTER(C.c_uint32), C.c_size_t, u64p, C.c_size_t, cp, err]),
         "zkm_eval_openings": (C.c_int, [cp, cp, u64p, u64p, err]),
+        "zkm_check_constraints": (C.c_int, [cp, C.c_int, C.POINTER(StarkConfig), cp, C.c_size_t, C.c_uint, cp, C.c_size_t, cp, cp, cp, C.c_size_t,
+                                            u64p, u64p, C.c_size_t, u64p, err]),
         "zkm_profile_enable": (None, [cp, C.c_int]),
         "zkm_profile_reset": (None, [cp]),
         "zkm_profile_count": (C.c_size_t, [cp]),
@@ -558,6 +560,35 @@ class Context:
                                                  None if lk is None else lk.ctypes.data_as(u64p), C.byref(ch),
                                                  proof.ctypes.data_as(u64p), C.byref(err)), err)
         return proof
+
+    def check_constraints(self, trace, log_n, aux, ctl_table, zs, colset_ids, alphas, cfg=None, ncols=POSEIDON_COLS, table_id=TABLE_POSEIDON,
+                          lookup_challenges=None):
+        """check_constraints (prover.rs:793-910): the table's whole vanishing polynomial on every row of the trace domain.  aux = all
+        auxiliary columns (lookup helper columns ++ CTL helper columns ++ Zs).  Returns None when every constraint holds, else the
+        first failing row."""
+        cfg = cfg or self.standard_config()
+        naux = (aux.size if isinstance(aux, np.ndarray) else aux.words) >> log_n
+        al = np.ascontiguousarray(alphas, dtype=np.uint64)
+        lk = None if lookup_challenges is None else np.ascontiguousarray(lookup_challenges, dtype=np.uint64)
+        first = C.c_uint64(0)
+        err = C.c_char_p()
+        if ctl_table is not None:
+            st = ctl_table.pack()
+            tp, zp, ip, nz = C.addressof(st), zs.ctypes.data, colset_ids.ctypes.data, len(zs)
+        else:     # fake CTL shape: zs = num_helpers list
+            from . import ctl as zc
+            z = np.zeros(len(zs), dtype=zc.CTLZ_DT)
+            z["num_helpers"] = zs
+            tp, zp, ip, nz = None, z.ctypes.data, None, len(zs)
+        rc = self.L.zkm_check_constraints(self.h, table_id, C.byref(cfg), _data_ptr(trace), ncols, log_n, _data_ptr(aux), naux, tp, zp, ip, nz,
+                                          None if lk is None else lk.ctypes.data_as(u64p), al.ctypes.data_as(u64p), al.size, C.byref(first),
+                                          C.byref(err))
+        if rc == 0:
+            return None
+        msg = err.value.decode() if err.value else ""
+        if "Constraint failed" not in msg:
+            _check(rc, err)
+        return int(first.value)
 
     def prove_with_traces(self, tables, ctls, public_values=(), cfg=None):
         """prove_with_traces (prover.rs:130-232).  tables: list of (table_id, trace (ndarray | DeviceBuffer), ncols, log_n, CtlTable);

@@ -136,10 +136,23 @@ struct quotient_point {
 // copy, no upload per table.  Every quotient kernel takes its segment from blockIdx.z: the segment's columns start W N (trace) / A N
 // (auxiliary) words after the previous segment's, its outputs NA * size words.
 typedef seg_gl2 alpha_args;
+// check mode (zkm_check_constraints == check_constraints, prover.rs:793-910, rate_bits = 0): the "LDE" is the trace itself, N = n rows in
+// natural order, point j = w_n^j (wpow: the table of w_n), next row j + 1 mod n, and the Lagrange selectors are the indicator values
+// of rows 0 and n - 1 -- signalled by gn == 0 (g^n is never 0 on the coset).
 template <int NA>
 __device__ __forceinline__ quotient_point quotient_setup(size_t j, unsigned lde_bits, const gl_t* __restrict__ alphas, const gl_t* __restrict__ wpow,
                                                          gl_t gn, gl_t last, gl_t w_n, gl_t n_inv, consumer_t<NA>& k) {
     const size_t N = (size_t)1 << lde_bits;
+    if (gn == 0) {
+        const unsigned h = (lde_bits + 1) / 2;
+        const gl_t x = gl_mul_loose(wpow[j & ((1u << h) - 1)], wpow[((size_t)1 << h) + (j >> h)]);
+#pragma unroll
+        for (int a = 0; a < NA; a++) { k.alpha[a] = alphas[a]; k.acc[a] = 0; }
+        k.z_last = gl_sub(x, last);
+        k.l_first = j == 0 ? 1 : 0;
+        k.l_last = j == N - 1 ? 1 : 0;
+        return quotient_point{j, (j + 1) & (N - 1), (uint32_t)j};
+    }
     uint32_t t = bitrev32((uint32_t)j, lde_bits);  // natural index in the 4n domain (even)
     uint32_t i = t >> 1;                           // natural index in the 2n quotient domain
     uint32_t tn = (t + 4) & (uint32_t)(N - 1);
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(256, (TABLE == ZKM_TABLE_CPU || TABLE == ZKM_TABLE_
                                                            size_t aux_seg) {
     const gl_t* const alphas = alphas_v.v + 2 * blockIdx.z;
     size_t N = (size_t)1 << lde_bits;
-    size_t size = N >> 1;
+    size_t size = gn == 0 ? N : N >> 1;       // (check mode: every row of the trace)
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= size) return;
     trace += (size_t)blockIdx.z * trace_seg;
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(256) void k_quotient_ctl(const gl_t* __restrict__ t
                                                       size_t trace_seg, size_t aux_seg) {
     const gl_t* const alphas = alphas_v.v + 2 * blockIdx.z;
     size_t N = (size_t)1 << lde_bits;
-    size_t size = N >> 1;
+    size_t size = gn == 0 ? N : N >> 1;
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= size) return;
     trace += (size_t)blockIdx.z * trace_seg;
@@ -293,8 +306,10 @@ __global__ __launch_bounds__(256) void k_quotient_ctl_sum(const gl_t* __restrict
 
 // quotient polys: d_out = nalphas x 2n natural-order coefficients (device) -- per segment of the stack (trace / aux: stacked batches of
 // the same nseg; alphas_host: nseg x nalphas; lookup_challenges: nseg x nalphas; own: a description with nseg lists of CtlZData)
+// check = true (zkm_check_constraints): trace / aux describe the VALUES (lde = ncols x n values, rate_bits 0) and d_out receives the
+// alpha-accumulated constraint values of every row, nalphas x n, instead of quotient coefficients.
 static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_batch* aux, const ctl_dev_owner& own,
-                            const uint64_t* lookup_challenges, const gl_t* alphas_host, size_t nalphas, gl_t* d_out) {
+                            const uint64_t* lookup_challenges, const gl_t* alphas_host, size_t nalphas, gl_t* d_out, bool check = false) {
     lookup_dev lookups{};
     seg_gl2 lookup_ch{};
     uint32_t NL = 0;
@@ -321,18 +336,18 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
     }
     if (zkm_table_width(table_id) == 0 || trace->ncols != zkm_table_width(table_id))
         throw std::runtime_error("zkm_quotient: unknown table id, or the trace width does not match the table");
-    if (trace->rate_bits != 2 || aux->rate_bits != 2 || trace->log_n != aux->log_n)
+    if (trace->rate_bits != (check ? 0u : 2u) || aux->rate_bits != trace->rate_bits || trace->log_n != aux->log_n)
         throw std::runtime_error("zkm_quotient: rate_bits must be 2 and the batches must have equal degree");
     if (nalphas < 1 || nalphas > 2) throw std::runtime_error("zkm_quotient: 1 or 2 challenges supported");
     if (own.naux + NL != aux->ncols) throw std::runtime_error("zkm_quotient: aux column count does not match the CTL description");
     const ctl_dev& ctl = own.d;
-    unsigned log_n = trace->log_n, lde_bits = log_n + 2, log_q = log_n + 1;
+    unsigned log_n = trace->log_n, lde_bits = check ? log_n : log_n + 2, log_q = check ? log_n : log_n + 1;
     size_t size = (size_t)1 << log_q;
     const size_t trace_seg = trace->lde_seg(), aux_seg = aux->lde_seg();
     gl_t w4 = gl_root_of_unity(lde_bits);
     const gl_t* wpow = c->pow_table(w4, lde_bits);
-    gl_t gn = gl_exp_pow2(GL_GENERATOR, log_n);
-    gl_t zh0 = gl_inv(gl_sub(gn, 1)), zh1 = gl_inv(gl_sub(gl_neg(gn), 1));
+    gl_t gn = check ? 0 : gl_exp_pow2(GL_GENERATOR, log_n);      // (0: the kernels' check mode, quotient_setup)
+    gl_t zh0 = check ? 1 : gl_inv(gl_sub(gn, 1)), zh1 = check ? 1 : gl_inv(gl_sub(gl_neg(gn), 1));
     gl_t w_n = gl_root_of_unity(log_n), last = gl_inv(w_n);
     gl_t n_inv = gl_inv((gl_t)(((uint64_t)1 << log_n) % GL_P));
     alpha_args d_alphas{};
@@ -347,7 +362,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
 #define ZKM_LAUNCH_QUOTIENT(T, NA)                                                                                              \
     hipLaunchKernelGGL((k_quotient<T, NA>), grid, block, 0, c->stream, trace->lde, aux->lde, log_n, lde_bits, lookups, d_alphas, lookup_ch, wpow, gn, \
                        last, w_n, n_inv, d_vals, trace_seg, aux_seg)
-        if (table_id == ZKM_TABLE_KECCAK && size * nseg <= c->keccak_parts_max_points) {
+        if (table_id == ZKM_TABLE_KECCAK && size * nseg <= c->keccak_parts_max_points && !check) {
             // short table: 25 threads per point, then the sum of the parts (constraints_dev.h)
             const size_t per = nalphas * (KECCAK_NUM_CONSTRAINTS + 1);
             std::vector<gl_t> apw(nseg * per);
@@ -426,7 +441,7 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             hstart += own.h_zs[zi].num_helpers;
         }
         for (size_t i = 0; i < plan.size(); i++) plan[i].tail = K - kend[i];
-        const bool chunked = plan.size() >= (short_table ? 2u : 8u) && size * nseg <= ((size_t)1 << 18);
+        const bool chunked = plan.size() >= (short_table ? 2u : 8u) && size * nseg <= ((size_t)1 << 18) && !check;
         if (!chunked) {
             if (nalphas == 1)
                 hipLaunchKernelGGL((k_quotient_ctl<1>), grid, block, 0, c->stream, trace->lde, aux->lde, lde_bits, ctl, NL, d_alphas, wpow, gn, zh0, zh1,
@@ -455,6 +470,11 @@ static void quotient_device(zkm_ctx* c, int table_id, const zkm_batch* trace, co
             c->release(d_tmp);
         }
         ZKM_HIP_CHECK(hipGetLastError());
+    }
+    if (check) {
+        ZKM_HIP_CHECK(hipMemcpyAsync(d_out, d_vals, nseg * nalphas * size * sizeof(gl_t), hipMemcpyDeviceToDevice, c->stream));
+        c->release(d_vals);
+        return;
     }
     // coset_ifft(g) of each challenge's evaluations (prover.rs:784-788)
     zkm_ntt_natural(c, d_vals, d_out, nseg * nalphas, size, size, log_q, true, GL_GENERATOR);
@@ -1798,6 +1818,68 @@ int zkm_quotient(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_bat
             c->download(out_coeffs, d, words * 8);
         }
     } catch (const std::exception& e) {
+        return fail(err, e.what());
+    }
+    return 0;
+}
+
+// first row (of n) at which any of the nalphas accumulators is nonzero, into *first (left untouched if none): one pass
+__global__ __launch_bounds__(256) void k_first_nonzero_row(const gl_t* __restrict__ acc, size_t n, unsigned nalphas, unsigned long long* first) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool bad = false;
+    for (unsigned a = 0; a < nalphas; a++) bad = bad || gl_canon(acc[(size_t)a * n + i]) != 0;
+    if (bad) atomicMin(first, (unsigned long long)i);
+}
+
+int zkm_check_constraints(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, const uint64_t* trace, size_t ncols, unsigned log_n,
+                          const uint64_t* aux, size_t naux, const zkm_ctl_table* table, const zkm_ctl_z* zs, const uint32_t* colset_ids, size_t nzs,
+                          const uint64_t* lookup_challenges, const uint64_t* alphas, size_t nalphas, uint64_t* first_failing_row, char** err) {
+    std::vector<void*> tmp;
+    if (!c || !cfg || !trace || !aux || !alphas || !first_failing_row) return fail(err, "zkm_check_constraints: null argument");
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        validate_config(cfg, log_n);
+        if (nalphas < 1 || nalphas > 2) throw std::runtime_error("zkm_check_constraints: 1 or 2 challenges supported");
+        for (size_t a = 0; a < nalphas; a++)
+            if (alphas[a] >= GL_P) throw std::runtime_error("zkm_check_constraints: non-canonical challenge");
+        const size_t n = (size_t)1 << log_n;
+        // the values stand where the quotient kernels expect an LDE: "batches" of rate 0 over device copies of the caller's columns
+        zkm_batch tb, ab;
+        tb.ctx = ab.ctx = c; tb.ncols = ncols; ab.ncols = naux; tb.log_n = ab.log_n = log_n; tb.rate_bits = ab.rate_bits = 0;
+        auto on_device = [&](const uint64_t* p, size_t words) -> gl_t* {
+            gl_t* d = (gl_t*)c->alloc(words * sizeof(gl_t));
+            tmp.push_back(d);
+            ZKM_HIP_CHECK(hipMemcpyAsync(d, p, words * sizeof(gl_t), hipMemcpyDefault, c->stream));
+            zkm_launch_canon(c, d, words);
+            return d;
+        };
+        tb.lde = on_device(trace, ncols * n);
+        ab.lde = on_device(aux, naux * n);
+        ctl_dev_owner own;
+        own.upload(c, table, zs, colset_ids, nzs, false, ncols);
+        gl_t* d_acc = (gl_t*)c->alloc(nalphas * n * sizeof(gl_t));
+        tmp.push_back(d_acc);
+        quotient_device(c, table_id, &tb, &ab, own, lookup_challenges, alphas, nalphas, d_acc, /*check=*/true);
+        unsigned long long* d_first = (unsigned long long*)c->alloc(8);
+        tmp.push_back(d_first);
+        ZKM_HIP_CHECK(hipMemsetAsync(d_first, 0xff, 8, c->stream));
+        hipLaunchKernelGGL(k_first_nonzero_row, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_acc, n, (unsigned)nalphas, d_first);
+        ZKM_HIP_CHECK(hipGetLastError());
+        unsigned long long first = ~0ULL;
+        c->download(&first, d_first, 8);
+        for (void* q : tmp) c->release(q);
+        tmp.clear();
+        *first_failing_row = first;
+        if (first != ~0ULL) {
+            static const char* const names[] = {"PoseidonStark", "LogicStark", "KeccakSpongeStark", "KeccakStark", "MemoryStark", "PoseidonSpongeStark",
+                                                "ShaExtendStark", "ShaExtendSpongeStark", "ShaCompressStark", "ShaCompressSpongeStark", "ArithmeticStark",
+                                                "CpuStark"};
+            return fail(err, std::string("Constraint failed in ") + names[table_id] + " (first failing row " + std::to_string(first) + ")");   // prover.rs:903-908
+        }
+    } catch (const std::exception& e) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* q : tmp) c->release(q);
         return fail(err, e.what());
     }
     return 0;
