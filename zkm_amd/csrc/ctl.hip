@@ -119,19 +119,50 @@ __global__ __launch_bounds__(256) void k_ctl_terms(ctl_dev d, uint32_t zi0, cons
     const gl_t* lv = trace + row;
     bool next_ok = row + 1 < n;
     gl_t total = 0;
-    for (uint32_t j = 0; 2 * j < z.ncolsets; j++) {
-        gl_t h = 0;
-        for (uint32_t e = 0; e < 2 && 2 * j + e < z.ncolsets; e++) {
-            const zkm_colset cs = d.colsets[ids[2 * j + e]];
-            gl_t f = ctl_eval_filter(d, cs, lv, n, 1, next_ok);
-            if (f == 1) {
-                h = gl_add(h, gl_inv(ctl_combine(d, cs, z.beta, z.gamma, lv, n, 1, next_ok)));
-            } else if (f != 0) {
-                *bad = 1;  // "Non-binary filter?" (cross_table_lookup.rs:741)
+    // The reference batch-inverts the combined columns (batch_multiplicative_inverse, cross_table_lookup.rs:748, 781); so does a lane
+    // here, eight column sets (four helper columns) at a time: prefix products, ONE inversion, back-substitution -- 3 products per
+    // set instead of an inversion each (a logUp lookup of the Arithmetic table has 18 looking columns per row).  Inverses are unique:
+    // the same words as one inversion per set; a set whose filter is 0 (or whose combination is 0) contributes 0 as before.
+    for (uint32_t j0 = 0; 2 * j0 < z.ncolsets; j0 += 4) {
+        gl_t v[8], pre[8];
+        bool on[8];
+        gl_t acc = 1;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t ci = 2 * j0 + e;
+            on[e] = false;
+            v[e] = 0;
+            if (ci < z.ncolsets) {
+                const zkm_colset cs = d.colsets[ids[ci]];
+                gl_t f = ctl_eval_filter(d, cs, lv, n, 1, next_ok);
+                if (f == 1) {
+                    v[e] = gl_canon(ctl_combine(d, cs, z.beta, z.gamma, lv, n, 1, next_ok));
+                    on[e] = v[e] != 0;
+                } else if (f != 0) {
+                    *bad = 1;  // "Non-binary filter?" (cross_table_lookup.rs:741)
+                }
+            }
+            pre[e] = acc;
+            if (on[e]) acc = gl_mul(acc, v[e]);
+        }
+        gl_t inv = gl_inv(acc);
+#pragma unroll
+        for (int e = 7; e >= 0; e--) {
+            if (on[e]) {
+                const gl_t r = gl_mul(inv, pre[e]);
+                inv = gl_mul(inv, v[e]);
+                v[e] = r;
             }
         }
-        if (helpers) helpers[(size_t)j * n + row] = h;
-        total = gl_add(total, h);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t j = j0 + q;
+            if (2 * j < z.ncolsets) {
+                const gl_t h = gl_add(v[2 * q], v[2 * q + 1]);
+                if (helpers) helpers[(size_t)j * n + row] = h;
+                total = gl_add(total, h);
+            }
+        }
     }
     hsum[row] = total;
 }
@@ -149,17 +180,27 @@ __global__ __launch_bounds__(256) void k_ctl_helper(ctl_dev d, uint32_t zi, cons
     const uint32_t j = blockIdx.y;
     const gl_t* lv = trace + row;
     bool next_ok = row + 1 < n;
-    gl_t h = 0;
-    for (uint32_t e = 0; e < 2 && 2 * j + e < z.ncolsets; e++) {
-        const zkm_colset cs = d.colsets[ids[2 * j + e]];
-        gl_t f = ctl_eval_filter(d, cs, lv, n, 1, next_ok);
-        if (f == 1) {
-            h = gl_add(h, gl_inv(ctl_combine(d, cs, z.beta, z.gamma, lv, n, 1, next_ok)));
-        } else if (f != 0) {
-            *bad = 1;  // "Non-binary filter?" (cross_table_lookup.rs:741)
+    // (the two column sets of a helper column share one inversion: 1 / a + 1 / b = (a + b) / (a b))
+    gl_t v[2] = {0, 0};
+    bool on[2] = {false, false};
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        if (2 * j + e < z.ncolsets) {
+            const zkm_colset cs = d.colsets[ids[2 * j + e]];
+            gl_t f = ctl_eval_filter(d, cs, lv, n, 1, next_ok);
+            if (f == 1) {
+                v[e] = gl_canon(ctl_combine(d, cs, z.beta, z.gamma, lv, n, 1, next_ok));
+                on[e] = v[e] != 0;
+            } else if (f != 0) {
+                *bad = 1;  // "Non-binary filter?" (cross_table_lookup.rs:741)
+            }
         }
     }
-    helpers[(size_t)j * n + row] = h;
+    gl_t h = 0;
+    if (on[0] && on[1]) h = gl_mul(gl_add(v[0], v[1]), gl_inv(gl_mul(v[0], v[1])));
+    else if (on[0]) h = gl_inv(v[0]);
+    else if (on[1]) h = gl_inv(v[1]);
+    helpers[(size_t)j * n + row] = gl_canon(h);
 }
 __global__ __launch_bounds__(256) void k_ctl_rowsum(const gl_t* __restrict__ helpers, uint32_t nh, size_t n, gl_t* __restrict__ hsum, size_t aux_seg,
                                                     size_t hsum_seg) {

@@ -273,10 +273,23 @@ GL_HD gl_t gl_pow(gl_t b, uint64_t e) {
     }
     return r;
 }
-GL_HD gl_t gl_inv(gl_t a) { return gl_pow(a, GL_P - 2); }
 GL_HD gl_t gl_exp_pow2(gl_t a, unsigned k) {
     while (k--) a = gl_sqr(a);
     return a;
+}
+// a^(p - 2), p - 2 = 2^64 - 2^32 - 1 = (31 one bits)(0)(32 one bits): the addition chain through a^(2^k - 1), k = 2, 3, 6, 12, 24, 30, 31,
+// then (a^(2^31 - 1))^(2^32) * a^(2^31 - 1), squared, times a -- 63 squarings and 9 products instead of the 64 + 63 of square-and-multiply
+// (the inverse is unique: the same canonical word; 0 -> 0).  The CTL / lookup column kernels invert once per row and column set.
+GL_HD gl_t gl_inv(gl_t a) {
+    const gl_t t2 = gl_mul(gl_sqr(a), a);
+    const gl_t t3 = gl_mul(gl_sqr(t2), a);
+    const gl_t t6 = gl_mul(gl_exp_pow2(t3, 3), t3);
+    const gl_t t12 = gl_mul(gl_exp_pow2(t6, 6), t6);
+    const gl_t t24 = gl_mul(gl_exp_pow2(t12, 12), t12);
+    const gl_t t30 = gl_mul(gl_exp_pow2(t24, 6), t6);
+    const gl_t t31 = gl_mul(gl_sqr(t30), a);
+    const gl_t t63 = gl_mul(gl_exp_pow2(t31, 32), t31);
+    return gl_mul(gl_sqr(t63), a);
 }
 GL_HD gl_t gl_root_of_unity(unsigned k) { return gl_exp_pow2(GL_POW2_GENERATOR, 32 - k); }
 
