@@ -129,3 +129,24 @@ def test_lockstep_segments_from_device_buffers_at_2_16_cycle_heights(ctx, zkm):
         for d in bufs:
             for b in d:
                 b.free()
+
+
+@pytest.mark.gpu
+def test_a_bad_segment_of_a_group_is_named(ctx, zkm):
+    """A non-binary filter value in ONE segment of a lock-step group (cross_table_lookup.rs:741 "Non-binary filter?"): the call fails
+    with the reference's message and names the caller's segment and the table; the context proves the good segments afterwards."""
+    from zkm_amd import tables as T
+    segs = []
+    for v in range(3):
+        tr, lg = _segment(v)
+        segs.append((tr, lg, [v]))
+    want = ctx.prove_segments(segs)
+    # Logic table (Table::all()[10]): its operation flags are the filter of its CTL column set (logic.rs ctl_filter); 2 is not a filter value
+    bad_tr = [t.copy() for t in segs[1][0]]
+    w = T.WIDTH[T.TABLE_ENUM_ORDER[10]]
+    bad_tr[10].reshape(w, -1)[0][0] = 2
+    with pytest.raises(zkm.ZkmError, match=r"segment 1, table 10: Non-binary filter"):
+        ctx.prove_segments([segs[0], (bad_tr, segs[1][1], segs[1][2]), segs[2]])
+    got = ctx.prove_segments(segs)
+    for v in range(3):
+        assert (got[v][0] == want[v][0]).all()

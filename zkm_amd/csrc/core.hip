@@ -699,6 +699,15 @@ __global__ __launch_bounds__(256) void k_canon(gl_t* __restrict__ v, size_t tota
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) v[i] = gl_canon(v[i]);
 }
+// The traces of a lock-step group gathered into their stack, canonical on the way (one read + one write per word instead of a copy and
+// an in-place pass): segment blockIdx.y's `words` words from its own device block.
+struct seg_ptrs { const uint64_t* p[ZKM_MAX_SEG]; };
+__global__ __launch_bounds__(256) void k_gather_canon(seg_ptrs src, size_t words, gl_t* __restrict__ dst) {
+    const uint64_t* __restrict__ s = src.p[blockIdx.y];
+    gl_t* __restrict__ d = dst + (size_t)blockIdx.y * words;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) d[i] = gl_canon(s[i]);
+}
+
 void zkm_launch_canon(zkm_ctx* c, gl_t* v, size_t total) {
     zkm_prof_scope ps(c, "ingest_canonicalise");
     hipLaunchKernelGGL(k_canon, dim3((total + 255) / 256), dim3(256), 0, c->stream, v, total);
@@ -814,8 +823,20 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
     } else if (src_is_values) {
         // stage the values in the (not yet used) LDE buffer (or the caller's device copy), transform, land natural-order coefficients
         gl_t* vals = dev_values ? dev_values : b->lde;
-        copy_cols(vals, 0, ncols, kind, c->stream);
-        if (dev_values) zkm_launch_canon(c, vals, ncols * n);
+        bool all_dev = seg_srcs != nullptr && dev_values != nullptr;
+        for (size_t sg = 0; all_dev && sg < nseg; sg++) all_dev = zkm_is_device_ptr(seg_srcs[sg]);
+        if (all_dev) {     // device-resident traces of a lock-step group: gathered and canonicalised in one pass
+            seg_ptrs sp{};
+            for (size_t sg = 0; sg < nseg; sg++) sp.p[sg] = seg_srcs[sg];
+            const size_t words = b->ncols * n;
+            zkm_prof_scope ps(c, "ingest_canonicalise");
+            hipLaunchKernelGGL(k_gather_canon, dim3((unsigned)std::min<size_t>((words + 255) / 256, 4096), (unsigned)nseg), dim3(256), 0, c->stream, sp,
+                               words, vals);
+            ZKM_HIP_CHECK(hipGetLastError());
+        } else {
+            copy_cols(vals, 0, ncols, kind, c->stream);
+            if (dev_values) zkm_launch_canon(c, vals, ncols * n);
+        }
         inverse_transform(vals, 0, ncols);
     } else {
         copy_cols(b->coeffs, 0, ncols, kind, c->stream);

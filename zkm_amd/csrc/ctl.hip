@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_ctl_terms(ctl_dev d, uint32_t zi0, cons
                     v[e] = gl_canon(ctl_combine(d, cs, z.beta, z.gamma, lv, n, 1, next_ok));
                     on[e] = v[e] != 0;
                 } else if (f != 0) {
-                    *bad = 1;  // "Non-binary filter?" (cross_table_lookup.rs:741)
+                    bad[blockIdx.z] = 1;  // "Non-binary filter?" (cross_table_lookup.rs:741) -- per segment of a stack
                 }
             }
             pre[e] = acc;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_ctl_helper(ctl_dev d, uint32_t zi, cons
                 v[e] = gl_canon(ctl_combine(d, cs, z.beta, z.gamma, lv, n, 1, next_ok));
                 on[e] = v[e] != 0;
             } else if (f != 0) {
-                *bad = 1;  // "Non-binary filter?" (cross_table_lookup.rs:741)
+                bad[blockIdx.z] = 1;  // "Non-binary filter?" (cross_table_lookup.rs:741)
             }
         }
     }
@@ -307,8 +307,8 @@ void zkm_ctl_data_device(zkm_ctx* c, const ctl_dev_owner& own, const gl_t* d_tra
     const size_t nzs = zs.size();
     const unsigned z = (unsigned)nseg;
     gl_t* const d_hsum_all = (gl_t*)c->alloc(nseg * (nzs ? nzs : 1) * n * sizeof(gl_t));   // the per-row sums of every Z, scanned together below
-    int* d_bad = (int*)c->alloc(sizeof(int));
-    ZKM_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+    int* d_bad = (int*)c->alloc(ZKM_MAX_SEG * sizeof(int));     // one flag per segment of the stack
+    ZKM_HIP_CHECK(hipMemsetAsync(d_bad, 0, ZKM_MAX_SEG * sizeof(int), c->stream));
     // Zs with many helper columns on a short table spread their column sets over blockIdx.y (few workgroups per launch otherwise);
     // every other run of consecutive Zs is ONE launch (blockIdx.y = Z)
     auto wide = [&](uint32_t i) { return zs[i].num_helpers >= 4 && ((n * nseg) >> 8) < 4096; };
@@ -336,11 +336,12 @@ void zkm_ctl_data_device(zkm_ctx* c, const ctl_dev_owner& own, const gl_t* d_tra
         zkm_prof_scope ps(c, "ctl_suffix_sum");
         suffix_sum(c, d_hsum_all, n, n, nzs, d_aux + (size_t)own.d.total_helpers * n, n, nseg, nzs * n, aux_seg);
     }
-    int bad = 0;
-    c->download(&bad, d_bad, sizeof(int));
+    int bad[ZKM_MAX_SEG];
+    c->download(bad, d_bad, ZKM_MAX_SEG * sizeof(int));
     c->release(d_hsum_all);
     c->release(d_bad);
-    if (bad) throw std::runtime_error("Non-binary filter?");
+    for (size_t sg = 0; sg < nseg; sg++)
+        if (bad[sg]) throw zkm_segment_error(sg, "Non-binary filter?");
 }
 
 // ------------------------------------------------------------------ per-table CtlZData lists (cross_table_lookup_data order)
@@ -448,9 +449,9 @@ static void lookup_helper_columns_device(zkm_ctx* c, const zkm_ctl_table* table,
         tmp.push_back(d_hsum);
         gl_t* d_x = (gl_t*)c->alloc(nseg * n * 8);
         tmp.push_back(d_x);
-        int* d_bad = (int*)c->alloc(sizeof(int));
+        int* d_bad = (int*)c->alloc(ZKM_MAX_SEG * sizeof(int));
         tmp.push_back(d_bad);
-        ZKM_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+        ZKM_HIP_CHECK(hipMemsetAsync(d_bad, 0, ZKM_MAX_SEG * sizeof(int), c->stream));
         {
             zkm_prof_scope ps(c, "lookup_terms");
             hipLaunchKernelGGL(k_ctl_terms, dim3((n + 255) / 256, 1, z), dim3(256), 0, c->stream, own.d, 0u, d_trace, n, d_out, d_hsum, d_bad, trace_seg,
@@ -462,11 +463,12 @@ static void lookup_helper_columns_device(zkm_ctx* c, const zkm_ctl_table* table,
         suffix_sum(c, d_x, n, n, 1, d_hsum, n, nseg, n, n);
         hipLaunchKernelGGL(k_prefix_from_suffix, dim3((n + 255) / 256, 1, z), dim3(256), 0, c->stream, d_hsum, n, d_out + nh * n, out_seg);
         ZKM_HIP_CHECK(hipGetLastError());
-        int bad = 0;
-        c->download(&bad, d_bad, sizeof(int));
+        int bad[ZKM_MAX_SEG];
+        c->download(bad, d_bad, ZKM_MAX_SEG * sizeof(int));
         for (void* p : tmp) c->release(p);
         tmp.clear();
-        if (bad) throw std::runtime_error("Non-binary filter?");
+        for (size_t sg = 0; sg < nseg; sg++)
+            if (bad[sg]) throw zkm_segment_error(sg, "Non-binary filter?");
     } catch (...) {
         (void)hipStreamSynchronize(c->stream);
         for (void* p : tmp) c->release(p);
@@ -932,13 +934,18 @@ static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t 
                 d_trace = d;
             }
             zkm_scratch d_all(w, G * A * n * sizeof(gl_t));   // per segment [lookup helper columns | CTL helper columns and Zs], prover.rs:497-508
-            {
-                zkm_prof_scope st(w, "stage/compute CTL data");
-                zkm_ctl_data_device(w, own, d_trace, g.log_n, d_all.as<gl_t>() + NL * n, G, W * n, A * n);
-            }
-            if (NL) {
-                zkm_prof_scope st(w, "stage/compute lookup helper columns");
-                zkm_table_lookup_columns_device(w, T0[t].table_id, glookup[j].data(), nch, d_trace, n, d_all.as<gl_t>(), G, W * n, A * n);
+            try {
+                {
+                    zkm_prof_scope st(w, "stage/compute CTL data");
+                    zkm_ctl_data_device(w, own, d_trace, g.log_n, d_all.as<gl_t>() + NL * n, G, W * n, A * n);
+                }
+                if (NL) {
+                    zkm_prof_scope st(w, "stage/compute lookup helper columns");
+                    zkm_table_lookup_columns_device(w, T0[t].table_id, glookup[j].data(), nch, d_trace, n, d_all.as<gl_t>(), G, W * n, A * n);
+                }
+            } catch (const zkm_segment_error& e) {   // (a stack names the position in the group: the caller wants ITS segment and the table)
+                if (nseg == 1) throw std::runtime_error(e.what());
+                throw std::runtime_error("segment " + std::to_string(g.segs[e.seg]) + ", table " + std::to_string(t) + ": " + e.what());
             }
             zkm_prof_scope st(w, "stage/compute auxiliary polynomials commitment");
             zkm_batch* ab = new zkm_batch();

@@ -25,6 +25,12 @@
                                      std::to_string(__LINE__) + ")");                                        \
     } while (0)
 
+// an error that belongs to ONE segment of a stacked launch (position in the stack); what() is the reference's message
+struct zkm_segment_error : std::runtime_error {
+    size_t seg;
+    zkm_segment_error(size_t s, const char* msg) : std::runtime_error(msg), seg(s) {}
+};
+
 struct zkm_prof_rec {
     const char* name;
     hipEvent_t start, stop;
