@@ -641,9 +641,11 @@ static double commit_cost_estimate(const zkm_ctx* c, size_t ncols, unsigned log_
 // seconds) -- not pulled from a queue: a worker that gets the same tables on every call finds every block it needs in its own
 // exact-size allocator cache from the second segment on (a dynamic queue kept hitting hipMalloc for ten or more calls: 37 -- 53 ms
 // per 2^16-cycle segment depending on who had grabbed what), and the memory the lanes cache stays that of ONE assignment.
-template <class F>
+struct no_prep { void operator()(zkm_ctx*, const std::vector<size_t>&) const {} };
+// prep(worker context, the jobs that worker will run, in order): called once on the worker's thread before its first job
+template <class F, class P = no_prep>
 static void run_on_lanes(zkm_ctx* c, const std::vector<size_t>& big, const std::vector<size_t>& small, const std::vector<double>& cost,
-                         F&& fn) {
+                         F&& fn, P&& prep = P()) {
     const size_t nlanes = small.size() >= 2 ? std::min<size_t>(std::max<size_t>(1, c->commit_lanes), small.size()) - 1 : 0;
     c->ensure_lanes(nlanes);
     std::vector<std::vector<size_t>> mine(nlanes + 1);
@@ -665,6 +667,12 @@ static void run_on_lanes(zkm_ctx* c, const std::vector<size_t>& big, const std::
     auto work = [&](zkm_ctx* w, size_t slot, bool take_big) {
         try {
             ZKM_HIP_CHECK(hipSetDevice(c->device));
+            {
+                std::vector<size_t> jobs;
+                if (take_big) jobs = big;
+                jobs.insert(jobs.end(), mine[slot].begin(), mine[slot].end());
+                prep(w, jobs);
+            }
             if (take_big)
                 for (size_t t : big) {
                     if (failed.load()) break;                // a lane threw: do not commit the remaining big tables before reporting it
@@ -710,6 +718,8 @@ struct table_group {
     gl_t* d_traces = nullptr;        // stacked device copy of the trace values (segs.size() x ncols x n), or null: read in place
     zkm_ctx* d_owner = nullptr;      // ... from the allocator of the context (commit lane) that made it
     bool host = false, keep = false;
+    hipEvent_t uploaded = nullptr;   // host-resident traces of a stack: recorded on the worker's copy stream behind their upload
+    zkm_ctx* uploaded_on = nullptr;
 };
 
 static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const seg_io* io, size_t ntables,
@@ -724,7 +734,16 @@ static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t 
     };
     auto drop_all = [&]() {
         (void)hipStreamSynchronize(c->stream);
-        for (zkm_ctx* l : c->lanes) (void)hipStreamSynchronize(l->stream);
+        if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+        for (zkm_ctx* l : c->lanes) {
+            (void)hipStreamSynchronize(l->stream);
+            if (l->copy_stream) (void)hipStreamSynchronize(l->copy_stream);
+        }
+        for (table_group& g : groups)
+            if (g.uploaded) {
+                g.uploaded_on->event_pool.push_back(g.uploaded);
+                g.uploaded = nullptr;
+            }
         for (table_group& g : groups) {
             zkm_batch_free(g.commit);
             zkm_batch_free(g.aux);
@@ -852,7 +871,7 @@ static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t 
             run_on_lanes(c, big, small, cost, [&](zkm_ctx* w, size_t j) {
                 table_group& g = groups[j];
                 const size_t W = T0[g.t].ncols, n = (size_t)1 << g.log_n, G = g.segs.size();
-                if (g.keep) {
+                if (g.keep && !g.d_traces) {
                     g.d_traces = (gl_t*)w->alloc(G * W * n * sizeof(gl_t));
                     g.d_owner = w;
                 }
@@ -864,6 +883,12 @@ static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t 
                 zkm_batch* b = new zkm_batch();
                 b->ctx = w; b->ncols = W; b->nseg = G; b->log_n = g.log_n; b->rate_bits = cfg->rate_bits; b->cap_height = cfg->cap_height;
                 g.commit = b;      // (owned from here on: freed on every exit path)
+                if (g.uploaded) {  // its traces came up on the copy stream while the worker's earlier groups were transformed and hashed
+                    ZKM_HIP_CHECK(hipStreamWaitEvent(w->stream, g.uploaded, 0));
+                    zkm_launch_canon(w, g.d_traces, G * W * n);
+                    zkm_batch_build(b, g.d_traces, true);
+                    return;
+                }
                 bool any_cols = false;
                 for (size_t s : g.segs) any_cols = any_cols || io[s].tables[g.t].columns;
                 if (any_cols) {    // one pointer per column of every segment
@@ -878,7 +903,42 @@ static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t 
                     for (size_t k = 0; k < G; k++) srcs[k] = io[g.segs[k]].tables[g.t].trace;
                     zkm_batch_build(b, nullptr, true, g.d_traces, nullptr, srcs.data());
                 }
+            }, [&](zkm_ctx* w, const std::vector<size_t>& jobs) {
+                // Host-resident traces of the worker's stacks (the deployed input: generate_traces leaves them in host memory) go up on
+                // the worker's COPY stream, all of them queued now, each followed by an event: the transforms and hashing of a group
+                // overlap the uploads of the groups behind it (0.3 GB per 2^16-cycle segment over PCIe).  Pinned (zkm_host_alloc /
+                // zkm_host_register) sources make the copies asynchronous; pageable ones are staged by the runtime inside the call.
+                for (size_t j : jobs) {
+                    table_group& g = groups[j];
+                    if (!(g.host && g.keep && g.segs.size() > 1)) continue;
+                    const size_t W = T0[g.t].ncols, n = (size_t)1 << g.log_n, G = g.segs.size();
+                    if (!w->copy_stream) {
+                        hipStream_t cs = nullptr;
+                        ZKM_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                        std::lock_guard<std::mutex> lk(w->alloc_mu);
+                        w->copy_stream = cs;
+                    }
+                    g.d_traces = (gl_t*)w->alloc(G * W * n * sizeof(gl_t));
+                    g.d_owner = w;
+                    for (size_t k = 0; k < G; k++) {
+                        const zkm_table_input& a = io[g.segs[k]].tables[g.t];
+                        gl_t* dst = g.d_traces + k * W * n;
+                        if (a.columns)
+                            for (size_t i = 0; i < W; i++)
+                                ZKM_HIP_CHECK(hipMemcpyAsync(dst + i * n, a.columns[i], n * sizeof(gl_t), hipMemcpyDefault, w->copy_stream));
+                        else
+                            ZKM_HIP_CHECK(hipMemcpyAsync(dst, a.trace, W * n * sizeof(gl_t), hipMemcpyDefault, w->copy_stream));
+                    }
+                    g.uploaded = w->get_event();
+                    g.uploaded_on = w;
+                    ZKM_HIP_CHECK(hipEventRecord(g.uploaded, w->copy_stream));
+                }
             });
+            for (table_group& g : groups)      // (every upload has been waited for by its group's commitment: the events go back)
+                if (g.uploaded) {
+                    g.uploaded_on->event_pool.push_back(g.uploaded);
+                    g.uploaded = nullptr;
+                }
         }
         const size_t C4 = (size_t)4 << cfg->cap_height;
         const unsigned nch = cfg->num_challenges;
