@@ -150,3 +150,38 @@ def test_a_bad_segment_of_a_group_is_named(ctx, zkm):
     got = ctx.prove_segments(segs)
     for v in range(3):
         assert (got[v][0] == want[v][0]).all()
+
+
+@pytest.mark.gpu
+def test_lockstep_edge_cases_memory_and_allocation_failures(zkm):
+    """Zero segments, one segment, more segments than a group holds (34 > ZKM_MAX_SEG = 32: two groups per table), the allocator's
+    out-of-memory retry while a stack is being built (the "debug_fail_allocs" test hook), and the memory accounting afterwards: every
+    blob equals the single-segment path's, nothing stays allocated."""
+    import os
+    c = zkm.Context(0)
+    os.environ["ZKM_ENABLE_TEST_HOOKS"] = "1"
+    try:
+        assert c.prove_segments([]) == []
+        tr, lg = _segment(0)
+        one = c.prove_segment(tr, lg, public_values=[4, 2])
+        got = c.prove_segments([(tr, lg, [4, 2])])
+        assert len(got) == 1 and (got[0][0] == one[0]).all() and (got[0][1] == one[1]).all() and list(got[0][2]) == list(one[2])
+        segs = [(tr, lg, [v, 1]) for v in range(34)]               # same traces, 34 transcripts
+        many = c.prove_segments(segs)
+        for v in (0, 31, 32, 33):
+            want = c.prove_segment(tr, lg, public_values=[v, 1])
+            assert (many[v][0] == want[0]).all() and (many[v][1] == want[1]).all(), v
+        few = [(_segment(v)[0], lg, [v]) for v in range(3)]
+        want = c.prove_segments(few)
+        for k in (25, 300, 100000):
+            c.set_tuning("debug_fail_allocs", k)
+            got = c.prove_segments(few)
+            for v in range(3):
+                assert (got[v][0] == want[v][0]).all(), (k, v)
+        c.set_tuning("debug_fail_allocs", 0)
+        c.synchronize()
+        live, cached = c.memory()
+        assert live == c.resident_bytes()
+    finally:
+        os.environ.pop("ZKM_ENABLE_TEST_HOOKS", None)
+        c.close()
