@@ -307,8 +307,10 @@ def test_tuning_fri_division_variants_agree(zkm, oracle, log_n):
     n = 1 << log_n
     tv, av, qc = (rng.integers(0, P, k * n, dtype=np.uint64) for k in (W, A, Q))
     blobs = []
-    for threshold in (1 << 30, 1):
+    # (third variant, round 5's default: the bottom level's scan and weighted sum in one launch, "fri_scan_combine"; 0 = two launches)
+    for threshold, fused_bottom in ((1 << 30, 1), (1, 1), (1 << 30, 0)):
         c = zkm.Context(0)
+        c.set_tuning("fri_scan_combine", fused_bottom)
         c.set_tuning("fri_fused_division_min", threshold)
         tb, ab = zkm.PolynomialBatch.from_values(c, tv, W, log_n), zkm.PolynomialBatch.from_values(c, av, A, log_n)
         qb = zkm.PolynomialBatch.from_coeffs(c, qc, Q, log_n)
@@ -318,7 +320,7 @@ def test_tuning_fri_division_variants_agree(zkm, oracle, log_n):
         for b in (tb, ab, qb):
             b.free()
         c.close()
-    assert (blobs[0] == blobs[1]).all()
+    assert (blobs[0] == blobs[1]).all() and (blobs[0] == blobs[2]).all()
     otb, oab = oracle.batch_from_values(tv, W, log_n), oracle.batch_from_values(av, A, log_n)
     oqb = oracle.batch_from_coeffs(qc, Q, log_n)
     och = oracle.challenger()

@@ -119,6 +119,7 @@ void zkm_ctx::ensure_lanes(size_t k) {
         l->tree_tail = tree_tail;
         l->commit_lanes = commit_lanes;
         l->max_stack = max_stack;
+        l->fri_scan_combine = fri_scan_combine;
         l->pow_round_log = pow_round_log;
         l->cu_part_k = cu_part_k;
         l->cu_part_n = cu_part_n;
@@ -495,6 +496,7 @@ int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) 
         else if (k == "small_ntt") x->small_ntt = value ? 1 : 0;
         else if (k == "tree_tail") x->tree_tail = value ? 1 : 0;
         else if (k == "pow_round_log") x->pow_round_log = value < 8 ? 8 : (value > 22 ? 22 : (unsigned)value);
+        else if (k == "fri_scan_combine") x->fri_scan_combine = value ? 1 : 0;
         else if (k == "aux_pipeline") x->aux_pipeline = value ? 1 : 0;
         else if (k == "commit_lanes") x->commit_lanes = value < 1 ? 1 : (value > 8 ? 8 : (size_t)value);
         else if (k == "max_stack") x->max_stack = value < 1 ? 1 : (value > ZKM_MAX_SEG ? ZKM_MAX_SEG : (size_t)value);

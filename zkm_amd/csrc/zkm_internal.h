@@ -60,6 +60,7 @@ struct zkm_ctx {
     size_t keccak_parts_max_points = (size_t)1 << 15;   // k_quotient_keccak_parts up to this many points  }
     size_t fri_fused_division_min = ~(size_t)0;         // k_seg_scan_final from this many coefficients (default: never -- since the
                                                         // LDS-tiled kernels of round 4 the per-batch scans are faster at every size)  }
+    int fri_scan_combine = 1;           // bottom level of the division by (X - z): scan and weighted sum in one launch (0: two launches)   } zkm_ctx_set_tuning
     size_t small_ntt = 1;               // transforms of 2^9 .. 2^13 points in one launch (k_ntt_small); 0: the two-pass plan          } zkm_ctx_set_tuning
     unsigned pow_round_log = 17;        // proof-of-work search: 2^this candidates per round of the search launch                          } zkm_ctx_set_tuning
     int aux_pipeline = 1;               // segments of short tables: lanes build later tables' auxiliary commitments behind the proofs      } zkm_ctx_set_tuning
