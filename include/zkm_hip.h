@@ -66,6 +66,10 @@ void zkm_ctx_trim(zkm_ctx* ctx);
  *                               the witness found is the smallest one whatever the value
  *   "max_stack"                 zkm_prove_segments: segments per lock-step group (default and maximum 32; 1 = one segment at a time, the
  *                               path of zkm_prove_segment); a table's group is also bounded by 65535 stacked columns (Keccak: 26 segments)
+ *   "segments_memory_budget"    zkm_prove_segments: bytes of HBM the segments proven together may hold (estimated: values, coefficients, 4x LDE
+ *                               and digests of every table's three commitments); more segments than that are proven in consecutive waves.
+ *                               Default 0 = 80 % of (the blocks this context has cached + free memory) at the call; contexts sharing a GPU
+ *                               are sized by the caller (contexts x segments per call x ~1.8 GB for 2^16-cycle segments)
  *   "aux_pipeline"              a segment whose tables are all short (no LDE over 1 GiB), commit_lanes > 1: the lanes build the auxiliary
  *                               commitments of tables 1.. BEHIND the proofs of the earlier tables instead of all of them before the
  *                               first proof (default 1; same transcript, same proofs); 0: all auxiliary commitments first
@@ -453,6 +457,9 @@ int zkm_prove_segment_columns(zkm_ctx* ctx, const zkm_stark_config* cfg, const u
  *   public_values[s]    npublic[s] words (arrays may be NULL when no segment has public values)
  *   proofs_out[s]       zkm_prove_segment(.., proofs_out = NULL, ..) sizes a segment's buffer and gives its thirteen offsets
  *   ctl_challenges_out[s]   2 * num_challenges words
+ * Memory: every commitment of every segment of a group is alive until its table has been proven (~1.8 GB of HBM per 2^16-cycle segment);
+ * a call with more segments than 80 % of (the blocks this context has cached + the memory that is free) holds is proven in
+ * consecutive, equally sized waves (the words are the same; only fewer segments share a launch).
  * A failure leaves every output undefined (no partial results). */
 int zkm_prove_segments(zkm_ctx* ctx, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* traces,
                        const unsigned* const* log_n, const uint64_t* const* public_values, const size_t* npublic, uint64_t* const* proofs_out,

@@ -171,6 +171,16 @@ def test_lockstep_edge_cases_memory_and_allocation_failures(zkm):
         for v in (0, 31, 32, 33):
             want = c.prove_segment(tr, lg, public_values=[v, 1])
             assert (many[v][0] == want[0]).all() and (many[v][1] == want[1]).all(), v
+        # a memory budget that holds two of these segments (~370 MB each by the library's estimate): five segments go in three waves of 2, 2, 1
+        five = [(_segment(v)[0], lg, [v, 9]) for v in range(5)]
+        want5 = c.prove_segments(five)
+        c.set_tuning("segments_memory_budget", 800 << 20)
+        got5 = c.prove_segments(five)
+        c.set_tuning("segments_memory_budget", 1)          # not even one: one segment per wave
+        got1 = c.prove_segments(five)
+        c.set_tuning("segments_memory_budget", 0)
+        for v in range(5):
+            assert (got5[v][0] == want5[v][0]).all() and (got1[v][0] == want5[v][0]).all() and (got5[v][1] == want5[v][1]).all()
         few = [(_segment(v)[0], lg, [v]) for v in range(3)]
         want = c.prove_segments(few)
         for k in (25, 300, 100000):

@@ -499,6 +499,7 @@ int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) 
         else if (k == "fri_scan_combine") x->fri_scan_combine = value ? 1 : 0;
         else if (k == "aux_pipeline") x->aux_pipeline = value ? 1 : 0;
         else if (k == "commit_lanes") x->commit_lanes = value < 1 ? 1 : (value > 8 ? 8 : (size_t)value);
+        else if (k == "segments_memory_budget") x->segments_memory_budget = (size_t)value;
         else if (k == "max_stack") x->max_stack = value < 1 ? 1 : (value > ZKM_MAX_SEG ? ZKM_MAX_SEG : (size_t)value);
         else if (k == "throughput_profile") {
             // MANY contexts on one GPU proving small segments (profiles/r04_throughput_profile.txt): one stream per context -- the runtime

@@ -1107,6 +1107,48 @@ static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t 
     drop_all();
 }
 
+// A call may hold more segments than fit in HBM together (every commitment of every segment of a lock-step call is alive until its
+// table has been proven): the segments are proven in consecutive WAVES whose estimated footprint -- per table the trace values,
+// coefficients, 4x LDE and digests of the trace, auxiliary and quotient batches -- stays within 80 % of the blocks its allocator has
+// cached plus the memory that is free right now.  One segment always goes (a single
+// segment that does not fit fails in the allocator, as it always did).
+static void prove_segments_waves(zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const seg_io* io, size_t ntables,
+                                 const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls) {
+    if (nseg <= 1) {
+        prove_segments_impl(c, cfg, nseg, io, ntables, ctls, sides, nctls);
+        return;
+    }
+    ZKM_HIP_CHECK(hipSetDevice(c->device));
+    size_t free_b = 0, total_b = 0, live = 0, cached = 0;
+    ZKM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    zkm_ctx_memory(c, &live, &cached);
+    // (what this context may count on: the blocks its own allocator has cached -- after the first call they hold a whole wave -- and what
+    // is free NOW.  Other contexts of the process look at the same free memory: the caller sizes contexts x segments per call for the
+    // GPU (1.8 GB per 2^16-cycle segment in flight); this is the safety net of ONE oversized call, not an arbiter between contexts --
+    // dividing the free memory among them starved the contexts that warmed up last and left their allocators with blocks of two wave
+    // sizes: 12 x 8 fell from 107 to 72 segments/s.)
+    const double budget = c->segments_memory_budget ? (double)c->segments_memory_budget : 0.8 * ((double)cached + (double)free_b);
+    const auto tz0 = derive_zs(ntables, ctls, sides, nctls, cfg->num_challenges, nullptr);
+    auto footprint = [&](const seg_io& s) {
+        double words = 0;
+        for (size_t t = 0; t < ntables && s.tables; t++) {
+            const double n = (double)((size_t)1 << std::min<unsigned>(s.tables[t].log_n, 40)), W = (double)s.tables[t].ncols;
+            const double A = (double)(tz0[t].naux + zkm_num_lookup_columns(s.tables[t].table_id, cfg)), Q = 2.0 * cfg->num_challenges;
+            words += W * n + (W + A + Q) * n * (1.0 + (double)(1u << cfg->rate_bits)) + 3.0 * 8.0 * n * (double)(1u << cfg->rate_bits);
+        }
+        return words * 8.0;
+    };
+    double total = 0;
+    for (size_t s = 0; s < nseg; s++) total += footprint(io[s]);
+    // equal waves (the exact-size allocator then caches the blocks of at most two stack heights, the same ones call after call)
+    const size_t nwaves = (size_t)std::min<double>((double)nseg, std::max(1.0, std::ceil(total / std::max(budget, 1.0))));
+    const size_t per = (nseg + nwaves - 1) / nwaves;
+    if (getenv("ZKM_DEBUG_WAVES"))
+        fprintf(stderr, "zkm waves: %zu segments, %.2f GB in all, budget %.2f GB (free %.2f, cached %.2f) -> %zu wave(s) of <= %zu\n", nseg, total / 1e9,
+                budget / 1e9, free_b / 1e9, cached / 1e9, nwaves, per);
+    for (size_t s0 = 0; s0 < nseg; s0 += per) prove_segments_impl(c, cfg, std::min(per, nseg - s0), io + s0, ntables, ctls, sides, nctls);
+}
+
 extern "C" {
 
 int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_table_input* tables, size_t ntables,
@@ -1143,7 +1185,7 @@ static int prove_segments_entry(const char* what, zkm_ctx* c, const zkm_stark_co
             io[s] = seg_io{tables[s].data(), pub ? pub[s] : nullptr, npub ? npub[s] : 0, proofs[s], challenges[s]};
             if (io[s].npub && !io[s].pub) throw std::runtime_error(std::string(what) + ": null public values");
         }
-        prove_segments_impl(c, cfg, nseg, io.data(), 12, AS_CTLS, AS_SIDES, AS_NCTLS);
+        prove_segments_waves(c, cfg, nseg, io.data(), 12, AS_CTLS, AS_SIDES, AS_NCTLS);
     } catch (const std::exception& e) {
         return fail(err, e.what());
     } catch (...) {

@@ -535,15 +535,31 @@ __global__ __launch_bounds__(256) void k_open_partials(const gl_t* __restrict__ 
     for (int c = 0; c < CPB; c++)
 #pragma unroll
         for (int q = 0; q < 5; q++) acc[c][q] = lazy_sum{0, 0};
-    for (size_t idx = t; idx < chunk_len; idx += 256) {
-        gl_t p[4];
+    // (software-pipelined by hand: the loads of step k + 1 -- four powers, CPB coefficients -- are issued before the 4 CPB products of step
+    // k; with one load-use pair per iteration every one of the 64 steps of a chunk exposed a trip to L2 / HBM at four waves per SIMD)
+    gl_t np[4], ncv[CPB];
+    auto fetch = [&](size_t idx) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) p[q] = pw[(size_t)q * chunk_len + idx];
+        for (int q = 0; q < 4; q++) np[q] = pw[(size_t)q * chunk_len + idx];
 #pragma unroll
         for (int c = 0; c < CPB; c++) {
             // (columns past the end of the batch read column ncols - 1 again; their sums are never stored)
             const size_t col = col0 + c < ncols ? col0 + c : ncols - 1;
-            const gl_t cv = coeffs[(col << log_n) + chunk * chunk_len + idx];
+            ncv[c] = coeffs[(col << log_n) + chunk * chunk_len + idx];
+        }
+    };
+    if (t < chunk_len) fetch(t);
+    for (size_t idx = t; idx < chunk_len; idx += 256) {
+        gl_t p[4], cvs[CPB];
+#pragma unroll
+        for (int q = 0; q < 4; q++) p[q] = np[q];
+#pragma unroll
+        for (int c = 0; c < CPB; c++) cvs[c] = ncv[c];
+        if (idx + 256 < chunk_len) fetch(idx + 256);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CPB; c++) {
+            const gl_t cv = cvs[c];
 #pragma unroll
             for (int q = 0; q < 4; q++) acc[c][q].add(gl_mul_loose(cv, p[q]));
             acc[c][4].add(cv);
