@@ -195,3 +195,36 @@ def test_lockstep_edge_cases_memory_and_allocation_failures(zkm):
     finally:
         os.environ.pop("ZKM_ENABLE_TEST_HOOKS", None)
         c.close()
+
+
+@pytest.mark.gpu
+def test_lockstep_groups_of_tall_tables_in_the_digit_coefficient_layout(ctx, zkm, oracle):
+    """Tables of 2^18 .. 2^20 rows keep their coefficients in the digit layout of the two-pass inverse transform (zkm_coeff_exponent):
+    the stacked forms of the layout conversions, the run-reading LDE pass and the exponent-indexed openings.  Three segments whose
+    Arithmetic, Logic and Memory tables are tiled to 2^18 / 2^18 / 2^19 rows (the narrow tables: the case stays small): lock-step ==
+    one at a time, and one of them == the oracle."""
+    import os
+    from zkm_amd import tables as T
+    base = _segment(0)[1]
+    heights = list(base)
+    heights[0], heights[10], heights[11] = 18, 18, 19          # Arithmetic, Logic, Memory (Table::all() positions)
+    segs = []
+    for v in range(3):
+        tr, lg = _segment(v, heights)
+        segs.append((tr, lg, [v, 77]))
+    got = ctx.prove_segments(segs)
+    for v, (tr, lg, pub) in enumerate(segs):
+        want, wchal, woffs = ctx.prove_segment(tr, lg, public_values=pub)
+        assert list(got[v][2]) == list(woffs) and (got[v][1] == wchal).all()
+        bad = np.nonzero(got[v][0] != want)[0]
+        assert bad.size == 0, "segment %d: first differing word %d (table %d)" % (v, bad[0], int(np.searchsorted(woffs, bad[0], side="right")) - 1)
+    ctl_tables, ctls = T.all_cross_table_lookups()
+    tr, lg, pub = segs[1]
+    tables = [(T.TABLE_ENUM_ORDER[i], tr[i], T.WIDTH[T.TABLE_ENUM_ORDER[i]], lg[i], ctl_tables[i]) for i in range(12)]
+    old = oracle.get_threads()
+    oracle.set_threads(min(64, os.cpu_count() or 1, __import__("bench").cpu_quota() or 64))
+    try:
+        ref, rchal, _ = oracle.prove_with_traces(tables, ctls, public_values=pub)
+    finally:
+        oracle.set_threads(old)
+    assert (got[1][0] == ref).all() and (got[1][1] == rchal).all()
