@@ -842,7 +842,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(seg_batches p, size_t m, const 
 // fin[k - 1] = sum_b w_b S_b[k] accumulated in an output tile
 __global__ __launch_bounds__(64) void k_seg_scan_final(seg_batches p, size_t m, const gl_t* __restrict__ upper, size_t nupper, gl_t* __restrict__ f0,
                                                        gl_t* __restrict__ f1) {
-    extern __shared__ __attribute__((aligned(16))) gl_t seg_lds[];   // four tiles: 66 KB (launched with the raised dynamic-LDS limit)
+    extern __shared__ __attribute__((aligned(16))) gl_t seg_lds[];   // four tiles of 64 rows x (FRI_SEG + 1) words: 18 KB at FRI_SEG = 8 (the dynamic-LDS limit is only raised for builds with longer segments)
     gl_t *const t0 = seg_lds, *const t1 = t0 + 64 * SEG_ROW, *const g0 = t1 + 64 * SEG_ROW, *const g1 = g0 + 64 * SEG_ROW;
     const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x, base = (size_t)blockIdx.x * SEG_TILE;
     gl_t *r0 = t0 + threadIdx.x * SEG_ROW, *r1 = t1 + threadIdx.x * SEG_ROW, *q0 = g0 + threadIdx.x * SEG_ROW, *q1 = g1 + threadIdx.x * SEG_ROW;
