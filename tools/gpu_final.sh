@@ -12,7 +12,7 @@ cp gpurun_out/prof_$TAG/pmc_latest.json profiles/pmc_latest.json      # (on the 
 bash tools/gpu_configs.sh ${TAG}_cfg > $O/configs.log 2>&1; tail -30 $O/configs.log
 bash tools/gpu_lockstep_prof.sh $TAG 16 > $O/lockstep_prof.log 2>&1; tail -12 $O/lockstep_prof.log
 cp gpurun_out/lockstep_valu_latest.json profiles/lockstep_valu_latest.json
-/usr/bin/time -f "bench.py wall %e s" python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.err
+T0=$SECONDS; python bench.py > $O/bench.json 2> $O/bench.err; echo "bench.py wall $((SECONDS - T0)) s"; tail -c 300 $O/bench.err
 python tools/bench_segment.py 16 > $O/seg16.json 2> $O/seg16.err
 rm -rf gpurun_out/prof_$TAG/trace
 find gpurun_out/prof_$TAG -name "*counter_collection.csv" -size +20M -delete
