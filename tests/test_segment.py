@@ -258,6 +258,7 @@ def test_pure_c_caller_proves_the_segment_image(ctx, zkm, oracle, tmp_path):
     ref, rchal, _ = oracle.prove_with_traces(tables, ctls, public_values=[1, 2, 3])
     assert (got == ref).all()
     assert "ok %d words, 12 tables, beta0 %016x" % (want.size, int(chal[0])) in r.stdout
+    assert "lockstep ok: 2 segments" in r.stdout      # zkm_prove_segments from plain C: both blobs == the single-segment proof
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 /* tools/c_smoke.c -- the C ABI used from plain C99, no Python anywhere: read a ZKMTRACE segment image from a file, prove it with
- * zkm_prove_segment_image, write the proof blobs to a file.  The reference-side caller of this boundary is Rust over FFI
+ * zkm_prove_segment_image (and, for a twelve-table image, twice more in one zkm_prove_segments call), write the proof blobs to a file.  The reference-side caller of this boundary is Rust over FFI
  * (its only existing FFI has this very shape: recursion/src/snark/snarks.rs:7-20, 39-59 -- int status, char** message
  * freed by the caller); this file is the proof that include/zkm_hip.h is usable as it stands by a C compiler in pedantic mode.
  *
@@ -57,6 +57,35 @@ int main(int argc, char** argv) {
     proofs = (uint64_t*)malloc(proof_words * 8);
     if (!proofs) return die("out of host memory", NULL);
     if (zkm_prove_segment_image(ctx, &cfg, image, words, proofs, &proof_words, offsets, challenges, &err)) return die("proving", err);
+    if (ntables == 12) {
+        /* the same segment twice through zkm_prove_segments (K = 2 in lock-step: one launch per stage for both): each blob must equal the
+         * single-segment proof word for word.  The traces are where the image holds them (table header words 2 and 3: log_n, offset). */
+        const uint64_t* th = image + 8 + image[3];
+        const uint64_t* traces[12];
+        const uint64_t* const* seg_traces[2];
+        unsigned log_n[12];
+        const unsigned* seg_log_n[2];
+        const uint64_t* pubs[2];
+        size_t npubs[2];
+        uint64_t *both[2], *chal[2], chal_words[2][8];
+        for (k = 0; k < 12; k++) {
+            log_n[k] = (unsigned)th[8 * k + 2];
+            traces[k] = image + th[8 * k + 3];
+        }
+        both[0] = (uint64_t*)malloc(proof_words * 8);
+        both[1] = (uint64_t*)malloc(proof_words * 8);
+        if (!both[0] || !both[1]) return die("out of host memory", NULL);
+        for (k = 0; k < 2; k++) {
+            seg_traces[k] = traces; seg_log_n[k] = log_n; pubs[k] = image + 8; npubs[k] = (size_t)image[3]; chal[k] = chal_words[k];
+        }
+        if (zkm_prove_segments(ctx, &cfg, 2, seg_traces, seg_log_n, pubs, npubs, both, chal, &err)) return die("zkm_prove_segments", err);
+        for (k = 0; k < 2; k++)
+            if (memcmp(both[k], proofs, proof_words * 8) != 0 || memcmp(chal[k], challenges, 4 * 8) != 0)
+                return die("a lock-step proof differs from the single-segment proof", NULL);
+        printf("lockstep ok: 2 segments, each blob == the single-segment proof\n");
+        free(both[0]);
+        free(both[1]);
+    }
     zkm_ctx_destroy(ctx);
 
     f = fopen(argv[2], "wb");
