@@ -24,14 +24,16 @@ HEIGHTS = {16: [16, 16, 10, 10, 11, 8, 12, 12, 12, 6, 13, 17],
            20: [19, 20, 14, 14, 15, 12, 16, 16, 16, 10, 17, 21]}
 
 
-def tiled_segment(ctx, log_cycles):
+def tiled_segment(ctx, log_cycles, shrink=0):
+    """shrink = k: the precompile tables (everything but Arithmetic, Cpu, Memory) are 2^k times shorter (never below the test segment's own
+    heights) -- segments of one program differ in how much hashing they do."""
     from zkm_amd import tables as T
     seg = np.load(os.path.join(ROOT, "tests", "golden", "segment12.npz"))
     base = [int(x) for x in seg["log_n"]]
     bufs, logs = [], []
     for i in range(12):
         w = T.WIDTH[T.TABLE_ENUM_ORDER[i]]
-        L = max(HEIGHTS[log_cycles][i], base[i])
+        L = max(HEIGHTS[log_cycles][i] - (shrink if i not in (0, 1, 11) else 0), base[i])
         t = np.ascontiguousarray(np.tile(seg["t%d" % i].reshape(w, -1), (1, 1 << (L - base[i])))).reshape(-1)
         bufs.append(ctx.alloc(t.size).upload(t))
         logs.append(L)
@@ -115,7 +117,7 @@ def concurrent_segment_rate(device, log_cycles, nctx, reps=6, tuning=None, cu_pa
     return {"contexts": nctx, "segments_per_context": reps, "segments_per_s": nctx * reps / wall, "ms_per_segment_amortised": wall * 1e3 / (nctx * reps)}
 
 
-def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, host=False):
+def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, host=False, ragged=0):
     """zkm_prove_segments: `nctx` host threads with one context each, every call proving `stack` independent segments in LOCK-STEP
     (one launch per stage for all of them; include/zkm_hip.h).  The segments of a call share the tiled traces in HBM and differ in
     their public values, so every segment has its own transcript, challenges and proof."""
@@ -140,6 +142,14 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, 
             pinned.append((c, hb))
             data[i] = (hb, logs)
     segs = [[(bufs, logs, [1, 2, 3, i, j]) for j in range(stack)] for i, (bufs, logs) in enumerate(data)]
+    extra = []
+    if ragged and not host:
+        # RAGGED calls: segment j of a call has its precompile tables 2^(j % ragged) times shorter -- every such table then forms `ragged`
+        # groups (one per height) instead of one
+        for i, c in enumerate(ctxs):
+            variants = [data[i]] + [tiled_segment(c, log_cycles, shrink=k) for k in range(1, ragged)]
+            extra.append(variants[1:])
+            segs[i] = [(variants[j % ragged][0], variants[j % ragged][1], [1, 2, 3, i, j]) for j in range(stack)]
     for c, sg in zip(ctxs, segs):
         c.prove_segments(sg)                      # warm-up: allocator, twiddles, power tables
         c.synchronize()
@@ -162,13 +172,17 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, 
     for c, hb in pinned:
         for h in hb:
             c.free_pinned(h)
+    for vs in extra:
+        for bufs, _ in vs:
+            for b in bufs:
+                b.free()
     for c, (bufs, _) in zip(ctxs, data):
         if not host:
             for b in bufs:
                 b.free()
         c.close()
     total = nctx * stack * reps
-    return {"contexts": nctx, "segments_per_call": stack, "calls_per_context": reps, "segments_per_s": total / wall, "traces": "pinned host memory" if host else "HBM",
+    return {"contexts": nctx, "segments_per_call": stack, "calls_per_context": reps, "segments_per_s": total / wall, "traces": "pinned host memory" if host else "HBM", "ragged_heights": ragged,
             "ms_per_segment_amortised": wall * 1e3 / total, "ms_per_call": wall * 1e3 / reps, "tuning": tuning or {},
             "memory_live_cached_GB": [round((m[0] + m[1]) / 2**30, 2) for m in mem]}
 

@@ -16,16 +16,19 @@ for spec in sys.argv[1:]:
     tuning = {}
     reps = 3
     host = False
+    ragged = 0
     for kv in parts[2:]:
         key, v = kv.split("=")
         if key == "reps":
             reps = int(v)
         elif key == "host":
             host = bool(int(v))
+        elif key == "ragged":
+            ragged = int(v)
         else:
             tuning[key] = int(v)
     try:
-        r = lockstep_segment_rate(int(os.environ.get("ZKM_BENCH_DEVICE", "0")), 16, g, k, reps=reps, tuning=tuning, host=host)
+        r = lockstep_segment_rate(int(os.environ.get("ZKM_BENCH_DEVICE", "0")), 16, g, k, reps=reps, tuning=tuning, host=host, ragged=ragged)
     except Exception as e:  # keep sweeping
         r = {"contexts": g, "segments_per_call": k, "tuning": tuning, "error": str(e)[:300]}
     print(json.dumps(r), flush=True)
