@@ -336,3 +336,13 @@ def test_every_tuning_key_is_documented_in_the_header():
     integ = open(os.path.join(root, "INTEGRATION.md")).read()
     named = set(re.findall(r'zkm_ctx_set_tuning\([^)]*?"([a-z_0-9]+)"', integ)) | set(re.findall(r'set_tuning\("([a-z_0-9]+)"', integ))
     assert named <= code_keys, sorted(named - code_keys)
+
+
+def test_every_tuning_key_is_documented_in_the_header():
+    """zkm_ctx_set_tuning: the keys the library accepts (csrc/core.hip) are exactly the keys include/zkm_hip.h documents -- a knob added to
+    one side only fails here."""
+    core = open(os.path.join(ROOT, "zkm_amd", "csrc", "core.hip")).read()
+    accepted = set(re.findall(r'k == "([a-z_0-9]+)"', core))
+    header = open(os.path.join(ROOT, "include", "zkm_hip.h")).read()
+    documented = set(re.findall(r'\*\s+"([a-z_0-9]+)"\s', header))
+    assert accepted and accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
