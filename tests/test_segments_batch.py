@@ -228,3 +228,30 @@ def test_lockstep_groups_of_tall_tables_in_the_digit_coefficient_layout(ctx, zkm
     finally:
         oracle.set_threads(old)
     assert (got[1][0] == ref).all() and (got[1][1] == rchal).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fields", [dict(num_challenges=1), dict(cap_height=2, num_queries=11), dict(arity_bits=3, final_poly_bits=2, pow_bits=9),
+                                    dict(cap_height=0, arity_bits=2, final_poly_bits=1, num_queries=5)])
+def test_lockstep_groups_under_other_stark_configs(ctx, zkm, oracle, fields):
+    """Every field of StarkConfig (config.rs:4-34) that the stacked kernels index by segment -- one or two constraint challenges, the
+    cap height (caps per segment in one download), the FRI arity / final polynomial length, the proof-of-work bits, the number of query
+    rounds: lock-step == one at a time == the oracle under a non-standard config."""
+    from zkm_amd import tables as T
+    cfg, ocfg = ctx.standard_config(), oracle.standard_config()
+    for k, v in fields.items():
+        setattr(cfg, k, v)
+        setattr(ocfg, k, v)
+    segs = []
+    for v in range(3):
+        tr, lg = _segment(v)
+        segs.append((tr, lg, [v, 5]))
+    got = ctx.prove_segments(segs, cfg=cfg)
+    for v, (tr, lg, pub) in enumerate(segs):
+        want, wchal, woffs = ctx.prove_segment(tr, lg, public_values=pub, cfg=cfg)
+        assert list(got[v][2]) == list(woffs) and (got[v][1] == wchal).all() and (got[v][0] == want).all(), (fields, v)
+    ctl_tables, ctls = T.all_cross_table_lookups()
+    tr, lg, pub = segs[2]
+    tables = [(T.TABLE_ENUM_ORDER[i], tr[i], T.WIDTH[T.TABLE_ENUM_ORDER[i]], lg[i], ctl_tables[i]) for i in range(12)]
+    ref, rchal, _ = oracle.prove_with_traces(tables, ctls, public_values=pub, cfg=ocfg)
+    assert (got[2][0] == ref).all() and (got[2][1] == rchal).all()
