@@ -123,6 +123,9 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, 
     their public values, so every segment has its own transcript, challenges and proof."""
     import threading
     import zkm_amd
+    if os.environ.get("ZKM_SLEEPING_WAITS") == "1":     # host waits that sleep (with tuning block_after_us=0): before the first context
+        import ctypes
+        ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(ctypes.c_uint(4))       # hipDeviceScheduleBlockingSync
     ctxs = [zkm_amd.Context(device) for _ in range(nctx)]
     for c in ctxs:
         for k, v in (tuning or {}).items():
@@ -164,10 +167,14 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, 
     for t in th:
         t.start()
     start.wait()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     for t in th:
         t.join()
     wall = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     mem = [c.memory() for c in ctxs]
     for c, hb in pinned:
         for h in hb:
@@ -183,7 +190,8 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, 
         c.close()
     total = nctx * stack * reps
     return {"contexts": nctx, "segments_per_call": stack, "calls_per_context": reps, "segments_per_s": total / wall, "traces": "pinned host memory" if host else "HBM", "ragged_heights": ragged,
-            "ms_per_segment_amortised": wall * 1e3 / total, "ms_per_call": wall * 1e3 / reps, "tuning": tuning or {},
+            "ms_per_segment_amortised": wall * 1e3 / total, "ms_per_call": wall * 1e3 / reps, "cpu_seconds_per_segment": cpu_s / total,
+            "host_cpus_busy": cpu_s / wall, "tuning": tuning or {},
             "memory_live_cached_GB": [round((m[0] + m[1]) / 2**30, 2) for m in mem]}
 
 
