@@ -191,7 +191,8 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, 
     total = nctx * stack * reps
     return {"contexts": nctx, "segments_per_call": stack, "calls_per_context": reps, "segments_per_s": total / wall, "traces": "pinned host memory" if host else "HBM", "ragged_heights": ragged,
             "ms_per_segment_amortised": wall * 1e3 / total, "ms_per_call": wall * 1e3 / reps, "cpu_seconds_per_segment": cpu_s / total,
-            "host_cpus_busy": cpu_s / wall, "tuning": tuning or {},
+            "host_cpus_busy": cpu_s / wall, "host_waits": "sleeping" if os.environ.get("ZKM_SLEEPING_WAITS") == "1" else "polling",
+            "tuning": tuning or {},
             "memory_live_cached_GB": [round((m[0] + m[1]) / 2**30, 2) for m in mem]}
 
 
@@ -232,6 +233,9 @@ def lockstep_rates(device, shapes=((4, 8), (8, 8)), reps=3):
     import subprocess
     env = dict(os.environ, GPU_MAX_HW_QUEUES="16", ZKM_BENCH_DEVICE=str(device))
     specs = ["%d,%d,throughput_profile=1,reps=%d" % (g, k, reps) for g, k in shapes]
+    # ... and the last shape once more with SLEEPING host waits (blocking-sync device flag + block_after_us 0): the rate next to the host
+    # CPUs it keeps busy (`host_cpus_busy`; polling: one per context)
+    specs.append("%d,%d,throughput_profile=1,reps=%d,sleeping=1" % (shapes[-1][0], shapes[-1][1], reps))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_lockstep.py")] + specs, capture_output=True, text=True, timeout=600, env=env)
     if r.returncode != 0:
         raise RuntimeError("sweep_lockstep failed: " + r.stderr[-400:])

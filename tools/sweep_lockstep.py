@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Sweep of zkm_prove_segments on 2^16-cycle twelve-table segments: contexts x segments per call x tunings -> segments/s.
-   python tools/sweep_lockstep.py "G,K[,key=value...]" ...     one JSON line per configuration"""
+   python tools/sweep_lockstep.py "G,K[,key=value...]" ...     one JSON line per configuration
+   keys: any zkm_ctx_set_tuning key, reps=N, host=1 (traces in pinned host memory), ragged=k, sleeping=1 (blocking-sync waits; last spec only)"""
 import json
 import os
 import sys
@@ -25,6 +26,10 @@ for spec in sys.argv[1:]:
             host = bool(int(v))
         elif key == "ragged":
             ragged = int(v)
+        elif key == "sleeping":        # host waits that sleep: the device flag is process-wide, so put such a spec LAST
+            if int(v):
+                os.environ["ZKM_SLEEPING_WAITS"] = "1"
+                tuning["block_after_us"] = 0
         else:
             tuning[key] = int(v)
     try:
