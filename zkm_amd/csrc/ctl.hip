@@ -767,6 +767,12 @@ static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t 
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         if (nseg == 0) return;
+        // The allocator's free lists are exact-size, and the sizes of a call's blocks are those of its stacks: a call of another
+        // height would leave the blocks of BOTH heights cached (8 segments per call: 14.5 GB per context -- twice that after one
+        // call of 7).  The cache is returned to the device when the number of segments per call changes (a few hipFree / hipMalloc
+        // on the next call; calls of one height -- the steady state -- never get here).
+        if (c->last_stack && c->last_stack != nseg && (nseg > 1 || c->last_stack > 1)) c->trim();
+        c->last_stack = nseg;
         const zkm_table_input* T0 = io[0].tables;
         for (size_t s = 0; s < nseg; s++) {
             if (!io[s].tables || !io[s].proofs || !io[s].challenges) throw std::runtime_error("zkm_prove_with_traces: null argument");

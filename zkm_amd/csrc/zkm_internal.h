@@ -66,6 +66,7 @@ struct zkm_ctx {
     int aux_pipeline = 1;               // segments of short tables: lanes build later tables' auxiliary commitments behind the proofs      } zkm_ctx_set_tuning
     size_t commit_lanes = ZKM_COMMIT_LANES;   // trace / auxiliary commitments of one segment in flight (this context + lanes)   } zkm_ctx_set_tuning
     size_t segments_memory_budget = 0;  // bytes one wave of a zkm_prove_segments call may hold (0: 60 % of what is free, per live context)   } zkm_ctx_set_tuning
+    size_t last_stack = 0;              // segments of the previous prove_with_traces call of this context (0: none yet)
     size_t max_stack = ZKM_MAX_SEG;     // segments of one lock-step group (zkm_prove_segments): 1 .. ZKM_MAX_SEG               } zkm_ctx_set_tuning
     size_t wide_max_hashes = 1024;      // launches of up to this many hashes use 16 lanes per hash (latency form)   } 0 / 0: one lane
     size_t quad_max_hashes = 32768;     // ... and up to this many four lanes per hash                                } per hash always
