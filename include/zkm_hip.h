@@ -353,6 +353,15 @@ int zkm_prove_single_table(zkm_ctx* ctx, int table_id, const zkm_stark_config* c
                            char** err);
 
 
+/* K proofs of the same table at the same height in lock-step (cf. zkm_prove_segments): K calls of zkm_prove_single_table -- traces[k],
+ * aux[k], challengers[k], proofs_out[k] as that entry point takes them (trace values required; the benchmark's CtlData shape) -- as one:
+ * stacked trace / auxiliary / quotient commitments, one launch per stage and one transcript round trip per stage for all K.  Every
+ * blob and every challenger state equals the single call's.  At most 32 proofs per call; tables with lookups of their own (Memory,
+ * Arithmetic) go through zkm_prove_segments.  ~14.6 GB of HBM per 262 x 2^20 proof in flight. */
+int zkm_prove_single_tables(zkm_ctx* ctx, int table_id, const zkm_stark_config* cfg, size_t nproofs, const uint64_t* const* traces, size_t ncols,
+                            unsigned log_n, const uint64_t* const* aux, size_t naux, const uint32_t* num_helpers, size_t nctl_zs,
+                            zkm_challenger* const* challengers, uint64_t* const* proofs_out, char** err);
+
 /* ------------------------------------------------------------------ a3/a7: cross-table lookups, data-driven
  * Column / Filter / TableWithColumns / CrossTableLookup (prover/src/cross_table_lookup.rs:31-415) restated as
  * plain arrays so that the same description drives CTL data generation (a3), the CTL constraint checks inside

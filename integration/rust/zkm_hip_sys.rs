@@ -168,6 +168,9 @@ extern "C" {
     pub fn zkm_prove_segments_columns(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, nseg: usize, columns: *const *const *const *const u64,
                                       log_n: *const *const c_uint, public_values: *const *const u64, npublic: *const usize,
                                       proofs_out: *const *mut u64, ctl_challenges_out: *const *mut u64, err: *mut *mut c_char) -> c_int;
+    pub fn zkm_prove_single_tables(ctx: *mut zkm_ctx, table_id: c_int, cfg: *const zkm_stark_config, nproofs: usize, traces: *const *const u64,
+                                   ncols: usize, log_n: c_uint, aux: *const *const u64, naux: usize, num_helpers: *const u32, nctl_zs: usize,
+                                   challengers: *const *mut zkm_challenger, proofs_out: *const *mut u64, err: *mut *mut c_char) -> c_int;
     pub fn zkm_fri_proof_words(cfg: *const zkm_stark_config, log_n: c_uint, oracle_cols: *const usize, noracles: usize) -> usize;
     pub fn zkm_fri_prove(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, oracles: *const *const zkm_batch, noracles: usize,
                          batches: *const zkm_fri_batch, nbatches: usize, challenger: *mut zkm_challenger, proof_out: *mut u64,

@@ -436,3 +436,33 @@ def test_every_admitted_fri_arity_proves_like_the_oracle(ctx, zkm, oracle, arity
     assert oracle.verify(got, 4, [1, 1], cfg=ocfg) == 0
     assert int(got[11]) == arity_bits
     trace_dev.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,K", [(6, 2), (11, 3), (14, 2), (18, 2)])
+def test_single_table_proofs_in_lockstep_equal_single_proofs(ctx, zkm, oracle, log_n, K):
+    """zkm_prove_single_tables: K PoseidonStark proofs (own witness seed, own transcript each) as ONE lock-step call -- stacked trace /
+    auxiliary / quotient commitments, the device-resident traces transformed where they lie -- against K zkm_prove_single_table calls,
+    and one of them against the oracle.  2^18 rows: the digit coefficient layout."""
+    n = 1 << log_n
+    traces = [ctx.poseidon_trace(seed=60 + k, num_perms=n - 1 - k, log_n=log_n) for k in range(K)]
+    aux = np.zeros(4 * n, dtype=np.uint64)
+    chs = []
+    for k in range(K):
+        ch = zkm.challenger_new()
+        zkm.challenger_observe(ch, [k, 17])
+        chs.append(ch)
+    got = ctx.prove_single_tables(traces, log_n, aux, [1, 1], challengers=chs)
+    for k in range(K):
+        ch = zkm.challenger_new()
+        zkm.challenger_observe(ch, [k, 17])
+        want = ctx.prove_single_table(traces[k], log_n, aux, [1, 1], challenger=ch)
+        assert (got[k] == want).all(), k
+        assert list(ch.state) == list(chs[k].state) and ch.n_in == chs[k].n_in and ch.n_out == chs[k].n_out   # same transcript state
+    if log_n <= 14:
+        och = oracle.challenger()
+        oracle.observe(och, [1, 17])
+        ref = oracle.prove(traces[1].download(), log_n, aux, [1, 1], challenger=och)
+        assert (got[1] == ref).all()
+    for t in traces:
+        t.free()

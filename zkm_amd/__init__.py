@@ -36,7 +36,7 @@ EXPORTS = [
     "zkm_sha_compress_trace", "zkm_sha_compress_sponge_trace",
     "zkm_table_width", "zkm_num_lookup_columns", "zkm_challenger_init",
     "zkm_challenger_observe", "zkm_challenger_get", "zkm_challenger_compact", "zkm_standard_config", "zkm_proof_words",
-    "zkm_prove_single_table", "zkm_prove_openings", "zkm_fri_prove", "zkm_fri_proof_words", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
+    "zkm_prove_single_table", "zkm_prove_single_tables", "zkm_prove_openings", "zkm_fri_prove", "zkm_fri_proof_words", "zkm_prove_single_table_ctl", "zkm_ctl_data", "zkm_lookup_helper_columns", "zkm_all_proof_words", "zkm_prove_with_traces",
     "zkm_proof_get_layout", "zkm_proof_get_query_layout", "zkm_segment_image_words", "zkm_segment_image_write", "zkm_prove_segment_image",
     "zkm_quotient", "zkm_eval_openings", "zkm_check_constraints", "zkm_profile_enable", "zkm_profile_reset",
     "zkm_profile_count", "zkm_profile_get", "zkm_version",
@@ -180,6 +180,9 @@ def load():
         "zkm_proof_words": (C.c_size_t, [C.POINTER(StarkConfig), C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t]),
         "zkm_prove_single_table": (C.c_int, [cp, C.c_int, C.POINTER(StarkConfig), cp, C.c_size_t, C.c_uint, cp, cp, C.c_size_t,
                                              C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Challenger), u64p, err]),
+        "zkm_prove_single_tables": (C.c_int, [cp, C.c_int, C.POINTER(StarkConfig), C.c_size_t, C.POINTER(C.c_void_p), C.c_size_t, C.c_uint,
+                                              C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_void_p), err]),
         "zkm_fri_proof_words": (C.c_size_t, [C.POINTER(StarkConfig), C.c_uint, C.POINTER(C.c_size_t), C.c_size_t]),
         "zkm_fri_prove": (C.c_int, [cp, C.POINTER(StarkConfig), cpp, C.c_size_t, cp, C.c_size_t, C.POINTER(Challenger), u64p, err]),
         "zkm_prove_openings": (C.c_int, [cp, C.POINTER(StarkConfig), cp, cp, cp, C.c_size_t, C.POINTER(Challenger), u64p, err]),
@@ -519,6 +522,27 @@ class Context:
                                              naux, nh, len(num_helpers), C.byref(ch), proof.ctypes.data_as(u64p),
                                              C.byref(err)), err)
         return proof
+
+    def prove_single_tables(self, traces, log_n, auxs, num_helpers, cfg=None, ncols=POSEIDON_COLS, table_id=TABLE_POSEIDON, challengers=None):
+        """zkm_prove_single_tables: K proofs of the same table in lock-step.  traces[k] / auxs[k] as prove_single_table takes them
+        (auxs may be ONE array used for every proof).  Returns the list of K proof blobs."""
+        cfg = cfg or self.standard_config()
+        K = len(traces)
+        if not isinstance(auxs, (list, tuple)):
+            auxs = [auxs] * K
+        chs = challengers if challengers is not None else [Challenger() for _ in range(K)]
+        naux = (auxs[0].size if isinstance(auxs[0], np.ndarray) else auxs[0].words) >> log_n
+        nh = (C.c_uint32 * len(num_helpers))(*num_helpers)
+        words = self.proof_words(cfg, log_n, ncols, naux, len(num_helpers))
+        proofs = [np.zeros(words, dtype=np.uint64) for _ in range(K)]
+        tp = (C.c_void_p * K)(*[_data_ptr(t).value for t in traces])
+        ap = (C.c_void_p * K)(*[_data_ptr(a).value for a in auxs])
+        cp_ = (C.c_void_p * K)(*[C.addressof(ch) for ch in chs])
+        pp = (C.c_void_p * K)(*[p.ctypes.data for p in proofs])
+        err = C.c_char_p()
+        _check(self.L.zkm_prove_single_tables(self.h, table_id, C.byref(cfg), K, tp, ncols, log_n, ap, naux, nh, len(num_helpers), cp_, pp,
+                                              C.byref(err)), err)
+        return proofs
 
     # ---- cross-table lookups (descriptor builders: zkm_amd/ctl.py)
     def ctl_data(self, ctl_table, zs, colset_ids, trace, ncols, log_n, out=None):

@@ -826,9 +826,13 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
     } else if (src_is_values) {
         // stage the values in the (not yet used) LDE buffer (or the caller's device copy), transform, land natural-order coefficients
         gl_t* vals = dev_values ? dev_values : b->lde;
-        bool all_dev = seg_srcs != nullptr && dev_values != nullptr;
+        bool all_dev = seg_srcs != nullptr;
         for (size_t sg = 0; all_dev && sg < nseg; sg++) all_dev = zkm_is_device_ptr(seg_srcs[sg]);
-        if (all_dev) {     // device-resident traces of a lock-step group: gathered and canonicalised in one pass
+        if (all_dev && !dev_values) {
+            // device-resident value matrices nobody needs a stacked copy of: every segment's inverse transform reads its matrix where
+            // it lies and lands its coefficients in the segment's columns of the stack (no gather: 2 GiB per 262 x 2^20 matrix)
+            for (size_t sg = 0; sg < nseg; sg++) inverse_transform(seg_srcs[sg], sg * b->ncols, b->ncols);
+        } else if (all_dev) {     // device-resident traces of a lock-step group: gathered and canonicalised in one pass
             seg_ptrs sp{};
             for (size_t sg = 0; sg < nseg; sg++) sp.p[sg] = seg_srcs[sg];
             const size_t words = b->ncols * n;
@@ -840,7 +844,7 @@ void zkm_batch_build(zkm_batch* b, const uint64_t* src, bool src_is_values, gl_t
             copy_cols(vals, 0, ncols, kind, c->stream);
             if (dev_values) zkm_launch_canon(c, vals, ncols * n);
         }
-        inverse_transform(vals, 0, ncols);
+        if (!(all_dev && !dev_values)) inverse_transform(vals, 0, ncols);
     } else {
         copy_cols(b->coeffs, 0, ncols, kind, c->stream);
     }

@@ -1884,6 +1884,69 @@ int zkm_prove_single_table(zkm_ctx* c, int table_id, const zkm_stark_config* cfg
     }
 }
 
+// K proofs of the same table at the same height in LOCK-STEP (the benchmark shape: CtlData given as auxiliary columns, no column sets):
+// the K trace and auxiliary commitments are stacked batches, every stage is one launch for all K, each transcript round trip serves
+// all K.  Tables with lookups of their own need zkm_prove_segments.
+int zkm_prove_single_tables(zkm_ctx* c, int table_id, const zkm_stark_config* cfg, size_t nproofs, const uint64_t* const* traces, size_t ncols,
+                            unsigned log_n, const uint64_t* const* aux, size_t naux, const uint32_t* num_helpers, size_t nctl_zs,
+                            zkm_challenger* const* challengers, uint64_t* const* proofs_out, char** err) {
+    if (!c || !cfg || !traces || !aux || !challengers || !proofs_out) return fail(err, "zkm_prove_single_tables: null argument");
+    if (nproofs == 0) return 0;
+    zkm_batch *tb = nullptr, *ab = nullptr;
+    std::vector<zkm_challenger> local(nproofs);
+    try {
+        ZKM_HIP_CHECK(hipSetDevice(c->device));
+        if (nproofs > ZKM_MAX_SEG) throw std::runtime_error("zkm_prove_single_tables: at most 32 proofs per call");
+        validate_config(cfg, log_n);
+        if (zkm_num_lookup_columns(table_id, cfg)) throw std::runtime_error("zkm_prove_single_tables: a table with lookups of its own needs zkm_prove_segments");
+        auto zs1 = fake_zs(num_helpers, nctl_zs);
+        std::vector<zkm_ctl_z> zs;
+        for (size_t k = 0; k < nproofs; k++) zs.insert(zs.end(), zs1.begin(), zs1.end());
+        std::vector<zkm_challenger*> chs(nproofs);
+        std::vector<uint64_t*> proofs(nproofs);
+        for (size_t k = 0; k < nproofs; k++) {
+            if (!traces[k] || !aux[k] || !challengers[k] || !proofs_out[k]) throw std::runtime_error("zkm_prove_single_tables: null proof argument");
+            local[k] = *challengers[k];
+            chs[k] = &local[k];
+            proofs[k] = proofs_out[k];
+        }
+        auto stacked = [&](size_t cols, const uint64_t* const* srcs) {
+            zkm_batch* b = new zkm_batch();
+            b->ctx = c; b->ncols = cols; b->nseg = nproofs; b->log_n = log_n; b->rate_bits = cfg->rate_bits; b->cap_height = cfg->cap_height;
+            try {
+                if (nproofs == 1) zkm_batch_build(b, srcs[0], true);
+                else zkm_batch_build(b, nullptr, true, nullptr, nullptr, srcs);   // (device matrices are transformed where they lie)
+            } catch (...) {
+                zkm_batch_free(b);
+                throw;
+            }
+            return b;
+        };
+        {
+            zkm_prof_scope st(c, "stage/compute trace commitment");
+            tb = stacked(ncols, traces);
+        }
+        {
+            zkm_prof_scope st(c, "stage/compute auxiliary polynomials commitment");
+            ab = stacked(naux, aux);
+        }
+        prove_single_table(c, table_id, cfg, nullptr, ncols, log_n, tb, nullptr, naux, nullptr, zs.data(), nullptr, nctl_zs, nullptr, chs, proofs, ab,
+                           nullptr);
+    } catch (const std::exception& e) {
+        zkm_batch_free(tb);
+        zkm_batch_free(ab);
+        return fail(err, e.what());
+    } catch (...) {
+        zkm_batch_free(tb);
+        zkm_batch_free(ab);
+        return fail(err, "zkm_prove_single_tables: unknown error");
+    }
+    zkm_batch_free(tb);
+    zkm_batch_free(ab);
+    for (size_t k = 0; k < nproofs; k++) *challengers[k] = local[k];
+    return 0;
+}
+
 int zkm_quotient(zkm_ctx* c, int table_id, const zkm_batch* trace, const zkm_batch* aux, const uint32_t* num_helpers, size_t nctl_zs,
                  const uint64_t* alphas, size_t nalphas, uint64_t* out_coeffs, char** err) {
     try {
