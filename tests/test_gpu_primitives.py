@@ -116,6 +116,30 @@ def test_leaf_sponge_modes_at_chunk_boundaries(ctx, zkm, oracle, ncols):
     b.free()
 
 
+@pytest.mark.parametrize("log_n,ncols", [(5, 13), (6, 262), (9, 9), (11, 16), (13, 135)])
+def test_leaf_hashing_on_the_matrix_core_equals_the_vector_form(zkm, oracle, log_n, ncols):
+    """One-lane-per-leaf hashing with the MDS layers of the full rounds on the matrix core (tuning key leaf_mfma, poseidon_mfma_dev.h)
+    against the multiply-add form and the oracle: every digest.  The latency forms are switched off so that short matrices take the
+    one-lane kernel too -- 2^5 rows = 128 leaves leave half of a 256-lane workgroup past the end (MFMA ignores EXEC: those lanes stay
+    alive on the last row); column counts cover the capacity-only, all-rows and digest forms of the last layer."""
+    rng = np.random.default_rng(5100 + 7 * log_n + ncols)
+    vals = rand_field(rng, ncols << log_n)
+    ob = oracle.batch_from_values(vals, ncols, log_n)
+    layers = {}
+    for mfma in (0, 1):
+        c = zkm.Context(0)
+        for k in ("wide_max_hashes", "quad_max_hashes"):
+            c.set_tuning(k, 0)
+        c.set_tuning("leaf_mfma", mfma)
+        b = zkm.PolynomialBatch.from_values(c, vals, ncols, log_n)
+        layers[mfma] = b.digest_layer(0).copy()
+        assert (b.cap() == ob.cap()).all(), mfma
+        b.free()
+        c.close()
+    assert (layers[0] == layers[1]).all()
+    assert (layers[1] == ob.digest_layer(0)).all()
+
+
 def test_commit_other_rate_and_cap(ctx, zkm, oracle):
     rng = np.random.default_rng(77)
     log_n, ncols = 6, 11

@@ -114,6 +114,7 @@ void zkm_ctx::ensure_lanes(size_t k) {
         l->keccak_parts_max_points = keccak_parts_max_points;
         l->fri_fused_division_min = fri_fused_division_min;
         l->wide_max_hashes = wide_max_hashes;
+        l->leaf_mfma = leaf_mfma;
         l->quad_max_hashes = quad_max_hashes;
         l->small_ntt = small_ntt;
         l->tree_tail = tree_tail;
@@ -491,6 +492,7 @@ int zkm_ctx_set_tuning(zkm_ctx* c, const char* key, uint64_t value, char** err) 
         else if (k == "keccak_parts_max_points") x->keccak_parts_max_points = (size_t)value;
         else if (k == "fri_fused_division_min") x->fri_fused_division_min = (size_t)value;
         else if (k == "wide_max_hashes") x->wide_max_hashes = (size_t)value;
+        else if (k == "leaf_mfma") x->leaf_mfma = value ? 1 : 0;
         else if (k == "quad_max_hashes") x->quad_max_hashes = (size_t)value;
         else if (k == "block_after_us") x->block_after_us = value;
         else if (k == "small_ntt") x->small_ntt = value ? 1 : 0;

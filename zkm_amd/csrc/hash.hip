@@ -12,6 +12,7 @@
 #include <atomic>
 #include "poseidon_dev.h"
 #include "poseidon_lat_dev.h"
+#include "poseidon_mfma_dev.h"
 #include "hash_constants_dev.h"
 #include "zkm_internal.h"
 
@@ -51,12 +52,19 @@ void zkm_launch_poseidon_permute(zkm_ctx* c, gl_t* states, size_t k) {
 // ------------------------------------------------------------------ Merkle leaves (column-major rows)
 // (every leaf / tree kernel: blockIdx.z = segment of a stacked batch, zkm_internal.h -- its matrix starts lde_seg words, its digest
 // block dig_seg words after the previous segment's)
-__global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ lde, size_t nrows, size_t ncols,
-                                                       size_t col_stride, gl_t* __restrict__ digests, size_t lde_seg, size_t dig_seg) {
+// MFMA = true: the MDS layers of the full rounds run on the matrix core (poseidon_mfma_dev.h).  MFMA ignores EXEC, so that form keeps
+// the lanes past the last row alive on the last row's data and only masks their store.
+template <bool MFMA>
+__device__ __forceinline__ void merkle_leaves_body(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests,
+                                                   size_t lde_seg, size_t dig_seg) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nrows) return;
+    const bool live = j < nrows;
+    if (!MFMA && !live) return;
+    if (!live) j = nrows - 1;
     lde += (size_t)blockIdx.z * lde_seg;
     digests += (size_t)blockIdx.z * dig_seg;
+    typename std::conditional<MFMA, poseidon_mds_mfma, poseidon_mds_valu>::type mds;
+    if constexpr (MFMA) mds.A = poseidon_mfma_operand();
     uint64_t s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
@@ -73,19 +81,35 @@ __global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ 
             for (int i = 0; i < 8; i++) s[i] = v[i];
             // another whole chunk follows: it replaces words 0..7, only the capacity words are carried over.  Before a ragged chunk
             // (it keeps words rem..7) and at the end (digest) the whole state is needed.
-            poseidon_permute_out(s, c + 16 <= ncols ? POSEIDON_OUT_CAPACITY : (c + 8 == ncols ? POSEIDON_OUT_DIGEST : POSEIDON_OUT_ALL));
+            poseidon_permute_out_t(s, c + 16 <= ncols ? POSEIDON_OUT_CAPACITY : (c + 8 == ncols ? POSEIDON_OUT_DIGEST : POSEIDON_OUT_ALL), mds);
         }
         if (c < ncols) {
             size_t rem = ncols - c;
 #pragma unroll
             for (int i = 0; i < 8; i++)
                 if ((size_t)i < rem) s[i] = p[(c + i) * col_stride];
-            poseidon_permute_out(s, POSEIDON_OUT_DIGEST);
+            poseidon_permute_out_t(s, POSEIDON_OUT_DIGEST, mds);
         }
     }
+    if (!live) return;
     uint64_t* d = digests + 4 * j;
     *reinterpret_cast<ulonglong2*>(d) = make_ulonglong2(s[0], s[1]);
     *reinterpret_cast<ulonglong2*>(d + 2) = make_ulonglong2(s[2], s[3]);
+}
+
+__global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride,
+                                                       gl_t* __restrict__ digests, size_t lde_seg, size_t dig_seg) {
+    merkle_leaves_body<false>(lde, nrows, ncols, col_stride, digests, lde_seg, dig_seg);
+}
+// four waves per SIMD (<= 128 registers): the layer holds 24 byte planes, a 16-register accumulator tuple and up to 48 registers of
+// half-word sums next to the operand of the matrix and the prefetched chunk
+#ifndef ZKM_LEAF_MFMA_WAVES
+#define ZKM_LEAF_MFMA_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZKM_LEAF_MFMA_WAVES, ZKM_LEAF_MFMA_WAVES)))
+void k_merkle_leaves_mfma(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests, size_t lde_seg,
+                          size_t dig_seg) {
+    merkle_leaves_body<true>(lde, nrows, ncols, col_stride, digests, lde_seg, dig_seg);
 }
 
 __global__ void k_merkle_leaves_quad(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests,
@@ -109,9 +133,12 @@ void zkm_launch_merkle_leaves(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t 
         // permutation's full latency per 8 columns; four lanes per leaf cut that latency to a third and fill 4x the lanes
         hipLaunchKernelGGL(k_merkle_leaves_quad, dim3((nrows * 4 + 255) / 256, 1, z), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests,
                            lde_seg, dig_seg);
+    else if (c->leaf_mfma && ncols > 4)
+        hipLaunchKernelGGL(k_merkle_leaves_mfma, dim3((nrows + 255) / 256, 1, z), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests,
+                           lde_seg, dig_seg);
     else
-        hipLaunchKernelGGL(k_merkle_leaves, dim3((nrows + 255) / 256, 1, z), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests, lde_seg,
-                           dig_seg);
+        hipLaunchKernelGGL(k_merkle_leaves, dim3((nrows + 255) / 256, 1, z), dim3(256), 0, c->stream, lde, nrows, ncols, col_stride, digests,
+                           lde_seg, dig_seg);
     ZKM_HIP_CHECK(hipGetLastError());
 }
 

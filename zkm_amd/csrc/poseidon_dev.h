@@ -218,8 +218,16 @@ GL_HD void poseidon_partial_group(uint64_t s[12], uint64_t c1, uint64_t c2, cons
 //   DIGEST: words 0..3, canonical; words 4..11 are garbage.
 enum { POSEIDON_OUT_ALL = 0, POSEIDON_OUT_CAPACITY = 1, POSEIDON_OUT_DIGEST = 2 };
 
+// The MDS layer of a full round: s <- M s + constants of round `next` (30 = none).  poseidon_mfma_dev.h has the matrix-core form.
+struct poseidon_mds_valu {
+    GL_HD void layer(uint64_t s[12], int next) const {
+        poseidon_mds_add<true>(s, next < 30 ? &PC::ZKM_POSEIDON_RC[next * 12] : PC::ZKM_POSEIDON_ZERO12);
+    }
+};
+
 // In: any uint64 words (loose).  `out` must be wave-uniform on the device (it selects code, not lanes).
-GL_HD void poseidon_permute_out(uint64_t s[12], int out) {
+template <class MDS>
+GL_HD void poseidon_permute_out_t(uint64_t s[12], int out, const MDS& mds) {
     POSEIDON_REGION("entry");
     const uint64_t* rc0 = PC::ZKM_POSEIDON_RC;
     POSEIDON_OPAQUE_PTR(rc0);
@@ -257,7 +265,7 @@ GL_HD void poseidon_permute_out(uint64_t s[12], int out) {
             POSEIDON_REGION("full_mds");
             // full round r < 3 is round r, r > 3 is round 22 + r; the constants added are those of the NEXT round (none after the last)
             const int next = (r < 3 ? r : 22 + r) + 1;
-            poseidon_mds_add<true>(s, next < 30 ? &PC::ZKM_POSEIDON_RC[next * 12] : PC::ZKM_POSEIDON_ZERO12);
+            mds.layer(s, next);
         }
     }
     POSEIDON_REGION("exit");
@@ -269,6 +277,8 @@ GL_HD void poseidon_permute_out(uint64_t s[12], int out) {
         for (int i = 0; i < 4; i++) s[i] = gl_canon(s[i]);
     }
 }
+
+GL_HD void poseidon_permute_out(uint64_t s[12], int out) { poseidon_permute_out_t(s, out, poseidon_mds_valu{}); }
 
 // In: any uint64 words (loose).  Out: canonical.
 GL_HD void poseidon_permute(uint64_t s[12]) { poseidon_permute_out(s, POSEIDON_OUT_ALL); }

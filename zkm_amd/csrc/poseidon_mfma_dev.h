@@ -1,0 +1,137 @@
+// poseidon_mfma_dev.h -- the dense 12x12 MDS layer of the FULL rounds on the matrix core (device only, leaf hashing).
+//
+// v_mfma_i32_32x32x32_i8 computes D[i][n] = sum_k A[i][k] B[k][n] with lane l holding column n = l & 31 of B for the k-block l >> 5
+// (16 bytes) and, of D, column n = l & 31, rows (reg & 3) + 8 (reg >> 2) + 4 (l >> 5), reg = 0..15.  With A = blockdiag(M, M) written in
+// THAT row / k numbering, every lane receives M times the 16 bytes it supplied itself: one instruction multiplies one byte position
+// of the twelve state words of all 64 lanes by the matrix -- no cross-lane traffic, the permutation stays one hash per lane.
+// (Layout probed and the layer checked bit for bit against poseidon_mds_add by tools/ubench_mfma32.hip.)
+//
+//   per layer:  48 v_perm (4x4 byte transposes: byte b of words 4g..4g+3 -> one register) + 24 v_xor (byte - 128: the operands are int8)
+//               8 MFMAs (one per byte position; the matrix pipe, not the vector ALU)
+//               96 multiply-adds (four signed digits of weight 2^0, 2^8, 2^16, 2^24 per half-word) + the fold of poseidon_mds_add
+//   instead of 288 multiply-adds + the fold.  The accumulators start at half of the round constant + 128 rowsum 0x01010101, which makes each
+//   half the plain unsigned byte sum although the MFMA sees byte - 128 (tables below, derived at compile time from the round constants).
+//
+// MFMA ignores EXEC: a kernel that uses this keeps all lanes of its waves alive (no early return for the tail; clamp the index instead).
+// The fused partial-round layers (M^3: three int8 digit planes) and the 4-row last layer stay on the vector ALU (poseidon_dev.h).
+#pragma once
+#include "poseidon_dev.h"
+
+typedef int zkm_v4i __attribute__((ext_vector_type(4)));
+typedef int zkm_v16i __attribute__((ext_vector_type(16)));
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host pass of a .hip file: the names exist (kernels are parsed for the host too), nothing runs
+struct poseidon_mds_mfma {
+    zkm_v4i A;
+    GL_HD void layer(uint64_t s[12], int next) const { poseidon_mds_valu{}.layer(s, next); }
+};
+GL_HD zkm_v4i poseidon_mfma_operand() { return zkm_v4i{0, 0, 0, 0}; }
+#else
+
+namespace pc_cx {   // the round constants once more, as constant expressions
+#define ZKM_CONST static constexpr
+#define ZKM_CONSTEXPR static constexpr
+#include "poseidon_constants.inc"
+#undef ZKM_CONST
+#undef ZKM_CONSTEXPR
+}  // namespace pc_cx
+struct poseidon_mdsc_t { uint64_t v[31][12][2]; };   // [constants of round r; 30 = none][word][low / high half]
+constexpr poseidon_mdsc_t poseidon_make_mdsc() {
+    poseidon_mdsc_t t{};
+    for (int r = 0; r < 31; r++)
+        for (int w = 0; w < 12; w++) {
+            const uint64_t c = r < 30 ? pc_cx::ZKM_POSEIDON_RC[r * 12 + w] : 0;
+            const uint64_t off = (uint64_t)(w == 0 ? 128 * 264 : 128 * 256) * 0x01010101ull;   // rowsum: 256, + 8 on row 0
+            t.v[r][w][0] = (c & 0xFFFFFFFFull) + off;
+            t.v[r][w][1] = (c >> 32) + off;
+        }
+    return t;
+}
+static __device__ __constant__ const poseidon_mdsc_t ZKM_POSEIDON_MDSC = poseidon_make_mdsc();
+
+// A operand of this lane: lane l = (i = l & 31, h = l >> 5) holds row i of A for the k-block h.  Row i belongs to half (i >> 2) & 1 and
+// is register reg = (i & 3) + 4 (i >> 3) of that half's D tuple; registers 0..11 are the state words, 12..15 unused.
+__device__ __forceinline__ zkm_v4i poseidon_mfma_operand() {
+    const int l = threadIdx.x & 63, i = l & 31, h = l >> 5;
+    const int reg = (i & 3) + 4 * (i >> 3);
+    const bool mine = (((i >> 2) & 1) == h) && reg < 12;
+    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    zkm_v4i a = {0, 0, 0, 0};
+    for (int g = 0; g < 3; g++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 4; k++) {
+            const int j = 4 * g + k;
+            uint32_t m = 0;
+            for (int t = 0; t < 12; t++) m = ((j - reg + 12) % 12 == t) ? C[t] : m;   // C[(j - reg) mod 12] with a run-time reg
+            if (reg == 0 && j == 0) m += 8;
+            w |= m << (8 * k);
+        }
+        a[g] = mine ? (int)w : 0;
+    }
+    return a;
+}
+
+// in[k] = one 32-bit half of word k; out[b] = (in[0].byte b, in[1].byte b, in[2].byte b, in[3].byte b)
+__device__ __forceinline__ void poseidon_transpose4(const uint32_t in[4], uint32_t out[4]) {
+    // v_perm_b32(hi, lo, sel): byte i of the result = byte sel_i of the 8-byte value {hi, lo} (0..3 = lo, 4..7 = hi)
+    const uint32_t t0 = __builtin_amdgcn_perm(in[1], in[0], 0x05010400);  // (in0.b0, in1.b0, in0.b1, in1.b1)
+    const uint32_t t1 = __builtin_amdgcn_perm(in[1], in[0], 0x07030602);  // (in0.b2, in1.b2, in0.b3, in1.b3)
+    const uint32_t t2 = __builtin_amdgcn_perm(in[3], in[2], 0x05010400);
+    const uint32_t t3 = __builtin_amdgcn_perm(in[3], in[2], 0x07030602);
+    out[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100);
+    out[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302);
+    out[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100);
+    out[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302);
+}
+
+// s <- M s + (constants of round `next`; 30 = none).  In: loose words.  Out: loose words.
+__device__ __forceinline__ void poseidon_mds_add_mfma(uint64_t s[12], int next, const zkm_v4i A) {
+    const uint64_t (*cc)[2] = ZKM_POSEIDON_MDSC.v[next];
+    uint32_t T[3][8];
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            lo[k] = (uint32_t)s[4 * g + k];
+            hi[k] = (uint32_t)(s[4 * g + k] >> 32);
+        }
+        poseidon_transpose4(lo, &T[g][0]);
+        poseidon_transpose4(hi, &T[g][4]);
+    }
+    int m8 = 1 << 8, m16 = 1 << 16, m24 = 1 << 24;   // (kept in SGPRs: as literals they become 64-bit shifts and adds)
+    POSEIDON_OPAQUE(m8);
+    POSEIDON_OPAQUE(m16);
+    POSEIDON_OPAQUE(m24);
+    const zkm_v16i zero = {0};
+    int64_t al[12], ah[12];
+    // High halves first (byte positions 4..7), then the low ones: a word is folded as soon as its last digit has arrived.  An
+    // accumulator starts in the multiply-add of its first digit, from the scalar pair of its constant: nothing is live before.
+#pragma unroll
+    for (int bb = 0; bb < 8; bb++) {
+        const int b = bb ^ 4;   // 4, 5, 6, 7, 0, 1, 2, 3
+        const zkm_v4i B = {(int)(T[0][b] ^ 0x80808080u), (int)(T[1][b] ^ 0x80808080u), (int)(T[2][b] ^ 0x80808080u), 0};
+        zkm_v16i D = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, zero, 0, 0, 0);
+        // the first consumers of D_4 and D_0 are asm statements: nothing pads the MFMA's latency (8 passes) for those
+        if ((b & 3) == 0) asm volatile("s_nop 15" : "+v"(D));
+        const int mult = (b & 3) == 1 ? m8 : (b & 3) == 2 ? m16 : m24;
+#pragma unroll
+        for (int r = 0; r < 12; r++) {
+            if ((b & 3) == 0) {
+                int64_t acc;
+                uint64_t unused;
+                asm("v_mad_i64_i32 %0, %1, %2, 1, %3" : "=&v"(acc), "=&s"(unused) : "v"(D[r]), "s"(cc[r][b >> 2]));
+                if (b == 4) ah[r] = acc; else al[r] = acc;
+            } else if (b > 4) ah[r] += (int64_t)D[r] * mult;
+            else al[r] += (int64_t)D[r] * mult;
+            if (b == 3) s[r] = poseidon_fold((uint64_t)al[r], (uint64_t)ah[r]);
+        }
+        POSEIDON_SCHED_FENCE();   // one accumulator tuple live at a time
+    }
+}
+
+struct poseidon_mds_mfma {
+    zkm_v4i A;
+    __device__ __forceinline__ void layer(uint64_t s[12], int next) const { poseidon_mds_add_mfma(s, next, A); }
+};
+#endif

@@ -44,6 +44,9 @@ struct seg_gl2 { gl_t v[2 * ZKM_MAX_SEG]; };     // two per segment (an F2 eleme
 
 #ifndef ZKM_COMMIT_LANES
 #define ZKM_COMMIT_LANES 4   // trace commitments in flight per context (the context itself + 3 lanes)
+#ifndef ZKM_LEAF_MFMA_DEFAULT
+#define ZKM_LEAF_MFMA_DEFAULT 1
+#endif
 #endif
 
 struct zkm_twiddles {
@@ -68,6 +71,7 @@ struct zkm_ctx {
     size_t segments_memory_budget = 0;  // bytes one wave of a zkm_prove_segments call may hold (0: 60 % of what is free, per live context)   } zkm_ctx_set_tuning
     size_t last_stack = 0;              // segments of the previous prove_with_traces call of this context (0: none yet)
     size_t max_stack = ZKM_MAX_SEG;     // segments of one lock-step group (zkm_prove_segments): 1 .. ZKM_MAX_SEG               } zkm_ctx_set_tuning
+    int leaf_mfma = ZKM_LEAF_MFMA_DEFAULT;   // one-lane-per-leaf hashing: MDS layers of the full rounds on the matrix core (poseidon_mfma_dev.h)   } zkm_ctx_set_tuning
     size_t wide_max_hashes = 1024;      // launches of up to this many hashes use 16 lanes per hash (latency form)   } 0 / 0: one lane
     size_t quad_max_hashes = 32768;     // ... and up to this many four lanes per hash                                } per hash always
     int num_cus = 256;
