@@ -22,7 +22,7 @@ def main():
         tot["valu"] += c["SQ_INSTS_VALU"]
         tot["waves"] += c["SQ_WAVES"]
     rows.sort(reverse=True)
-    simds, ghz, cyc = 1024, 2.2, 3.6      # k_merkle_leaves at five waves per SIMD: 3.5-3.7 cycles per VALU instruction
+    simds, ghz, cyc = 1024, 2.2, 3.6      # the leaf kernel (k_merkle_leaves 5 waves / k_merkle_leaves_mfma 4 waves per SIMD): 3.5-3.7 cycles per VALU instruction
     ms = lambda v: v / nseg / simds * cyc / (ghz * 1e6)
     print("VALU wave-instructions per segment: %.3e in %.3e waves -> %.2f ms of a full GPU at %.1f cycles per instruction, %.1f GHz" %
           (tot["valu"] / nseg, tot["waves"] / nseg, ms(tot["valu"]), cyc, ghz))

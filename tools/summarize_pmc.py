@@ -41,15 +41,18 @@ except Exception:
 latest = {"source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; "
                     "the 262-column trace launch = max over the launches)" % os.path.basename(out.rstrip("/")),
           "code_fingerprint": fp, "proofs_profiled": proofs}
-ml = res.get("k_merkle_leaves", {}).get("pmc", {})
+# the one-lane leaf kernel: k_merkle_leaves_mfma when the tuning key leaf_mfma is on (the default), k_merkle_leaves otherwise; the digest
+# keeps the key "k_merkle_leaves" and names the kernel it was taken from
+leaf_kernel = "k_merkle_leaves_mfma" if "k_merkle_leaves_mfma" in res else "k_merkle_leaves"
+ml = res.get(leaf_kernel, {}).get("pmc", {})
 if "FETCH_SIZE" in ml and "WRITE_SIZE" in ml:
     fb, wb = 2 * 1024 * ml["FETCH_SIZE"]["max"], 1024 * ml["WRITE_SIZE"]["max"]
-    latest["k_merkle_leaves"] = {"fetch_bytes": fb, "write_bytes": wb, "traffic_bytes": fb + wb}
+    latest["k_merkle_leaves"] = {"kernel": leaf_kernel, "fetch_bytes": fb, "write_bytes": wb, "traffic_bytes": fb + wb}
     if "SQ_INSTS_VALU" in ml and "SQ_WAVES" in ml:
         latest["k_merkle_leaves"]["valu_insts_per_wave"] = ml["SQ_INSTS_VALU"]["max"] / ml["SQ_WAVES"]["max"]
     if "GRBM_GUI_ACTIVE" in ml:
         latest["k_merkle_leaves"]["grbm_gui_active_max"] = ml["GRBM_GUI_ACTIVE"]["max"]
-        st = res.get("k_merkle_leaves", {}).get("stats", {})
+        st = res.get(leaf_kernel, {}).get("stats", {})
         if st.get("max_ns"):
             # GPU cycles of the launch (the counter is summed over the 8 XCDs) over its duration in the kernel-trace pass: the clock the
             # kernel really ran at, which is what its issue fractions should be taken against (nominal: 2.4 GHz)
