@@ -88,7 +88,9 @@ __device__ __forceinline__ void merkle_leaves_body(const gl_t* __restrict__ lde,
 #pragma unroll
             for (int i = 0; i < 8; i++)
                 if ((size_t)i < rem) s[i] = p[(c + i) * col_stride];
-            poseidon_permute_out_t(s, POSEIDON_OUT_DIGEST, mds);
+            // (the one permutation of the ragged chunk in the multiply-add form: with the matrix-core layer this second copy of the
+            // round code needed 9 more registers than the 128 of four waves per SIMD and spilled them, 36 B per leaf)
+            poseidon_permute_out_t(s, POSEIDON_OUT_DIGEST, poseidon_mds_valu{});
         }
     }
     if (!live) return;
