@@ -62,6 +62,7 @@ BENCH_WORKER = textwrap.dedent("""
     import zkm_amd
     from zkm_amd import dist as zd
     proved = []
+    calls = []
     class Buf:
         def __init__(self, seed): self.seed = seed
         def upload(self, a): return self
@@ -73,6 +74,9 @@ BENCH_WORKER = textwrap.dedent("""
         def alloc(self, words): return Buf(None)
         def prove_single_table(self, trace, log_n, aux, nh):
             proved.append(trace.seed); time.sleep(0.01); return np.full(5, trace.seed, dtype=np.uint64)
+        def prove_single_tables(self, traces, log_n, aux, nh):
+            calls.append([t.seed for t in traces]); time.sleep(0.01 * len(traces))
+            return [self.prove_single_table(t, log_n, aux, nh) for t in traces]
         def synchronize(self): pass
         def set_tuning(self, key, value): pass
         def profile(self, on): pass
@@ -82,7 +86,7 @@ BENCH_WORKER = textwrap.dedent("""
     zkm_amd.Context = StubContext
     torch.cuda.is_available = lambda: True
     torch.cuda.set_device = lambda d: None
-    torch.cuda.synchronize = lambda: None
+    torch.cuda.synchronize = lambda: proved.append("sync")      # (the timed region is what lies between the first two)
     torch.cuda.device_count = lambda: 2
     torch.cuda.current_device = lambda: 0
     torch.cuda.mem_get_info = lambda d=None: (200 << 30, 288 << 30)
@@ -90,17 +94,27 @@ BENCH_WORKER = textwrap.dedent("""
     real_init = zd.init
     zd.init = lambda backend=None: real_init(%r)
     NCTX = %d
+    STACK = %d
     sys.argv = ["bench.py", "--gpus", "2", "--segments", "7", "--warmup", "1", "--log-n", "10", "--no-cpu-baseline", "--no-extras",
-                "--contexts", str(NCTX)]
+                "--contexts", str(NCTX), "--stack", str(STACK)]
     import runpy
     runpy.run_path(%r, run_name="__main__")
     rank = int(__import__("os").environ["RANK"])
     want = [100 + s for s in range(rank, 7, 2)]
-    timed = proved[NCTX:NCTX + len(want)]                           # the first NCTX calls are the warm-ups, one per context
-    if NCTX == 1:
-        assert timed == want, (rank, proved)                        # one context: in segment order
+    i0 = proved.index("sync"); i1 = proved.index("sync", i0 + 1)
+    warm, timed = proved[:i0], proved[i0 + 1:i1]
+    if NCTX == 1 and STACK == 1:
+        assert timed == want, (rank, proved)                        # one context, one proof per call: in segment order
     else:
-        assert sorted(timed) == want, (rank, proved)                # a queue: every segment of this rank exactly once
+        assert sorted(timed) == want, (rank, proved)                # a queue: every segment of this rank exactly once inside the clock
+    if STACK == 1:
+        assert len(warm) == NCTX and not calls                      # the warm-ups, one per context
+    else:
+        # lock-step calls: this rank's 4 (rank 0) or 3 (rank 1) segments in calls of at most STACK, the same number of calls per context
+        # (a call of one goes through prove_single_table); every context warms up with one call of its own first
+        assert all(1 < len(c) <= STACK for c in calls) and calls, (rank, calls)
+        nctx = min(NCTX, -(-len(want) // STACK))
+        assert len(warm) >= nctx, (rank, proved)
     print("RANK%%d OK %%s" %% (rank, proved))
 """)
 
@@ -108,15 +122,15 @@ BENCH_WORKER = textwrap.dedent("""
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("nctx,backend", [(1, "gloo"), (2, "gloo"), (2, "nccl")])
-def test_bench_sharding_path_two_rank_gloo(tmp_path, nctx, backend):
+@pytest.mark.parametrize("nctx,backend,stack", [(1, "gloo", 1), (2, "gloo", 1), (2, "nccl", 1), (2, "gloo", 2), (1, "gloo", 4)])
+def test_bench_sharding_path_two_rank_gloo(tmp_path, nctx, backend, stack):
     """backend "nccl": what the driver's multi-GPU run asks for.  There is no GPU here, so RCCL cannot come up -- the probe child of
     every rank fails, the ranks agree on that over the gloo control group, and the job must finish on gloo and say so."""
     script = tmp_path / "bench_worker.py"
-    script.write_text(BENCH_WORKER % (ROOT, backend, nctx, os.path.join(ROOT, "bench.py")))
+    script.write_text(BENCH_WORKER % (ROOT, backend, nctx, stack, os.path.join(ROOT, "bench.py")))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(29517 + nctx + (10 if backend == "nccl" else 0)), str(script)],
+                        "127.0.0.1", "--master-port", str(29517 + nctx + (10 if backend == "nccl" else 0) + 20 * stack), str(script)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "RANK0 OK" in r.stdout and "RANK1 OK" in r.stdout
@@ -125,7 +139,8 @@ def test_bench_sharding_path_two_rank_gloo(tmp_path, nctx, backend):
     import json
     j = json.loads(line[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["segments_total"] == 7 and j["config"]["segments_per_gpu"] == 4
-    assert j["config"]["contexts_per_gpu"] == nctx and j["single_context"]["ms_per_step"] > 0
+    assert j["config"]["contexts_per_gpu"] == min(nctx, -(-4 // stack)) and j["single_context"]["ms_per_step"] > 0
+    assert j["config"]["proofs_per_call"] == (1 if stack == 1 else (2 if stack == 2 else 4)) and sum(j["config"]["calls_per_gpu"]) == 4
     assert j["timed_segments"] == 7 and j["timed_segments_per_gpu"] == 4 and j["config"]["distinct_traces_per_gpu"] == 4
     assert j["config"]["proofs_gathered_on_rank0"] == 7            # gathered over the process group after the clock stopped
     if backend == "nccl":
@@ -160,6 +175,27 @@ def test_run_workers_queue_and_errors():
         return s
     with pytest.raises(ValueError, match="segment 5"):
         run_workers(bad, range(50), 3)
+
+    # lock-step calls: the queue holds calls of up to `stack` segments, every worker gets the same number of calls, sizes as even as possible
+    from zkm_amd.dist import chunk_segments
+    assert [len(c) for c in chunk_segments(range(20), 2, 4)] == [4, 4, 3, 3, 3, 3]
+    assert [len(c) for c in chunk_segments(range(8), 2, 4)] == [4, 4]
+    assert [len(c) for c in chunk_segments(range(3), 2, 4)] == [2, 1] and chunk_segments(range(3), 2, 1) == [[0], [1], [2]]
+    for nseg in range(0, 70):
+        for w in (1, 2, 3, 4):
+            for st in (2, 4, 5, 32):
+                c = chunk_segments(range(nseg), w, st)
+                assert [x for call in c for x in call] == list(range(nseg)) and all(0 < len(call) <= st for call in c)
+                assert len(c) % w == 0 or len(c) == nseg, (nseg, w, st, c)
+    shapes = []
+
+    def many(segs, w):
+        with lock:
+            shapes.append(len(segs))
+        return [s * s for s in segs]
+    assert run_workers(many, range(23), 2, stack=4) == {s: s * s for s in range(23)} and max(shapes) <= 4 and len(shapes) == 6
+    with pytest.raises(RuntimeError, match="proofs for a call"):
+        run_workers(lambda segs, w: [0], range(8), 2, stack=4)
 
 
 def test_one_rank_per_gpu_is_enforced(monkeypatch):

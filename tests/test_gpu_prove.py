@@ -439,11 +439,12 @@ def test_every_admitted_fri_arity_proves_like_the_oracle(ctx, zkm, oracle, arity
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_n,K", [(6, 2), (11, 3), (14, 2), (18, 2)])
+@pytest.mark.parametrize("log_n,K", [(6, 2), (11, 3), (14, 2), (18, 2), (20, 4)])
 def test_single_table_proofs_in_lockstep_equal_single_proofs(ctx, zkm, oracle, log_n, K):
     """zkm_prove_single_tables: K PoseidonStark proofs (own witness seed, own transcript each) as ONE lock-step call -- stacked trace /
     auxiliary / quotient commitments, the device-resident traces transformed where they lie -- against K zkm_prove_single_table calls,
-    and one of them against the oracle.  2^18 rows: the digit coefficient layout."""
+    and one of them against the oracle.  2^18 rows: the digit coefficient layout.  (20, 4): the call bench.py's timed region makes
+    (four 262 x 2^20 proofs per call); the single-call proof at that size is the one test_gpu_large_parity.py holds against the oracle."""
     n = 1 << log_n
     traces = [ctx.poseidon_trace(seed=60 + k, num_perms=n - 1 - k, log_n=log_n) for k in range(K)]
     aux = np.zeros(4 * n, dtype=np.uint64)
@@ -466,3 +467,5 @@ def test_single_table_proofs_in_lockstep_equal_single_proofs(ctx, zkm, oracle, l
         assert (got[1] == ref).all()
     for t in traces:
         t.free()
+    if log_n >= 20:
+        ctx.trim()      # (four proofs' worth of cached buffers: give them back before the next test)

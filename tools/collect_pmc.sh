@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # one context: kernels of concurrent contexts would overlap and their durations / counters would not be attributable
-CMD="python $R/bench.py --steps 2 --warmup 1 --contexts 1 --no-cpu-baseline --no-extras"
+CMD="python $R/bench.py --steps 2 --warmup 1 --contexts 1 --stack 1 --no-cpu-baseline --no-extras"   # (--stack 1: one proof per launch, per-launch figures)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_')

@@ -305,13 +305,34 @@ def shutdown():
     _PG.update(group=None, backend=None, device=None)
 
 
-def run_workers(prove_fn, segments, workers):
+def chunk_segments(segments, workers, stack):
+    """The calls a rank makes when `workers` contexts prove up to `stack` segments per call in lock-step: every worker gets the same
+    number of calls (the fewest that keeps a call within `stack`), and the calls are as even as the count allows -- 20 segments,
+    2 workers, stack 4 -> six calls of 4, 4, 3, 3, 3, 3; 8 -> two calls of 4.  stack <= 1: one segment per call."""
+    segs = list(segments)
+    if stack <= 1 or not segs:
+        return [[s] for s in segs]
+    workers = max(1, workers)
+    per_worker = -(-len(segs) // (workers * stack))
+    ncalls = min(len(segs), workers * per_worker)
+    base, extra = divmod(len(segs), ncalls)
+    out, i = [], 0
+    for k in range(ncalls):
+        size = base + (1 if k < extra else 0)
+        out.append(segs[i:i + size])
+        i += size
+    return out
+
+
+def run_workers(prove_fn, segments, workers, stack=1):
     """`workers` host threads pull `segments` from one queue; thread w calls prove_fn(s, w) -- w selects the worker's own context
     (own stream, allocator and transcript; a context is single-owner).  Independent segments proven side by side on
-    one GPU fill each other's transcript round trips and overlap HBM-bound NTT passes with VALU-bound hashing.  The first
-    exception stops the queue and is re-raised here."""
+    one GPU fill each other's transcript round trips and overlap HBM-bound NTT passes with VALU-bound hashing.  stack > 1: the queue
+    holds CALLS of up to `stack` segments (chunk_segments) and prove_fn(list_of_segments, w) returns their proofs in order -- the
+    lock-step entry points (zkm_prove_single_tables / zkm_prove_segments).  The first exception stops the queue and is re-raised here."""
     import threading
-    it = iter(list(segments))
+    items = chunk_segments(segments, workers, stack) if stack > 1 else list(segments)
+    it = iter(items)
     lock = threading.Lock()
     out, errs = {}, []
 
@@ -324,7 +345,12 @@ def run_workers(prove_fn, segments, workers):
             try:
                 r = prove_fn(s, w)
                 with lock:
-                    out[s] = r
+                    if stack > 1:
+                        if len(r) != len(s):
+                            raise RuntimeError("run_workers: %d proofs for a call of %d segments" % (len(r), len(s)))
+                        out.update(zip(s, r))
+                    else:
+                        out[s] = r
             except BaseException as e:  # noqa: B902 -- re-raised on the calling thread
                 errs.append(e)
     th = [threading.Thread(target=loop, args=(w,), name="zkm-worker-%d" % w) for w in range(workers)]
@@ -337,13 +363,14 @@ def run_workers(prove_fn, segments, workers):
     return out
 
 
-def prove_segments(prove_fn, num_segments, sync_fn=None, gather=True, workers=1):
+def prove_segments(prove_fn, num_segments, sync_fn=None, gather=True, workers=1, stack=1):
     """Prove `num_segments` independent segments across all ranks (this is bench.py's timed region).
 
     prove_fn(segment_index) -> proof; sync_fn() drains the local GPU (torch.cuda.synchronize).  The clock runs from a
     barrier + sync to a sync + barrier and the slowest rank defines the job time.  The proofs are gathered on rank 0 AFTER the
     clock has stopped (gather=False skips it).  workers = k > 1: this rank's segments go through run_workers and prove_fn is
-    called as prove_fn(segment_index, worker_index).  A rank without segments (num_segments < world) only takes part in the barriers.
+    called as prove_fn(segment_index, worker_index); stack > 1: as prove_fn(list_of_segment_indices, worker_index) -> list of proofs
+    (run_workers).  A rank without segments (num_segments < world) only takes part in the barriers.
     Returns (proofs_on_rank0_or_None, whole_job_seconds)."""
     world, rank, _ = env_world()
     mine = assign_segments(num_segments, world, rank)
@@ -351,7 +378,7 @@ def prove_segments(prove_fn, num_segments, sync_fn=None, gather=True, workers=1)
     if sync_fn:
         sync_fn()
     t0 = time.perf_counter()
-    local = {s: prove_fn(s) for s in mine} if workers <= 1 else run_workers(prove_fn, mine, workers)
+    local = {s: prove_fn(s) for s in mine} if (workers <= 1 and stack <= 1) else run_workers(prove_fn, mine, max(1, workers), stack)
     if sync_fn:
         sync_fn()
     barrier()
