@@ -95,7 +95,7 @@ BENCH_WORKER = textwrap.dedent("""
     zd.init = lambda backend=None: real_init(%r)
     NCTX = %d
     STACK = %d
-    sys.argv = ["bench.py", "--gpus", "2", "--segments", "7", "--warmup", "1", "--log-n", "10", "--no-cpu-baseline", "--no-extras",
+    sys.argv = [__file__, "--gpus", "2", "--segments", "7", "--warmup", "1", "--log-n", "10", "--no-cpu-baseline", "--no-extras",
                 "--contexts", str(NCTX), "--stack", str(STACK)]
     import runpy
     runpy.run_path(%r, run_name="__main__")
@@ -150,6 +150,35 @@ def test_bench_sharding_path_two_rank_gloo(tmp_path, nctx, backend, stack):
         assert j["config"]["process_group"] == "gloo"
     assert j["config"]["preflight"]["world"] == 2 and r.stderr.count("zkm preflight rank=") == 2     # one pre-flight line per rank
     assert j["value"] > 0 and abs(j["value"] * j["ms_per_step"] * 4 / 7 / 1e3 - 1) < 1e-6   # value = total / elapsed, ms_per_step = elapsed / 4
+
+
+def test_bench_started_as_a_plain_process_relaunches_itself_under_torchrun(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` -- the driver's N = 1 command with N swapped -- used to exit with a hint.  Started without
+    a launcher's environment it now replaces itself by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port <free> bench.py ...` (zkm_amd.dist.self_launch): both ranks run, rank 0 prints the one JSON line.  A process
+    that HAS a launcher's environment and the wrong world is an error, not a relaunch."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER % (ROOT, "gloo", 1, 1, os.path.join(ROOT, "bench.py")))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["ZKM_BENCH_ENTRY"] = str(script)      # (the stub-context wrapper is the script to relaunch; runpy hides it from bench.py's sys.argv[0])
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "relaunching as 2 ranks" in r.stderr and "--nproc-per-node 2 --master-addr 127.0.0.1" in r.stderr
+    assert "RANK0 OK" in r.stdout and "RANK1 OK" in r.stdout
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["config"]["segments_total"] == 7 and j["config"]["preflight"]["world"] == 2
+    sys.path.insert(0, ROOT)
+    from zkm_amd import dist as zd
+    cmd = zd.self_launch_command(8, ["bench.py", "--gpus", "8", "--steps", "20"], port=29400)
+    assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29400",
+                       "bench.py", "--gpus", "8", "--steps", "20"]
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(SystemExit, match="launcher's environment says WORLD_SIZE=1"):
+        zd.self_launch(2, ["bench.py", "--gpus", "2"])
 
 
 def test_run_workers_queue_and_errors():

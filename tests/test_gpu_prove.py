@@ -268,6 +268,35 @@ def test_generic_fri_instance_equals_the_stark_instance(ctx, zkm, oracle, log_n)
         b.free()
 
 
+@pytest.mark.parametrize("log_n", [10, 16])
+def test_fri_instance_with_eight_batches(zkm, log_n):
+    """zkm_fri_prove admits up to FRI_MAX_BATCHES = 8 opening batches, and the one-launch bottom level of the division by
+    (X - z) (k_seg_scan_combine) keeps two LDS tiles per batch: eight batches are 73,728 B, over the 64 KB a launch gets without a
+    raised limit.  The instance must prove, and the blob must equal the one the two-launch path (k_seg_scan + k_seg_combine,
+    fri_scan_combine 0) makes -- the path the oracle-checked tests of round 4 ran on.  A ninth batch is refused."""
+    W, A = 6, 4
+    rng = np.random.default_rng(95)
+    n = 1 << log_n
+    tv, av = (rng.integers(0, P, k * n, dtype=np.uint64) for k in (W, A))
+    batches = [((3 + b, 10 * b + 1), [(b & 1, c) for c in range(1 + b % 4)] + [((b + 1) & 1, b % 4)]) for b in range(8)]
+    blobs = []
+    for combine in (1, 0):
+        c = zkm.Context(0)
+        c.set_tuning("fri_scan_combine", combine)
+        tb, ab = zkm.PolynomialBatch.from_values(c, tv, W, log_n), zkm.PolynomialBatch.from_values(c, av, A, log_n)
+        ch = zkm.challenger_new()
+        zkm.challenger_observe(ch, [4, 2])
+        blobs.append(c.fri_prove([tb, ab], batches, ch))
+        if combine:
+            with pytest.raises(zkm.ZkmError):
+                c.fri_prove([tb, ab], batches + [((9, 9), [(0, 0)])], zkm.challenger_new())
+        tb.free()
+        ab.free()
+        c.close()
+    assert int(blobs[0][0]) == int.from_bytes(b"ZKMFRIPF", "little")
+    assert blobs[0].size == blobs[1].size and (blobs[0] == blobs[1]).all()
+
+
 def test_concurrent_contexts_are_bit_exact(ctx, zkm):
     """bench.py's throughput mode: k contexts on one GPU, one host thread each, proving independent segments side by side
     (zkm_amd.dist.run_workers).  Every proof made that way must equal the proof the same segment gets from one context working

@@ -88,9 +88,25 @@ void zkm_ctx::trim_self() {
     if (cs) (void)hipStreamSynchronize(cs);                    // (or was the target of an upload in flight)
     for (auto& kv : drop) (void)hipFree(kv.second);
 }
+// The pinned download area grows with the largest lock-step group seen (up to XFER_DOWN_MAX per context and per lane) and nothing
+// else gave it back: a trim between calls returns it to its base size.  Only from the owner's thread, between calls
+// (downloads are waited for before their caller returns, the stream is drained by trim_self) -- not from a relative's
+// out-of-memory retry, which trims device blocks only.
+void zkm_ctx::shrink_down() {
+    if (!h_down || down_cap <= XFER_DOWN) return;
+    (void)hipStreamSynchronize(stream);
+    (void)hipHostFree(h_down);
+    h_down = nullptr;
+    down_cap = 0;
+    ensure_down(XFER_DOWN);
+}
 void zkm_ctx::trim() {   // public: between calls (zkm_ctx_trim)
     trim_self();
-    for (zkm_ctx* l : lanes) l->trim_self();
+    shrink_down();
+    for (zkm_ctx* l : lanes) {
+        l->trim_self();
+        l->shrink_down();
+    }
 }
 // A stream of the library.  ZKM_CU_MASK_PART = "k/n" (measurement aid, read when a context is created; its lanes inherit it): the
 // context's streams may only use the k-th of n equal parts of the GPU's compute units (mask bits [k N/n, (k+1) N/n)) --

@@ -722,8 +722,9 @@ struct table_group {
     zkm_ctx* uploaded_on = nullptr;
 };
 
+// (seg_base: position of io[0] in the caller's call -- the waves of an oversized call; only error messages use it)
 static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const seg_io* io, size_t ntables,
-                                const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls) {
+                                const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls, size_t seg_base = 0) {
     std::vector<table_group> groups;
     auto drop_traces = [&]() {
         (void)hipStreamSynchronize(c->stream);
@@ -771,7 +772,18 @@ static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t 
         // height would leave the blocks of BOTH heights cached (8 segments per call: 14.5 GB per context -- twice that after one
         // call of 7).  The cache is returned to the device when the number of segments per call changes (a few hipFree / hipMalloc
         // on the next call; calls of one height -- the steady state -- never get here).
-        if (c->last_stack && c->last_stack != nseg && (nseg > 1 || c->last_stack > 1)) c->trim();
+        // TWO heights may stay cached side by side: the waves of one oversized call have floor and ceil(nseg / nwaves) segments, and a
+        // caller that cuts k segments into calls (bench.py: 20 steps = 4, 4, 3, 3, 3, 3) alternates between two heights as well -- with
+        // one remembered height every such call trimmed and re-hipMalloc'ed its blocks.  A third height trims.
+        if (nseg != c->last_stack && nseg != c->prev_stack) {
+            if (c->last_stack && c->prev_stack) {
+                c->trim();
+                c->last_stack = 0;
+            }
+            c->prev_stack = c->last_stack;
+        } else if (nseg == c->prev_stack) {
+            c->prev_stack = c->last_stack;
+        }
         c->last_stack = nseg;
         const zkm_table_input* T0 = io[0].tables;
         for (size_t s = 0; s < nseg; s++) {
@@ -1010,8 +1022,8 @@ static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t 
                     zkm_table_lookup_columns_device(w, T0[t].table_id, glookup[j].data(), nch, d_trace, n, d_all.as<gl_t>(), G, W * n, A * n);
                 }
             } catch (const zkm_segment_error& e) {   // (a stack names the position in the group: the caller wants ITS segment and the table)
-                if (nseg == 1) throw std::runtime_error(e.what());
-                throw std::runtime_error("segment " + std::to_string(g.segs[e.seg]) + ", table " + std::to_string(t) + ": " + e.what());
+                if (nseg == 1 && seg_base == 0) throw std::runtime_error(e.what());
+                throw std::runtime_error("segment " + std::to_string(seg_base + g.segs[e.seg]) + ", table " + std::to_string(t) + ": " + e.what());
             }
             zkm_prof_scope st(w, "stage/compute auxiliary polynomials commitment");
             zkm_batch* ab = new zkm_batch();
@@ -1042,8 +1054,14 @@ static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t 
                 zkm_prove_single_table_aux(c, T0[t].table_id, cfg, T0[t].ncols, g.log_n, g.commit, g.aux, tz0[t].naux, T0[t].ctl, gzs[j].data(),
                                            tz0[t].ids.data(), tz0[t].zs.size(), glookup[j].data(), chs, proofs);
                 for (size_t k = 0; k < g.segs.size(); k++) ch[g.segs[k]] = local[k];
+            } catch (const zkm_segment_error& e) {
+                throw std::runtime_error("segment " + std::to_string(seg_base + g.segs[e.seg]) + ", table " + std::to_string(t) + ": " + e.what());
             } catch (const std::exception& e) {
-                throw std::runtime_error("table " + std::to_string(t) + ": " + e.what());
+                if (nseg == 1 && seg_base == 0) throw std::runtime_error("table " + std::to_string(t) + ": " + e.what());
+                // a stacked group fails as a whole: name its members (positions in the caller's call) next to the table
+                std::string who = g.segs.size() == 1 ? "segment " : "segments ";
+                for (size_t k = 0; k < g.segs.size(); k++) who += (k ? "," : "") + std::to_string(seg_base + g.segs[k]);
+                throw std::runtime_error(who + ", table " + std::to_string(t) + ": " + e.what());
             }
         };
         // (groups are numbered table by table: job order is proof order)
@@ -1146,13 +1164,18 @@ static void prove_segments_waves(zkm_ctx* c, const zkm_stark_config* cfg, size_t
     };
     double total = 0;
     for (size_t s = 0; s < nseg; s++) total += footprint(io[s]);
-    // equal waves (the exact-size allocator then caches the blocks of at most two stack heights, the same ones call after call)
+    // even waves: nseg mod nwaves of them hold ceil(nseg / nwaves) segments, the others floor -- two stack heights at most, which is
+    // what the exact-size allocator keeps cached side by side (prove_segments_impl), the same ones call after call
     const size_t nwaves = (size_t)std::min<double>((double)nseg, std::max(1.0, std::ceil(total / std::max(budget, 1.0))));
-    const size_t per = (nseg + nwaves - 1) / nwaves;
+    const size_t lo = nseg / nwaves, extra = nseg % nwaves;
     if (getenv("ZKM_DEBUG_WAVES"))
-        fprintf(stderr, "zkm waves: %zu segments, %.2f GB in all, budget %.2f GB (free %.2f, cached %.2f) -> %zu wave(s) of <= %zu\n", nseg, total / 1e9,
-                budget / 1e9, free_b / 1e9, cached / 1e9, nwaves, per);
-    for (size_t s0 = 0; s0 < nseg; s0 += per) prove_segments_impl(c, cfg, std::min(per, nseg - s0), io + s0, ntables, ctls, sides, nctls);
+        fprintf(stderr, "zkm waves: %zu segments, %.2f GB in all, budget %.2f GB (free %.2f, cached %.2f) -> %zu wave(s): %zu of %zu, %zu of %zu\n", nseg,
+                total / 1e9, budget / 1e9, free_b / 1e9, cached / 1e9, nwaves, extra, lo + 1, nwaves - extra, lo);
+    for (size_t w = 0, s0 = 0; w < nwaves; w++) {
+        const size_t k = lo + (w < extra ? 1 : 0);
+        prove_segments_impl(c, cfg, k, io + s0, ntables, ctls, sides, nctls, s0);   // (s0: errors name positions in the CALL, not in the wave)
+        s0 += k;
+    }
 }
 
 extern "C" {

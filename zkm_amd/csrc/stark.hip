@@ -1179,8 +1179,19 @@ static void divide_accumulate_all(zkm_ctx* c, const std::vector<std::vector<fri_
             break;
         }
         if (l == 0 && c->fri_scan_combine) {   // bottom level: scan + weighted sum of the batches in one launch (no suffix arrays in HBM)
-            hipLaunchKernelGGL(k_seg_scan_combine, dim3((unsigned)((nsegm + 63) / 64), 1, z), dim3(64 * nb), (size_t)2 * nb * 64 * SEG_ROW * sizeof(gl_t),
-                               c->stream, lv[0], n, upper, nupper, f0, f1);
+            // two tiles per batch: 9,216 B per batch with segments of 8 -- eight batches (FRI_MAX_BATCHES) are 73,728 B, over the 64 KB a
+            // launch gets without asking; the limit is raised once per device like k_fri_fold's
+            const size_t lds = (size_t)2 * nb * 64 * SEG_ROW * sizeof(gl_t);
+            if (lds > 64 * 1024) {
+                static std::atomic<uint64_t> sc_lds_ok{0};
+                const uint64_t bit = (uint64_t)1 << (c->device & 63);
+                if (!(sc_lds_ok.load(std::memory_order_acquire) & bit)) {
+                    ZKM_HIP_CHECK(hipFuncSetAttribute((const void*)k_seg_scan_combine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    sc_lds_ok.fetch_or(bit, std::memory_order_release);
+                }
+            }
+            hipLaunchKernelGGL(k_seg_scan_combine, dim3((unsigned)((nsegm + 63) / 64), 1, z), dim3(64 * nb), lds, c->stream, lv[0], n, upper, nupper, f0,
+                               f1);
             break;
         }
         suf[l] = (gl_t*)c->alloc(nseg * 2 * nb * m[l] * sizeof(gl_t));
@@ -1985,6 +1996,10 @@ int zkm_check_constraints(zkm_ctx* c, int table_id, const zkm_stark_config* cfg,
     try {
         ZKM_HIP_CHECK(hipSetDevice(c->device));
         validate_config(cfg, log_n);
+        if (table_id < 0 || table_id >= 12) throw std::runtime_error("zkm_check_constraints: unknown table id");
+        // a table with lookups of its own (Memory, Arithmetic) takes its challenges from the caller: none given is an error here, not a
+        // null dereference on the host
+        if (!lookup_challenges && zkm_num_lookup_columns(table_id, cfg)) throw std::runtime_error("zkm_check_constraints: this table has lookups of its own: lookup_challenges is null");
         if (nalphas < 1 || nalphas > 2) throw std::runtime_error("zkm_check_constraints: 1 or 2 challenges supported");
         for (size_t a = 0; a < nalphas; a++)
             if (alphas[a] >= GL_P) throw std::runtime_error("zkm_check_constraints: non-canonical challenge");
@@ -2026,6 +2041,10 @@ int zkm_check_constraints(zkm_ctx* c, int table_id, const zkm_stark_config* cfg,
         (void)hipStreamSynchronize(c->stream);
         for (void* q : tmp) c->release(q);
         return fail(err, e.what());
+    } catch (...) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void* q : tmp) c->release(q);
+        return fail(err, "zkm_check_constraints: unknown error");
     }
     return 0;
 }

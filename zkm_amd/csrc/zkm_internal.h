@@ -44,9 +44,9 @@ struct seg_gl2 { gl_t v[2 * ZKM_MAX_SEG]; };     // two per segment (an F2 eleme
 
 #ifndef ZKM_COMMIT_LANES
 #define ZKM_COMMIT_LANES 4   // trace commitments in flight per context (the context itself + 3 lanes)
+#endif
 #ifndef ZKM_LEAF_MFMA_DEFAULT
 #define ZKM_LEAF_MFMA_DEFAULT 1
-#endif
 #endif
 
 struct zkm_twiddles {
@@ -68,8 +68,9 @@ struct zkm_ctx {
     unsigned pow_round_log = 17;        // proof-of-work search: 2^this candidates per round of the search launch                          } zkm_ctx_set_tuning
     int aux_pipeline = 1;               // segments of short tables: lanes build later tables' auxiliary commitments behind the proofs      } zkm_ctx_set_tuning
     size_t commit_lanes = ZKM_COMMIT_LANES;   // trace / auxiliary commitments of one segment in flight (this context + lanes)   } zkm_ctx_set_tuning
-    size_t segments_memory_budget = 0;  // bytes one wave of a zkm_prove_segments call may hold (0: 60 % of what is free, per live context)   } zkm_ctx_set_tuning
+    size_t segments_memory_budget = 0;  // bytes one wave of a zkm_prove_segments call may hold (0: 80 % of cached + free HBM, shared out over the contexts of the process that are inside such a call)   } zkm_ctx_set_tuning
     size_t last_stack = 0;              // segments of the previous prove_with_traces call of this context (0: none yet)
+    size_t prev_stack = 0;              // ... and the other height whose blocks may still be cached (two heights are kept: ctl.hip prove_segments_impl)
     size_t max_stack = ZKM_MAX_SEG;     // segments of one lock-step group (zkm_prove_segments): 1 .. ZKM_MAX_SEG               } zkm_ctx_set_tuning
     int leaf_mfma = ZKM_LEAF_MFMA_DEFAULT;   // one-lane-per-leaf hashing: MDS layers of the full rounds on the matrix core (poseidon_mfma_dev.h)   } zkm_ctx_set_tuning
     size_t wide_max_hashes = 1024;      // launches of up to this many hashes use 16 lanes per hash (latency form)   } 0 / 0: one lane
@@ -110,6 +111,7 @@ struct zkm_ctx {
     void release(void* p);
     void trim_self();  // hipFree every cached (not live) block of THIS allocator (any thread: used by a relative's out-of-memory retry)
     void trim();       // ... and of the lanes; only between calls
+    void shrink_down();   // the pinned download area back to its base size (trim(): between calls, owner's thread)
     void ensure_twiddles(unsigned log_n);
     const gl_t* pow_table(uint64_t shift, unsigned log_n);  // lo: 2^ceil(log_n/2) entries, then hi
     uint64_t* staging(size_t words);

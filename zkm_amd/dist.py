@@ -18,6 +18,37 @@ def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def self_launch_command(nproc, argv, port=None):
+    """The command that runs `argv` (script + its arguments) as `nproc` ranks of one node, one per GPU: the driver's launch line
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script args...).  The
+    rendezvous is on 127.0.0.1 (the container hostname may not resolve) and the port is a free one unless given."""
+    import socket
+    import sys
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+            "--master-port", str(port)] + list(argv)
+
+
+def self_launch(nproc, argv):
+    """`python bench.py --gpus N` started as a PLAIN process (no RANK / WORLD_SIZE in the environment): replace this process by the
+    torchrun launch of the same command line -- the multi-GPU job must be startable the way the single-GPU one is.  A
+    process that already has a launcher's environment and the wrong world size is an error, not a relaunch (it would recurse)."""
+    import sys
+    if any(k in os.environ for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")):
+        raise SystemExit("zkm_amd.dist: --gpus %d but the launcher's environment says WORLD_SIZE=%s: launch one rank per GPU "
+                         "(python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 ...)" % (
+                             nproc, os.environ.get("WORLD_SIZE", "unset"), nproc))
+    cmd = self_launch_command(nproc, argv)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print("zkm_amd.dist: relaunching as %d ranks: %s" % (nproc, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execv(cmd[0], cmd)
+
+
 def check_gpus(world, local_rank, share_gpu=False):
     """One process per GPU means one GPU per process: refuse to start when torchrun's world does not fit the visible devices
     (two ranks silently sharing a device would report a scaling curve that is not one).  share_gpu is the single-GPU rehearsal."""
