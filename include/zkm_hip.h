@@ -483,6 +483,41 @@ int zkm_prove_segments_columns(zkm_ctx* ctx, const zkm_stark_config* cfg, size_t
                                const unsigned* const* log_n, const uint64_t* const* public_values, const size_t* npublic,
                                uint64_t* const* proofs_out, uint64_t* const* ctl_challenges_out, char** err);
 
+/* ------------------------------------------------------------------ one process, many GPUs: a pool of contexts
+ * The reference drives all segments of a program from ONE process (prover/examples/utils/src/utils.rs:57-68 prove_single_seg_common,
+ * :105-133 prove_multi_seg_common: a loop of prove_with_traces calls); segments are independent proofs, so N GPUs take them
+ * side by side with no data-path collective.  A pool owns `contexts_per_device` contexts on each of `devices[0 .. ndevices)` (a device
+ * may be listed once only) and, per call, one worker thread per context: the nseg segments of a call are cut into consecutive groups of
+ * at most `max_stack` segments (every worker the same number of groups, sizes as even as the count allows), the workers pull groups
+ * from one queue, and a group is ONE lock-step call (zkm_prove_segments[_columns]) on the worker's context.  Every proof blob and
+ * every challenge is word for word what zkm_prove_segment returns for that segment alone, whatever the device count.
+ *   traces / columns / log_n / public_values / npublic / proofs_out / ctl_challenges_out   as zkm_prove_segments[_columns]
+ *   max_stack   segments per lock-step call, 1 .. 32 (0 = 8; also bounded by the contexts' "max_stack" tuning)
+ * The inputs must be readable from every device of the pool: HOST memory (pageable, zkm_host_alloc'ed or zkm_host_register'ed -- what a
+ * Rust Vec is), or device memory when the pool has one device.  The first failing group stops the queue; its message names the worker,
+ * the device and the positions of its segments in the call.  A failure leaves every output undefined.  A pool is single-owner like
+ * a context: one call at a time.  zkm_pool_context hands out worker w's context (0 <= w < zkm_pool_workers) for zkm_ctx_set_tuning,
+ * zkm_ctx_memory, zkm_profile_*; zkm_pool_set_tuning applies one key to all of them. */
+typedef struct zkm_pool zkm_pool;
+int zkm_pool_create(const int* devices, size_t ndevices, size_t contexts_per_device, zkm_pool** out, char** err);
+void zkm_pool_destroy(zkm_pool* pool);
+size_t zkm_pool_workers(const zkm_pool* pool);
+zkm_ctx* zkm_pool_context(zkm_pool* pool, size_t worker);
+int zkm_pool_device(const zkm_pool* pool, size_t worker);
+int zkm_pool_set_tuning(zkm_pool* pool, const char* key, uint64_t value, char** err);
+int zkm_pool_prove_segments(zkm_pool* pool, const zkm_stark_config* cfg, size_t nseg, size_t max_stack, const uint64_t* const* const* traces,
+                            const unsigned* const* log_n, const uint64_t* const* public_values, const size_t* npublic,
+                            uint64_t* const* proofs_out, uint64_t* const* ctl_challenges_out, char** err);
+int zkm_pool_prove_segments_columns(zkm_pool* pool, const zkm_stark_config* cfg, size_t nseg, size_t max_stack,
+                                    const uint64_t* const* const* const* columns, const unsigned* const* log_n,
+                                    const uint64_t* const* public_values, const size_t* npublic, uint64_t* const* proofs_out,
+                                    uint64_t* const* ctl_challenges_out, char** err);
+/* The groups a pool call of nseg segments is cut into for `workers` workers (a pure function: no pool, no GPU): returns their number and
+ * writes the first min(capacity, number) sizes, in segment order.  20 segments, 2 workers, max_stack 4 -> 4, 4, 3, 3, 3, 3. */
+size_t zkm_pool_plan(size_t nseg, size_t workers, size_t max_stack, size_t* group_sizes_out, size_t capacity);
+/* which worker proved segment s of the pool's LAST call, and in which group (diagnostics / tests): 0 on success */
+int zkm_pool_last_assignment(const zkm_pool* pool, size_t segment, size_t* worker_out, size_t* group_out);
+
 /* a10 alone (BASELINE config 4): PolynomialBatch::prove_openings (call site prover.rs:618-628) for the STARK FRI
  * instance (stark.rs:91-148: batches at zeta, g*zeta and 1 over the trace / auxiliary / quotient oracles) on three
  * existing commitments.  Transcript: compact, zeta <- challenger, openings observed (proof.rs:336-367), prove_openings.

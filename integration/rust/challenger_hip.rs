@@ -12,7 +12,7 @@ use crate::hash::hash_types::RichField;
 use crate::hash::poseidon::PoseidonHash;
 use crate::hip::sys::zkm_challenger;
 use crate::iop::challenger::Challenger;
-use crate::plonk::plonk_common::PlonkyPermutation;
+use crate::hash::hashing::PlonkyPermutation;
 
 impl<F: RichField> Challenger<F, PoseidonHash> {
     pub fn to_zkm(&self) -> zkm_challenger {

@@ -25,7 +25,7 @@ use plonky2::hash::hash_types::{HashOut, RichField};
 use plonky2::hash::merkle_proofs::MerkleProof;
 use plonky2::hash::merkle_tree::MerkleCap;
 use plonky2::plonk::config::{GenericConfig, Hasher};
-use plonky2::plonk::plonk_common::PlonkyPermutation;
+use plonky2::hash::hashing::PlonkyPermutation;
 
 use crate::config::StarkConfig;
 use crate::proof::{StarkOpeningSet, StarkProof, StarkProofWithMetadata};

@@ -172,6 +172,83 @@ where
     }).collect())
 }
 
+/// A pool of contexts over the GPUs of one node, owned by the ONE process that drives all segments of a program -- the shape of the
+/// reference's driver (prover/examples/utils/src/utils.rs:57-68 `prove_single_seg_common`, :105-133 `prove_multi_seg_common`: a loop
+/// of `prove_with_traces` calls).  `contexts_per_device` worker threads per device live inside the library (include/zkm_hip.h
+/// zkm_pool_*); nothing here is `Send` across the FFI: the pool is used from the thread that holds it, one call at a time.
+pub struct HipPool(*mut zkm_pool);
+
+impl HipPool {
+    pub fn new(devices: &[i32], contexts_per_device: usize) -> Result<Self> {
+        let mut pool = std::ptr::null_mut();
+        let mut err = std::ptr::null_mut();
+        check(unsafe { zkm_pool_create(devices.as_ptr(), devices.len(), contexts_per_device, &mut pool, &mut err) }, err)?;
+        Ok(Self(pool))
+    }
+    pub fn workers(&self) -> usize {
+        unsafe { zkm_pool_workers(self.0) }
+    }
+    pub fn set_tuning(&mut self, key: &std::ffi::CStr, value: u64) -> Result<()> {
+        let mut err = std::ptr::null_mut();
+        check(unsafe { zkm_pool_set_tuning(self.0, key.as_ptr(), value, &mut err) }, err)
+    }
+}
+
+impl Drop for HipPool {
+    fn drop(&mut self) {
+        unsafe { zkm_pool_destroy(self.0) };
+    }
+}
+
+/// All segments of a program over all GPUs of the pool: the segments are cut into lock-step groups of at most `max_stack` (0 = 8), the
+/// pool's workers pull the groups from a queue, and every `AllProof` is word for word what `prove_with_traces_hip` returns for that
+/// segment alone, whatever the device count.  The traces are read where `generate_traces` left them (host `Vec`s, one pointer per
+/// column): every device of the pool reads host memory.
+pub fn prove_segments_multi_hip<F, C, const D: usize>(
+    pool: &mut HipPool,
+    config: &StarkConfig,
+    max_stack: usize,
+    segments: &[([Vec<PolynomialValues<F>>; NUM_TABLES], PublicValues)],
+) -> Result<Vec<AllProof<F, C, D>>>
+where
+    F: RichField + Extendable<D>,
+    C: GenericConfig<D, F = F>,
+    C::Hasher: Hasher<F, Hash = HashOut<F>>,
+{
+    let cfg = zkm_config(config);
+    let k = segments.len();
+    let pubs: Vec<Vec<u64>> = segments.iter().map(|(_, pv)| public_values_words(pv)).collect();
+    let cols: Vec<Vec<Vec<*const u64>>> = segments.iter().map(|(tr, _)| tr.iter().map(|t| column_ptrs(t)).collect()).collect();
+    let tabs: Vec<Vec<*const *const u64>> = cols.iter().map(|seg| seg.iter().map(|v| v.as_ptr()).collect()).collect();
+    let log_n: Vec<Vec<u32>> = segments.iter().map(|(tr, _)| tr.iter().map(|t| t[0].len().trailing_zeros()).collect()).collect();
+    let mut err = std::ptr::null_mut();
+    let mut offs = vec![vec![0usize; NUM_TABLES + 1]; k];
+    for s in 0..k {     // sizing pass per segment (no context needed: proofs_out = NULL)
+        check(unsafe { zkm_prove_segment_columns(std::ptr::null_mut(), &cfg, tabs[s].as_ptr(), log_n[s].as_ptr(), pubs[s].as_ptr(), pubs[s].len(),
+                                         std::ptr::null_mut(), offs[s].as_mut_ptr(), std::ptr::null_mut(), &mut err) }, err)?;
+    }
+    let mut blobs: Vec<Vec<u64>> = offs.iter().map(|o| vec![0u64; o[NUM_TABLES]]).collect();
+    let mut chals: Vec<Vec<u64>> = (0..k).map(|_| vec![0u64; 2 * config.num_challenges]).collect();
+    let seg_ptrs: Vec<*const *const *const u64> = tabs.iter().map(|v| v.as_ptr()).collect();
+    let log_ptrs: Vec<*const u32> = log_n.iter().map(|v| v.as_ptr()).collect();
+    let pub_ptrs: Vec<*const u64> = pubs.iter().map(|v| v.as_ptr()).collect();
+    let pub_lens: Vec<usize> = pubs.iter().map(|v| v.len()).collect();
+    let blob_ptrs: Vec<*mut u64> = blobs.iter_mut().map(|v| v.as_mut_ptr()).collect();
+    let chal_ptrs: Vec<*mut u64> = chals.iter_mut().map(|v| v.as_mut_ptr()).collect();
+    check(unsafe { zkm_pool_prove_segments_columns(pool.0, &cfg, k, max_stack, seg_ptrs.as_ptr(), log_ptrs.as_ptr(), pub_ptrs.as_ptr(),
+                                           pub_lens.as_ptr(), blob_ptrs.as_ptr(), chal_ptrs.as_ptr(), &mut err) }, err)?;
+    Ok(segments.iter().enumerate().map(|(s, (_, pv))| {
+        let stark_proofs: [StarkProofWithMetadata<F, C, D>; NUM_TABLES] =
+            core::array::from_fn(|t| stark_proof_from_blob::<F, C, D>(&blobs[s][offs[s][t]..offs[s][t + 1]]));
+        let ctl_challenges = GrandProductChallengeSet {
+            challenges: (0..config.num_challenges)
+                .map(|c| GrandProductChallenge { beta: F::from_canonical_u64(chals[s][2 * c]), gamma: F::from_canonical_u64(chals[s][2 * c + 1]) })
+                .collect(),
+        };
+        AllProof { stark_proofs, ctl_challenges, public_values: pv.clone() }
+    }).collect())
+}
+
 /// Body of `prove_single_table` (prover.rs:441-641) for the benchmark shape the reference's own tests use
 /// (poseidon_stark.rs:751-816, keccak_stark.rs:689-754): existing trace values, CtlData given as auxiliary columns.
 pub fn prove_single_table_hip<F, C, const D: usize>(

@@ -12,6 +12,7 @@ use std::os::raw::{c_char, c_double, c_int, c_uint, c_void};
 
 #[repr(C)] pub struct zkm_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct zkm_batch { _p: [u8; 0] }
+#[repr(C)] pub struct zkm_pool { _p: [u8; 0] }
 
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct zkm_challenger { pub state: [u64; 12], pub in_buf: [u64; 8], pub out_buf: [u64; 8], pub n_in: u32, pub n_out: u32 }
@@ -168,6 +169,23 @@ extern "C" {
     pub fn zkm_prove_segments_columns(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, nseg: usize, columns: *const *const *const *const u64,
                                       log_n: *const *const c_uint, public_values: *const *const u64, npublic: *const usize,
                                       proofs_out: *const *mut u64, ctl_challenges_out: *const *mut u64, err: *mut *mut c_char) -> c_int;
+    // one process, many GPUs: contexts_per_device contexts on each device, one worker thread per context, groups of <= max_stack segments
+    pub fn zkm_pool_create(devices: *const c_int, ndevices: usize, contexts_per_device: usize, out: *mut *mut zkm_pool, err: *mut *mut c_char) -> c_int;
+    pub fn zkm_pool_destroy(pool: *mut zkm_pool);
+    pub fn zkm_pool_workers(pool: *const zkm_pool) -> usize;
+    pub fn zkm_pool_context(pool: *mut zkm_pool, worker: usize) -> *mut zkm_ctx;
+    pub fn zkm_pool_device(pool: *const zkm_pool, worker: usize) -> c_int;
+    pub fn zkm_pool_set_tuning(pool: *mut zkm_pool, key: *const c_char, value: u64, err: *mut *mut c_char) -> c_int;
+    pub fn zkm_pool_prove_segments(pool: *mut zkm_pool, cfg: *const zkm_stark_config, nseg: usize, max_stack: usize,
+                                   traces: *const *const *const u64, log_n: *const *const c_uint, public_values: *const *const u64,
+                                   npublic: *const usize, proofs_out: *const *mut u64, ctl_challenges_out: *const *mut u64,
+                                   err: *mut *mut c_char) -> c_int;
+    pub fn zkm_pool_prove_segments_columns(pool: *mut zkm_pool, cfg: *const zkm_stark_config, nseg: usize, max_stack: usize,
+                                           columns: *const *const *const *const u64, log_n: *const *const c_uint,
+                                           public_values: *const *const u64, npublic: *const usize, proofs_out: *const *mut u64,
+                                           ctl_challenges_out: *const *mut u64, err: *mut *mut c_char) -> c_int;
+    pub fn zkm_pool_plan(nseg: usize, workers: usize, max_stack: usize, group_sizes_out: *mut usize, capacity: usize) -> usize;
+    pub fn zkm_pool_last_assignment(pool: *const zkm_pool, segment: usize, worker_out: *mut usize, group_out: *mut usize) -> c_int;
     pub fn zkm_prove_single_tables(ctx: *mut zkm_ctx, table_id: c_int, cfg: *const zkm_stark_config, nproofs: usize, traces: *const *const u64,
                                    ncols: usize, log_n: c_uint, aux: *const *const u64, naux: usize, num_helpers: *const u32, nctl_zs: usize,
                                    challengers: *const *mut zkm_challenger, proofs_out: *const *mut u64, err: *mut *mut c_char) -> c_int;

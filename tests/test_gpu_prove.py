@@ -469,23 +469,31 @@ def test_every_admitted_fri_arity_proves_like_the_oracle(ctx, zkm, oracle, arity
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_n,K", [(6, 2), (11, 3), (14, 2), (18, 2), (20, 4)])
-def test_single_table_proofs_in_lockstep_equal_single_proofs(ctx, zkm, oracle, log_n, K):
+def test_single_table_proofs_in_lockstep_equal_single_proofs(ctx, zkm, oracle, oracle_proof_2_20, log_n, K):
     """zkm_prove_single_tables: K PoseidonStark proofs (own witness seed, own transcript each) as ONE lock-step call -- stacked trace /
     auxiliary / quotient commitments, the device-resident traces transformed where they lie -- against K zkm_prove_single_table calls,
     and one of them against the oracle.  2^18 rows: the digit coefficient layout.  (20, 4): the call bench.py's timed region makes
-    (four 262 x 2^20 proofs per call); the single-call proof at that size is the one test_gpu_large_parity.py holds against the oracle."""
+    (four 262 x 2^20 proofs per call) -- proof 0 of THAT call is bench.py's segment 0 (witness seed 100, a fresh transcript) and is held
+    against the oracle's 2^20-row proof directly (VERDICT r05 #7), not only through the single-proof path."""
     n = 1 << log_n
-    traces = [ctx.poseidon_trace(seed=60 + k, num_perms=n - 1 - k, log_n=log_n) for k in range(K)]
+    bench0 = log_n == 20                  # proof 0 = the oracle_proof_2_20 fixture's workload
+    traces = [ctx.poseidon_trace(seed=100, num_perms=n, log_n=log_n) if (bench0 and k == 0) else
+              ctx.poseidon_trace(seed=60 + k, num_perms=n - 1 - k, log_n=log_n) for k in range(K)]
     aux = np.zeros(4 * n, dtype=np.uint64)
-    chs = []
-    for k in range(K):
+
+    def transcript(k):
         ch = zkm.challenger_new()
-        zkm.challenger_observe(ch, [k, 17])
-        chs.append(ch)
+        if not (bench0 and k == 0):
+            zkm.challenger_observe(ch, [k, 17])
+        return ch
+    chs = [transcript(k) for k in range(K)]
     got = ctx.prove_single_tables(traces, log_n, aux, [1, 1], challengers=chs)
+    if bench0 and oracle_proof_2_20 is not None:
+        ref = oracle_proof_2_20["proof"]
+        bad = np.nonzero(got[0] != ref)[0] if got[0].size == ref.size else np.array([-1])
+        assert bad.size == 0, "proof 0 of the lock-step call vs the ORACLE's 2^20-row proof: first differing word %d of %d" % (bad[0], ref.size)
     for k in range(K):
-        ch = zkm.challenger_new()
-        zkm.challenger_observe(ch, [k, 17])
+        ch = transcript(k)
         want = ctx.prove_single_table(traces[k], log_n, aux, [1, 1], challenger=ch)
         assert (got[k] == want).all(), k
         assert list(ch.state) == list(chs[k].state) and ch.n_in == chs[k].n_in and ch.n_out == chs[k].n_out   # same transcript state

@@ -284,3 +284,135 @@ def test_calls_of_reference_functions_pass_the_right_number_of_arguments():
                         f, name, got, os.path.relpath(mf, "/root/reference") if not mf.startswith(ROOT) else os.path.relpath(mf, ROOT), want))
     assert not problems, "\n".join(problems)
     assert checked >= 5
+
+
+# ------------------------------------------------------------------ the plonky2 side: paths and call-site arities
+# plonky2 itself is un-vendored (prover/Cargo.toml:17-20), so its items cannot be looked up in source.  What the reference tree DOES hold
+# is its own use of the pinned fork: every `use plonky2::a::b::Item` anywhere under /root/reference is proof that the item exists at that
+# path in zkMIPS/plonky2@zkm_dev, and every call site of a PolynomialBatch method fixes that method's argument list.
+PLONKY2_FILES = {   # file -> how it names the plonky2 crate ("crate" for files that go INTO the fork, "plonky2" for zkm-prover files)
+    "integration/rust/oracle_hip.rs": "crate", "integration/rust/challenger_hip.rs": "crate",
+    "integration/rust/prove_hip.rs": "plonky2", "integration/rust/proof_blob.rs": "plonky2", "tools/ref_dump/ref_dump.rs": "plonky2",
+}
+# items of plonky2 0.1.4 the reference never imports by name (it reaches them through type inference or not at all): the MODULE must still
+# be one the reference imports from, unless listed here with the module
+KNOWN_UNIMPORTED = {
+    ("hash", "hash_types", "HashOut"), ("fri", "proof", "FriInitialTreeProof"), ("fri", "proof", "FriQueryRound"), ("fri", "proof", "FriQueryStep"),
+    ("hash", "poseidon", "PoseidonHash"), ("hash", "merkle_proofs", "MerkleProof"), ("field", "fft", "FftRootTable"),
+    ("fri", "structure", "FriOracleInfo"), ("fri", "structure", "FriPolynomialInfo"),
+}
+KNOWN_UNIMPORTED_MODULES = {("hash", "merkle_proofs"), ("field", "fft")}
+OURS = {"hip"}          # plonky2::hip::* is the module this integration adds to the fork
+
+
+def use_items(src, root):
+    """[(module path tuple, item)] of every `use <root>::...;` -- nested braces one level deep, multi-line lists, `self` / `*` skipped"""
+    out = []
+    for m in re.finditer(r"\buse\s+%s::([A-Za-z0-9_:]+?)(?:::\{([^}]*)\})?\s*;" % re.escape(root), src, flags=re.S):
+        path = m.group(1).split("::")
+        if m.group(2) is None:
+            out.append((tuple(path[:-1]), path[-1]))
+        else:
+            for it in m.group(2).replace("\n", " ").split(","):
+                it = it.strip().split(" as ")[0].strip()
+                if it and it not in ("self", "*"):
+                    out.append((tuple(path), it))
+    return out
+
+
+def reference_plonky2_imports():
+    seen = set()
+    for base, _, files in os.walk("/root/reference"):
+        if "/target" in base or "/.git" in base:
+            continue
+        for fn in files:
+            if fn.endswith(".rs"):
+                try:
+                    src = strip_comments(open(os.path.join(base, fn), errors="replace").read())
+                except OSError:
+                    continue
+                seen.update(use_items(src, "plonky2"))
+    return seen
+
+
+_REF_TEXT = []
+
+
+def ref_text():
+    if not _REF_TEXT:
+        parts = []
+        for base, _, files in os.walk(REF):
+            parts += [strip_comments(open(os.path.join(base, fn)).read()) for fn in files if fn.endswith(".rs")]
+        _REF_TEXT.append("\n".join(parts))
+    return _REF_TEXT[0]
+
+
+def test_every_plonky2_path_is_one_the_reference_itself_uses():
+    ref = reference_plonky2_imports()
+    assert len(ref) >= 60
+    ref_modules = {mod for mod, _ in ref}
+    problems, checked = [], 0
+    for f, root in PLONKY2_FILES.items():
+        src = strip_comments(open(os.path.join(ROOT, f)).read())
+        for mod, item in use_items(src, root):
+            if root == "crate" and (not mod or mod[0] in OURS):
+                continue
+            if root == "plonky2" and mod and mod[0] in OURS:
+                continue
+            if root == "crate" and f.startswith("integration/rust/") and PLONKY2_FILES[f] == "crate" and not mod:
+                continue
+            checked += 1
+            if (mod, item) in ref:
+                continue
+            if mod + (item,) in KNOWN_UNIMPORTED and (mod in ref_modules or mod in KNOWN_UNIMPORTED_MODULES):
+                continue
+            if len(mod) >= 2 and (mod[:-1], mod[-1]) in ref and ("%s::%s" % (mod[-1], item)) in ref_text():
+                continue            # an enum variant / associated item of an imported type, spelled that way in the reference itself
+            where = sorted("::".join(m) for m, i in ref if i == item)
+            problems.append("%s: plonky2::%s::%s -- the reference never imports that path%s" % (
+                f, "::".join(mod), item, (" (it imports %s from plonky2::%s)" % (item, ", plonky2::".join(where))) if where else ""))
+    assert not problems, "\n".join(problems)
+    assert checked >= 40
+
+
+def reference_call_arities(method):
+    """argument counts of every `PolynomialBatch::[<..>::]method(` (associated functions) or `.method(` (methods) call under prover/src"""
+    out = []
+    for base, _, files in os.walk(REF):
+        for fn in files:
+            if not fn.endswith(".rs"):
+                continue
+            src = strip_comments(open(os.path.join(base, fn)).read())
+            # mark the qualified / method calls with a unique name, then count the arguments of the marked calls only
+            marked = re.sub(r"PolynomialBatch\s*(?:::\s*<[^;{}()]*?>)?\s*::\s*%s\b" % re.escape(method), "ZKMSITE_" + method, src)
+            marked = re.sub(r"\.\s*%s\b(?=\s*\()" % re.escape(method), ".ZKMSITE_" + method, marked)
+            out += call_arities(marked, "ZKMSITE_" + method)
+    return out
+
+
+def test_polynomial_batch_facade_takes_what_the_reference_call_sites_pass():
+    """integration/rust/oracle_hip.rs: HipPolynomialBatch::{from_values, from_coeffs, get_lde_values_packed, prove_openings} have the
+    argument lists of the reference's call sites (prover.rs:154-163, 514-521, 579-586, 621-627, 687, 723-748 and the six benchmark
+    tests), and every zkm_* function the facade calls is declared in zkm_hip_sys.rs with that many parameters."""
+    src = strip_comments(open(os.path.join(ROOT, "integration", "rust", "oracle_hip.rs")).read())
+    for method, min_sites in (("from_values", 8), ("from_coeffs", 1), ("get_lde_values_packed", 5), ("prove_openings", 1)):
+        sites = reference_call_arities(method)
+        assert len(sites) >= min_sites and len(set(sites)) == 1, (method, sites)
+        assert fn_arity(src, method) == sites[0], "%s: the facade takes %s arguments, the reference passes %d" % (method, fn_arity(src, method), sites[0])
+    # the fields the reference reads become methods here: both must exist
+    for name in ("cap", "polynomials", "hip_batch", "get_lde_values"):
+        assert re.search(r"\bpub fn %s\b" % name, src), name
+    assert re.search(r"\bDrop\s+for\s+HipPolynomialBatch", src) and "zkm_batch_free" in src
+    sys_src = strip_comments(open(os.path.join(ROOT, "integration", "rust", "zkm_hip_sys.rs")).read())
+    checked = 0
+    for f in ("integration/rust/oracle_hip.rs", "integration/rust/prove_hip.rs"):
+        body = strip_comments(open(os.path.join(ROOT, f)).read())
+        for name in sorted(set(re.findall(r"\b(zkm_[a-z0-9_]+)\s*\(", body))):
+            if re.search(r"\bfn\s+%s\b" % name, body):
+                continue        # (a Rust helper of the file itself: zkm_config, zkm_table_id)
+            want = fn_arity(sys_src, name)
+            assert want is not None, "%s calls %s, which zkm_hip_sys.rs does not declare" % (f, name)
+            for got in call_arities(body, name):
+                checked += 1
+                assert got == want, "%s: %s called with %d arguments, declared with %d" % (f, name, got, want)
+    assert checked >= 15

@@ -259,6 +259,7 @@ def test_pure_c_caller_proves_the_segment_image(ctx, zkm, oracle, tmp_path):
     assert (got == ref).all()
     assert "ok %d words, 12 tables, beta0 %016x" % (want.size, int(chal[0])) in r.stdout
     assert "lockstep ok: 2 segments" in r.stdout      # zkm_prove_segments from plain C: both blobs == the single-segment proof
+    assert "pool ok: 3 segments, 2 workers on device 0" in r.stdout   # zkm_pool_* from plain C: groups 2 + 1 on two workers, same words
 
 
 @pytest.mark.gpu

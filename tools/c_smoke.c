@@ -1,5 +1,6 @@
 /* tools/c_smoke.c -- the C ABI used from plain C99, no Python anywhere: read a ZKMTRACE segment image from a file, prove it with
- * zkm_prove_segment_image (and, for a twelve-table image, twice more in one zkm_prove_segments call), write the proof blobs to a file.  The reference-side caller of this boundary is Rust over FFI
+ * zkm_prove_segment_image (and, for a twelve-table image, twice more in one zkm_prove_segments call and three times through a zkm_pool of
+ * two workers), write the proof blobs to a file.  The reference-side caller of this boundary is Rust over FFI
  * (its only existing FFI has this very shape: recursion/src/snark/snarks.rs:7-20, 39-59 -- int status, char** message
  * freed by the caller); this file is the proof that include/zkm_hip.h is usable as it stands by a C compiler in pedantic mode.
  *
@@ -85,6 +86,36 @@ int main(int argc, char** argv) {
         printf("lockstep ok: 2 segments, each blob == the single-segment proof\n");
         free(both[0]);
         free(both[1]);
+        {
+            /* the one-process multi-device shape (zkm_pool_*): three copies of the segment through a pool of two workers on device 0,
+             * groups of at most 2 -> a group of 2 and a group of 1 served side by side; every blob == the single-segment proof */
+            const int devices[1] = {0};
+            zkm_pool* pool = NULL;
+            const uint64_t* const* p_traces[3];
+            const unsigned* p_log_n[3];
+            const uint64_t* p_pubs[3];
+            size_t p_npubs[3], plan[3], ngroups, w0 = 9, g0 = 9, w2 = 9, g2 = 9;
+            uint64_t *p_proofs[3], *p_chal[3], p_chal_words[3][8];
+            for (k = 0; k < 3; k++) {
+                p_traces[k] = traces; p_log_n[k] = log_n; p_pubs[k] = image + 8; p_npubs[k] = (size_t)image[3]; p_chal[k] = p_chal_words[k];
+                p_proofs[k] = (uint64_t*)malloc(proof_words * 8);
+                if (!p_proofs[k]) return die("out of host memory", NULL);
+            }
+            ngroups = zkm_pool_plan(3, 2, 2, plan, 3);
+            if (ngroups != 2 || plan[0] != 2 || plan[1] != 1) return die("zkm_pool_plan: 3 segments, 2 workers, groups of <= 2 should be 2 + 1", NULL);
+            if (zkm_pool_create(devices, 1, 2, &pool, &err)) return die("zkm_pool_create", err);
+            if (zkm_pool_workers(pool) != 2 || zkm_pool_device(pool, 1) != 0 || !zkm_pool_context(pool, 1)) return die("pool shape", NULL);
+            if (zkm_pool_prove_segments(pool, &cfg, 3, 2, p_traces, p_log_n, p_pubs, p_npubs, p_proofs, p_chal, &err))
+                return die("zkm_pool_prove_segments", err);
+            for (k = 0; k < 3; k++)
+                if (memcmp(p_proofs[k], proofs, proof_words * 8) != 0 || memcmp(p_chal[k], challenges, 4 * 8) != 0)
+                    return die("a pool proof differs from the single-segment proof", NULL);
+            if (zkm_pool_last_assignment(pool, 0, &w0, &g0) || zkm_pool_last_assignment(pool, 2, &w2, &g2) || g0 != 0 || g2 != 1 || w0 == w2)
+                return die("pool assignment: two groups on two workers expected", NULL);
+            printf("pool ok: 3 segments, 2 workers on device 0, groups 2 + 1, each blob == the single-segment proof\n");
+            zkm_pool_destroy(pool);
+            for (k = 0; k < 3; k++) free(p_proofs[k]);
+        }
     }
     zkm_ctx_destroy(ctx);
 

@@ -40,6 +40,8 @@ EXPORTS = [
     "zkm_proof_get_layout", "zkm_proof_get_query_layout", "zkm_segment_image_words", "zkm_segment_image_write", "zkm_prove_segment_image",
     "zkm_quotient", "zkm_eval_openings", "zkm_check_constraints", "zkm_profile_enable", "zkm_profile_reset",
     "zkm_profile_count", "zkm_profile_get", "zkm_version",
+    "zkm_pool_create", "zkm_pool_destroy", "zkm_pool_workers", "zkm_pool_context", "zkm_pool_device", "zkm_pool_set_tuning",
+    "zkm_pool_prove_segments", "zkm_pool_prove_segments_columns", "zkm_pool_plan", "zkm_pool_last_assignment",
 ]
 
 
@@ -165,6 +167,18 @@ def load():
                                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), err]),
         "zkm_prove_segment_columns": (C.c_int, [cp, C.POINTER(StarkConfig), C.POINTER(C.c_void_p), C.POINTER(C.c_uint), u64p, C.c_size_t, u64p,
                                                 C.POINTER(C.c_size_t), u64p, err]),
+        "zkm_pool_create": (C.c_int, [C.POINTER(C.c_int), C.c_size_t, C.c_size_t, cpp, err]),
+        "zkm_pool_destroy": (None, [cp]),
+        "zkm_pool_workers": (C.c_size_t, [cp]),
+        "zkm_pool_context": (cp, [cp, C.c_size_t]),
+        "zkm_pool_device": (C.c_int, [cp, C.c_size_t]),
+        "zkm_pool_set_tuning": (C.c_int, [cp, C.c_char_p, C.c_uint64, err]),
+        "zkm_pool_prove_segments": (C.c_int, [cp, C.POINTER(StarkConfig), C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), err]),
+        "zkm_pool_prove_segments_columns": (C.c_int, [cp, C.POINTER(StarkConfig), C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), err]),
+        "zkm_pool_plan": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.c_size_t]),
+        "zkm_pool_last_assignment": (C.c_int, [cp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "zkm_host_alloc": (C.c_int, [cp, C.c_size_t, cpp, err]),
         "zkm_host_free": (C.c_int, [cp, cp]),
         "zkm_host_register": (C.c_int, [cp, cp, C.c_size_t, err]),
@@ -272,6 +286,113 @@ def _data_ptr(x):
     if hasattr(x, "data_ptr"):
         return C.c_void_p(x.data_ptr())
     raise TypeError("unsupported buffer type %r" % type(x))
+
+
+class _marshal_segments:
+    """The argument arrays of zkm_prove_segments[_columns] / zkm_pool_prove_segments[_columns] for segments = list of (traces, log_ns,
+    public_values): traces[t] either one block per table or a list of per-column arrays (each its own allocation, like
+    Vec<PolynomialValues<F>>).  Output buffers are sized with the sizing pass of zkm_prove_segment[_columns] (no context needed)."""
+
+    def __init__(self, L, segments, cfg):
+        K = len(segments)
+        self.keep, self.ptr_arrays, self.log_arrays, self.pubs, self.sizes, self.col_arrays = [], [], [], [], [], []
+        err = C.c_char_p()
+        self.by_columns = all(isinstance(t, (list, tuple)) for seg in segments for t in seg[0])
+        for traces, log_ns, public_values in segments:
+            assert len(traces) == 12 and len(log_ns) == 12
+            if self.by_columns:
+                k = [[c if isinstance(c, DeviceBuffer) else np.ascontiguousarray(c, dtype=np.uint64) for c in t] for t in traces]
+                cols = [(C.c_void_p * len(t))(*[_data_ptr(c).value for c in t]) for t in k]
+                self.col_arrays.append(cols)
+                self.keep.append(k)
+                self.ptr_arrays.append((C.c_void_p * 12)(*[C.addressof(c) for c in cols]))
+            else:
+                k = [t if isinstance(t, DeviceBuffer) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
+                self.keep.append(k)
+                self.ptr_arrays.append((C.c_void_p * 12)(*[_data_ptr(t).value for t in k]))
+            self.log_arrays.append((C.c_uint * 12)(*[int(x) for x in log_ns]))
+            self.pubs.append(np.ascontiguousarray(public_values, dtype=np.uint64))
+            offs = (C.c_size_t * 13)()
+            sizer = L.zkm_prove_segment_columns if self.by_columns else L.zkm_prove_segment
+            _check(sizer(None, C.byref(cfg), self.ptr_arrays[-1], self.log_arrays[-1], self.pubs[-1].ctypes.data_as(u64p), self.pubs[-1].size, None,
+                         offs, None, C.byref(err)), err)
+            self.sizes.append(list(offs))
+        self.proofs = [np.zeros(o[12], dtype=np.uint64) for o in self.sizes]
+        self.chals = [np.zeros(2 * cfg.num_challenges, dtype=np.uint64) for _ in range(K)]
+        self.tr = (C.c_void_p * K)(*[C.addressof(a) for a in self.ptr_arrays])
+        self.lg = (C.c_void_p * K)(*[C.addressof(a) for a in self.log_arrays])
+        self.pv = (C.c_void_p * K)(*[p.ctypes.data for p in self.pubs])
+        self.npv = (C.c_size_t * K)(*[p.size for p in self.pubs])
+        self.po = (C.c_void_p * K)(*[p.ctypes.data for p in self.proofs])
+        self.co = (C.c_void_p * K)(*[p.ctypes.data for p in self.chals])
+
+    def results(self):
+        return [(self.proofs[i], self.chals[i], self.sizes[i]) for i in range(len(self.proofs))]
+
+
+def pool_plan(nseg, workers, max_stack=0):
+    """zkm_pool_plan: the sizes of the lock-step groups a pool call of nseg segments is cut into (a pure function of the library)."""
+    L = load()
+    n = L.zkm_pool_plan(nseg, workers, max_stack, None, 0)
+    out = (C.c_size_t * max(1, n))()
+    L.zkm_pool_plan(nseg, workers, max_stack, out, n)
+    return [int(out[i]) for i in range(n)]
+
+
+class Pool:
+    """zkm_pool: `contexts_per_device` contexts on each of `devices`, one worker thread per context inside ONE process; a call cuts its
+    segments into lock-step groups of at most max_stack and the workers pull them from a queue (include/zkm_hip.h).  The reference's
+    one-process segment loop (prover/examples/utils/src/utils.rs:57-68, 105-133) over N GPUs."""
+
+    def __init__(self, devices=(0,), contexts_per_device=1):
+        self.L = load()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h, err = C.c_void_p(), C.c_char_p()
+        _check(self.L.zkm_pool_create(devs, len(devices), contexts_per_device, C.byref(h), C.byref(err)), err)
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.zkm_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def workers(self):
+        return int(self.L.zkm_pool_workers(self.h))
+
+    def device(self, worker):
+        return int(self.L.zkm_pool_device(self.h, worker))
+
+    def set_tuning(self, key, value):
+        err = C.c_char_p()
+        _check(self.L.zkm_pool_set_tuning(self.h, key.encode(), int(value), C.byref(err)), err)
+
+    def standard_config(self):
+        cfg = StarkConfig()
+        self.L.zkm_standard_config(C.byref(cfg))
+        return cfg
+
+    def prove_segments(self, segments, max_stack=0, cfg=None):
+        """zkm_pool_prove_segments[_columns]: segments as Context.prove_segments takes them (HOST arrays unless the pool has one device).
+        Returns the list of (proofs, ctl_challenges, offsets), one per segment."""
+        cfg = cfg or self.standard_config()
+        m = _marshal_segments(self.L, segments, cfg)
+        err = C.c_char_p()
+        fn = self.L.zkm_pool_prove_segments_columns if m.by_columns else self.L.zkm_pool_prove_segments
+        _check(fn(self.h, C.byref(cfg), len(segments), max_stack, m.tr, m.lg, m.pv, m.npv, m.po, m.co, C.byref(err)), err)
+        return m.results()
+
+    def last_assignment(self, segment):
+        """(worker, group) that proved `segment` in the last call."""
+        w, g = C.c_size_t(), C.c_size_t()
+        if self.L.zkm_pool_last_assignment(self.h, segment, C.byref(w), C.byref(g)) != 0:
+            raise ZkmError("zkm_pool_last_assignment: segment %d was not proven by the last call" % segment)
+        return int(w.value), int(g.value)
 
 
 class Context:
@@ -663,41 +784,11 @@ class Context:
         height).  segments = list of (traces, log_ns, public_values) as prove_segment takes them.  Returns a list of
         (proofs, ctl_challenges, offsets), one per segment -- each equal to prove_segment's result for that segment alone."""
         cfg = cfg or self.standard_config()
-        K = len(segments)
-        keep, ptr_arrays, log_arrays, pubs, sizes = [], [], [], [], []
+        m = _marshal_segments(self.L, segments, cfg)
         err = C.c_char_p()
-        by_columns = all(isinstance(t, (list, tuple)) for seg in segments for t in seg[0])
-        col_arrays = []
-        for traces, log_ns, public_values in segments:
-            assert len(traces) == 12 and len(log_ns) == 12
-            if by_columns:       # traces[t] = list of per-column arrays (each its own allocation, like Vec<PolynomialValues<F>>)
-                k = [[c if isinstance(c, DeviceBuffer) else np.ascontiguousarray(c, dtype=np.uint64) for c in t] for t in traces]
-                cols = [(C.c_void_p * len(t))(*[_data_ptr(c).value for c in t]) for t in k]
-                col_arrays.append(cols)
-                keep.append(k)
-                ptr_arrays.append((C.c_void_p * 12)(*[C.addressof(c) for c in cols]))
-            else:
-                k = [t if isinstance(t, DeviceBuffer) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
-                keep.append(k)
-                ptr_arrays.append((C.c_void_p * 12)(*[_data_ptr(t).value for t in k]))
-            log_arrays.append((C.c_uint * 12)(*[int(x) for x in log_ns]))
-            pubs.append(np.ascontiguousarray(public_values, dtype=np.uint64))
-            offs = (C.c_size_t * 13)()
-            sizer = self.L.zkm_prove_segment_columns if by_columns else self.L.zkm_prove_segment
-            _check(sizer(None, C.byref(cfg), ptr_arrays[-1], log_arrays[-1], pubs[-1].ctypes.data_as(u64p), pubs[-1].size, None, offs, None,
-                         C.byref(err)), err)
-            sizes.append(list(offs))
-        proofs = [np.zeros(o[12], dtype=np.uint64) for o in sizes]
-        chals = [np.zeros(2 * cfg.num_challenges, dtype=np.uint64) for _ in range(K)]
-        tr = (C.c_void_p * K)(*[C.addressof(a) for a in ptr_arrays])
-        lg = (C.c_void_p * K)(*[C.addressof(a) for a in log_arrays])
-        pv = (C.c_void_p * K)(*[p.ctypes.data for p in pubs])
-        npv = (C.c_size_t * K)(*[p.size for p in pubs])
-        po = (C.c_void_p * K)(*[p.ctypes.data for p in proofs])
-        co = (C.c_void_p * K)(*[p.ctypes.data for p in chals])
-        fn = self.L.zkm_prove_segments_columns if by_columns else self.L.zkm_prove_segments
-        _check(fn(self.h, C.byref(cfg), K, tr, lg, pv, npv, po, co, C.byref(err)), err)
-        return [(proofs[i], chals[i], sizes[i]) for i in range(K)]
+        fn = self.L.zkm_prove_segments_columns if m.by_columns else self.L.zkm_prove_segments
+        _check(fn(self.h, C.byref(cfg), len(segments), m.tr, m.lg, m.pv, m.npv, m.po, m.co, C.byref(err)), err)
+        return m.results()
 
     def _prove_segment_columns(self, traces, log_ns, public_values, cfg):
         """zkm_prove_segment_columns: traces[t] = list of per-column arrays (each its own allocation, like Vec<PolynomialValues<F>>)."""

@@ -1137,9 +1137,9 @@ static void prove_segments_impl(zkm_ctx* c, const zkm_stark_config* cfg, size_t 
 // cached plus the memory that is free right now.  One segment always goes (a single
 // segment that does not fit fails in the allocator, as it always did).
 static void prove_segments_waves(zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const seg_io* io, size_t ntables,
-                                 const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls) {
+                                 const zkm_cross_table_lookup* ctls, const zkm_ctl_side* sides, size_t nctls, size_t seg_base = 0) {
     if (nseg <= 1) {
-        prove_segments_impl(c, cfg, nseg, io, ntables, ctls, sides, nctls);
+        prove_segments_impl(c, cfg, nseg, io, ntables, ctls, sides, nctls, seg_base);
         return;
     }
     ZKM_HIP_CHECK(hipSetDevice(c->device));
@@ -1173,7 +1173,7 @@ static void prove_segments_waves(zkm_ctx* c, const zkm_stark_config* cfg, size_t
                 total / 1e9, budget / 1e9, free_b / 1e9, cached / 1e9, nwaves, extra, lo + 1, nwaves - extra, lo);
     for (size_t w = 0, s0 = 0; w < nwaves; w++) {
         const size_t k = lo + (w < extra ? 1 : 0);
-        prove_segments_impl(c, cfg, k, io + s0, ntables, ctls, sides, nctls, s0);   // (s0: errors name positions in the CALL, not in the wave)
+        prove_segments_impl(c, cfg, k, io + s0, ntables, ctls, sides, nctls, seg_base + s0);   // (errors name positions in the CALL, not in the wave)
         s0 += k;
     }
 }
@@ -1196,9 +1196,10 @@ int zkm_prove_with_traces(zkm_ctx* c, const zkm_stark_config* cfg, const zkm_tab
 }
 
 // traces[s][t] (one block per table) or columns[s][t][i] (one pointer per column) -- exactly one of the two is non-null
-static int prove_segments_entry(const char* what, zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* traces,
-                                const uint64_t* const* const* const* columns, const unsigned* const* log_n, const uint64_t* const* pub,
-                                const size_t* npub, uint64_t* const* proofs, uint64_t* const* challenges, char** err) {
+// (zkm_internal.h: the pool's workers call it with the position of their group in the pool call as seg_base -- error messages only)
+int zkm_prove_segments_entry(const char* what, zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* traces,
+                             const uint64_t* const* const* const* columns, const unsigned* const* log_n, const uint64_t* const* pub,
+                             const size_t* npub, uint64_t* const* proofs, uint64_t* const* challenges, char** err, size_t seg_base) {
     try {
         if (!c || !cfg || (!traces && !columns) || !log_n || !proofs || !challenges) throw std::runtime_error(std::string(what) + ": null argument");
         std::vector<std::vector<zkm_table_input>> tables(nseg, std::vector<zkm_table_input>(12));
@@ -1214,7 +1215,7 @@ static int prove_segments_entry(const char* what, zkm_ctx* c, const zkm_stark_co
             io[s] = seg_io{tables[s].data(), pub ? pub[s] : nullptr, npub ? npub[s] : 0, proofs[s], challenges[s]};
             if (io[s].npub && !io[s].pub) throw std::runtime_error(std::string(what) + ": null public values");
         }
-        prove_segments_waves(c, cfg, nseg, io.data(), 12, AS_CTLS, AS_SIDES, AS_NCTLS);
+        prove_segments_waves(c, cfg, nseg, io.data(), 12, AS_CTLS, AS_SIDES, AS_NCTLS, seg_base);
     } catch (const std::exception& e) {
         return fail(err, e.what());
     } catch (...) {
@@ -1225,13 +1226,13 @@ static int prove_segments_entry(const char* what, zkm_ctx* c, const zkm_stark_co
 
 int zkm_prove_segments(zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* traces, const unsigned* const* log_n,
                        const uint64_t* const* pub, const size_t* npub, uint64_t* const* proofs, uint64_t* const* challenges, char** err) {
-    return prove_segments_entry("zkm_prove_segments", c, cfg, nseg, traces, nullptr, log_n, pub, npub, proofs, challenges, err);
+    return zkm_prove_segments_entry("zkm_prove_segments", c, cfg, nseg, traces, nullptr, log_n, pub, npub, proofs, challenges, err, 0);
 }
 
 int zkm_prove_segments_columns(zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* const* columns,
                                const unsigned* const* log_n, const uint64_t* const* pub, const size_t* npub, uint64_t* const* proofs,
                                uint64_t* const* challenges, char** err) {
-    return prove_segments_entry("zkm_prove_segments_columns", c, cfg, nseg, nullptr, columns, log_n, pub, npub, proofs, challenges, err);
+    return zkm_prove_segments_entry("zkm_prove_segments_columns", c, cfg, nseg, nullptr, columns, log_n, pub, npub, proofs, challenges, err, 0);
 }
 
 }  // extern "C"

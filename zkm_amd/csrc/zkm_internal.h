@@ -301,4 +301,8 @@ void zkm_launch_sha_compress_trace(zkm_ctx* c, bool sponge, const uint32_t* d_hx
 void zkm_launch_keccak_trace(zkm_ctx* c, const uint64_t* d_inputs, const uint64_t* d_ts, size_t nperms, size_t n, gl_t* out);
 void zkm_launch_logic_trace(zkm_ctx* c, const uint32_t* d_ops, size_t nops, size_t n, gl_t* out, int* d_bad);
 
-
+// ctl.hip: the body of zkm_prove_segments[_columns] (exactly one of traces / columns non-null); seg_base = position of segment 0 in the
+// caller's larger call (csrc/pool.hip deals groups of one pool call to its workers) -- used in error messages only
+extern "C" int zkm_prove_segments_entry(const char* what, zkm_ctx* c, const zkm_stark_config* cfg, size_t nseg, const uint64_t* const* const* traces,
+                                        const uint64_t* const* const* const* columns, const unsigned* const* log_n, const uint64_t* const* pub,
+                                        const size_t* npub, uint64_t* const* proofs, uint64_t* const* challenges, char** err, size_t seg_base);
