@@ -483,6 +483,28 @@ int zkm_prove_segments_columns(zkm_ctx* ctx, const zkm_stark_config* cfg, size_t
                                const unsigned* const* log_n, const uint64_t* const* public_values, const size_t* npublic,
                                uint64_t* const* proofs_out, uint64_t* const* ctl_challenges_out, char** err);
 
+/* ------------------------------------------------------------------ staged traces: the NEXT proof's upload behind the CURRENT proof
+ * The reference commits from host Vecs (prover.rs:144-167).  A prove call handed a host trace pipelines the upload INSIDE the proof
+ * (column chunks absorbed as they arrive: zkm_batch_commit_values); a driver that has the next segment's trace while the current one is
+ * being proven -- the witness generator runs ahead of the prover -- stages it instead: zkm_trace_stage[_columns] queues the upload of
+ * an ncols x 2^log_n host matrix on the context's two copy streams (alternate 8-column pieces) into a block of the context's
+ * allocator and RETURNS AT ONCE; zkm_staged_ptr gives the device matrix to pass as `trace` / `traces[k]` of a later prove call ON THE
+ * SAME CONTEXT, ordered behind the upload on the context's compute stream (a device-side wait; NULL on a runtime error).  That call
+ * runs the device-resident path at full speed while the copy engines bring in the trace after it.
+ *   canonical   nonzero: the caller vouches that every word is < p; 0: the staged copy is canonicalised once when first consumed
+ *   host memory pinned (zkm_host_alloc, or a Vec under zkm_host_register): the copies are asynchronous.  Pageable memory works and
+ *               makes zkm_trace_stage itself take the time of the upload (the runtime stages it through its own pinned buffer).
+ *   The host matrix must stay valid and unchanged until zkm_staged_ready(h, ..) returns 1 or zkm_staged_free(h) has returned.
+ * zkm_staged_ready: 1 = uploaded, 0 = in flight (wait = 0 only), -1 = runtime error.  zkm_staged_free waits for the upload and returns
+ * the block; call it after the prove call that consumed the matrix has returned. */
+typedef struct zkm_staged zkm_staged;
+int zkm_trace_stage(zkm_ctx* ctx, const uint64_t* values, size_t ncols, unsigned log_n, int canonical, zkm_staged** out, char** err);
+int zkm_trace_stage_columns(zkm_ctx* ctx, const uint64_t* const* columns, size_t ncols, unsigned log_n, int canonical, zkm_staged** out,
+                            char** err);
+const uint64_t* zkm_staged_ptr(zkm_staged* staged);
+int zkm_staged_ready(zkm_staged* staged, int wait);
+void zkm_staged_free(zkm_staged* staged);
+
 /* ------------------------------------------------------------------ one process, many GPUs: a pool of contexts
  * The reference drives all segments of a program from ONE process (prover/examples/utils/src/utils.rs:57-68 prove_single_seg_common,
  * :105-133 prove_multi_seg_common: a loop of prove_with_traces calls); segments are independent proofs, so N GPUs take them

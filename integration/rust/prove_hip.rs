@@ -172,6 +172,38 @@ where
     }).collect())
 }
 
+/// A host trace on its way into HBM BEHIND the proof the context is working on (include/zkm_hip.h "staged traces"): the driver that
+/// has segment i + 1's traces while segment i is being proven stages them, then hands `ptr()` to the next prove call of the SAME
+/// context -- that proof runs the device-resident path and the 2.2 GB of a 262 x 2^20 trace cross PCIe behind its predecessor
+/// (17.05 proofs/s from host memory against 17.15 device-resident, profiles/r06_host_resident.txt).  The columns must stay alive
+/// and unchanged until `ready(true)` or drop; pinned memory (zkm_host_alloc, or the Vecs registered once with zkm_host_register)
+/// makes `stage` return at once, pageable memory makes it take the time of the upload.
+pub struct StagedTrace(*mut zkm_staged);
+
+impl StagedTrace {
+    pub fn stage<F: PrimeField64>(ctx: *mut zkm_ctx, cols: &[PolynomialValues<F>], canonical: bool) -> Result<Self> {
+        let ptrs = column_ptrs(cols);
+        let log_n = cols[0].len().trailing_zeros();
+        let mut h = std::ptr::null_mut();
+        let mut err = std::ptr::null_mut();
+        check(unsafe { zkm_trace_stage_columns(ctx, ptrs.as_ptr(), ptrs.len(), log_n, canonical as i32, &mut h, &mut err) }, err)?;
+        Ok(Self(h))
+    }
+    /// the device matrix (column-major, ncols x 2^log_n), ordered behind the upload on the context's compute stream
+    pub fn ptr(&mut self) -> *const u64 {
+        unsafe { zkm_staged_ptr(self.0) }
+    }
+    pub fn ready(&mut self, wait: bool) -> bool {
+        unsafe { zkm_staged_ready(self.0, wait as i32) == 1 }
+    }
+}
+
+impl Drop for StagedTrace {
+    fn drop(&mut self) {
+        unsafe { zkm_staged_free(self.0) };
+    }
+}
+
 /// A pool of contexts over the GPUs of one node, owned by the ONE process that drives all segments of a program -- the shape of the
 /// reference's driver (prover/examples/utils/src/utils.rs:57-68 `prove_single_seg_common`, :105-133 `prove_multi_seg_common`: a loop
 /// of `prove_with_traces` calls).  `contexts_per_device` worker threads per device live inside the library (include/zkm_hip.h

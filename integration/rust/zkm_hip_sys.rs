@@ -13,6 +13,7 @@ use std::os::raw::{c_char, c_double, c_int, c_uint, c_void};
 #[repr(C)] pub struct zkm_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct zkm_batch { _p: [u8; 0] }
 #[repr(C)] pub struct zkm_pool { _p: [u8; 0] }
+#[repr(C)] pub struct zkm_staged { _p: [u8; 0] }
 
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct zkm_challenger { pub state: [u64; 12], pub in_buf: [u64; 8], pub out_buf: [u64; 8], pub n_in: u32, pub n_out: u32 }
@@ -169,6 +170,14 @@ extern "C" {
     pub fn zkm_prove_segments_columns(ctx: *mut zkm_ctx, cfg: *const zkm_stark_config, nseg: usize, columns: *const *const *const *const u64,
                                       log_n: *const *const c_uint, public_values: *const *const u64, npublic: *const usize,
                                       proofs_out: *const *mut u64, ctl_challenges_out: *const *mut u64, err: *mut *mut c_char) -> c_int;
+    // staged traces: the next proof's upload behind the current proof (copy streams; returns at once)
+    pub fn zkm_trace_stage(ctx: *mut zkm_ctx, values: *const u64, ncols: usize, log_n: c_uint, canonical: c_int, out: *mut *mut zkm_staged,
+                           err: *mut *mut c_char) -> c_int;
+    pub fn zkm_trace_stage_columns(ctx: *mut zkm_ctx, columns: *const *const u64, ncols: usize, log_n: c_uint, canonical: c_int,
+                                   out: *mut *mut zkm_staged, err: *mut *mut c_char) -> c_int;
+    pub fn zkm_staged_ptr(staged: *mut zkm_staged) -> *const u64;
+    pub fn zkm_staged_ready(staged: *mut zkm_staged, wait: c_int) -> c_int;
+    pub fn zkm_staged_free(staged: *mut zkm_staged);
     // one process, many GPUs: contexts_per_device contexts on each device, one worker thread per context, groups of <= max_stack segments
     pub fn zkm_pool_create(devices: *const c_int, ndevices: usize, contexts_per_device: usize, out: *mut *mut zkm_pool, err: *mut *mut c_char) -> c_int;
     pub fn zkm_pool_destroy(pool: *mut zkm_pool);

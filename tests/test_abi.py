@@ -275,7 +275,7 @@ def test_rust_mirror_matches_the_c_layout(tmp_path):
     lay = c_layouts(tmp_path)
     structs = rust_structs()
     opaque = {k for k, v in structs.items() if [f for f, _ in v] == ["_p"]}
-    assert opaque == {"zkm_ctx", "zkm_batch", "zkm_pool"}
+    assert opaque == {"zkm_ctx", "zkm_batch", "zkm_pool", "zkm_staged"}
     assert set(structs) - opaque == set(lay), (set(structs) - opaque) ^ set(lay)
     memo = {}
     for name in lay:

@@ -180,3 +180,59 @@ def test_pipelined_host_ingest_equals_monolithic(zkm, oracle):
                 assert (b.cap() == want.cap()).all()
                 b.free()
             c.close()
+
+
+@pytest.mark.parametrize("log_n", [9, 14])
+def test_staged_traces_prove_like_host_and_device_traces(zkm, oracle, log_n):
+    """zkm_trace_stage[_columns] (round 6: the NEXT proof's upload behind the CURRENT proof, include/zkm_hip.h "staged traces"): a proof
+    from a staged trace -- one block or one pointer per column, pageable or pinned memory, words vouched canonical or not, consumed by
+    zkm_prove_single_table or as one of K proofs of a lock-step call, the next trace being staged while the current proof runs --
+    equals the proof from the host array and the oracle's, word for word; ready / free behave."""
+    n = 1 << log_n
+    c = zkm.Context(0)
+    try:
+        traces = []
+        for k in range(3):
+            d = c.poseidon_trace(seed=70 + k, num_perms=n - 2 - k, log_n=log_n)
+            traces.append(d.download())
+            d.free()
+        aux = np.zeros(4 * n, dtype=np.uint64)
+        want = [oracle.prove(t, log_n, aux, [1, 1]) for t in traces]
+        for k in range(3):
+            assert (c.prove_single_table(traces[k], log_n, aux, [1, 1]) == want[k]).all()
+        # a loop as bench.py's host_resident block runs it: stage the next, prove the current, free it
+        pinned = [c.pinned_array(262 * n) for _ in range(3)]
+        for k in range(3):
+            pinned[k][:] = traces[k]
+        cur = c.stage_trace(pinned[0], 262, log_n)
+        for k in range(3):
+            nxt = c.stage_trace(pinned[k + 1], 262, log_n) if k < 2 else None
+            got = c.prove_single_table(cur, log_n, aux, [1, 1])
+            assert (got == want[k]).all(), k
+            assert cur.ready() is True            # the proof consumed it: the upload has landed
+            cur.free()
+            cur = nxt
+        # one pointer per column, pageable memory, NOT vouched canonical: every word + p where that still fits 64 bits
+        cols = [np.ascontiguousarray(traces[1].reshape(262, n)[i]).copy() for i in range(262)]
+        for col in cols[::7]:
+            small = col < (1 << 32) - 1
+            col[small] += np.uint64(P)
+        st = c.stage_trace(cols, 262, log_n, canonical=False)
+        assert st.ready(wait=True) is True
+        assert (c.prove_single_table(st, log_n, aux, [1, 1]) == want[1]).all()
+        # K proofs in lock-step from staged traces
+        sts = [c.stage_trace(pinned[k], 262, log_n) for k in range(3)]
+        got = c.prove_single_tables(sts, log_n, aux, [1, 1])
+        for k in range(3):
+            assert (got[k] == want[k]).all(), k
+        for s_ in sts + [st]:
+            s_.free()
+        for p_ in pinned:
+            c.free_pinned(p_)
+        c.synchronize()
+        live, _ = c.memory()
+        assert live == c.resident_bytes()          # every staged block went back to the allocator
+        with pytest.raises(zkm.ZkmError, match="zkm_trace_stage"):
+            c.stage_trace(np.zeros(0, dtype=np.uint64), 0, log_n)
+    finally:
+        c.close()

@@ -40,6 +40,7 @@ EXPORTS = [
     "zkm_proof_get_layout", "zkm_proof_get_query_layout", "zkm_segment_image_words", "zkm_segment_image_write", "zkm_prove_segment_image",
     "zkm_quotient", "zkm_eval_openings", "zkm_check_constraints", "zkm_profile_enable", "zkm_profile_reset",
     "zkm_profile_count", "zkm_profile_get", "zkm_version",
+    "zkm_trace_stage", "zkm_trace_stage_columns", "zkm_staged_ptr", "zkm_staged_ready", "zkm_staged_free",
     "zkm_pool_create", "zkm_pool_destroy", "zkm_pool_workers", "zkm_pool_context", "zkm_pool_device", "zkm_pool_set_tuning",
     "zkm_pool_prove_segments", "zkm_pool_prove_segments_columns", "zkm_pool_plan", "zkm_pool_last_assignment",
 ]
@@ -179,6 +180,11 @@ def load():
                                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), err]),
         "zkm_pool_plan": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.c_size_t]),
         "zkm_pool_last_assignment": (C.c_int, [cp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+        "zkm_trace_stage": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, C.c_int, cpp, err]),
+        "zkm_trace_stage_columns": (C.c_int, [cp, C.POINTER(C.c_void_p), C.c_size_t, C.c_uint, C.c_int, cpp, err]),
+        "zkm_staged_ptr": (cp, [cp]),
+        "zkm_staged_ready": (C.c_int, [cp, C.c_int]),
+        "zkm_staged_free": (None, [cp]),
         "zkm_host_alloc": (C.c_int, [cp, C.c_size_t, cpp, err]),
         "zkm_host_free": (C.c_int, [cp, cp]),
         "zkm_host_register": (C.c_int, [cp, cp, C.c_size_t, err]),
@@ -275,9 +281,35 @@ class DeviceBuffer:
             self.ptr = None
 
 
+class StagedTrace:
+    """zkm_staged: a host matrix on its way into HBM behind the context's current work (include/zkm_hip.h "staged traces").  Pass it
+    wherever a prove call of the SAME context takes a trace; free() after that call has returned."""
+
+    def __init__(self, ctx, handle, words):
+        self.ctx, self.h, self.words = ctx, handle, words
+
+    @property
+    def ptr(self):
+        p = self.ctx.L.zkm_staged_ptr(self.h)
+        if not p:
+            raise ZkmError("zkm_staged_ptr: the upload could not be ordered before the compute stream")
+        return p
+
+    def ready(self, wait=False):
+        r = self.ctx.L.zkm_staged_ready(self.h, 1 if wait else 0)
+        if r < 0:
+            raise ZkmError("zkm_staged_ready: runtime error")
+        return bool(r)
+
+    def free(self):
+        if self.h:
+            self.ctx.L.zkm_staged_free(self.h)
+            self.h = None
+
+
 def _data_ptr(x):
-    """Accept numpy host arrays, DeviceBuffers, raw integer device pointers or torch CUDA tensors."""
-    if isinstance(x, DeviceBuffer):
+    """Accept numpy host arrays, DeviceBuffers, staged traces, raw integer device pointers or torch CUDA tensors."""
+    if isinstance(x, (DeviceBuffer, StagedTrace)):
         return C.c_void_p(x.ptr)
     if isinstance(x, np.ndarray):
         return _np_ptr(x)
@@ -627,6 +659,23 @@ class Context:
 
     def proof_words(self, cfg, log_n, ncols, naux, nctl):
         return self.L.zkm_proof_words(C.byref(cfg), log_n, ncols, naux, nctl)
+
+    def stage_trace(self, values, ncols, log_n, canonical=True):
+        """zkm_trace_stage[_columns]: queue the upload of a host matrix (one array, or a list of per-column arrays) on the copy streams and
+        return at once; the StagedTrace goes where a prove call of this context takes a trace.  The host arrays must stay alive and
+        unchanged until ready() or free()."""
+        h, err = C.c_void_p(), C.c_char_p()
+        if isinstance(values, (list, tuple)):
+            keep = [np.ascontiguousarray(c, dtype=np.uint64) for c in values]
+            cols = (C.c_void_p * len(keep))(*[c.ctypes.data for c in keep])
+            _check(self.L.zkm_trace_stage_columns(self.h, cols, ncols, log_n, 1 if canonical else 0, C.byref(h), C.byref(err)), err)
+        else:
+            keep = np.ascontiguousarray(values, dtype=np.uint64)
+            assert keep.size == ncols << log_n
+            _check(self.L.zkm_trace_stage(self.h, _np_ptr(keep), ncols, log_n, 1 if canonical else 0, C.byref(h), C.byref(err)), err)
+        st = StagedTrace(self, h, ncols << log_n)
+        st._keep = keep
+        return st
 
     def prove_single_table(self, trace, log_n, aux, num_helpers, challenger=None, cfg=None, ncols=POSEIDON_COLS,
                            trace_batch=None, naux=None, table_id=TABLE_POSEIDON):

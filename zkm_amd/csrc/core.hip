@@ -80,12 +80,14 @@ void zkm_ctx::trim_self() {
         drop.swap(free_blocks);                                // from here on nobody can be handed these blocks again ...
     }
     (void)hipStreamSynchronize(stream);                        // ... and what was queued on them before has completed after this
-    hipStream_t cs;
+    hipStream_t cs, cs2;
     {
-        std::lock_guard<std::mutex> g(alloc_mu);               // (the owner publishes its copy stream under the same lock: zkm_batch_build)
+        std::lock_guard<std::mutex> g(alloc_mu);               // (the owner publishes its copy streams under the same lock: zkm_batch_build, zkm_trace_stage)
         cs = copy_stream;
+        cs2 = copy_stream2;
     }
     if (cs) (void)hipStreamSynchronize(cs);                    // (or was the target of an upload in flight)
+    if (cs2) (void)hipStreamSynchronize(cs2);
     for (auto& kv : drop) (void)hipFree(kv.second);
 }
 // The pinned download area grows with the largest lock-step group seen (up to XFER_DOWN_MAX per context and per lane) and nothing
@@ -100,12 +102,27 @@ void zkm_ctx::shrink_down() {
     down_cap = 0;
     ensure_down(XFER_DOWN);
 }
+// The upload streams go as well (created again on first use): an idle stream still holds one of the runtime's hardware queues, and a GPU
+// whose queues are oversubscribed by idle contexts runs everybody's launches slower -- bench.py's small-segment extra, a fresh process,
+// fell from 105 to 95 segments/s next to four parked contexts with two copy streams each (round 6).
+void zkm_ctx::drop_copy_streams() {
+    hipStream_t a, b;
+    {
+        std::lock_guard<std::mutex> g(alloc_mu);
+        a = copy_stream; b = copy_stream2;
+        copy_stream = copy_stream2 = nullptr;
+    }
+    for (hipStream_t st : {a, b})
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+}
 void zkm_ctx::trim() {   // public: between calls (zkm_ctx_trim)
     trim_self();
     shrink_down();
+    drop_copy_streams();
     for (zkm_ctx* l : lanes) {
         l->trim_self();
         l->shrink_down();
+        l->drop_copy_streams();
     }
 }
 // A stream of the library.  ZKM_CU_MASK_PART = "k/n" (measurement aid, read when a context is created; its lanes inherit it): the
@@ -390,6 +407,19 @@ void zkm_ctx::download(std::initializer_list<xfer> xs) {
         off += (x.bytes + 63) & ~(size_t)63;
     }
 }
+// Small uploads (challenge powers, query indices, descriptors: <= 64 KB) are copied by a one-workgroup KERNEL reading the pinned ring
+// slot, not by the copy engines: a hipMemcpyAsync of a few hundred bytes queues behind whatever the engines are busy with -- with the
+// next proof's trace being staged behind the current proof (zkm_trace_stage, 2.2 GB in 268 MB pieces) every transcript round trip waited
+// for a piece: 70 ms per proof instead of 58 (round 6).  The kernel runs on the context's compute stream like the work that needs it.
+__global__ __launch_bounds__(256) void k_upload_small(void* __restrict__ dst, const void* __restrict__ src, size_t bytes) {
+    if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 7) == 0) {
+        for (size_t i = threadIdx.x; i < bytes / 8; i += 256) ((uint64_t*)dst)[i] = ((const uint64_t*)src)[i];
+    } else if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 3) == 0) {
+        for (size_t i = threadIdx.x; i < bytes / 4; i += 256) ((uint32_t*)dst)[i] = ((const uint32_t*)src)[i];
+    } else {
+        for (size_t i = threadIdx.x; i < bytes; i += 256) ((uint8_t*)dst)[i] = ((const uint8_t*)src)[i];
+    }
+}
 void zkm_ctx::upload(void* dst, const void* src, size_t bytes) {
     if (!bytes) return;
     if (bytes > XFER_UP / 4) {   // large: straight from the caller's memory, and waited for (the runtime may pin `src` and copy later)
@@ -401,7 +431,13 @@ void zkm_ctx::upload(void* dst, const void* src, size_t bytes) {
     if (up_off + bytes > XFER_UP) sync();                        // the ring is full: wait for the uploads in flight (sync() rewinds it)
     char* slot = h_xfer + up_off;
     memcpy(slot, src, bytes);
-    ZKM_HIP_CHECK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, stream));
+    static const bool by_kernel = !(getenv("ZKM_UPLOAD_KERNEL") && atoi(getenv("ZKM_UPLOAD_KERNEL")) == 0);    // (measurement aid: 0 = copy engine)
+    if (by_kernel) {
+        hipLaunchKernelGGL(k_upload_small, dim3(1), dim3(256), 0, stream, dst, (const void*)slot, bytes);
+        ZKM_HIP_CHECK(hipGetLastError());
+    } else {
+        ZKM_HIP_CHECK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, stream));
+    }
     up_off += (bytes + 63) & ~(size_t)63;
 }
 hipEvent_t zkm_ctx::get_event() {
@@ -487,6 +523,7 @@ void zkm_ctx_destroy(zkm_ctx* c) {
     c->lanes.clear();
     (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->copy_stream2) { (void)hipStreamSynchronize(c->copy_stream2); (void)hipStreamDestroy(c->copy_stream2); }
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
     for (auto& kv : c->live_blocks) (void)hipFree(kv.first);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
@@ -621,6 +658,149 @@ int zkm_dev_download(zkm_ctx* c, void* dst, const void* src, size_t bytes, char*
     ZKM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     c->sync();
     ZKM_API_END(err)
+}
+
+// ------------------------------------------------------------------ staged traces: the upload of the NEXT proof behind the CURRENT one
+// The reference commits from host Vecs (prover/src/prover.rs:144-167); over PCIe a 262 x 2^20 trace is 2.2 GB = ~40 ms, most of a
+// proof.  The intra-proof pipeline of zkm_batch_build (column chunks absorbed as they arrive) hides that behind hashing at the price of
+// the chunked kernels (sponge state parked in HBM, short transforms, the multiply-add leaf form).  With the next segment's traces at
+// hand while the current one is being proven -- the witness generator runs ahead of the prover -- the upload belongs BEHIND THE
+// PREVIOUS PROOF instead: zkm_trace_stage queues it on the context's two copy streams (alternate 8-column pieces)
+// and returns; the proof that consumes it runs the device-resident path at full speed.
+struct zkm_staged {
+    zkm_ctx* ctx;
+    gl_t* dev;
+    size_t words;
+    hipEvent_t done[2];
+    bool joined, canonical;
+};
+
+static zkm_staged* stage_begin(zkm_ctx* c, size_t words, int canonical) {
+    ZKM_HIP_CHECK(hipSetDevice(c->device));
+    for (hipStream_t* cs : {&c->copy_stream, &c->copy_stream2})
+        if (!*cs) {
+            hipStream_t st = nullptr;
+            ZKM_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            std::lock_guard<std::mutex> g(c->alloc_mu);      // (published under the allocator's lock, like zkm_batch_build's)
+            *cs = st;
+        }
+    zkm_staged* s = new zkm_staged();
+    s->ctx = c; s->words = words; s->joined = false; s->canonical = canonical != 0;
+    s->done[0] = s->done[1] = nullptr;
+    try {
+        s->dev = (gl_t*)c->alloc(words * sizeof(gl_t));
+        // the block may be one a finished call of this context released: whatever the compute stream still has queued on it comes first
+        hipEvent_t e = c->get_event();
+        ZKM_HIP_CHECK(hipEventRecord(e, c->stream));
+        ZKM_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, e, 0));
+        ZKM_HIP_CHECK(hipStreamWaitEvent(c->copy_stream2, e, 0));
+        c->event_pool.push_back(e);
+    } catch (...) {
+        if (s->dev) c->release(s->dev);
+        delete s;
+        throw;
+    }
+    return s;
+}
+static void stage_end(zkm_staged* s) {
+    zkm_ctx* c = s->ctx;
+    s->done[0] = c->get_event();
+    s->done[1] = c->get_event();
+    ZKM_HIP_CHECK(hipEventRecord(s->done[0], c->copy_stream));
+    ZKM_HIP_CHECK(hipEventRecord(s->done[1], c->copy_stream2));
+}
+static void stage_abort(zkm_staged* s) {
+    (void)hipStreamSynchronize(s->ctx->copy_stream);
+    (void)hipStreamSynchronize(s->ctx->copy_stream2);
+    s->ctx->release(s->dev);
+    for (hipEvent_t e : s->done)
+        if (e) s->ctx->event_pool.push_back(e);
+    delete s;
+}
+
+int zkm_trace_stage(zkm_ctx* c, const uint64_t* values, size_t ncols, unsigned log_n, int canonical, zkm_staged** out, char** err) {
+    ZKM_API_BEGIN
+    if (!c || !values || !out || !ncols || log_n > 30) throw std::runtime_error("zkm_trace_stage: bad argument");
+    const size_t n = (size_t)1 << log_n;
+    zkm_staged* s = stage_begin(c, ncols * n, canonical);
+    try {
+        size_t piece = 8;              // columns per copy (67 MB at 2^20 rows): the two streams take alternate pieces; small pieces let the
+                                       // other contexts' copies interleave (4 contexts: 16.3 proofs/s against 15.6 with 32-column pieces)
+        if (const char* e = getenv("ZKM_STAGE_PIECE_COLS")) piece = std::max<size_t>(1, (size_t)atoi(e));   // (measurement aid)
+        for (size_t c0 = 0, k = 0; c0 < ncols; c0 += piece, k++) {
+            const size_t nc = std::min(piece, ncols - c0);
+            ZKM_HIP_CHECK(hipMemcpyAsync(s->dev + c0 * n, values + c0 * n, nc * n * sizeof(gl_t), hipMemcpyHostToDevice, (k & 1) ? c->copy_stream2 : c->copy_stream));
+        }
+        stage_end(s);
+    } catch (...) {
+        stage_abort(s);
+        throw;
+    }
+    *out = s;
+    ZKM_API_END(err)
+}
+int zkm_trace_stage_columns(zkm_ctx* c, const uint64_t* const* columns, size_t ncols, unsigned log_n, int canonical, zkm_staged** out, char** err) {
+    ZKM_API_BEGIN
+    if (!c || !columns || !out || !ncols || log_n > 30) throw std::runtime_error("zkm_trace_stage_columns: bad argument");
+    for (size_t i = 0; i < ncols; i++)
+        if (!columns[i]) throw std::runtime_error("zkm_trace_stage_columns: null column pointer");
+    const size_t n = (size_t)1 << log_n;
+    zkm_staged* s = stage_begin(c, ncols * n, canonical);
+    try {
+        for (size_t i = 0; i < ncols; i++)
+            ZKM_HIP_CHECK(hipMemcpyAsync(s->dev + i * n, columns[i], n * sizeof(gl_t), hipMemcpyHostToDevice, ((i / 8) & 1) ? c->copy_stream2 : c->copy_stream));
+        stage_end(s);
+    } catch (...) {
+        stage_abort(s);
+        throw;
+    }
+    *out = s;
+    ZKM_API_END(err)
+}
+// The device matrix, ordered behind its upload on the context's compute stream (a device-side wait: the host does not block); the
+// first call also canonicalises words the caller did not vouch for.
+const uint64_t* zkm_staged_ptr(zkm_staged* s) {
+    if (!s) return nullptr;
+    zkm_ctx* c = s->ctx;
+    if (!s->joined) {
+        (void)hipSetDevice(c->device);
+        if (hipStreamWaitEvent(c->stream, s->done[0], 0) != hipSuccess || hipStreamWaitEvent(c->stream, s->done[1], 0) != hipSuccess) return nullptr;
+        try {
+            if (!s->canonical) zkm_launch_canon(c, s->dev, s->words);
+        } catch (...) {
+            return nullptr;
+        }
+        s->joined = true;
+    }
+    return s->dev;
+}
+// host-side: has the upload finished (1), is it still in flight (0)?  `wait` != 0 blocks until it has.
+int zkm_staged_ready(zkm_staged* s, int wait) {
+    if (!s) return 1;
+    (void)hipSetDevice(s->ctx->device);
+    for (hipEvent_t e : s->done) {
+        if (wait) {
+            if (hipEventSynchronize(e) != hipSuccess) return -1;
+        } else {
+            const hipError_t q = hipEventQuery(e);
+            if (q == hipErrorNotReady) return 0;
+            if (q != hipSuccess) return -1;
+        }
+    }
+    return 1;
+}
+void zkm_staged_free(zkm_staged* s) {
+    if (!s) return;
+    zkm_ctx* c = s->ctx;
+    (void)hipSetDevice(c->device);
+    // the host source may go away after this returns, and the block goes back to an allocator whose blocks are reused by later work of
+    // the COMPUTE stream only: the uploads must have landed
+    (void)hipEventSynchronize(s->done[0]);
+    (void)hipEventSynchronize(s->done[1]);
+    c->release(s->dev);
+    c->event_pool.push_back(s->done[0]);
+    c->event_pool.push_back(s->done[1]);
+    delete s;
 }
 
 // ------------------------------------------------------------------ profiling

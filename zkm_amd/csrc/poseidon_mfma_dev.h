@@ -130,8 +130,114 @@ __device__ __forceinline__ void poseidon_mds_add_mfma(uint64_t s[12], int next, 
     }
 }
 
+// ---- the register-lean form of the same layer (round 6): five waves per SIMD
+// The form above keeps all 24 byte planes and two 64-bit accumulators per row (48 registers) next to the 16-register tuple: 126 registers,
+// four waves per SIMD.  This one keeps ONE 64-bit sum T and ONE 32-bit sum Y per row (36 registers) and transposes a half at a time:
+//     M s + c  ==  T + 2^48 Y,      T = t0 + X + 2^16 Z + 2^32 (D4 + 2^8 D5),   Y = y0 + D6 + 2^8 D7,   X = D0 + 2^8 D1,  Z = D2 + 2^8 D3
+// with D_b the matrix core's result for byte position b (a signed 18-bit number per row), X / Z / Y built with 32-bit shift-adds and only
+// X and Z entering T through a multiply-add.  t0 / y0 hold the round constant in three pieces (low word, bits 32..47 at weight 2^32, bits
+// 48..63 in Y) and the 128 rowsum offsets of their byte positions, so every partial sum is a plain non-negative number: T < 2^57,
+// Y < 2^27.  The fold: 2^48 Y = 2^48 (Y mod 2^16) + 2^64 (Y >> 16) == 2^48 (Y mod 2^16) + EPS (Y >> 16).
+struct poseidon_mdsc2_t { uint64_t t0[31][12]; uint32_t y0[31][12]; };
+constexpr poseidon_mdsc2_t poseidon_make_mdsc2() {
+    poseidon_mdsc2_t t{};
+    for (int r = 0; r < 31; r++)
+        for (int w = 0; w < 12; w++) {
+            const uint64_t c = r < 30 ? pc_cx::ZKM_POSEIDON_RC[r * 12 + w] : 0;
+            const uint64_t off = (uint64_t)(w == 0 ? 128 * 264 : 128 * 256);   // 128 x rowsum: 256, + 8 on row 0
+            t.t0[r][w] = (c & 0xFFFFFFFFull) + off * 0x01010101ull + ((((c >> 32) & 0xFFFFull) + off * 0x0101ull) << 32);
+            t.y0[r][w] = (uint32_t)((c >> 48) + off * 0x0101ull);
+        }
+    return t;
+}
+static __device__ __constant__ const poseidon_mdsc2_t ZKM_POSEIDON_MDSC2 = poseidon_make_mdsc2();
+
+// T + 2^48 Y -> loose, for T < 2^57, Y < 2^27 (carry of the high-word add as a VALUE, like poseidon_fold)
+__device__ __forceinline__ uint64_t poseidon_fold_ty(uint64_t T, uint32_t Y) {
+    const uint64_t t = (uint64_t)(Y >> 16) * 0xFFFFFFFFu + T;             // < 2^57 + 2^43: cannot wrap
+    uint32_t rhi, wrap;
+    uint64_t carry;
+    asm("v_add_co_u32_e64 %0, %1, %3, %4\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, -1, %1"
+        : "=&v"(rhi), "=&s"(carry), "=v"(wrap)
+        : "v"((uint32_t)(t >> 32)), "v"(Y << 16));
+    // a carry means rhi wrapped below 2^26: adding EPS cannot wrap again
+    return (((uint64_t)rhi << 32) | (uint32_t)t) + wrap;
+}
+
+__device__ __forceinline__ void poseidon_mds_add_mfma_lean(uint64_t s[12], int next, const zkm_v4i A) {
+    const uint64_t* t0 = ZKM_POSEIDON_MDSC2.t0[next];
+    const uint32_t* y0 = ZKM_POSEIDON_MDSC2.y0[next];
+    const zkm_v16i zero = {0};
+    int m16 = 1 << 16, one = 1;
+    POSEIDON_OPAQUE(m16);
+    POSEIDON_OPAQUE(one);
+    // every partial sum is a 32-bit register until a row is finished: U = D4 + 2^8 D5 and Y = y0 + D6 + 2^8 D7 from the high halves first
+    // (the low halves of the state wait in their registers), then X = D0 + 2^8 D1 and Z = D2 + 2^8 D3, and row by row
+    // T = t0 + X + 2^16 Z + 2^32 U, fold(T, Y)
+    uint32_t U[12], Y[12];
+    {
+        uint32_t P[3][4];
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            uint32_t hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) hi[k] = (uint32_t)(s[4 * g + k] >> 32);
+            poseidon_transpose4(hi, P[g]);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const zkm_v4i B = {(int)(P[0][b] ^ 0x80808080u), (int)(P[1][b] ^ 0x80808080u), (int)(P[2][b] ^ 0x80808080u), 0};
+            const zkm_v16i D = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 12; r++) {
+                if (b == 0) U[r] = (uint32_t)D[r];
+                else if (b == 1) U[r] += (uint32_t)D[r] << 8;
+                else if (b == 2) Y[r] = y0[r] + (uint32_t)D[r];
+                else Y[r] += (uint32_t)D[r] << 8;
+            }
+            POSEIDON_SCHED_FENCE();   // one result tuple live at a time
+        }
+    }
+    {
+        uint32_t P[3][4];
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            uint32_t lo[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) lo[k] = (uint32_t)s[4 * g + k];
+            poseidon_transpose4(lo, P[g]);
+        }
+        uint32_t X[12], Z[12];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const zkm_v4i B = {(int)(P[0][b] ^ 0x80808080u), (int)(P[1][b] ^ 0x80808080u), (int)(P[2][b] ^ 0x80808080u), 0};
+            const zkm_v16i D = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 12; r++) {
+                if (b == 0) X[r] = (uint32_t)D[r];
+                else if (b == 1) X[r] += (uint32_t)D[r] << 8;
+                else if (b == 2) Z[r] = (uint32_t)D[r];
+                else {
+                    Z[r] += (uint32_t)D[r] << 8;
+                    int64_t acc = (int64_t)t0[r] + (int64_t)(int32_t)X[r] * one;
+                    acc += (int64_t)(int32_t)Z[r] * m16;
+                    const uint64_t T = ((uint64_t)((uint32_t)((uint64_t)acc >> 32) + U[r]) << 32) | (uint32_t)acc;
+                    s[r] = poseidon_fold_ty(T, Y[r]);
+                }
+            }
+            POSEIDON_SCHED_FENCE();
+        }
+    }
+}
+
+#ifndef ZKM_MFMA_LEAN
+#define ZKM_MFMA_LEAN 0
+#endif
 struct poseidon_mds_mfma {
     zkm_v4i A;
-    __device__ __forceinline__ void layer(uint64_t s[12], int next) const { poseidon_mds_add_mfma(s, next, A); }
+    __device__ __forceinline__ void layer(uint64_t s[12], int next) const {
+        if (ZKM_MFMA_LEAN) poseidon_mds_add_mfma_lean(s, next, A);
+        else poseidon_mds_add_mfma(s, next, A);
+    }
 };
 #endif

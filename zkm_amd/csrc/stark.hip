@@ -1999,7 +1999,7 @@ int zkm_check_constraints(zkm_ctx* c, int table_id, const zkm_stark_config* cfg,
         if (table_id < 0 || table_id >= 12) throw std::runtime_error("zkm_check_constraints: unknown table id");
         // a table with lookups of its own (Memory, Arithmetic) takes its challenges from the caller: none given is an error here, not a
         // null dereference on the host
-        if (!lookup_challenges && zkm_num_lookup_columns(table_id, cfg)) throw std::runtime_error("zkm_check_constraints: this table has lookups of its own: lookup_challenges is null");
+        if (!lookup_challenges && zkm_num_lookup_columns(table_id, cfg)) throw std::runtime_error("zkm_check_constraints: this table has lookups of its own: lookup challenges are required");
         if (nalphas < 1 || nalphas > 2) throw std::runtime_error("zkm_check_constraints: 1 or 2 challenges supported");
         for (size_t a = 0; a < nalphas; a++)
             if (alphas[a] >= GL_P) throw std::runtime_error("zkm_check_constraints: non-canonical challenge");

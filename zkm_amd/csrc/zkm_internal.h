@@ -59,6 +59,7 @@ struct zkm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host -> device ingest, overlapped with the compute stream (created on first use)
+    hipStream_t copy_stream2 = nullptr; // second upload stream of staged traces (zkm_trace_stage: alternate pieces, two copy engines)
     size_t ingest_chunk_cols = 32;      // columns per ingest chunk (0 = monolithic upload)           } zkm_ctx_set_tuning
     size_t keccak_parts_max_points = (size_t)1 << 15;   // k_quotient_keccak_parts up to this many points  }
     size_t fri_fused_division_min = ~(size_t)0;         // k_seg_scan_final from this many coefficients (default: never -- since the
@@ -111,6 +112,7 @@ struct zkm_ctx {
     void release(void* p);
     void trim_self();  // hipFree every cached (not live) block of THIS allocator (any thread: used by a relative's out-of-memory retry)
     void trim();       // ... and of the lanes; only between calls
+    void drop_copy_streams();   // trim(): the idle upload streams give their hardware queues back
     void shrink_down();   // the pinned download area back to its base size (trim(): between calls, owner's thread)
     void ensure_twiddles(unsigned log_n);
     const gl_t* pow_table(uint64_t shift, unsigned log_n);  // lo: 2^ceil(log_n/2) entries, then hi
