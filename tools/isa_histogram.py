@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def compile_asm(src, arch="gfx950"):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=" + arch, "-Wno-unused-function", "--cuda-device-only", "-S", "-o", out, src]
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=" + arch, "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "--cuda-device-only", "-S", "-o", out, src]   # (the flags of csrc/Makefile)
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     text = open(out).read()
     os.unlink(out)

@@ -64,7 +64,13 @@ __device__ __forceinline__ void merkle_leaves_body(const gl_t* __restrict__ lde,
     lde += (size_t)blockIdx.z * lde_seg;
     digests += (size_t)blockIdx.z * dig_seg;
     typename std::conditional<MFMA, poseidon_mds_mfma, poseidon_mds_valu>::type mds;
-    if constexpr (MFMA) mds.A = poseidon_mfma_operand();
+    if constexpr (MFMA) {
+        mds.A = poseidon_mfma_operand();
+#if ZKM_MFMA_PARK
+        __shared__ uint32_t park[24 * ZKM_MFMA_PARK_STRIDE];
+        mds.park = park + threadIdx.x;
+#endif
+    }
     uint64_t s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
@@ -103,10 +109,9 @@ __global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ 
                                                        gl_t* __restrict__ digests, size_t lde_seg, size_t dig_seg) {
     merkle_leaves_body<false>(lde, nrows, ncols, col_stride, digests, lde_seg, dig_seg);
 }
-// four waves per SIMD (<= 128 registers): the layer holds 24 byte planes, a 16-register accumulator tuple and up to 48 registers of
-// half-word sums next to the operand of the matrix and the prefetched chunk
+// five waves per SIMD (93 registers) with the layer's high-half sums parked in LDS, four (110 registers) without (poseidon_mfma_dev.h)
 #ifndef ZKM_LEAF_MFMA_WAVES
-#define ZKM_LEAF_MFMA_WAVES 4
+#define ZKM_LEAF_MFMA_WAVES (ZKM_MFMA_PARK ? 5 : 4)
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZKM_LEAF_MFMA_WAVES, ZKM_LEAF_MFMA_WAVES)))
 void k_merkle_leaves_mfma(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests, size_t lde_seg,

@@ -8,21 +8,29 @@
 //
 //   per layer:  48 v_perm (4x4 byte transposes: byte b of words 4g..4g+3 -> one register) + 24 v_xor (byte - 128: the operands are int8)
 //               8 MFMAs (one per byte position; the matrix pipe, not the vector ALU)
-//               96 multiply-adds (four signed digits of weight 2^0, 2^8, 2^16, 2^24 per half-word) + the fold of poseidon_mds_add
-//   instead of 288 multiply-adds + the fold.  The accumulators start at half of the round constant + 128 rowsum 0x01010101, which makes each
-//   half the plain unsigned byte sum although the MFMA sees byte - 128 (tables below, derived at compile time from the round constants).
+//               per row 5 shift-adds / adds on 32-bit partial sums, 2 multiply-adds and a 6-instruction fold
+//   instead of 288 multiply-adds + the fold (poseidon_mds_add).  Round 5's form (96 multiply-adds into two 64-bit accumulators per row, all 24
+//   byte planes up front) needed 126 registers = four waves per SIMD; round 6's keeps 32-bit partial sums, transposes a half at a time and
+//   parks the high-half sums in LDS while the low half is worked on: 93 registers, five waves (profiles/r06_mfma_lean.txt).
 //
 // MFMA ignores EXEC: a kernel that uses this keeps all lanes of its waves alive (no early return for the tail; clamp the index instead).
 // The fused partial-round layers (M^3: three int8 digit planes) and the 4-row last layer stay on the vector ALU (poseidon_dev.h).
 #pragma once
 #include "poseidon_dev.h"
 
+// ZKM_MFMA_PARK: the high-half sums of the layer wait in LDS (24 words per lane, stride ZKM_MFMA_PARK_STRIDE = the workgroup size) while the
+// low half is worked on: the kernel then fits the 96 registers of five waves per SIMD (0: everything in registers, 110 of them, four waves)
+#ifndef ZKM_MFMA_PARK
+#define ZKM_MFMA_PARK 1
+#endif
+#define ZKM_MFMA_PARK_STRIDE 256
 typedef int zkm_v4i __attribute__((ext_vector_type(4)));
 typedef int zkm_v16i __attribute__((ext_vector_type(16)));
 #if !defined(__HIP_DEVICE_COMPILE__)
 // host pass of a .hip file: the names exist (kernels are parsed for the host too), nothing runs
 struct poseidon_mds_mfma {
     zkm_v4i A;
+    uint32_t* park = nullptr;
     GL_HD void layer(uint64_t s[12], int next) const { poseidon_mds_valu{}.layer(s, next); }
 };
 GL_HD zkm_v4i poseidon_mfma_operand() { return zkm_v4i{0, 0, 0, 0}; }
@@ -35,20 +43,6 @@ namespace pc_cx {   // the round constants once more, as constant expressions
 #undef ZKM_CONST
 #undef ZKM_CONSTEXPR
 }  // namespace pc_cx
-struct poseidon_mdsc_t { uint64_t v[31][12][2]; };   // [constants of round r; 30 = none][word][low / high half]
-constexpr poseidon_mdsc_t poseidon_make_mdsc() {
-    poseidon_mdsc_t t{};
-    for (int r = 0; r < 31; r++)
-        for (int w = 0; w < 12; w++) {
-            const uint64_t c = r < 30 ? pc_cx::ZKM_POSEIDON_RC[r * 12 + w] : 0;
-            const uint64_t off = (uint64_t)(w == 0 ? 128 * 264 : 128 * 256) * 0x01010101ull;   // rowsum: 256, + 8 on row 0
-            t.v[r][w][0] = (c & 0xFFFFFFFFull) + off;
-            t.v[r][w][1] = (c >> 32) + off;
-        }
-    return t;
-}
-static __device__ __constant__ const poseidon_mdsc_t ZKM_POSEIDON_MDSC = poseidon_make_mdsc();
-
 // A operand of this lane: lane l = (i = l & 31, h = l >> 5) holds row i of A for the k-block h.  Row i belongs to half (i >> 2) & 1 and
 // is register reg = (i & 3) + 4 (i >> 3) of that half's D tuple; registers 0..11 are the state words, 12..15 unused.
 __device__ __forceinline__ zkm_v4i poseidon_mfma_operand() {
@@ -85,59 +79,11 @@ __device__ __forceinline__ void poseidon_transpose4(const uint32_t in[4], uint32
 }
 
 // s <- M s + (constants of round `next`; 30 = none).  In: loose words.  Out: loose words.
-__device__ __forceinline__ void poseidon_mds_add_mfma(uint64_t s[12], int next, const zkm_v4i A) {
-    const uint64_t (*cc)[2] = ZKM_POSEIDON_MDSC.v[next];
-    uint32_t T[3][8];
-#pragma unroll
-    for (int g = 0; g < 3; g++) {
-        uint32_t lo[4], hi[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            lo[k] = (uint32_t)s[4 * g + k];
-            hi[k] = (uint32_t)(s[4 * g + k] >> 32);
-        }
-        poseidon_transpose4(lo, &T[g][0]);
-        poseidon_transpose4(hi, &T[g][4]);
-    }
-    int m8 = 1 << 8, m16 = 1 << 16, m24 = 1 << 24;   // (kept in SGPRs: as literals they become 64-bit shifts and adds)
-    POSEIDON_OPAQUE(m8);
-    POSEIDON_OPAQUE(m16);
-    POSEIDON_OPAQUE(m24);
-    const zkm_v16i zero = {0};
-    int64_t al[12], ah[12];
-    // High halves first (byte positions 4..7), then the low ones: a word is folded as soon as its last digit has arrived.  An
-    // accumulator starts in the multiply-add of its first digit, from the scalar pair of its constant: nothing is live before.
-#pragma unroll
-    for (int bb = 0; bb < 8; bb++) {
-        const int b = bb ^ 4;   // 4, 5, 6, 7, 0, 1, 2, 3
-        const zkm_v4i B = {(int)(T[0][b] ^ 0x80808080u), (int)(T[1][b] ^ 0x80808080u), (int)(T[2][b] ^ 0x80808080u), 0};
-        zkm_v16i D = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, zero, 0, 0, 0);
-        // the first consumers of D_4 and D_0 are asm statements: nothing pads the MFMA's latency (8 passes) for those
-        if ((b & 3) == 0) asm volatile("s_nop 15" : "+v"(D));
-        const int mult = (b & 3) == 1 ? m8 : (b & 3) == 2 ? m16 : m24;
-#pragma unroll
-        for (int r = 0; r < 12; r++) {
-            if ((b & 3) == 0) {
-                int64_t acc;
-                uint64_t unused;
-                asm("v_mad_i64_i32 %0, %1, %2, 1, %3" : "=&v"(acc), "=&s"(unused) : "v"(D[r]), "s"(cc[r][b >> 2]));
-                if (b == 4) ah[r] = acc; else al[r] = acc;
-            } else if (b > 4) ah[r] += (int64_t)D[r] * mult;
-            else al[r] += (int64_t)D[r] * mult;
-            if (b == 3) s[r] = poseidon_fold((uint64_t)al[r], (uint64_t)ah[r]);
-        }
-        POSEIDON_SCHED_FENCE();   // one accumulator tuple live at a time
-    }
-}
-
-// ---- the register-lean form of the same layer (round 6): five waves per SIMD
-// The form above keeps all 24 byte planes and two 64-bit accumulators per row (48 registers) next to the 16-register tuple: 126 registers,
-// four waves per SIMD.  This one keeps ONE 64-bit sum T and ONE 32-bit sum Y per row (36 registers) and transposes a half at a time:
-//     M s + c  ==  T + 2^48 Y,      T = t0 + X + 2^16 Z + 2^32 (D4 + 2^8 D5),   Y = y0 + D6 + 2^8 D7,   X = D0 + 2^8 D1,  Z = D2 + 2^8 D3
-// with D_b the matrix core's result for byte position b (a signed 18-bit number per row), X / Z / Y built with 32-bit shift-adds and only
-// X and Z entering T through a multiply-add.  t0 / y0 hold the round constant in three pieces (low word, bits 32..47 at weight 2^32, bits
-// 48..63 in Y) and the 128 rowsum offsets of their byte positions, so every partial sum is a plain non-negative number: T < 2^57,
-// Y < 2^27.  The fold: 2^48 Y = 2^48 (Y mod 2^16) + 2^64 (Y >> 16) == 2^48 (Y mod 2^16) + EPS (Y >> 16).
+// ONE 64-bit sum T and ONE 32-bit sum Y per row, built from 32-bit pieces:
+//     M s + c  ==  T + 2^48 Y,      T = t0 + X + 2^16 Z + 2^32 U,   X = D0 + 2^8 D1,  Z = D2 + 2^8 D3,  U = D4 + 2^8 D5,   Y = y0 + D6 + 2^8 D7
+// with D_b the matrix core's result for byte position b (a signed 18-bit number per row).  t0 / y0 hold the round constant in three pieces
+// (low word, bits 32..47 at weight 2^32, bits 48..63 in Y) and the 128 rowsum offsets of their byte positions, so every partial sum is a
+// plain non-negative number: T < 2^57, Y < 2^27.  The fold: 2^48 Y = 2^48 (Y mod 2^16) + 2^64 (Y >> 16) == 2^48 (Y mod 2^16) + EPS (Y >> 16).
 struct poseidon_mdsc2_t { uint64_t t0[31][12]; uint32_t y0[31][12]; };
 constexpr poseidon_mdsc2_t poseidon_make_mdsc2() {
     poseidon_mdsc2_t t{};
@@ -164,13 +110,15 @@ __device__ __forceinline__ uint64_t poseidon_fold_ty(uint64_t T, uint32_t Y) {
     return (((uint64_t)rhi << 32) | (uint32_t)t) + wrap;
 }
 
-__device__ __forceinline__ void poseidon_mds_add_mfma_lean(uint64_t s[12], int next, const zkm_v4i A) {
+// (park: 24 words of LDS per lane, stride ZKM_MFMA_PARK_STRIDE -- the high-half sums U and Y wait there while the low half is worked on, so
+// that the layer fits the 96 registers of five waves per SIMD; LDS instructions are not vector-ALU instructions)
+template <bool PARK>
+__device__ __forceinline__ void poseidon_mds_add_mfma(uint64_t s[12], int next, const zkm_v4i A, uint32_t* park) {
     const uint64_t* t0 = ZKM_POSEIDON_MDSC2.t0[next];
     const uint32_t* y0 = ZKM_POSEIDON_MDSC2.y0[next];
     const zkm_v16i zero = {0};
-    int m16 = 1 << 16, one = 1;
+    int m16 = 1 << 16;
     POSEIDON_OPAQUE(m16);
-    POSEIDON_OPAQUE(one);
     // every partial sum is a 32-bit register until a row is finished: U = D4 + 2^8 D5 and Y = y0 + D6 + 2^8 D7 from the high halves first
     // (the low halves of the state wait in their registers), then X = D0 + 2^8 D1 and Z = D2 + 2^8 D3, and row by row
     // T = t0 + X + 2^16 Z + 2^32 U, fold(T, Y)
@@ -198,6 +146,14 @@ __device__ __forceinline__ void poseidon_mds_add_mfma_lean(uint64_t s[12], int n
             POSEIDON_SCHED_FENCE();   // one result tuple live at a time
         }
     }
+    if constexpr (PARK) {
+#pragma unroll
+        for (int r = 0; r < 12; r++) {
+            park[r * ZKM_MFMA_PARK_STRIDE] = U[r];
+            park[(12 + r) * ZKM_MFMA_PARK_STRIDE] = Y[r];
+        }
+        POSEIDON_SCHED_FENCE();
+    }
     {
         uint32_t P[3][4];
 #pragma unroll
@@ -219,10 +175,16 @@ __device__ __forceinline__ void poseidon_mds_add_mfma_lean(uint64_t s[12], int n
                 else if (b == 2) Z[r] = (uint32_t)D[r];
                 else {
                     Z[r] += (uint32_t)D[r] << 8;
-                    int64_t acc = (int64_t)t0[r] + (int64_t)(int32_t)X[r] * one;
+                    // (t0 + X as ONE multiply-add with the inline constant 1 and the scalar pair of t0: a VALU instruction of this ISA reads
+                    // one scalar operand, so with the multiplier in an SGPR as well the compiler copies t0 into a register pair first)
+                    int64_t acc;
+                    uint64_t unused;
+                    asm("v_mad_i64_i32 %0, %1, %2, 1, %3" : "=&v"(acc), "=&s"(unused) : "v"(X[r]), "s"(t0[r]));
                     acc += (int64_t)(int32_t)Z[r] * m16;
-                    const uint64_t T = ((uint64_t)((uint32_t)((uint64_t)acc >> 32) + U[r]) << 32) | (uint32_t)acc;
-                    s[r] = poseidon_fold_ty(T, Y[r]);
+                    const uint32_t u = PARK ? park[r * ZKM_MFMA_PARK_STRIDE] : U[r], y = PARK ? park[(12 + r) * ZKM_MFMA_PARK_STRIDE] : Y[r];
+                    const uint64_t T = ((uint64_t)((uint32_t)((uint64_t)acc >> 32) + u) << 32) | (uint32_t)acc;
+                    s[r] = poseidon_fold_ty(T, y);
+                    if ((r & 1) == 1) POSEIDON_SCHED_FENCE();   // (two rows' temporaries at a time)
                 }
             }
             POSEIDON_SCHED_FENCE();
@@ -230,14 +192,11 @@ __device__ __forceinline__ void poseidon_mds_add_mfma_lean(uint64_t s[12], int n
     }
 }
 
-#ifndef ZKM_MFMA_LEAN
-#define ZKM_MFMA_LEAN 0
-#endif
 struct poseidon_mds_mfma {
     zkm_v4i A;
+    uint32_t* park = nullptr;
     __device__ __forceinline__ void layer(uint64_t s[12], int next) const {
-        if (ZKM_MFMA_LEAN) poseidon_mds_add_mfma_lean(s, next, A);
-        else poseidon_mds_add_mfma(s, next, A);
+        poseidon_mds_add_mfma<(ZKM_MFMA_PARK != 0)>(s, next, A, park);
     }
 };
 #endif
