@@ -16,6 +16,11 @@
 #include "hash_constants_dev.h"
 #include "zkm_internal.h"
 
+// five waves per SIMD (93 registers) with the layer's high-half sums parked in LDS, four (110 registers) without (poseidon_mfma_dev.h)
+#ifndef ZKM_LEAF_MFMA_WAVES
+#define ZKM_LEAF_MFMA_WAVES (ZKM_MFMA_PARK ? 5 : 4)
+#endif
+
 // The latency forms of the permutation (16 lanes or a quad per hash) exist for launches that are a CHAIN of dependent permutations
 // with too few hashes to fill the machine: the top of every tree, the leaves of short tables, small FRI layers.  When such a launch
 // shares the GPU with throughput kernels (the commit lanes of the same segment, other contexts), its few waves compete for issue
@@ -109,10 +114,6 @@ __global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ 
                                                        gl_t* __restrict__ digests, size_t lde_seg, size_t dig_seg) {
     merkle_leaves_body<false>(lde, nrows, ncols, col_stride, digests, lde_seg, dig_seg);
 }
-// five waves per SIMD (93 registers) with the layer's high-half sums parked in LDS, four (110 registers) without (poseidon_mfma_dev.h)
-#ifndef ZKM_LEAF_MFMA_WAVES
-#define ZKM_LEAF_MFMA_WAVES (ZKM_MFMA_PARK ? 5 : 4)
-#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZKM_LEAF_MFMA_WAVES, ZKM_LEAF_MFMA_WAVES)))
 void k_merkle_leaves_mfma(const gl_t* __restrict__ lde, size_t nrows, size_t ncols, size_t col_stride, gl_t* __restrict__ digests, size_t lde_seg,
                           size_t dig_seg) {
@@ -199,11 +200,23 @@ void zkm_launch_merkle_leaves_chunk(zkm_ctx* c, const gl_t* lde, size_t nrows, s
 }
 
 // leaves of a FRI layer: leaf k = arity consecutive F2 values (bit-reversed order), flattened c0,c1,c0,c1..
-__global__ __launch_bounds__(256) void k_merkle_leaves_ext(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1,
-                                                           size_t nleaves, unsigned arity, gl_t* __restrict__ digests, size_t val_seg, size_t dig_seg) {
+// (MFMA: the matrix-core MDS layer of the leaf kernel -- MFMA ignores EXEC: lanes past the last leaf hash the last leaf and do not store)
+template <bool MFMA>
+__device__ __forceinline__ void merkle_leaves_ext_body(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nleaves, unsigned arity,
+                                                       gl_t* __restrict__ digests, size_t val_seg, size_t dig_seg) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nleaves) return;
+    const bool live = k < nleaves;
+    if (!MFMA && !live) return;
+    if (!live) k = nleaves - 1;
     c0 += (size_t)blockIdx.z * val_seg; c1 += (size_t)blockIdx.z * val_seg; digests += (size_t)blockIdx.z * dig_seg;
+    typename std::conditional<MFMA, poseidon_mds_mfma, poseidon_mds_valu>::type mds;
+    if constexpr (MFMA) {
+        mds.A = poseidon_mfma_operand();
+#if ZKM_MFMA_PARK
+        __shared__ uint32_t park[24 * ZKM_MFMA_PARK_STRIDE];
+        mds.park = park + threadIdx.x;
+#endif
+    }
     uint64_t s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
@@ -216,11 +229,21 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_ext(const gl_t* __restric
             s[2 * i] = a[e + i];
             s[2 * i + 1] = b[e + i];
         }
-        poseidon_permute_out(s, e + 4 < arity ? POSEIDON_OUT_CAPACITY : POSEIDON_OUT_DIGEST);
+        poseidon_permute_out_t(s, e + 4 < arity ? POSEIDON_OUT_CAPACITY : POSEIDON_OUT_DIGEST, mds);
     }
+    if (!live) return;
     uint64_t* d = digests + 4 * k;
     *reinterpret_cast<ulonglong2*>(d) = make_ulonglong2(s[0], s[1]);
     *reinterpret_cast<ulonglong2*>(d + 2) = make_ulonglong2(s[2], s[3]);
+}
+__global__ __launch_bounds__(256) void k_merkle_leaves_ext(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1,
+                                                           size_t nleaves, unsigned arity, gl_t* __restrict__ digests, size_t val_seg, size_t dig_seg) {
+    merkle_leaves_ext_body<false>(c0, c1, nleaves, arity, digests, val_seg, dig_seg);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZKM_LEAF_MFMA_WAVES, ZKM_LEAF_MFMA_WAVES)))
+void k_merkle_leaves_ext_mfma(const gl_t* __restrict__ c0, const gl_t* __restrict__ c1, size_t nleaves, unsigned arity, gl_t* __restrict__ digests,
+                              size_t val_seg, size_t dig_seg) {
+    merkle_leaves_ext_body<true>(c0, c1, nleaves, arity, digests, val_seg, dig_seg);
 }
 
 // ------------------------------------------------------------------ Merkle inner levels, fused (K5)
@@ -273,7 +296,6 @@ __global__ __launch_bounds__(256) void k_merkle_fused(merkle_fused_args p) {
         if (tid >= (width >> 1)) return;
     }
 }
-
 // Small levels, fused: a workgroup (256 threads = 16 hash slots of 16 lanes) owns a subtree with 2^J children (J <= 6) and climbs
 // its J levels through LDS -- ceil(2^(J-k) / 16) rounds of wide permutations at level k -- instead of one launch per level: the top
 // of a tree is a chain of dependent permutations (one wide permutation ~10 us), and every launch boundary added its gap to it.
@@ -467,6 +489,9 @@ void zkm_launch_merkle_leaves_ext(zkm_ctx* c, const gl_t* c0, const gl_t* c1, si
     else if (hashes <= c->quad_max_hashes)   // small layers: one hash per quad of lanes
         hipLaunchKernelGGL(k_merkle_leaves_ext_quad, dim3((nleaves * 4 + 255) / 256, 1, z), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests,
                            val_seg, dig_seg);
+    else if (c->leaf_mfma)     // (the leaf kernel's matrix-core layer: layer 0 of a 2^22-row FRI proof 1.70 -> 1.62 ms)
+        hipLaunchKernelGGL(k_merkle_leaves_ext_mfma, dim3((nleaves + 255) / 256, 1, z), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests, val_seg,
+                           dig_seg);
     else
         hipLaunchKernelGGL(k_merkle_leaves_ext, dim3((nleaves + 255) / 256, 1, z), dim3(256), 0, c->stream, c0, c1, nleaves, arity, digests, val_seg,
                            dig_seg);
@@ -635,6 +660,8 @@ void zkm_merkle_build_inner(zkm_ctx* c, gl_t* digests, const std::vector<size_t>
             a.children = digests + level_off[l];
             a.levels = rem < 3 ? rem : 3;
             for (unsigned k = 0; k < a.levels; k++) a.parents[k] = digests + level_off[l + 1 + k];
+            // (the matrix-core layer was measured here too, rounds 5 and 6: the 24 KB it parks in LDS next to this kernel's 16 KB leave four
+            // workgroups per CU -- merkle_compress 1.59 -> 1.72 ms per 262 x 2^20 commitment, lock-step segments 108 -> 106/s: not adopted)
             hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(((size_t)1 << log_p1) / 256), 1, z), dim3(256), 0, c->stream, a);
             l += a.levels;
         } else if (h1 <= c->wide_max_hashes) {
