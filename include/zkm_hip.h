@@ -56,10 +56,11 @@ void zkm_ctx_trim(zkm_ctx* ctx);
  *                               every tree level of >= 256 parents (the levels below that, a few hundred hashes per tree, keep the
  *                               quad form: the one-lane kernel works on blocks of 256 parents); a GPU shared by many contexts
  *                               proving small segments may prefer throughput -- measured in profiles/r03_hw_queues.txt
- *   "leaf_mfma"                 one-lane-per-leaf hashing with the dense MDS layers of the FULL rounds on the matrix core
- *                               (v_mfma_i32_32x32x32_i8 with a block-diagonal matrix operand: every lane gets M times its own state;
- *                               csrc/poseidon_mfma_dev.h) and the s-boxes / partial rounds on the vector ALU (default 1: leaf hashing
- *                               40.9 -> 39.8 ms at 262 x 2^22, +1.6 % proofs/s); 0: every layer as 32-bit multiply-adds
+ *   "leaf_mfma"                 one-lane-per-leaf hashing (trace / auxiliary leaves, FRI layer leaves) with the dense MDS layers of the FULL
+ *                               rounds on the matrix core (v_mfma_i32_32x32x32_i8 with a block-diagonal matrix operand: every lane gets M
+ *                               times its own state; csrc/poseidon_mfma_dev.h: 32-bit partial sums, 93 registers, five waves per SIMD) and the
+ *                               s-boxes / partial rounds on the vector ALU (default 1: leaf hashing 40.9 -> 39.4 ms at 262 x 2^22, +2 %
+ *                               proofs/s and lock-step segments/s); 0: every layer as 32-bit multiply-adds
  *   "small_ntt"                 transforms of 2^9 .. 2^13 points (inverse transforms and coset-LDE blocks of short tables, quotient
  *                               chunks, FRI layers) in ONE launch, a column per workgroup (default 1); 0: two strided passes
  *   "tree_tail"                 Merkle trees of up to 2^15 leaves built in ONE launch that also delivers the cap to the host (default 1);
