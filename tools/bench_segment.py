@@ -158,12 +158,49 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, 
         c.synchronize()
     start = threading.Barrier(nctx + 1)
 
-    def work(c, sg):
+    staged = host == 2      # the NEXT call's traces staged behind the current call (zkm_trace_stage: cross-call pipelining of the uploads)
+
+    def stage_call(c, sg):
+        from zkm_amd import tables as T
+        out = []
+        for bufs, logs, pub in sg:
+            out.append(([c.stage_trace(bufs[t], T.WIDTH[T.TABLE_ENUM_ORDER[t]], logs[t]) for t in range(12)], logs, pub))
+        return out
+
+    def free_call(call):
+        for sts, _, _ in call:
+            for st in sts:
+                st.free()
+    if staged:
+        for c, sg in zip(ctxs, segs):              # warm-up of this path: two calls' worth of staged blocks alive at once
+            a, b = stage_call(c, sg), stage_call(c, sg)
+            c.prove_segments(a)
+            c.prove_segments(b)
+            free_call(a)
+            free_call(b)
+            c.synchronize()
+    first = [stage_call(c, sg) for c, sg in zip(ctxs, segs)] if staged else None
+    if staged:
+        for call in first:
+            for sts, _, _ in call:
+                for st in sts:
+                    st.ready(wait=True)
+
+    def work(c, sg, k=0):
         start.wait()
-        for _ in range(reps):
-            c.prove_segments(sg)
+        if staged:                                  # every call of the timed region stages exactly one call (the last one's is waited for)
+            cur = first[k]
+            for _ in range(reps):
+                nxt = stage_call(c, sg)
+                c.prove_segments(cur)
+                free_call(cur)
+                cur = nxt
+            free_call(cur)
+        else:
+            for _ in range(reps):
+                c.prove_segments(sg)
         c.synchronize()
-    th = [threading.Thread(target=work, args=(c, sg)) for c, sg in zip(ctxs, segs)]
+    th = [threading.Thread(target=work, args=(c, sg, k)) for k, (c, sg) in enumerate(zip(ctxs, segs))]
     for t in th:
         t.start()
     start.wait()
@@ -189,7 +226,7 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, 
                 b.free()
         c.close()
     total = nctx * stack * reps
-    return {"contexts": nctx, "segments_per_call": stack, "calls_per_context": reps, "segments_per_s": total / wall, "traces": "pinned host memory" if host else "HBM", "ragged_heights": ragged,
+    return {"contexts": nctx, "segments_per_call": stack, "calls_per_context": reps, "segments_per_s": total / wall, "traces": ("pinned host memory, next call staged behind the current one" if host == 2 else "pinned host memory") if host else "HBM", "ragged_heights": ragged,
             "ms_per_segment_amortised": wall * 1e3 / total, "ms_per_call": wall * 1e3 / reps, "cpu_seconds_per_segment": cpu_s / total,
             "host_cpus_busy": cpu_s / wall, "host_waits": "sleeping" if os.environ.get("ZKM_SLEEPING_WAITS") == "1" else "polling",
             "tuning": tuning or {},

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sweep of zkm_prove_segments on 2^16-cycle twelve-table segments: contexts x segments per call x tunings -> segments/s.
    python tools/sweep_lockstep.py "G,K[,key=value...]" ...     one JSON line per configuration
-   keys: any zkm_ctx_set_tuning key, reps=N, host=1 (traces in pinned host memory), ragged=k, sleeping=1 (blocking-sync waits; last spec only)"""
+   keys: any zkm_ctx_set_tuning key, reps=N, host=1 (traces in pinned host memory, uploaded inside the call) / host=2 (the next call staged behind the current one), ragged=k, sleeping=1 (blocking-sync waits; last spec only)"""
 import json
 import os
 import sys
@@ -23,7 +23,7 @@ for spec in sys.argv[1:]:
         if key == "reps":
             reps = int(v)
         elif key == "host":
-            host = bool(int(v))
+            host = int(v)            # 1: uploads inside the call; 2: the next call's traces staged behind the current call
         elif key == "ragged":
             ragged = int(v)
         elif key == "sleeping":        # host waits that sleep: the device flag is process-wide, so put such a spec LAST

@@ -333,13 +333,13 @@ class _marshal_segments:
         for traces, log_ns, public_values in segments:
             assert len(traces) == 12 and len(log_ns) == 12
             if self.by_columns:
-                k = [[c if isinstance(c, DeviceBuffer) else np.ascontiguousarray(c, dtype=np.uint64) for c in t] for t in traces]
+                k = [[c if isinstance(c, (DeviceBuffer, StagedTrace)) else np.ascontiguousarray(c, dtype=np.uint64) for c in t] for t in traces]
                 cols = [(C.c_void_p * len(t))(*[_data_ptr(c).value for c in t]) for t in k]
                 self.col_arrays.append(cols)
                 self.keep.append(k)
                 self.ptr_arrays.append((C.c_void_p * 12)(*[C.addressof(c) for c in cols]))
             else:
-                k = [t if isinstance(t, DeviceBuffer) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
+                k = [t if isinstance(t, (DeviceBuffer, StagedTrace)) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
                 self.keep.append(k)
                 self.ptr_arrays.append((C.c_void_p * 12)(*[_data_ptr(t).value for t in k]))
             self.log_arrays.append((C.c_uint * 12)(*[int(x) for x in log_ns]))
@@ -815,7 +815,7 @@ class Context:
         assert len(traces) == 12 and len(log_ns) == 12
         if all(isinstance(t, (list, tuple)) for t in traces):
             return self._prove_segment_columns(traces, log_ns, public_values, cfg)
-        keep = [t if isinstance(t, DeviceBuffer) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
+        keep = [t if isinstance(t, (DeviceBuffer, StagedTrace)) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
         ptrs = (C.c_void_p * 12)(*[_data_ptr(t).value for t in keep])
         lg = (C.c_uint * 12)(*[int(x) for x in log_ns])
         pub = np.ascontiguousarray(public_values, dtype=np.uint64)
@@ -841,7 +841,7 @@ class Context:
 
     def _prove_segment_columns(self, traces, log_ns, public_values, cfg):
         """zkm_prove_segment_columns: traces[t] = list of per-column arrays (each its own allocation, like Vec<PolynomialValues<F>>)."""
-        keep = [[c if isinstance(c, DeviceBuffer) else np.ascontiguousarray(c, dtype=np.uint64) for c in t] for t in traces]
+        keep = [[c if isinstance(c, (DeviceBuffer, StagedTrace)) else np.ascontiguousarray(c, dtype=np.uint64) for c in t] for t in traces]
         cols = [(C.c_void_p * len(t))(*[_data_ptr(c).value for c in t]) for t in keep]
         tabs = (C.c_void_p * 12)(*[C.addressof(c) for c in cols])
         lg = (C.c_uint * 12)(*[int(x) for x in log_ns])
@@ -937,7 +937,7 @@ class PolynomialBatch:
     def from_columns(cls, ctx, columns, log_n, values=True, rate_bits=2, cap_height=4):
         """from_values / from_coeffs from one array per column (zkm_batch_commit_columns): the shape of the reference's
         Vec<PolynomialValues<F>> -- nothing is flattened on the host."""
-        keep = [c if isinstance(c, DeviceBuffer) else np.ascontiguousarray(c, dtype=np.uint64) for c in columns]
+        keep = [c if isinstance(c, (DeviceBuffer, StagedTrace)) else np.ascontiguousarray(c, dtype=np.uint64) for c in columns]
         ptrs = (C.c_void_p * len(keep))(*[_data_ptr(c).value for c in keep])
         h = C.c_void_p()
         err = C.c_char_p()

@@ -724,8 +724,10 @@ int zkm_trace_stage(zkm_ctx* c, const uint64_t* values, size_t ncols, unsigned l
     const size_t n = (size_t)1 << log_n;
     zkm_staged* s = stage_begin(c, ncols * n, canonical);
     try {
-        size_t piece = 8;              // columns per copy (67 MB at 2^20 rows): the two streams take alternate pieces; small pieces let the
-                                       // other contexts' copies interleave (4 contexts: 16.3 proofs/s against 15.6 with 32-column pieces)
+        // pieces of >= 64 MB (8 columns at 2^20 rows; a short table is ONE copy): the two streams take alternate pieces; small pieces let
+        // the other contexts' copies interleave (4 contexts at 2^20 rows: 16.3 proofs/s against 15.6 with 268 MB pieces), tiny ones are
+        // all call overhead (a 2431-column table of 2^10 rows in 8-column pieces was 304 copies of 64 KB)
+        size_t piece = std::max<size_t>(8, (((size_t)64 << 20) / (n * sizeof(gl_t)) + 7) / 8 * 8);
         if (const char* e = getenv("ZKM_STAGE_PIECE_COLS")) piece = std::max<size_t>(1, (size_t)atoi(e));   // (measurement aid)
         for (size_t c0 = 0, k = 0; c0 < ncols; c0 += piece, k++) {
             const size_t nc = std::min(piece, ncols - c0);
