@@ -84,6 +84,11 @@ def test_pool_on_one_device_equals_single_context_and_oracle(ctx, zkm, oracle):
             assert (got[v][0] == want[v][0]).all()
         with pytest.raises(zkm.ZkmError, match="unknown key"):
             pool.set_tuning("no_such_key", 1)
+        assert pool.prove_segments([]) == []                                   # no segment: nothing to do, no worker started
+        with pytest.raises(zkm.ZkmError, match="max_stack beyond 32"):
+            pool.prove_segments(segs[:2], max_stack=33)
+        one = pool.prove_segments(segs[5:6], max_stack=8)                       # fewer groups than workers: the calling thread proves it
+        assert (one[0][0] == want[5][0]).all() and pool.last_assignment(0) == (0, 0)
     finally:
         pool.close()
     ctl_tables, ctls = T.all_cross_table_lookups()
