@@ -262,7 +262,7 @@ def throughput_rates(device, contexts=(8, 12, 16)):
     return out
 
 
-def lockstep_rates(device, shapes=((4, 8), (8, 8)), reps=3):
+def lockstep_rates(device, shapes=((4, 8), (16, 8), (8, 8)), reps=3):
     """zkm_prove_segments (K segments per call in lock-step; include/zkm_hip.h) in a FRESH process per measurement (tools/sweep_lockstep.py):
     contexts x segments per call, throughput profile.  With the VALU count of a lock-step segment from profiles/lockstep_valu_latest.json
     (rocprofv3 --pmc SQ_INSTS_VALU pass of tools/gpu_lockstep_prof.sh, quoted while its code fingerprint matches) every rate also says
