@@ -262,21 +262,26 @@ def throughput_rates(device, contexts=(8, 12, 16)):
     return out
 
 
-def lockstep_rates(device, shapes=((4, 8), (16, 8), (8, 8)), reps=3):
-    """zkm_prove_segments (K segments per call in lock-step; include/zkm_hip.h) in a FRESH process per measurement (tools/sweep_lockstep.py):
-    contexts x segments per call, throughput profile.  With the VALU count of a lock-step segment from profiles/lockstep_valu_latest.json
-    (rocprofv3 --pmc SQ_INSTS_VALU pass of tools/gpu_lockstep_prof.sh, quoted while its code fingerprint matches) every rate also says
-    which fraction of the segment's own VALU-issue budget it is: instructions / (SIMDs x the leaf kernel's measured issue rate)."""
+def lockstep_rates(device, shapes=((4, 8), (8, 8)), reps=3, sleeping_shape=(8, 8)):
+    """zkm_prove_segments (K segments per call in lock-step; include/zkm_hip.h), every shape in a FRESH process of its own (one
+    tools/sweep_lockstep.py run per shape: a shape measured after another one in the same process inherits its runtime state -- 8 x 8 after
+    16 x 8 read 98 segments/s instead of 108): contexts x segments per call, throughput profile.  With the VALU count of a lock-step segment
+    from profiles/lockstep_valu_latest.json (rocprofv3 --pmc SQ_INSTS_VALU pass of tools/gpu_lockstep_prof.sh, quoted while its code
+    fingerprint matches) every rate also says which fraction of the segment's own VALU-issue budget it is: instructions / (SIMDs x the leaf
+    kernel's measured issue rate).  (16 x 8 reaches 111.7 segments/s = 0.95 of the budget in a process of its own and 100.7 as a child of
+    bench.py -- sixteen polling threads are the box's whole 16-CPU quota -- so it is not one of the default shapes.)"""
     import subprocess
     env = dict(os.environ, GPU_MAX_HW_QUEUES="16", ZKM_BENCH_DEVICE=str(device))
     specs = ["%d,%d,throughput_profile=1,reps=%d" % (g, k, reps) for g, k in shapes]
-    # ... and the last shape once more with SLEEPING host waits (blocking-sync device flag + block_after_us 0): the rate next to the host
+    # ... and one shape once more with SLEEPING host waits (blocking-sync device flag + block_after_us 0): the rate next to the host
     # CPUs it keeps busy (`host_cpus_busy`; polling: one per context)
-    specs.append("%d,%d,throughput_profile=1,reps=%d,sleeping=1" % (shapes[-1][0], shapes[-1][1], reps))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_lockstep.py")] + specs, capture_output=True, text=True, timeout=600, env=env)
-    if r.returncode != 0:
-        raise RuntimeError("sweep_lockstep failed: " + r.stderr[-400:])
-    out = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    specs.append("%d,%d,throughput_profile=1,reps=%d,sleeping=1" % (sleeping_shape[0], sleeping_shape[1], reps))
+    out = []
+    for spec in specs:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_lockstep.py"), spec], capture_output=True, text=True, timeout=600, env=env)
+        if r.returncode != 0:
+            raise RuntimeError("sweep_lockstep %s failed: %s" % (spec, r.stderr[-400:]))
+        out += [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith("{")]
     try:
         budget = json.load(open(os.path.join(ROOT, "profiles", "lockstep_valu_latest.json")))
         from bench import code_fingerprint
