@@ -293,3 +293,30 @@ def test_forced_process_group_at_world_1():
         r = subprocess.run([sys.executable, "-c", code, want], capture_output=True, text=True, timeout=240, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         assert expect in r.stdout, r.stdout + r.stderr
+
+
+def test_cpu_baseline_is_measured_in_the_run(tmp_path):
+    """bench.py's cpu_baseline leg at toy sizes (the oracle on this host, no GPU): with --cpu-full always the value is ONE full-size
+    proof timed in the run (verified by the oracle's verifier) and the bounded sample stays beside it; with --cpu-full never the value is
+    the sample's extrapolation and a tracked full-size figure may only appear as `full_size_reference`, marked as not measured in the run
+    (the figure in the line is measured by the run that prints it)."""
+    code = textwrap.dedent("""
+        import json, sys
+        sys.path.insert(0, %r)
+        sys.argv = ["bench.py"]
+        import bench
+        a, checker = bench.cpu_baseline(5, 7, full="always")
+        assert a["value_source"] == "measured in this run at full size" and abs(a["value"] * a["full_size_s"] - 1) < 1e-9
+        assert a["sample_log_n"] == 5 and a["sample_value_extrapolated"] > 0 and a["kind"] == "port" and a["cores"] >= 1
+        b, _ = bench.cpu_baseline(5, 7, full="never")
+        assert b["value"] == b["sample_value_extrapolated"] and "extrapolated from this run's bounded sample" in b["value_source"]
+        assert "full_size_s" not in b and "full_size_reference" not in b          # (the tracked file is a 2^20-row figure: not quoted at 2^7)
+        c, _ = bench.cpu_baseline(5, 20, full="never")
+        ref = c.get("full_size_reference")
+        assert ref is None or "NOT measured in this run" in ref["source"]
+        assert sorted(bench.FINGERPRINT_FILES) == bench.FINGERPRINT_FILES and "zkm_amd/csrc/poseidon_mfma_dev.h" in bench.FINGERPRINT_FILES
+        assert "zkm_amd/csrc/pool.hip" in bench.FINGERPRINT_FILES and "include/zkm_hip.h" in bench.FINGERPRINT_FILES
+        print("OK")
+    """) % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
