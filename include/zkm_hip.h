@@ -502,6 +502,13 @@ typedef struct zkm_staged zkm_staged;
 int zkm_trace_stage(zkm_ctx* ctx, const uint64_t* values, size_t ncols, unsigned log_n, int canonical, zkm_staged** out, char** err);
 int zkm_trace_stage_columns(zkm_ctx* ctx, const uint64_t* const* columns, size_t ncols, unsigned log_n, int canonical, zkm_staged** out,
                             char** err);
+/* All twelve tables of ONE segment in one call (Table::all() order; traces[t]: zkm_table_width x 2^log_n[t] words, or columns[t][i]): one
+ * device block, one pair of events; zkm_staged_segment_ptrs gives the twelve device matrices to pass as traces[s] of zkm_prove_segments.
+ * A lock-step call of K segments then costs K stage calls instead of 12 K. */
+int zkm_segment_stage(zkm_ctx* ctx, const uint64_t* const* traces, const unsigned* log_n, int canonical, zkm_staged** out, char** err);
+int zkm_segment_stage_columns(zkm_ctx* ctx, const uint64_t* const* const* columns, const unsigned* log_n, int canonical, zkm_staged** out,
+                              char** err);
+int zkm_staged_segment_ptrs(zkm_staged* staged, const uint64_t** ptrs_out);
 const uint64_t* zkm_staged_ptr(zkm_staged* staged);
 int zkm_staged_ready(zkm_staged* staged, int wait);
 void zkm_staged_free(zkm_staged* staged);

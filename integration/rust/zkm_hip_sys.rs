@@ -175,6 +175,11 @@ extern "C" {
                            err: *mut *mut c_char) -> c_int;
     pub fn zkm_trace_stage_columns(ctx: *mut zkm_ctx, columns: *const *const u64, ncols: usize, log_n: c_uint, canonical: c_int,
                                    out: *mut *mut zkm_staged, err: *mut *mut c_char) -> c_int;
+    pub fn zkm_segment_stage(ctx: *mut zkm_ctx, traces: *const *const u64, log_n: *const c_uint, canonical: c_int, out: *mut *mut zkm_staged,
+                             err: *mut *mut c_char) -> c_int;
+    pub fn zkm_segment_stage_columns(ctx: *mut zkm_ctx, columns: *const *const *const u64, log_n: *const c_uint, canonical: c_int,
+                                     out: *mut *mut zkm_staged, err: *mut *mut c_char) -> c_int;
+    pub fn zkm_staged_segment_ptrs(staged: *mut zkm_staged, ptrs_out: *mut *const u64) -> c_int;
     pub fn zkm_staged_ptr(staged: *mut zkm_staged) -> *const u64;
     pub fn zkm_staged_ready(staged: *mut zkm_staged, wait: c_int) -> c_int;
     pub fn zkm_staged_free(staged: *mut zkm_staged);

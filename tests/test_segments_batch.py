@@ -273,3 +273,52 @@ def test_lockstep_groups_under_other_stark_configs(ctx, zkm, oracle, fields):
     tables = [(T.TABLE_ENUM_ORDER[i], tr[i], T.WIDTH[T.TABLE_ENUM_ORDER[i]], lg[i], ctl_tables[i]) for i in range(12)]
     ref, rchal, _ = oracle.prove_with_traces(tables, ctls, public_values=pub, cfg=ocfg)
     assert (got[2][0] == ref).all() and (got[2][1] == rchal).all()
+
+
+@pytest.mark.gpu
+def test_lockstep_segments_from_staged_segments(ctx, zkm):
+    """zkm_segment_stage[_columns] (round 6): all twelve tables of a segment staged in ONE call -- one device block, one pair of events --
+    while the previous call proves; zkm_staged_segment_ptrs gives the twelve device matrices.  Three staged segments (block form, column
+    pointers, one of them not vouched canonical) through one lock-step call == the same segments from host arrays; the next call is staged
+    before the current one is proven, as a driver would."""
+    from zkm_amd import tables as T
+    P = 0xFFFFFFFF00000001
+    segs = []
+    for v in range(3):
+        tr, lg = _segment(v)
+        segs.append((tr, lg, [v, 3]))
+    want = ctx.prove_segments(segs)
+    c = zkm.Context(0)
+    try:
+        def stage(v, form):
+            tr, lg, _ = segs[v]
+            if form == "columns":
+                cols = [[np.ascontiguousarray(tr[i].reshape(T.WIDTH[T.TABLE_ENUM_ORDER[i]], -1)[k]) for k in range(T.WIDTH[T.TABLE_ENUM_ORDER[i]])] for i in range(12)]
+                return c.stage_segment(cols, lg)
+            if form == "loose":          # every small word + p: the staged copy is canonicalised when first consumed
+                loose = [t.copy() for t in tr]
+                for t in loose[::3]:
+                    small = t < (1 << 32) - 1
+                    t[small] += np.uint64(P)
+                return c.stage_segment(loose, lg, canonical=False)
+            return c.stage_segment(tr, lg)
+        cur = [stage(0, "block"), stage(1, "columns"), stage(2, "loose")]
+        nxt = [stage(v, "block") for v in range(3)]                      # the next call, staged before the current one is proven
+        for call in (cur, nxt):
+            got = c.prove_segments([(st.tables(), segs[v][1], segs[v][2]) for v, st in enumerate(call)])
+            for v in range(3):
+                assert list(got[v][2]) == list(want[v][2]) and (got[v][1] == want[v][1]).all()
+                bad = np.nonzero(got[v][0] != want[v][0])[0]
+                assert bad.size == 0, "segment %d: first differing word %d" % (v, bad[0])
+            for st in call:
+                assert st.ready() is True
+                st.free()
+        c.synchronize()
+        live, _ = c.memory()
+        assert live == c.resident_bytes()
+        single = c.stage_trace(segs[0][0][0], T.WIDTH[T.TABLE_ENUM_ORDER[0]], segs[0][1][0])
+        with pytest.raises(zkm.ZkmError, match="not a staged segment"):
+            single.tables()
+        single.free()
+    finally:
+        c.close()

@@ -158,42 +158,47 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, 
         c.synchronize()
     start = threading.Barrier(nctx + 1)
 
+    stage_ms = []           # (staged mode: host milliseconds of the stage calls / the prove call / the frees of every call)
     staged = host == 2      # the NEXT call's traces staged behind the current call (zkm_trace_stage: cross-call pipelining of the uploads)
 
-    def stage_call(c, sg):
-        from zkm_amd import tables as T
+    def stage_call(c, sg):      # one zkm_segment_stage per segment: (device pointers of its twelve tables, heights, public values, handle)
         out = []
         for bufs, logs, pub in sg:
-            out.append(([c.stage_trace(bufs[t], T.WIDTH[T.TABLE_ENUM_ORDER[t]], logs[t]) for t in range(12)], logs, pub))
+            out.append((c.stage_segment(bufs, logs), logs, pub))
         return out
 
+    def as_segments(call):      # (tables() orders the compute stream behind the upload: only when the call's turn has come)
+        return [(st.tables(), logs, pub) for st, logs, pub in call]
+
     def free_call(call):
-        for sts, _, _ in call:
-            for st in sts:
-                st.free()
+        for st, _, _ in call:
+            st.free()
     if staged:
         for c, sg in zip(ctxs, segs):              # warm-up of this path: two calls' worth of staged blocks alive at once
             a, b = stage_call(c, sg), stage_call(c, sg)
-            c.prove_segments(a)
-            c.prove_segments(b)
+            c.prove_segments(as_segments(a))
+            c.prove_segments(as_segments(b))
             free_call(a)
             free_call(b)
             c.synchronize()
     first = [stage_call(c, sg) for c, sg in zip(ctxs, segs)] if staged else None
     if staged:
         for call in first:
-            for sts, _, _ in call:
-                for st in sts:
-                    st.ready(wait=True)
+            for st, _, _ in call:
+                st.ready(wait=True)
 
     def work(c, sg, k=0):
         start.wait()
         if staged:                                  # every call of the timed region stages exactly one call (the last one's is waited for)
             cur = first[k]
             for _ in range(reps):
+                t_a = time.perf_counter()
                 nxt = stage_call(c, sg)
-                c.prove_segments(cur)
+                t_b = time.perf_counter()
+                c.prove_segments(as_segments(cur))
+                t_c = time.perf_counter()
                 free_call(cur)
+                stage_ms.append(((t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (time.perf_counter() - t_c) * 1e3))
                 cur = nxt
             free_call(cur)
         else:
@@ -230,7 +235,9 @@ def lockstep_segment_rate(device, log_cycles, nctx, stack, reps=3, tuning=None, 
             "ms_per_segment_amortised": wall * 1e3 / total, "ms_per_call": wall * 1e3 / reps, "cpu_seconds_per_segment": cpu_s / total,
             "host_cpus_busy": cpu_s / wall, "host_waits": "sleeping" if os.environ.get("ZKM_SLEEPING_WAITS") == "1" else "polling",
             "tuning": tuning or {},
-            "memory_live_cached_GB": [round((m[0] + m[1]) / 2**30, 2) for m in mem]}
+            "memory_live_cached_GB": [round((m[0] + m[1]) / 2**30, 2) for m in mem],
+            **({"staged_host_ms_per_call": {"stage": round(sum(x[0] for x in stage_ms) / len(stage_ms), 2), "prove": round(sum(x[1] for x in stage_ms) / len(stage_ms), 1),
+                                            "free": round(sum(x[2] for x in stage_ms) / len(stage_ms), 2)}} if stage_ms else {})}
 
 
 def multi_process_rate(procs, nctx, reps=8, tuning=""):

@@ -40,7 +40,7 @@ EXPORTS = [
     "zkm_proof_get_layout", "zkm_proof_get_query_layout", "zkm_segment_image_words", "zkm_segment_image_write", "zkm_prove_segment_image",
     "zkm_quotient", "zkm_eval_openings", "zkm_check_constraints", "zkm_profile_enable", "zkm_profile_reset",
     "zkm_profile_count", "zkm_profile_get", "zkm_version",
-    "zkm_trace_stage", "zkm_trace_stage_columns", "zkm_staged_ptr", "zkm_staged_ready", "zkm_staged_free",
+    "zkm_trace_stage", "zkm_trace_stage_columns", "zkm_segment_stage", "zkm_segment_stage_columns", "zkm_staged_segment_ptrs", "zkm_staged_ptr", "zkm_staged_ready", "zkm_staged_free",
     "zkm_pool_create", "zkm_pool_destroy", "zkm_pool_workers", "zkm_pool_context", "zkm_pool_device", "zkm_pool_set_tuning",
     "zkm_pool_prove_segments", "zkm_pool_prove_segments_columns", "zkm_pool_plan", "zkm_pool_last_assignment",
 ]
@@ -182,6 +182,9 @@ def load():
         "zkm_pool_last_assignment": (C.c_int, [cp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "zkm_trace_stage": (C.c_int, [cp, cp, C.c_size_t, C.c_uint, C.c_int, cpp, err]),
         "zkm_trace_stage_columns": (C.c_int, [cp, C.POINTER(C.c_void_p), C.c_size_t, C.c_uint, C.c_int, cpp, err]),
+        "zkm_segment_stage": (C.c_int, [cp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint), C.c_int, cpp, err]),
+        "zkm_segment_stage_columns": (C.c_int, [cp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint), C.c_int, cpp, err]),
+        "zkm_staged_segment_ptrs": (C.c_int, [cp, C.POINTER(C.c_void_p)]),
         "zkm_staged_ptr": (cp, [cp]),
         "zkm_staged_ready": (C.c_int, [cp, C.c_int]),
         "zkm_staged_free": (None, [cp]),
@@ -295,6 +298,13 @@ class StagedTrace:
             raise ZkmError("zkm_staged_ptr: the upload could not be ordered before the compute stream")
         return p
 
+    def tables(self):
+        """A staged SEGMENT's twelve device matrices (integers), ordered behind the upload: traces[s] of prove_segments."""
+        out = (C.c_void_p * 12)()
+        if self.ctx.L.zkm_staged_segment_ptrs(self.h, out) != 0:
+            raise ZkmError("zkm_staged_segment_ptrs: not a staged segment, or the upload could not be ordered before the compute stream")
+        return [int(out[t]) for t in range(12)]
+
     def ready(self, wait=False):
         r = self.ctx.L.zkm_staged_ready(self.h, 1 if wait else 0)
         if r < 0:
@@ -339,7 +349,7 @@ class _marshal_segments:
                 self.keep.append(k)
                 self.ptr_arrays.append((C.c_void_p * 12)(*[C.addressof(c) for c in cols]))
             else:
-                k = [t if isinstance(t, (DeviceBuffer, StagedTrace)) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
+                k = [t if isinstance(t, (DeviceBuffer, StagedTrace, int)) else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
                 self.keep.append(k)
                 self.ptr_arrays.append((C.c_void_p * 12)(*[_data_ptr(t).value for t in k]))
             self.log_arrays.append((C.c_uint * 12)(*[int(x) for x in log_ns]))
@@ -674,6 +684,26 @@ class Context:
             assert keep.size == ncols << log_n
             _check(self.L.zkm_trace_stage(self.h, _np_ptr(keep), ncols, log_n, 1 if canonical else 0, C.byref(h), C.byref(err)), err)
         st = StagedTrace(self, h, ncols << log_n)
+        st._keep = keep
+        return st
+
+    def stage_segment(self, traces, log_ns, canonical=True):
+        """zkm_segment_stage[_columns]: all twelve tables of one segment (host arrays, or lists of per-column arrays) in ONE call.  Returns a
+        StagedTrace whose .tables() are the twelve device pointers to hand to prove_segments as that segment's traces."""
+        assert len(traces) == 12 and len(log_ns) == 12
+        h, err = C.c_void_p(), C.c_char_p()
+        lg = (C.c_uint * 12)(*[int(x) for x in log_ns])
+        if all(isinstance(t, (list, tuple)) for t in traces):
+            keep = [[np.ascontiguousarray(c, dtype=np.uint64) for c in t] for t in traces]
+            cols = [(C.c_void_p * len(t))(*[c.ctypes.data for c in t]) for t in keep]
+            tabs = (C.c_void_p * 12)(*[C.addressof(c) for c in cols])
+            keep = (keep, cols)
+            _check(self.L.zkm_segment_stage_columns(self.h, tabs, lg, 1 if canonical else 0, C.byref(h), C.byref(err)), err)
+        else:
+            keep = [np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
+            tabs = (C.c_void_p * 12)(*[t.ctypes.data for t in keep])
+            _check(self.L.zkm_segment_stage(self.h, tabs, lg, 1 if canonical else 0, C.byref(h), C.byref(err)), err)
+        st = StagedTrace(self, h, 0)
         st._keep = keep
         return st
 

@@ -673,6 +673,8 @@ struct zkm_staged {
     size_t words;
     hipEvent_t done[2];
     bool joined, canonical;
+    size_t off[13];     // a staged SEGMENT: word offset of table t (Table::all() order) in the block, off[12] = words; one matrix: unused
+    bool segment;
 };
 
 static zkm_staged* stage_begin(zkm_ctx* c, size_t words, int canonical) {
@@ -687,6 +689,8 @@ static zkm_staged* stage_begin(zkm_ctx* c, size_t words, int canonical) {
     zkm_staged* s = new zkm_staged();
     s->ctx = c; s->words = words; s->joined = false; s->canonical = canonical != 0;
     s->done[0] = s->done[1] = nullptr;
+    s->segment = false;
+    for (size_t& o : s->off) o = 0;
     try {
         s->dev = (gl_t*)c->alloc(words * sizeof(gl_t));
         // the block may be one a finished call of this context released: whatever the compute stream still has queued on it comes first
@@ -759,6 +763,63 @@ int zkm_trace_stage_columns(zkm_ctx* c, const uint64_t* const* columns, size_t n
     *out = s;
     ZKM_API_END(err)
 }
+// All twelve tables of ONE segment in one call (Table::all() order, zkm_table_width columns x 2^log_n[t] words each): one block, one pair
+// of events -- a lock-step call of K segments is K stage calls instead of 12 K (96 calls per 8-segment call cost its host thread 9 ms of
+// the 600 the call takes).  Exactly one of traces / columns is non-null.
+static int stage_segment(const char* what, zkm_ctx* c, const uint64_t* const* traces, const uint64_t* const* const* columns, const unsigned* log_n,
+                         int canonical, zkm_staged** out, char** err) {
+    ZKM_API_BEGIN
+    if (!c || (!traces && !columns) || !log_n || !out) throw std::runtime_error(std::string(what) + ": null argument");
+    static const int order[12] = {ZKM_TABLE_ARITHMETIC, ZKM_TABLE_CPU, ZKM_TABLE_POSEIDON, ZKM_TABLE_POSEIDON_SPONGE, ZKM_TABLE_KECCAK,
+                                  ZKM_TABLE_KECCAK_SPONGE, ZKM_TABLE_SHA_EXTEND, ZKM_TABLE_SHA_EXTEND_SPONGE, ZKM_TABLE_SHA_COMPRESS,
+                                  ZKM_TABLE_SHA_COMPRESS_SPONGE, ZKM_TABLE_LOGIC, ZKM_TABLE_MEMORY};   // Table::all(), all_stark.rs:117-134
+    size_t off[13], W[12];
+    off[0] = 0;
+    for (int t = 0; t < 12; t++) {
+        if (log_n[t] > 30 || (traces && !traces[t]) || (columns && !columns[t])) throw std::runtime_error(std::string(what) + ": bad table");
+        W[t] = zkm_table_width(order[t]);
+        off[t + 1] = off[t] + (W[t] << log_n[t]);
+    }
+    zkm_staged* s = stage_begin(c, off[12], canonical);
+    try {
+        s->segment = true;
+        for (int t = 0; t <= 12; t++) s->off[t] = off[t];
+        size_t k = 0, bytes_on[2] = {0, 0};
+        for (int t = 0; t < 12; t++) {
+            const size_t n = (size_t)1 << log_n[t];
+            const size_t piece = std::max<size_t>(8, (((size_t)64 << 20) / (n * sizeof(gl_t)) + 7) / 8 * 8);
+            for (size_t c0 = 0; c0 < W[t]; c0 += columns ? 1 : piece) {
+                const size_t nc = columns ? 1 : std::min(piece, W[t] - c0);
+                if (!columns || c0 % piece == 0) k = bytes_on[0] <= bytes_on[1] ? 0 : 1;     // the less loaded stream takes the next piece
+                if (columns && !columns[t][c0]) throw std::runtime_error(std::string(what) + ": null column pointer");
+                const void* src = columns ? (const void*)columns[t][c0] : (const void*)(traces[t] + c0 * n);
+                ZKM_HIP_CHECK(hipMemcpyAsync(s->dev + off[t] + c0 * n, src, nc * n * sizeof(gl_t), hipMemcpyHostToDevice, k ? c->copy_stream2 : c->copy_stream));
+                bytes_on[k] += nc * n * sizeof(gl_t);
+            }
+        }
+        stage_end(s);
+    } catch (...) {
+        stage_abort(s);
+        throw;
+    }
+    *out = s;
+    ZKM_API_END(err)
+}
+int zkm_segment_stage(zkm_ctx* c, const uint64_t* const* traces, const unsigned* log_n, int canonical, zkm_staged** out, char** err) {
+    return stage_segment("zkm_segment_stage", c, traces, nullptr, log_n, canonical, out, err);
+}
+int zkm_segment_stage_columns(zkm_ctx* c, const uint64_t* const* const* columns, const unsigned* log_n, int canonical, zkm_staged** out, char** err) {
+    return stage_segment("zkm_segment_stage_columns", c, nullptr, columns, log_n, canonical, out, err);
+}
+// the twelve device matrices of a staged segment (each as zkm_staged_ptr gives a single matrix: ordered behind the upload)
+int zkm_staged_segment_ptrs(zkm_staged* s, const uint64_t** ptrs_out) {
+    if (!s || !s->segment || !ptrs_out) return 1;
+    const uint64_t* base = zkm_staged_ptr(s);
+    if (!base) return 1;
+    for (int t = 0; t < 12; t++) ptrs_out[t] = base + s->off[t];
+    return 0;
+}
+
 // The device matrix, ordered behind its upload on the context's compute stream (a device-side wait: the host does not block); the
 // first call also canonicalises words the caller did not vouch for.
 const uint64_t* zkm_staged_ptr(zkm_staged* s) {
