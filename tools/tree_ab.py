@@ -7,7 +7,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import zkm_amd
-key = sys.argv[1] if len(sys.argv) > 1 else "tree_mfma"
+key = sys.argv[1] if len(sys.argv) > 1 else "leaf_mfma"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 log_n = 20
 ctx = zkm_amd.Context(0)
