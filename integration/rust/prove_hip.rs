@@ -189,6 +189,22 @@ impl StagedTrace {
         check(unsafe { zkm_trace_stage_columns(ctx, ptrs.as_ptr(), ptrs.len(), log_n, canonical as i32, &mut h, &mut err) }, err)?;
         Ok(Self(h))
     }
+    /// All twelve tables of one segment in ONE call (zkm_segment_stage_columns: one device block, one pair of events); `tables()` gives
+    /// the twelve device matrices to pass as that segment's `traces` to zkm_prove_segments.
+    pub fn stage_segment<F: PrimeField64>(ctx: *mut zkm_ctx, traces: &[Vec<PolynomialValues<F>>; NUM_TABLES], canonical: bool) -> Result<Self> {
+        let cols: Vec<Vec<*const u64>> = traces.iter().map(|t| column_ptrs(t)).collect();
+        let tabs: Vec<*const *const u64> = cols.iter().map(|v| v.as_ptr()).collect();
+        let log_n: Vec<u32> = traces.iter().map(|t| t[0].len().trailing_zeros()).collect();
+        let mut h = std::ptr::null_mut();
+        let mut err = std::ptr::null_mut();
+        check(unsafe { zkm_segment_stage_columns(ctx, tabs.as_ptr(), log_n.as_ptr(), canonical as i32, &mut h, &mut err) }, err)?;
+        Ok(Self(h))
+    }
+    pub fn tables(&mut self) -> Result<[*const u64; NUM_TABLES]> {
+        let mut out = [std::ptr::null(); NUM_TABLES];
+        anyhow::ensure!(unsafe { zkm_staged_segment_ptrs(self.0, out.as_mut_ptr()) } == 0, "libzkmhip: not a staged segment");
+        Ok(out)
+    }
     /// the device matrix (column-major, ncols x 2^log_n), ordered behind the upload on the context's compute stream
     pub fn ptr(&mut self) -> *const u64 {
         unsafe { zkm_staged_ptr(self.0) }
