@@ -155,10 +155,21 @@ void zkm_launch_merkle_leaves(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t 
 // exists, with the 12-word sponge state of every row parked in HBM between chunks (state[i * nrows + j], lane-contiguous).
 // first: the state starts at zero; last: the digest is written instead of the state.  Same permutation sequence as
 // k_merkle_leaves, so digests are identical.
-__global__ __launch_bounds__(256) void k_merkle_leaves_chunk(const gl_t* __restrict__ lde, size_t nrows, size_t nc, size_t col_stride,
-                                                             gl_t* __restrict__ state, int first, int last, gl_t* __restrict__ digests) {
+template <bool MFMA>
+__device__ __forceinline__ void merkle_leaves_chunk_body(const gl_t* __restrict__ lde, size_t nrows, size_t nc, size_t col_stride,
+                                                         gl_t* __restrict__ state, int first, int last, gl_t* __restrict__ digests) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nrows) return;
+    const bool live = j < nrows;
+    if (!MFMA && !live) return;
+    if (!live) j = nrows - 1;          // (MFMA ignores EXEC: lanes past the last row hash the last row and store nothing)
+    typename std::conditional<MFMA, poseidon_mds_mfma, poseidon_mds_valu>::type mds;
+    if constexpr (MFMA) {
+        mds.A = poseidon_mfma_operand();
+#if ZKM_MFMA_PARK
+        __shared__ uint32_t park[24 * ZKM_MFMA_PARK_STRIDE];
+        mds.park = park + threadIdx.x;
+#endif
+    }
     uint64_t s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = first ? 0 : state[(size_t)i * nrows + j];
@@ -171,15 +182,16 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_chunk(const gl_t* __restr
 #pragma unroll
         for (int i = 0; i < 8; i++) s[i] = v[i];
         // (the state parked between chunks is the whole, canonical state: the last permutation of a launch keeps all twelve words)
-        poseidon_permute_out(s, c + 16 <= nc ? POSEIDON_OUT_CAPACITY : POSEIDON_OUT_ALL);
+        poseidon_permute_out_t(s, c + 16 <= nc ? POSEIDON_OUT_CAPACITY : POSEIDON_OUT_ALL, mds);
     }
     if (c < nc) {  // ragged tail: only legal in the last chunk
         size_t rem = nc - c;
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if ((size_t)i < rem) s[i] = p[(c + i) * col_stride];
-        poseidon_permute_out(s, POSEIDON_OUT_ALL);
+        poseidon_permute_out_t(s, POSEIDON_OUT_ALL, poseidon_mds_valu{});   // (the ragged chunk's one permutation: the second copy of the round code stays on the multiply-add form, as in k_merkle_leaves_mfma)
     }
+    if (!live) return;
     if (last) {
         uint64_t* d = digests + 4 * j;
         *reinterpret_cast<ulonglong2*>(d) = make_ulonglong2(s[0], s[1]);
@@ -189,13 +201,26 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_chunk(const gl_t* __restr
         for (int i = 0; i < 12; i++) state[(size_t)i * nrows + j] = s[i];
     }
 }
+__global__ __launch_bounds__(256) void k_merkle_leaves_chunk(const gl_t* __restrict__ lde, size_t nrows, size_t nc, size_t col_stride,
+                                                             gl_t* __restrict__ state, int first, int last, gl_t* __restrict__ digests) {
+    merkle_leaves_chunk_body<false>(lde, nrows, nc, col_stride, state, first, last, digests);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZKM_LEAF_MFMA_WAVES, ZKM_LEAF_MFMA_WAVES)))
+void k_merkle_leaves_chunk_mfma(const gl_t* __restrict__ lde, size_t nrows, size_t nc, size_t col_stride, gl_t* __restrict__ state, int first, int last,
+                                gl_t* __restrict__ digests) {
+    merkle_leaves_chunk_body<true>(lde, nrows, nc, col_stride, state, first, last, digests);
+}
 
 void zkm_launch_merkle_leaves_chunk(zkm_ctx* c, const gl_t* lde, size_t nrows, size_t nc, size_t col_stride, gl_t* state, bool first,
                                     bool last, gl_t* digests) {
     if (!last && nc % 8) throw std::runtime_error("merkle_leaves_chunk: only the last chunk may hold a ragged group of columns");
     zkm_prof_scope ps(c, "merkle_leaves");
-    hipLaunchKernelGGL(k_merkle_leaves_chunk, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, lde, nrows, nc, col_stride, state,
-                       first ? 1 : 0, last ? 1 : 0, digests);
+    if (c->leaf_mfma)
+        hipLaunchKernelGGL(k_merkle_leaves_chunk_mfma, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, lde, nrows, nc, col_stride, state,
+                           first ? 1 : 0, last ? 1 : 0, digests);
+    else
+        hipLaunchKernelGGL(k_merkle_leaves_chunk, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, lde, nrows, nc, col_stride, state,
+                           first ? 1 : 0, last ? 1 : 0, digests);
     ZKM_HIP_CHECK(hipGetLastError());
 }
 
