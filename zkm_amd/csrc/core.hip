@@ -411,6 +411,7 @@ void zkm_ctx::download(std::initializer_list<xfer> xs) {
 // slot, not by the copy engines: a hipMemcpyAsync of a few hundred bytes queues behind whatever the engines are busy with -- with the
 // next proof's trace being staged behind the current proof (zkm_trace_stage, 2.2 GB in 268 MB pieces) every transcript round trip waited
 // for a piece: 70 ms per proof instead of 58 (round 6).  The kernel runs on the context's compute stream like the work that needs it.
+static std::atomic<int> g_staged_live{0};     // staged traces / segments outstanding in this process (zkm_trace_stage .. zkm_staged_free)
 __global__ __launch_bounds__(256) void k_upload_small(void* __restrict__ dst, const void* __restrict__ src, size_t bytes) {
     if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 7) == 0) {
         for (size_t i = threadIdx.x; i < bytes / 8; i += 256) ((uint64_t*)dst)[i] = ((const uint64_t*)src)[i];
@@ -431,7 +432,10 @@ void zkm_ctx::upload(void* dst, const void* src, size_t bytes) {
     if (up_off + bytes > XFER_UP) sync();                        // the ring is full: wait for the uploads in flight (sync() rewinds it)
     char* slot = h_xfer + up_off;
     memcpy(slot, src, bytes);
-    static const bool by_kernel = !(getenv("ZKM_UPLOAD_KERNEL") && atoi(getenv("ZKM_UPLOAD_KERNEL")) == 0);    // (measurement aid: 0 = copy engine)
+    // ... but only while some context of the process has a staged trace outstanding: on idle copy engines the hipMemcpyAsync is the faster of
+    // the two for a chain of dependent launches (one 2^16-cycle segment alone: 28.9 ms against 29.3 with the kernel, ~120 small uploads)
+    static const int forced = getenv("ZKM_UPLOAD_KERNEL") ? atoi(getenv("ZKM_UPLOAD_KERNEL")) : -1;              // (measurement aid: 0 / 1)
+    const bool by_kernel = forced >= 0 ? forced != 0 : g_staged_live.load(std::memory_order_relaxed) > 0;
     if (by_kernel) {
         hipLaunchKernelGGL(k_upload_small, dim3(1), dim3(256), 0, stream, dst, (const void*)slot, bytes);
         ZKM_HIP_CHECK(hipGetLastError());
@@ -704,6 +708,7 @@ static zkm_staged* stage_begin(zkm_ctx* c, size_t words, int canonical) {
         delete s;
         throw;
     }
+    g_staged_live.fetch_add(1, std::memory_order_relaxed);
     return s;
 }
 static void stage_end(zkm_staged* s) {
@@ -714,6 +719,7 @@ static void stage_end(zkm_staged* s) {
     ZKM_HIP_CHECK(hipEventRecord(s->done[1], c->copy_stream2));
 }
 static void stage_abort(zkm_staged* s) {
+    g_staged_live.fetch_sub(1, std::memory_order_relaxed);
     (void)hipStreamSynchronize(s->ctx->copy_stream);
     (void)hipStreamSynchronize(s->ctx->copy_stream2);
     s->ctx->release(s->dev);
@@ -864,6 +870,7 @@ void zkm_staged_free(zkm_staged* s) {
     c->event_pool.push_back(s->done[0]);
     c->event_pool.push_back(s->done[1]);
     delete s;
+    g_staged_live.fetch_sub(1, std::memory_order_relaxed);
 }
 
 // ------------------------------------------------------------------ profiling
