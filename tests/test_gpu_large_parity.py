@@ -236,3 +236,30 @@ def test_staged_traces_prove_like_host_and_device_traces(zkm, oracle, log_n):
             c.stage_trace(np.zeros(0, dtype=np.uint64), 0, log_n)
     finally:
         c.close()
+
+
+def test_staged_trace_at_bench_size_equals_the_oracle(zkm, oracle_proof_2_20):
+    """The deployed input at the bench's own size: the 262 x 2^20 trace of witness seed 100 staged from pinned HOST memory
+    (zkm_trace_stage: 2.2 GB over PCIe on the copy streams) and proven -- the proof equals the oracle's 2^20-row proof word for word, as the
+    device-resident and the in-proof-pipelined paths do (test_proof_is_bit_exact_2_20, test_pipelined_host_ingest_equals_monolithic)."""
+    log_n = 20
+    n = 1 << log_n
+    c = zkm.Context(0)
+    try:
+        dev = c.poseidon_trace(100, n, log_n)
+        host = c.pinned_array(262 * n)
+        host[:] = dev.download()
+        dev.free()
+        aux = np.zeros(4 * n, dtype=np.uint64)
+        st = c.stage_trace(host, 262, log_n)
+        got = c.prove_single_table(st, log_n, aux, [1, 1])
+        st.free()
+        piped = c.prove_single_table(host, log_n, aux, [1, 1])          # the same bytes through the in-proof pipeline (chunk kernel on the matrix core)
+        assert (got == piped).all()
+        if oracle_proof_2_20 is not None:
+            want = oracle_proof_2_20["proof"]
+            bad = np.nonzero(got != want)[0] if got.size == want.size else np.array([-1])
+            assert bad.size == 0, "first differing proof word: %d of %d" % (bad[0], want.size)
+        c.free_pinned(host)
+    finally:
+        c.close()
