@@ -488,7 +488,7 @@ int zkm_prove_segments_columns(zkm_ctx* ctx, const zkm_stark_config* cfg, size_t
  * The reference commits from host Vecs (prover.rs:144-167).  A prove call handed a host trace pipelines the upload INSIDE the proof
  * (column chunks absorbed as they arrive: zkm_batch_commit_values); a driver that has the next segment's trace while the current one is
  * being proven -- the witness generator runs ahead of the prover -- stages it instead: zkm_trace_stage[_columns] queues the upload of
- * an ncols x 2^log_n host matrix on the context's two copy streams (alternate 8-column pieces) into a block of the context's
+ * an ncols x 2^log_n host matrix on the context's two copy streams (alternate pieces of >= 64 MB: 8 columns at 2^20 rows, a short table in one copy) into a block of the context's
  * allocator and RETURNS AT ONCE; zkm_staged_ptr gives the device matrix to pass as `trace` / `traces[k]` of a later prove call ON THE
  * SAME CONTEXT, ordered behind the upload on the context's compute stream (a device-side wait; NULL on a runtime error).  That call
  * runs the device-resident path at full speed while the copy engines bring in the trace after it.

@@ -669,7 +669,7 @@ int zkm_dev_download(zkm_ctx* c, void* dst, const void* src, size_t bytes, char*
 // proof.  The intra-proof pipeline of zkm_batch_build (column chunks absorbed as they arrive) hides that behind hashing at the price of
 // the chunked kernels (sponge state parked in HBM, short transforms, the multiply-add leaf form).  With the next segment's traces at
 // hand while the current one is being proven -- the witness generator runs ahead of the prover -- the upload belongs BEHIND THE
-// PREVIOUS PROOF instead: zkm_trace_stage queues it on the context's two copy streams (alternate 8-column pieces)
+// PREVIOUS PROOF instead: zkm_trace_stage queues it on the context's two copy streams (alternate pieces of >= 64 MB)
 // and returns; the proof that consumes it runs the device-resident path at full speed.
 struct zkm_staged {
     zkm_ctx* ctx;

@@ -9,7 +9,6 @@
 // launches; this is what a Rust caller binds (integration/rust/prove_hip.rs prove_segments_multi_hip).
 //
 // Host only: no kernel lives here.
-#include <condition_variable>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -104,7 +103,7 @@ static int pool_prove(const char* what, zkm_pool* p, const zkm_stark_config* cfg
     try {
         for (size_t w = 1; w < nthreads; w++) th.emplace_back(worker, w);
     } catch (...) {
-        std::lock_guard<std::mutex> lk(mu);     // (could not start a thread: the ones that run drain the queue)
+        // (a thread could not be started: the ones that run, and the calling thread below, drain the queue)
     }
     worker(0);
     for (auto& t : th) t.join();
