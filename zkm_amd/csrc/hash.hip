@@ -84,24 +84,24 @@ __device__ __forceinline__ void merkle_leaves_body(const gl_t* __restrict__ lde,
     } else {
         const gl_t* p = lde + j;
         size_t c = 0;
-        for (; c + 8 <= ncols; c += 8) {
-            uint64_t v[8];
+        // ONE copy of the round code: the ragged last chunk (it overwrites the words that exist) goes through the same call site.  (Round 5's
+        // 126-register layer needed a second, multiply-add copy for it; at 93 registers it does not, and two copies buy nothing: 39.25
+        // against 39.33 ms, measured.)  Another whole chunk follows: it replaces words 0..7 and only the capacity words are carried over;
+        // before a ragged chunk (it keeps words rem..7) the whole state is needed, at the end the digest.
+        for (; c < ncols; c += 8) {
+            const size_t rem = ncols - c;          // (uniform)
+            if (rem >= 8) {
+                uint64_t v[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = p[(c + i) * col_stride];
+                for (int i = 0; i < 8; i++) v[i] = p[(c + i) * col_stride];
 #pragma unroll
-            for (int i = 0; i < 8; i++) s[i] = v[i];
-            // another whole chunk follows: it replaces words 0..7, only the capacity words are carried over.  Before a ragged chunk
-            // (it keeps words rem..7) and at the end (digest) the whole state is needed.
-            poseidon_permute_out_t(s, c + 16 <= ncols ? POSEIDON_OUT_CAPACITY : (c + 8 == ncols ? POSEIDON_OUT_DIGEST : POSEIDON_OUT_ALL), mds);
-        }
-        if (c < ncols) {
-            size_t rem = ncols - c;
+                for (int i = 0; i < 8; i++) s[i] = v[i];
+            } else {
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if ((size_t)i < rem) s[i] = p[(c + i) * col_stride];
-            // (the one permutation of the ragged chunk in the multiply-add form: with the matrix-core layer this second copy of the
-            // round code needed 9 more registers than the 128 of four waves per SIMD and spilled them, 36 B per leaf)
-            poseidon_permute_out_t(s, POSEIDON_OUT_DIGEST, poseidon_mds_valu{});
+                for (int i = 0; i < 8; i++)
+                    if ((size_t)i < rem) s[i] = p[(c + i) * col_stride];
+            }
+            poseidon_permute_out_t(s, c + 16 <= ncols ? POSEIDON_OUT_CAPACITY : (c + 8 >= ncols ? POSEIDON_OUT_DIGEST : POSEIDON_OUT_ALL), mds);
         }
     }
     if (!live) return;
