@@ -220,6 +220,49 @@ impl Drop for StagedTrace {
     }
 }
 
+/// The driver loop the staged path is made for: single-table proofs of a sequence of host traces (the benchmark shape of
+/// poseidon_stark.rs:751-816, one transcript per proof), the NEXT trace crossing PCIe behind the CURRENT proof.  Every proof is word for
+/// word what `prove_single_table_hip` returns for that trace (tests/test_gpu_large_parity.py holds the staged 2^20-row proof against the
+/// oracle's).  The traces' columns should be pinned (zkm_host_alloc) or registered once (zkm_host_register): see INTEGRATION.md section 4.
+pub fn prove_single_tables_pipelined_hip<F, C, const D: usize>(
+    ctx: *mut zkm_ctx,
+    table: Table,
+    config: &StarkConfig,
+    traces: &[Vec<PolynomialValues<F>>],
+    aux_columns: &[PolynomialValues<F>],
+    num_ctl_helper_polys: &[usize],
+) -> Result<Vec<StarkProofWithMetadata<F, C, D>>>
+where
+    F: RichField + Extendable<D>,
+    C: GenericConfig<D, F = F, Hasher = plonky2::hash::poseidon::PoseidonHash>,
+{
+    let cfg = zkm_config(config);
+    let helpers: Vec<u32> = num_ctl_helper_polys.iter().map(|&x| x as u32).collect();
+    let aux: Vec<u64> = aux_columns.iter().flat_map(|c| c.values.iter().map(|x| x.to_canonical_u64())).collect();
+    let mut proofs = Vec::with_capacity(traces.len());
+    let mut staged = match traces.first() {
+        Some(t) => Some(StagedTrace::stage(ctx, t, false)?),
+        None => None,
+    };
+    for (i, trace) in traces.iter().enumerate() {
+        let mut cur = staged.take().expect("staged above");
+        if let Some(next) = traces.get(i + 1) {
+            staged = Some(StagedTrace::stage(ctx, next, false)?);          // returns at once: the copy streams work behind the proof below
+        }
+        let log_n = trace[0].len().trailing_zeros();
+        let words = unsafe { zkm_proof_words(&cfg, log_n, trace.len(), aux_columns.len(), helpers.len()) };
+        anyhow::ensure!(words != 0, "libzkmhip: unsupported StarkConfig");
+        let mut blob = vec![0u64; words];
+        let mut ch = Challenger::<F, C::Hasher>::new().to_zkm();
+        let mut err = std::ptr::null_mut();
+        check(unsafe { zkm_prove_single_table(ctx, zkm_table_id(table), &cfg, cur.ptr(), trace.len(), log_n, std::ptr::null(), aux.as_ptr(),
+                                              aux_columns.len(), helpers.as_ptr(), helpers.len(), &mut ch, blob.as_mut_ptr(), &mut err) }, err)?;
+        proofs.push(stark_proof_from_blob::<F, C, D>(&blob));
+        drop(cur);                                                           // zkm_staged_free: the block goes back to the context's allocator
+    }
+    Ok(proofs)
+}
+
 /// A pool of contexts over the GPUs of one node, owned by the ONE process that drives all segments of a program -- the shape of the
 /// reference's driver (prover/examples/utils/src/utils.rs:57-68 `prove_single_seg_common`, :105-133 `prove_multi_seg_common`: a loop
 /// of `prove_with_traces` calls).  `contexts_per_device` worker threads per device live inside the library (include/zkm_hip.h
